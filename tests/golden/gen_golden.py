@@ -1,0 +1,534 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (BUILD CONTAINER ONLY).
+
+Imports the upstream reference from /root/reference (read-only, pure PyTorch) behind the
+shims documented in SURVEY.md Appendix A, runs its hot-path functions on small seeded
+inputs on the CPU, and writes inputs + expected outputs as .npz fixtures next to this
+script.  The fixtures are data only; nothing of the reference travels with the repo.
+
+Re-run:  python tests/golden/gen_golden.py          (needs /root/reference)
+
+Fixture index:
+  g01_raybundle.npz   get_ray_bundle                    nerf_helpers.py:507-549
+  g02_ndc.npz         ndc_rays                          nerf_helpers.py:578-605
+  g03_coarse_z.npz    stratified coarse depths          train_utils.py:95-111
+  g04_decoder.npz     TwoDimPlanesModel.forward         models.py:381-421 (+ intermediates)
+  g05_composite.npz   volume_render_radiance_field      volume_rendering_utils.py:6-51
+  g06_sample_pdf.npz  sample_pdf_2                      nerf_helpers.py:668-702
+  g07_sort.npz        sort(cat(z, z_samples))           train_utils.py:155
+  g08_render.npz      eval_nerf / run_one_iter_of_nerf  train_utils.py:185-331 (16x16 rays)
+  g09_edsr.npz        EDSR + PlanesSR (mini net)        models.py:769-926
+  g10_posenc.npz      positional_encoding, FlexibleNeRFModel   nerf_helpers.py:552-575, models.py:14-108
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def import_reference():
+    for m in ["cv2", "torchvision", "imageio", "magic", "deepdiff"]:
+        sys.modules[m] = types.ModuleType(m)
+    sys.modules["magic"].from_file = lambda *a, **k: None
+    sys.modules["deepdiff"].DeepDiff = dict
+    import scipy.signal
+    import scipy.signal.windows
+
+    scipy.signal.gaussian = scipy.signal.windows.gaussian
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    import nerf_helpers, volume_rendering_utils, models, train_utils  # noqa
+    from cfgnode import CfgNode
+
+    return nerf_helpers, volume_rendering_utils, models, train_utils, CfgNode
+
+
+nh, vru, models, tu, CfgNode = import_reference()
+
+BOX = [[-4.0, -4.0, -4.0, -np.pi, -np.pi / 2], [4.0, 4.0, 4.0, np.pi, np.pi / 2]]
+POSE = np.array(
+    [
+        [-0.9999, 0.0042, -0.0133, -0.0538],
+        [-0.0140, -0.2997, 0.9539, 3.8455],
+        [0.0, 0.9540, 0.2997, 1.2081],
+        [0.0, 0.0, 0.0, 1.0],
+    ],
+    dtype=np.float32,
+)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote %-22s %8.1f KB  (%d arrays)" % (name, os.path.getsize(path) / 1024, len(arrs)))
+
+
+def build_models(R, Rv, plane_std, seed, ds=8):
+    """Coarse + fine TwoDimPlanesModel wired the way PlanesOptimizer would (models.py:545-550,601-604)."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    sid = models.get_scene_id("lego", ds, (R, Rv))
+    sc = models.SceneCoupler([sid], planes_res="LR", num_pos_planes=3, training_scenes=[sid])
+    kw = dict(
+        use_viewdirs=True,
+        skip_connect_every=3,
+        proj_combination="avg",
+        viewdir_proj_combination="concat_pos",
+        align_corners=True,
+        scene_coupler=sc,
+    )
+    mc = models.TwoDimPlanesModel(**kw)
+    mc.optional_no_grad = nh.null_with
+    mf = models.TwoDimPlanesModel(num_planes_or_rot_mats=mc.rot_mats(), **kw)
+    mf.optional_no_grad = nh.null_with
+    planes = nn.ParameterDict(
+        [
+            (models.get_plane_name(sid, d), models.create_plane(R if d < 3 else Rv, 48, plane_std))
+            for d in range(4)
+        ]
+    )
+    box = torch.tensor(BOX, dtype=torch.float64)
+    for m in (mc, mf):
+        m.planes_ = planes
+        m.plane_rank = None
+        m.generated_planes = {}
+        m.downsampled_planes = {}
+        m.coverages = {}
+        m.box_coords = {sid: box}
+        m.set_cur_scene_id(sid)
+    # Calibrate fc_alpha so that sigma straddles zero and acc_map is spread ("degenerate scenes").
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        pts = torch.rand(4096, 3, generator=g) * 6 - 3
+        d = torch.randn(4096, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        x = torch.cat([pts, d], -1)
+        for m in (mc, mf):
+            m.eval()
+            raw = m(x)[:, 3]
+            scale = 1.0 / float(raw.std())
+            m.fc_alpha["0"].weight.mul_(scale)
+            m.fc_alpha["0"].bias.mul_(scale)
+            raw = m(x)[:, 3]
+            m.fc_alpha["0"].bias.add_(-float(raw.mean()) - 0.5)
+    return sid, mc, mf, planes, box
+
+
+def state_arrays(prefix, model):
+    return {prefix + k: npy(v) for k, v in model.state_dict().items() if "planes_" not in k}
+
+
+def make_cfg(v_train, v_val, ndc=False, near=2.0, far=6.0):
+    return CfgNode(
+        {
+            "nerf": {"use_viewdirs": True, "train": v_train, "validation": v_val},
+            "dataset": {"synt": {"near": near, "far": far, "no_ndc": not ndc}},
+        }
+    )
+
+
+def mode_cfg(nc, nf, perturb=False, noise=0.0, white=False, lindisp=False, chunk=131072):
+    return dict(
+        chunksize=chunk,
+        perturb=perturb,
+        num_coarse=nc,
+        num_fine=nf,
+        white_background=white,
+        radiance_field_noise_std=noise,
+        lindisp=lindisp,
+    )
+
+
+# --------------------------------------------------------------------------------------
+def g01_raybundle():
+    torch.manual_seed(1)
+    out = {}
+    cases = []
+    for i, (H, W, ds, pad) in enumerate([(5, 7, 1, 0), (5, 7, 2, 0), (6, 4, 8, 0), (4, 6, 2, 2)]):
+        q, _ = torch.linalg.qr(torch.randn(3, 3))
+        c2w = torch.eye(4)
+        c2w[:3, :3] = q
+        c2w[:3, 3] = torch.randn(3) * 2
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        off = (ds - 1) / (2 * ds)
+        ro, rd = nh.get_ray_bundle(H, W, focal, c2w, padding_size=pad, downsampling_offset=off)
+        out.update(
+            {
+                "c%d_c2w" % i: npy(c2w),
+                "c%d_params" % i: np.array([H, W, focal, pad, off], dtype=np.float64),
+                "c%d_ro" % i: npy(ro.contiguous()),
+                "c%d_rd" % i: npy(rd),
+            }
+        )
+        cases.append(i)
+    # Blender-style pose used by the render fixtures
+    H = W = 8
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+    i = len(cases)
+    out.update(
+        {
+            "c%d_c2w" % i: POSE,
+            "c%d_params" % i: np.array([H, W, focal, 0, 0.0], dtype=np.float64),
+            "c%d_ro" % i: npy(ro.contiguous()),
+            "c%d_rd" % i: npy(rd),
+        }
+    )
+    out["n_cases"] = np.array(i + 1)
+    save("g01_raybundle.npz", **out)
+
+
+def g02_ndc():
+    torch.manual_seed(2)
+    H, W, focal = 378, 504, 407.5
+    ro = torch.randn(37, 3) * 0.3
+    rd = torch.randn(37, 3)
+    rd[:, 2] = -rd[:, 2].abs() - 0.2
+    o, d = nh.ndc_rays(H, W, focal, 1.0, ro, rd)
+    save(
+        "g02_ndc.npz",
+        params=np.array([H, W, focal, 1.0], dtype=np.float64),
+        ro=npy(ro),
+        rd=npy(rd),
+        ro_ndc=npy(o),
+        rd_ndc=npy(d),
+    )
+
+
+def g03_coarse_z():
+    """Drives predict_and_render_radiance's own depth code (train_utils.py:95-109): run_network is
+    swapped for a recorder that captures the z_vals argument and returns a zero radiance field."""
+    out = {}
+    N = 9
+    near = torch.full((N, 1), 2.0)
+    far = torch.full((N, 1), 6.0)
+    far[3:] = 5.5
+    near[5:] = 0.5
+    torch.manual_seed(3)
+    ro = torch.randn(N, 3)
+    rd = torch.randn(N, 3)
+    rays = torch.cat([ro, rd, near, far, rd / rd.norm(dim=-1, keepdim=True)], -1)
+    captured = {}
+
+    def recorder(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn, scene_id, **kw):
+        captured["z"] = kw["z_vals"].clone()
+        captured["pts"] = pts.clone()
+        return torch.zeros(list(pts.shape[:-1]) + [4])
+
+    class Stub:
+        optional_no_grad = nh.null_with
+
+    real = tu.run_network
+    tu.run_network = recorder
+    try:
+        for ci, (nc, lindisp, perturb) in enumerate([(64, False, False), (32, True, False), (64, False, True), (16, True, True)]):
+            cfg = make_cfg(mode_cfg(nc, 0, perturb=perturb, lindisp=lindisp), mode_cfg(nc, 0))
+            torch.manual_seed(30 + ci)
+            tu.predict_and_render_radiance(rays, Stub(), Stub(), cfg, scene_id="x", mode="train")
+            torch.manual_seed(30 + ci)
+            t_rand = torch.rand(N, nc)
+            out.update(
+                {
+                    "c%d_params" % ci: np.array([nc, int(lindisp), int(perturb)]),
+                    "c%d_t_rand" % ci: npy(t_rand),
+                    "c%d_z" % ci: npy(captured["z"].contiguous()),
+                    "c%d_pts" % ci: npy(captured["pts"].contiguous()),
+                }
+            )
+    finally:
+        tu.run_network = real
+    out["ro"] = npy(ro)
+    out["rd"] = npy(rd)
+    out["near"] = npy(near[:, 0])
+    out["far"] = npy(far[:, 0])
+    out["n_cases"] = np.array(4)
+    save("g03_coarse_z.npz", **out)
+
+
+def g04_decoder():
+    R, Rv = 16, 8
+    sid, mc, mf, planes, box = build_models(R, Rv, 0.5, seed=4)
+    m = mc
+    torch.manual_seed(40)
+    P = 257
+    pts = torch.rand(P, 3) * 8.4 - 4.2  # some points outside the box -> border clamp
+    pts[0] = torch.tensor([-4.0, -4.0, -4.0])
+    pts[1] = torch.tensor([4.0, 4.0, 4.0])
+    pts[2] = torch.tensor([0.0, 0.0, 0.0])
+    d = torch.randn(P, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    d[3] = torch.tensor([0.0, 0.0, 1.0])
+    d[4] = torch.tensor([-1.0, 0.0, 0.0])
+    x = torch.cat([pts, d], -1)
+    with torch.no_grad():
+        out = m(x)
+        x5 = torch.cat([x[..., :3], nh.cart2az_el(x[..., 3:])], -1)
+        n5 = m.normalize_coords(x5)
+        pos = m.project_xyz(n5[..., :3])
+        view = m.project_viewdir(n5[..., 3:])
+        dens_in = m.combine_pos_planes(pos)
+        rgb_in = m.combine_all_planes(pos_planes=1 * pos, viewdir_planes=view)
+    arrs = dict(
+        x=npy(x),
+        out=npy(out),
+        norm_coords=npy(n5),
+        feat0=npy(pos[0]),
+        feat1=npy(pos[1]),
+        feat2=npy(pos[2]),
+        feat_view=npy(view),
+        density_in=npy(dens_in),
+        rgb_in=npy(rgb_in),
+        box=npy(box),
+    )
+    for dnum in range(4):
+        arrs["plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
+    arrs.update(state_arrays("sd.", m))
+    save("g04_decoder.npz", **arrs)
+
+
+def g05_composite():
+    out = {}
+    torch.manual_seed(5)
+    ci = 0
+    for S in (8, 64, 192):
+        for white in (False, True):
+            for noise_std in (0.0, 0.2):
+                N = 11
+                raw = torch.randn(N, S, 4) * 2.0
+                raw[..., 3] = raw[..., 3] * 3.0 - 2.0
+                raw[0, :, 3] = -1.0  # sigma all-zero ray -> acc = 0, disp = nan
+                raw[1, :, 3] = 50.0  # opaque at first sample
+                z = torch.sort(torch.rand(N, S) * 4 + 2, dim=-1)[0]
+                rd = torch.randn(N, 3)
+                torch.manual_seed(500 + ci)
+                rgb, disp, acc, w, depth = vru.volume_render_radiance_field(
+                    raw, z, rd, radiance_field_noise_std=noise_std, white_background=white
+                )
+                torch.manual_seed(500 + ci)
+                noise = torch.randn(N, S) * noise_std if noise_std > 0 else torch.zeros(N, S)
+                out.update(
+                    {
+                        "c%d_params" % ci: np.array([S, int(white), noise_std]),
+                        "c%d_raw" % ci: npy(raw),
+                        "c%d_z" % ci: npy(z),
+                        "c%d_rd" % ci: npy(rd),
+                        "c%d_noise" % ci: npy(noise),
+                        "c%d_rgb" % ci: npy(rgb),
+                        "c%d_disp" % ci: npy(disp),
+                        "c%d_acc" % ci: npy(acc),
+                        "c%d_weights" % ci: npy(w),
+                        "c%d_depth" % ci: npy(depth),
+                    }
+                )
+                ci += 1
+    out["n_cases"] = np.array(ci)
+    # cumprod_exclusive on its own (nerf_helpers.py:409-430)
+    t = torch.rand(5, 17)
+    out["cumprod_in"] = npy(t)
+    out["cumprod_out"] = npy(nh.cumprod_exclusive(t))
+    save("g05_composite.npz", **out)
+
+
+def g06_sample_pdf():
+    out = {}
+    torch.manual_seed(6)
+    ci = 0
+    for nb, ns, det, kind in [
+        (63, 128, True, "rand"),
+        (63, 64, True, "spike"),
+        (63, 128, False, "rand"),
+        (63, 128, True, "flat"),
+        (31, 17, False, "zero"),
+        (7, 5, True, "rand"),
+        (63, 128, False, "spike"),
+    ]:
+        N = 13
+        bins = torch.sort(torch.rand(N, nb) * 4 + 2, dim=-1)[0]
+        if kind == "rand":
+            w = torch.rand(N, nb - 1)
+        elif kind == "flat":
+            w = torch.ones(N, nb - 1) * 0.3
+        elif kind == "zero":
+            w = torch.zeros(N, nb - 1)
+        else:
+            w = torch.zeros(N, nb - 1)
+            w[torch.arange(N), torch.randint(0, nb - 1, (N,))] = 0.9
+        torch.manual_seed(600 + ci)
+        s = nh.sample_pdf_2(bins, w, ns, det=det)
+        torch.manual_seed(600 + ci)
+        u = torch.linspace(0.0, 1.0, ns).expand(N, ns) if det else torch.rand(N, ns)
+        out.update(
+            {
+                "c%d_params" % ci: np.array([nb, ns, int(det)]),
+                "c%d_bins" % ci: npy(bins),
+                "c%d_weights" % ci: npy(w),
+                "c%d_u" % ci: npy(u.contiguous()),
+                "c%d_samples" % ci: npy(s),
+            }
+        )
+        ci += 1
+    out["n_cases"] = np.array(ci)
+    save("g06_sample_pdf.npz", **out)
+
+
+def g07_sort():
+    torch.manual_seed(7)
+    out = {}
+    for ci, (nc, nf) in enumerate([(64, 128), (64, 64), (5, 3)]):
+        N = 9
+        zc = torch.sort(torch.rand(N, nc) * 4 + 2, -1)[0]
+        zs = torch.rand(N, nf) * 4 + 2  # unsorted (train-mode importance samples)
+        zs[0, : min(nf, nc)] = zc[0, : min(nf, nc)]  # ties
+        z, _ = torch.sort(torch.cat((zc, zs), dim=-1), dim=-1)
+        out.update({"c%d_zc" % ci: npy(zc), "c%d_zs" % ci: npy(zs), "c%d_sorted" % ci: npy(z)})
+    out["n_cases"] = np.array(3)
+    save("g07_sort.npz", **out)
+
+
+def g08_render():
+    R, Rv = 32, 8
+    sid, mc, mf, planes, box = build_models(R, Rv, 0.5, seed=8)
+    H = W = 16
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = torch.from_numpy(POSE)
+    ro, rd = nh.get_ray_bundle(H, W, focal, pose)
+    arrs = dict(box=npy(box), pose=POSE, hwf=np.array([H, W, focal], dtype=np.float64), ro=npy(ro.contiguous()), rd=npy(rd))
+    for dnum in range(4):
+        arrs["plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
+    arrs.update(state_arrays("coarse.", mc))
+    arrs.update(state_arrays("fine.", mf))
+    mc.eval()
+    mf.eval()
+    ci = 0
+    for nc, nf, white in [(32, 0, False), (64, 64, False), (64, 128, False), (64, 128, True)]:
+        v = mode_cfg(nc, nf, white=white)
+        cfg = make_cfg(v, v)
+        with torch.no_grad():
+            rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
+                H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0), cfg,
+                scene_id=sid, mode="validation", scene_config=cfg.dataset["synt"],
+            )
+            img_c, _, _, img_f, *_ = tu.eval_nerf(H, W, focal, mc, mf, ro, rd, cfg, scene_id=sid, scene_config=cfg.dataset["synt"])
+        assert torch.equal(img_c.reshape(-1, 3), rc)
+        arrs["e%d_params" % ci] = np.array([nc, nf, int(white), 0, 0.0])
+        arrs["e%d_rgb_coarse" % ci] = npy(rc)
+        arrs["e%d_disp_coarse" % ci] = npy(dc)
+        arrs["e%d_acc_coarse" % ci] = npy(ac)
+        if nf > 0:
+            arrs["e%d_rgb_fine" % ci] = npy(rf)
+            arrs["e%d_disp_fine" % ci] = npy(df)
+            arrs["e%d_acc_fine" % ci] = npy(af)
+        print("   eval %s: acc_coarse mean %.3f  min %.3f max %.3f%s" % (
+            (nc, nf, white), float(ac.mean()), float(ac.min()), float(ac.max()),
+            "" if nf == 0 else "  acc_fine mean %.3f" % float(af.mean())))
+        ci += 1
+    # train mode: perturb + density noise + random u; RNG draws captured by re-seeding (CPU generator,
+    # order: t_rand -> coarse noise -> u -> fine noise; train_utils.py:108, volume_rendering_utils.py:32,
+    # nerf_helpers.py:683)
+    nc, nf, std = 64, 64, 0.2
+    vt = mode_cfg(nc, nf, perturb=True, noise=std)
+    cfg = make_cfg(vt, mode_cfg(nc, nf))
+    sel = torch.arange(0, H * W, 5)
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    N = rays.shape[1]
+    mc.train()
+    mf.train()
+    torch.manual_seed(88)
+    with torch.no_grad():
+        rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
+            H, W, focal, mc, mf, rays, cfg, scene_id=sid, mode="train", scene_config=cfg.dataset["synt"])
+    torch.manual_seed(88)
+    t_rand = torch.rand(N, nc)
+    noise_c = torch.randn(N, nc) * std
+    u = torch.rand(N, nf)
+    noise_f = torch.randn(N, nc + nf) * std
+    arrs.update(
+        t_params=np.array([nc, nf, 0, 1, std]),
+        t_sel=npy(sel),
+        t_t_rand=npy(t_rand),
+        t_noise_coarse=npy(noise_c),
+        t_u=npy(u),
+        t_noise_fine=npy(noise_f),
+        t_rgb_coarse=npy(rc), t_disp_coarse=npy(dc), t_acc_coarse=npy(ac),
+        t_rgb_fine=npy(rf), t_disp_fine=npy(df), t_acc_fine=npy(af),
+    )
+    arrs["n_eval"] = np.array(ci)
+    save("g08_render.npz", **arrs)
+
+
+def g09_edsr():
+    torch.manual_seed(9)
+    C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+    sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bilinear")
+    sr.align_corners = True
+    sr.eval()
+    # default init is N(0, sqrt(2/(9*Cout))/10) (models.py:843-848): scale up so the net output is not ~0
+    with torch.no_grad():
+        for p in sr.parameters():
+            p.mul_(10.0)
+    lr = torch.randn(1, C, R, R) * 0.5
+    sr.set_LR_plane(lr, id="p", save_interpolated=False)
+    arrs = dict(
+        cfg=np.array([C, hidden, nblocks, sf, R, sr.inner_model.required_padding, sr.HR_overpadding]),
+        lr=npy(lr),
+    )
+    arrs.update({"sd." + k: npy(v) for k, v in sr.state_dict().items()})
+    with torch.no_grad():
+        x = torch.randn(1, C, 30, 26)
+        arrs["edsr_in"] = npy(x)
+        arrs["edsr_out"] = npy(sr.inner_model(x))
+        blk = sr.inner_model.residual[0]
+        h = torch.randn(1, hidden, 12, 9)
+        arrs["block_in"] = npy(h)
+        arrs["block_out"] = npy(blk(h.clone()))
+        arrs["upsampled_lr"] = npy(sr.interpolate_LR("p"))
+        hr = sr("p")
+        arrs["sr_full"] = npy(hr)
+        sr.clear_SR_planes()
+        sr.train()  # ROI path is only taken in training mode (models.py:277); noise knobs are 0
+        roi = torch.tensor([[-0.35, -0.6], [0.2, 0.15]])  # rows=(min,max), cols=(y,x) as built at models.py:278-279
+        arrs["roi"] = npy(roi)
+        arrs["sr_roi"] = npy(sr(("p", roi)))
+        sr.eval()
+    save("g09_edsr.npz", **arrs)
+
+
+def g10_posenc():
+    torch.manual_seed(10)
+    x = torch.randn(19, 3) * 2
+    arrs = dict(x=npy(x))
+    arrs["pe_L6"] = npy(nh.positional_encoding(x, 6, True))
+    arrs["pe_L4"] = npy(nh.positional_encoding(x, 4, True))
+    arrs["pe_L4_noinput"] = npy(nh.positional_encoding(x, 4, False))
+    m = models.FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    m.eval()
+    P = 33
+    pts = torch.randn(P, 3)
+    d = torch.randn(P, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    inp = torch.cat([nh.positional_encoding(pts, 6), nh.positional_encoding(d, 4)], -1)
+    with torch.no_grad():
+        arrs["nerf_out"] = npy(m(inp))
+    arrs["nerf_pts"] = npy(pts)
+    arrs["nerf_dirs"] = npy(d)
+    arrs.update({"sd." + k: npy(v) for k, v in m.state_dict().items()})
+    save("g10_posenc.npz", **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10"]
+    for name, fn in list(globals().items()):
+        if callable(fn) and name[:3] in which and name.startswith("g"):
+            fn()
