@@ -1,0 +1,653 @@
+/*
+ * nvsr_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, CPU restatement of the volumetric-rendering hot path of
+ * princeton-computational-imaging/Neural-Volume-Super-Resolution (pure PyTorch, fp32).
+ * It is the checker for the HIP kernels: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product path never calls into it.
+ *
+ * Parity status: PINNED.  The reference has no tests of its own, so every
+ * function below is checked against outputs of the reference itself, generated in the build
+ * container by tests/golden/gen_golden.py and committed under tests/golden/ (tests/test_oracle.py).
+ *
+ * Each function cites the reference file:line it follows (paths relative to the upstream repo).
+ * All arithmetic is fp32 like the reference; dot products (Linear / conv) accumulate in ORC_ACC
+ * (double by default: the reference's sgemm/conv summation order is unspecified, so the checker
+ * sits at the centre of all fp32 orderings; build with -DORC_ACC=float for the timed CPU baseline).
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared -fPIC).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef ORC_ACC
+#define ORC_ACC double
+#endif
+typedef ORC_ACC acc_t;
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+ORC_EXPORT int orc_acc_is_double(void) { return sizeof(acc_t) == 8; }
+
+/* ------------------------------------------------------------------------------------------
+ * get_ray_bundle  (nerf_helpers.py:507-549, meshgrid_xy :396-406, get_focal :432-437)
+ *   ii = col + off (- pad), jj = row + off (- pad); dir = [(ii - W/2)/f_x, -(jj - H/2)/f_y, -1]
+ *   rd[r] = sum_k dir[k] * c2w[r][k];  ro = c2w[:3,3].  Directions are NOT normalised.
+ * f_x = get_focal(focal,'H'), f_y = get_focal(focal,'W') (the reference's naming, :539-540).
+ * Output rows: (H+2*pad) x (W+2*pad) x 3.
+ */
+ORC_EXPORT void orc_get_ray_bundle(int H, int W, double focal_x, double focal_y, const float* c2w /*4x4*/,
+                                   int pad, double off, float* ro, float* rd) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const float fx = (float)focal_x, fy = (float)focal_y;
+    const float hw = (float)(W * 0.5), hh = (float)(H * 0.5);
+    for (int r = 0; r < Hp; ++r)
+        for (int c = 0; c < Wp; ++c) {
+            float ii = (float)c + (float)off;
+            float jj = (float)r + (float)off;
+            if (pad > 0) { ii = ii - (float)pad; jj = jj - (float)pad; }
+            const float d0 = (ii - hw) / fx;
+            const float d1 = -(jj - hh) / fy;
+            const float d2 = -1.0f;
+            float* o = ro + ((size_t)r * Wp + c) * 3;
+            float* d = rd + ((size_t)r * Wp + c) * 3;
+            for (int k = 0; k < 3; ++k) {
+                volatile float p0 = d0 * c2w[k * 4 + 0];
+                volatile float p1 = d1 * c2w[k * 4 + 1];
+                volatile float p2 = d2 * c2w[k * 4 + 2];
+                volatile float s = p0 + p1;
+                d[k] = s + p2;
+                o[k] = c2w[k * 4 + 3];
+            }
+        }
+}
+
+/* ndc_rays (nerf_helpers.py:578-605) */
+ORC_EXPORT void orc_ndc_rays(int H, int W, double focal, double near_, int N, const float* ro, const float* rd,
+                             float* ro_out, float* rd_out) {
+    const float nr = (float)near_;
+    const float sx = (float)(-1.0 / (W / (2.0 * focal)));
+    const float sy = (float)(-1.0 / (H / (2.0 * focal)));
+    const float two_near = (float)(2.0 * near_);
+    const float m_two_near = (float)(-2.0 * near_);
+    for (int i = 0; i < N; ++i) {
+        const float* o = ro + 3 * i;
+        const float* d = rd + 3 * i;
+        const float t = -(nr + o[2]) / d[2];
+        const float ox = o[0] + t * d[0], oy = o[1] + t * d[1], oz = o[2] + t * d[2];
+        ro_out[3 * i + 0] = sx * ox / oz;
+        ro_out[3 * i + 1] = sy * oy / oz;
+        ro_out[3 * i + 2] = 1.0f + two_near / oz;
+        rd_out[3 * i + 0] = sx * (d[0] / d[2] - ox / oz);
+        rd_out[3 * i + 1] = sy * (d[1] / d[2] - oy / oz);
+        rd_out[3 * i + 2] = m_two_near / oz;
+    }
+}
+
+/* linspace as torch computes it for float (steps n): step=(end-start)/(n-1); i<n/2 ? start+i*step : end-(n-1-i)*step */
+static inline float orc_linspace01(int i, int n) {
+    if (n == 1) return 0.0f;
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? (0.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+/* coarse depths, stratified jitter (train_utils.py:95-109) */
+ORC_EXPORT void orc_coarse_z(int N, int Nc, const float* near_, const float* far_, int lindisp, int perturb,
+                             const float* t_rand /*[N,Nc] or NULL*/, float* z /*[N,Nc]*/) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        float* zi = z + (size_t)i * Nc;
+        const float nr = near_[i], fr = far_[i];
+        for (int s = 0; s < Nc; ++s) {
+            const float t = orc_linspace01(s, Nc);
+            if (!lindisp)
+                zi[s] = nr * (1.0f - t) + fr * t;
+            else
+                zi[s] = 1.0f / (1.0f / nr * (1.0f - t) + 1.0f / fr * t);
+        }
+        if (perturb) {
+            float* tmp = (float*)malloc(sizeof(float) * (size_t)Nc);
+            for (int s = 0; s < Nc; ++s) {
+                const float lower = (s == 0) ? zi[0] : 0.5f * (zi[s] + zi[s - 1]);
+                const float upper = (s == Nc - 1) ? zi[Nc - 1] : 0.5f * (zi[s + 1] + zi[s]);
+                tmp[s] = lower + (upper - lower) * t_rand[(size_t)i * Nc + s];
+            }
+            memcpy(zi, tmp, sizeof(float) * (size_t)Nc);
+            free(tmp);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tri-plane decoder: TwoDimPlanesModel.forward (models.py:381-421)
+ *   cart2az_el (nerf_helpers.py:492-496), normalize_coords (models.py:261-268),
+ *   CoordProjector.forward (models.py:495-497), project_xyz / project_viewdir (models.py:289-326):
+ *   grid_sample(bilinear, align_corners=True, padding_mode='border'),
+ *   combine_pos_planes 'avg' (:358-359), combine_all_planes 'concat_pos' (:379), decoders (:395-421).
+ */
+typedef struct {
+    int C;                 /* plane channels (48) */
+    int hidden;            /* dec_channels (128) */
+    int n_density_layers;  /* 4 */
+    int n_rgb_layers;      /* 4 */
+    const float* blob;     /* state-dict order: density_dec.{i}.{weight[out,in],bias}, fc_alpha.{weight[1,h],bias},
+                              rgb_dec.{i}.{weight,bias}, fc_rgb.{weight[3,h],bias} */
+} orc_decoder;
+
+static size_t orc_decoder_floats(const orc_decoder* d) {
+    const size_t h = d->hidden, C = d->C;
+    size_t n = C * h + h + (size_t)(d->n_density_layers - 1) * (h * h + h) + h + 1;
+    n += 4 * C * h + h + (size_t)(d->n_rgb_layers - 1) * (h * h + h) + 3 * h + 3;
+    return n;
+}
+ORC_EXPORT long orc_decoder_blob_floats(int C, int hidden, int nd, int nr) {
+    orc_decoder d = {C, hidden, nd, nr, NULL};
+    return (long)orc_decoder_floats(&d);
+}
+
+/* unnormalise + clip for align_corners=True, border padding (ATen GridSamplerKernel.cpp ComputeLocation) */
+static inline float orc_grid_loc(float g, int size) {
+    const float scaling = (float)(size - 1) / 2.0f;
+    float x = (g + 1.0f) * scaling;
+    const float mx = (float)(size - 1);
+    x = fminf(mx, fmaxf(x, 0.0f));
+    return x;
+}
+
+/* bilinear sample of one NCHW plane [C,Hp,Wp] at normalised (gx -> width, gy -> height) */
+static void orc_sample_plane(const float* plane, int C, int Hp, int Wp, float gx, float gy, float* out) {
+    const float x = orc_grid_loc(gx, Wp), y = orc_grid_loc(gy, Hp);
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+    const int ix = (int)xw, iy = (int)yn;
+    const int x1ok = (ix + 1 <= Wp - 1), y1ok = (iy + 1 <= Hp - 1);
+    const size_t HW = (size_t)Hp * Wp;
+    for (int c = 0; c < C; ++c) {
+        const float* p = plane + (size_t)c * HW;
+        float v = p[(size_t)iy * Wp + ix] * nw;
+        if (x1ok) v += p[(size_t)iy * Wp + ix + 1] * ne;
+        if (y1ok) v += p[(size_t)(iy + 1) * Wp + ix] * sw;
+        if (x1ok && y1ok) v += p[(size_t)(iy + 1) * Wp + ix + 1] * se;
+        out[c] = v;
+    }
+}
+
+/* y[o] = relu?(b[o] + sum_k x[k] W[o][k]) */
+static void orc_linear(const float* W, const float* b, const float* x, int in, int out, int relu, float* y) {
+    for (int o = 0; o < out; ++o) {
+        acc_t a = 0;
+        const float* w = W + (size_t)o * in;
+        for (int k = 0; k < in; ++k) a += (acc_t)x[k] * (acc_t)w[k];
+        float v = (float)a + b[o];
+        y[o] = (relu && v < 0.0f) ? 0.0f : v;
+    }
+}
+
+typedef struct {
+    const float* planes[4]; /* NCHW [C,H,W] each */
+    int ph[4], pw[4];
+    float lo[5], range[5];  /* box[0] and (box[1]-box[0]) cast to f32 */
+    float proj[3][6];       /* rot_mats[d][:,1:] row-major 3x2 */
+} orc_scene;
+
+ORC_EXPORT void orc_scene_init(orc_scene* sc, const float* p0, const float* p1, const float* p2, const float* pv,
+                               const int* hw /*8 ints*/, const double* box /*[2,5]*/, const float* rot /*[3,3,3] or NULL*/) {
+    sc->planes[0] = p0; sc->planes[1] = p1; sc->planes[2] = p2; sc->planes[3] = pv;
+    for (int d = 0; d < 4; ++d) { sc->ph[d] = hw[2 * d]; sc->pw[d] = hw[2 * d + 1]; }
+    for (int i = 0; i < 5; ++i) { sc->lo[i] = (float)box[i]; sc->range[i] = (float)(box[5 + i] - box[i]); }
+    static const float def_rot[3][9] = {{1,0,0, 0,1,0, 0,0,1}, {0,1,0, 1,0,0, 0,0,1}, {0,1,0, 0,0,1, 1,0,0}};
+    for (int d = 0; d < 3; ++d)
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 2; ++c) sc->proj[d][k * 2 + c] = rot ? rot[d * 9 + k * 3 + 1 + c] : def_rot[d][k * 3 + 1 + c];
+}
+ORC_EXPORT int orc_scene_sizeof(void) { return (int)sizeof(orc_scene); }
+
+/* One point.  feats (optional) receives [f0|f1|f2|fview|density_in] = 5*C floats, n5 (optional) 5 floats. */
+static void orc_decode_point(const orc_scene* sc, const orc_decoder* dec, const float* x6, float* out4,
+                             float* feats, float* n5_out) {
+    const int C = dec->C, h = dec->hidden;
+    float x5[5], n5[5];
+    x5[0] = x6[0]; x5[1] = x6[1]; x5[2] = x6[2];
+    x5[3] = atan2f(x6[4], x6[3]);
+    x5[4] = atan2f(x6[5], sqrtf(x6[3] * x6[3] + x6[4] * x6[4]));
+    for (int i = 0; i < 5; ++i) n5[i] = 2.0f * (x5[i] - sc->lo[i]) / sc->range[i] - 1.0f;
+    if (n5_out) memcpy(n5_out, n5, sizeof(n5));
+    float f[4 * 64 + 64]; /* C <= 64 */
+    float* rgb_in = f;
+    for (int d = 0; d < 3; ++d) {
+        const float* M = sc->proj[d];
+        const float gx = n5[0] * M[0] + n5[1] * M[2] + n5[2] * M[4];
+        const float gy = n5[0] * M[1] + n5[1] * M[3] + n5[2] * M[5];
+        orc_sample_plane(sc->planes[d], C, sc->ph[d], sc->pw[d], gx, gy, rgb_in + d * C);
+    }
+    orc_sample_plane(sc->planes[3], C, sc->ph[3], sc->pw[3], n5[3], n5[4], rgb_in + 3 * C);
+    float* dens_in = f + 4 * C;
+    for (int c = 0; c < C; ++c) dens_in[c] = ((rgb_in[c] + rgb_in[C + c]) + rgb_in[2 * C + c]) / 3.0f;
+    if (feats) memcpy(feats, f, sizeof(float) * 5 * (size_t)C);
+
+    float a[512], b[512];
+    const float* p = dec->blob;
+    const float* cur = dens_in;
+    int in = C;
+    float* dst = a;
+    for (int l = 0; l < dec->n_density_layers; ++l) {
+        orc_linear(p, p + (size_t)h * in, cur, in, h, 1, dst);
+        p += (size_t)h * in + h;
+        cur = dst; dst = (dst == a) ? b : a; in = h;
+    }
+    float alpha;
+    orc_linear(p, p + h, cur, h, 1, 0, &alpha);
+    p += h + 1;
+    cur = rgb_in; in = 4 * C; dst = a;
+    for (int l = 0; l < dec->n_rgb_layers; ++l) {
+        orc_linear(p, p + (size_t)h * in, cur, in, h, 1, dst);
+        p += (size_t)h * in + h;
+        cur = dst; dst = (dst == a) ? b : a; in = h;
+    }
+    orc_linear(p, p + 3 * h, cur, h, 3, 0, out4);
+    out4[3] = alpha;
+}
+
+ORC_EXPORT void orc_triplane_decode(const orc_scene* sc, const orc_decoder* dec, long P, const float* x /*[P,6]*/,
+                                    float* out /*[P,4]*/, float* feats /*[P,5C] or NULL*/, float* n5 /*[P,5] or NULL*/) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < P; ++i)
+        orc_decode_point(sc, dec, x + 6 * i, out + 4 * i, feats ? feats + (size_t)i * 5 * dec->C : NULL, n5 ? n5 + 5 * i : NULL);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * volume_render_radiance_field (volume_rendering_utils.py:6-51) + cumprod_exclusive (nerf_helpers.py:409-430)
+ */
+static void orc_composite_ray(int S, const float* raw /*[S,4]*/, const float* z, const float* rd3, const float* noise,
+                              int white, float* rgb3, float* disp, float* acc, float* weights, float* depth) {
+    const float nrm = sqrtf(rd3[0] * rd3[0] + rd3[1] * rd3[1] + rd3[2] * rd3[2]);
+    float T = 1.0f, r = 0, g = 0, b = 0, dep = 0, ac = 0;
+    for (int s = 0; s < S; ++s) {
+        const float dist = ((s == S - 1) ? 1e10f : (z[s + 1] - z[s])) * nrm;
+        float sig = raw[4 * s + 3] + (noise ? noise[s] : 0.0f);
+        sig = sig > 0.0f ? sig : 0.0f;
+        const float alpha = 1.0f - expf(-sig * dist);
+        const float w = alpha * T;
+        T = T * (1.0f - alpha + 1e-10f);
+        if (weights) weights[s] = w;
+        r += w * (1.0f / (1.0f + expf(-raw[4 * s + 0])));
+        g += w * (1.0f / (1.0f + expf(-raw[4 * s + 1])));
+        b += w * (1.0f / (1.0f + expf(-raw[4 * s + 2])));
+        dep += w * z[s];
+        ac += w;
+    }
+    { const float q = dep / ac; *disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q)); } /* torch.max propagates NaN (acc == 0) */
+    if (white) { r += 1.0f - ac; g += 1.0f - ac; b += 1.0f - ac; }
+    rgb3[0] = r; rgb3[1] = g; rgb3[2] = b;
+    *acc = ac; *depth = dep;
+}
+
+ORC_EXPORT void orc_composite(long N, int S, const float* raw, const float* z, const float* rd, const float* noise,
+                              int white, float* rgb, float* disp, float* acc, float* weights, float* depth) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i)
+        orc_composite_ray(S, raw + (size_t)i * S * 4, z + (size_t)i * S, rd + 3 * i, noise ? noise + (size_t)i * S : NULL,
+                          white, rgb + 3 * i, disp + i, acc + i, weights ? weights + (size_t)i * S : NULL, depth + i);
+}
+
+ORC_EXPORT void orc_cumprod_exclusive(long N, int S, const float* in, float* out) {
+    for (long i = 0; i < N; ++i) {
+        float T = 1.0f;
+        for (int s = 0; s < S; ++s) { out[i * S + s] = T; T *= in[i * S + s]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sample_pdf_2 (nerf_helpers.py:668-702).  bins [N,nb], weights [N,nb-1], u [N,ns] (the caller supplies u:
+ * linspace(0,1,ns) for det=True, the CPU generator's rand otherwise) -> samples [N,ns]
+ */
+static void orc_sample_pdf_ray(int nb, int ns, const float* bins, const float* w, const float* u, float* out) {
+    float cdf[1024];
+    float sum = 0.0f;
+    for (int i = 0; i < nb - 1; ++i) sum += (w[i] + 1e-5f);
+    cdf[0] = 0.0f;
+    float run = 0.0f;
+    for (int i = 0; i < nb - 1; ++i) { run += (w[i] + 1e-5f) / sum; cdf[i + 1] = run; }
+    for (int j = 0; j < ns; ++j) {
+        /* searchsorted(cdf, u, right=True): first index with cdf[idx] > u */
+        int lo = 0, hi = nb;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > u[j]) hi = mid; else lo = mid + 1; }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nb - 1 ? lo : nb - 1;
+        float denom = cdf[above] - cdf[below];
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u[j] - cdf[below]) / denom;
+        out[j] = bins[below] + t * (bins[above] - bins[below]);
+    }
+}
+
+ORC_EXPORT void orc_sample_pdf(long N, int nb, int ns, const float* bins, const float* weights, const float* u, float* samples) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i)
+        orc_sample_pdf_ray(nb, ns, bins + (size_t)i * nb, weights + (size_t)i * (nb - 1), u + (size_t)i * ns, samples + (size_t)i * ns);
+}
+
+static int orc_cmp_float(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+/* sort(cat(z_vals, z_samples)) along the last dim (train_utils.py:155) */
+ORC_EXPORT void orc_sort_rows(long N, int n, float* data) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) qsort(data + (size_t)i * n, (size_t)n, sizeof(float), orc_cmp_float);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * predict_and_render_radiance + run_network (train_utils.py:15-182) on packed rays [N,11] =
+ * [ro, rd, near, far, viewdir] (run_one_iter_of_nerf, train_utils.py:213-226).
+ * t_rand/u/noise_* are the explicit random inputs (NULL: perturb off / det=True / no noise).
+ */
+typedef struct {
+    int num_coarse, num_fine, lindisp, perturb, white_background;
+} orc_render_cfg;
+
+ORC_EXPORT void orc_pack_rays(long N, const float* ro, const float* rd, const float* dirs_for_view, double near_, double far_, float* rays) {
+    for (long i = 0; i < N; ++i) {
+        float* r = rays + 11 * i;
+        const float* v = dirs_for_view + 3 * i;
+        memcpy(r, ro + 3 * i, 12); memcpy(r + 3, rd + 3 * i, 12);
+        r[6] = (float)near_; r[7] = (float)far_;
+        const float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        r[8] = v[0] / nrm; r[9] = v[1] / nrm; r[10] = v[2] / nrm;
+    }
+}
+
+ORC_EXPORT void orc_render_rays(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
+                                long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
+                                const float* noise_f, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f,
+                                float* acc_f, float* z_fine_out /*[N,Nc+Nf] or NULL*/, float* weights_c_out /*[N,Nc] or NULL*/) {
+    const int Nc = cfg->num_coarse, Nf = cfg->num_fine, St = Nc + Nf;
+#pragma omp parallel
+    {
+        float* z = (float*)malloc(sizeof(float) * (size_t)(St + 4));
+        float* zs = (float*)malloc(sizeof(float) * (size_t)(Nf + 4));
+        float* zm = (float*)malloc(sizeof(float) * (size_t)(Nc + 4));
+        float* raw = (float*)malloc(sizeof(float) * 4 * (size_t)(St + 4));
+        float* w = (float*)malloc(sizeof(float) * (size_t)(St + 4));
+        float* ud = (float*)malloc(sizeof(float) * (size_t)(Nf + 4));
+#pragma omp for schedule(dynamic, 16)
+        for (long i = 0; i < N; ++i) {
+            const float* r = rays + 11 * i;
+            orc_coarse_z(1, Nc, r + 6, r + 7, cfg->lindisp, cfg->perturb, t_rand ? t_rand + (size_t)i * Nc : NULL, z);
+            float x6[6], depth;
+            x6[3] = r[8]; x6[4] = r[9]; x6[5] = r[10];
+            for (int s = 0; s < Nc; ++s) {
+                for (int k = 0; k < 3; ++k) x6[k] = r[k] + r[3 + k] * z[s];
+                orc_decode_point(sc, coarse, x6, raw + 4 * s, NULL, NULL);
+            }
+            orc_composite_ray(Nc, raw, z, r + 3, noise_c ? noise_c + (size_t)i * Nc : NULL, cfg->white_background,
+                              rgb_c + 3 * i, disp_c + i, acc_c + i, w, &depth);
+            if (weights_c_out) memcpy(weights_c_out + (size_t)i * Nc, w, sizeof(float) * (size_t)Nc);
+            if (Nf <= 0) continue;
+            for (int s = 0; s < Nc - 1; ++s) zm[s] = 0.5f * (z[s + 1] + z[s]);
+            const float* ui;
+            if (u) ui = u + (size_t)i * Nf;
+            else { for (int j = 0; j < Nf; ++j) ud[j] = orc_linspace01(j, Nf); ui = ud; }
+            orc_sample_pdf_ray(Nc - 1, Nf, zm, w + 1, ui, zs);
+            memcpy(z + Nc, zs, sizeof(float) * (size_t)Nf);
+            qsort(z, (size_t)St, sizeof(float), orc_cmp_float);
+            if (z_fine_out) memcpy(z_fine_out + (size_t)i * St, z, sizeof(float) * (size_t)St);
+            for (int s = 0; s < St; ++s) {
+                for (int k = 0; k < 3; ++k) x6[k] = r[k] + r[3 + k] * z[s];
+                orc_decode_point(sc, fine, x6, raw + 4 * s, NULL, NULL);
+            }
+            orc_composite_ray(St, raw, z, r + 3, noise_f ? noise_f + (size_t)i * St : NULL, cfg->white_background,
+                              rgb_f + 3 * i, disp_f + i, acc_f + i, NULL, &depth);
+        }
+        free(z); free(zs); free(zm); free(raw); free(w); free(ud);
+    }
+}
+
+/* One pass of run_network + volume_render_radiance_field on given depths z [N,S] (train_utils.py:111-139 / :156-180) */
+ORC_EXPORT void orc_render_given_z(const orc_scene* sc, const orc_decoder* dec, long N, int S, const float* rays, const float* z,
+                                   const float* noise, int white, float* rgb, float* disp, float* acc, float* weights /*or NULL*/,
+                                   float* depth, float* raw_out /*[N,S,4] or NULL*/) {
+#pragma omp parallel
+    {
+        float* raw = (float*)malloc(sizeof(float) * 4 * (size_t)S);
+        float* w = (float*)malloc(sizeof(float) * (size_t)S);
+#pragma omp for schedule(dynamic, 16)
+        for (long i = 0; i < N; ++i) {
+            const float* r = rays + 11 * i;
+            const float* zi = z + (size_t)i * S;
+            float x6[6];
+            x6[3] = r[8]; x6[4] = r[9]; x6[5] = r[10];
+            for (int s = 0; s < S; ++s) {
+                for (int k = 0; k < 3; ++k) x6[k] = r[k] + r[3 + k] * zi[s];
+                orc_decode_point(sc, dec, x6, raw + 4 * s, NULL, NULL);
+            }
+            if (raw_out) memcpy(raw_out + (size_t)i * S * 4, raw, sizeof(float) * 4 * (size_t)S);
+            orc_composite_ray(S, raw, zi, r + 3, noise ? noise + (size_t)i * S : NULL, white, rgb + 3 * i, disp + i, acc + i,
+                              w, depth + i);
+            if (weights) memcpy(weights + (size_t)i * S, w, sizeof(float) * (size_t)S);
+        }
+        free(raw); free(w);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * EDSR (models.py:769-822): 3x3 valid convolutions without bias, residual blocks with a centre-cropped
+ * identity and x0.1 scaling, PixelShuffle(2) upscaling.
+ */
+/* out[co][y][x] = sum_{ci,ky,kx} w[co][ci][ky][kx] in[ci][y+ky][x+kx];   in [Ci,H,W] -> out [Co,H-2,W-2] */
+ORC_EXPORT void orc_conv3x3_valid(const float* in, int Ci, int H, int W, const float* wgt, int Co, int relu, float* out) {
+    const int Ho = H - 2, Wo = W - 2;
+#pragma omp parallel
+    {
+        acc_t* row = (acc_t*)malloc(sizeof(acc_t) * (size_t)Wo);
+#pragma omp for collapse(2) schedule(static)
+        for (int co = 0; co < Co; ++co)
+            for (int y = 0; y < Ho; ++y) {
+                for (int x = 0; x < Wo; ++x) row[x] = 0;
+                for (int ci = 0; ci < Ci; ++ci)
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float* ip = in + ((size_t)ci * H + (y + ky)) * W;
+                        const float* wp = wgt + (((size_t)co * Ci + ci) * 3 + ky) * 3;
+                        const acc_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        for (int x = 0; x < Wo; ++x) row[x] += w0 * (acc_t)ip[x] + w1 * (acc_t)ip[x + 1] + w2 * (acc_t)ip[x + 2];
+                    }
+                float* op = out + ((size_t)co * Ho + y) * Wo;
+                for (int x = 0; x < Wo; ++x) { float v = (float)row[x]; op[x] = (relu && v < 0) ? 0.0f : v; }
+            }
+        free(row);
+    }
+}
+
+/* nn.PixelShuffle(2): in [4C,H,W] -> out [C,2H,2W] */
+ORC_EXPORT void orc_pixel_shuffle2(const float* in, int C, int H, int W, float* out) {
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        out[((size_t)c * 2 * H + 2 * y + i) * 2 * W + 2 * x + j] = in[((size_t)(c * 4 + i * 2 + j) * H + y) * W + x];
+}
+
+/* weights blob order = state-dict order: conv_input [hid,Cin,3,3], residual.{b}.conv1, .conv2 [hid,hid,3,3],
+ * conv_mid, upscale.{0,2,..} [4hid,hid,3,3], conv_output [Cout,hid,3,3].  scale_factor = 2^n_up. */
+ORC_EXPORT long orc_edsr_blob_floats(int Cin, int Cout, int hid, int nblocks, int n_up) {
+    return 9L * ((long)hid * Cin + 2L * nblocks * hid * hid + (long)hid * hid + (long)n_up * 4 * hid * hid + (long)Cout * hid);
+}
+ORC_EXPORT void orc_edsr_out_size(int H, int W, int nblocks, int n_up, int* Ho, int* Wo) {
+    int h = H - 2 - 4 * nblocks - 2, w = W - 2 - 4 * nblocks - 2;
+    for (int u = 0; u < n_up; ++u) { h = (h - 2) * 2; w = (w - 2) * 2; }
+    *Ho = h - 2; *Wo = w - 2;
+}
+
+ORC_EXPORT void orc_edsr_forward(const float* x, int Cin, int H, int W, const float* blob, int Cout, int hid, int nblocks,
+                                 int n_up, float* out) {
+    const float* p = blob;
+    int h = H - 2, w = W - 2;
+    float* cur = (float*)malloc(sizeof(float) * (size_t)hid * h * w);
+    orc_conv3x3_valid(x, Cin, H, W, p, hid, 0, cur);
+    p += 9 * (size_t)hid * Cin;
+    for (int b = 0; b < nblocks; ++b) {          /* _Residual_Block.forward (models.py:777-786) */
+        float* t1 = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, p, hid, 1, t1);
+        p += 9 * (size_t)hid * hid;
+        float* t2 = (float*)malloc(sizeof(float) * (size_t)hid * (h - 4) * (w - 4));
+        orc_conv3x3_valid(t1, hid, h - 2, w - 2, p, hid, 0, t2);
+        p += 9 * (size_t)hid * hid;
+        for (int c = 0; c < hid; ++c)
+            for (int y = 0; y < h - 4; ++y)
+                for (int xx = 0; xx < w - 4; ++xx) {
+                    float* o = t2 + ((size_t)c * (h - 4) + y) * (w - 4) + xx;
+                    *o = *o * 0.1f + cur[((size_t)c * h + y + 2) * w + xx + 2];
+                }
+        free(t1); free(cur);
+        cur = t2; h -= 4; w -= 4;
+    }
+    {
+        float* t = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, p, hid, 0, t);
+        p += 9 * (size_t)hid * hid;
+        free(cur); cur = t; h -= 2; w -= 2;
+    }
+    for (int uidx = 0; uidx < n_up; ++uidx) {
+        float* t = (float*)malloc(sizeof(float) * 4 * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, p, 4 * hid, 0, t);
+        p += 9 * 4 * (size_t)hid * hid;
+        free(cur);
+        h -= 2; w -= 2;
+        cur = (float*)malloc(sizeof(float) * (size_t)hid * 4 * h * w);
+        orc_pixel_shuffle2(t, hid, h, w, cur);
+        free(t);
+        h *= 2; w *= 2;
+    }
+    orc_conv3x3_valid(cur, hid, h, w, p, Cout, 0, out);
+    free(cur);
+}
+
+/* F.interpolate(mode='bilinear', align_corners=True, scale_factor=sf) (models.py:858-859) on [C,H,W] */
+ORC_EXPORT void orc_upsample_bilinear_ac(const float* in, int C, int H, int W, int sf, float* out) {
+    const int Ho = H * sf, Wo = W * sf;
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
+    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < C; ++c)
+        for (int oy = 0; oy < Ho; ++oy) {
+            const float fy = sh * (float)oy;
+            const int y0 = (int)fy;
+            const int yp = (y0 < H - 1) ? 1 : 0;
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+            for (int ox = 0; ox < Wo; ++ox) {
+                const float fx = sw * (float)ox;
+                const int x0 = (int)fx;
+                const int xp = (x0 < W - 1) ? 1 : 0;
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                const float* p = in + ((size_t)c * H + y0) * W + x0;
+                out[((size_t)c * Ho + oy) * Wo + ox] =
+                    ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[(size_t)yp * W] + lx1 * p[(size_t)yp * W + xp]);
+            }
+        }
+}
+
+/* PlanesSR.forward (models.py:884-926).  roi = NULL: full plane (eval).  roi = [[ymin,xmin],[ymax,xmax]] in [-1,1]
+ * (training ROI path): the area outside the ROI is NaN.  pad = inner_model.required_padding, over = HR_overpadding
+ * (models.py:836-842).  mean/std (optional) = planes_{mean,std}_NON_LEARNED.  out [C, sf*R0, sf*R1]. */
+ORC_EXPORT void orc_planes_sr(const float* lr, int C, int R0, int R1, const float* blob, int hid, int nblocks, int n_up,
+                              int pad, int over, const float* roi, const float* mean, const float* std_, float* out) {
+    const int sf = 1 << n_up;
+    int lo[2] = {0, 0}, hi[2] = {R0, R1};
+    const int shape[2] = {R0, R1};
+    if (roi)
+        for (int a = 0; a < 2; ++a) {
+            const float mn = (float)shape[a] * (1.0f + roi[a]) / 2.0f, mx = (float)shape[a] * (1.0f + roi[2 + a]) / 2.0f;
+            int l = (int)floorf(mn), h = (int)ceilf(mx);
+            l = l - 1 > 0 ? l - 1 : 0;
+            h = h + 1 < shape[a] ? h + 1 : shape[a];
+            lo[a] = l; hi[a] = h;
+        }
+    const int ch = hi[0] - lo[0], cw = hi[1] - lo[1];
+    const int Hp = ch + 2 * pad, Wp = cw + 2 * pad;
+    float* x = (float*)malloc(sizeof(float) * (size_t)C * Hp * Wp);
+    /* crop (with as much real context as available, models.py:906-911) + replicate pad (:912-914) == clamped gather */
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Hp; ++y) {
+            int sy = lo[0] - pad + y; sy = sy < 0 ? 0 : (sy > R0 - 1 ? R0 - 1 : sy);
+            for (int xx = 0; xx < Wp; ++xx) {
+                int sx = lo[1] - pad + xx; sx = sx < 0 ? 0 : (sx > R1 - 1 ? R1 - 1 : sx);
+                float v = lr[((size_t)c * R0 + sy) * R1 + sx];
+                if (mean) v = (v - mean[c]) / std_[c];
+                x[((size_t)c * Hp + y) * Wp + xx] = v;
+            }
+        }
+    int Ho, Wo;
+    orc_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo);
+    float* diff = (float*)malloc(sizeof(float) * (size_t)C * Ho * Wo);
+    orc_edsr_forward(x, C, Hp, Wp, blob, C, hid, nblocks, n_up, diff);
+    free(x);
+    float* res = (float*)malloc(sizeof(float) * (size_t)C * R0 * sf * R1 * sf);
+    orc_upsample_bilinear_ac(lr, C, R0, R1, sf, res);
+    const size_t HRh = (size_t)R0 * sf, HRw = (size_t)R1 * sf;
+    for (size_t i = 0; i < (size_t)C * HRh * HRw; ++i) out[i] = NAN;
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < ch * sf; ++y)
+            for (int xx = 0; xx < cw * sf; ++xx) {
+                const size_t o = ((size_t)c * HRh + (size_t)lo[0] * sf + y) * HRw + (size_t)lo[1] * sf + xx;
+                out[o] = diff[((size_t)c * Ho + y + over) * Wo + xx + over] + res[o];
+            }
+    free(diff); free(res);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * positional_encoding (nerf_helpers.py:552-575): [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
+ */
+ORC_EXPORT void orc_positional_encoding(long P, int D, const float* x, int L, int include_input, float* out) {
+    const int stride = (include_input ? D : 0) + 2 * D * L;
+    for (long i = 0; i < P; ++i) {
+        float* o = out + (size_t)i * stride;
+        if (include_input) { memcpy(o, x + (size_t)i * D, sizeof(float) * (size_t)D); o += D; }
+        for (int l = 0; l < L; ++l) {
+            const float f = (float)ldexp(1.0, l);
+            for (int k = 0; k < D; ++k) o[k] = sinf(f * x[(size_t)i * D + k]);
+            for (int k = 0; k < D; ++k) o[D + k] = cosf(f * x[(size_t)i * D + k]);
+            o += 2 * D;
+        }
+    }
+}
+
+/* FlexibleNeRFModel.forward (models.py:83-108), use_viewdirs=True, num_layers_dir=1, xyz_input_2_dir=False.
+ * blob = state-dict order: layer1.{w,b}, layers_xyz.{i}.{w,b}, layers_dir.0.{w,b}, fc_alpha.{w,b}, fc_rgb.{w,b}, fc_feat.{w,b} */
+ORC_EXPORT void orc_flexible_nerf(long P, const float* x /*[P,dim_xyz+dim_dir]*/, int dim_xyz, int dim_dir, int hidden,
+                                  int num_layers, int skip_every, const float* blob, float* out /*[P,4]*/) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < P; ++i) {
+        const float* xi = x + (size_t)i * (dim_xyz + dim_dir);
+        float a[1024], b[1024];
+        const float* p = blob;
+        orc_linear(p, p + (size_t)hidden * dim_xyz, xi, dim_xyz, hidden, 0, a);
+        p += (size_t)hidden * dim_xyz + hidden;
+        float* cur = a; float* nxt = b;
+        int width = hidden;
+        for (int l = 0; l < num_layers - 1; ++l) {
+            int in = hidden;
+            if (l % skip_every == 0 && l > 0) { memcpy(cur + width, xi, sizeof(float) * (size_t)dim_xyz); in = hidden + dim_xyz; }
+            orc_linear(p, p + (size_t)hidden * in, cur, in, hidden, 1, nxt);
+            p += (size_t)hidden * in + hidden;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        const int hd = hidden / 2;
+        const float* dir_w = p; p += (size_t)hd * (dim_dir + hidden) + hd;
+        const float* alpha_w = p; p += hidden + 1;
+        const float* rgb_w = p; p += 3 * (size_t)hd + 3;
+        const float* feat_w = p;
+        float feat[1024 + 64];
+        orc_linear(feat_w, feat_w + (size_t)hidden * hidden, cur, hidden, hidden, 1, feat);
+        float alpha;
+        orc_linear(alpha_w, alpha_w + hidden, cur, hidden, 1, 0, &alpha);
+        memcpy(feat + hidden, xi + dim_xyz, sizeof(float) * (size_t)dim_dir);
+        float hdir[512];
+        orc_linear(dir_w, dir_w + (size_t)hd * (dim_dir + hidden), feat, dim_dir + hidden, hd, 1, hdir);
+        orc_linear(rgb_w, rgb_w + 3 * (size_t)hd, hdir, hd, 3, 0, out + 4 * i);
+        out[4 * i + 3] = alpha;
+    }
+}

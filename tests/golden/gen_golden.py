@@ -414,11 +414,25 @@ def g08_render():
     for nc, nf, white in [(32, 0, False), (64, 64, False), (64, 128, False), (64, 128, True)]:
         v = mode_cfg(nc, nf, white=white)
         cfg = make_cfg(v, v)
+        zrec = []
+        real_rn = tu.run_network
+
+        def rec_rn(*a, **k):            # record the depths each pass is evaluated at (train_utils.py:122,167)
+            zrec.append(k["z_vals"].clone())
+            return real_rn(*a, **k)
+
+        tu.run_network = rec_rn
+        try:
+            with torch.no_grad():
+                rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
+                    H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0), cfg,
+                    scene_id=sid, mode="validation", scene_config=cfg.dataset["synt"],
+                )
+        finally:
+            tu.run_network = real_rn
+        if nf > 0:
+            arrs["e%d_z_fine" % ci] = npy(zrec[1])
         with torch.no_grad():
-            rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
-                H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0), cfg,
-                scene_id=sid, mode="validation", scene_config=cfg.dataset["synt"],
-            )
             img_c, _, _, img_f, *_ = tu.eval_nerf(H, W, focal, mc, mf, ro, rd, cfg, scene_id=sid, scene_config=cfg.dataset["synt"])
         assert torch.equal(img_c.reshape(-1, 3), rc)
         arrs["e%d_params" % ci] = np.array([nc, nf, int(white), 0, 0.0])
@@ -445,9 +459,22 @@ def g08_render():
     mc.train()
     mf.train()
     torch.manual_seed(88)
-    with torch.no_grad():
-        rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
-            H, W, focal, mc, mf, rays, cfg, scene_id=sid, mode="train", scene_config=cfg.dataset["synt"])
+    zrec = []
+    real_rn = tu.run_network
+
+    def rec_rn(*a, **k):
+        zrec.append(k["z_vals"].clone())
+        return real_rn(*a, **k)
+
+    tu.run_network = rec_rn
+    try:
+        with torch.no_grad():
+            rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(
+                H, W, focal, mc, mf, rays, cfg, scene_id=sid, mode="train", scene_config=cfg.dataset["synt"])
+    finally:
+        tu.run_network = real_rn
+    arrs["t_z_coarse"] = npy(zrec[0])
+    arrs["t_z_fine"] = npy(zrec[1])
     torch.manual_seed(88)
     t_rand = torch.rand(N, nc)
     noise_c = torch.randn(N, nc) * std
