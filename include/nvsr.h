@@ -1,0 +1,121 @@
+/*
+ * nvsr.h -- C ABI of the MI355X (gfx950) implementation of the Neural-Volume-Super-Resolution rendering hot path.
+ *
+ * The reference (pure PyTorch) has no FFI; its boundary for this path is the Python call surface used by
+ * train_nerf.py.  Every entry point below replaces the ATen dispatches of one reference
+ * function; the citation gives the reference file:line.  The host-side mirror of the reference interface lives in
+ * neural-volume-super-resolution_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (fp32 unless stated) except `const nvsr_scene*`, a small host struct passed by value
+ *     to the kernels; the library never allocates, never synchronises, and launches on `stream` (a hipStream_t);
+ *   - tensors are dense row-major with the shapes given; "ray-major" [N,S] means S contiguous per ray;
+ *   - return value: 0 = NVSR_OK, otherwise an nvsr_status; nothing is written on a shape error;
+ *   - random inputs of the reference (stratified jitter t_rand, importance u, density noise) are explicit tensors so that
+ *     train-mode results are reproducible (reference draws them on the CPU generator: train_utils.py:108,
+ *     nerf_helpers.py:683, volume_rendering_utils.py:32).
+ */
+#ifndef NVSR_H
+#define NVSR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nvsr_stream_t; /* hipStream_t */
+
+typedef enum {
+    NVSR_OK = 0,
+    NVSR_ERR_SHAPE = 1,   /* argument out of the supported range */
+    NVSR_ERR_LAUNCH = 2,  /* hipGetLastError() != hipSuccess after a launch */
+    NVSR_ERR_NULL = 3,    /* required pointer is NULL */
+    NVSR_ERR_ALIGN = 4    /* pointer not 16-byte aligned */
+} nvsr_status;
+
+/* Decoder geometry compiled into the MFMA kernels: TwoDimPlanesModel(dec_density_layers=4, dec_rgb_layers=4,
+ * dec_channels=128, num_plane_channels=48, proj_combination='avg', viewdir_proj_combination='concat_pos'), the only
+ * configuration the shipped YAMLs instantiate (config/TrainModels.yml, Feature_Planes_Only.yml; models.py:118-197). */
+#define NVSR_PLANE_CHANNELS 48
+#define NVSR_DEC_CHANNELS 128
+#define NVSR_DEC_LAYERS 4
+#define NVSR_DECODER_NATURAL_FLOATS 130564 /* state-dict order, see nvsr_pack_decoder */
+#define NVSR_DECODER_PACKED_FLOATS 130576  /* MFMA-fragment order + biases/heads */
+
+/* One scene = 3 position planes + 1 view-direction plane, CHANNEL-LAST [H][W][48] (192 B per texel), the per-scene
+ * normalisation box (models.py:261-268) and the plane projections rot_mats[d][:,1:] (models.py:471-497). */
+typedef struct nvsr_scene {
+    const float* planes[4]; /* device, channel-last; [0..2] position planes D0..D2, [3] view-direction plane */
+    int32_t ph[4], pw[4];   /* rows (grid y) and columns (grid x) of each plane */
+    float lo[5];            /* (float)box[0][i] */
+    float range[5];         /* (float)(box[1][i] - box[0][i]), subtraction in double like the reference */
+    float proj[3][6];       /* row-major 3x2: grid = n_xyz @ proj[d] */
+} nvsr_scene;
+
+int nvsr_version(void);
+
+/* ---- data layout ------------------------------------------------------------------------------------------------ */
+/* [C,H,W] (reference plane layout, models.py:436-439) -> channel-last [H,W,C]; and back. */
+int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int C, int H, int W, nvsr_stream_t stream);
+int nvsr_plane_from_channel_last(const float* nhwc, float* nchw, int C, int H, int W, nvsr_stream_t stream);
+
+/* natural blob = state-dict order (models.py:169-195): density_dec.0.{0..3}.{weight[out,in],bias}, fc_alpha.0.{weight,bias},
+ * rgb_dec.0.{0..3}.{weight,bias}, fc_rgb.0.{weight,bias}  ->  packed blob consumed by the decode/render kernels. */
+int nvsr_pack_decoder(const float* natural, float* packed, nvsr_stream_t stream);
+
+/* ---- rays (nerf_helpers.py) -------------------------------------------------------------------------------------- */
+/* get_ray_bundle (nerf_helpers.py:507-549).  c2w: 16 floats row-major (device).  ro, rd: [(H+2p)*(W+2p), 3].
+ * focal_x = get_focal(f,'H'), focal_y = get_focal(f,'W') as the reference names them (:539-540). */
+int nvsr_get_ray_bundle(int H, int W, double focal_x, double focal_y, const float* c2w, int padding, double offset,
+                        float* ro, float* rd, nvsr_stream_t stream);
+/* ndc_rays (nerf_helpers.py:578-605) */
+int nvsr_ndc_rays(int H, int W, double focal, double near_, int64_t N, const float* ro, const float* rd, float* ro_out,
+                  float* rd_out, nvsr_stream_t stream);
+/* rays [N,11] = [ro, rd, near, far, viewdir = view_src/|view_src|]  (run_one_iter_of_nerf, train_utils.py:213-226) */
+int nvsr_pack_rays(int64_t N, const float* ro, const float* rd, const float* view_src, double near_, double far_,
+                   float* rays, nvsr_stream_t stream);
+/* coarse depths + stratified jitter (predict_and_render_radiance, train_utils.py:95-109); t_rand [N,Nc] or NULL */
+int nvsr_coarse_z(int64_t N, int Nc, const float* rays, int lindisp, const float* t_rand, float* z, nvsr_stream_t stream);
+
+/* ---- importance sampling ------------------------------------------------------------------------------------------ */
+/* sample_pdf_2 (nerf_helpers.py:668-702): bins [N,nb], weights [N,nb-1], u [N,ns] or NULL (det=True: linspace(0,1,ns))
+ * -> samples [N,ns].  nb <= 256. */
+int nvsr_sample_pdf(int64_t N, int nb, int ns, const float* bins, const float* weights, const float* u, float* samples,
+                    nvsr_stream_t stream);
+/* torch.sort(x, dim=-1) values of [N,n] rows, n <= 512 (train_utils.py:155); in and out may alias */
+int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream);
+/* fused train_utils.py:144-155: z_mid, sample_pdf(z_mid, w[1:-1], Nf, det = (u == NULL)), sort(cat(z, samples)) -> [N,Nc+Nf] */
+int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, const float* weights, const float* u,
+                             float* z_fine, nvsr_stream_t stream);
+
+/* ---- tri-plane decoder -------------------------------------------------------------------------------------------- */
+/* TwoDimPlanesModel.forward (models.py:381-421): x [P,6] = [xyz, viewdir] -> out [P,4] = [rgb_raw, sigma_raw] */
+int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out,
+                         nvsr_stream_t stream);
+
+/* ---- compositing -------------------------------------------------------------------------------------------------- */
+/* volume_render_radiance_field (volume_rendering_utils.py:6-51), mip_nerf=False.  raw [N,S,4], z [N,S], rd [N,3],
+ * noise [N,S] or NULL (already scaled by radiance_field_noise_std).  weights/depth may be NULL. */
+int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                   float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream);
+
+/* ---- fused per-ray render pass --------------------------------------------------------------------------------------
+ * run_network + TwoDimPlanesModel.forward + volume_render_radiance_field for one pass (train_utils.py:111-139 or :156-180):
+ * points ro + rd*z are generated, decoded and composited inside one kernel; no [N,S,*] intermediate reaches HBM.
+ * rays [N,11], z [N,S] -> rgb [N,3], disp [N], acc [N]; weights [N,S] / depth [N] optional (NULL). */
+int nvsr_render_pass(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                     const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                     nvsr_stream_t stream);
+
+/* predict_and_render_radiance (train_utils.py:71-182) for a ray chunk: coarse z -> coarse pass -> importance resample ->
+ * fine pass.  workspace: nvsr_render_workspace_floats(N, Nc, Nf) floats.  Nf == 0: coarse only (fine outputs untouched). */
+int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf);
+int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
+                     const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u,
+                     const float* noise_coarse, const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c,
+                     float* rgb_f, float* disp_f, float* acc_f, float* workspace, nvsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVSR_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI declared in include/nvsr.h (libnvsr_hip.so, built by build.py).
+
+This is the only place that touches the native library.  The signatures carry raw device pointers, sizes and a
+hipStream_t -- no torch types; torch tensors are turned into pointers here (`ptr`).  Loading fails loudly when the
+library is missing: there is no CPU fallback for the product path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from .build import LIB_PATH
+
+PLANE_CHANNELS = 48
+DEC_CHANNELS = 128
+DECODER_NATURAL_FLOATS = 130564
+DECODER_PACKED_FLOATS = 130576
+
+_STATUS = {1: "NVSR_ERR_SHAPE (argument out of the supported range)", 2: "NVSR_ERR_LAUNCH (kernel launch failed)",
+           3: "NVSR_ERR_NULL (required pointer is NULL)", 4: "NVSR_ERR_ALIGN (pointer not 16-byte aligned)"}
+
+
+class NvsrError(RuntimeError):
+    pass
+
+
+class Scene(C.Structure):
+    """struct nvsr_scene"""
+    _fields_ = [("planes", C.c_void_p * 4), ("ph", C.c_int32 * 4), ("pw", C.c_int32 * 4), ("lo", C.c_float * 5),
+                ("range", C.c_float * 5), ("proj", (C.c_float * 6) * 3)]
+
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_PROTOS = {
+    "nvsr_version": ([], C.c_int),
+    "nvsr_plane_to_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "nvsr_plane_from_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "nvsr_pack_decoder": ([_vp, _vp, _vp], _i),
+    "nvsr_get_ray_bundle": ([_i, _i, _d, _d, _vp, _i, _d, _vp, _vp, _vp], _i),
+    "nvsr_ndc_rays": ([_i, _i, _d, _d, _i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_pack_rays": ([_i64, _vp, _vp, _vp, _d, _d, _vp, _vp], _i),
+    "nvsr_coarse_z": ([_i64, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "nvsr_sample_pdf": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_sort_rows": ([_i64, _i, _vp, _vp, _vp], _i),
+    "nvsr_importance_resample": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
+    "nvsr_composite": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_render_pass": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_render_workspace_floats": ([_i64, _i, _i], _i64),
+    "nvsr_render_rays": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp], _i),
+}
+_PROTOS_OPTIONAL = {}  # filled by later additions (SR convolution); kept separate so symbol checks stay explicit
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/nvsr.h declares (used by the CPU test that checks the library exports them all)."""
+    return sorted(list(_PROTOS) + list(_PROTOS_OPTIONAL))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NvsrError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in {**_PROTOS, **_PROTOS_OPTIONAL}.items():
+            fn = getattr(_lib, name)
+            fn.argtypes, fn.restype = args, res
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-status entry point; raise NvsrError on a non-zero status."""
+    st = getattr(lib(), name)(*args)
+    if st != 0:
+        raise NvsrError("%s failed: %s" % (name, _STATUS.get(st, "status %d" % st)))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NvsrError("nvsr_amd runs on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def f32c(t):
+    """float32 + contiguous view/copy of a CUDA tensor."""
+    require_cuda(t)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,422 @@
+// Ray generation, depth sampling, inverse-CDF importance sampling, row sort, compositing and plane re-layout kernels (gfx950).
+// These are the HBM-bound stages of the path: one wavefront (64 lanes) per ray, coalesced row reads, wave scans in registers.
+//
+// Reference functions replaced (upstream paths): get_ray_bundle nerf_helpers.py:507-549, ndc_rays :578-605,
+// sample_pdf_2 :668-702, cumprod_exclusive :409-430, predict_and_render_radiance train_utils.py:95-109,144-155,
+// run_one_iter_of_nerf train_utils.py:213-226, volume_render_radiance_field volume_rendering_utils.py:6-51.
+#include "nvsr_common.h"
+
+namespace nvsr {
+
+constexpr int WPB = 4;  // waves per block for the wave-per-ray kernels
+
+// ---- wave-level primitives (64 lanes) ----------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive Hillis-Steele scans across the wave
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+    return v;
+}
+
+// ---- plane layout ------------------------------------------------------------------------------------------------------
+// [C, HW] -> [HW, C]: a block moves 64 pixels x all channels through LDS so that both sides are coalesced.
+__global__ void to_channel_last_kernel(const float* __restrict__ in, float* __restrict__ out, int Cc, long HW) {
+    extern __shared__ float tile[];  // [Cc][65]
+    const long p0 = (long)blockIdx.x * 64;
+    const int npx = (int)min((long)64, HW - p0);
+    for (int i = threadIdx.x; i < Cc * 64; i += blockDim.x) {
+        const int c = i >> 6, px = i & 63;
+        if (px < npx) tile[c * 65 + px] = in[(long)c * HW + p0 + px];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npx * Cc; i += blockDim.x) {
+        const int px = i / Cc, c = i - px * Cc;
+        out[p0 * Cc + i] = tile[c * 65 + px];
+    }
+}
+__global__ void from_channel_last_kernel(const float* __restrict__ in, float* __restrict__ out, int Cc, long HW) {
+    extern __shared__ float tile[];
+    const long p0 = (long)blockIdx.x * 64;
+    const int npx = (int)min((long)64, HW - p0);
+    for (int i = threadIdx.x; i < npx * Cc; i += blockDim.x) {
+        const int px = i / Cc, c = i - px * Cc;
+        tile[c * 65 + px] = in[p0 * Cc + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cc * 64; i += blockDim.x) {
+        const int c = i >> 6, px = i & 63;
+        if (px < npx) out[(long)c * HW + p0 + px] = tile[c * 65 + px];
+    }
+}
+
+// ---- rays --------------------------------------------------------------------------------------------------------------
+__global__ void ray_bundle_kernel(int H, int W, float fx, float fy, const float* __restrict__ c2w, int pad, float off,
+                                  float* __restrict__ ro, float* __restrict__ rd) {
+    const int Wp = W + 2 * pad;
+    const long n = (long)(H + 2 * pad) * Wp;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = (int)(i / Wp), c = (int)(i - (long)r * Wp);
+    float ii = __fadd_rn((float)c, off), jj = __fadd_rn((float)r, off);
+    if (pad > 0) { ii = __fsub_rn(ii, (float)pad); jj = __fsub_rn(jj, (float)pad); }
+    const float d0 = __fdiv_rn(__fsub_rn(ii, (float)(W * 0.5)), fx);
+    const float d1 = -__fdiv_rn(__fsub_rn(jj, (float)(H * 0.5)), fy);
+    const float d2 = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // torch.sum over the 3 products, left to right, no FMA contraction (bit-exact with the reference on CPU)
+        rd[i * 3 + k] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[k * 4 + 0]), __fmul_rn(d1, c2w[k * 4 + 1])), __fmul_rn(d2, c2w[k * 4 + 2]));
+        ro[i * 3 + k] = c2w[k * 4 + 3];
+    }
+}
+
+__global__ void ndc_rays_kernel(float sx, float sy, float nr, float two_near, float m_two_near, long N, const float* __restrict__ ro,
+                                const float* __restrict__ rd, float* __restrict__ ro_out, float* __restrict__ rd_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float o0 = ro[3 * i], o1 = ro[3 * i + 1], o2 = ro[3 * i + 2];
+    const float d0 = rd[3 * i], d1 = rd[3 * i + 1], d2 = rd[3 * i + 2];
+    const float t = __fdiv_rn(-__fadd_rn(nr, o2), d2);
+    const float ox = __fadd_rn(o0, __fmul_rn(t, d0)), oy = __fadd_rn(o1, __fmul_rn(t, d1)), oz = __fadd_rn(o2, __fmul_rn(t, d2));
+    ro_out[3 * i + 0] = __fdiv_rn(__fmul_rn(sx, ox), oz);
+    ro_out[3 * i + 1] = __fdiv_rn(__fmul_rn(sy, oy), oz);
+    ro_out[3 * i + 2] = __fadd_rn(1.0f, __fdiv_rn(two_near, oz));
+    rd_out[3 * i + 0] = __fmul_rn(sx, __fsub_rn(__fdiv_rn(d0, d2), __fdiv_rn(ox, oz)));
+    rd_out[3 * i + 1] = __fmul_rn(sy, __fsub_rn(__fdiv_rn(d1, d2), __fdiv_rn(oy, oz)));
+    rd_out[3 * i + 2] = __fdiv_rn(m_two_near, oz);
+}
+
+__global__ void pack_rays_kernel(long N, const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ vs,
+                                 float near_, float far_, float* __restrict__ rays) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float* r = rays + 11 * i;
+    const float v0 = vs[3 * i], v1 = vs[3 * i + 1], v2 = vs[3 * i + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)), __fmul_rn(v2, v2)));
+    r[0] = ro[3 * i]; r[1] = ro[3 * i + 1]; r[2] = ro[3 * i + 2];
+    r[3] = rd[3 * i]; r[4] = rd[3 * i + 1]; r[5] = rd[3 * i + 2];
+    r[6] = near_; r[7] = far_;
+    r[8] = __fdiv_rn(v0, nrm); r[9] = __fdiv_rn(v1, nrm); r[10] = __fdiv_rn(v2, nrm);
+}
+
+__device__ __forceinline__ float coarse_depth(float nr, float fr, int s, int Nc, int lindisp) {
+    const float t = linspace01(s, Nc);
+    if (!lindisp) return __fadd_rn(__fmul_rn(nr, __fsub_rn(1.0f, t)), __fmul_rn(fr, t));
+    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, nr), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, fr), t)));
+}
+
+__global__ void coarse_z_kernel(long N, int Nc, const float* __restrict__ rays, int lindisp, const float* __restrict__ t_rand,
+                                float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Nc) return;
+    const long ray = i / Nc;
+    const int s = (int)(i - ray * Nc);
+    const float nr = rays[ray * 11 + 6], fr = rays[ray * 11 + 7];
+    const float zc = coarse_depth(nr, fr, s, Nc, lindisp);
+    if (!t_rand) { z[i] = zc; return; }
+    const float lower = (s == 0) ? zc : __fmul_rn(0.5f, __fadd_rn(zc, coarse_depth(nr, fr, s - 1, Nc, lindisp)));
+    const float upper = (s == Nc - 1) ? zc : __fmul_rn(0.5f, __fadd_rn(coarse_depth(nr, fr, s + 1, Nc, lindisp), zc));
+    z[i] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[i]));
+}
+
+// ---- inverse-CDF importance sampling: one wave per ray -------------------------------------------------------------------
+// cdf (nb entries) is built in LDS by a wave scan; every lane then inverts it for samples lane, lane+64, ...
+// `bins`/`w` may come from global memory or LDS.  Returns through out_fn(j, sample).
+template <class LoadBin, class LoadW, class Store>
+__device__ __forceinline__ void sample_pdf_wave(int nb, int ns, LoadBin bin, LoadW wgt, const float* __restrict__ u, float* cdf /*LDS[nb]*/,
+                                                int lane, Store store) {
+    const int nw = nb - 1;
+    // pdf = (w + 1e-5) / sum(w + 1e-5)
+    float part = 0.0f;
+    for (int i = lane; i < nw; i += 64) part += __fadd_rn(wgt(i), 1e-5f);
+    const float total = wave_sum(part);
+    float carry = 0.0f;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int base = 0; base < nw; base += 64) {
+        const int i = base + lane;
+        const float p = (i < nw) ? __fdiv_rn(__fadd_rn(wgt(i), 1e-5f), total) : 0.0f;
+        const float sc = wave_scan_add(p, lane) + carry;
+        if (i < nw) cdf[i + 1] = sc;
+        carry = __shfl(sc, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): cdf visible to the whole wave
+    for (int j = lane; j < ns; j += 64) {
+        const float uj = u ? u[j] : linspace01(j, ns);
+        int lo = 0, hi = nb;                 // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > uj) hi = mid; else lo = mid + 1; }
+        const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+        const float c0 = cdf[below], c1 = cdf[above];
+        float denom = __fsub_rn(c1, c0);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = __fdiv_rn(__fsub_rn(uj, c0), denom);
+        const float b0 = bin(below), b1 = bin(above);
+        store(j, __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0))));
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void sample_pdf_kernel(long N, int nb, int ns, const float* __restrict__ bins,
+                                                             const float* __restrict__ weights, const float* __restrict__ u,
+                                                             float* __restrict__ samples) {
+    __shared__ float cdf_s[WPB][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * WPB + wave;
+    if (ray >= N) return;
+    const float* b = bins + ray * nb;
+    const float* w = weights + ray * (nb - 1);
+    float* out = samples + ray * ns;
+    sample_pdf_wave(nb, ns, [&](int i) { return b[i]; }, [&](int i) { return w[i]; }, u ? u + ray * ns : nullptr, cdf_s[wave], lane,
+                    [&](int j, float v) { out[j] = v; });
+}
+
+// rank sort of n <= 512 values held in LDS: rank = #smaller + #equal-with-lower-index (values only matter, like torch.sort)
+__device__ __forceinline__ void rank_sort_wave(const float* vals /*LDS[n]*/, int n, float* __restrict__ out, int lane) {
+    for (int e = lane; e < n; e += 64) {
+        const float v = vals[e];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) {
+            const float o = vals[k];
+            rank += (o < v) || (o == v && k < e);
+        }
+        out[rank] = v;
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float vals[WPB][512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * WPB + wave;
+    if (row >= N) return;
+    for (int i = lane; i < n; i += 64) vals[wave][i] = in[row * n + i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    rank_sort_wave(vals[wave], n, out + row * n, lane);
+}
+
+// train_utils.py:144-155 fused: z_mid -> sample_pdf(z_mid, w[1:-1]) -> sort(cat(z, samples))
+__global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, int Nc, int Nf, const float* __restrict__ zc,
+                                                                      const float* __restrict__ weights,
+                                                                      const float* __restrict__ u, float* __restrict__ zf) {
+    __shared__ float cdf_s[WPB][256];
+    __shared__ float zmid_s[WPB][256];
+    __shared__ float all_s[WPB][512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * WPB + wave;
+    if (ray >= N) return;
+    const float* z = zc + ray * Nc;
+    const float* w = weights + ray * Nc;
+    float* all = all_s[wave];
+    float* zm = zmid_s[wave];
+    for (int i = lane; i < Nc; i += 64) all[i] = z[i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int i = lane; i < Nc - 1; i += 64) zm[i] = __fmul_rn(0.5f, __fadd_rn(all[i + 1], all[i]));
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    sample_pdf_wave(Nc - 1, Nf, [&](int i) { return zm[i]; }, [&](int i) { return w[i + 1]; }, u ? u + ray * Nf : nullptr,
+                    cdf_s[wave], lane, [&](int j, float v) { all[Nc + j] = v; });
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    rank_sort_wave(all, Nc + Nf, zf + ray * (Nc + Nf), lane);
+}
+
+// ---- compositing: one wave per ray, samples across lanes, transmittance by a wave scan ------------------------------------
+__global__ __launch_bounds__(WPB * 64) void composite_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
+                                                            const float* __restrict__ rd, const float* __restrict__ noise, int white,
+                                                            float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc,
+                                                            float* __restrict__ weights, float* __restrict__ depth) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * WPB + wave;
+    if (ray >= N) return;
+    const float d0 = rd[ray * 3], d1 = rd[ray * 3 + 1], d2 = rd[ray * 3 + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+    const float* zr = z + ray * S;
+    const f32x4* rr = reinterpret_cast<const f32x4*>(raw) + ray * S;
+    float Tcarry = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, dep = 0.0f, ac = 0.0f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool in = s < S;
+        float w = 0.0f, zs = 0.0f, fac = 1.0f;
+        f32x4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (in) {
+            zs = zr[s];
+            rv = rr[s];
+            const float dist = __fmul_rn((s + 1 < S) ? __fsub_rn(zr[s + 1], zs) : 1e10f, nrm);
+            float sig = rv[3];
+            if (noise) sig = __fadd_rn(sig, noise[ray * S + s]);
+            sig = fmaxf(sig, 0.0f);
+            const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sig, dist)));
+            fac = __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f);
+            w = alpha;
+        }
+        const float incl = wave_scan_mul(fac, lane);          // prod_{k<=lane} fac_k
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float T = __fmul_rn(excl, Tcarry);
+        Tcarry = __fmul_rn(__shfl(incl, 63), Tcarry);
+        w = __fmul_rn(w, T);
+        if (in) {
+            if (weights) weights[ray * S + s] = w;
+            cr += w * (1.0f / (1.0f + expf(-rv[0])));
+            cg += w * (1.0f / (1.0f + expf(-rv[1])));
+            cb += w * (1.0f / (1.0f + expf(-rv[2])));
+            dep += w * zs;
+            ac += w;
+        }
+    }
+    cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dep = wave_sum(dep); ac = wave_sum(ac);
+    if (lane == 0) {
+        const float q = dep / ac;
+        disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+        if (white) { const float bg = 1.0f - ac; cr += bg; cg += bg; cb += bg; }
+        rgb[ray * 3] = cr; rgb[ray * 3 + 1] = cg; rgb[ray * 3 + 2] = cb;
+        acc[ray] = ac;
+        if (depth) depth[ray] = dep;
+    }
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+extern "C" {
+
+int nvsr_version(void) { return 100; }
+
+int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int Cc, int H, int W, nvsr_stream_t stream) {
+    if (!nchw || !nhwc) return NVSR_ERR_NULL;
+    if (Cc < 1 || Cc > 256 || H < 1 || W < 1) return NVSR_ERR_SHAPE;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(to_channel_last_kernel, dim3(blocks_for(HW, 64)), dim3(256), Cc * 65 * sizeof(float), (hipStream_t)stream,
+                       nchw, nhwc, Cc, HW);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_plane_from_channel_last(const float* nhwc, float* nchw, int Cc, int H, int W, nvsr_stream_t stream) {
+    if (!nchw || !nhwc) return NVSR_ERR_NULL;
+    if (Cc < 1 || Cc > 256 || H < 1 || W < 1) return NVSR_ERR_SHAPE;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(from_channel_last_kernel, dim3(blocks_for(HW, 64)), dim3(256), Cc * 65 * sizeof(float), (hipStream_t)stream,
+                       nhwc, nchw, Cc, HW);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_get_ray_bundle(int H, int W, double focal_x, double focal_y, const float* c2w, int padding, double offset, float* ro,
+                        float* rd, nvsr_stream_t stream) {
+    if (!c2w || !ro || !rd) return NVSR_ERR_NULL;
+    if (H < 1 || W < 1 || padding < 0) return NVSR_ERR_SHAPE;
+    const int64_t n = (int64_t)(H + 2 * padding) * (W + 2 * padding);
+    hipLaunchKernelGGL(ray_bundle_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, (float)focal_x,
+                       (float)focal_y, c2w, padding, (float)offset, ro, rd);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_ndc_rays(int H, int W, double focal, double near_, int64_t N, const float* ro, const float* rd, float* ro_out, float* rd_out,
+                  nvsr_stream_t stream) {
+    if (!ro || !rd || !ro_out || !rd_out) return NVSR_ERR_NULL;
+    if (N < 0 || H < 1 || W < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const float sx = (float)(-1.0 / (W / (2.0 * focal))), sy = (float)(-1.0 / (H / (2.0 * focal)));
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, sx, sy, (float)near_,
+                       (float)(2.0 * near_), (float)(-2.0 * near_), (long)N, ro, rd, ro_out, rd_out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_pack_rays(int64_t N, const float* ro, const float* rd, const float* view_src, double near_, double far_, float* rays,
+                   nvsr_stream_t stream) {
+    if (!ro || !rd || !view_src || !rays) return NVSR_ERR_NULL;
+    if (N < 0) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, (long)N, ro, rd, view_src,
+                       (float)near_, (float)far_, rays);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_coarse_z(int64_t N, int Nc, const float* rays, int lindisp, const float* t_rand, float* z, nvsr_stream_t stream) {
+    if (!rays || !z) return NVSR_ERR_NULL;
+    if (N < 0 || Nc < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(coarse_z_kernel, dim3(blocks_for(N * Nc, 256)), dim3(256), 0, (hipStream_t)stream, (long)N, Nc, rays, lindisp,
+                       t_rand, z);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_sample_pdf(int64_t N, int nb, int ns, const float* bins, const float* weights, const float* u, float* samples,
+                    nvsr_stream_t stream) {
+    if (!bins || !weights || !samples) return NVSR_ERR_NULL;
+    if (N < 0 || nb < 2 || nb > 256 || ns < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, nb, ns, bins,
+                       weights, u, samples);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream) {
+    if (!in || !out) return NVSR_ERR_NULL;
+    if (N < 0 || n < 1 || n > 512) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, n, in, out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, const float* weights, const float* u, float* z_fine,
+                             nvsr_stream_t stream) {
+    if (!z_coarse || !weights || !z_fine) return NVSR_ERR_NULL;
+    if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
+                       z_coarse, weights, u, z_fine);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd, float* rgb,
+                   float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream) {
+    if (!raw || !z || !rd || !rgb || !disp || !acc) return NVSR_ERR_NULL;
+    if (!aligned16(raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rd, noise,
+                       white_bkgd, rgb, disp, acc, weights, depth);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf) {
+    return N * (int64_t)(2 * Nc + (Nf > 0 ? Nc + Nf : 0));
+}
+
+int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
+                     const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u, const float* noise_coarse,
+                     const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f,
+                     float* workspace, nvsr_stream_t stream) {
+    if (!workspace) return NVSR_ERR_NULL;
+    if (N < 0 || Nc < 1 || Nf < 0) return NVSR_ERR_SHAPE;
+    if (Nf > 0 && (Nc < 3 || Nc > 256 || Nf > 256)) return NVSR_ERR_SHAPE;
+    if (Nf > 0 && (!packed_fine || !rgb_f || !disp_f || !acc_f)) return NVSR_ERR_NULL;
+    if (N == 0) return NVSR_OK;
+    float* z_c = workspace;
+    float* w_c = z_c + N * Nc;
+    float* z_f = w_c + N * Nc;
+    int e = nvsr_coarse_z(N, Nc, rays, lindisp, t_rand, z_c, stream);
+    if (e) return e;
+    e = nvsr_render_pass(scene, packed_coarse, N, Nc, rays, z_c, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, Nf > 0 ? w_c : nullptr,
+                         nullptr, stream);
+    if (e || Nf <= 0) return e;
+    e = nvsr_importance_resample(N, Nc, Nf, z_c, w_c, u, z_f, stream);
+    if (e) return e;
+    return nvsr_render_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, nullptr,
+                            stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Shared device-side definitions for the gfx950 kernels (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nvsr.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NVSR_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? NVSR_OK : NVSR_ERR_LAUNCH)
+
+namespace nvsr {
+
+constexpr int C = NVSR_PLANE_CHANNELS;  // 48 channels per plane texel
+constexpr int HID = NVSR_DEC_CHANNELS;  // 128 decoder width
+constexpr int HALF_C = C / 2;           // channels per lane-half (lane>>5) in the MFMA B-fragment
+
+// ---- natural (state-dict order) blob offsets, in floats ----------------------------------------------------------
+constexpr int N_DEN_W0 = 0;
+constexpr int N_DEN_B0 = HID * C;                               // 6144
+constexpr int N_DEN_W1 = N_DEN_B0 + HID;                        // 6272
+constexpr int N_HID_STRIDE = HID * HID + HID;                   // 16512
+constexpr int N_ALPHA_W = N_DEN_W1 + 3 * N_HID_STRIDE;          // 55808
+constexpr int N_ALPHA_B = N_ALPHA_W + HID;                      // 55936
+constexpr int N_RGB_W0 = N_ALPHA_B + 1;                         // 55937
+constexpr int N_RGB_B0 = N_RGB_W0 + HID * 4 * C;                // 80513
+constexpr int N_RGB_W1 = N_RGB_B0 + HID;                        // 80641
+constexpr int N_FCRGB_W = N_RGB_W1 + 3 * N_HID_STRIDE;          // 130177
+constexpr int N_FCRGB_B = N_FCRGB_W + 3 * HID;                  // 130561
+static_assert(N_FCRGB_B + 3 == NVSR_DECODER_NATURAL_FLOATS, "natural blob size");
+
+// ---- packed blob: A-operand fragments of v_mfma_f32_32x32x2_f32 in consumption order ------------------------------
+// A fragment unit = 256 floats = [lane 0..63][j 0..3]: lane l holds W[32*ib + (l&31)][k(l>>5, j)], read with one
+// ds_read_b128 per lane (conflict-free, lane-linear) and consumed by 4 consecutive MFMAs.
+//   feature layers  (K = 48 per plane):  [plane p][q 0..5][ib 0..3][lane][j]   k = 48p + 24h + 4q + j
+//   hidden layers   (K = 128)         :  [kb 0..3][q 0..3][ib 0..3][lane][j]   k = 32kb + 8q + 4h + j
+// (h = lane>>5; the k of a hidden layer is exactly the C/D register layout of the previous layer's accumulator, so
+//  activations chain through registers without any lane movement.)
+constexpr int P_PLANE_FLOATS = 6 * 4 * 256;                     // 6144  (24 KB) one plane's share of a feature layer
+constexpr int P_HID_FLOATS = HID * HID;                         // 16384 (64 KB)
+constexpr int P_RGB0 = 0;                                       // 4 planes
+constexpr int P_DEN0 = P_RGB0 + 4 * P_PLANE_FLOATS;             // 24576
+constexpr int P_DEN1 = P_DEN0 + P_PLANE_FLOATS;                 // 30720
+constexpr int P_RGB1 = P_DEN1 + 3 * P_HID_FLOATS;               // 79872
+constexpr int P_SMALL = P_RGB1 + 3 * P_HID_FLOATS;              // 129024
+// small region: biases [layer: den0..3, rgb0..3][ib][q][h][j], fc_alpha weight, fc_rgb weights (same order), head biases
+constexpr int S_BIAS = 0;                                       // 8 * 128
+constexpr int S_ALPHA_W = 8 * HID;                              // 1024
+constexpr int S_RGB_W = S_ALPHA_W + HID;                        // 1152
+constexpr int S_HEAD_B = S_RGB_W + 3 * HID;                     // 1536: alpha_b, rgb_b[3]
+constexpr int SMALL_FLOATS = 1552;                              // padded to a multiple of 16 B
+static_assert(P_SMALL + SMALL_FLOATS == NVSR_DECODER_PACKED_FLOATS, "packed blob size");
+
+struct SceneDev {
+    const float* plane[4];
+    int ph[4], pw[4];
+    float lo[5], range[5];
+    float proj[18];
+};
+
+inline SceneDev to_dev(const nvsr_scene* s) {
+    SceneDev d;
+    for (int i = 0; i < 4; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
+    for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
+    for (int i = 0; i < 18; ++i) d.proj[i] = (&s->proj[0][0])[i];
+    return d;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// torch.linspace(0, 1, n) element i in fp32 (symmetric two-sided form used by ATen's RangeFactories)
+__host__ __device__ inline float linspace01(int i, int n) {
+    if (n == 1) return 0.0f;
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? (step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+}  // namespace nvsr

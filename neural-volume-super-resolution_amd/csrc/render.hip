@@ -1,0 +1,472 @@
+// Tri-plane decoder + fused per-ray render pass for gfx950 (MI355X).
+//
+// Reference functions replaced (upstream paths): TwoDimPlanesModel.forward models.py:381-421 (normalize_coords :261-268,
+// CoordProjector :495-497, project_xyz/project_viewdir :289-326, combine_* :355-379), run_network train_utils.py:15-64,
+// volume_render_radiance_field volume_rendering_utils.py:6-51.
+//
+// Design:
+//   * one workgroup = 8 waves = 256 points per step (32 points per wave, one point per lane-pair l / l+32);
+//   * the decoder runs on v_mfma_f32_32x32x2_f32 (exact fp32): D[feature][point] = W[feature][k] * H[k][point];
+//     the accumulator (C/D) register layout of one layer IS the B-operand layout of the next, so activations never
+//     leave registers; bias is the accumulator's initial value, ReLU is applied in place;
+//   * weights (518 KB) stream L2 -> LDS as pre-permuted A fragments by LDS-DMA (global_load_lds, 16 B/lane) into a
+//     2 x 64 KB ring, one chunk (<= 64 KB) ahead of the MFMAs that consume it; biases and the two heads stay in LDS;
+//   * plane features: each lane gathers 24 of the 48 channels (96 contiguous bytes) of the 4 bilinear taps straight into the
+//     B-fragment registers (channel-last planes), blends in registers;
+//   * the render pass walks the samples of its 32 rays front to back, so transmittance is a running product in a register
+//     (the reference's exclusive cumprod, in the same order) and only per-ray results are written.
+#include "nvsr_common.h"
+
+namespace nvsr {
+
+constexpr int TPB = 512;
+constexpr int NWAVES = TPB / 64;
+constexpr int PTS_PER_WG = NWAVES * 32;
+constexpr int SLOT_FLOATS = 16384;                    // 64 KB ring slot
+constexpr int LDS_FLOATS = 2 * SLOT_FLOATS + SMALL_FLOATS;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// LDS-DMA: the 8 waves copy `BLOCKS` 1-KiB blocks (lane-linear, 16 B per lane); wave w takes blocks w, w+8, ...
+// gsrc is wave-uniform (SGPR base), voff = wave*1024 + lane*16 bytes is the only per-lane address register.
+template <int BLOCKS>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ gsrc, float* lds_dst, unsigned voff, int wave) {
+    static_assert(BLOCKS % NWAVES == 0, "chunk must split evenly over the waves");
+    const char* g = reinterpret_cast<const char*>(gsrc);
+#pragma unroll
+    for (int i = 0; i < BLOCKS / NWAVES; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * (NWAVES * 1024) + voff),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + (i * NWAVES + wave) * 256), 16, 0, 0);
+    }
+}
+
+// Wait for this wave's DMA, then meet the other waves: afterwards the chunk issued one phase ago is readable by everyone
+// and the slot read one phase ago is free.
+__device__ __forceinline__ void ring_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---- bilinear taps (grid_sample, align_corners=True, padding_mode='border') ------------------------------------------
+struct Taps {
+    int o00, o01, o10, o11;   // float offsets of the 4 texels (channel 0)
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
+    const float mx = (float)(W - 1), my = (float)(H - 1);
+    float x = (gx + 1.0f) * (mx / 2.0f);
+    float y = (gy + 1.0f) * (my / 2.0f);
+    x = fminf(mx, fmaxf(x, 0.0f));
+    y = fminf(my, fmaxf(y, 0.0f));
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    Taps t;
+    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    const int ix = (int)xw, iy = (int)yn;
+    const int ix1 = min(ix + 1, W - 1), iy1 = min(iy + 1, H - 1);   // a clamped neighbour always carries weight 0
+    t.o00 = (iy * W + ix) * C;  t.o01 = (iy * W + ix1) * C;
+    t.o10 = (iy1 * W + ix) * C; t.o11 = (iy1 * W + ix1) * C;
+    return t;
+}
+
+// 24 channels (half h of the texel) of the bilinear blend -> f[0..23]
+__device__ __forceinline__ void gather24(const float* __restrict__ plane, const Taps& t, int h, float (&f)[HALF_C]) {
+    const f32x4* p00 = reinterpret_cast<const f32x4*>(plane + t.o00 + HALF_C * h);
+    const f32x4* p01 = reinterpret_cast<const f32x4*>(plane + t.o01 + HALF_C * h);
+    const f32x4* p10 = reinterpret_cast<const f32x4*>(plane + t.o10 + HALF_C * h);
+    const f32x4* p11 = reinterpret_cast<const f32x4*>(plane + t.o11 + HALF_C * h);
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i) {
+        const f32x4 a = p00[i], b = p01[i], c = p10[i], d = p11[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(d[j], t.se, fmaf(c[j], t.sw, fmaf(b[j], t.ne, a[j] * t.nw)));
+    }
+}
+
+__device__ __forceinline__ float norm_coord(float v, float lo, float range) {
+    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v, lo)), range), 1.0f);
+}
+
+// ---- MFMA layers ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_bias(const float* bias /*LDS, packed [ib][q][h][j]*/, int h, f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ib][4 * q + j] = b[j];
+        }
+}
+
+__device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+}
+
+// one plane's 48 channels of a feature layer: acc += W[:, 48p .. 48p+47] * f
+__device__ __forceinline__ void feat_layer(const float* wl /*LDS: [q][ib][lane][j]*/, const float (&f)[HALF_C], int lane,
+                                           f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int q = 0; q < HALF_C / 4; ++q)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (q * 4 + ib) * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ib] = mfma32(a[j], f[4 * q + j], acc[ib]);
+        }
+}
+
+// hidden layer 128 -> 128: acc += W * in   (in = previous accumulators, already ReLU'd)
+__device__ __forceinline__ void hidden_layer(const float* wl /*LDS: [kb][q][ib][lane][j]*/, const f32x16 (&in)[4], int lane,
+                                             f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wl + ((kb * 4 + q) * 4 + ib) * 256 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ib] = mfma32(a[j], in[kb][4 * q + j], acc[ib]);
+            }
+}
+
+// 128 -> 1 head on the VALU: each lane owns 64 of the 128 features of its point, the partner lane (l ^ 32) the rest
+__device__ __forceinline__ float head_dot(const float* w /*LDS packed [ib][q][h][j]*/, int h, const f32x16 (&in)[4]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = fmaf(in[ib][4 * q + j], wv[j], s);
+        }
+    return s + __shfl_xor(s, 32);
+}
+
+struct RingState {
+    const float* packed;   // global packed decoder blob
+    float* lds;            // LDS base
+    int slot;              // slot that receives the NEXT issued chunk
+    int wave, lane;
+    unsigned voff;         // wave*1024 + lane*16: per-lane byte offset of the LDS-DMA source
+};
+
+template <int BLOCKS>
+__device__ __forceinline__ const float* ring_issue(RingState& rs, int packed_off) {
+    float* dst = rs.lds + rs.slot * SLOT_FLOATS;
+    stage_chunk<BLOCKS>(rs.packed + packed_off, dst, rs.voff, rs.wave);
+    rs.slot ^= 1;
+    return dst;
+}
+
+// Decode the wave's 32 points (px,py,pz given per lane, both lane halves hold the same point) -> raw rgb + sigma.
+// vt: bilinear taps on the view-direction plane.  Must be called by all waves of the workgroup together (ring barriers).
+// On entry the chunk RGB0a (position planes 0,1 of rgb layer 0) has been issued into `cur`; on exit the same holds for the
+// next call.  Chunk order: RGB0a, RGB0b, RGB1, RGB2, RGB3, DEN0, DEN1, DEN2, DEN3.
+__device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, const float*& cur, float px, float py, float pz,
+                                            const Taps& vt, float (&raw)[4]) {
+    // Re-derive the per-lane address registers every step: left loop-invariant, hipcc hoists one 64-bit address per
+    // DMA / LDS read out of the sample loop and spills them all.
+    asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+    const int lane = rs.lane, h = lane >> 5;
+    const float* small = rs.lds + 2 * SLOT_FLOATS;
+    const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
+    const float n1 = norm_coord(py, sc.lo[1], sc.range[1]);
+    const float n2 = norm_coord(pz, sc.lo[2], sc.range[2]);
+
+    // Order chosen for register pressure (256 VGPRs at 2 waves/SIMD): the rgb decoder runs first and consumes the plane
+    // features as they are gathered (only 24 + 24 feature registers live), the density decoder then runs from the 24
+    // registers of the averaged position features.
+    f32x16 accA[4], accB[4];
+    float D[HALF_C], F[HALF_C];
+
+    // ---- rgb layer 0: K = 192 = [f0 | f1 | f2 | f_view], one plane at a time ------------------------------------------
+    {
+        const float* M = sc.proj;
+        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[0], sc.pw[0]);
+        gather24(sc.plane[0], t, h, F);
+    }
+    ring_sync();
+    const float* nxt = ring_issue<48>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
+    load_bias(small + S_BIAS + 4 * HID, h, accA);
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
+    feat_layer(cur, F, lane, accA);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float* M = sc.proj + 6;
+        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[1], sc.pw[1]);
+        gather24(sc.plane[1], t, h, F);
+    }
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
+    feat_layer(cur + P_PLANE_FLOATS, F, lane, accA);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float* M = sc.proj + 12;
+        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[2], sc.pw[2]);
+        gather24(sc.plane[2], t, h, F);
+    }
+    // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = __fdiv_rn(__fadd_rn(D[c], F[c]), 3.0f);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_RGB1);
+    feat_layer(cur, F, lane, accA);
+    __builtin_amdgcn_sched_barrier(0);
+    gather24(sc.plane[3], vt, h, F);
+    feat_layer(cur + P_PLANE_FLOATS, F, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    // ---- rgb decoder layers 1..3 -> 3 ---------------------------------------------------------------------------------
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_RGB1 + P_HID_FLOATS);
+    load_bias(small + S_BIAS + 5 * HID, h, accB);
+    hidden_layer(cur, accA, lane, accB);
+    relu_inplace(accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_RGB1 + 2 * P_HID_FLOATS);
+    load_bias(small + S_BIAS + 6 * HID, h, accA);
+    hidden_layer(cur, accB, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<24>(rs, P_DEN0);
+    load_bias(small + S_BIAS + 7 * HID, h, accB);
+    hidden_layer(cur, accA, lane, accB);
+    relu_inplace(accB);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) raw[c] = head_dot(small + S_RGB_W + c * HID, h, accB) + small[S_HEAD_B + 1 + c];
+    cur = nxt;
+    // ---- density decoder: 48 -> 128 x4 -> 1 --------------------------------------------------------------------------
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_DEN1);
+    load_bias(small + S_BIAS + 0 * HID, h, accA);
+    feat_layer(cur, D, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_DEN1 + P_HID_FLOATS);
+    load_bias(small + S_BIAS + 1 * HID, h, accB);
+    hidden_layer(cur, accA, lane, accB);
+    relu_inplace(accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<64>(rs, P_DEN1 + 2 * P_HID_FLOATS);
+    load_bias(small + S_BIAS + 2 * HID, h, accA);
+    hidden_layer(cur, accB, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<48>(rs, P_RGB0);                 // first chunk of the next step
+    load_bias(small + S_BIAS + 3 * HID, h, accB);
+    hidden_layer(cur, accA, lane, accB);
+    relu_inplace(accB);
+    raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
+    cur = nxt;
+}
+
+// workgroup prologue: heads/biases -> LDS (plain copy), first ring chunk in flight
+__device__ __forceinline__ const float* decode_prologue(RingState& rs) {
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB) rs.lds[2 * SLOT_FLOATS + i] = rs.packed[P_SMALL + i];
+    return ring_issue<48>(rs, P_RGB0);
+}
+
+__device__ __forceinline__ Taps view_taps(const SceneDev& sc, float vx, float vy, float vz) {
+    // cart2az_el (nerf_helpers.py:492-496) + normalize_coords
+    const float az = atan2f(vy, vx);
+    const float el = atan2f(vz, sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy))));
+    return make_taps(norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.ph[3], sc.pw[3]);
+}
+
+// =====================================================================================================================
+// TwoDimPlanesModel.forward on an explicit point list x[P,6] -> out[P,4]
+// =====================================================================================================================
+__global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, const float* __restrict__ packed, long P,
+                                                                 const float* __restrict__ x, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    const float* cur = decode_prologue(rs);
+    const long ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
+        long p = tile * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
+        const bool valid = p < P;
+        if (!valid) p = P - 1;
+        const float* xp = x + p * 6;
+        const Taps vt = view_taps(sc, xp[3], xp[4], xp[5]);
+        float raw[4];
+        decode_step(sc, rs, cur, xp[0], xp[1], xp[2], vt, raw);
+        if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(out + p * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+    ring_sync();   // drain the chunk prefetched for a step that will not run
+}
+
+// =====================================================================================================================
+// Fused render pass: rays [N,11], depths z [N,S] -> per-ray rgb / disp / acc (/ weights / depth)
+// =====================================================================================================================
+__global__ __launch_bounds__(TPB, 2) void render_pass_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                             const float* __restrict__ rays, const float* __restrict__ z,
+                                                             const float* __restrict__ noise, int white,
+                                                             float* __restrict__ rgb, float* __restrict__ disp,
+                                                             float* __restrict__ acc, float* __restrict__ weights,
+                                                             float* __restrict__ depth) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    const float* cur = decode_prologue(rs);
+
+    long ray = (long)blockIdx.x * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
+    const bool valid = ray < N;
+    if (!valid) ray = N - 1;
+    const float* r = rays + ray * 11;
+    const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+    const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+    // dists * ||rd||  (volume_rendering_utils.py:27)
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float* zr = z + ray * S;
+    const float* nz = noise ? noise + ray * S : nullptr;
+    float* wr = weights ? weights + ray * S : nullptr;
+
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, dep = 0.0f, ac = 0.0f;
+    float zc = zr[0];
+    for (int s = 0; s < S; ++s) {
+        const float zn = (s + 1 < S) ? zr[s + 1] : 0.0f;
+        float raw[4];
+        decode_step(sc, rs, cur, __fadd_rn(ox, __fmul_rn(dx, zc)), __fadd_rn(oy, __fmul_rn(dy, zc)),
+                    __fadd_rn(oz, __fmul_rn(dz, zc)), vt, raw);
+        // volume_render_radiance_field, one sample (volume_rendering_utils.py:18-45)
+        const float dist = __fmul_rn((s + 1 < S) ? __fsub_rn(zn, zc) : 1e10f, nrm);
+        float sig = raw[3];
+        if (nz) sig = __fadd_rn(sig, nz[s]);
+        sig = fmaxf(sig, 0.0f);
+        const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sig, dist)));
+        const float w = __fmul_rn(alpha, T);
+        T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f));
+        cr = __fadd_rn(cr, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[0]))));
+        cg = __fadd_rn(cg, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[1]))));
+        cb = __fadd_rn(cb, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[2]))));
+        dep = __fadd_rn(dep, __fmul_rn(w, zc));
+        ac = __fadd_rn(ac, w);
+        if (wr && valid && rs.lane < 32) wr[s] = w;
+        zc = zn;
+    }
+    ring_sync();
+    if (valid && rs.lane < 32) {
+        const float q = dep / ac;                       // NaN when acc == 0, like torch.max(1e-10, nan)
+        disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+        if (white) { const float bg = 1.0f - ac; cr += bg; cg += bg; cb += bg; }
+        rgb[ray * 3 + 0] = cr; rgb[ray * 3 + 1] = cg; rgb[ray * 3 + 2] = cb;
+        acc[ray] = ac;
+        if (depth) depth[ray] = dep;
+    }
+}
+
+// =====================================================================================================================
+// natural (state-dict) blob -> packed blob
+// =====================================================================================================================
+__device__ __forceinline__ int bias_src(int layer, int f) {
+    if (layer == 0) return N_DEN_B0 + f;
+    if (layer < 4) return N_DEN_W1 + (layer - 1) * N_HID_STRIDE + HID * HID + f;
+    if (layer == 4) return N_RGB_B0 + f;
+    return N_RGB_W1 + (layer - 5) * N_HID_STRIDE + HID * HID + f;
+}
+
+__global__ void pack_decoder_kernel(const float* __restrict__ nat, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NVSR_DECODER_PACKED_FLOATS) return;
+    int src = -1;
+    if (idx < P_SMALL) {
+        const int j = idx & 3, lane = (idx >> 2) & 63, ib = (idx >> 8) & 3;
+        const int i = 32 * ib + (lane & 31), h = lane >> 5;
+        if (idx < P_DEN0) {                                     // rgb layer 0: [p][q][ib][lane][j]
+            const int p = idx / P_PLANE_FLOATS, q = (idx % P_PLANE_FLOATS) >> 10;
+            src = N_RGB_W0 + i * (4 * C) + C * p + HALF_C * h + 4 * q + j;
+        } else if (idx < P_DEN1) {                              // density layer 0
+            const int q = (idx - P_DEN0) >> 10;
+            src = N_DEN_W0 + i * C + HALF_C * h + 4 * q + j;
+        } else {                                                // hidden layers: [kb][q][ib][lane][j]
+            const bool is_rgb = idx >= P_RGB1;
+            const int rem0 = idx - (is_rgb ? P_RGB1 : P_DEN1);
+            const int l = rem0 / P_HID_FLOATS, rem = rem0 % P_HID_FLOATS;
+            const int kb = rem >> 12, q = (rem >> 10) & 3;
+            const int k = 32 * kb + 8 * q + 4 * h + j;
+            src = (is_rgb ? N_RGB_W1 : N_DEN_W1) + l * N_HID_STRIDE + i * HID + k;
+        }
+    } else {
+        const int s = idx - P_SMALL;
+        if (s < S_HEAD_B) {                                     // [vec][ib][q][h][j]
+            const int vec = s >> 7, rem = s & 127;
+            const int ib = rem >> 5, q = (rem >> 3) & 3, h = (rem >> 2) & 1, j = rem & 3;
+            const int f = 32 * ib + 8 * q + 4 * h + j;
+            if (vec < 8) src = bias_src(vec, f);
+            else if (vec == 8) src = N_ALPHA_W + f;
+            else src = N_FCRGB_W + (vec - 9) * HID + f;
+        } else if (s == S_HEAD_B) src = N_ALPHA_B;
+        else if (s < S_HEAD_B + 4) src = N_FCRGB_B + (s - S_HEAD_B - 1);
+    }
+    packed[idx] = src >= 0 ? nat[src] : 0.0f;
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" {
+
+int nvsr_pack_decoder(const float* natural, float* packed, nvsr_stream_t stream) {
+    if (!natural || !packed) return NVSR_ERR_NULL;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    const int n = NVSR_DECODER_PACKED_FLOATS;
+    hipLaunchKernelGGL(pack_decoder_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, packed);
+    return NVSR_CHECK_LAUNCH();
+}
+
+static int check_scene(const nvsr_scene* s) {
+    if (!s) return NVSR_ERR_NULL;
+    for (int d = 0; d < 4; ++d) {
+        if (!s->planes[d]) return NVSR_ERR_NULL;
+        if (!aligned16(s->planes[d])) return NVSR_ERR_ALIGN;
+        if (s->ph[d] < 1 || s->pw[d] < 1 || (int64_t)s->ph[d] * s->pw[d] * NVSR_PLANE_CHANNELS >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
+    }
+    return NVSR_OK;
+}
+
+int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out,
+                         nvsr_stream_t stream) {
+    if (int e = check_scene(scene)) return e;
+    if (!packed_decoder || !x || !out) return NVSR_ERR_NULL;
+    if (!aligned16(packed_decoder) || !aligned16(out)) return NVSR_ERR_ALIGN;
+    if (P < 0) return NVSR_ERR_SHAPE;
+    if (P == 0) return NVSR_OK;
+    const int64_t ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    hipLaunchKernelGGL(triplane_decode_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                       (long)P, x, out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_render_pass(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                     const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                     nvsr_stream_t stream) {
+    if (int e = check_scene(scene)) return e;
+    if (!packed_decoder || !rays || !z || !rgb || !disp || !acc) return NVSR_ERR_NULL;
+    if (!aligned16(packed_decoder)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const int64_t grid = (N + PTS_PER_WG - 1) / PTS_PER_WG;
+    if (grid > 0x7fffffff) return NVSR_ERR_SHAPE;
+    hipLaunchKernelGGL(render_pass_kernel, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                       (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth);
+    return NVSR_CHECK_LAUNCH();
+}
+
+}  // extern "C"

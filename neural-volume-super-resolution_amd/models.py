@@ -1,0 +1,293 @@
+"""Tri-plane decoder model -- mirror of the reference's models.py hot subset (a6; 8b surface).
+
+`TwoDimPlanesModel` keeps the reference's constructor signature, attribute protocol (`planes_`, `box_coords`, `cur_id`, ...)
+and state-dict keys, so checkpoints and the `PlanesOptimizer`-style wiring of the reference carry over; `forward` runs the
+fused gather + MFMA decoder kernel (csrc/render.hip) on channel-last copies of the planes and a fragment-packed copy of the
+weights, both cached and refreshed when the source tensors change."""
+import ctypes as C
+from re import search
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import capi
+
+
+def get_plane_name(scene_id, dimension):
+    """models.py:110-113"""
+    if scene_id is None:
+        return "_D%d" % (dimension)
+    return "sc%s_D%d" % (scene_id, dimension)
+
+
+def plane_name2scene(plane_name):
+    """models.py:115-116"""
+    return search("(?<=sc).*(?=_D)", plane_name).group(0)
+
+
+def get_scene_id(basedir, ds_factor, plane_res):
+    """models.py:928-929"""
+    return "%s_DS%d%s" % (basedir, ds_factor, "" if plane_res[0] is None else "_PlRes%d_%d" % (plane_res))
+
+
+def create_plane(resolution, num_plane_channels, init_STD):
+    """models.py:436-439 -- planes stay NCHW [1,C,H,W] at the interface, like the reference"""
+    if not isinstance(resolution, list):
+        resolution = [resolution, resolution]
+    return nn.Parameter(init_STD * torch.randn(size=[1, num_plane_channels, resolution[0], resolution[1]]))
+
+
+class CoordProjector(nn.Module):
+    """models.py:471-497.  Only the axis-aligned N<=3 constructor is reproduced (random rotations for N>3 are not used by
+    any shipped config); pre-built rot_mats of any N are accepted."""
+
+    def __init__(self, N: int = None, rot_mats=None) -> None:
+        super().__init__()
+        if rot_mats is None:
+            if N > 3:
+                raise NotImplementedError("random plane orientations (N>3) are not part of the hot path")
+            base_mat = torch.eye(3)
+            self.rot_mats_NON_LEARNED = nn.ParameterList(
+                [nn.Parameter(p) for p in [base_mat, base_mat[:, [1, 0, 2]], base_mat[:, [2, 0, 1]]][:N]])
+        else:
+            assert len(rot_mats) == N
+            self.rot_mats_NON_LEARNED = rot_mats
+
+    def forward(self, points_dim):
+        with torch.no_grad():
+            return torch.matmul(points_dim[0], self.rot_mats_NON_LEARNED[points_dim[1]][:, 1:].type(points_dim[0].type()))
+
+
+def to_channel_last(plane_nchw):
+    """[1,C,H,W] or [C,H,W] -> [H,W,C] through the re-layout kernel"""
+    p = capi.f32c(plane_nchw)
+    Cc, H, W = p.shape[-3:]
+    out = torch.empty((H, W, Cc), dtype=torch.float32, device=p.device)
+    capi.call("nvsr_plane_to_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
+    return out
+
+
+def from_channel_last(plane_hwc):
+    p = capi.f32c(plane_hwc)
+    H, W, Cc = p.shape
+    out = torch.empty((1, Cc, H, W), dtype=torch.float32, device=p.device)
+    capi.call("nvsr_plane_from_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
+    return out
+
+
+# plane name -> (source key, channel-last copy).  Shared by the coarse and the fine model, which sample the same planes
+# (the reference assigns one ParameterDict to both, models.py:601,707); refreshed when the source tensor changes.
+_PLANE_CACHE = {}
+
+
+def clear_plane_cache():
+    _PLANE_CACHE.clear()
+
+
+DECODER_KEYS = (
+    [("density_dec.0.%d.weight" % i, "density_dec.0.%d.bias" % i) for i in range(4)]
+    + [("fc_alpha.0.weight", "fc_alpha.0.bias")]
+    + [("rgb_dec.0.%d.weight" % i, "rgb_dec.0.%d.bias" % i) for i in range(4)]
+    + [("fc_rgb.0.weight", "fc_rgb.0.bias")]
+)
+
+
+class TwoDimPlanesModel(nn.Module):
+    """models.py:118-434"""
+
+    def __init__(self, use_viewdirs, dec_density_layers=4, dec_rgb_layers=4, dec_channels=128, skip_connect_every=None,
+                 num_plane_channels=48, num_viewdir_plane_channels=None, rgb_dec_input="projections", proj_combination="sum",
+                 plane_interp="bilinear", align_corners=True, viewdir_proj_combination=None, num_planes_or_rot_mats=3,
+                 plane_stats=False, detach_LR_planes=False, scene_coupler=None, point_coords_noise=0, ensemble_size=1):
+        self.num_density_planes = num_planes_or_rot_mats if isinstance(num_planes_or_rot_mats, int) else len(num_planes_or_rot_mats)
+        super().__init__()
+        self.box_coords = None
+        self.use_viewdirs = use_viewdirs
+        assert use_viewdirs or (viewdir_proj_combination is None and num_viewdir_plane_channels is None)
+        self.point_coords_noise = point_coords_noise
+        self.num_plane_channels = num_plane_channels
+        if num_viewdir_plane_channels is None:
+            num_viewdir_plane_channels = num_plane_channels if use_viewdirs else 0
+        self.num_viewdir_plane_channels = num_viewdir_plane_channels
+        self.plane_stats = plane_stats
+        self.detach_LR_planes = detach_LR_planes
+        self.align_corners = align_corners
+        assert rgb_dec_input in ["projections", "features", "projections_features"]
+        self.rgb_dec_input = rgb_dec_input
+        assert proj_combination in ["sum", "concat", "avg"]
+        if viewdir_proj_combination is None:
+            viewdir_proj_combination = proj_combination
+        assert viewdir_proj_combination in ["sum", "concat", "avg", "mult", "concat_pos"]
+        if num_viewdir_plane_channels != num_plane_channels:
+            assert "concat" in viewdir_proj_combination
+        self.proj_combination = proj_combination
+        self.viewdir_proj_combination = viewdir_proj_combination
+        self.plane_interp = plane_interp
+        self.skip_connect_every = skip_connect_every
+        self.dec_channels = dec_channels
+        self.dec_density_layers, self.dec_rgb_layers, self.ensemble_size = dec_density_layers, dec_rgb_layers, ensemble_size
+        self.coord_projector = CoordProjector(self.num_density_planes,
+                                              rot_mats=None if isinstance(num_planes_or_rot_mats, int) else num_planes_or_rot_mats)
+        self.scene_coupler = scene_coupler
+
+        # same module tree / state-dict keys as the reference (models.py:169-195)
+        self.density_dec = nn.ModuleDict([(str(i), nn.ModuleList()) for i in range(ensemble_size)])
+        in_channels = num_plane_channels * (self.num_density_planes if proj_combination == "concat" else 1)
+        for i in range(ensemble_size):
+            self.density_dec[str(i)].append(nn.Linear(in_channels, dec_channels))
+            for layer_num in range(dec_density_layers - 1):
+                if self.is_skip_layer(layer_num=layer_num):
+                    self.density_dec[str(i)].append(nn.Linear(in_channels + dec_channels, dec_channels))
+                else:
+                    self.density_dec[str(i)].append(nn.Linear(dec_channels, dec_channels))
+        self.fc_alpha = nn.ModuleDict([(str(i), nn.Linear(dec_channels, 1)) for i in range(ensemble_size)])
+        if "features" in self.rgb_dec_input:
+            self.fc_feat = nn.ModuleDict([(str(i), nn.Linear(dec_channels, num_plane_channels)) for i in range(ensemble_size)])
+        self.rgb_dec = nn.ModuleDict([(str(i), nn.ModuleList()) for i in range(ensemble_size)])
+        plane_C_mult = 0
+        if proj_combination == "concat" or viewdir_proj_combination == "concat_pos":
+            plane_C_mult += self.num_density_planes
+        rgb_in = num_viewdir_plane_channels + num_plane_channels * plane_C_mult
+        for i in range(ensemble_size):
+            self.rgb_dec[str(i)].append(nn.Linear(rgb_in, dec_channels))
+            for layer_num in range(dec_rgb_layers - 1):
+                if self.is_skip_layer(layer_num=layer_num):
+                    self.rgb_dec[str(i)].append(nn.Linear(rgb_in + dec_channels, dec_channels))
+                else:
+                    self.rgb_dec[str(i)].append(nn.Linear(dec_channels, dec_channels))
+        self.fc_rgb = nn.ModuleDict([(str(i), nn.Linear(dec_channels, 3)) for i in range(ensemble_size)])
+
+        self.skip_SR_ = False
+        self._packed_cache = None  # (source key, packed blob)
+
+    # ---- reference protocol ------------------------------------------------------------------------------------------
+    def is_skip_layer(self, layer_num):
+        """models.py:203-207"""
+        if self.skip_connect_every is None:
+            return False
+        return layer_num % self.skip_connect_every == 0 and layer_num > 0
+
+    def rot_mats(self):
+        return self.coord_projector.rot_mats_NON_LEARNED
+
+    def rot_mat_backward_support(self, loaded_dict):
+        """models.py:246-249"""
+        if not any(["rot_mats" in k for k in loaded_dict]):
+            loaded_dict.update(dict([(k, v) for k, v in self.state_dict().items() if "rot_mats" in k]))
+        return loaded_dict
+
+    def assign_SR_model(self, SR_model, SR_viewdir):
+        """models.py:251-256"""
+        self.SR_model = SR_model
+        self.SR_model.align_corners = self.align_corners
+        self.SR_model.SR_viewdir = SR_viewdir
+        self.skip_SR_ = False
+        assert not SR_viewdir, "Ceased supporting this option"
+
+    def set_cur_scene_id(self, scene_id):
+        self.cur_id = scene_id
+
+    def skip_SR(self, skip):
+        self.skip_SR_ = skip
+
+    def planes2cpu(self):
+        for p in self.planes_.values():
+            p.data = p.data.to("cpu")
+
+    def assign_LR_planes(self, scene=None):
+        """models.py:426-434 (no plane down-sampling: `should_downsample` is always False in the supported configs)"""
+        for k in self.planes_:
+            if scene is not None and self.scene_coupler is not None and self.scene_coupler.scene2saved[scene] not in k:
+                continue
+            if not self.SR_model.SR_viewdir and get_plane_name(None, self.num_density_planes) in k:
+                continue
+            plane = self.planes_[k]
+            self.SR_model.set_LR_plane(plane.detach() if self.detach_LR_planes else plane, id=k, save_interpolated=False)
+
+    # ---- native path ---------------------------------------------------------------------------------------------------
+    def _check_native_geometry(self):
+        ok = (self.use_viewdirs and self.num_density_planes == 3 and self.num_plane_channels == capi.PLANE_CHANNELS
+              and self.num_viewdir_plane_channels == capi.PLANE_CHANNELS and self.dec_channels == capi.DEC_CHANNELS
+              and self.dec_density_layers == 4 and self.dec_rgb_layers == 4 and self.ensemble_size == 1
+              and self.proj_combination == "avg" and self.viewdir_proj_combination == "concat_pos"
+              and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear" and self.align_corners
+              and not any(self.is_skip_layer(l) for l in range(3)))
+        if not ok:
+            raise NotImplementedError(
+                "the gfx950 decoder kernel is compiled for the shipped configuration (3+1 planes x 48 channels, 'avg' / "
+                "'concat_pos', 4+4 layers x 128, no skip layer); got a different TwoDimPlanesModel geometry")
+
+    def natural_blob(self):
+        """Decoder parameters flattened in state-dict order (the layout nvsr_pack_decoder consumes)."""
+        sd = dict(self.named_parameters())
+        return torch.cat([sd[k].detach().reshape(-1).float() for pair in DECODER_KEYS for k in pair])
+
+    def packed_decoder(self):
+        self._check_native_geometry()
+        params = [p for n, p in self.named_parameters() if "rot_mats" not in n]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed_cache is None or self._packed_cache[0] != key:
+            nat = self.natural_blob()
+            capi.require_cuda(nat)
+            assert nat.numel() == capi.DECODER_NATURAL_FLOATS
+            packed = torch.empty(capi.DECODER_PACKED_FLOATS, dtype=torch.float32, device=nat.device)
+            capi.call("nvsr_pack_decoder", capi.ptr(nat), capi.ptr(packed), capi.stream())
+            self._packed_cache = (key, packed)
+        return self._packed_cache[1]
+
+    def _should_SR(self, plane_name):
+        if not hasattr(self, "SR_model") or self.skip_SR_:
+            return False
+        if self.scene_coupler is None:
+            return True
+        return self.scene_coupler.should_SR(plane_name, plane_not_scene=True)
+
+    def _plane_source(self, dim_num):
+        """models.py:270-284 `planes()`: the NCHW tensor a projection samples from (raw or super-resolved)."""
+        plane_name = get_plane_name(self.cur_id, dim_num)
+        super_resolve = dim_num < self.num_density_planes and self._should_SR(plane_name)
+        if self.scene_coupler is not None:
+            plane_name = self.scene_coupler.scene_with_saved_plane(plane_name, plane_not_scene=True)
+        if super_resolve:
+            return plane_name + "/SR", self.SR_model(plane_name)
+        return plane_name, self.planes_[plane_name]
+
+    def channel_last_plane(self, dim_num):
+        name, src = self._plane_source(dim_num)
+        key = (src.data_ptr(), src._version, tuple(src.shape))
+        hit = _PLANE_CACHE.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, to_channel_last(src.detach()))
+            _PLANE_CACHE[name] = hit
+        return hit[1]
+
+    def native_scene(self):
+        """struct nvsr_scene for the current scene id (+ the tensors that must outlive the launch)."""
+        self._check_native_geometry()
+        planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
+        sc = capi.Scene()
+        for d, p in enumerate(planes):
+            sc.planes[d] = p.data_ptr()
+            sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
+        box = self.box_coords[self.cur_id + ""].detach().double().cpu().numpy()
+        for i in range(5):
+            sc.lo[i] = np.float32(box[0, i])
+            sc.range[i] = np.float32(box[1, i] - box[0, i])   # subtraction in double, then cast (models.py:264-265)
+        for d in range(3):
+            m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().cpu().numpy()[:, 1:]
+            for k in range(3):
+                for c in range(2):
+                    sc.proj[d][k * 2 + c] = float(m[k, c])
+        return sc, planes
+
+    def forward(self, x):
+        """models.py:381-421: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb, sigma] (pre-activation)"""
+        x = capi.f32c(x)
+        assert x.shape[-1] == 6, "TwoDimPlanesModel expects [xyz, viewdir] rows"
+        P = x.numel() // 6
+        sc, keep = self.native_scene()
+        packed = self.packed_decoder()
+        out = torch.empty((P, 4), dtype=torch.float32, device=x.device)
+        capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
+        return out.reshape(list(x.shape[:-1]) + [4])

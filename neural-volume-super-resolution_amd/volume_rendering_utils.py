@@ -1,0 +1,28 @@
+"""Alpha compositing -- mirror of the reference's volume_rendering_utils.py (a7)."""
+import torch
+
+from . import capi
+
+
+def volume_render_radiance_field(radiance_field, depth_values, ray_directions, radiance_field_noise_std=0.0,
+                                 white_background=False, mip_nerf=False, noise=None):
+    """volume_rendering_utils.py:6-51 -> (rgb_map, disp_map, acc_map, weights, depth_map).
+
+    `noise` (extension): explicit density noise [..., S], already multiplied by the std.  Without it, a positive
+    radiance_field_noise_std draws torch.randn on the CPU generator exactly like the reference (:32-33)."""
+    if mip_nerf:
+        raise NotImplementedError("mip_nerf compositing is outside the tri-plane hot path (SURVEY.md 2)")
+    raw, z, rd = capi.f32c(radiance_field), capi.f32c(depth_values), capi.f32c(ray_directions)
+    lead, S = z.shape[:-1], z.shape[-1]
+    N = z.numel() // S
+    if noise is None and radiance_field_noise_std > 0.0:
+        noise = (torch.randn(raw[..., 3].shape) * radiance_field_noise_std).to(raw)
+    if noise is not None:
+        noise = capi.f32c(noise)
+    dev = raw.device
+    rgb = torch.empty(list(lead) + [3], dtype=torch.float32, device=dev)
+    disp, acc, depth = (torch.empty(list(lead), dtype=torch.float32, device=dev) for _ in range(3))
+    weights = torch.empty(list(lead) + [S], dtype=torch.float32, device=dev)
+    capi.call("nvsr_composite", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), int(bool(white_background)),
+              capi.ptr(rgb), capi.ptr(disp), capi.ptr(acc), capi.ptr(weights), capi.ptr(depth), capi.stream())
+    return rgb, disp, acc, weights, depth

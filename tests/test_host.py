@@ -1,0 +1,80 @@
+"""CPU tests of the host side: the package imports without a GPU, the C-ABI library loads and exports every symbol that
+include/nvsr.h declares (no compute calls), and the product path refuses CPU tensors instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import nvsr_amd
+
+    nvsr_amd.build_extension()
+    return nvsr_amd
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nvsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.lib()
+    declared = header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), "libnvsr_hip.so does not export %s" % name
+    assert sorted(pkg.capi.exported_symbols()) == declared      # the ctypes prototypes cover the whole header
+    assert lib.nvsr_version() >= 100
+    assert lib.nvsr_render_workspace_floats(10, 64, 128) == 10 * (2 * 64 + 192)
+
+
+def test_mirror_exposes_reference_surface(pkg):
+    for mod, names in {
+        "nerf_helpers": ["get_ray_bundle", "ndc_rays", "sample_pdf_2", "cumprod_exclusive", "get_minibatches", "meshgrid_xy"],
+        "volume_rendering_utils": ["volume_render_radiance_field"],
+        "train_utils": ["run_network", "predict_and_render_radiance", "run_one_iter_of_nerf", "eval_nerf"],
+        "models": ["TwoDimPlanesModel", "CoordProjector", "create_plane", "get_plane_name", "get_scene_id"],
+    }.items():
+        for n in names:
+            assert hasattr(getattr(pkg, mod), n), "%s.%s" % (mod, n)
+
+
+def test_state_dict_keys_match_reference(pkg):
+    m = pkg.models.TwoDimPlanesModel(use_viewdirs=True, skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos")
+    keys = set(m.state_dict().keys())
+    expect = {"coord_projector.rot_mats_NON_LEARNED.%d" % i for i in range(3)}
+    for dec, head in (("density_dec", "fc_alpha"), ("rgb_dec", "fc_rgb")):
+        expect |= {"%s.0.%d.%s" % (dec, i, p) for i in range(4) for p in ("weight", "bias")}
+        expect |= {"%s.0.%s" % (head, p) for p in ("weight", "bias")}
+    assert keys == expect
+    assert m.state_dict()["rgb_dec.0.0.weight"].shape == (128, 192) and m.state_dict()["density_dec.0.0.weight"].shape == (128, 48)
+    assert m.natural_blob().numel() == pkg.capi.DECODER_NATURAL_FLOATS
+    # D0 samples (y,z), D1 (x,z), D2 (x,y)  
+    r = [p[:, 1:] for p in m.rot_mats()]
+    x = torch.tensor([[1.0, 2.0, 3.0]])
+    assert (x @ r[0]).tolist() == [[2.0, 3.0]] and (x @ r[1]).tolist() == [[1.0, 3.0]] and (x @ r[2]).tolist() == [[1.0, 2.0]]
+
+
+def test_no_cpu_fallback(pkg):
+    with pytest.raises(pkg.capi.NvsrError):
+        pkg.nerf_helpers.get_ray_bundle(4, 4, 10.0, torch.eye(4))
+    with pytest.raises(pkg.capi.NvsrError):
+        pkg.volume_rendering_utils.volume_render_radiance_field(torch.zeros(2, 8, 4), torch.zeros(2, 8), torch.zeros(2, 3))
+    m = pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="concat")
+    with pytest.raises((NotImplementedError, pkg.capi.NvsrError)):
+        m(torch.zeros(4, 6))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "neural-volume-super-resolution_amd")
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dp, f)).read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, "%s mentions the oracle" % f
