@@ -286,6 +286,8 @@ class TwoDimPlanesModel(nn.Module):
         x = capi.f32c(x)
         assert x.shape[-1] == 6, "TwoDimPlanesModel expects [xyz, viewdir] rows"
         P = x.numel() // 6
+        if P == 0:
+            return torch.empty(list(x.shape[:-1]) + [4], dtype=torch.float32, device=x.device)
         sc, keep = self.native_scene()
         packed = self.packed_decoder()
         out = torch.empty((P, 4), dtype=torch.float32, device=x.device)

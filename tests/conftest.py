@@ -63,5 +63,13 @@ def sample_pdf_tolerance(bins, weights, u, eps=2e-6, floor=3e-6, w_noise=0.0):
             knife = np.abs(denom - 1e-5) < 4 * eps[i]
             denom = np.where(denom < 1e-5, 1.0, denom)
             tol_i = np.maximum(tol_i, np.where(knife, width, 2 * eps[i] * width / denom))
+            # u sitting on a cdf knot (always the case for u = 1.0 in det mode): searchsorted may pick either side, and if
+            # a bin next to the knot is below the 1e-5 threshold the sample collapses to that bin's start instead
+            ui = u[i].astype(np.float64)
+            on_knot = (np.abs(ui - cdf[i, below]) < 4 * eps[i]) | (np.abs(ui - cdf[i, above]) < 4 * eps[i])
+            lo_n = np.maximum(below - 1, 0)
+            hi_n = np.minimum(above + 1, cdf.shape[1] - 1)
+            span = np.abs(bins[i, hi_n] - bins[i, lo_n])
+            tol_i = np.maximum(tol_i, np.where(on_knot, span, 0.0))
         tol[i] = floor + tol_i
     return tol
