@@ -115,6 +115,32 @@ int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const 
                      const float* noise_coarse, const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c,
                      float* rgb_f, float* disp_f, float* acc_f, float* workspace, nvsr_stream_t stream);
 
+/* ---- feature-plane super-resolution (EDSR wrapped by PlanesSR) ------------------------------------------------------
+ * All activations are [C][H][W] fp32 (the reference's layout); convolutions are 3x3, stride 1, no padding, no bias. */
+/* one nn.Conv2d weight [Cout][Cin][3][3] -> MFMA fragment order; size = nvsr_conv3x3_packed_floats(Cin, Cout) */
+int64_t nvsr_conv3x3_packed_floats(int Cin, int Cout);
+int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_stream_t stream);
+/* out = epilogue(conv3x3(in)); epilogue 0 none | 1 ReLU | 2 residual: conv*0.1 + skip[..., 2:-2, 2:-2] with skip [Cout][H+2][W+2]
+ * (_Residual_Block.forward, models.py:777-786) | 3 nn.PixelShuffle(2) (out [Cout/4][2(H-2)][2(W-2)]) */
+int nvsr_conv3x3(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
+                 nvsr_stream_t stream);
+/* EDSR(in_channels, out_channels, hidden_size, n_blocks, scale_factor = 2^n_up, padding = 0)  (models.py:789-822).
+ * natural = state-dict order: conv_input, residual.{b}.conv1, residual.{b}.conv2, conv_mid, upscale.{0,2,..}, conv_output. */
+int64_t nvsr_edsr_natural_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
+int64_t nvsr_edsr_packed_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
+int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream);
+int nvsr_edsr_out_size(int H, int W, int nblocks, int n_up, int* Ho, int* Wo);
+int64_t nvsr_edsr_workspace_floats(int hid, int nblocks, int n_up, int H, int W);
+int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                      float* workspace, nvsr_stream_t stream);
+/* PlanesSR.forward (models.py:884-926): lr [C][R0][R1] -> out [C][sf*R0][sf*R1] = EDSR(replicate-padded crop)[over:-over] +
+ * bilinear_x{sf}(lr) inside the ROI, NaN outside.  roi: NULL = full plane, else 4 HOST floats [[ymin,xmin],[ymax,xmax]] in [-1,1]
+ * (models.py:278-279).  pad = EDSR.required_padding, over = HR_overpadding (models.py:836-842).  mean/std: optional [C] device
+ * vectors (planes_{mean,std}_NON_LEARNED). */
+int64_t nvsr_planes_sr_workspace_floats(int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi);
+int nvsr_planes_sr(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                   const float* roi, const float* mean, const float* std_, float* out, float* workspace, nvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

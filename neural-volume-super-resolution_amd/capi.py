@@ -50,7 +50,21 @@ _PROTOS = {
     "nvsr_render_rays": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp], _i),
 }
-_PROTOS_OPTIONAL = {}  # filled by later additions (SR convolution); kept separate so symbol checks stay explicit
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
+    "nvsr_conv3x3_packed_floats": ([_i, _i], _i64),
+    "nvsr_pack_conv3x3": ([_vp, _i, _i, _vp, _vp], _i),
+    "nvsr_conv3x3": ([_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "nvsr_edsr_natural_floats": ([_i, _i, _i, _i, _i], _i64),
+    "nvsr_edsr_packed_floats": ([_i, _i, _i, _i, _i], _i64),
+    "nvsr_pack_edsr": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "nvsr_edsr_out_size": ([_i, _i, _i, _i, _ip, _ip], _i),
+    "nvsr_edsr_workspace_floats": ([_i, _i, _i, _i, _i], _i64),
+    "nvsr_edsr_forward": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "nvsr_planes_sr_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp], _i),
+}
 
 _lib = None
 

@@ -1,0 +1,393 @@
+// Feature-plane super-resolution CNN (EDSR wrapped by PlanesSR) for gfx950.
+//
+// Reference functions replaced (upstream paths): _Residual_Block.forward models.py:777-786, EDSR.forward models.py:818-822,
+// PlanesSR.forward models.py:884-926 (interpolate_LR :858-859).
+//
+// conv3x3 (valid, stride 1, no bias) is an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32):
+//     D[co 32-block][32 pixels of one output row] += W[co][k] * X[k][pixel],   k = (ci, ky, kx)
+// A = weights (pre-packed fragments), B = input pixels read from an LDS patch (NCHW keeps the 32 pixels of a row
+// contiguous, so B reads are conflict-free ds_read_b32 and every input row is reused for the 3 ky taps from registers).
+// Input channels stream through LDS 4 at a time (36 k = 18 MFMA k-steps) by LDS-DMA, double-buffered, one barrier per
+// chunk.  A wave owns 2 co-blocks x 4 pixel-blocks (128 accumulator registers); a workgroup = 8 waves arranged
+// CO_WAVES x PX_WAVES: (4,2) = 256 channels x (8 rows x 32 cols) for the wide layers, (1,8) = 64 channels x (32 x 32) for the
+// narrow heads.  Epilogues fuse ReLU, the residual block's x0.1 + centre-cropped identity, and PixelShuffle(2).
+#include "nvsr_common.h"
+
+namespace nvsr {
+
+constexpr int CONV_TPB = 512;
+constexpr int CONV_WAVES = 8;
+constexpr int K_PER_CHUNK = 18;                 // MFMA k-steps per 4-channel chunk (36 k / 2)
+constexpr int FRAG_FLOATS = K_PER_CHUNK * 64;   // 1152 floats per (chunk, co-block)
+
+enum ConvEpilogue { EPI_NONE = 0, EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_PIXEL_SHUFFLE = 3 };
+
+struct ConvParams {
+    const float* in;      // [Cin][H][W]
+    const float* wpk;     // packed weights [chunk][cb][t][lane]
+    float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
+    const float* skip;    // residual identity [Cout][H+2][W+2] (block input), EPI_RESIDUAL only
+    int Cin, Cout, H, W;
+    int ncb_total;        // padded co-blocks in wpk (multiple of 2)
+    int nchunks;          // ceil(Cin/4)
+    int epilogue;
+};
+
+template <int CO_WAVES, int PX_WAVES>
+__global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
+    constexpr int NCB = CO_WAVES * 2;            // co-blocks per workgroup
+    constexpr int ROWS = PX_WAVES * 4;           // output rows per workgroup tile
+    constexpr int PR = ROWS + 2, PC = 34;        // input patch rows / cols (halo)
+    constexpr int P_FLOATS = 4 * PR * PC;
+    constexpr int P_PAD = (P_FLOATS + 63) / 64 * 64;
+    constexpr int W_FLOATS = NCB * FRAG_FLOATS;
+    constexpr int BUF = W_FLOATS + P_PAD;
+    constexpr int P_ITERS = (P_FLOATS + CONV_TPB - 1) / CONV_TPB;
+    constexpr int W_BLOCKS = W_FLOATS / 256;     // 1-KiB DMA blocks
+    constexpr int W_ITERS = (W_BLOCKS + CONV_WAVES - 1) / CONV_WAVES;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int cw = wave / PX_WAVES, rg = wave % PX_WAVES;   // co-wave, pixel-row group
+    const int Ho = p.H - 2, Wo = p.W - 2;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * ROWS, cg = blockIdx.z;
+    const long HW = (long)p.H * p.W;
+
+    // per-thread source offsets of the patch elements it DMA-copies (spatial part; the channel part changes per chunk)
+    int p_sp[P_ITERS], p_cl[P_ITERS];
+#pragma unroll
+    for (int i = 0; i < P_ITERS; ++i) {
+        const int e = (i * CONV_WAVES + wave) * 64 + lane;
+        const int cl = e / (PR * PC), rem = e - cl * (PR * PC), r = rem / PC, c = rem - r * PC;
+        p_cl[i] = (e < P_FLOATS) ? cl : -1;
+        p_sp[i] = min(y0 + r, p.H - 1) * p.W + min(x0 + c, p.W - 1);
+    }
+    const float* wsrc = p.wpk + (long)cg * NCB * FRAG_FLOATS;
+    const long wchunk_stride = (long)p.ncb_total * FRAG_FLOATS;
+
+    auto issue = [&](int chunk, int buf) {
+        float* wl = lds + buf * BUF;
+        float* pl = wl + W_FLOATS;
+        const char* g = reinterpret_cast<const char*>(wsrc + chunk * wchunk_stride);
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            const int blk = i * CONV_WAVES + wave;
+            if (blk < W_BLOCKS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + blk * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(wl + blk * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < P_ITERS; ++i) {
+            if (p_cl[i] >= 0) {
+                const int ci = min(chunk * 4 + p_cl[i], p.Cin - 1);   // padded channels carry zero weights
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + ci * HW + p_sp[i]),
+                                                 (__attribute__((address_space(3))) void*)(pl + (i * CONV_WAVES + wave) * 64), 4, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    issue(0, 0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // chunk landed for everyone; the other buffer is free
+        if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
+        const float* wl = lds + buf * BUF + (cw * 2) * FRAG_FLOATS + lane;
+        const float* pl = lds + buf * BUF + W_FLOATS + (rg * 4) * PC + j;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {      // lane half h works on channel c2 + 2h of the chunk
+            const float* pc = pl + (c2 + 2 * h) * (PR * PC);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float b[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) b[r] = pc[r * PC + kx];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int t = c2 * 9 + ky * 3 + kx;
+                    const float a0 = wl[t * 64], a1 = wl[FRAG_FLOATS + t * 64];
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        acc[0][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[pb + ky], acc[0][pb], 0, 0, 0);
+                        acc[1][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[pb + ky], acc[1][pb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    const int x = x0 + j;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int y = y0 + rg * 4 + pb;
+            if (y >= Ho || x >= Wo) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cg * NCB + cw * 2 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co >= p.Cout) continue;
+                float v = acc[cb][pb][r];
+                if (p.epilogue == EPI_RELU) v = fmaxf(v, 0.0f);
+                if (p.epilogue == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
+                    v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
+                if (p.epilogue == EPI_PIXEL_SHUFFLE)
+                    p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
+                else
+                    p.out[((long)co * Ho + y) * Wo + x] = v;
+            }
+        }
+}
+
+// [Cout][Cin][3][3] -> [chunk][cb][t][lane]
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int nchunks) {
+    const long n = (long)nchunks * ncb * FRAG_FLOATS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = idx & 63, t = (int)((idx >> 6) % K_PER_CHUNK);
+    const long rest = idx / FRAG_FLOATS;
+    const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
+    const int co = 32 * cb + (lane & 31), ci = 4 * chunk + t / 9 + 2 * (lane >> 5), tap = t % 9;
+    wpk[idx] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * 9 + tap] : 0.0f;
+}
+
+// PlanesSR input: crop with as much real context as available + replicate padding == clamped gather (models.py:906-914),
+// optional per-channel normalisation (:899-901).  out [C][ch+2pad][cw+2pad]
+__global__ void sr_prepare_kernel(const float* __restrict__ lr, int Cc, int R0, int R1, int lo0, int lo1, int Hp, int Wp, int pad,
+                                  const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ out) {
+    const long n = (long)Cc * Hp * Wp;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int xx = (int)(i % Wp), y = (int)((i / Wp) % Hp), c = (int)(i / ((long)Wp * Hp));
+    const int sy = min(max(lo0 - pad + y, 0), R0 - 1), sx = min(max(lo1 - pad + xx, 0), R1 - 1);
+    float v = lr[((long)c * R0 + sy) * R1 + sx];
+    if (mean) v = (v - mean[c]) / stdv[c];
+    out[i] = v;
+}
+
+// PlanesSR output (models.py:915-923): canvas = NaN; canvas[roi] = difference[over:-over] + bilinear_x{sf}(LR)[roi]
+// (F.interpolate(mode='bilinear', align_corners=True), :858-859)
+__global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo, int over, const float* __restrict__ lr, int Cc, int R0,
+                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out) {
+    const int HR0 = R0 * sf, HR1 = R1 * sf;
+    const long n = (long)Cc * HR0 * HR1;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ox = (int)(i % HR1), oy = (int)((i / HR1) % HR0), c = (int)(i / ((long)HR1 * HR0));
+    if (oy < lo0 * sf || oy >= hi0 * sf || ox < lo1 * sf || ox >= hi1 * sf) { out[i] = __builtin_nanf(""); return; }
+    const float sh = HR0 > 1 ? (float)(R0 - 1) / (float)(HR0 - 1) : 0.0f;
+    const float sw = HR1 > 1 ? (float)(R1 - 1) / (float)(HR1 - 1) : 0.0f;
+    const float fy = sh * (float)oy, fx = sw * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = (y0 < R0 - 1) ? 1 : 0, xp = (x0 < R1 - 1) ? 1 : 0;
+    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    const float* q = lr + ((long)c * R0 + y0) * R1 + x0;
+    const float res = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * R1] + lx1 * q[(long)yp * R1 + xp]);
+    const int dy = oy - lo0 * sf + over, dx = ox - lo1 * sf + over;
+    out[i] = diff[((long)c * Ho + dy) * Wo + dx] + res;
+}
+
+struct ConvLayer { int Cin, Cout; };
+
+static inline int conv_ncb(int Cout) { return (Cout + 63) / 64 * 2; }
+static inline int conv_nchunks(int Cin) { return (Cin + 3) / 4; }
+static inline int64_t conv_packed_floats(int Cin, int Cout) { return (int64_t)conv_nchunks(Cin) * conv_ncb(Cout) * FRAG_FLOATS; }
+
+static int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
+                       hipStream_t stream) {
+    if (H < 3 || W < 3) return NVSR_ERR_SHAPE;
+    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue};
+    const int Ho = H - 2, Wo = W - 2;
+    if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
+        dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncb_total / 8);
+        hipLaunchKernelGGL((conv3x3_kernel<4, 2>), grid, dim3(CONV_TPB), 0, stream, p);
+    } else {
+        dim3 grid((Wo + 31) / 32, (Ho + 31) / 32, p.ncb_total / 2);
+        hipLaunchKernelGGL((conv3x3_kernel<1, 8>), grid, dim3(CONV_TPB), 0, stream, p);
+    }
+    return NVSR_CHECK_LAUNCH();
+}
+
+static void edsr_layers(int Cin, int Cout, int hid, int nblocks, int n_up, ConvLayer* L, int* n) {
+    int k = 0;
+    L[k++] = {Cin, hid};
+    for (int b = 0; b < 2 * nblocks; ++b) L[k++] = {hid, hid};
+    L[k++] = {hid, hid};
+    for (int u = 0; u < n_up; ++u) L[k++] = {hid, 4 * hid};
+    L[k++] = {hid, Cout};
+    *n = k;
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" {
+
+/* one conv layer: weights [Cout][Cin][3][3] (nn.Conv2d layout) -> packed fragments */
+int64_t nvsr_conv3x3_packed_floats(int Cin, int Cout) { return conv_packed_floats(Cin, Cout); }
+
+int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_stream_t stream) {
+    if (!w || !packed) return NVSR_ERR_NULL;
+    if (Cin < 1 || Cout < 1) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    const int64_t n = conv_packed_floats(Cin, Cout);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout,
+                       conv_ncb(Cout), conv_nchunks(Cin));
+    return NVSR_CHECK_LAUNCH();
+}
+
+/* epilogue: 0 none, 1 ReLU, 2 residual (out = conv*0.1 + skip[..., 2:-2, 2:-2], skip = [Cout][H+2][W+2]), 3 PixelShuffle(2) */
+int nvsr_conv3x3(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
+                 nvsr_stream_t stream) {
+    if (!in || !packed || !out) return NVSR_ERR_NULL;
+    if (epilogue < 0 || epilogue > 3 || (epilogue == EPI_RESIDUAL && !skip) || (epilogue == EPI_PIXEL_SHUFFLE && Cout % 4)) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    return launch_conv(in, Cin, H, W, packed, Cout, epilogue, skip, out, (hipStream_t)stream);
+}
+
+/* EDSR(in_channels=Cin, out_channels=Cout, hidden_size=hid, n_blocks, scale_factor=2^n_up, padding=0)  (models.py:789-822).
+ * natural blob = state-dict order: conv_input, residual.{b}.conv1, residual.{b}.conv2, conv_mid, upscale.{0,2,..}, conv_output. */
+int64_t nvsr_edsr_natural_floats(int Cin, int Cout, int hid, int nblocks, int n_up) {
+    return 9LL * ((int64_t)hid * Cin + (2LL * nblocks + 1) * hid * hid + (int64_t)n_up * 4 * hid * hid + (int64_t)Cout * hid);
+}
+int64_t nvsr_edsr_packed_floats(int Cin, int Cout, int hid, int nblocks, int n_up) {
+    ConvLayer L[600]; int n;
+    if (nblocks < 0 || nblocks > 290 || n_up < 0 || n_up > 8) return -1;
+    edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
+    int64_t s = 0;
+    for (int i = 0; i < n; ++i) s += conv_packed_floats(L[i].Cin, L[i].Cout);
+    return s;
+}
+int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream) {
+    if (!natural || !packed) return NVSR_ERR_NULL;
+    if (nvsr_edsr_packed_floats(Cin, Cout, hid, nblocks, n_up) < 0) return NVSR_ERR_SHAPE;
+    ConvLayer L[600]; int n;
+    edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
+    for (int i = 0; i < n; ++i) {
+        if (int e = nvsr_pack_conv3x3(natural, L[i].Cin, L[i].Cout, packed, stream)) return e;
+        natural += 9LL * L[i].Cin * L[i].Cout;
+        packed += conv_packed_floats(L[i].Cin, L[i].Cout);
+    }
+    return NVSR_OK;
+}
+
+/* spatial size of the EDSR output for an [*, H, W] input */
+int nvsr_edsr_out_size(int H, int W, int nblocks, int n_up, int* Ho, int* Wo) {
+    int64_t h = (int64_t)H - 2 - 4 * nblocks - 2, w = (int64_t)W - 2 - 4 * nblocks - 2;
+    for (int u = 0; u < n_up; ++u) { h = (h - 2) * 2; w = (w - 2) * 2; }
+    h -= 2; w -= 2;
+    if (h < 1 || w < 1) return NVSR_ERR_SHAPE;
+    *Ho = (int)h; *Wo = (int)w;
+    return NVSR_OK;
+}
+
+/* two ping-pong activation buffers sized for the largest intermediate */
+int64_t nvsr_edsr_workspace_floats(int hid, int nblocks, int n_up, int H, int W) {
+    int64_t h = H - 2, w = W - 2, mx = (int64_t)hid * h * w;
+    h -= 4 * nblocks + 2; w -= 4 * nblocks + 2;
+    for (int u = 0; u < n_up; ++u) { h = (h - 2) * 2; w = (w - 2) * 2; if ((int64_t)hid * h * w > mx) mx = (int64_t)hid * h * w; }
+    return 3 * mx;
+}
+
+int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                      float* workspace, nvsr_stream_t stream_) {
+    if (!x || !packed || !out || !workspace) return NVSR_ERR_NULL;
+    int Ho, Wo;
+    if (int e = nvsr_edsr_out_size(H, W, nblocks, n_up, &Ho, &Wo)) return e;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t third = nvsr_edsr_workspace_floats(hid, nblocks, n_up, H, W) / 3;
+    float* bufs[3] = {workspace, workspace + third, workspace + 2 * third};
+    const float* wp = packed;
+    int h = H, w = W, e;
+    // conv_input
+    float* cur = bufs[0];
+    if ((e = launch_conv(x, Cin, h, w, wp, hid, EPI_NONE, nullptr, cur, stream))) return e;
+    wp += conv_packed_floats(Cin, hid); h -= 2; w -= 2;
+    int ci = 0;                                   // index of `cur` in bufs
+    for (int b = 0; b < nblocks; ++b) {           // _Residual_Block (models.py:777-786)
+        float* t1 = bufs[(ci + 1) % 3];
+        float* t2 = bufs[(ci + 2) % 3];
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_RELU, nullptr, t1, stream))) return e;
+        wp += conv_packed_floats(hid, hid);
+        if ((e = launch_conv(t1, hid, h - 2, w - 2, wp, hid, EPI_RESIDUAL, cur, t2, stream))) return e;
+        wp += conv_packed_floats(hid, hid);
+        cur = t2; ci = (ci + 2) % 3; h -= 4; w -= 4;
+    }
+    {   // conv_mid
+        float* t = bufs[(ci + 1) % 3];
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_NONE, nullptr, t, stream))) return e;
+        wp += conv_packed_floats(hid, hid);
+        cur = t; ci = (ci + 1) % 3; h -= 2; w -= 2;
+    }
+    for (int u = 0; u < n_up; ++u) {              // conv hid -> 4 hid + PixelShuffle(2), fused
+        float* t = bufs[(ci + 1) % 3];
+        if ((e = launch_conv(cur, hid, h, w, wp, 4 * hid, EPI_PIXEL_SHUFFLE, nullptr, t, stream))) return e;
+        wp += conv_packed_floats(hid, 4 * hid);
+        cur = t; ci = (ci + 1) % 3; h = (h - 2) * 2; w = (w - 2) * 2;
+    }
+    return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream);
+}
+
+/* PlanesSR.forward (models.py:884-926).  lr [C][R0][R1]; roi = NULL (full plane) or 4 HOST floats [[ymin,xmin],[ymax,xmax]] in
+ * [-1,1]; pad = inner_model.required_padding, over = HR_overpadding; mean/std optional [C] (device).
+ * out [C][sf*R0][sf*R1] (NaN outside the ROI).  workspace: nvsr_planes_sr_workspace_floats(...) floats. */
+static void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
+    lo[0] = lo[1] = 0; hi[0] = R0; hi[1] = R1;
+    if (!roi) return;
+    const int shape[2] = {R0, R1};
+    for (int a = 0; a < 2; ++a) {
+        const float mn = (float)shape[a] * (1.0f + roi[a]) / 2.0f, mx = (float)shape[a] * (1.0f + roi[2 + a]) / 2.0f;
+        int l = (int)floorf(mn), hh = (int)ceilf(mx);
+        l = l - 1 > 0 ? l - 1 : 0;
+        hh = hh + 1 < shape[a] ? hh + 1 : shape[a];
+        lo[a] = l; hi[a] = hh;
+    }
+}
+
+int64_t nvsr_planes_sr_workspace_floats(int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi) {
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int Hp = hi[0] - lo[0] + 2 * pad, Wp = hi[1] - lo[1] + 2 * pad;
+    int Ho, Wo;
+    if (nvsr_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo)) return -1;
+    return (int64_t)Cc * Hp * Wp + (int64_t)Cc * Ho * Wo + nvsr_edsr_workspace_floats(hid, nblocks, n_up, Hp, Wp);
+}
+
+int nvsr_planes_sr(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                   const float* roi, const float* mean, const float* stdv, float* out, float* workspace, nvsr_stream_t stream_) {
+    if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
+    if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int sf = 1 << n_up;
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int ch = hi[0] - lo[0], cw = hi[1] - lo[1];
+    const int Hp = ch + 2 * pad, Wp = cw + 2 * pad;
+    int Ho, Wo;
+    if (int e = nvsr_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo)) return e;
+    if (Ho != ch * sf + 2 * over || Wo != cw * sf + 2 * over) return NVSR_ERR_SHAPE;   // pad/over inconsistent with the net
+    float* xin = workspace;
+    float* diff = xin + (int64_t)Cc * Hp * Wp;
+    float* ews = diff + (int64_t)Cc * Ho * Wo;
+    const int64_t n_in = (int64_t)Cc * Hp * Wp;
+    hipLaunchKernelGGL(sr_prepare_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, lr, Cc, R0, R1, lo[0], lo[1], Hp, Wp,
+                       pad, mean, stdv, xin);
+    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    if (int e = nvsr_edsr_forward(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
+    const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
+    hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
+                       lo[0], lo[1], hi[0], hi[1], out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -293,3 +293,184 @@ class TwoDimPlanesModel(nn.Module):
         out = torch.empty((P, 4), dtype=torch.float32, device=x.device)
         capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
         return out.reshape(list(x.shape[:-1]) + [4])
+
+
+# =======================================================================================================================
+# Feature-plane super-resolution: EDSR wrapped by PlanesSR (models.py:768-926)
+# =======================================================================================================================
+def _cfg_get(node, name, default=None):
+    if isinstance(node, dict):
+        return node.get(name, default)
+    return getattr(node, name, default)
+
+
+class _Residual_Block(nn.Module):
+    """models.py:769-786 (parameters only; the arithmetic is the fused conv -> ReLU -> conv -> x0.1 + cropped identity kernels)"""
+
+    def __init__(self, hidden_size, padding, kernel_size):
+        super().__init__()
+        self.margins = None if (padding or kernel_size == 1) else 2 * (kernel_size // 2)
+        self.conv1 = nn.Conv2d(hidden_size, hidden_size, kernel_size, stride=1, padding=padding, bias=False)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(hidden_size, hidden_size, kernel_size, stride=1, padding=padding, bias=False)
+
+
+class EDSR(nn.Module):
+    """models.py:789-822.  Same constructor, `required_padding` arithmetic and state-dict keys; forward runs nvsr_edsr_forward
+    (MFMA implicit-GEMM convolutions with fused ReLU / residual / PixelShuffle epilogues)."""
+
+    def __init__(self, in_channels, out_channels, hidden_size, n_blocks, scale_factor, padding, receptive_field_bound=np.iinfo(np.int32).max,
+                 **kwargs):
+        super().__init__()
+        import math
+        KERNEL_SIZE = 3
+        self.required_padding, rf_factor = 0, 1
+        if padding != 0:
+            raise NotImplementedError("the SR kernels implement the un-padded convolutions PlanesSR uses (PADDING = 0, models.py:836)")
+
+        def kernel_size(num_layers=1):
+            if (1 + 2 * (self.required_padding + rf_factor * num_layers * ((KERNEL_SIZE - 1) // 2))) <= receptive_field_bound:
+                self.required_padding += rf_factor * num_layers * (KERNEL_SIZE // 2)
+                return KERNEL_SIZE
+            raise NotImplementedError("receptive_field_bound falls back to 1x1 convolutions, which no shipped config uses")
+
+        self.conv_input = nn.Conv2d(in_channels, hidden_size, kernel_size(), stride=1, padding=padding, bias=False)
+        self.residual = nn.Sequential()
+        for _ in range(n_blocks):
+            self.residual.append(_Residual_Block(hidden_size=hidden_size, padding=padding, kernel_size=kernel_size(2)))
+        self.conv_mid = nn.Conv2d(hidden_size, hidden_size, kernel_size(), stride=1, padding=padding, bias=False)
+        assert math.log2(scale_factor) == int(math.log2(scale_factor)), "Supperting only scale factors that are an integer power of 2."
+        upscaling_layers = []
+        for _ in range(int(math.log2(scale_factor))):
+            upscaling_layers += [nn.Conv2d(hidden_size, hidden_size * 4, kernel_size(), stride=1, padding=padding, bias=False), nn.PixelShuffle(2)]
+            rf_factor /= 2
+        self.upscale = nn.Sequential(*upscaling_layers)
+        self.conv_output = nn.Conv2d(hidden_size, out_channels, kernel_size(), stride=1, padding=padding, bias=False)
+        self.geometry = (in_channels, out_channels, hidden_size, n_blocks, int(math.log2(scale_factor)))
+        self._packed_cache = None
+
+    def conv_weights(self):
+        ws = [self.conv_input.weight]
+        for blk in self.residual:
+            ws += [blk.conv1.weight, blk.conv2.weight]
+        ws.append(self.conv_mid.weight)
+        ws += [m.weight for m in self.upscale if isinstance(m, nn.Conv2d)]
+        ws.append(self.conv_output.weight)
+        return ws
+
+    def packed_weights(self):
+        ws = self.conv_weights()
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._packed_cache is None or self._packed_cache[0] != key:
+            nat = torch.cat([w.detach().reshape(-1).float() for w in ws])
+            capi.require_cuda(nat)
+            n = capi.lib().nvsr_edsr_packed_floats(*self.geometry)
+            assert nat.numel() == capi.lib().nvsr_edsr_natural_floats(*self.geometry) and n > 0
+            packed = torch.empty(n, dtype=torch.float32, device=nat.device)
+            capi.call("nvsr_pack_edsr", capi.ptr(nat), *self.geometry, capi.ptr(packed), capi.stream())
+            self._packed_cache = (key, packed)
+        return self._packed_cache[1]
+
+    def forward(self, x):
+        x = capi.f32c(x)
+        lead = x.shape[:-3]
+        assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
+        Cin, H, W = x.shape[-3:]
+        cin, cout, hid, nb, n_up = self.geometry
+        assert Cin == cin
+        Ho, Wo = C.c_int(), C.c_int()
+        capi.call("nvsr_edsr_out_size", H, W, nb, n_up, C.byref(Ho), C.byref(Wo))
+        out = torch.empty(list(lead) + [cout, Ho.value, Wo.value], dtype=torch.float32, device=x.device)
+        ws = torch.empty(capi.lib().nvsr_edsr_workspace_floats(hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
+        capi.call("nvsr_edsr_forward", capi.ptr(x), Cin, H, W, capi.ptr(self.packed_weights()), cout, hid, nb, n_up, capi.ptr(out),
+                  capi.ptr(ws), capi.stream())
+        return out
+
+
+class PlanesSR(nn.Module):
+    """models.py:824-926.  `forward(plane_name | (plane_name, roi))` -> super-resolved plane [1,C,sf*R,sf*R]; NaN outside the ROI."""
+
+    def __init__(self, model_arch, scale_factor, in_channels, out_channels, sr_config, plane_interp):
+        super().__init__()
+        import math
+        model_cfg = _cfg_get(sr_config, "model")
+        hidden_size, n_blocks = _cfg_get(model_cfg, "hidden_size"), _cfg_get(model_cfg, "n_blocks")
+        input_normalization = _cfg_get(sr_config, "input_normalization", False)
+        self.scale_factor = scale_factor
+        self.plane_interp = plane_interp
+        self.input_noise = _cfg_get(sr_config, "sr_input_noise", 0)
+        self.output_noise = _cfg_get(sr_config, "sr_output_noise", 0)
+        if plane_interp != "bilinear":
+            raise NotImplementedError("PlanesSR kernels implement the bilinear residual up-sampling of the shipped configs")
+        self.inner_model = model_arch(in_channels=in_channels, out_channels=out_channels, hidden_size=hidden_size, n_blocks=n_blocks,
+                                      scale_factor=scale_factor, padding=0,
+                                      receptive_field_bound=_cfg_get(model_cfg, "receptive_field_bound", np.iinfo(np.int32).max))
+        # models.py:840-842
+        self.HR_overpadding = int(self.inner_model.required_padding * self.scale_factor)
+        self.inner_model.required_padding = int(np.ceil(self.inner_model.required_padding))
+        self.HR_overpadding = self.inner_model.required_padding * self.scale_factor - self.HR_overpadding
+        for m in self.modules():       # models.py:843-848
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n) / 10)
+        self.clear_SR_planes(all_planes=True)
+        self.align_corners = True
+        self.SR_viewdir = False
+        if input_normalization:
+            self.normalization_params({"mean": float("nan") * torch.ones([in_channels]), "std": float("nan") * torch.ones([in_channels])})
+
+    def normalization_params(self, norm_dict):
+        self.planes_mean_NON_LEARNED = nn.Parameter(norm_dict["mean"].reshape([1, -1, 1, 1]))
+        self.planes_std_NON_LEARNED = nn.Parameter(norm_dict["std"].reshape([1, -1, 1, 1]))
+
+    def interpolate_LR(self, id):
+        return torch.nn.functional.interpolate(self.LR_planes[id], scale_factor=self.scale_factor, mode=self.plane_interp,
+                                               align_corners=self.align_corners)
+
+    def set_LR_plane(self, plane, id: str, save_interpolated: bool):
+        assert id not in self.LR_planes, "Plane ID already exists."
+        self.LR_planes[id] = plane
+        # `save_interpolated` cached the bilinear up-sampling on the CPU in the reference (models.py:874-875); the finish kernel
+        # recomputes it on the fly, so there is nothing to store.
+
+    def clear_SR_planes(self, all_planes=False):
+        planes_2_clear = ["SR_planes"]
+        if all_planes:
+            planes_2_clear += ["LR_planes", "residual_planes"]
+        for attr in planes_2_clear:
+            setattr(self, attr, {})
+
+    def forward(self, plane_name):
+        if isinstance(plane_name, tuple):
+            full_plane, plane_roi, plane_name = False, plane_name[1], plane_name[0]
+        else:
+            full_plane, plane_roi = True, None
+        if plane_name in self.SR_planes:
+            return self.SR_planes[plane_name]
+        if not self.align_corners:
+            raise NotImplementedError("align_corners=False is not used by the planes model")
+        if self.training and (self.input_noise > 0 or self.output_noise > 0):
+            raise NotImplementedError("sr_input_noise / sr_output_noise are 0 in every shipped config")
+        lr = capi.f32c(self.LR_planes[plane_name].detach())
+        Cc, R0, R1 = lr.shape[-3:]
+        cin, cout, hid, nb, n_up = self.inner_model.geometry
+        assert Cc == cin == cout
+        roi_c = None
+        if plane_roi is not None:
+            r = [float(v) for v in torch.as_tensor(plane_roi).detach().cpu().reshape(-1)]
+            roi_c = (C.c_float * 4)(*r)
+        mean = std = None
+        if hasattr(self, "planes_mean_NON_LEARNED"):
+            mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
+        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
+        nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+        if nws < 0:
+            raise capi.NvsrError("PlanesSR: region of interest too small for the network")
+        ws = torch.empty(nws, dtype=torch.float32, device=lr.device)
+        sf = self.scale_factor
+        out = torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lr.device)
+        capi.call("nvsr_planes_sr", capi.ptr(lr), Cc, R0, R1, capi.ptr(self.inner_model.packed_weights()), hid, nb, n_up, pad, over, roi_c,
+                  capi.ptr(mean), capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.stream())
+        if full_plane:
+            self.SR_planes[plane_name] = out      # kept on the GPU (the reference parks it on the CPU and re-uploads per call, :893,:925)
+        return out

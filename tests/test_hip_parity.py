@@ -358,3 +358,116 @@ def test_full_size_frame_properties_and_oracle_subset(hip, oracle):
     err = np.abs(N_(rf)[ids] - o["rgb_fine"]).max(-1)
     assert np.mean(err <= 2e-4) >= 0.98 and err.max() <= 5e-3, "fine rgb: %.4f of rays within 2e-4 (max %.2e)" % (np.mean(err <= 2e-4), err.max())
     assert psnr(N_(rf)[ids], o["rgb_fine"]) >= 75.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# feature-plane super-resolution
+def _sr_model(hip, g):
+    Cc, hid, nblocks, sf, R, pad, over = [int(v) for v in g["cfg"]]
+    sr = hip.models.PlanesSR(hip.models.EDSR, sf, Cc, Cc, {"model": {"hidden_size": hid, "n_blocks": nblocks}}, "bilinear")
+    sr.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    sr = sr.to(DEV)
+    assert sr.inner_model.required_padding == pad and sr.HR_overpadding == over
+    return sr, (Cc, hid, nblocks, sf, R, pad, over)
+
+
+def test_edsr_and_planes_sr_golden(hip):
+    g = load_golden("g09_edsr.npz")
+    sr, (Cc, hid, nblocks, sf, R, pad, over) = _sr_model(hip, g)
+    sr.eval()
+    # single residual block through the conv entry point with its fused epilogues
+    capi = hip.capi
+    blk_in = T(g["block_in"][0])
+    h, w = blk_in.shape[-2:]
+    w1, w2 = T(g["sd.inner_model.residual.0.conv1.weight"]), T(g["sd.inner_model.residual.0.conv2.weight"])
+    pk = [torch.empty(capi.lib().nvsr_conv3x3_packed_floats(hid, hid), device=DEV) for _ in range(2)]
+    for wt, p in zip((w1, w2), pk):
+        capi.call("nvsr_pack_conv3x3", capi.ptr(wt), hid, hid, capi.ptr(p), capi.stream())
+    t1 = torch.empty((hid, h - 2, w - 2), device=DEV)
+    t2 = torch.empty((hid, h - 4, w - 4), device=DEV)
+    capi.call("nvsr_conv3x3", capi.ptr(blk_in), hid, h, w, capi.ptr(pk[0]), hid, 1, None, capi.ptr(t1), capi.stream())
+    capi.call("nvsr_conv3x3", capi.ptr(t1), hid, h - 2, w - 2, capi.ptr(pk[1]), hid, 2, capi.ptr(blk_in), capi.ptr(t2), capi.stream())
+    np.testing.assert_allclose(N_(t2), g["block_out"][0], rtol=0, atol=3e-6)
+    # whole network, then PlanesSR full plane and ROI
+    out = sr.inner_model(T(g["edsr_in"]))
+    assert tuple(out.shape) == g["edsr_out"].shape
+    np.testing.assert_allclose(N_(out), g["edsr_out"], rtol=0, atol=1e-5)
+    sr.set_LR_plane(T(g["lr"]), id="p", save_interpolated=False)
+    full = sr("p")
+    assert tuple(full.shape) == (1, Cc, R * sf, R * sf)
+    np.testing.assert_allclose(N_(full), g["sr_full"], rtol=0, atol=1e-5)
+    assert sr("p") is full                      # cached like the reference's SR_planes
+    sr.clear_SR_planes()
+    sr.train()
+    roi = N_(sr(("p", T(g["roi"]))))
+    ref = g["sr_roi"]
+    assert np.array_equal(np.isnan(roi), np.isnan(ref)) and np.isnan(ref).any()
+    m = ~np.isnan(ref)
+    np.testing.assert_allclose(roi[m], ref[m], rtol=0, atol=1e-5)
+
+
+def test_conv3x3_shapes_vs_oracle(hip, oracle):
+    """channel counts that exercise both workgroup shapes and the padding of Cin/Cout (48->256, 256->256, 256->48, 16->64 shuffle)"""
+    rng = np.random.default_rng(3)
+    capi = hip.capi
+    for Cin, Cout, H, W, epi in [(48, 256, 21, 45, 0), (256, 256, 14, 40, 1), (256, 48, 37, 35, 0), (16, 64, 9, 70, 3), (5, 7, 3, 3, 0)]:
+        x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+        w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+        xd, wd = T(x), T(w)
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cin, Cout), device=DEV)
+        capi.call("nvsr_pack_conv3x3", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+        ref = oracle.conv3x3(x, w, relu=(epi == 1))
+        if epi == 3:
+            out = torch.empty((Cout // 4, 2 * (H - 2), 2 * (W - 2)), device=DEV)
+            ref = ref.reshape(Cout // 4, 2, 2, H - 2, W - 2).transpose(0, 3, 1, 4, 2).reshape(Cout // 4, 2 * (H - 2), 2 * (W - 2))
+        else:
+            out = torch.empty((Cout, H - 2, W - 2), device=DEV)
+        capi.call("nvsr_conv3x3", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, None, capi.ptr(out), capi.stream())
+        # unit-variance data: fp32 accumulation over K = 9*Cin terms, |out| up to ~4  ->  ~sqrt(K)*2^-24*|out|
+        np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi)))
+
+
+def test_render_through_super_resolved_planes(hip, oracle):
+    """BASELINE config 3 in miniature: the fine model samples planes produced by PlanesSR(EDSR) (x4), the coarse model the LR
+    planes (models.py:270-284, 289-310); oracle = its own planes_sr + render."""
+    g = load_golden("g08_render.npz")
+    rng = np.random.default_rng(11)
+    R, Rv, hid, nb = 24, 8, 16, 2
+    planes = [rng.standard_normal((1, 48, R, R), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, Rv, Rv), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes24_8"
+    mc, _ = build_model(hip, sd(g, "coarse."), planes, g["box"], sid=sid)
+    mf, _ = build_model(hip, sd(g, "fine."), planes, g["box"], sid=sid)
+    mf.planes_ = mc.planes_
+    torch.manual_seed(5)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr.eval()
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    assert sorted(sr.LR_planes) == sorted(hip.models.get_plane_name(sid, d) for d in range(3))   # the view plane is never SR'd
+    H = W = 12
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    opts, scfg = make_options(32, 32)
+    _, _, _, img_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    # oracle
+    from oracle.oracle import Oracle
+    blob, _ = Oracle.edsr_blob({k: N_(v) for k, v in sr.state_dict().items()}, n_up=2)
+    pad, over = sr.inner_model.required_padding, sr.HR_overpadding
+    hr = [oracle.planes_sr(planes[d][0], blob, hid, nb, 2, pad, over)[None] for d in range(3)] + [planes[3]]
+    for d in range(3):
+        np.testing.assert_allclose(N_(sr(hip.models.get_plane_name(sid, d))), hr[d], rtol=0, atol=2e-5)
+    rays = oracle.pack_rays(N_(ro), N_(rd), 2.0, 6.0)
+    o_c = oracle.render_rays(oracle.scene(planes, g["box"]), oracle.decoder(decoder_blob(sd(g, "coarse."))),
+                             oracle.decoder(decoder_blob(sd(g, "fine."))), rays, 32, 32, want_aux=True)
+    fo = oracle.render_given_z(oracle.scene(hr, g["box"]), oracle.decoder(decoder_blob(sd(g, "fine."))), rays, o_c["z_fine"])
+    err = np.abs(N_(img_f).reshape(-1, 3) - fo["rgb"]).max(-1)
+    assert np.mean(err <= 2e-4) >= 0.97 and psnr(N_(img_f).reshape(-1, 3), fo["rgb"]) >= 70.0, (np.mean(err <= 2e-4), err.max())
+    # skip_SR(True) falls back to the LR planes (train_nerf.py:701-705)
+    mf.skip_SR(True)
+    _, _, _, img_lr, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    np.testing.assert_allclose(N_(img_lr).reshape(-1, 3), o_c["rgb_fine"], rtol=0, atol=1e-3)
+    assert not torch.equal(img_lr, img_f)
