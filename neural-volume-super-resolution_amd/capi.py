@@ -9,7 +9,10 @@ import os
 
 import torch
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# developer hook for kernel experiments (scratch/): load an alternative build of the same ABI
+LIB_PATH = os.environ.get("NVSR_HIP_LIB", _DEFAULT_LIB_PATH)
 
 PLANE_CHANNELS = 48
 DEC_CHANNELS = 128

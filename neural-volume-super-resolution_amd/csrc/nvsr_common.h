@@ -57,6 +57,9 @@ struct SceneDev {
     int ph[4], pw[4];
     float lo[5], range[5];
     float proj[18];
+    // (W-1), (H-1) and their halves as floats: kernel arguments live in SGPRs; computed in the kernel they become
+    // loop-invariant VGPRs that hipcc hoists out of the sample loop and spills
+    float mx[4], my[4], hx[4], hy[4];
 };
 
 inline SceneDev to_dev(const nvsr_scene* s) {
@@ -64,6 +67,10 @@ inline SceneDev to_dev(const nvsr_scene* s) {
     for (int i = 0; i < 4; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
     for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
     for (int i = 0; i < 18; ++i) d.proj[i] = (&s->proj[0][0])[i];
+    for (int i = 0; i < 4; ++i) {
+        d.mx[i] = (float)(s->pw[i] - 1); d.my[i] = (float)(s->ph[i] - 1);
+        d.hx[i] = d.mx[i] / 2.0f; d.hy[i] = d.my[i] / 2.0f;
+    }
     return d;
 }
 

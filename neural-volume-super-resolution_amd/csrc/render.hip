@@ -19,10 +19,14 @@
 
 namespace nvsr {
 
-constexpr int TPB = 512;
+// Workgroup = 4 waves (one per SIMD); TWO workgroups share a CU (2 x 70 KB LDS), so each SIMD hosts one wave of each.  The
+// two workgroups have independent ring barriers and drift apart: while one sits in a gather / barrier / epilogue, the other
+// keeps the SIMD's matrix pipe busy.  (One 8-wave workgroup per CU phase-locks both waves of a SIMD: measured 78 % MFMA
+// busy vs the figure in DESIGN.md for this form.)
+constexpr int TPB = 256;
 constexpr int NWAVES = TPB / 64;
 constexpr int PTS_PER_WG = NWAVES * 32;
-constexpr int SLOT_FLOATS = 16384;                    // 64 KB ring slot
+constexpr int SLOT_FLOATS = 8192;                     // 32 KB ring slot: one plane of a feature layer, or half a hidden layer
 constexpr int LDS_FLOATS = 2 * SLOT_FLOATS + SMALL_FLOATS;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -45,8 +49,10 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ gsrc, floa
 // Wait for this wave's DMA, then meet the other waves: afterwards the chunk issued one phase ago is readable by everyone
 // and the slot read one phase ago is free.
 __device__ __forceinline__ void ring_sync() {
+#if !(NVSR_ABLATE & 4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
 }
 
 // ---- bilinear taps (grid_sample, align_corners=True, padding_mode='border') ------------------------------------------
@@ -55,10 +61,11 @@ struct Taps {
     float nw, ne, sw, se;
 };
 
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
-    const float mx = (float)(W - 1), my = (float)(H - 1);
-    float x = (gx + 1.0f) * (mx / 2.0f);
-    float y = (gy + 1.0f) * (my / 2.0f);
+__device__ __forceinline__ Taps make_taps(const SceneDev& sc, int d, float gx, float gy) {
+    const int H = sc.ph[d], W = sc.pw[d];
+    const float mx = sc.mx[d], my = sc.my[d];
+    float x = (gx + 1.0f) * sc.hx[d];
+    float y = (gy + 1.0f) * sc.hy[d];
     x = fminf(mx, fmaxf(x, 0.0f));
     y = fminf(my, fmaxf(y, 0.0f));
     const float xw = floorf(x), yn = floorf(y);
@@ -72,18 +79,36 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
     return t;
 }
 
-// 24 channels (half h of the texel) of the bilinear blend -> f[0..23]
+// 24 channels (half h of the texel) of the bilinear blend -> f[0..23].  Two taps are in flight at a time (48 registers).
 __device__ __forceinline__ void gather24(const float* __restrict__ plane, const Taps& t, int h, float (&f)[HALF_C]) {
+#if NVSR_ABLATE & 1
+#pragma unroll
+    for (int i = 0; i < HALF_C; ++i) f[i] = t.nw * (float)(i + h);
+    return;
+#endif
     const f32x4* p00 = reinterpret_cast<const f32x4*>(plane + t.o00 + HALF_C * h);
     const f32x4* p01 = reinterpret_cast<const f32x4*>(plane + t.o01 + HALF_C * h);
     const f32x4* p10 = reinterpret_cast<const f32x4*>(plane + t.o10 + HALF_C * h);
     const f32x4* p11 = reinterpret_cast<const f32x4*>(plane + t.o11 + HALF_C * h);
 #pragma unroll
     for (int i = 0; i < HALF_C / 4; ++i) {
-        const f32x4 a = p00[i], b = p01[i], c = p10[i], d = p11[i];
+        const f32x4 a = p00[i], b = p01[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(d[j], t.se, fmaf(c[j], t.sw, fmaf(b[j], t.ne, a[j] * t.nw)));
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(b[j], t.ne, a[j] * t.nw);
     }
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i) {
+        const f32x4 c = p10[i], d = p11[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(d[j], t.se, fmaf(c[j], t.sw, f[4 * i + j]));
+    }
+}
+
+// x / 3 correctly rounded in 3 instructions (Markstein: q = RN(x*c), r = x - 3q exactly by FMA, q + r*c)
+__device__ __forceinline__ float div3(float x) {
+    const float c = 0x1.555556p-2f;
+    const float q = x * c;
+    return fmaf(fmaf(-3.0f, q, x), c, q);
 }
 
 __device__ __forceinline__ float norm_coord(float v, float lo, float range) {
@@ -92,6 +117,13 @@ __device__ __forceinline__ float norm_coord(float v, float lo, float range) {
 
 // ---- MFMA layers ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_bias(const float* bias /*LDS, packed [ib][q][h][j]*/, int h, f32x16 (&acc)[4]) {
+#if NVSR_ABLATE & 2
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
+    return;
+#endif
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -103,42 +135,55 @@ __device__ __forceinline__ void load_bias(const float* bias /*LDS, packed [ib][q
 }
 
 __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
+#if NVSR_ABLATE & 2
+    return;
+#endif
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
 }
 
-// one plane's 48 channels of a feature layer: acc += W[:, 48p .. 48p+47] * f
-__device__ __forceinline__ void feat_layer(const float* wl /*LDS: [q][ib][lane][j]*/, const float (&f)[HALF_C], int lane,
-                                           f32x16 (&acc)[4]) {
+// MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
+// wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
+// ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every
+// outstanding read, so the next fragment gets 3 MFMAs (192 cycles) to land; left alone hipcc sinks the read to its use.
+// (Measured: a v_mfma_f32_32x32x2_f32 stream fed this way sustains 64.2 cycles per MFMA, scratch/mfma_ubench.hip.)
+template <int NG, class BFn>
+__device__ __forceinline__ void mfma_groups(const float* wl, int lane, f32x16 (&acc)[4], BFn b) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wl) + lane;
+    f32x4 a = wv[0];
 #pragma unroll
-    for (int q = 0; q < HALF_C / 4; ++q)
+    for (int g = 0; g < NG; ++g) {
+        const int ib = g & 3;
+        acc[ib] = mfma32(a[0], b(g, 0), acc[ib]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 an = wv[(g + 1 < NG ? g + 1 : g) * 64];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (q * 4 + ib) * 256 + lane * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ib] = mfma32(a[j], f[4 * q + j], acc[ib]);
-        }
+        for (int j = 1; j < 4; ++j) acc[ib] = mfma32(a[j], b(g, j), acc[ib]);
+        a = an;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-// hidden layer 128 -> 128: acc += W * in   (in = previous accumulators, already ReLU'd)
-__device__ __forceinline__ void hidden_layer(const float* wl /*LDS: [kb][q][ib][lane][j]*/, const f32x16 (&in)[4], int lane,
-                                             f32x16 (&acc)[4]) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wl + ((kb * 4 + q) * 4 + ib) * 256 + lane * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ib] = mfma32(a[j], in[kb][4 * q + j], acc[ib]);
-            }
+// one plane's 48 channels of a feature layer: acc += W[:, 48p .. 48p+47] * f      (chunk layout [q 6][ib][lane][j])
+__device__ __forceinline__ void feat_layer(const float* wl, const float (&f)[HALF_C], int lane, f32x16 (&acc)[4]) {
+    mfma_groups<(HALF_C / 4) * 4>(wl, lane, acc, [&](int g, int j) { return f[4 * (g >> 2) + j]; });
+}
+
+// half of a hidden layer 128 -> 128: acc += W[:, 64*HALF .. 64*HALF+63] * in[2*HALF .. 2*HALF+1]   (in = previous accumulators,
+// already ReLU'd).  wl = the 32 KB chunk [kb 2][q 4][ib][lane][j].
+template <int HALF>
+__device__ __forceinline__ void hidden_half(const float* wl, const f32x16 (&in)[4], int lane, f32x16 (&acc)[4]) {
+    mfma_groups<32>(wl, lane, acc, [&](int g, int j) { return in[2 * HALF + (g >> 4)][4 * ((g >> 2) & 3) + j]; });
 }
 
 // 128 -> 1 head on the VALU: each lane owns 64 of the 128 features of its point, the partner lane (l ^ 32) the rest
 __device__ __forceinline__ float head_dot(const float* w /*LDS packed [ib][q][h][j]*/, int h, const f32x16 (&in)[4]) {
+#if NVSR_ABLATE & 8
+    return in[0][0] + in[1][1] + in[2][2] + in[3][3];
+#endif
     float s = 0.0f;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -169,10 +214,10 @@ __device__ __forceinline__ const float* ring_issue(RingState& rs, int packed_off
 
 // Decode the wave's 32 points (px,py,pz given per lane, both lane halves hold the same point) -> raw rgb + sigma.
 // vt: bilinear taps on the view-direction plane.  Must be called by all waves of the workgroup together (ring barriers).
-// On entry the chunk RGB0a (position planes 0,1 of rgb layer 0) has been issued into `cur`; on exit the same holds for the
-// next call.  Chunk order: RGB0a, RGB0b, RGB1, RGB2, RGB3, DEN0, DEN1, DEN2, DEN3.
-__device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, const float*& cur, float px, float py, float pz,
-                                            const Taps& vt, float (&raw)[4]) {
+// No DMA is outstanding on entry or on exit.
+// Chunk order: RGB0.p0..p3, RGB1..3 (two halves each), DEN0, DEN1..3 (two halves each).
+__device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, float px, float py, float pz, const Taps& vt,
+                                            float (&raw)[4]) {
     // Re-derive the per-lane address registers every step: left loop-invariant, hipcc hoists one 64-bit address per
     // DMA / LDS read out of the sample loop and spills them all.
     asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
@@ -184,109 +229,161 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, c
 
     // Order chosen for register pressure (256 VGPRs at 2 waves/SIMD): the rgb decoder runs first and consumes the plane
     // features as they are gathered (only 24 + 24 feature registers live), the density decoder then runs from the 24
-    // registers of the averaged position features.
+    // registers of the averaged position features.  17 ring chunks per step (<= 32 KB each).
     f32x16 accA[4], accB[4];
     float D[HALF_C], F[HALF_C];
+    constexpr int HH = P_HID_FLOATS / 2;   // half hidden layer
 
-    // ---- rgb layer 0: K = 192 = [f0 | f1 | f2 | f_view], one plane at a time ------------------------------------------
+    // ---- rgb layer 0: K = 192 = [f0 | f1 | f2 | f_view], one plane (= one chunk) at a time ----------------------------
+    // The step's first chunk is issued here, next to the first gather (their latencies overlap), NOT at the end of the previous
+    // step: vector-memory waits are in order, so anything the caller loads between two steps would otherwise wait for the DMA.
+    const float* cur = ring_issue<24>(rs, P_RGB0);
     {
         const float* M = sc.proj;
-        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[0], sc.pw[0]);
+        const Taps t = make_taps(sc, 0, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[0], t, h, F);
     }
     ring_sync();
-    const float* nxt = ring_issue<48>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
+    const float* nxt = ring_issue<24>(rs, P_RGB0 + P_PLANE_FLOATS);
     load_bias(small + S_BIAS + 4 * HID, h, accA);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
     feat_layer(cur, F, lane, accA);
-    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<24>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
     {
         const float* M = sc.proj + 6;
-        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[1], sc.pw[1]);
+        const Taps t = make_taps(sc, 1, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[1], t, h, F);
     }
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
-    feat_layer(cur + P_PLANE_FLOATS, F, lane, accA);
-    __builtin_amdgcn_sched_barrier(0);
+    feat_layer(cur, F, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<24>(rs, P_RGB0 + 3 * P_PLANE_FLOATS);
     {
         const float* M = sc.proj + 12;
-        const Taps t = make_taps(n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.ph[2], sc.pw[2]);
+        const Taps t = make_taps(sc, 2, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[2], t, h, F);
     }
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
 #pragma unroll
-    for (int c = 0; c < HALF_C; ++c) D[c] = __fdiv_rn(__fadd_rn(D[c], F[c]), 3.0f);
+    for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+    feat_layer(cur, F, lane, accA);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<64>(rs, P_RGB1);
-    feat_layer(cur, F, lane, accA);
-    __builtin_amdgcn_sched_barrier(0);
+    nxt = ring_issue<32>(rs, P_RGB1);
     gather24(sc.plane[3], vt, h, F);
-    feat_layer(cur + P_PLANE_FLOATS, F, lane, accA);
+    feat_layer(cur, F, lane, accA);
     relu_inplace(accA);
     cur = nxt;
     // ---- rgb decoder layers 1..3 -> 3 ---------------------------------------------------------------------------------
     ring_sync();
-    nxt = ring_issue<64>(rs, P_RGB1 + P_HID_FLOATS);
+    nxt = ring_issue<32>(rs, P_RGB1 + HH);
     load_bias(small + S_BIAS + 5 * HID, h, accB);
-    hidden_layer(cur, accA, lane, accB);
+#if NVSR_ABLATE & 64
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    hidden_half<0>(cur, accA, lane, accB);
+#if NVSR_ABLATE & 64
+    __builtin_amdgcn_sched_barrier(0);
+    raw[0] = (float)(__builtin_amdgcn_s_memtime() - st0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<32>(rs, P_RGB1 + 2 * HH);
+    hidden_half<1>(cur, accA, lane, accB);
     relu_inplace(accB);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<64>(rs, P_RGB1 + 2 * P_HID_FLOATS);
+    nxt = ring_issue<32>(rs, P_RGB1 + 3 * HH);
     load_bias(small + S_BIAS + 6 * HID, h, accA);
-    hidden_layer(cur, accB, lane, accA);
+    hidden_half<0>(cur, accB, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<32>(rs, P_RGB1 + 4 * HH);
+    hidden_half<1>(cur, accB, lane, accA);
     relu_inplace(accA);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<24>(rs, P_DEN0);
+    nxt = ring_issue<32>(rs, P_RGB1 + 5 * HH);
     load_bias(small + S_BIAS + 7 * HID, h, accB);
-    hidden_layer(cur, accA, lane, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<24>(rs, P_DEN0);
+    hidden_half<1>(cur, accA, lane, accB);
     relu_inplace(accB);
+#if NVSR_ABLATE & 64
+    const float stamp = raw[0];
+#endif
 #pragma unroll
     for (int c = 0; c < 3; ++c) raw[c] = head_dot(small + S_RGB_W + c * HID, h, accB) + small[S_HEAD_B + 1 + c];
+#if NVSR_ABLATE & 64
+    raw[1] = stamp;
+#endif
     cur = nxt;
     // ---- density decoder: 48 -> 128 x4 -> 1 --------------------------------------------------------------------------
     ring_sync();
-    nxt = ring_issue<64>(rs, P_DEN1);
+    nxt = ring_issue<32>(rs, P_DEN1);
     load_bias(small + S_BIAS + 0 * HID, h, accA);
     feat_layer(cur, D, lane, accA);
     relu_inplace(accA);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<64>(rs, P_DEN1 + P_HID_FLOATS);
+    nxt = ring_issue<32>(rs, P_DEN1 + HH);
     load_bias(small + S_BIAS + 1 * HID, h, accB);
-    hidden_layer(cur, accA, lane, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<32>(rs, P_DEN1 + 2 * HH);
+    hidden_half<1>(cur, accA, lane, accB);
     relu_inplace(accB);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<64>(rs, P_DEN1 + 2 * P_HID_FLOATS);
+    nxt = ring_issue<32>(rs, P_DEN1 + 3 * HH);
     load_bias(small + S_BIAS + 2 * HID, h, accA);
-    hidden_layer(cur, accB, lane, accA);
+    hidden_half<0>(cur, accB, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<32>(rs, P_DEN1 + 4 * HH);
+    hidden_half<1>(cur, accB, lane, accA);
     relu_inplace(accA);
     cur = nxt;
     ring_sync();
-    nxt = ring_issue<48>(rs, P_RGB0);                 // first chunk of the next step
+    nxt = ring_issue<32>(rs, P_DEN1 + 5 * HH);
     load_bias(small + S_BIAS + 3 * HID, h, accB);
-    hidden_layer(cur, accA, lane, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    hidden_half<1>(cur, accA, lane, accB);
     relu_inplace(accB);
     raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
-    cur = nxt;
 }
 
-// workgroup prologue: heads/biases -> LDS (plain copy), first ring chunk in flight
-__device__ __forceinline__ const float* decode_prologue(RingState& rs) {
+// workgroup prologue: heads/biases -> LDS (plain copy; the first ring barrier publishes them), then the STAGGER: the two
+// workgroups of a CU start together and run the same program at the same rate, so left alone they stay phase-locked and
+// their gathers, barriers and VALU epilogues coincide (measured: those costs add up instead of hiding behind the partner's
+// MFMAs).  The workgroup whose wave 0 sits in an odd wave slot of its SIMD (HW_ID.wave_id) starts half a chunk-phase late.
+__device__ __forceinline__ void decode_prologue(RingState& rs) {
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB) rs.lds[2 * SLOT_FLOATS + i] = rs.packed[P_SMALL + i];
-    return ring_issue<48>(rs, P_RGB0);
+#if !(NVSR_ABLATE & 32)
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(127);   // ~8k cycles = half of a shared 128-MFMA phase
+#endif
 }
 
 __device__ __forceinline__ Taps view_taps(const SceneDev& sc, float vx, float vy, float vz) {
     // cart2az_el (nerf_helpers.py:492-496) + normalize_coords
     const float az = atan2f(vy, vx);
     const float el = atan2f(vz, sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy))));
-    return make_taps(norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.ph[3], sc.pw[3]);
+    return make_taps(sc, 3, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]));
 }
 
 // =====================================================================================================================
@@ -296,7 +393,7 @@ __global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, co
                                                                  const float* __restrict__ x, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
-    const float* cur = decode_prologue(rs);
+    decode_prologue(rs);
     const long ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
         long p = tile * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
@@ -305,61 +402,89 @@ __global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, co
         const float* xp = x + p * 6;
         const Taps vt = view_taps(sc, xp[3], xp[4], xp[5]);
         float raw[4];
-        decode_step(sc, rs, cur, xp[0], xp[1], xp[2], vt, raw);
+        decode_step(sc, rs, xp[0], xp[1], xp[2], vt, raw);
         if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(out + p * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
-    ring_sync();   // drain the chunk prefetched for a step that will not run
 }
 
 // =====================================================================================================================
 // Fused render pass: rays [N,11], depths z [N,S] -> per-ray rgb / disp / acc (/ weights / depth)
 // =====================================================================================================================
+// Per-ray constants live in LDS (16 floats per ray, 8 KB per workgroup) and are re-read every step: kept in VGPRs they push
+// the 2016-MFMA step body over 256 registers, and a spill reload is a vector-memory load whose wait also waits for the
+// (older, in-order) LDS-DMA of the next weight chunk -- ~2 us per reload point.
+constexpr int RAY_FLOATS = 16;
+constexpr int RENDER_LDS_FLOATS = LDS_FLOATS + PTS_PER_WG * RAY_FLOATS;
+static_assert(RENDER_LDS_FLOATS * 4 <= 80 * 1024, "two workgroups must fit one CU's 160 KB of LDS");
+
 __global__ __launch_bounds__(TPB, 2) void render_pass_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                              const float* __restrict__ rays, const float* __restrict__ z,
                                                              const float* __restrict__ noise, int white,
                                                              float* __restrict__ rgb, float* __restrict__ disp,
                                                              float* __restrict__ acc, float* __restrict__ weights,
                                                              float* __restrict__ depth) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[RENDER_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
-    const float* cur = decode_prologue(rs);
+    decode_prologue(rs);
 
-    long ray = (long)blockIdx.x * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
-    const bool valid = ray < N;
-    if (!valid) ray = N - 1;
-    const float* r = rays + ray * 11;
-    const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
-    const Taps vt = view_taps(sc, r[8], r[9], r[10]);
-    // dists * ||rd||  (volume_rendering_utils.py:27)
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const long ray0 = (long)blockIdx.x * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
+    const bool valid = ray0 < N;
+    const long ray = valid ? ray0 : N - 1;
+    float* rc = lds + LDS_FLOATS + (rs.wave * 32 + (rs.lane & 31)) * RAY_FLOATS;
+    {
+        const float* r = rays + ray * 11;
+        const float dx = r[3], dy = r[4], dz = r[5];
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        // dists * ||rd||  (volume_rendering_utils.py:27)
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        if (rs.lane < 32) {
+            reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], dx};
+            reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, 0.0f};
+            reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
+            reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
+        }
+    }
     const float* zr = z + ray * S;
-    const float* nz = noise ? noise + ray * S : nullptr;
-    float* wr = weights ? weights + ray * S : nullptr;
-
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, dep = 0.0f, ac = 0.0f;
     float zc = zr[0];
+#if NVSR_ABLATE & 16
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < S; ++s) {
+        // next depth / this sample's noise: issued before this step's DMAs so that their waits do not include them
         const float zn = (s + 1 < S) ? zr[s + 1] : 0.0f;
+        const float nzs = noise ? noise[ray * S + s] : 0.0f;
+        const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
+        const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
+        Taps vt;
+        vt.o00 = __float_as_int(c2[0]); vt.o01 = __float_as_int(c2[1]); vt.o10 = __float_as_int(c2[2]); vt.o11 = __float_as_int(c2[3]);
+        vt.nw = c3[0]; vt.ne = c3[1]; vt.sw = c3[2]; vt.se = c3[3];
         float raw[4];
-        decode_step(sc, rs, cur, __fadd_rn(ox, __fmul_rn(dx, zc)), __fadd_rn(oy, __fmul_rn(dy, zc)),
-                    __fadd_rn(oz, __fmul_rn(dz, zc)), vt, raw);
+        decode_step(sc, rs, __fadd_rn(c0[0], __fmul_rn(c0[3], zc)), __fadd_rn(c0[1], __fmul_rn(c1[0], zc)),
+                    __fadd_rn(c0[2], __fmul_rn(c1[1], zc)), vt, raw);
         // volume_render_radiance_field, one sample (volume_rendering_utils.py:18-45)
+        const float nrm = reinterpret_cast<const f32x4*>(rc)[1][2];
         const float dist = __fmul_rn((s + 1 < S) ? __fsub_rn(zn, zc) : 1e10f, nrm);
-        float sig = raw[3];
-        if (nz) sig = __fadd_rn(sig, nz[s]);
-        sig = fmaxf(sig, 0.0f);
+        const float sig = fmaxf(__fadd_rn(raw[3], nzs), 0.0f);
         const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sig, dist)));
         const float w = __fmul_rn(alpha, T);
         T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f));
         cr = __fadd_rn(cr, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[0]))));
+#if NVSR_ABLATE & 64
+        cg = raw[1];   // debug: cycles of one hidden half (128 MFMAs)
+#else
         cg = __fadd_rn(cg, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[1]))));
+#endif
         cb = __fadd_rn(cb, __fmul_rn(w, 1.0f / (1.0f + expf(-raw[2]))));
         dep = __fadd_rn(dep, __fmul_rn(w, zc));
         ac = __fadd_rn(ac, w);
-        if (wr && valid && rs.lane < 32) wr[s] = w;
+        if (weights && valid && rs.lane < 32) weights[ray * S + s] = w;
         zc = zn;
     }
     ring_sync();
+#if NVSR_ABLATE & 16
+    if (threadIdx.x == 0) acc[N + blockIdx.x] = (NVSR_ABLATE & 64) ? cg : (float)(__builtin_amdgcn_s_memtime() - t_begin) / (float)S;   // debug build
+#endif
     if (valid && rs.lane < 32) {
         const float q = dep / ac;                       // NaN when acc == 0, like torch.max(1e-10, nan)
         disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
@@ -448,7 +573,7 @@ int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, i
     if (P < 0) return NVSR_ERR_SHAPE;
     if (P == 0) return NVSR_OK;
     const int64_t ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
-    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(triplane_decode_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
                        (long)P, x, out);
     return NVSR_CHECK_LAUNCH();
