@@ -141,6 +141,14 @@ int64_t nvsr_planes_sr_workspace_floats(int C, int R0, int R1, int hid, int nblo
 int nvsr_planes_sr(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* std_, float* out, float* workspace, nvsr_stream_t stream);
 
+/* ---- positional-encoding baseline (MipNeRF_baseline.yml; not on the tri-plane path) ------------------------------------ */
+/* positional_encoding (nerf_helpers.py:552-575): x [P,D] -> [P, (include_input ? D : 0) + 2*D*L] = [x, sin(2^0 x), cos(2^0 x), ...] */
+int nvsr_positional_encoding(int64_t P, int D, const float* x, int L, int include_input, float* out, nvsr_stream_t stream);
+/* FlexibleNeRFModel.forward (models.py:83-108), use_viewdirs=True, num_layers_dir=1: x [P, dim_xyz+dim_dir] -> [P,4].
+ * blob = state-dict order: layer1, layers_xyz.{i}, layers_dir.0, fc_alpha, fc_rgb, fc_feat, each {weight[out,in], bias}. */
+int nvsr_flexible_nerf_forward(int64_t P, const float* x, int dim_xyz, int dim_dir, int hidden, int num_layers, int skip_every,
+                               const float* blob, float* out, nvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,9 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_edsr_forward": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "nvsr_planes_sr_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp], _i),
+    # positional-encoding baseline (csrc/posenc.hip)
+    "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
+    "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
 }
 
 _lib = None

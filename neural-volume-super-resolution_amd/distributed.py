@@ -1,0 +1,95 @@
+"""Multi-GPU layer of the path: one process per GPU, rays sharded, scene replicated.
+
+The reference is single-process.  Rays are independent units, so inference shards contiguous blocks of rays (image rows) over
+the ranks with NO data-path collective; the only exchange is an optional all_gather of the finished pixels (7.7 MB for an
+800x800 frame).  Training adds one all-reduce (RCCL over xGMI; backend "nccl" on ROCm) of the plane / decoder gradients, bucketed
+so that a ring step moves a few MB per link."""
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """[lo, hi) of rank's contiguous block when n units are split as evenly as possible (first n % world ranks get one more)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rays(batch_rays, rank=None, world=None, group=None):
+    """batch_rays [2,N,3] (run_one_iter_of_nerf's input) -> this rank's [2,n_local,3] block and its (lo, hi)."""
+    if rank is None:
+        rank, world = world_info(group)
+    lo, hi = shard_bounds(batch_rays.shape[1], rank, world)
+    return batch_rays[:, lo:hi], (lo, hi)
+
+
+def gather_rows(local, n_total, group=None):
+    """all_gather of per-rank row blocks of unequal length -> [n_total, ...] on every rank"""
+    rank, world = world_info(group)
+    if world == 1:
+        return local
+    n_max = -(-n_total // world)
+    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out.append(parts[r][: hi - lo])
+    return torch.cat(out, 0)
+
+
+def render_image_sharded(height, width, focal, model_coarse, model_fine, ray_origins, ray_directions, options, scene_id, scene_config,
+                         group=None, gather=True, render_fn=None):
+    """eval_nerf with the rays of one view sharded over the ranks (contiguous row blocks).  Returns (rgb_coarse, rgb_fine) as
+    [H,W,3] on every rank when gather=True, else this rank's [n_local,3] blocks and its (lo, hi)."""
+    if render_fn is None:
+        from .train_utils import run_one_iter_of_nerf as render_fn
+    rank, world = world_info(group)
+    batch = torch.stack([ray_origins.reshape(-1, 3), ray_directions.reshape(-1, 3)], 0)
+    local, (lo, hi) = shard_rays(batch, rank, world)
+    out = render_fn(height, width, focal, model_coarse, model_fine, local, options, scene_id, mode="validation", scene_config=scene_config)
+    rgb_c, rgb_f = out[0], out[3]
+    if not gather:
+        return rgb_c, rgb_f, (lo, hi)
+    n = height * width
+    rgb_c = gather_rows(rgb_c, n, group).reshape(height, width, 3)
+    rgb_f = None if rgb_f is None else gather_rows(rgb_f, n, group).reshape(height, width, 3)
+    return rgb_c, rgb_f
+
+
+def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):
+    """Sum (or average) a list of gradient tensors over the ranks in flat buckets of ~bucket_bytes.  The loss is a mean over rays
+    (train_nerf.py:884-891), so with rays sharded evenly the data-parallel gradient is the average of the per-rank gradients."""
+    rank, world = world_info(group)
+    if world == 1:
+        return
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off: off + t.numel()].view_as(t))
+            off += t.numel()
+        bucket, size = [], 0
+
+    for t in tensors:
+        bucket.append(t)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()

@@ -474,3 +474,50 @@ class PlanesSR(nn.Module):
         if full_plane:
             self.SR_planes[plane_name] = out      # kept on the GPU (the reference parks it on the CPU and re-uploads per call, :893,:925)
         return out
+
+
+# =======================================================================================================================
+# Positional-encoding baseline (models.py:14-108) -- interface completeness, not the tri-plane hot path
+# =======================================================================================================================
+class FlexibleNeRFModel(nn.Module):
+    """models.py:14-108 with use_viewdirs=True, num_layers_dir=1, scalar hidden_size (what train_nerf.py:342-348 builds)."""
+
+    def __init__(self, num_layers=4, num_layers_dir=1, dirs_hidden_width_ratio=2, hidden_size=128, skip_connect_every=4,
+                 num_encoding_fn_xyz=6, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=True, use_viewdirs=True,
+                 input_dim=None, xyz_input_2_dir=False):
+        super().__init__()
+        if isinstance(hidden_size, list) or not use_viewdirs or num_layers_dir != 1 or dirs_hidden_width_ratio != 2 or xyz_input_2_dir \
+                or input_dim is not None:
+            raise NotImplementedError("only the default FlexibleNeRFModel head layout is implemented natively")
+        self.skip_connect_every = skip_connect_every
+        self.dim_xyz = (3 if include_input_xyz else 0) + 2 * 3 * num_encoding_fn_xyz
+        self.dim_dir = (3 if include_input_dir else 0) + 2 * 3 * num_encoding_fn_dir
+        self.hidden_size, self.num_layers = hidden_size, num_layers
+        self.layer1 = nn.Linear(self.dim_xyz, hidden_size)
+        self.layers_xyz = nn.ModuleList()
+        for i in range(num_layers - 1):
+            if i % self.skip_connect_every == 0 and i > 0 and i != num_layers - 1:
+                self.layers_xyz.append(nn.Linear(self.dim_xyz + hidden_size, hidden_size))
+            else:
+                self.layers_xyz.append(nn.Linear(hidden_size, hidden_size))
+        self.use_viewdirs = True
+        self.layers_dir = nn.ModuleList([nn.Linear(self.dim_dir + hidden_size, hidden_size // 2)])
+        self.fc_alpha = nn.Linear(hidden_size, 1)
+        self.fc_rgb = nn.Linear(hidden_size // 2, 3)
+        self.fc_feat = nn.Linear(hidden_size, hidden_size)
+        for i, l in enumerate(self.layers_xyz):      # the reference's forward concatenates whenever i % skip == 0 and i > 0 (:90-95)
+            expect = hidden_size + (self.dim_xyz if (i % skip_connect_every == 0 and i > 0) else 0)
+            if l.in_features != expect:
+                raise NotImplementedError("this num_layers / skip_connect_every combination is inconsistent in the reference as well")
+
+    def forward(self, x):
+        x = capi.f32c(x)
+        assert x.shape[-1] == self.dim_xyz + self.dim_dir
+        P = x.numel() // x.shape[-1]
+        mods = [self.layer1] + list(self.layers_xyz) + [self.layers_dir[0], self.fc_alpha, self.fc_rgb, self.fc_feat]
+        blob = torch.cat([t.detach().reshape(-1).float() for m in mods for t in (m.weight, m.bias)])
+        capi.require_cuda(blob)
+        out = torch.empty((P, 4), dtype=torch.float32, device=x.device)
+        capi.call("nvsr_flexible_nerf_forward", P, capi.ptr(x), self.dim_xyz, self.dim_dir, self.hidden_size, self.num_layers,
+                  self.skip_connect_every, capi.ptr(blob), capi.ptr(out), capi.stream())
+        return out.reshape(list(x.shape[:-1]) + [4])

@@ -65,6 +65,17 @@ def sort_depths(z):
     return out
 
 
+def positional_encoding(tensor, num_encoding_functions=6, include_input=True) -> torch.Tensor:
+    """nerf_helpers.py:552-575: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] along the last dim"""
+    x = capi.f32c(tensor)
+    D = x.shape[-1]
+    P = x.numel() // D
+    width = (D if include_input else 0) + 2 * D * num_encoding_functions
+    out = torch.empty(list(x.shape[:-1]) + [width], dtype=torch.float32, device=x.device)
+    capi.call("nvsr_positional_encoding", P, D, capi.ptr(x), num_encoding_functions, int(bool(include_input)), capi.ptr(out), capi.stream())
+    return out
+
+
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     """nerf_helpers.py:409-430 (plumbing for callers outside the fused path; the kernels carry the running product in a register)"""
     cumprod = torch.cumprod(tensor, -1)

@@ -1,0 +1,59 @@
+"""CPU tests of the multi-GPU layer with the gloo backend, world_size 2 (one process per rank, rendezvous on 127.0.0.1)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _fake_render(H, W, focal, mc, mf, batch, options, scene_id, mode="validation", scene_config=None):
+    """stand-in for run_one_iter_of_nerf (no GPU here): a per-ray function, so sharding must not change any pixel"""
+    ro, rd = batch[0], batch[1]
+    c = torch.sin(ro * 3.0 + rd)
+    f = torch.cos(rd * 2.0) * ro.sum(-1, keepdim=True)
+    return c, None, None, f, None, None, None, None, None
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nvsr_amd
+    D = nvsr_amd.distributed
+    torch.manual_seed(0)                       # same data on every rank (scene and view are replicated)
+    H, W = 7, 5                                # 35 rays: not divisible by 2
+    ro, rd = torch.randn(H, W, 3), torch.randn(H, W, 3)
+    full = _fake_render(H, W, 1.0, None, None, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0), None, None)
+    c, f = D.render_image_sharded(H, W, 1.0, None, None, ro, rd, None, "s", None, render_fn=_fake_render)
+    assert torch.equal(c.reshape(-1, 3), full[0]) and torch.equal(f.reshape(-1, 3), full[3])
+    lc, lf, (lo, hi) = D.render_image_sharded(H, W, 1.0, None, None, ro, rd, None, "s", None, render_fn=_fake_render, gather=False)
+    assert (lo, hi) == D.shard_bounds(H * W, rank, world) and torch.equal(lc, full[0][lo:hi])
+    # gradient all-reduce: rank r holds r+1 everywhere -> average 1.5
+    grads = [torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(rank + 1)), torch.full((70000,), float(rank + 1))]
+    D.allreduce_gradients(grads, bucket_bytes=1 << 16)
+    assert all(torch.allclose(g, torch.full_like(g, 1.5)) for g in grads)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+def test_shard_bounds_cover_everything():
+    sys.path.insert(0, ROOT)
+    import nvsr_amd
+    sb = nvsr_amd.distributed.shard_bounds
+    for n in (0, 1, 7, 640000, 640001):
+        for world in (1, 2, 3, 8):
+            spans = [sb(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_sharded_render_and_grad_allreduce(tmp_path):
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))

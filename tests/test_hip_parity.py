@@ -471,3 +471,16 @@ def test_render_through_super_resolved_planes(hip, oracle):
     _, _, _, img_lr, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
     np.testing.assert_allclose(N_(img_lr).reshape(-1, 3), o_c["rgb_fine"], rtol=0, atol=1e-3)
     assert not torch.equal(img_lr, img_f)
+
+
+def test_positional_encoding_and_nerf_mlp_golden(hip):
+    g = load_golden("g10_posenc.npz")
+    pe = hip.nerf_helpers.positional_encoding
+    np.testing.assert_allclose(N_(pe(T(g["x"]), 6, True)), g["pe_L6"], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(N_(pe(T(g["x"]), 4, True)), g["pe_L4"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N_(pe(T(g["x"]), 4, False)), g["pe_L4_noinput"], rtol=0, atol=2e-6)
+    m = hip.models.FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    m = m.to(DEV)
+    x = torch.cat([pe(T(g["nerf_pts"]), 6), pe(T(g["nerf_dirs"]), 4)], -1)
+    np.testing.assert_allclose(N_(m(x)), g["nerf_out"], rtol=0, atol=1e-5)
