@@ -41,6 +41,7 @@ typedef enum {
 #define NVSR_DEC_LAYERS 4
 #define NVSR_DECODER_NATURAL_FLOATS 130564 /* state-dict order, see nvsr_pack_decoder */
 #define NVSR_DECODER_PACKED_FLOATS 130576  /* MFMA-fragment order + biases/heads */
+#define NVSR_DECODER_PACKED_BWD_FLOATS 139264 /* transposed layers for the backward pass, see nvsr_pack_decoder_bwd */
 
 /* One scene = 3 position planes + 1 view-direction plane, CHANNEL-LAST [H][W][48] (192 B per texel), the per-scene
  * normalisation box (models.py:261-268) and the plane projections rot_mats[d][:,1:] (models.py:471-497). */
@@ -148,6 +149,23 @@ int nvsr_positional_encoding(int64_t P, int D, const float* x, int L, int includ
  * blob = state-dict order: layer1, layers_xyz.{i}, layers_dir.0, fc_alpha, fc_rgb, fc_feat, each {weight[out,in], bias}. */
 int nvsr_flexible_nerf_forward(int64_t P, const float* x, int dim_xyz, int dim_dir, int hidden, int num_layers, int skip_every,
                                const float* blob, float* out, nvsr_stream_t stream);
+
+/* ---- training: gradient with respect to the feature planes -------------------------------------------------------------
+ * The reference differentiates run_one_iter_of_nerf with torch.autograd (train_nerf.py:860-903); with the decoder frozen
+ * (Feature_Planes_Only.yml) the leaves are the planes.  z_samples carry no gradient (`.detach()`, train_utils.py:153). */
+/* nvsr_render_pass that also returns the decoder outputs raw [N,S,4] (needed by nvsr_composite_backward); raw_out may be NULL */
+int nvsr_render_pass_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                        const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                        float* raw_out, nvsr_stream_t stream);
+/* transposed decoder layers in MFMA-fragment order (NVSR_DECODER_PACKED_BWD_FLOATS floats) from the natural blob */
+int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t stream);
+/* backward of volume_render_radiance_field (volume_rendering_utils.py:18-49): g_rgb [N,3], g_acc [N] or NULL -> g_raw [N,S,4]; S <= 512 */
+int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                            const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);
+/* backward of one decode pass: g_raw [N,S,4] -> grad_planes[4] (host array of 4 device pointers, CHANNEL-LAST like the scene's
+ * planes, accumulated with float atomics: zero them first) */
+int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                              const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ PLANE_CHANNELS = 48
 DEC_CHANNELS = 128
 DECODER_NATURAL_FLOATS = 130564
 DECODER_PACKED_FLOATS = 130576
+DECODER_PACKED_BWD_FLOATS = 139264
 
 _STATUS = {1: "NVSR_ERR_SHAPE (argument out of the supported range)", 2: "NVSR_ERR_LAUNCH (kernel launch failed)",
            3: "NVSR_ERR_NULL (required pointer is NULL)", 4: "NVSR_ERR_ALIGN (pointer not 16-byte aligned)"}
@@ -67,6 +68,11 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_edsr_forward": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "nvsr_planes_sr_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp], _i),
+    # training: plane gradients (csrc/render_bwd.hip)
+    "nvsr_render_pass_ex": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_pack_decoder_bwd": ([_vp, _vp, _vp], _i),
+    "nvsr_composite_backward": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
+    "nvsr_render_pass_backward": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp], _i),
     # positional-encoding baseline (csrc/posenc.hip)
     "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),

@@ -1,0 +1,375 @@
+// Device-side core of the tri-plane decoder shared by the forward (render.hip) and backward (render_bwd.hip) kernels:
+// LDS-DMA weight ring, bilinear taps + feature gather, MFMA layer blocks, one decode step.  NWAVES = waves per workgroup.
+#pragma once
+#include "nvsr_common.h"
+
+#ifndef NVSR_ABLATE
+#define NVSR_ABLATE 0   // timing experiments only (scratch/): 1 no gather, 2 no bias/ReLU, 4 no ring barrier, 8 no heads
+#endif
+
+namespace nvsr {
+
+constexpr int SLOT_FLOATS = 8192;                     // 32 KB ring slot: one plane of a feature layer, or half a hidden layer
+constexpr int LDS_FLOATS = 2 * SLOT_FLOATS + SMALL_FLOATS;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// LDS-DMA: the 8 waves copy `BLOCKS` 1-KiB blocks (lane-linear, 16 B per lane); wave w takes blocks w, w+8, ...
+// gsrc is wave-uniform (SGPR base), voff = wave*1024 + lane*16 bytes is the only per-lane address register.
+template <int NWAVES, int BLOCKS>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ gsrc, float* lds_dst, unsigned voff, int wave) {
+    static_assert(BLOCKS % NWAVES == 0, "chunk must split evenly over the waves");
+    const char* g = reinterpret_cast<const char*>(gsrc);
+#pragma unroll
+    for (int i = 0; i < BLOCKS / NWAVES; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * (NWAVES * 1024) + voff),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + (i * NWAVES + wave) * 256), 16, 0, 0);
+    }
+}
+
+// Wait for this wave's DMA, then meet the other waves: afterwards the chunk issued one phase ago is readable by everyone
+// and the slot read one phase ago is free.
+__device__ __forceinline__ void ring_sync() {
+#if !(NVSR_ABLATE & 4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+}
+
+// ---- bilinear taps (grid_sample, align_corners=True, padding_mode='border') ------------------------------------------
+struct Taps {
+    int o00, o01, o10, o11;   // float offsets of the 4 texels (channel 0)
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Taps make_taps(const SceneDev& sc, int d, float gx, float gy) {
+    const int H = sc.ph[d], W = sc.pw[d];
+    const float mx = sc.mx[d], my = sc.my[d];
+    float x = (gx + 1.0f) * sc.hx[d];
+    float y = (gy + 1.0f) * sc.hy[d];
+    x = fminf(mx, fmaxf(x, 0.0f));
+    y = fminf(my, fmaxf(y, 0.0f));
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    Taps t;
+    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    const int ix = (int)xw, iy = (int)yn;
+    const int ix1 = min(ix + 1, W - 1), iy1 = min(iy + 1, H - 1);   // a clamped neighbour always carries weight 0
+    t.o00 = (iy * W + ix) * C;  t.o01 = (iy * W + ix1) * C;
+    t.o10 = (iy1 * W + ix) * C; t.o11 = (iy1 * W + ix1) * C;
+    return t;
+}
+
+// 24 channels (half h of the texel) of the bilinear blend -> f[0..23].  Two taps are in flight at a time (48 registers).
+__device__ __forceinline__ void gather24(const float* __restrict__ plane, const Taps& t, int h, float (&f)[HALF_C]) {
+#if NVSR_ABLATE & 1
+#pragma unroll
+    for (int i = 0; i < HALF_C; ++i) f[i] = t.nw * (float)(i + h);
+    return;
+#endif
+    const f32x4* p00 = reinterpret_cast<const f32x4*>(plane + t.o00 + HALF_C * h);
+    const f32x4* p01 = reinterpret_cast<const f32x4*>(plane + t.o01 + HALF_C * h);
+    const f32x4* p10 = reinterpret_cast<const f32x4*>(plane + t.o10 + HALF_C * h);
+    const f32x4* p11 = reinterpret_cast<const f32x4*>(plane + t.o11 + HALF_C * h);
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i) {
+        const f32x4 a = p00[i], b = p01[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(b[j], t.ne, a[j] * t.nw);
+    }
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i) {
+        const f32x4 c = p10[i], d = p11[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = fmaf(d[j], t.se, fmaf(c[j], t.sw, f[4 * i + j]));
+    }
+}
+
+// x / 3 correctly rounded in 3 instructions (Markstein: q = RN(x*c), r = x - 3q exactly by FMA, q + r*c)
+__device__ __forceinline__ float div3(float x) {
+    const float c = 0x1.555556p-2f;
+    const float q = x * c;
+    return fmaf(fmaf(-3.0f, q, x), c, q);
+}
+
+__device__ __forceinline__ float norm_coord(float v, float lo, float range) {
+    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v, lo)), range), 1.0f);
+}
+
+// ---- MFMA layers ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_bias(const float* bias /*LDS, packed [ib][q][h][j]*/, int h, f32x16 (&acc)[4]) {
+#if NVSR_ABLATE & 2
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
+    return;
+#endif
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ib][4 * q + j] = b[j];
+        }
+}
+
+__device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
+#if NVSR_ABLATE & 2
+    return;
+#endif
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+}
+
+// MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
+// wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
+// ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every
+// outstanding read, so the next fragment gets 3 MFMAs (192 cycles) to land; left alone hipcc sinks the read to its use.
+// (Measured: a v_mfma_f32_32x32x2_f32 stream fed this way sustains 64.2 cycles per MFMA, scratch/mfma_ubench.hip.)
+template <int NG, class BFn>
+__device__ __forceinline__ void mfma_groups(const float* wl, int lane, f32x16 (&acc)[4], BFn b) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wl) + lane;
+    f32x4 a = wv[0];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ib = g & 3;
+        acc[ib] = mfma32(a[0], b(g, 0), acc[ib]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 an = wv[(g + 1 < NG ? g + 1 : g) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) acc[ib] = mfma32(a[j], b(g, j), acc[ib]);
+        a = an;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one plane's 48 channels of a feature layer: acc += W[:, 48p .. 48p+47] * f      (chunk layout [q 6][ib][lane][j])
+__device__ __forceinline__ void feat_layer(const float* wl, const float (&f)[HALF_C], int lane, f32x16 (&acc)[4]) {
+    mfma_groups<(HALF_C / 4) * 4>(wl, lane, acc, [&](int g, int j) { return f[4 * (g >> 2) + j]; });
+}
+
+// half of a hidden layer 128 -> 128: acc += W[:, 64*HALF .. 64*HALF+63] * in[2*HALF .. 2*HALF+1]   (in = previous accumulators,
+// already ReLU'd).  wl = the 32 KB chunk [kb 2][q 4][ib][lane][j].
+template <int HALF>
+__device__ __forceinline__ void hidden_half(const float* wl, const f32x16 (&in)[4], int lane, f32x16 (&acc)[4]) {
+    mfma_groups<32>(wl, lane, acc, [&](int g, int j) { return in[2 * HALF + (g >> 4)][4 * ((g >> 2) & 3) + j]; });
+}
+
+// 128 -> 1 head on the VALU: each lane owns 64 of the 128 features of its point, the partner lane (l ^ 32) the rest
+__device__ __forceinline__ float head_dot(const float* w /*LDS packed [ib][q][h][j]*/, int h, const f32x16 (&in)[4]) {
+#if NVSR_ABLATE & 8
+    return in[0][0] + in[1][1] + in[2][2] + in[3][3];
+#endif
+    float s = 0.0f;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = fmaf(in[ib][4 * q + j], wv[j], s);
+        }
+    return s + __shfl_xor(s, 32);
+}
+
+struct RingState {
+    const float* packed;   // global packed decoder blob
+    float* lds;            // LDS base
+    int slot;              // slot that receives the NEXT issued chunk
+    int wave, lane;
+    unsigned voff;         // wave*1024 + lane*16: per-lane byte offset of the LDS-DMA source
+};
+
+template <int NWAVES, int BLOCKS>
+__device__ __forceinline__ const float* ring_issue(RingState& rs, int packed_off) {
+    float* dst = rs.lds + rs.slot * SLOT_FLOATS;
+    stage_chunk<NWAVES, BLOCKS>(rs.packed + packed_off, dst, rs.voff, rs.wave);
+    rs.slot ^= 1;
+    return dst;
+}
+
+// Decode the wave's 32 points (px,py,pz given per lane, both lane halves hold the same point) -> raw rgb + sigma.
+// vt: bilinear taps on the view-direction plane.  Must be called by all waves of the workgroup together (ring barriers).
+// No DMA is outstanding on entry or on exit.
+// Chunk order: RGB0.p0..p3, RGB1..3 (two halves each), DEN0, DEN1..3 (two halves each).
+template <int NWAVES>
+__device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, float px, float py, float pz, const Taps& vt,
+                                            float (&raw)[4]) {
+    // Re-derive the per-lane address registers every step: left loop-invariant, hipcc hoists one 64-bit address per
+    // DMA / LDS read out of the sample loop and spills them all.
+    asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+    const int lane = rs.lane, h = lane >> 5;
+    const float* small = rs.lds + 2 * SLOT_FLOATS;
+    const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
+    const float n1 = norm_coord(py, sc.lo[1], sc.range[1]);
+    const float n2 = norm_coord(pz, sc.lo[2], sc.range[2]);
+
+    // Order chosen for register pressure (256 VGPRs at 2 waves/SIMD): the rgb decoder runs first and consumes the plane
+    // features as they are gathered (only 24 + 24 feature registers live), the density decoder then runs from the 24
+    // registers of the averaged position features.  17 ring chunks per step (<= 32 KB each).
+    f32x16 accA[4], accB[4];
+    float D[HALF_C], F[HALF_C];
+    constexpr int HH = P_HID_FLOATS / 2;   // half hidden layer
+
+    // ---- rgb layer 0: K = 192 = [f0 | f1 | f2 | f_view], one plane (= one chunk) at a time ----------------------------
+    // The step's first chunk is issued here, next to the first gather (their latencies overlap), NOT at the end of the previous
+    // step: vector-memory waits are in order, so anything the caller loads between two steps would otherwise wait for the DMA.
+    const float* cur = ring_issue<NWAVES, 24>(rs, P_RGB0);
+    {
+        const float* M = sc.proj;
+        const Taps t = make_taps(sc, 0, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        gather24(sc.plane[0], t, h, F);
+    }
+    ring_sync();
+    const float* nxt = ring_issue<NWAVES, 24>(rs, P_RGB0 + P_PLANE_FLOATS);
+    load_bias(small + S_BIAS + 4 * HID, h, accA);
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
+    feat_layer(cur, F, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 24>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
+    {
+        const float* M = sc.proj + 6;
+        const Taps t = make_taps(sc, 1, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        gather24(sc.plane[1], t, h, F);
+    }
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
+    feat_layer(cur, F, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 24>(rs, P_RGB0 + 3 * P_PLANE_FLOATS);
+    {
+        const float* M = sc.proj + 12;
+        const Taps t = make_taps(sc, 2, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        gather24(sc.plane[2], t, h, F);
+    }
+    // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+    feat_layer(cur, F, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1);
+    gather24(sc.plane[3], vt, h, F);
+    feat_layer(cur, F, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    // ---- rgb decoder layers 1..3 -> 3 ---------------------------------------------------------------------------------
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + HH);
+    load_bias(small + S_BIAS + 5 * HID, h, accB);
+#if NVSR_ABLATE & 64
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    hidden_half<0>(cur, accA, lane, accB);
+#if NVSR_ABLATE & 64
+    __builtin_amdgcn_sched_barrier(0);
+    raw[0] = (float)(__builtin_amdgcn_s_memtime() - st0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 2 * HH);
+    hidden_half<1>(cur, accA, lane, accB);
+    relu_inplace(accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 3 * HH);
+    load_bias(small + S_BIAS + 6 * HID, h, accA);
+    hidden_half<0>(cur, accB, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 4 * HH);
+    hidden_half<1>(cur, accB, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 5 * HH);
+    load_bias(small + S_BIAS + 7 * HID, h, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 24>(rs, P_DEN0);
+    hidden_half<1>(cur, accA, lane, accB);
+    relu_inplace(accB);
+#if NVSR_ABLATE & 64
+    const float stamp = raw[0];
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) raw[c] = head_dot(small + S_RGB_W + c * HID, h, accB) + small[S_HEAD_B + 1 + c];
+#if NVSR_ABLATE & 64
+    raw[1] = stamp;
+#endif
+    cur = nxt;
+    // ---- density decoder: 48 -> 128 x4 -> 1 --------------------------------------------------------------------------
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1);
+    load_bias(small + S_BIAS + 0 * HID, h, accA);
+    feat_layer(cur, D, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + HH);
+    load_bias(small + S_BIAS + 1 * HID, h, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 2 * HH);
+    hidden_half<1>(cur, accA, lane, accB);
+    relu_inplace(accB);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 3 * HH);
+    load_bias(small + S_BIAS + 2 * HID, h, accA);
+    hidden_half<0>(cur, accB, lane, accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 4 * HH);
+    hidden_half<1>(cur, accB, lane, accA);
+    relu_inplace(accA);
+    cur = nxt;
+    ring_sync();
+    nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 5 * HH);
+    load_bias(small + S_BIAS + 3 * HID, h, accB);
+    hidden_half<0>(cur, accA, lane, accB);
+    cur = nxt;
+    ring_sync();
+    hidden_half<1>(cur, accA, lane, accB);
+    relu_inplace(accB);
+    raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
+}
+
+// workgroup prologue: heads/biases -> LDS (plain copy; the first ring barrier publishes them), then the STAGGER: the two
+// workgroups of a CU start together and run the same program at the same rate, so left alone they stay phase-locked and
+// their gathers, barriers and VALU epilogues coincide (measured: those costs add up instead of hiding behind the partner's
+// MFMAs).  The workgroup whose wave 0 sits in an odd wave slot of its SIMD (HW_ID.wave_id) starts half a chunk-phase late.
+template <int NWAVES>
+__device__ __forceinline__ void decode_prologue(RingState& rs) {
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += NWAVES * 64) rs.lds[2 * SLOT_FLOATS + i] = rs.packed[P_SMALL + i];
+#if !(NVSR_ABLATE & 32)
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(127);   // ~8k cycles = half of a shared 128-MFMA phase
+#endif
+}
+
+__device__ __forceinline__ Taps view_taps(const SceneDev& sc, float vx, float vy, float vz) {
+    // cart2az_el (nerf_helpers.py:492-496) + normalize_coords
+    const float az = atan2f(vy, vx);
+    const float el = atan2f(vz, sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy))));
+    return make_taps(sc, 3, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]));
+}
+
+
+}  // namespace nvsr

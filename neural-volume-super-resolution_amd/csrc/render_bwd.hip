@@ -1,0 +1,453 @@
+// Backward of the fused render pass with respect to the feature planes (gfx950).
+//
+// The reference obtains it from torch.autograd through run_network / TwoDimPlanesModel.forward / grid_sample
+// (train_utils.py:185-282, models.py:381-421; `grid_sampler_2d_backward` scatter-adds into the planes).  Decoder weights are
+// treated as constants (Feature_Planes_Only.yml: `what: ['LR_planes']`).
+//
+// Per step a wave takes 32 points (one sample of its 32 rays):
+//   1. recomputes the decoder forward on the MFMA path of decode_core.h, keeping only the ReLU masks (2 VGPRs per layer);
+//   2. chains dL/d(raw) back through the transposed layers -- the same register-chained v_mfma_f32_32x32x2_f32 scheme, fed with
+//      W^T fragments (second packed blob): D[in-feature][point] += W^T[in][out] * G[out][point];
+//   3. transposes the feature gradients of one plane at a time through a per-wave LDS tile ([point][48 channels]) and adds
+//      them into the channel-last gradient plane with one global_atomic_add_f32 wave-instruction per (point, tap): 48 lanes =
+//      192 contiguous bytes, the fast shape of float atomics (one-lane-per-row scatter is ~17x slower, MI355X_MICROARCH.md).
+#include "decode_core.h"
+
+namespace nvsr {
+
+constexpr int BTPB = 512;                 // 8 waves: 2 per SIMD, one workgroup per CU (137 KB of LDS)
+constexpr int BNW = BTPB / 64;
+constexpr int BPTS = BNW * 32;
+constexpr int RAYB_FLOATS = 16;
+constexpr int TILE_FLOATS = 32 * C;       // per-wave transposition tile [32 points][48 channels]
+constexpr int BWD_LDS_FLOATS = LDS_FLOATS + BPTS * RAYB_FLOATS + BNW * TILE_FLOATS;
+static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+// ---- transposed-weight blob ("packed_bwd"), in consumption order ------------------------------------------------------------
+//   hidden^T layer (16384 floats): [kb][q][ib][lane][j] = W[32kb + 8q + 4h + j][32ib + (lane&31)]        (W = [out][in])
+//   layer-0^T of one plane (8192 floats): [kb][q][ib 2][lane][j] = W0[32kb + 8q + 4h + j][48p + 32ib + (lane&31)], 0 for channel >= 48
+constexpr int B_DEN_H = 0;                               // density L3^T, L2^T, L1^T
+constexpr int B_DEN0 = B_DEN_H + 3 * P_HID_FLOATS;       // 49152
+constexpr int B_RGB_H = B_DEN0 + 8192;                   // 57344: rgb L3^T, L2^T, L1^T
+constexpr int B_RGB0 = B_RGB_H + 3 * P_HID_FLOATS;       // 106496: planes 0..3
+constexpr int B_TOTAL = B_RGB0 + 4 * 8192;               // 139264
+static_assert(B_TOTAL == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
+
+__global__ void pack_decoder_bwd_kernel(const float* __restrict__ nat, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B_TOTAL) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, h = lane >> 5;
+    float v = 0.0f;
+    if (idx < B_DEN0 || (idx >= B_RGB_H && idx < B_RGB0)) {          // hidden^T
+        const bool rgb = idx >= B_RGB_H;
+        const int rem0 = idx - (rgb ? B_RGB_H : B_DEN_H);
+        const int li = rem0 / P_HID_FLOATS, rem = rem0 % P_HID_FLOATS;   // li 0 -> layer 3, 1 -> layer 2, 2 -> layer 1
+        const int ib = (rem >> 8) & 3, q = (rem >> 10) & 3, kb = rem >> 12;
+        const int out = 32 * kb + 8 * q + 4 * h + j, in = 32 * ib + (lane & 31);
+        const int layer = 3 - li;                                          // forward layer index 1..3
+        v = nat[(rgb ? N_RGB_W1 : N_DEN_W1) + (layer - 1) * N_HID_STRIDE + out * HID + in];
+    } else {                                                               // layer-0^T
+        const bool rgb = idx >= B_RGB0;
+        const int rem0 = idx - (rgb ? B_RGB0 : B_DEN0);
+        const int p = rem0 / 8192, rem = rem0 % 8192;
+        const int ib = (rem >> 8) & 1, q = (rem >> 9) & 3, kb = rem >> 11;
+        const int out = 32 * kb + 8 * q + 4 * h + j, c = 32 * ib + (lane & 31);
+        if (c < C) v = rgb ? nat[N_RGB_W0 + out * (4 * C) + C * p + c] : nat[N_DEN_W0 + out * C + c];
+    }
+    packed[idx] = v;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------------
+struct Masks { unsigned m[2]; };   // bit (ib&1)*16 + r of m[ib>>1]  <=>  post-ReLU activation acc[ib][r] > 0
+
+__device__ __forceinline__ Masks relu_masks(f32x16 (&acc)[4]) {
+    Masks k{{0u, 0u}};
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool on = acc[ib][r] > 0.0f;
+            acc[ib][r] = on ? acc[ib][r] : 0.0f;
+            k.m[ib >> 1] |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+        }
+    return k;
+}
+__device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[ib][r] = ((k.m[ib >> 1] >> ((ib & 1) * 16 + r)) & 1u) ? g[ib][r] : 0.0f;
+}
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[4]) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[ib][r] = 0.0f;
+}
+
+// layer-0^T of one plane: acc2[ib] += W0p^T[32ib.., :] * g     (chunk [kb][q][ib 2][lane][j], 128 MFMAs)
+__device__ __forceinline__ void layer0_T(const float* wl, const f32x16 (&g)[4], int lane, f32x16 (&acc2)[2]) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wl) + lane;
+    f32x4 a = wv[0];
+#pragma unroll
+    for (int gi = 0; gi < 32; ++gi) {
+        const int ib = gi & 1, q = (gi >> 1) & 3, kb = gi >> 3;
+        acc2[ib] = mfma32(a[0], g[kb][4 * q + 0], acc2[ib]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 an = wv[(gi + 1 < 32 ? gi + 1 : gi) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) acc2[ib] = mfma32(a[j], g[kb][4 * q + j], acc2[ib]);
+        a = an;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one full hidden^T layer (two ring chunks): gn = mask .* (W^T g)
+template <int NW>
+__device__ __forceinline__ void hidden_T(RingState& rs, const float*& cur, int next_off, int next_blocks24, const f32x16 (&g)[4],
+                                         const Masks& mk, f32x16 (&gn)[4], int this_off) {
+    // chunk h0 is `cur` (already issued); issue h1, compute h0, then issue the caller's next chunk, compute h1
+    ring_sync();
+    const float* nxt = ring_issue<NW, 32>(rs, this_off + P_HID_FLOATS / 2);
+    zero_acc(gn);
+    hidden_half<0>(cur, g, rs.lane, gn);
+    cur = nxt;
+    ring_sync();
+    nxt = next_blocks24 ? ring_issue<NW, 24>(rs, next_off) : ring_issue<NW, 32>(rs, next_off);
+    hidden_half<1>(cur, g, rs.lane, gn);
+    apply_mask(mk, gn);
+    cur = nxt;
+}
+
+// feature gradients of one plane (acc2: rows c = 32b + (r&3) + 8(r>>2) + 4h) -> LDS tile [pt][48] -> atomics into the plane
+__device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
+                                              bool valid) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    // taps of an invalid (padding) ray carry zero weight
+    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    for (int p = 0; p < 32; ++p) {
+        const int o0 = __shfl(t.o00, p), o1 = __shfl(t.o01, p), o2 = __shfl(t.o10, p), o3 = __shfl(t.o11, p);
+        const float a0 = __shfl(w0, p), a1 = __shfl(w1, p), a2 = __shfl(w2, p), a3 = __shfl(w3, p);
+        if (lane < C) {
+            const float v = tile[p * C + lane];
+            unsafeAtomicAdd(gplane + o0 + lane, v * a0);
+            unsafeAtomicAdd(gplane + o1 + lane, v * a1);
+            unsafeAtomicAdd(gplane + o2 + lane, v * a2);
+            unsafeAtomicAdd(gplane + o3 + lane, v * a3);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct GradPlanes { float* p[4]; };
+
+// =====================================================================================================================
+__global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
+                                                                      const float* __restrict__ packed_bwd, long N, int S,
+                                                                      const float* __restrict__ rays, const float* __restrict__ z,
+                                                                      const float* __restrict__ g_raw, GradPlanes gp) {
+    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
+    RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    decode_prologue<BNW>(rs);
+    const int lane0 = rs.lane, h0 = lane0 >> 5;
+    const long ray0 = (long)blockIdx.x * BPTS + rs.wave * 32 + (lane0 & 31);
+    const bool valid = ray0 < N;
+    const long ray = valid ? ray0 : N - 1;
+    float* rc = lds + LDS_FLOATS + (rs.wave * 32 + (lane0 & 31)) * RAYB_FLOATS;
+    float* tile = lds + LDS_FLOATS + BPTS * RAYB_FLOATS + rs.wave * TILE_FLOATS;
+    {
+        const float* r = rays + ray * 11;
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        if (lane0 < 32) {
+            reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], r[3]};
+            reinterpret_cast<f32x4*>(rc)[1] = f32x4{r[4], r[5], 0.0f, 0.0f};
+            reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
+            reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
+        }
+    }
+    const float* small = lds + 2 * SLOT_FLOATS;
+    constexpr int HH = P_HID_FLOATS / 2;
+
+    for (int s = 0; s < S; ++s) {
+        asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+        const int lane = rs.lane, h = lane >> 5;
+        const float zc = z[ray * S + s];
+        const f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
+        const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
+        Taps vt;
+        vt.o00 = __float_as_int(c2[0]); vt.o01 = __float_as_int(c2[1]); vt.o10 = __float_as_int(c2[2]); vt.o11 = __float_as_int(c2[3]);
+        vt.nw = c3[0]; vt.ne = c3[1]; vt.sw = c3[2]; vt.se = c3[3];
+        const float n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
+        const float n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
+        const float n2 = norm_coord(__fadd_rn(c0[2], __fmul_rn(c1[1], zc)), sc.lo[2], sc.range[2]);
+        auto pos_taps = [&](int d) {
+            const float* M = sc.proj + 6 * d;
+            return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        };
+
+        // ================= forward recompute, ReLU masks only =================
+        f32x16 accA[4], accB[4];
+        float D[HALF_C], F[HALF_C];
+        Masks mr[4], md[4];
+        const float* cur = ring_issue<BNW, 24>(rs, P_RGB0);
+        gather24(sc.plane[0], pos_taps(0), h, F);
+        ring_sync();
+        const float* nxt = ring_issue<BNW, 24>(rs, P_RGB0 + P_PLANE_FLOATS);
+        load_bias(small + S_BIAS + 4 * HID, h, accA);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
+        feat_layer(cur, F, lane, accA);
+        cur = nxt;
+        ring_sync();
+        nxt = ring_issue<BNW, 24>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
+        gather24(sc.plane[1], pos_taps(1), h, F);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
+        feat_layer(cur, F, lane, accA);
+        cur = nxt;
+        ring_sync();
+        nxt = ring_issue<BNW, 24>(rs, P_RGB0 + 3 * P_PLANE_FLOATS);
+        gather24(sc.plane[2], pos_taps(2), h, F);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+        feat_layer(cur, F, lane, accA);
+        cur = nxt;
+        ring_sync();
+        nxt = ring_issue<BNW, 32>(rs, P_RGB1);
+        gather24(sc.plane[3], vt, h, F);
+        feat_layer(cur, F, lane, accA);
+        mr[0] = relu_masks(accA);
+        cur = nxt;
+#pragma unroll
+        for (int l = 1; l <= 3; ++l) {                 // rgb layers 1..3 (ping-pong A -> B -> A -> B)
+            f32x16 (&in)[4] = (l & 1) ? accA : accB;
+            f32x16 (&out)[4] = (l & 1) ? accB : accA;
+            ring_sync();
+            nxt = ring_issue<BNW, 32>(rs, P_RGB1 + (l - 1) * P_HID_FLOATS + HH);
+            load_bias(small + S_BIAS + (4 + l) * HID, h, out);
+            hidden_half<0>(cur, in, lane, out);
+            cur = nxt;
+            ring_sync();
+            nxt = (l < 3) ? ring_issue<BNW, 32>(rs, P_RGB1 + l * P_HID_FLOATS) : ring_issue<BNW, 24>(rs, P_DEN0);
+            hidden_half<1>(cur, in, lane, out);
+            mr[l] = relu_masks(out);
+            cur = nxt;
+        }
+        ring_sync();
+        nxt = ring_issue<BNW, 32>(rs, P_DEN1);
+        load_bias(small + S_BIAS + 0 * HID, h, accA);
+        feat_layer(cur, D, lane, accA);
+        md[0] = relu_masks(accA);
+        cur = nxt;
+#pragma unroll
+        for (int l = 1; l <= 3; ++l) {                 // density layers 1..3
+            f32x16 (&in)[4] = (l & 1) ? accA : accB;
+            f32x16 (&out)[4] = (l & 1) ? accB : accA;
+            ring_sync();
+            nxt = ring_issue<BNW, 32>(rs, P_DEN1 + (l - 1) * P_HID_FLOATS + HH);
+            load_bias(small + S_BIAS + l * HID, h, out);
+            hidden_half<0>(cur, in, lane, out);
+            cur = nxt;
+            ring_sync();
+            if (l < 3) nxt = ring_issue<BNW, 32>(rs, P_DEN1 + l * P_HID_FLOATS);
+            hidden_half<1>(cur, in, lane, out);
+            md[l] = relu_masks(out);
+            cur = nxt;
+        }
+
+        // ================= backward: density branch -> gD (rows = 48 channels, 2 blocks) =================
+        rs.packed = packed_bwd;
+        cur = ring_issue<BNW, 32>(rs, B_DEN_H);
+        // d raw_sigma / d h3 = fc_alpha weight, masked by ReLU(h3)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(small + S_ALPHA_W + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
+            }
+        apply_mask(md[3], accA);
+        hidden_T<BNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
+        hidden_T<BNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
+        hidden_T<BNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
+        f32x16 gD[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gD[b][r] = 0.0f;
+        ring_sync();
+        nxt = ring_issue<BNW, 32>(rs, B_RGB_H);
+        layer0_T(cur, accB, lane, gD);
+        cur = nxt;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gD[b][r] = div3(gD[b][r]);      // 'avg' combination: each position plane gets gD / 3
+
+        // ================= backward: rgb branch =================
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = (ib * 4 + q) * 8 + h * 4;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + o);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + HID + o);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + 2 * HID + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
+            }
+        apply_mask(mr[3], accA);
+        hidden_T<BNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
+        hidden_T<BNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
+        hidden_T<BNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
+        // layer 0^T, one plane at a time, + gD/3 on the position planes, then scatter
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f32x16 gF[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gF[b][r] = (d < 3) ? gD[b][r] : 0.0f;
+            ring_sync();
+            if (d < 3) nxt = ring_issue<BNW, 32>(rs, B_RGB0 + (d + 1) * 8192);
+            layer0_T(cur, accB, lane, gF);
+            cur = nxt;
+            const Taps t = (d < 3) ? pos_taps(d) : vt;
+            scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+        }
+        rs.packed = packed;
+    }
+    ring_sync();
+}
+
+// =====================================================================================================================
+// volume_render_radiance_field backward: (g_rgb [N,3], g_acc [N] or NULL) -> g_raw [N,S,4]; one wave per ray, S <= 512
+// =====================================================================================================================
+constexpr int CB_WPB = 4;
+__global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
+                                                                        const float* __restrict__ rd, const float* __restrict__ noise, int white,
+                                                                        const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
+                                                                        float* __restrict__ g_raw) {
+    __shared__ float sT[CB_WPB][512], sA[CB_WPB][512], sG[CB_WPB][512];   // T_s, alpha_s, dL/dw_s
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * CB_WPB + wave;
+    if (ray >= N) return;
+    const float d0 = rd[ray * 3], d1 = rd[ray * 3 + 1], d2 = rd[ray * 3 + 2];
+    const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float g0 = g_rgb[ray * 3], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
+    const float ga = (g_acc ? g_acc[ray] : 0.0f) - (white ? (g0 + g1 + g2) : 0.0f);
+    const f32x4* rr = reinterpret_cast<const f32x4*>(raw) + ray * S;
+    f32x4* gout = reinterpret_cast<f32x4*>(g_raw) + ray * S;
+    // forward sweep: T_s (exclusive running product), alpha_s, dL/dw_s
+    float Tcarry = 1.0f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        float fac = 1.0f, alpha = 0.0f, gw = 0.0f;
+        if (s < S) {
+            const f32x4 rv = rr[s];
+            const float dist = ((s + 1 < S) ? (z[ray * S + s + 1] - z[ray * S + s]) : 1e10f) * nrm;
+            const float sig = fmaxf(rv[3] + (noise ? noise[ray * S + s] : 0.0f), 0.0f);
+            alpha = 1.0f - expf(-sig * dist);
+            fac = (1.0f - alpha) + 1e-10f;
+            gw = g0 / (1.0f + expf(-rv[0])) + g1 / (1.0f + expf(-rv[1])) + g2 / (1.0f + expf(-rv[2])) + ga;
+        }
+        float incl = fac;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if (lane >= o) incl *= t; }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float T = excl * Tcarry;
+        Tcarry *= __shfl(incl, 63);
+        if (s < S) { sT[wave][s] = T; sA[wave][s] = alpha; sG[wave][s] = gw; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // second sweep, back to front: suffix_s = sum_{k>s} w_k dL/dw_k by a REVERSE scan (total - prefix would cancel, and the
+    // suffix is divided by (1 - alpha + 1e-10), which reaches 1e-10 behind an opaque sample)
+    float scarry = 0.0f;
+    const int nchunks = (S + 63) / 64;
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int s = ch * 64 + lane;
+        float T = 0.0f, alpha = 0.0f, gw = 0.0f;
+        f32x4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (s < S) { T = sT[wave][s]; alpha = sA[wave][s]; gw = sG[wave][s]; rv = rr[s]; }
+        const float w = alpha * T;
+        const float own = w * gw;
+        float suf = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
+        const float suffix = (suf - own) + scarry;
+        scarry += __shfl(suf, 0);
+        if (s < S) {
+            const float g_alpha = T * gw - suffix / ((1.0f - alpha) + 1e-10f);
+            const float dist = ((s + 1 < S) ? (z[ray * S + s + 1] - z[ray * S + s]) : 1e10f) * nrm;
+            const float pre_sig = rv[3] + (noise ? noise[ray * S + s] : 0.0f);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float c = 1.0f / (1.0f + expf(-rv[k]));
+                const float gk = (k == 0) ? g0 : (k == 1 ? g1 : g2);
+                o[k] = w * gk * c * (1.0f - c);
+            }
+            o[3] = (pre_sig > 0.0f) ? g_alpha * dist * (1.0f - alpha) : 0.0f;
+            gout[s] = o;
+        }
+    }
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" {
+
+int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t stream) {
+    if (!natural || !packed_bwd) return NVSR_ERR_NULL;
+    if (!aligned16(packed_bwd)) return NVSR_ERR_ALIGN;
+    hipLaunchKernelGGL(pack_decoder_bwd_kernel, dim3((B_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, packed_bwd);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                            const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream) {
+    if (!raw || !z || !rd || !g_rgb || !g_raw) return NVSR_ERR_NULL;
+    if (!aligned16(raw) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
+                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                              const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream) {
+    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !grad_planes) return NVSR_ERR_NULL;
+    GradPlanes gp;
+    for (int d = 0; d < 4; ++d) {
+        if (!scene->planes[d] || !grad_planes[d]) return NVSR_ERR_NULL;
+        if (!aligned16(scene->planes[d])) return NVSR_ERR_ALIGN;
+        if (scene->ph[d] < 1 || scene->pw[d] < 1) return NVSR_ERR_SHAPE;
+        gp.p[d] = grad_planes[d];
+    }
+    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const int64_t grid = (N + BPTS - 1) / BPTS;
+    hipLaunchKernelGGL(render_pass_backward_kernel, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                       packed_bwd, (long)N, S, rays, z, g_raw, gp);
+    return NVSR_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -236,6 +236,21 @@ class TwoDimPlanesModel(nn.Module):
             self._packed_cache = (key, packed)
         return self._packed_cache[1]
 
+    def packed_decoder_bwd(self):
+        """transposed layers for the backward kernels (nvsr_pack_decoder_bwd), cached like packed_decoder()"""
+        self._check_native_geometry()
+        params = [p for n, p in self.named_parameters() if "rot_mats" not in n]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = getattr(self, "_packed_bwd_cache", None)
+        if cache is None or cache[0] != key:
+            nat = self.natural_blob()
+            capi.require_cuda(nat)
+            packed = torch.empty(capi.DECODER_PACKED_BWD_FLOATS, dtype=torch.float32, device=nat.device)
+            capi.call("nvsr_pack_decoder_bwd", capi.ptr(nat), capi.ptr(packed), capi.stream())
+            cache = (key, packed)
+            self._packed_bwd_cache = cache
+        return cache[1]
+
     def _should_SR(self, plane_name):
         if not hasattr(self, "SR_model") or self.skip_SR_:
             return False

@@ -46,6 +46,78 @@ def _reference_chunks(n_rays, options, mode, model_coarse, model_fine):
     return [(i, min(i + chunk, n_rays)) for i in range(0, n_rays, chunk)]
 
 
+class _RenderRaysFn(torch.autograd.Function):
+    """Differentiable predict_and_render_radiance with the four planes of the current scene as leaves (decoder frozen).
+
+    forward  = coarse z -> fused coarse pass (keeps raw + weights) -> importance resampling (no gradient, train_utils.py:153)
+               -> fused fine pass (keeps raw);
+    backward = per pass: composite backward (wave per ray) -> decoder backward + plane scatter-add (MFMA + float atomics)."""
+
+    @staticmethod
+    def forward(ctx, cfg, p0, p1, p2, pv):
+        capi_ = capi
+        N, Nc, Nf, dev = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"].device
+        rays, st = cfg["rays"], capi.stream()
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        z_c, w_c, raw_c = f(N, Nc), f(N, Nc), f(N, Nc, 4)
+        rgb_c, disp_c, acc_c = f(N, 3), f(N), f(N)
+        capi_.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), cfg["lindisp"], capi.ptr(cfg["t_rand"]), capi.ptr(z_c), st)
+        capi_.call("nvsr_render_pass_ex", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c),
+                   capi.ptr(cfg["noise_c"]), cfg["white"], capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None,
+                   capi.ptr(raw_c), st)
+        outs = [rgb_c, disp_c, acc_c]
+        saved = dict(z_c=z_c, raw_c=raw_c)
+        if Nf > 0:
+            z_f, raw_f = f(N, Nc + Nf), f(N, Nc + Nf, 4)
+            rgb_f, disp_f, acc_f = f(N, 3), f(N), f(N)
+            capi_.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(cfg["u"]), capi.ptr(z_f), st)
+            capi_.call("nvsr_render_pass_ex", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
+                       capi.ptr(cfg["noise_f"]), cfg["white"], capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None,
+                       capi.ptr(raw_f), st)
+            outs += [rgb_f, disp_f, acc_f]
+            saved.update(z_f=z_f, raw_f=raw_f)
+        ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 == 1])    # disparity: no gradient path implemented
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg, sv = ctx.cfg, ctx.saved
+        N, Nc, Nf, rays, st = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"], capi.stream()
+        dev = rays.device
+        rd = rays[:, 3:6].contiguous()
+        shapes = cfg["plane_shapes"]                                    # channel-last (H, W, C)
+        gplanes = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes]
+        gptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in gplanes])
+
+        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc):
+            if g_rgb is None and g_acc is None:
+                return
+            g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
+            g_acc = None if g_acc is None else capi.f32c(g_acc)
+            g_raw = torch.empty((N, S, 4), dtype=torch.float32, device=dev)
+            capi.call("nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), cfg["white"],
+                      capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), st)
+            capi.call("nvsr_render_pass_backward", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
+                      capi.ptr(z), capi.ptr(g_raw), gptrs, st)
+
+        if cfg["coarse_grad"]:
+            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2])
+        if Nf > 0:
+            one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5])
+        out = [None]
+        for g, need in zip(gplanes, ctx.needs_input_grad[1:]):
+            out.append(models.from_channel_last(g) if need else None)    # back to the reference's [1,C,H,W]
+        return tuple(out)
+
+
+def _planes_need_grad(model):
+    if not torch.is_grad_enabled() or getattr(model, "planes_", None) is None:
+        return False
+    names = [models.get_plane_name(model.cur_id, d) for d in range(model.num_density_planes + 1)]
+    return any(n in model.planes_ and model.planes_[n].requires_grad for n in names)
+
+
 def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, scene_id, mode="train", encode_position_fn=None,
                                 encode_direction_fn=None, randoms=None):
     """train_utils.py:71-182 on packed rays [N,11].  `randoms` (extension) = dict(t_rand, u, noise_coarse, noise_fine) of
@@ -86,6 +158,26 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         same = all(sc_c.planes[d] == sc_f.planes[d] for d in range(4))
     else:
         sc_f, keep_f, same = sc_c, keep_c, True
+
+    if mode == "train" and _planes_need_grad(model_fine if Nf > 0 else model_coarse) and N > 0:
+        # training path (mode == "train" only; evaluation never builds a graph): gradients flow to the planes of the current
+        # scene, decoder parameters are constants here
+        if hasattr(model_fine, "SR_model") and not model_fine.skip_SR_:
+            raise NotImplementedError("gradients through the super-resolved planes (EDSR backward) are not implemented yet")
+        if any(p.requires_grad for n, p in model_fine.named_parameters() if "rot_mats" not in n):
+            import warnings
+            warnings.warn("nvsr_amd: decoder parameters require grad but only plane gradients are implemented; decoder grads stay None")
+        names = [models.get_plane_name(scene_id, d) for d in range(4)]
+        leaves = [model_fine.planes_[n] for n in names]
+        coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
+        cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=int(bool(m.lindisp)), white=int(bool(m.white_background)), t_rand=t_rand, u=u,
+                   noise_c=n_c, noise_f=n_f, scene_c=sc_c, scene_f=sc_f, keep=(keep_c, keep_f), packed_c=packed_c, packed_f=packed_f,
+                   packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
+                   plane_shapes=[tuple(k.shape) for k in keep_f], coarse_grad=coarse_grad)
+        outs = _RenderRaysFn.apply(cfg, *leaves)
+        if Nf > 0:
+            return outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], None, None, None
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
     rgb_c = torch.empty((N, 3), dtype=torch.float32, device=dev)
     disp_c, acc_c = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2))

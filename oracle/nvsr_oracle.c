@@ -651,3 +651,243 @@ ORC_EXPORT void orc_flexible_nerf(long P, const float* x /*[P,dim_xyz+dim_dir]*/
         out[4 * i + 3] = alpha;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of one training step with respect to the feature planes (the reference gets it from torch.autograd through
+ * train_utils.py:185-282; decoder frozen as in Feature_Planes_Only.yml).  Analytic chain rule in double:
+ *   composite (volume_rendering_utils.py:18-49) -> sigma/rgb heads -> ReLU MLPs (models.py:395-421) -> 'avg' / 'concat_pos'
+ *   combination (models.py:355-379) -> transposed bilinear taps of grid_sample (models.py:303-326).
+ * Pinned against tests/golden/g11_grads.npz (autograd of the reference itself).
+ */
+typedef struct {
+    int ix, iy, x1ok, y1ok;
+    double w[4]; /* nw, ne, sw, se */
+} orc_taps;
+
+static void orc_plane_taps(int Hp, int Wp, float gx, float gy, orc_taps* t) {
+    const float x = orc_grid_loc(gx, Wp), y = orc_grid_loc(gy, Hp);
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    t->w[0] = s * e; t->w[1] = s * w; t->w[2] = n * e; t->w[3] = n * w;
+    t->ix = (int)xw; t->iy = (int)yn;
+    t->x1ok = (t->ix + 1 <= Wp - 1); t->y1ok = (t->iy + 1 <= Hp - 1);
+}
+
+#define ORC_MAXH 256
+typedef struct {
+    orc_taps taps[4];
+    double in_rgb[4 * 64], in_den[64];
+    double h_den[8][ORC_MAXH], h_rgb[8][ORC_MAXH]; /* post-ReLU activations per layer */
+    double raw[4];
+} orc_act;
+
+static void orc_lin_d(const float* W, const float* b, const double* x, int in, int out, int relu, double* y) {
+    for (int o = 0; o < out; ++o) {
+        double a = b[o];
+        const float* w = W + (size_t)o * in;
+        for (int k = 0; k < in; ++k) a += x[k] * (double)w[k];
+        y[o] = (relu && a < 0) ? 0.0 : a;
+    }
+}
+
+static void orc_forward_store(const orc_scene* sc, const orc_decoder* dec, const float* x6, orc_act* A) {
+    const int C = dec->C, h = dec->hidden;
+    float x5[5], n5[5];
+    x5[0] = x6[0]; x5[1] = x6[1]; x5[2] = x6[2];
+    x5[3] = atan2f(x6[4], x6[3]);
+    x5[4] = atan2f(x6[5], sqrtf(x6[3] * x6[3] + x6[4] * x6[4]));
+    for (int i = 0; i < 5; ++i) n5[i] = 2.0f * (x5[i] - sc->lo[i]) / sc->range[i] - 1.0f;
+    for (int d = 0; d < 4; ++d) {
+        float gx, gy;
+        if (d < 3) {
+            const float* M = sc->proj[d];
+            gx = n5[0] * M[0] + n5[1] * M[2] + n5[2] * M[4];
+            gy = n5[0] * M[1] + n5[1] * M[3] + n5[2] * M[5];
+        } else { gx = n5[3]; gy = n5[4]; }
+        orc_taps* t = &A->taps[d];
+        orc_plane_taps(sc->ph[d], sc->pw[d], gx, gy, t);
+        const int Hp = sc->ph[d], Wp = sc->pw[d];
+        const size_t HW = (size_t)Hp * Wp;
+        for (int c = 0; c < C; ++c) {
+            const float* p = sc->planes[d] + (size_t)c * HW;
+            double v = p[(size_t)t->iy * Wp + t->ix] * t->w[0];
+            if (t->x1ok) v += p[(size_t)t->iy * Wp + t->ix + 1] * t->w[1];
+            if (t->y1ok) v += p[(size_t)(t->iy + 1) * Wp + t->ix] * t->w[2];
+            if (t->x1ok && t->y1ok) v += p[(size_t)(t->iy + 1) * Wp + t->ix + 1] * t->w[3];
+            A->in_rgb[d * C + c] = v;
+        }
+    }
+    for (int c = 0; c < C; ++c) A->in_den[c] = (A->in_rgb[c] + A->in_rgb[C + c] + A->in_rgb[2 * C + c]) / 3.0;
+    const float* p = dec->blob;
+    const double* cur = A->in_den;
+    int in = C;
+    for (int l = 0; l < dec->n_density_layers; ++l) {
+        orc_lin_d(p, p + (size_t)h * in, cur, in, h, 1, A->h_den[l]);
+        p += (size_t)h * in + h; cur = A->h_den[l]; in = h;
+    }
+    orc_lin_d(p, p + h, cur, h, 1, 0, &A->raw[3]);
+    p += h + 1;
+    cur = A->in_rgb; in = 4 * C;
+    for (int l = 0; l < dec->n_rgb_layers; ++l) {
+        orc_lin_d(p, p + (size_t)h * in, cur, in, h, 1, A->h_rgb[l]);
+        p += (size_t)h * in + h; cur = A->h_rgb[l]; in = h;
+    }
+    orc_lin_d(p, p + 3 * h, cur, h, 3, 0, A->raw);
+}
+
+/* g_raw[4] -> scatter-add into gp[4] (double, NCHW like the planes) */
+static void orc_backward_point(const orc_scene* sc, const orc_decoder* dec, const orc_act* A, const double* g_raw, double* const* gp) {
+    const int C = dec->C, h = dec->hidden, nd = dec->n_density_layers, nr = dec->n_rgb_layers;
+    const float* Wd[8]; const float* Wr[8];
+    const float* p = dec->blob;
+    int in = C;
+    for (int l = 0; l < nd; ++l) { Wd[l] = p; p += (size_t)h * in + h; in = h; }
+    const float* Wa = p; p += h + 1;
+    in = 4 * C;
+    for (int l = 0; l < nr; ++l) { Wr[l] = p; p += (size_t)h * in + h; in = h; }
+    const float* Wc = p;
+    double g[ORC_MAXH], gn[ORC_MAXH], g_in_rgb[4 * 64], g_in_den[64];
+    /* rgb branch */
+    for (int f = 0; f < h; ++f) {
+        double a = 0;
+        for (int c = 0; c < 3; ++c) a += (double)Wc[(size_t)c * h + f] * g_raw[c];
+        g[f] = A->h_rgb[nr - 1][f] > 0 ? a : 0.0;
+    }
+    for (int l = nr - 1; l >= 1; --l) {
+        for (int k = 0; k < h; ++k) {
+            double a = 0;
+            for (int o = 0; o < h; ++o) a += (double)Wr[l][(size_t)o * h + k] * g[o];
+            gn[k] = A->h_rgb[l - 1][k] > 0 ? a : 0.0;
+        }
+        memcpy(g, gn, sizeof(double) * (size_t)h);
+    }
+    for (int k = 0; k < 4 * C; ++k) {
+        double a = 0;
+        for (int o = 0; o < h; ++o) a += (double)Wr[0][(size_t)o * 4 * C + k] * g[o];
+        g_in_rgb[k] = a;
+    }
+    /* density branch */
+    for (int f = 0; f < h; ++f) g[f] = A->h_den[nd - 1][f] > 0 ? (double)Wa[f] * g_raw[3] : 0.0;
+    for (int l = nd - 1; l >= 1; --l) {
+        for (int k = 0; k < h; ++k) {
+            double a = 0;
+            for (int o = 0; o < h; ++o) a += (double)Wd[l][(size_t)o * h + k] * g[o];
+            gn[k] = A->h_den[l - 1][k] > 0 ? a : 0.0;
+        }
+        memcpy(g, gn, sizeof(double) * (size_t)h);
+    }
+    for (int k = 0; k < C; ++k) {
+        double a = 0;
+        for (int o = 0; o < h; ++o) a += (double)Wd[0][(size_t)o * C + k] * g[o];
+        g_in_den[k] = a;
+    }
+    for (int d = 0; d < 4; ++d) {
+        const orc_taps* t = &A->taps[d];
+        const int Hp = sc->ph[d], Wp = sc->pw[d];
+        const size_t HW = (size_t)Hp * Wp;
+        for (int c = 0; c < C; ++c) {
+            const double gf = g_in_rgb[d * C + c] + (d < 3 ? g_in_den[c] / 3.0 : 0.0);
+            double* q = gp[d] + (size_t)c * HW;
+            q[(size_t)t->iy * Wp + t->ix] += t->w[0] * gf;
+            if (t->x1ok) q[(size_t)t->iy * Wp + t->ix + 1] += t->w[1] * gf;
+            if (t->y1ok) q[(size_t)(t->iy + 1) * Wp + t->ix] += t->w[2] * gf;
+            if (t->x1ok && t->y1ok) q[(size_t)(t->iy + 1) * Wp + t->ix + 1] += t->w[3] * gf;
+        }
+    }
+}
+
+/* d(rgb, acc)/d raw of one ray; g_rgb[3], g_acc upstream; g_raw [S,4] out */
+static void orc_composite_backward_ray(int S, const double* raw /*[S,4]*/, const float* z, const float* rd3, const float* noise, int white,
+                                       const double* g_rgb, double g_acc, double* g_raw) {
+    const double nrm = sqrt((double)rd3[0] * rd3[0] + (double)rd3[1] * rd3[1] + (double)rd3[2] * rd3[2]);
+    double* alpha = (double*)malloc(sizeof(double) * 6 * (size_t)S);
+    double *T = alpha + S, *w = alpha + 2 * S, *gw = alpha + 3 * S, *dist = alpha + 4 * S, *sig = alpha + 5 * S;
+    double Tr = 1.0;
+    for (int s = 0; s < S; ++s) {
+        dist[s] = ((s == S - 1) ? 1e10 : ((double)z[s + 1] - (double)z[s])) * nrm;
+        double sg = raw[4 * s + 3] + (noise ? (double)noise[s] : 0.0);
+        sig[s] = sg;
+        sg = sg > 0 ? sg : 0;
+        alpha[s] = 1.0 - exp(-sg * dist[s]);
+        T[s] = Tr;
+        w[s] = alpha[s] * Tr;
+        Tr *= (1.0 - alpha[s] + 1e-10);
+    }
+    const double ga = g_acc - (white ? (g_rgb[0] + g_rgb[1] + g_rgb[2]) : 0.0);
+    double suffix = 0.0;   /* sum_{k>s} w_k * dL/dw_k */
+    for (int s = S - 1; s >= 0; --s) {
+        double c[3];
+        for (int k = 0; k < 3; ++k) c[k] = 1.0 / (1.0 + exp(-raw[4 * s + k]));
+        gw[s] = g_rgb[0] * c[0] + g_rgb[1] * c[1] + g_rgb[2] * c[2] + ga;
+        for (int k = 0; k < 3; ++k) g_raw[4 * s + k] = w[s] * g_rgb[k] * c[k] * (1.0 - c[k]);
+        const double g_alpha = T[s] * gw[s] - suffix / (1.0 - alpha[s] + 1e-10);
+        g_raw[4 * s + 3] = (sig[s] > 0) ? g_alpha * dist[s] * (1.0 - alpha[s]) : 0.0;
+        suffix += w[s] * gw[s];
+    }
+    free(alpha);
+}
+
+/* One train step: forward recomputed in double, gradient of (sum g_rgb_c . rgb_c + sum g_rgb_f . rgb_f) wrt the 4 planes.
+ * grad planes: NCHW float [C,H,W] each (overwritten). */
+ORC_EXPORT void orc_render_backward(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
+                                    long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
+                                    const float* noise_f, const float* g_rgb_c /*[N,3] or NULL*/, const float* g_rgb_f /*[N,3] or NULL*/,
+                                    const float* z_fine_in /*[N,Nc+Nf] or NULL: use these fine depths instead of resampling*/,
+                                    float* gp0, float* gp1, float* gp2, float* gpv) {
+    const int Nc = cfg->num_coarse, Nf = cfg->num_fine, St = Nc + Nf, C = coarse->C;
+    float* gout[4] = {gp0, gp1, gp2, gpv};
+    double* gp[4];
+    for (int d = 0; d < 4; ++d) gp[d] = (double*)calloc((size_t)C * sc->ph[d] * sc->pw[d], sizeof(double));
+    orc_act* acts = (orc_act*)malloc(sizeof(orc_act) * (size_t)(St > Nc ? St : Nc));
+    float* z = (float*)malloc(sizeof(float) * (size_t)(St + 4));
+    float* zs = (float*)malloc(sizeof(float) * (size_t)(Nf + 4));
+    float* zm = (float*)malloc(sizeof(float) * (size_t)(Nc + 4));
+    float* rawf = (float*)malloc(sizeof(float) * 4 * (size_t)(St + 4));
+    double* rawd = (double*)malloc(sizeof(double) * 4 * (size_t)(St + 4));
+    double* graw = (double*)malloc(sizeof(double) * 4 * (size_t)(St + 4));
+    float* w = (float*)malloc(sizeof(float) * (size_t)(St + 4));
+    float* ud = (float*)malloc(sizeof(float) * (size_t)(Nf + 4));
+    for (long i = 0; i < N; ++i) {
+        const float* r = rays + 11 * i;
+        float x6[6], rgb3[3], dsp, ac, dep;
+        x6[3] = r[8]; x6[4] = r[9]; x6[5] = r[10];
+        orc_coarse_z(1, Nc, r + 6, r + 7, cfg->lindisp, cfg->perturb, t_rand ? t_rand + (size_t)i * Nc : NULL, z);
+        for (int s = 0; s < Nc; ++s) {
+            for (int k = 0; k < 3; ++k) x6[k] = r[k] + r[3 + k] * z[s];
+            orc_forward_store(sc, coarse, x6, &acts[s]);
+            for (int k = 0; k < 4; ++k) { rawd[4 * s + k] = acts[s].raw[k]; rawf[4 * s + k] = (float)acts[s].raw[k]; }
+        }
+        if (g_rgb_c) {
+            const double g3[3] = {g_rgb_c[3 * i], g_rgb_c[3 * i + 1], g_rgb_c[3 * i + 2]};
+            orc_composite_backward_ray(Nc, rawd, z, r + 3, noise_c ? noise_c + (size_t)i * Nc : NULL, cfg->white_background, g3, 0.0, graw);
+            for (int s = 0; s < Nc; ++s) orc_backward_point(sc, coarse, &acts[s], graw + 4 * s, gp);
+        }
+        if (Nf <= 0 || !g_rgb_f) continue;
+        if (z_fine_in) {
+            memcpy(z, z_fine_in + (size_t)i * St, sizeof(float) * (size_t)St);
+        } else {
+            orc_composite_ray(Nc, rawf, z, r + 3, noise_c ? noise_c + (size_t)i * Nc : NULL, cfg->white_background, rgb3, &dsp, &ac, w, &dep);
+            for (int s = 0; s < Nc - 1; ++s) zm[s] = 0.5f * (z[s + 1] + z[s]);
+            const float* ui;
+            if (u) ui = u + (size_t)i * Nf;
+            else { for (int j = 0; j < Nf; ++j) ud[j] = orc_linspace01(j, Nf); ui = ud; }
+            orc_sample_pdf_ray(Nc - 1, Nf, zm, w + 1, ui, zs);      /* detached: no gradient through the depths (train_utils.py:153) */
+            memcpy(z + Nc, zs, sizeof(float) * (size_t)Nf);
+            qsort(z, (size_t)St, sizeof(float), orc_cmp_float);
+        }
+        for (int s = 0; s < St; ++s) {
+            for (int k = 0; k < 3; ++k) x6[k] = r[k] + r[3 + k] * z[s];
+            orc_forward_store(sc, fine, x6, &acts[s]);
+            for (int k = 0; k < 4; ++k) rawd[4 * s + k] = acts[s].raw[k];
+        }
+        const double g3[3] = {g_rgb_f[3 * i], g_rgb_f[3 * i + 1], g_rgb_f[3 * i + 2]};
+        orc_composite_backward_ray(St, rawd, z, r + 3, noise_f ? noise_f + (size_t)i * St : NULL, cfg->white_background, g3, 0.0, graw);
+        for (int s = 0; s < St; ++s) orc_backward_point(sc, fine, &acts[s], graw + 4 * s, gp);
+    }
+    for (int d = 0; d < 4; ++d) {
+        const size_t n = (size_t)C * sc->ph[d] * sc->pw[d];
+        for (size_t k = 0; k < n; ++k) gout[d][k] = (float)gp[d][k];
+        free(gp[d]);
+    }
+    free(acts); free(z); free(zs); free(zm); free(rawf); free(rawd); free(graw); free(w); free(ud);
+}

@@ -181,6 +181,18 @@ class Oracle:
             o["raw"] = raw
         return o
 
+    def render_backward(self, scene, plane_shapes, dec_c, dec_f, rays, num_coarse, num_fine, g_rgb_coarse, g_rgb_fine, lindisp=False,
+                        perturb=False, white_background=False, t_rand=None, u=None, noise_coarse=None, noise_fine=None, z_fine=None):
+        """gradient of sum(g_rgb_coarse * rgb_coarse) + sum(g_rgb_fine * rgb_fine) wrt the 4 planes ([C,H,W] each)"""
+        rays = _f(rays)
+        N = rays.shape[0]
+        cfg = _Cfg(num_coarse, num_fine, int(lindisp), int(perturb), int(white_background))
+        t_rand, u, nc, nf, gc, gf, zf = (None if a is None else _f(a) for a in (t_rand, u, noise_coarse, noise_fine, g_rgb_coarse, g_rgb_fine, z_fine))
+        grads = [np.zeros(tuple(sh[-3:]), np.float32) for sh in plane_shapes]
+        self.lib.orc_render_backward(scene, C.byref(dec_c), C.byref(dec_f), C.byref(cfg), C.c_long(N), _p(rays), _p(t_rand), _p(u), _p(nc),
+                                     _p(nf), _p(gc), _p(gf), _p(zf), *[_p(g) for g in grads])
+        return grads
+
     # -- feature-plane super-resolution -----------------------------------------------------------
     @staticmethod
     def edsr_blob(sd, prefix="inner_model.", nblocks=None, n_up=2):

@@ -19,6 +19,7 @@ Fixture index:
   g08_render.npz      eval_nerf / run_one_iter_of_nerf  train_utils.py:185-331 (16x16 rays)
   g09_edsr.npz        EDSR + PlanesSR (mini net)        models.py:769-926
   g10_posenc.npz      positional_encoding, FlexibleNeRFModel   nerf_helpers.py:552-575, models.py:14-108
+  g11_grads.npz       autograd of one train step wrt the planes (train_nerf.py:860-903)
 """
 import os
 import sys
@@ -553,9 +554,62 @@ def g10_posenc():
     save("g10_posenc.npz", **arrs)
 
 
+def g11_grads():
+    """d(mse_coarse + mse_fine)/d planes through run_one_iter_of_nerf (train_nerf.py:860,884-891,903), decoder frozen like
+    Feature_Planes_Only.yml; case 0: train mode (perturb + density noise + random u), case 1: deterministic sampling."""
+    R, Rv = 16, 8
+    sid, mc, mf, planes, box = build_models(R, Rv, 0.5, seed=11)
+    H = W = 16
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+    arrs = dict(box=npy(box), hwf=np.array([H, W, focal], dtype=np.float64))
+    for dnum in range(4):
+        arrs["plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
+    arrs.update(state_arrays("coarse.", mc))
+    arrs.update(state_arrays("fine.", mf))
+    torch.manual_seed(110)
+    sel = torch.randperm(H * W)[:64]
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    target = torch.rand(64, 3)
+    arrs.update(rays=npy(rays), target=npy(target))
+    N = 64
+    for ci, (nc, nf, perturb, std) in enumerate([(32, 32, True, 0.2), (24, 40, False, 0.0)]):
+        vt = mode_cfg(nc, nf, perturb=perturb, noise=std)
+        cfg = make_cfg(vt, vt)
+        mc.train(); mf.train()
+        for p_ in planes.values():
+            p_.grad = None
+        torch.manual_seed(111 + ci)
+        rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(H, W, focal, mc, mf, rays, cfg, scene_id=sid, mode="train",
+                                                             scene_config=cfg.dataset["synt"])
+        loss = torch.nn.functional.mse_loss(rc, target) + torch.nn.functional.mse_loss(rf, target)
+        loss.backward()
+        torch.manual_seed(111 + ci)
+        if perturb:
+            arrs["c%d_t_rand" % ci] = npy(torch.rand(N, nc))
+        if std > 0:
+            arrs["c%d_noise_coarse" % ci] = npy(torch.randn(N, nc) * std)
+        if perturb:
+            arrs["c%d_u" % ci] = npy(torch.rand(N, nf))
+        if std > 0:
+            arrs["c%d_noise_fine" % ci] = npy(torch.randn(N, nc + nf) * std)
+        arrs["c%d_params" % ci] = np.array([nc, nf, int(perturb), std])
+        arrs["c%d_rgb_coarse" % ci] = npy(rc)
+        arrs["c%d_rgb_fine" % ci] = npy(rf)
+        arrs["c%d_loss" % ci] = np.array(float(loss))
+        for dnum in range(4):
+            g_ = planes[models.get_plane_name(sid, dnum)].grad
+            arrs["c%d_grad_plane%d" % (ci, dnum)] = npy(g_)
+        print("   grads case %d: loss %.5f, |grad| per plane %s, nonzero texel fraction %.2f" % (
+            ci, float(loss), ["%.2e" % float(planes[models.get_plane_name(sid, d)].grad.abs().mean()) for d in range(4)],
+            float((planes[models.get_plane_name(sid, 0)].grad.abs().sum(1) > 0).float().mean())))
+    arrs["n_cases"] = np.array(2)
+    save("g11_grads.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

@@ -484,3 +484,128 @@ def test_positional_encoding_and_nerf_mlp_golden(hip):
     m = m.to(DEV)
     x = torch.cat([pe(T(g["nerf_pts"]), 6), pe(T(g["nerf_dirs"]), 4)], -1)
     np.testing.assert_allclose(N_(m(x)), g["nerf_out"], rtol=0, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training: gradients with respect to the feature planes
+def _grad_models(hip, g, planes, sid):
+    mc, _ = build_model(hip, sd(g, "coarse."), planes, g["box"], sid=sid)
+    mf, _ = build_model(hip, sd(g, "fine."), planes, g["box"], sid=sid)
+    mf.planes_ = mc.planes_
+    for m in (mc, mf):
+        for n, p in m.named_parameters():
+            p.requires_grad_("planes_" in n)   # decoder frozen (Feature_Planes_Only.yml); the planes are the leaves
+        m.train()
+    return mc, mf
+
+
+def test_plane_gradients_golden(hip):
+    """loss.backward() through run_one_iter_of_nerf vs torch.autograd through the reference (g11)"""
+    g = load_golden("g11_grads.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    sid = "lego_DS8_PlRes16_8"
+    mc, mf = _grad_models(hip, g, planes, sid)
+    rays = T(g["rays"])
+    target = T(g["target"])
+    for ci in range(int(g["n_cases"])):
+        nc, nf, perturb, std = g["c%d_params" % ci]
+        opts, scfg = make_options(int(nc), int(nf), perturb=bool(perturb), noise=float(std))
+        rnd = {k: T(g["c%d_%s" % (ci, k)]) for k in ("t_rand", "u", "noise_coarse", "noise_fine") if "c%d_%s" % (ci, k) in g}
+        for p_ in mc.planes_.values():
+            p_.grad = None
+        out = hip.train_utils.run_one_iter_of_nerf(16, 16, float(g["hwf"][2]), mc, mf, rays, opts, sid, mode="train", scene_config=scfg,
+                                                   randoms=rnd)
+        np.testing.assert_allclose(N_(out[0]), g["c%d_rgb_coarse" % ci], rtol=0, atol=2e-5)
+        loss = torch.nn.functional.mse_loss(out[0], target) + torch.nn.functional.mse_loss(out[3], target)
+        assert abs(float(loss) - float(g["c%d_loss" % ci])) < 2e-4
+        loss.backward()
+        for d in range(4):
+            got = N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad)
+            ref = g["c%d_grad_plane%d" % (ci, d)]
+            assert got.shape == ref.shape
+            # the fine depths are regenerated by each side: a few importance samples move (sample_pdf conditioning) and shift
+            # gradient between neighbouring texels, so the end-to-end comparison is in aggregate
+            rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            assert rel < 1e-2, "case %d plane %d: relative L2 error %.2e" % (ci, d, rel)
+            assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
+
+
+def test_composite_backward_vs_autograd_formula(hip):
+    """nvsr_composite_backward against torch.autograd of the same formula evaluated in float64 on the host"""
+    rng = np.random.default_rng(21)
+    N, S = 37, 96
+    raw = rng.standard_normal((N, S, 4)).astype(np.float32) * 2
+    raw[..., 3] = raw[..., 3] * 3 - 1
+    raw[3, 10, 3] = 60.0                      # an opaque sample: everything behind it has T ~ 1e-10
+    z = np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1)
+    rd = rng.standard_normal((N, 3)).astype(np.float32)
+    noise = (rng.standard_normal((N, S)) * 0.2).astype(np.float32)
+    g_rgb = rng.standard_normal((N, 3)).astype(np.float32)
+    g_acc = rng.standard_normal(N).astype(np.float32)
+    for white in (0, 1):
+        r64 = torch.tensor(raw, dtype=torch.float64, requires_grad=True)
+        z64, rd64, n64 = (torch.tensor(a, dtype=torch.float64) for a in (z, rd, noise))
+        dists = torch.cat([z64[:, 1:] - z64[:, :-1], torch.full((N, 1), 1e10, dtype=torch.float64)], -1) * rd64.norm(dim=-1, keepdim=True)
+        alpha = 1.0 - torch.exp(-torch.relu(r64[..., 3] + n64) * dists)
+        T_ = torch.cumprod(torch.cat([torch.ones(N, 1, dtype=torch.float64), (1.0 - alpha + 1e-10)[:, :-1]], -1), -1)
+        w = alpha * T_
+        rgb = (w[..., None] * torch.sigmoid(r64[..., :3])).sum(1)
+        acc = w.sum(-1)
+        if white:
+            rgb = rgb + (1.0 - acc[:, None])
+        (rgb * torch.tensor(g_rgb, dtype=torch.float64)).sum().add((acc * torch.tensor(g_acc, dtype=torch.float64)).sum()).backward()
+        ref = r64.grad.numpy()
+        capi = hip.capi
+        raw_d, z_d, rd_d, n_d, gr_d, ga_d = T(raw), T(z), T(rd), T(noise), T(g_rgb), T(g_acc)
+        out = torch.empty((N, S, 4), device=DEV)
+        capi.call("nvsr_composite_backward", N, S, capi.ptr(raw_d), capi.ptr(z_d), capi.ptr(rd_d), capi.ptr(n_d), white, capi.ptr(gr_d),
+                  capi.ptr(ga_d), capi.ptr(out), capi.stream())
+        got = N_(out)
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale)
+
+
+def test_plane_gradients_vs_oracle_larger(hip, oracle):
+    """600 rays, planes 40x56 (non-square) + view 12x12, 48+80 samples, white background: HIP backward vs the analytic oracle,
+    first at the SAME fine depths (isolates the backward kernels), then end to end (depths regenerated by each side)."""
+    g = load_golden("g11_grads.npz")
+    rng = np.random.default_rng(31)
+    planes = [rng.standard_normal((1, 48, 40, 56), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 12, 12), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes40_12"
+    mc, mf = _grad_models(hip, g, planes, sid)
+    N, nc, nf = 600, 48, 80
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(load_golden("g08_render.npz")["pose"]))
+    sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
+    batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    opts, scfg = make_options(nc, nf, white=True)
+    out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+    z_fine = N_(out[3].grad_fn.saved["z_f"]) if hasattr(out[3].grad_fn, "saved") else None
+    gc = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+    gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+    ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+    sc = oracle.scene(planes, g["box"])
+    rays_np = oracle.pack_rays(N_(batch[0]), N_(batch[1]), 2.0, 6.0)
+    dec_c, dec_f = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    grads = [N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad)[0] for d in range(4)]
+    assert z_fine is not None
+    same_z = oracle.render_backward(sc, [p.shape for p in planes], dec_c, dec_f, rays_np, nc, nf, N_(gc), N_(gf), white_background=True,
+                                    z_fine=z_fine)
+    for d in range(4):
+        rel = np.linalg.norm(grads[d] - same_z[d]) / np.linalg.norm(same_z[d])
+        # the view-direction plane sums every sample of a ray into the same 4 texels with mixed signs: its net gradient is ~1000x
+        # smaller than the terms added, so fp32 summation order shows (the reference's own fp32 autograd has the same noise)
+        # position planes: ReLU pre-activations / last-sample sigmas within fp32 noise of zero flip their mask between the fp32
+        # kernel and the double oracle for a handful of points; each flip moves a finite amount of gradient
+        assert rel < (2e-3 if d < 3 else 5e-3), "same depths, plane %d: relative L2 error %.2e" % (d, rel)
+    e2e = oracle.render_backward(sc, [p.shape for p in planes], dec_c, dec_f, rays_np, nc, nf, N_(gc), N_(gf), white_background=True)
+    for d in range(4):
+        rel = np.linalg.norm(grads[d] - e2e[d]) / np.linalg.norm(e2e[d])
+        assert rel < 1e-2, "end to end, plane %d: relative L2 error %.2e" % (d, rel)
+    # a second backward accumulates into .grad like any autograd leaf
+    g0 = mc.planes_[hip.models.get_plane_name(sid, 0)].grad.clone()
+    out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+    ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+    assert torch.allclose(mc.planes_[hip.models.get_plane_name(sid, 0)].grad, 2 * g0, rtol=1e-3, atol=1e-7)
