@@ -100,6 +100,10 @@ int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, i
 int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                    float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream);
 
+/* same with the ray directions taken from packed rays [N,11] (columns 3..5) */
+int nvsr_composite_rays(int64_t N, int S, const float* raw, const float* z, const float* rays, const float* noise, int white_bkgd,
+                        float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream);
+
 /* ---- fused per-ray render pass --------------------------------------------------------------------------------------
  * run_network + TwoDimPlanesModel.forward + volume_render_radiance_field for one pass (train_utils.py:111-139 or :156-180):
  * points ro + rd*z are generated, decoded and composited inside one kernel; no [N,S,*] intermediate reaches HBM.
@@ -108,8 +112,15 @@ int nvsr_render_pass(const nvsr_scene* scene, const float* packed_decoder, int64
                      const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
                      nvsr_stream_t stream);
 
+/* Un-fused variant for small ray counts (training batches): decoder outputs raw [N,S,4] for all samples of all rays, tiled over
+ * (ray block, sample) so that N*S/128 workgroup-steps fill the chip; feed raw to nvsr_composite. */
+int nvsr_decode_rays(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                     float* raw, nvsr_stream_t stream);
+
 /* predict_and_render_radiance (train_utils.py:71-182) for a ray chunk: coarse z -> coarse pass -> importance resample ->
- * fine pass.  workspace: nvsr_render_workspace_floats(N, Nc, Nf) floats.  Nf == 0: coarse only (fine outputs untouched). */
+ * fine pass.  workspace: nvsr_render_workspace_floats(N, Nc, Nf) floats.  Nf == 0: coarse only (fine outputs untouched).
+ * Up to NVSR_FUSED_MIN_RAYS rays the passes run un-fused (nvsr_decode_rays + nvsr_composite), above it fused (nvsr_render_pass). */
+#define NVSR_FUSED_MIN_RAYS 65536
 int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf);
 int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
                      const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u,

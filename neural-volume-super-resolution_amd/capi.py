@@ -49,7 +49,9 @@ _PROTOS = {
     "nvsr_importance_resample": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
     "nvsr_composite": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_composite_rays": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_decode_rays": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_workspace_floats": ([_i64, _i, _i], _i64),
     "nvsr_render_rays": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp], _i),

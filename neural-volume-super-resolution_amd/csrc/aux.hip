@@ -232,13 +232,13 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
 
 // ---- compositing: one wave per ray, samples across lanes, transmittance by a wave scan ------------------------------------
 __global__ __launch_bounds__(WPB * 64) void composite_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
-                                                            const float* __restrict__ rd, const float* __restrict__ noise, int white,
+                                                            const float* __restrict__ rd, int rd_stride, const float* __restrict__ noise, int white,
                                                             float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc,
                                                             float* __restrict__ weights, float* __restrict__ depth) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * WPB + wave;
     if (ray >= N) return;
-    const float d0 = rd[ray * 3], d1 = rd[ray * 3 + 1], d2 = rd[ray * 3 + 2];
+    const float d0 = rd[ray * rd_stride], d1 = rd[ray * rd_stride + 1], d2 = rd[ray * rd_stride + 2];
     const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
     const float* zr = z + ray * S;
     const f32x4* rr = reinterpret_cast<const f32x4*>(raw) + ray * S;
@@ -387,13 +387,37 @@ int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const flo
     if (!aligned16(raw)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rd, noise,
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rd, 3, noise,
                        white_bkgd, rgb, disp, acc, weights, depth);
     return NVSR_CHECK_LAUNCH();
 }
 
+/* same, reading the directions out of packed rays [N,11] (columns 3..5) */
+int nvsr_composite_rays(int64_t N, int S, const float* raw, const float* z, const float* rays, const float* noise, int white_bkgd,
+                        float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream) {
+    if (!raw || !z || !rays || !rgb || !disp || !acc) return NVSR_ERR_NULL;
+    if (!aligned16(raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rays + 3, 11,
+                       noise, white_bkgd, rgb, disp, acc, weights, depth);
+    return NVSR_CHECK_LAUNCH();
+}
+
 int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf) {
-    return N * (int64_t)(2 * Nc + (Nf > 0 ? Nc + Nf : 0));
+    const int64_t base = N * (int64_t)(2 * Nc + (Nf > 0 ? Nc + Nf : 0));
+    return base + (N < NVSR_FUSED_MIN_RAYS ? 4 * N * (int64_t)(Nc + (Nf > 0 ? Nf : 0)) : 0);   // + raw [N,S,4] for the un-fused path
+}
+
+static int render_one_pass(const nvsr_scene* scene, const float* packed, int64_t N, int S, const float* rays, const float* z,
+                           const float* noise, int white, float* rgb, float* disp, float* acc, float* weights, float* raw_ws,
+                           nvsr_stream_t stream) {
+    if (N >= NVSR_FUSED_MIN_RAYS)
+        return nvsr_render_pass(scene, packed, N, S, rays, z, noise, white, rgb, disp, acc, weights, nullptr, stream);
+    // few rays: one workgroup per 128 rays would leave most CUs idle -> tile over samples, composite separately
+    if (int e = nvsr_decode_rays(scene, packed, N, S, rays, z, raw_ws, stream)) return e;
+    // rd = rays[:, 3:6]: the composite kernel reads rd with stride 3, so pass a strided view through a tiny repack
+    return nvsr_composite_rays(N, S, raw_ws, z, rays, noise, white, rgb, disp, acc, weights, nullptr, stream);
 }
 
 int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
@@ -408,15 +432,15 @@ int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const 
     float* z_c = workspace;
     float* w_c = z_c + N * Nc;
     float* z_f = w_c + N * Nc;
+    float* raw_ws = z_f + (Nf > 0 ? N * (int64_t)(Nc + Nf) : 0);
     int e = nvsr_coarse_z(N, Nc, rays, lindisp, t_rand, z_c, stream);
     if (e) return e;
-    e = nvsr_render_pass(scene, packed_coarse, N, Nc, rays, z_c, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, Nf > 0 ? w_c : nullptr,
-                         nullptr, stream);
+    e = render_one_pass(scene, packed_coarse, N, Nc, rays, z_c, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, Nf > 0 ? w_c : nullptr,
+                        raw_ws, stream);
     if (e || Nf <= 0) return e;
     e = nvsr_importance_resample(N, Nc, Nf, z_c, w_c, u, z_f, stream);
     if (e) return e;
-    return nvsr_render_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, nullptr,
-                            stream);
+    return render_one_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, raw_ws, stream);
 }
 
 }  // extern "C"

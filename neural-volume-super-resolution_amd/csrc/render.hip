@@ -46,6 +46,35 @@ __global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, co
 }
 
 // =====================================================================================================================
+// Decoder over the samples of a ray block WITHOUT fusing the compositing: raw [N,S,4].  Used when there are too few rays to
+// fill the chip with one workgroup per 128 rays (training batches: 4096 rays = 32 workgroups): tiles are (ray block, sample)
+// pairs, so N*S/128 workgroup-steps are spread over the whole grid; nvsr_composite then consumes raw.
+// =====================================================================================================================
+__global__ __launch_bounds__(TPB, 2) void decode_rays_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                             const float* __restrict__ rays, const float* __restrict__ z,
+                                                             float* __restrict__ raw_out) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    decode_prologue<NWAVES>(rs);
+    const long nrb = (N + PTS_PER_WG - 1) / PTS_PER_WG;
+    const long ntiles = nrb * S;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
+        const long rb = tile / S;
+        const int s = (int)(tile - rb * S);
+        long ray = rb * PTS_PER_WG + rs.wave * 32 + (rs.lane & 31);
+        const bool valid = ray < N;
+        if (!valid) ray = N - 1;
+        const float* r = rays + ray * 11;
+        const float zc = z[ray * S + s];
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        float raw[4];
+        decode_step<NWAVES>(sc, rs, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
+                            __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw);
+        if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+}
+
+// =====================================================================================================================
 // Fused render pass: rays [N,11], depths z [N,S] -> per-ray rgb / disp / acc (/ weights / depth)
 // =====================================================================================================================
 // Per-ray constants live in LDS (16 floats per ray, 8 KB per workgroup) and are re-read every step: kept in VGPRs they push
@@ -215,6 +244,20 @@ int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, i
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(triplane_decode_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
                        (long)P, x, out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_decode_rays(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                     float* raw, nvsr_stream_t stream) {
+    if (int e = check_scene(scene)) return e;
+    if (!packed_decoder || !rays || !z || !raw) return NVSR_ERR_NULL;
+    if (!aligned16(packed_decoder) || !aligned16(raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    hipLaunchKernelGGL(decode_rays_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N, S, rays,
+                       z, raw);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -20,7 +20,7 @@ constexpr int BNW = BTPB / 64;
 constexpr int BPTS = BNW * 32;
 constexpr int RAYB_FLOATS = 16;
 constexpr int TILE_FLOATS = 32 * C;       // per-wave transposition tile [32 points][48 channels]
-constexpr int BWD_LDS_FLOATS = LDS_FLOATS + BPTS * RAYB_FLOATS + BNW * TILE_FLOATS;
+constexpr int BWD_LDS_FLOATS = LDS_FLOATS + BPTS * RAYB_FLOATS + BNW * TILE_FLOATS;   // (the RAYB region is unused padding now)
 static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 // ---- transposed-weight blob ("packed_bwd"), in consumption order ------------------------------------------------------------
@@ -160,35 +160,25 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<BNW>(rs);
-    const int lane0 = rs.lane, h0 = lane0 >> 5;
-    const long ray0 = (long)blockIdx.x * BPTS + rs.wave * 32 + (lane0 & 31);
-    const bool valid = ray0 < N;
-    const long ray = valid ? ray0 : N - 1;
-    float* rc = lds + LDS_FLOATS + (rs.wave * 32 + (lane0 & 31)) * RAYB_FLOATS;
     float* tile = lds + LDS_FLOATS + BPTS * RAYB_FLOATS + rs.wave * TILE_FLOATS;
-    {
-        const float* r = rays + ray * 11;
-        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
-        if (lane0 < 32) {
-            reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], r[3]};
-            reinterpret_cast<f32x4*>(rc)[1] = f32x4{r[4], r[5], 0.0f, 0.0f};
-            reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
-            reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
-        }
-    }
     const float* small = lds + 2 * SLOT_FLOATS;
     constexpr int HH = P_HID_FLOATS / 2;
+    const long nrb = (N + BPTS - 1) / BPTS;
+    const long ntiles = nrb * S;            // tiles = (ray block, sample): every sample of every ray is independent here
 
-    for (int s = 0; s < S; ++s) {
+    for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
+        const long rb = tix / S;
+        const int s = (int)(tix - rb * S);
+        const long ray0 = rb * BPTS + rs.wave * 32 + (lane & 31);
+        const bool valid = ray0 < N;
+        const long ray = valid ? ray0 : N - 1;
+        const float* r = rays + ray * 11;
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
         const float zc = z[ray * S + s];
         const f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
-        const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
-        const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
-        Taps vt;
-        vt.o00 = __float_as_int(c2[0]); vt.o01 = __float_as_int(c2[1]); vt.o10 = __float_as_int(c2[2]); vt.o11 = __float_as_int(c2[3]);
-        vt.nw = c3[0]; vt.ne = c3[1]; vt.sw = c3[2]; vt.se = c3[3];
+        const f32x4 c0 = f32x4{r[0], r[1], r[2], r[3]}, c1 = f32x4{r[4], r[5], 0.0f, 0.0f};
         const float n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
         const float n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
         const float n2 = norm_coord(__fadd_rn(c0[2], __fmul_rn(c1[1], zc)), sc.lo[2], sc.range[2]);
@@ -444,7 +434,8 @@ int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decod
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    const int64_t grid = (N + BPTS - 1) / BPTS;
+    const int64_t ntiles = ((N + BPTS - 1) / BPTS) * S;
+    const int64_t grid = ntiles < 1024 ? ntiles : 1024;
     hipLaunchKernelGGL(render_pass_backward_kernel, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
                        packed_bwd, (long)N, S, rays, z, g_raw, gp);
     return NVSR_CHECK_LAUNCH();

@@ -62,18 +62,21 @@ class _RenderRaysFn(torch.autograd.Function):
         z_c, w_c, raw_c = f(N, Nc), f(N, Nc), f(N, Nc, 4)
         rgb_c, disp_c, acc_c = f(N, 3), f(N), f(N)
         capi_.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), cfg["lindisp"], capi.ptr(cfg["t_rand"]), capi.ptr(z_c), st)
-        capi_.call("nvsr_render_pass_ex", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c),
-                   capi.ptr(cfg["noise_c"]), cfg["white"], capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None,
-                   capi.ptr(raw_c), st)
+        # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip,
+        # the fused per-ray kernel would run 32 workgroups; raw is needed by the backward anyway
+        capi_.call("nvsr_decode_rays", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(raw_c), st)
+        capi_.call("nvsr_composite_rays", N, Nc, capi.ptr(raw_c), capi.ptr(z_c), capi.ptr(rays), capi.ptr(cfg["noise_c"]), cfg["white"],
+                   capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None, st)
         outs = [rgb_c, disp_c, acc_c]
         saved = dict(z_c=z_c, raw_c=raw_c)
         if Nf > 0:
             z_f, raw_f = f(N, Nc + Nf), f(N, Nc + Nf, 4)
             rgb_f, disp_f, acc_f = f(N, 3), f(N), f(N)
             capi_.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(cfg["u"]), capi.ptr(z_f), st)
-            capi_.call("nvsr_render_pass_ex", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
-                       capi.ptr(cfg["noise_f"]), cfg["white"], capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None,
+            capi_.call("nvsr_decode_rays", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
                        capi.ptr(raw_f), st)
+            capi_.call("nvsr_composite_rays", N, Nc + Nf, capi.ptr(raw_f), capi.ptr(z_f), capi.ptr(rays), capi.ptr(cfg["noise_f"]), cfg["white"],
+                       capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None, st)
             outs += [rgb_f, disp_f, acc_f]
             saved.update(z_f=z_f, raw_f=raw_f)
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)

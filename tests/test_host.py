@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), "libnvsr_hip.so does not export %s" % name
     assert sorted(pkg.capi.exported_symbols()) == declared      # the ctypes prototypes cover the whole header
     assert lib.nvsr_version() >= 100
-    assert lib.nvsr_render_workspace_floats(10, 64, 128) == 10 * (2 * 64 + 192)
+    assert lib.nvsr_render_workspace_floats(10, 64, 128) == 10 * (2 * 64 + 192) + 4 * 10 * 192      # small N: + raw [N,S,4]
+    assert lib.nvsr_render_workspace_floats(640000, 64, 128) == 640000 * (2 * 64 + 192)           # fused path
 
 
 def test_mirror_exposes_reference_surface(pkg):
