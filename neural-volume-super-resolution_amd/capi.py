@@ -11,7 +11,7 @@ import torch
 
 from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
-# developer hook for kernel experiments (scratch/): load an alternative build of the same ABI
+# developer hook for kernel experiments (tools/): load an alternative build of the same ABI
 LIB_PATH = os.environ.get("NVSR_HIP_LIB", _DEFAULT_LIB_PATH)
 
 PLANE_CHANNELS = 48

@@ -4,7 +4,7 @@
 #include "nvsr_common.h"
 
 #ifndef NVSR_ABLATE
-#define NVSR_ABLATE 0   // timing experiments only (scratch/): 1 no gather, 2 no bias/ReLU, 4 no ring barrier, 8 no heads
+#define NVSR_ABLATE 0   // timing experiments only (tools/README.md): 1 no gather, 2 no bias/ReLU, 4 no ring barrier, 8 no heads
 #endif
 
 namespace nvsr {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
 // wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
 // ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every
 // outstanding read, so the next fragment gets 3 MFMAs (192 cycles) to land; left alone hipcc sinks the read to its use.
-// (Measured: a v_mfma_f32_32x32x2_f32 stream fed this way sustains 64.2 cycles per MFMA, scratch/mfma_ubench.hip.)
+// (Measured: a v_mfma_f32_32x32x2_f32 stream fed this way sustains 64.2 cycles per MFMA, tools/mfma_ubench.hip.)
 template <int NG, class BFn>
 __device__ __forceinline__ void mfma_groups(const float* wl, int lane, f32x16 (&acc)[4], BFn b) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wl) + lane;
