@@ -74,8 +74,9 @@ __global__ void ray_bundle_kernel(int H, int W, float fx, float fy, const float*
     const float d2 = -1.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // torch.sum over the 3 products, left to right, no FMA contraction (bit-exact with the reference on CPU)
-        rd[i * 3 + k] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[k * 4 + 0]), __fmul_rn(d1, c2w[k * 4 + 1])), __fmul_rn(d2, c2w[k * 4 + 2]));
+        // torch.sum over the 3 products: accumulator starts at +0.0 (so an all-(-0.0) row sums to +0.0, which matters to atan2 in
+        // cart2az_el), left to right, no FMA contraction -- bit-exact with the reference on CPU including the sign of zero
+        rd[i * 3 + k] = __fadd_rn(__fadd_rn(__fadd_rn(0.0f, __fmul_rn(d0, c2w[k * 4 + 0])), __fmul_rn(d1, c2w[k * 4 + 1])), __fmul_rn(d2, c2w[k * 4 + 2]));
         ro[i * 3 + k] = c2w[k * 4 + 3];
     }
 }

@@ -57,7 +57,8 @@ ORC_EXPORT void orc_get_ray_bundle(int H, int W, double focal_x, double focal_y,
                 volatile float p0 = d0 * c2w[k * 4 + 0];
                 volatile float p1 = d1 * c2w[k * 4 + 1];
                 volatile float p2 = d2 * c2w[k * 4 + 2];
-                volatile float s = p0 + p1;
+                volatile float s0 = 0.0f + p0;   /* torch.sum starts from +0.0: (-0.0) + (-0.0) + (-0.0) must give +0.0 */
+                volatile float s = s0 + p1;
                 d[k] = s + p2;
                 o[k] = c2w[k * 4 + 3];
             }

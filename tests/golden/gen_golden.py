@@ -20,6 +20,7 @@ Fixture index:
   g09_edsr.npz        EDSR + PlanesSR (mini net)        models.py:769-926
   g10_posenc.npz      positional_encoding, FlexibleNeRFModel   nerf_helpers.py:552-575, models.py:14-108
   g11_grads.npz       autograd of one train step wrt the planes (train_nerf.py:860-903)
+  g12_ndc_render.npz  eval_nerf of a forward-facing (LLFF-style) view through NDC rays (train_utils.py:215-218)
 """
 import os
 import sys
@@ -607,9 +608,71 @@ def g11_grads():
     save("g11_grads.npz", **arrs)
 
 
+def g12_ndc_render():
+    """BASELINE config 5 in miniature: no_ndc=False, near=0, far=1 (config dataset.llff), 64+128 samples."""
+    R, Rv = 24, 8
+    torch.manual_seed(12)
+    np.random.seed(12)
+    sid = models.get_scene_id("fern", 8, (R, Rv))
+    sc = models.SceneCoupler([sid], planes_res="LR", num_pos_planes=3, training_scenes=[sid])
+    kw = dict(use_viewdirs=True, skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos",
+              align_corners=True, scene_coupler=sc)
+    mc = models.TwoDimPlanesModel(**kw); mc.optional_no_grad = nh.null_with
+    mf = models.TwoDimPlanesModel(num_planes_or_rot_mats=mc.rot_mats(), **kw); mf.optional_no_grad = nh.null_with
+    planes = nn.ParameterDict([(models.get_plane_name(sid, d), models.create_plane(R if d < 3 else Rv, 48, 0.5)) for d in range(4)])
+    # NDC box: x,y in [-1.2,1.2], z in [-1,1]; view directions of a forward-facing rig
+    box = torch.tensor([[-1.2, -1.2, -1.05, -np.pi, -np.pi / 2], [1.2, 1.2, 1.05, np.pi, np.pi / 2]], dtype=torch.float64)
+    for m in (mc, mf):
+        m.planes_ = planes; m.plane_rank = None; m.generated_planes = {}; m.downsampled_planes = {}; m.coverages = {}
+        m.box_coords = {sid: box}; m.set_cur_scene_id(sid); m.eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(13)
+        pts = torch.rand(4096, 3, generator=g) * 2 - 1
+        d = torch.randn(4096, 3, generator=g); d = d / d.norm(dim=-1, keepdim=True)
+        x = torch.cat([pts, d], -1)
+        for m in (mc, mf):
+            raw = m(x)[:, 3]
+            scale = 8.0 / float(raw.std())         # NDC depths span [0,1]: 4x shorter rays than the synthetic scenes
+            m.fc_alpha["0"].weight.mul_(scale); m.fc_alpha["0"].bias.mul_(scale)
+            raw = m(x)[:, 3]
+            m.fc_alpha["0"].bias.add_(-float(raw.mean()) - 3.0)
+    H, W, focal = 12, 16, 14.0
+    pose = torch.eye(4)
+    pose[:3, 3] = torch.tensor([0.05, -0.03, 0.1])
+    c, s_ = np.cos(0.1), np.sin(0.1)
+    pose[:3, :3] = torch.tensor([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], dtype=torch.float32)
+    ro, rd = nh.get_ray_bundle(H, W, focal, pose)
+    v = mode_cfg(64, 128)
+    cfg = CfgNode({"nerf": {"use_viewdirs": True, "train": v, "validation": v},
+                   "dataset": {"llff": {"near": 0, "far": 1, "no_ndc": False}}})
+    zrec = []
+    real_rn = tu.run_network
+
+    def rec_rn(*a, **k):
+        zrec.append(k["z_vals"].clone())
+        return real_rn(*a, **k)
+
+    tu.run_network = rec_rn
+    try:
+        with torch.no_grad():
+            rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0),
+                                                                 cfg, scene_id=sid, mode="validation", scene_config=cfg.dataset["llff"])
+    finally:
+        tu.run_network = real_rn
+    print("   ndc eval: acc_coarse mean %.3f [%.3f, %.3f]  acc_fine mean %.3f" % (float(ac.mean()), float(ac.min()), float(ac.max()), float(af.mean())))
+    arrs = dict(box=npy(box), pose=npy(pose), hwf=np.array([H, W, focal], dtype=np.float64), ro=npy(ro.contiguous()), rd=npy(rd),
+                rgb_coarse=npy(rc), acc_coarse=npy(ac), disp_coarse=npy(dc), rgb_fine=npy(rf), acc_fine=npy(af), disp_fine=npy(df),
+                z_fine=npy(zrec[1]))
+    for dnum in range(4):
+        arrs["plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
+    arrs.update(state_arrays("coarse.", mc))
+    arrs.update(state_arrays("fine.", mf))
+    save("g12_ndc_render.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

@@ -28,6 +28,13 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
+def assert_bits_equal(a, b):
+    """bit-for-bit, i.e. also the sign of zero (atan2 in cart2az_el turns a -0.0 direction component into -pi instead of +pi)"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def sd(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
 
@@ -73,8 +80,8 @@ def test_ray_bundle_bit_exact(hip):
         H, W, focal, pad, off = g["c%d_params" % i]
         ro, rd = hip.nerf_helpers.get_ray_bundle(int(H), int(W), float(focal), T(g["c%d_c2w" % i]), int(pad), float(off))
         assert tuple(ro.shape) == g["c%d_ro" % i].shape
-        np.testing.assert_array_equal(N_(ro), g["c%d_ro" % i])
-        np.testing.assert_array_equal(N_(rd), g["c%d_rd" % i])
+        assert_bits_equal(N_(ro), g["c%d_ro" % i])
+        assert_bits_equal(N_(rd), g["c%d_rd" % i])
 
 
 def test_ray_bundle_full_size_vs_oracle(hip, oracle):
@@ -82,8 +89,8 @@ def test_ray_bundle_full_size_vs_oracle(hip, oracle):
     focal = 0.5 * 800 / np.tan(0.5 * 0.6911112)
     ro, rd = hip.nerf_helpers.get_ray_bundle(800, 800, focal, T(c2w))
     ro_o, rd_o = oracle.get_ray_bundle(800, 800, focal, c2w)
-    np.testing.assert_array_equal(N_(ro), ro_o)
-    np.testing.assert_array_equal(N_(rd), rd_o)
+    assert_bits_equal(N_(ro), ro_o)
+    assert_bits_equal(N_(rd), rd_o)
 
 
 def test_ndc_rays(hip):
@@ -617,3 +624,22 @@ def test_plane_gradients_vs_oracle_larger(hip, oracle):
     out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
     ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
     assert torch.allclose(mc.planes_[hip.models.get_plane_name(sid, 0)].grad, 2 * g0, rtol=1e-3, atol=1e-7)
+
+
+def test_ndc_render_golden(hip):
+    """BASELINE config 5 in miniature: scene_config.no_ndc = False routes the rays through nvsr_ndc_rays (train_utils.py:215-218)"""
+    g = load_golden("g12_ndc_render.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    sid = "fern_DS8_PlRes24_8"
+    mc, _ = build_model(hip, sd(g, "coarse."), planes, g["box"], sid=sid)
+    mf, _ = build_model(hip, sd(g, "fine."), planes, g["box"], sid=sid)
+    mf.planes_ = mc.planes_
+    H, W, focal = int(g["hwf"][0]), int(g["hwf"][1]), float(g["hwf"][2])
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    assert_bits_equal(N_(rd), g["rd"])        # incl. the sign of the zero y-components of the middle image row
+    opts, _ = make_options(64, 128)
+    scfg = Opt(near=0, far=1, no_ndc=False)
+    img_c, _, _, img_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    np.testing.assert_allclose(N_(img_c).reshape(-1, 3), g["rgb_coarse"], rtol=0, atol=3e-5)
+    err = np.abs(N_(img_f).reshape(-1, 3) - g["rgb_fine"]).max(-1)
+    assert np.mean(err <= 2e-4) >= 0.97 and psnr(N_(img_f).reshape(-1, 3), g["rgb_fine"]) >= 70.0, (np.mean(err <= 2e-4), err.max())

@@ -79,3 +79,29 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dp, f)).read()
                 assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, "%s mentions the oracle" % f
+
+
+def test_plane_store_round_trip_and_backup_fallback(pkg, tmp_path):
+    """the reference's .par plane files (models.py:640-670 / nerf_helpers.py:19-67): same keys, atomic replace, _bckp fallback"""
+    ps, M = pkg.plane_store, pkg.models
+    sid = M.get_scene_id("lego", 8, (6, 4))
+    assert sid == "lego_DS8_PlRes6_4" and M.get_plane_name(sid, 2) == "sclego_DS8_PlRes6_4_D2"
+    planes = torch.nn.ParameterDict({M.get_plane_name(sid, d): M.create_plane(6 if d < 3 else 4, 48, 0.1) for d in range(4)})
+    box = torch.tensor([[-4.0, -4, -4, -3.14, -1.57], [4, 4, 4, 3.14, 1.57]], dtype=torch.float64)
+    path = ps.plane_file(str(tmp_path), sid)
+    assert path.endswith("coarse_lego_DS8_PlRes6_4.par")
+    ps.save_plane_file(path, planes, box)
+    got = ps.load_plane_file(path)
+    assert sorted(got) == ["coords_normalization", "opt_states", "params"] and len(got["opt_states"]) == 4
+    assert all(torch.equal(got["params"][k], planes[k]) for k in planes) and torch.equal(got["coords_normalization"], box)
+    # overwrite keeps exactly one file; a corrupted main file falls back to the backup copy
+    ps.save_plane_file(path, planes, box)
+    assert sorted(os.listdir(tmp_path)) == ["coarse_lego_DS8_PlRes6_4.par"]
+    os.rename(path, path + "_bckp")
+    open(path, "wb").write(b"garbage")
+    assert torch.equal(ps.load_plane_file(path)["coords_normalization"], box)
+    # wiring into a model pair (CPU tensors are fine until a kernel is asked to run)
+    mc = M.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos")
+    mf = M.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", num_planes_or_rot_mats=mc.rot_mats())
+    ps.load_scene([mc, mf], str(tmp_path), sid, device="cpu")
+    assert mc.planes_ is mf.planes_ and mc.cur_id == sid and torch.equal(mf.box_coords[sid], box)

@@ -6,6 +6,13 @@ from conftest import load_golden, sample_pdf_tolerance
 from oracle.oracle import Oracle, decoder_blob
 
 
+def assert_bits_equal(a, b):
+    """bit-for-bit, i.e. also the sign of zero (atan2 in cart2az_el turns a -0.0 direction component into -pi instead of +pi)"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def sd(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
 
@@ -16,8 +23,8 @@ def test_ray_bundle_bit_exact(oracle):
         H, W, focal, pad, off = g["c%d_params" % i]
         ro, rd = oracle.get_ray_bundle(int(H), int(W), float(focal), g["c%d_c2w" % i], int(pad), float(off))
         assert ro.shape == g["c%d_ro" % i].shape
-        np.testing.assert_array_equal(ro, g["c%d_ro" % i])
-        np.testing.assert_array_equal(rd, g["c%d_rd" % i])
+        assert_bits_equal(ro, g["c%d_ro" % i])
+        assert_bits_equal(rd, g["c%d_rd" % i])
 
 
 def test_ndc_rays(oracle):
@@ -229,3 +236,24 @@ def test_plane_gradients_against_reference_autograd(oracle):
             rel = np.linalg.norm(grads[d] - ref) / np.linalg.norm(ref)
             assert rel < 2e-3, "case %d plane %d: relative L2 error %.2e" % (ci, d, rel)
             assert np.abs(grads[d] - ref).max() <= 5e-3 * scale
+
+
+def test_ndc_render_end_to_end(oracle):
+    """forward-facing (LLFF-style) view: ndc_rays -> packed rays with the ORIGINAL directions as view directions
+    (train_utils.py:213-218) -> two-pass render"""
+    g = load_golden("g12_ndc_render.npz")
+    H, W, focal = int(g["hwf"][0]), int(g["hwf"][1]), float(g["hwf"][2])
+    sc = oracle.scene([g["plane%d" % d] for d in range(4)], g["box"])
+    dc, df = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    ro_o, rd_o = oracle.get_ray_bundle(H, W, focal, g["pose"])
+    assert_bits_equal(rd_o, g["rd"])          # this view has an image row with rd_y == 0: the sign of that zero must match
+    o_ndc, d_ndc = oracle.ndc_rays(H, W, focal, 1.0, g["ro"], g["rd"])
+    rays = oracle.pack_rays(o_ndc, d_ndc, 0.0, 1.0, dirs_for_view=g["rd"])
+    o = oracle.render_rays(sc, dc, df, rays, 64, 128)
+    np.testing.assert_allclose(o["rgb_coarse"], g["rgb_coarse"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(o["acc_coarse"], g["acc_coarse"], rtol=0, atol=2e-5)
+    f = oracle.render_given_z(sc, df, rays, g["z_fine"], want_raw=True)
+    ok = np.abs(f["raw"][:, -1, 3]) >= 1e-4
+    np.testing.assert_allclose(f["rgb"][ok], g["rgb_fine"][ok], rtol=0, atol=2e-5)
+    err = np.abs(o["rgb_fine"] - g["rgb_fine"]).max(-1)
+    assert np.mean(err <= 2e-4) >= 0.97 and psnr(o["rgb_fine"], g["rgb_fine"]) >= 70.0
