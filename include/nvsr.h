@@ -178,6 +178,20 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
 int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                               const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream);
 
+/* ---- training: gradient with respect to the decoder parameters ('decoder' in nerf.train.what, train_nerf.py:75-77) ------
+ * torch.autograd's addmm backward (dW = delta^T @ input, db = sum delta) through models.py:169-195,395-421 becomes two calls:
+ * the backward pass additionally RECORDS every layer's input and pre-activation gradient, then one contraction over all points
+ * adds the weight / bias gradients into a blob in the natural (state-dict) order of nvsr_pack_decoder. */
+/* floats of the record workspace of one pass (9.2 KB per point; N rounded up to 256 rays) */
+int64_t nvsr_decoder_record_floats(int64_t N, int S);
+/* nvsr_render_pass_backward with optional outputs: grad_planes may be NULL (planes frozen) or hold NULL entries (that plane
+ * frozen); record may be NULL (decoder frozen) or a workspace of nvsr_decoder_record_floats(N, S) floats, fully overwritten */
+int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                 const float* rays, const float* z, const float* g_raw, float* const* grad_planes, float* record,
+                                 nvsr_stream_t stream);
+/* grad_natural [NVSR_DECODER_NATURAL_FLOATS] += gradient of this pass (float atomics: zero it before the first pass) */
+int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, float* grad_natural, nvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+// Decoder weight / bias gradients from the record written by render_pass_backward_kernel<true> (gfx950).
+//
+// The reference gets them from torch.autograd (addmm backward: dW = delta^T @ input, db = sum(delta)) when 'decoder' is in
+// `nerf.train.what` (train_nerf.py:75-77, models.py:169-195).  Here every layer is one contraction over the record's slots:
+//
+//     dW_l[out][in] = sum_q  G_l[q][out] * X_l[q][in]            (X_0 = plane features, X_l = H_{l-1}),   db_l[out] = sum_q G_l[q][out]
+//
+// on v_mfma_f32_32x32x2_f32 with the slot index as K.  Both operands are read straight from HBM in operand layout: a lane takes one
+// f32x4 of G (4 output rows of 4 MFMAs) and one f32x2 of X (2 input columns) for slot pair (q, q+1), so a half-wave reads whole
+// 512-byte / 256-byte rows.  A workgroup owns a [128 out x 64 in] block of one layer for a slab of slots; its 4 waves split the
+// slab, reduce through LDS and add the block into the gradient blob (state-dict order) with float atomics.
+#include "nvsr_common.h"
+
+namespace nvsr {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WJob {
+    const float* G;     // [Pp][128]
+    const float* X;     // [Pp][xstride]
+    int xstride, col0;  // this block covers input columns col0 .. col0+63 of X
+    int w_off;          // weight [128][in_total] in the gradient blob
+    int in_total;       // also the number of valid input columns
+    int b_off;          // bias offset, or -1 when another block of the same layer owns it
+};
+constexpr int WJOBS = 16;
+struct WJobs { WJob j[WJOBS]; };
+
+constexpr int WG_TPB = 256;
+
+__device__ __forceinline__ f32x16 mfma32w(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, long Pp, int slab, float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) float tile[128 * 64];
+    const WJob jb = jobs.j[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int per_wave = slab / 4;                                   // even (host guarantees slab % 8 == 0)
+    long q0 = (long)blockIdx.x * slab + (long)wave * per_wave;
+    long q1 = q0 + per_wave;
+    if (q1 > Pp) q1 = Pp;                                            // Pp is a multiple of 256: the range stays even
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (q0 < q1) {
+        const float* gp_ = jb.G + (q0 + kh) * HID + 4 * i;
+        const float* xp = jb.X + (q0 + kh) * (long)jb.xstride + jb.col0 + 2 * i;
+        const long xs2 = 2L * jb.xstride;
+        constexpr int UN = 4;
+        long q = q0;
+        for (; q + 2 * UN <= q1; q += 2 * UN) {
+            f32x4 g[UN];
+            f32x2 x[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                g[u] = *reinterpret_cast<const f32x4*>(gp_ + (long)u * 2 * HID);
+                x[u] = *reinterpret_cast<const f32x2*>(xp + u * xs2);
+            }
+            gp_ += UN * 2 * HID;
+            xp += UN * xs2;
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    acc[a][0] = mfma32w(g[u][a], x[u][0], acc[a][0]);
+                    acc[a][1] = mfma32w(g[u][a], x[u][1], acc[a][1]);
+                    bs[a] += g[u][a];
+                }
+        }
+        for (; q < q1; q += 2) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gp_);
+            const f32x2 x = *reinterpret_cast<const f32x2*>(xp);
+            gp_ += 2 * HID;
+            xp += xs2;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc[a][0] = mfma32w(g[a], x[0], acc[a][0]);
+                acc[a][1] = mfma32w(g[a], x[1], acc[a][1]);
+                bs[a] += g[a];
+            }
+        }
+    }
+    // acc[a][b][r]: out = 4 * ((r&3) + 8(r>>2) + 4kh) + a,  in = 2i + b.   Sum the 4 waves in LDS (same element per lane in every wave).
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int out = 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + a;
+                    f32x2* t = reinterpret_cast<f32x2*>(tile + out * 64 + 2 * i);
+                    f32x2 v = f32x2{acc[a][0][r], acc[a][1][r]};
+                    if (w > 0) { const f32x2 o = *t; v[0] += o[0]; v[1] += o[1]; }
+                    *t = v;
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < 128 * 64; idx += WG_TPB) {
+        const int out = idx >> 6, col = jb.col0 + (idx & 63);
+        if (col < jb.in_total) unsafeAtomicAdd(grad + jb.w_off + out * jb.in_total + col, tile[idx]);
+    }
+    if (jb.b_off >= 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float v = bs[a] + __shfl_xor(bs[a], 32);
+            if (kh == 0) unsafeAtomicAdd(grad + jb.b_off + 4 * i + a, v);
+        }
+    }
+}
+
+// fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k]   (thread = feature f of one branch)
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
+                                                         const float* __restrict__ g4, long Pp, int slab, float* __restrict__ grad) {
+    const int f = threadIdx.x & 127, rgb = threadIdx.x >> 7;
+    const float* H = rgb ? Hr3 : Hd3;
+    const long q0 = (long)blockIdx.x * slab;
+    const long q1 = (q0 + slab < Pp) ? q0 + slab : Pp;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 8
+    for (long q = q0; q < q1; ++q) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(g4 + 4 * q);
+        const float hv = H[q * HID + f];
+        if (rgb) {
+            a0 = fmaf(g[0], hv, a0); a1 = fmaf(g[1], hv, a1); a2 = fmaf(g[2], hv, a2);
+            s0 += g[0]; s1 += g[1]; s2 += g[2];
+        } else {
+            a0 = fmaf(g[3], hv, a0);
+            s0 += g[3];
+        }
+    }
+    if (rgb) {
+        unsafeAtomicAdd(grad + N_FCRGB_W + f, a0);
+        unsafeAtomicAdd(grad + N_FCRGB_W + HID + f, a1);
+        unsafeAtomicAdd(grad + N_FCRGB_W + 2 * HID + f, a2);
+        if (f == 0) { unsafeAtomicAdd(grad + N_FCRGB_B, s0); unsafeAtomicAdd(grad + N_FCRGB_B + 1, s1); unsafeAtomicAdd(grad + N_FCRGB_B + 2, s2); }
+    } else {
+        unsafeAtomicAdd(grad + N_ALPHA_W + f, a0);
+        if (f == 0) unsafeAtomicAdd(grad + N_ALPHA_B, s0);
+    }
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, float* grad_natural, nvsr_stream_t stream) {
+    if (!record || !grad_natural) return NVSR_ERR_NULL;
+    if (!aligned16(record)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const long Pp = record_slots((long)N, S);
+    const DecRecord rec = make_record(const_cast<float*>(record), Pp);
+    WJobs jobs;
+    int n = 0;
+    auto add = [&](const float* G, const float* X, int xstride, int col0, int w_off, int in_total, int b_off) {
+        jobs.j[n++] = WJob{G, X, xstride, col0, w_off, in_total, b_off};
+    };
+    const long LP = (long)HID * Pp;
+    add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0);
+    for (int l = 1; l <= 3; ++l)
+        for (int c = 0; c < 2; ++c) {
+            const int w = N_DEN_W1 + (l - 1) * N_HID_STRIDE;
+            add(rec.Gd + l * LP, rec.Hd + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1);
+        }
+    for (int c = 0; c < 3; ++c) add(rec.Gr, rec.Xr, 4 * C, 64 * c, N_RGB_W0, 4 * C, c == 0 ? N_RGB_B0 : -1);
+    for (int l = 1; l <= 3; ++l)
+        for (int c = 0; c < 2; ++c) {
+            const int w = N_RGB_W1 + (l - 1) * N_HID_STRIDE;
+            add(rec.Gr + l * LP, rec.Hr + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1);
+        }
+    if (n != WJOBS) return NVSR_ERR_SHAPE;
+    // slabs: ~32 per layer block keeps 512 workgroups in flight (2 per CU) while each block is flushed only 32 times
+    long slab = (Pp + 31) / 32;
+    slab = ((slab + 255) / 256) * 256;
+    if (slab < 256) slab = 256;
+    const unsigned nslabs = (unsigned)((Pp + slab - 1) / slab);
+    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, Pp, (int)slab, grad_natural);
+    const int hslab = 1024;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((Pp + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
+                       rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, Pp, hslab, grad_natural);
+    return NVSR_CHECK_LAUNCH();
+}

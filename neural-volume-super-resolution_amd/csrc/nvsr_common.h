@@ -74,6 +74,31 @@ inline SceneDev to_dev(const nvsr_scene* s) {
     return d;
 }
 
+// ---- activation / delta record of one backward pass (decoder-weight gradients) -------------------------------------------
+// Rows are "slots": slot q = tile * 256 + wave * 32 + (lane & 31) of render_pass_backward_kernel; padding rays hold zeros in G*/g4.
+//   Xd [Pp][64]   density-decoder input (mean of the 3 position features; columns 48..63 zero)
+//   Hd [4][Pp][128]  post-ReLU output of density layer l          Gd [4][Pp][128]  dL/d(pre-activation of density layer l)
+//   Xr [Pp][192]  rgb-decoder input [f0|f1|f2|f_view]              Hr, Gr likewise for the rgb decoder
+//   g4 [Pp][4]    dL/d raw (rgb, sigma)
+struct DecRecord {
+    float *Xd, *Hd, *Gd, *Xr, *Hr, *Gr, *g4;
+    long Pp;
+};
+constexpr long DEC_RECORD_FLOATS_PER_SLOT = 64 + 4 * HID + 4 * HID + 4 * C + 4 * HID + 4 * HID + 4;   // 2308
+inline long record_slots(long N, int S) { return ((N + 255) / 256) * (long)S * 256; }
+inline DecRecord make_record(float* base, long Pp) {
+    DecRecord r;
+    r.Pp = Pp;
+    r.Xd = base;            base += 64 * Pp;
+    r.Hd = base;            base += 4L * HID * Pp;
+    r.Gd = base;            base += 4L * HID * Pp;
+    r.Xr = base;            base += 4L * C * Pp;
+    r.Hr = base;            base += 4L * HID * Pp;
+    r.Gr = base;            base += 4L * HID * Pp;
+    r.g4 = base;
+    return r;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // torch.linspace(0, 1, n) element i in fp32 (symmetric two-sided form used by ATen's RangeFactories)

@@ -1,8 +1,9 @@
 // Backward of the fused render pass with respect to the feature planes (gfx950).
 //
 // The reference obtains it from torch.autograd through run_network / TwoDimPlanesModel.forward / grid_sample
-// (train_utils.py:185-282, models.py:381-421; `grid_sampler_2d_backward` scatter-adds into the planes).  Decoder weights are
-// treated as constants (Feature_Planes_Only.yml: `what: ['LR_planes']`).
+// (train_utils.py:185-282, models.py:381-421; `grid_sampler_2d_backward` scatter-adds into the planes).  With RECORD the kernel
+// also writes every layer's input and pre-activation gradient to a workspace; decoder_wgrad.hip contracts those over the points
+// into the weight / bias gradients (`what: ['decoder']`, train_nerf.py:75-77).
 //
 // Per step a wave takes 32 points (one sample of its 32 rays):
 //   1. recomputes the decoder forward on the MFMA path of decode_core.h, keeping only the ReLU masks (2 VGPRs per layer);
@@ -152,11 +153,29 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
 
 struct GradPlanes { float* p[4]; };
 
+// record helpers: one accumulator set (128 features x 32 points, C/D layout) -> rows [slot][128]; 32 B per lane pair and store,
+// the wave's 16 stores fill 32 complete 512-byte rows
+__device__ __forceinline__ void record128(float* __restrict__ base, long q, int h, const f32x16 (&a)[4]) {
+    float* row = base + q * HID + 4 * h;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
+}
+// a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[col0 + 24h ..]
+__device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i)
+        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+}
+
 // =====================================================================================================================
+template <bool RECORD>
 __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                       const float* __restrict__ packed_bwd, long N, int S,
                                                                       const float* __restrict__ rays, const float* __restrict__ z,
-                                                                      const float* __restrict__ g_raw, GradPlanes gp) {
+                                                                      const float* __restrict__ g_raw, GradPlanes gp, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<BNW>(rs);
@@ -177,7 +196,10 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
         const float* r = rays + ray * 11;
         const Taps vt = view_taps(sc, r[8], r[9], r[10]);
         const float zc = z[ray * S + s];
-        const f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // padding rays: every gradient below becomes an exact zero
+        const long q = tix * BPTS + rs.wave * 32 + (lane & 31);      // record slot of this point
+        if (RECORD && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         const f32x4 c0 = f32x4{r[0], r[1], r[2], r[3]}, c1 = f32x4{r[4], r[5], 0.0f, 0.0f};
         const float n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
         const float n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
@@ -198,6 +220,7 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
         load_bias(small + S_BIAS + 4 * HID, h, accA);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
+        if (RECORD) record24(rec.Xr + q * (4 * C), h, F);
         feat_layer(cur, F, lane, accA);
         cur = nxt;
         ring_sync();
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
         gather24(sc.plane[1], pos_taps(1), h, F);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
+        if (RECORD) record24(rec.Xr + q * (4 * C) + C, h, F);
         feat_layer(cur, F, lane, accA);
         cur = nxt;
         ring_sync();
@@ -212,13 +236,21 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
         gather24(sc.plane[2], pos_taps(2), h, F);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+        if (RECORD) {
+            record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
+            record24(rec.Xd + q * 64, h, D);
+            *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
         feat_layer(cur, F, lane, accA);
         cur = nxt;
         ring_sync();
         nxt = ring_issue<BNW, 32>(rs, P_RGB1);
         gather24(sc.plane[3], vt, h, F);
+        if (RECORD) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
         feat_layer(cur, F, lane, accA);
         mr[0] = relu_masks(accA);
+        if (RECORD) record128(rec.Hr, q, h, accA);
         cur = nxt;
 #pragma unroll
         for (int l = 1; l <= 3; ++l) {                 // rgb layers 1..3 (ping-pong A -> B -> A -> B)
@@ -233,6 +265,7 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
             nxt = (l < 3) ? ring_issue<BNW, 32>(rs, P_RGB1 + l * P_HID_FLOATS) : ring_issue<BNW, 24>(rs, P_DEN0);
             hidden_half<1>(cur, in, lane, out);
             mr[l] = relu_masks(out);
+            if (RECORD) record128(rec.Hr + (long)l * HID * rec.Pp, q, h, out);
             cur = nxt;
         }
         ring_sync();
@@ -240,6 +273,7 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
         load_bias(small + S_BIAS + 0 * HID, h, accA);
         feat_layer(cur, D, lane, accA);
         md[0] = relu_masks(accA);
+        if (RECORD) record128(rec.Hd, q, h, accA);
         cur = nxt;
 #pragma unroll
         for (int l = 1; l <= 3; ++l) {                 // density layers 1..3
@@ -254,6 +288,7 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
             if (l < 3) nxt = ring_issue<BNW, 32>(rs, P_DEN1 + l * P_HID_FLOATS);
             hidden_half<1>(cur, in, lane, out);
             md[l] = relu_masks(out);
+            if (RECORD) record128(rec.Hd + (long)l * HID * rec.Pp, q, h, out);
             cur = nxt;
         }
 
@@ -270,9 +305,13 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
             }
         apply_mask(md[3], accA);
+        if (RECORD) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
+        if (RECORD) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<BNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
+        if (RECORD) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
+        if (RECORD) record128(rec.Gd, q, h, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -300,9 +339,13 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
             }
         apply_mask(mr[3], accA);
+        if (RECORD) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
+        if (RECORD) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<BNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
+        if (RECORD) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
+        if (RECORD) record128(rec.Gr, q, h, accB);
         // layer 0^T, one plane at a time, + gD/3 on the position planes, then scatter
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -315,8 +358,10 @@ __global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev 
             if (d < 3) nxt = ring_issue<BNW, 32>(rs, B_RGB0 + (d + 1) * 8192);
             layer0_T(cur, accB, lane, gF);
             cur = nxt;
-            const Taps t = (d < 3) ? pos_taps(d) : vt;
-            scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+            if (gp.p[d]) {                                            // (wave-uniform) planes frozen: nothing to scatter
+                const Taps t = (d < 3) ? pos_taps(d) : vt;
+                scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+            }
         }
         rs.packed = packed;
     }
@@ -421,24 +466,46 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
     return NVSR_CHECK_LAUNCH();
 }
 
-int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
-                              const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream) {
-    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !grad_planes) return NVSR_ERR_NULL;
+int64_t nvsr_decoder_record_floats(int64_t N, int S) {
+    if (N < 0 || S < 1) return 0;
+    return record_slots((long)N, S) * DEC_RECORD_FLOATS_PER_SLOT;
+}
+
+int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                 const float* rays, const float* z, const float* g_raw, float* const* grad_planes, float* record,
+                                 nvsr_stream_t stream) {
+    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw) return NVSR_ERR_NULL;
+    if (!grad_planes && !record) return NVSR_ERR_NULL;
     GradPlanes gp;
     for (int d = 0; d < 4; ++d) {
-        if (!scene->planes[d] || !grad_planes[d]) return NVSR_ERR_NULL;
+        if (!scene->planes[d]) return NVSR_ERR_NULL;
         if (!aligned16(scene->planes[d])) return NVSR_ERR_ALIGN;
         if (scene->ph[d] < 1 || scene->pw[d] < 1) return NVSR_ERR_SHAPE;
-        gp.p[d] = grad_planes[d];
+        gp.p[d] = grad_planes ? grad_planes[d] : nullptr;         // a NULL plane pointer = that plane is frozen
     }
-    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
+    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
+    static_assert(BPTS == 256, "record slots are laid out for 256-point tiles");
     const int64_t ntiles = ((N + BPTS - 1) / BPTS) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
-    hipLaunchKernelGGL(render_pass_backward_kernel, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                       packed_bwd, (long)N, S, rays, z, g_raw, gp);
+    if (record) {
+        const DecRecord rec = make_record(record, record_slots((long)N, S));
+        hipLaunchKernelGGL(render_pass_backward_kernel<true>, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, rec);
+    } else {
+        hipLaunchKernelGGL(render_pass_backward_kernel<false>, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, DecRecord{});
+    }
     return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                              const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream) {
+    if (!grad_planes) return NVSR_ERR_NULL;
+    for (int d = 0; d < 4; ++d)
+        if (!grad_planes[d]) return NVSR_ERR_NULL;
+    return nvsr_render_pass_backward_ex(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, grad_planes, nullptr, stream);
 }
 
 }  // extern "C"

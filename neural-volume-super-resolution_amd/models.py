@@ -218,14 +218,20 @@ class TwoDimPlanesModel(nn.Module):
                 "the gfx950 decoder kernel is compiled for the shipped configuration (3+1 planes x 48 channels, 'avg' / "
                 "'concat_pos', 4+4 layers x 128, no skip layer); got a different TwoDimPlanesModel geometry")
 
-    def natural_blob(self):
-        """Decoder parameters flattened in state-dict order (the layout nvsr_pack_decoder consumes)."""
+    def decoder_parameters(self):
+        """the decoder's weights and biases in state-dict order (planes and the fixed projection matrices excluded)"""
         sd = dict(self.named_parameters())
-        return torch.cat([sd[k].detach().reshape(-1).float() for pair in DECODER_KEYS for k in pair])
+        return [sd[k] for pair in DECODER_KEYS for k in pair]
+
+    def natural_blob(self, differentiable=False):
+        """Decoder parameters flattened in state-dict order (the layout nvsr_pack_decoder consumes).  differentiable=True keeps
+        the autograd graph, so a gradient with respect to the blob reaches the individual parameters."""
+        ps = self.decoder_parameters()
+        return torch.cat([(p if differentiable else p.detach()).reshape(-1).float() for p in ps])
 
     def packed_decoder(self):
         self._check_native_geometry()
-        params = [p for n, p in self.named_parameters() if "rot_mats" not in n]
+        params = self.decoder_parameters()
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._packed_cache is None or self._packed_cache[0] != key:
             nat = self.natural_blob()
@@ -239,7 +245,7 @@ class TwoDimPlanesModel(nn.Module):
     def packed_decoder_bwd(self):
         """transposed layers for the backward kernels (nvsr_pack_decoder_bwd), cached like packed_decoder()"""
         self._check_native_geometry()
-        params = [p for n, p in self.named_parameters() if "rot_mats" not in n]
+        params = self.decoder_parameters()
         key = tuple((p.data_ptr(), p._version) for p in params)
         cache = getattr(self, "_packed_bwd_cache", None)
         if cache is None or cache[0] != key:

@@ -46,15 +46,21 @@ def _reference_chunks(n_rays, options, mode, model_coarse, model_fine):
     return [(i, min(i + chunk, n_rays)) for i in range(0, n_rays, chunk)]
 
 
-class _RenderRaysFn(torch.autograd.Function):
-    """Differentiable predict_and_render_radiance with the four planes of the current scene as leaves (decoder frozen).
+RECORD_RAYS = 8192   # rays per backward launch when decoder gradients are wanted (bounds the record: 9.2 KB per point)
 
-    forward  = coarse z -> fused coarse pass (keeps raw + weights) -> importance resampling (no gradient, train_utils.py:153)
-               -> fused fine pass (keeps raw);
-    backward = per pass: composite backward (wave per ray) -> decoder backward + plane scatter-add (MFMA + float atomics)."""
+
+class _RenderRaysFn(torch.autograd.Function):
+    """Differentiable predict_and_render_radiance.  Leaves: the four planes of the current scene and the decoder parameters of
+    the coarse / fine model, the latter as flat blobs in state-dict order (`TwoDimPlanesModel.natural_blob(differentiable=True)`;
+    torch's own cat/reshape backward hands the slices to the parameters).
+
+    forward  = coarse z -> decode + composite (keeps raw + weights) -> importance resampling (no gradient, train_utils.py:153)
+               -> fine decode + composite (keeps raw);
+    backward = per pass: composite backward (wave per ray) -> decoder backward + plane scatter-add (MFMA + float atomics)
+               [+ record of layer inputs / deltas -> weight-gradient contraction]."""
 
     @staticmethod
-    def forward(ctx, cfg, p0, p1, p2, pv):
+    def forward(ctx, cfg, p0, p1, p2, pv, nat_c, nat_f):
         capi_ = capi
         N, Nc, Nf, dev = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"].device
         rays, st = cfg["rays"], capi.stream()
@@ -90,28 +96,41 @@ class _RenderRaysFn(torch.autograd.Function):
         dev = rays.device
         rd = rays[:, 3:6].contiguous()
         shapes = cfg["plane_shapes"]                                    # channel-last (H, W, C)
-        gplanes = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes]
-        gptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in gplanes])
+        need = ctx.needs_input_grad
+        gplanes = [torch.zeros(sh, dtype=torch.float32, device=dev) if need[1 + d] else None for d, sh in enumerate(shapes)]
+        gptrs = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gplanes]) if any(need[1:5]) else None
+        gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if need[5] else None
+        gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if (need[6] and Nf > 0) else None
 
-        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc):
-            if g_rgb is None and g_acc is None:
+        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec):
+            if (g_rgb is None and g_acc is None) or (gptrs is None and gdec is None):
                 return
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
             g_acc = None if g_acc is None else capi.f32c(g_acc)
             g_raw = torch.empty((N, S, 4), dtype=torch.float32, device=dev)
             capi.call("nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), cfg["white"],
                       capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), st)
-            capi.call("nvsr_render_pass_backward", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                      capi.ptr(z), capi.ptr(g_raw), gptrs, st)
+            if gdec is None:
+                capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
+                          capi.ptr(z), capi.ptr(g_raw), gptrs, None, st)
+                return
+            step = min(N, RECORD_RAYS)
+            record = torch.empty(capi.lib().nvsr_decoder_record_floats(step, S), dtype=torch.float32, device=dev)
+            for a in range(0, N, step):
+                n = min(step, N - a)
+                capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), n, S, capi.ptr(rays[a:]),
+                          capi.ptr(z[a:]), capi.ptr(g_raw[a:]), gptrs, capi.ptr(record), st)
+                capi.call("nvsr_decoder_weight_grad", n, S, capi.ptr(record), capi.ptr(gdec), st)
 
         if cfg["coarse_grad"]:
-            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2])
+            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2], gdec_c)
         if Nf > 0:
-            one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5])
+            one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
+                     gdec_f)
         out = [None]
-        for g, need in zip(gplanes, ctx.needs_input_grad[1:]):
-            out.append(models.from_channel_last(g) if need else None)    # back to the reference's [1,C,H,W]
-        return tuple(out)
+        for g in gplanes:
+            out.append(None if g is None else models.from_channel_last(g))    # back to the reference's [1,C,H,W]
+        return tuple(out) + (gdec_c, gdec_f)
 
 
 def _planes_need_grad(model):
@@ -119,6 +138,10 @@ def _planes_need_grad(model):
         return False
     names = [models.get_plane_name(model.cur_id, d) for d in range(model.num_density_planes + 1)]
     return any(n in model.planes_ and model.planes_[n].requires_grad for n in names)
+
+
+def _decoder_needs_grad(model):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in model.decoder_parameters())
 
 
 def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, scene_id, mode="train", encode_position_fn=None,
@@ -162,16 +185,18 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
     else:
         sc_f, keep_f, same = sc_c, keep_c, True
 
-    if mode == "train" and _planes_need_grad(model_fine if Nf > 0 else model_coarse) and N > 0:
+    top = model_fine if Nf > 0 else model_coarse
+    dec_c_grad = _decoder_needs_grad(model_coarse)
+    dec_f_grad = Nf > 0 and _decoder_needs_grad(model_fine)
+    if mode == "train" and N > 0 and (_planes_need_grad(top) or dec_c_grad or dec_f_grad):
         # training path (mode == "train" only; evaluation never builds a graph): gradients flow to the planes of the current
-        # scene, decoder parameters are constants here
+        # scene and / or to the decoder parameters of the two models, whichever require grad
         if hasattr(model_fine, "SR_model") and not model_fine.skip_SR_:
             raise NotImplementedError("gradients through the super-resolved planes (EDSR backward) are not implemented yet")
-        if any(p.requires_grad for n, p in model_fine.named_parameters() if "rot_mats" not in n):
-            import warnings
-            warnings.warn("nvsr_amd: decoder parameters require grad but only plane gradients are implemented; decoder grads stay None")
         names = [models.get_plane_name(scene_id, d) for d in range(4)]
-        leaves = [model_fine.planes_[n] for n in names]
+        leaves = [top.planes_[n] for n in names]
+        leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
+                   model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=int(bool(m.lindisp)), white=int(bool(m.white_background)), t_rand=t_rand, u=u,
                    noise_c=n_c, noise_f=n_f, scene_c=sc_c, scene_f=sc_f, keep=(keep_c, keep_f), packed_c=packed_c, packed_f=packed_f,

@@ -737,7 +737,9 @@ static void orc_forward_store(const orc_scene* sc, const orc_decoder* dec, const
 }
 
 /* g_raw[4] -> scatter-add into gp[4] (double, NCHW like the planes) */
-static void orc_backward_point(const orc_scene* sc, const orc_decoder* dec, const orc_act* A, const double* g_raw, double* const* gp) {
+/* gw (optional): d/d(decoder parameters), accumulated in the blob's own layout (weight[out,in], bias per layer) */
+static void orc_backward_point(const orc_scene* sc, const orc_decoder* dec, const orc_act* A, const double* g_raw, double* const* gp,
+                               double* gw) {
     const int C = dec->C, h = dec->hidden, nd = dec->n_density_layers, nr = dec->n_rgb_layers;
     const float* Wd[8]; const float* Wr[8];
     const float* p = dec->blob;
@@ -749,12 +751,27 @@ static void orc_backward_point(const orc_scene* sc, const orc_decoder* dec, cons
     const float* Wc = p;
     double g[ORC_MAXH], gn[ORC_MAXH], g_in_rgb[4 * 64], g_in_den[64];
     /* rgb branch */
+    if (gw) {
+        double* q = gw + (Wc - dec->blob);
+        for (int c = 0; c < 3; ++c) {
+            for (int f = 0; f < h; ++f) q[(size_t)c * h + f] += g_raw[c] * A->h_rgb[nr - 1][f];
+            q[(size_t)3 * h + c] += g_raw[c];
+        }
+    }
     for (int f = 0; f < h; ++f) {
         double a = 0;
         for (int c = 0; c < 3; ++c) a += (double)Wc[(size_t)c * h + f] * g_raw[c];
         g[f] = A->h_rgb[nr - 1][f] > 0 ? a : 0.0;
     }
     for (int l = nr - 1; l >= 1; --l) {
+        if (gw) {   /* g = dL/d(pre-activation of layer l); its input is the post-ReLU output of layer l-1 */
+            double* q = gw + (Wr[l] - dec->blob);
+            for (int o = 0; o < h; ++o) {
+                if (g[o] == 0.0) continue;
+                for (int k = 0; k < h; ++k) q[(size_t)o * h + k] += g[o] * A->h_rgb[l - 1][k];
+                q[(size_t)h * h + o] += g[o];
+            }
+        }
         for (int k = 0; k < h; ++k) {
             double a = 0;
             for (int o = 0; o < h; ++o) a += (double)Wr[l][(size_t)o * h + k] * g[o];
@@ -762,20 +779,49 @@ static void orc_backward_point(const orc_scene* sc, const orc_decoder* dec, cons
         }
         memcpy(g, gn, sizeof(double) * (size_t)h);
     }
+    if (gw) {
+        double* q = gw + (Wr[0] - dec->blob);
+        for (int o = 0; o < h; ++o) {
+            if (g[o] == 0.0) continue;
+            for (int k = 0; k < 4 * C; ++k) q[(size_t)o * 4 * C + k] += g[o] * A->in_rgb[k];
+            q[(size_t)h * 4 * C + o] += g[o];
+        }
+    }
     for (int k = 0; k < 4 * C; ++k) {
         double a = 0;
         for (int o = 0; o < h; ++o) a += (double)Wr[0][(size_t)o * 4 * C + k] * g[o];
         g_in_rgb[k] = a;
     }
     /* density branch */
+    if (gw) {
+        double* q = gw + (Wa - dec->blob);
+        for (int f = 0; f < h; ++f) q[f] += g_raw[3] * A->h_den[nd - 1][f];
+        q[h] += g_raw[3];
+    }
     for (int f = 0; f < h; ++f) g[f] = A->h_den[nd - 1][f] > 0 ? (double)Wa[f] * g_raw[3] : 0.0;
     for (int l = nd - 1; l >= 1; --l) {
+        if (gw) {
+            double* q = gw + (Wd[l] - dec->blob);
+            for (int o = 0; o < h; ++o) {
+                if (g[o] == 0.0) continue;
+                for (int k = 0; k < h; ++k) q[(size_t)o * h + k] += g[o] * A->h_den[l - 1][k];
+                q[(size_t)h * h + o] += g[o];
+            }
+        }
         for (int k = 0; k < h; ++k) {
             double a = 0;
             for (int o = 0; o < h; ++o) a += (double)Wd[l][(size_t)o * h + k] * g[o];
             gn[k] = A->h_den[l - 1][k] > 0 ? a : 0.0;
         }
         memcpy(g, gn, sizeof(double) * (size_t)h);
+    }
+    if (gw) {
+        double* q = gw + (Wd[0] - dec->blob);
+        for (int o = 0; o < h; ++o) {
+            if (g[o] == 0.0) continue;
+            for (int k = 0; k < C; ++k) q[(size_t)o * C + k] += g[o] * A->in_den[k];
+            q[(size_t)h * C + o] += g[o];
+        }
     }
     for (int k = 0; k < C; ++k) {
         double a = 0;
@@ -830,13 +876,14 @@ static void orc_composite_backward_ray(int S, const double* raw /*[S,4]*/, const
 
 /* One train step: forward recomputed in double, gradient of (sum g_rgb_c . rgb_c + sum g_rgb_f . rgb_f) wrt the 4 planes.
  * grad planes: NCHW float [C,H,W] each (overwritten). */
-ORC_EXPORT void orc_render_backward(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
-                                    long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
-                                    const float* noise_f, const float* g_rgb_c /*[N,3] or NULL*/, const float* g_rgb_f /*[N,3] or NULL*/,
-                                    const float* z_fine_in /*[N,Nc+Nf] or NULL: use these fine depths instead of resampling*/,
-                                    float* gp0, float* gp1, float* gp2, float* gpv) {
+static void orc_render_backward_impl(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
+                                     long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
+                                     const float* noise_f, const float* g_rgb_c, const float* g_rgb_f, const float* z_fine_in,
+                                     float* gp0, float* gp1, float* gp2, float* gpv, float* gdec_c, float* gdec_f) {
     const int Nc = cfg->num_coarse, Nf = cfg->num_fine, St = Nc + Nf, C = coarse->C;
     float* gout[4] = {gp0, gp1, gp2, gpv};
+    double* gwc = gdec_c ? (double*)calloc(orc_decoder_floats(coarse), sizeof(double)) : NULL;
+    double* gwf = (gdec_f && fine) ? (double*)calloc(orc_decoder_floats(fine), sizeof(double)) : NULL;
     double* gp[4];
     for (int d = 0; d < 4; ++d) gp[d] = (double*)calloc((size_t)C * sc->ph[d] * sc->pw[d], sizeof(double));
     orc_act* acts = (orc_act*)malloc(sizeof(orc_act) * (size_t)(St > Nc ? St : Nc));
@@ -861,7 +908,7 @@ ORC_EXPORT void orc_render_backward(const orc_scene* sc, const orc_decoder* coar
         if (g_rgb_c) {
             const double g3[3] = {g_rgb_c[3 * i], g_rgb_c[3 * i + 1], g_rgb_c[3 * i + 2]};
             orc_composite_backward_ray(Nc, rawd, z, r + 3, noise_c ? noise_c + (size_t)i * Nc : NULL, cfg->white_background, g3, 0.0, graw);
-            for (int s = 0; s < Nc; ++s) orc_backward_point(sc, coarse, &acts[s], graw + 4 * s, gp);
+            for (int s = 0; s < Nc; ++s) orc_backward_point(sc, coarse, &acts[s], graw + 4 * s, gp, gwc);
         }
         if (Nf <= 0 || !g_rgb_f) continue;
         if (z_fine_in) {
@@ -883,12 +930,33 @@ ORC_EXPORT void orc_render_backward(const orc_scene* sc, const orc_decoder* coar
         }
         const double g3[3] = {g_rgb_f[3 * i], g_rgb_f[3 * i + 1], g_rgb_f[3 * i + 2]};
         orc_composite_backward_ray(St, rawd, z, r + 3, noise_f ? noise_f + (size_t)i * St : NULL, cfg->white_background, g3, 0.0, graw);
-        for (int s = 0; s < St; ++s) orc_backward_point(sc, fine, &acts[s], graw + 4 * s, gp);
+        for (int s = 0; s < St; ++s) orc_backward_point(sc, fine, &acts[s], graw + 4 * s, gp, gwf);
     }
     for (int d = 0; d < 4; ++d) {
         const size_t n = (size_t)C * sc->ph[d] * sc->pw[d];
-        for (size_t k = 0; k < n; ++k) gout[d][k] = (float)gp[d][k];
+        if (gout[d]) for (size_t k = 0; k < n; ++k) gout[d][k] = (float)gp[d][k];
         free(gp[d]);
     }
+    if (gwc) { for (size_t k = 0; k < orc_decoder_floats(coarse); ++k) gdec_c[k] = (float)gwc[k]; free(gwc); }
+    if (gwf) { for (size_t k = 0; k < orc_decoder_floats(fine); ++k) gdec_f[k] = (float)gwf[k]; free(gwf); }
     free(acts); free(z); free(zs); free(zm); free(rawf); free(rawd); free(graw); free(w); free(ud);
+}
+
+ORC_EXPORT void orc_render_backward(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
+                                    long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
+                                    const float* noise_f, const float* g_rgb_c /*[N,3] or NULL*/, const float* g_rgb_f /*[N,3] or NULL*/,
+                                    const float* z_fine_in /*[N,Nc+Nf] or NULL: use these fine depths instead of resampling*/,
+                                    float* gp0, float* gp1, float* gp2, float* gpv) {
+    orc_render_backward_impl(sc, coarse, fine, cfg, N, rays, t_rand, u, noise_c, noise_f, g_rgb_c, g_rgb_f, z_fine_in, gp0, gp1, gp2, gpv,
+                             NULL, NULL);
+}
+
+/* Same step, additionally d/d(decoder parameters) of both models (what: ['decoder'], train_nerf.py:75-77), each in the blob's
+ * state-dict order.  Pinned against tests/golden/g13_decoder_grads.npz.  Plane outputs may be NULL. */
+ORC_EXPORT void orc_render_backward_dec(const orc_scene* sc, const orc_decoder* coarse, const orc_decoder* fine, const orc_render_cfg* cfg,
+                                        long N, const float* rays, const float* t_rand, const float* u, const float* noise_c,
+                                        const float* noise_f, const float* g_rgb_c, const float* g_rgb_f, const float* z_fine_in,
+                                        float* gp0, float* gp1, float* gp2, float* gpv, float* gdec_c, float* gdec_f) {
+    orc_render_backward_impl(sc, coarse, fine, cfg, N, rays, t_rand, u, noise_c, noise_f, g_rgb_c, g_rgb_f, z_fine_in, gp0, gp1, gp2, gpv,
+                             gdec_c, gdec_f);
 }

@@ -193,6 +193,19 @@ class Oracle:
                                      _p(nf), _p(gc), _p(gf), _p(zf), *[_p(g) for g in grads])
         return grads
 
+    def render_backward_decoder(self, scene, dec_c, dec_f, rays, num_coarse, num_fine, g_rgb_coarse, g_rgb_fine, lindisp=False,
+                                perturb=False, white_background=False, t_rand=None, u=None, noise_coarse=None, noise_fine=None, z_fine=None):
+        """same step as render_backward: gradients wrt the decoder parameters of (coarse, fine), state-dict order"""
+        rays = _f(rays)
+        N = rays.shape[0]
+        cfg = _Cfg(num_coarse, num_fine, int(lindisp), int(perturb), int(white_background))
+        t_rand, u, nc, nf, gc, gf, zf = (None if a is None else _f(a) for a in (t_rand, u, noise_coarse, noise_fine, g_rgb_coarse, g_rgb_fine, z_fine))
+        n = self.lib.orc_decoder_blob_floats(dec_c.C, dec_c.hidden, dec_c.nd, dec_c.nr)
+        gc_, gf_ = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self.lib.orc_render_backward_dec(scene, C.byref(dec_c), C.byref(dec_f), C.byref(cfg), C.c_long(N), _p(rays), _p(t_rand), _p(u), _p(nc),
+                                         _p(nf), _p(gc), _p(gf), _p(zf), None, None, None, None, _p(gc_), _p(gf_))
+        return gc_, gf_
+
     # -- feature-plane super-resolution -----------------------------------------------------------
     @staticmethod
     def edsr_blob(sd, prefix="inner_model.", nblocks=None, n_up=2):

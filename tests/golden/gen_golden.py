@@ -21,6 +21,7 @@ Fixture index:
   g10_posenc.npz      positional_encoding, FlexibleNeRFModel   nerf_helpers.py:552-575, models.py:14-108
   g11_grads.npz       autograd of one train step wrt the planes (train_nerf.py:860-903)
   g12_ndc_render.npz  eval_nerf of a forward-facing (LLFF-style) view through NDC rays (train_utils.py:215-218)
+  g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
 """
 import os
 import sys
@@ -670,9 +671,55 @@ def g12_ndc_render():
     save("g12_ndc_render.npz", **arrs)
 
 
+DEC_KEYS = (["density_dec.0.%d" % i for i in range(4)] + ["fc_alpha.0"] + ["rgb_dec.0.%d" % i for i in range(4)] + ["fc_rgb.0"])
+
+
+def g13_decoder_grads():
+    """d(mse_coarse + mse_fine)/d(decoder weights and biases) of model_coarse and model_fine for the g11 train step (same
+    planes, rays, targets and random draws: g11_grads.npz holds the inputs).  Gradients are stored flattened in state-dict
+    order (weight, bias per layer: density_dec 0..3, fc_alpha, rgb_dec 0..3, fc_rgb), the layout of the 'natural' blob."""
+    R, Rv = 16, 8
+    sid, mc, mf, planes, box = build_models(R, Rv, 0.5, seed=11)
+    H = W = 16
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+    torch.manual_seed(110)
+    sel = torch.randperm(H * W)[:64]
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    target = torch.rand(64, 3)
+    arrs = {}
+    for ci, (nc, nf, perturb, std) in enumerate([(32, 32, True, 0.2), (24, 40, False, 0.0)]):
+        vt = mode_cfg(nc, nf, perturb=perturb, noise=std)
+        cfg = make_cfg(vt, vt)
+        mc.train(); mf.train()
+        for m in (mc, mf):
+            m.zero_grad(set_to_none=True)
+        for p_ in planes.values():
+            p_.grad = None
+        torch.manual_seed(111 + ci)
+        rc, dc, ac, rf, df, af, *_ = tu.run_one_iter_of_nerf(H, W, focal, mc, mf, rays, cfg, scene_id=sid, mode="train",
+                                                             scene_config=cfg.dataset["synt"])
+        loss = torch.nn.functional.mse_loss(rc, target) + torch.nn.functional.mse_loss(rf, target)
+        loss.backward()
+        arrs["c%d_loss" % ci] = np.array(float(loss))
+        for tag, m in (("coarse", mc), ("fine", mf)):
+            sd = dict(m.named_parameters())
+            flat = []
+            for k in DEC_KEYS:
+                for leaf in ("weight", "bias"):
+                    g_ = sd[k + "." + leaf].grad
+                    assert g_ is not None, k
+                    flat.append(npy(g_).reshape(-1))
+            arrs["c%d_%s_grad" % (ci, tag)] = np.concatenate(flat).astype(np.float32)
+        print("   decoder grads case %d: loss %.5f  |g| coarse %.3e fine %.3e" % (
+            ci, float(loss), np.abs(arrs["c%d_coarse_grad" % ci]).mean(), np.abs(arrs["c%d_fine_grad" % ci]).mean()))
+    arrs["n_cases"] = np.array(2)
+    save("g13_decoder_grads.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

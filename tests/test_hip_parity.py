@@ -503,15 +503,21 @@ def test_positional_encoding_and_nerf_mlp_golden(hip):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # training: gradients with respect to the feature planes
-def _grad_models(hip, g, planes, sid):
+def _grad_models(hip, g, planes, sid, what=("planes",)):
     mc, _ = build_model(hip, sd(g, "coarse."), planes, g["box"], sid=sid)
     mf, _ = build_model(hip, sd(g, "fine."), planes, g["box"], sid=sid)
     mf.planes_ = mc.planes_
     for m in (mc, mf):
         for n, p in m.named_parameters():
-            p.requires_grad_("planes_" in n)   # decoder frozen (Feature_Planes_Only.yml); the planes are the leaves
+            # ("planes",): decoder frozen (Feature_Planes_Only.yml); ("decoder",) / both: nerf.train.what of train_nerf.py:75-77
+            is_plane = "planes_" in n
+            p.requires_grad_(("planes" in what) if is_plane else ("decoder" in what and "rot_mats" not in n))
         m.train()
     return mc, mf
+
+
+def _decoder_grad_blob(model):
+    return np.concatenate([N_(p.grad).reshape(-1) for p in model.decoder_parameters()])
 
 
 def test_plane_gradients_golden(hip):
@@ -543,6 +549,120 @@ def test_plane_gradients_golden(hip):
             rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
             assert rel < 1e-2, "case %d plane %d: relative L2 error %.2e" % (ci, d, rel)
             assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
+
+
+def test_decoder_gradients_golden(hip):
+    """loss.backward() fills the decoder parameters' .grad of both models like torch.autograd through the reference (g13); planes
+    and decoder trained together, then the decoder alone (planes frozen)"""
+    g, gd = load_golden("g11_grads.npz"), load_golden("g13_decoder_grads.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    sid = "lego_DS8_PlRes16_8"
+    rays, target = T(g["rays"]), T(g["target"])
+    for what in (("planes", "decoder"), ("decoder",)):
+        mc, mf = _grad_models(hip, g, planes, sid, what=what)
+        for ci in range(int(g["n_cases"])):
+            nc, nf, perturb, std = g["c%d_params" % ci]
+            opts, scfg = make_options(int(nc), int(nf), perturb=bool(perturb), noise=float(std))
+            rnd = {k: T(g["c%d_%s" % (ci, k)]) for k in ("t_rand", "u", "noise_coarse", "noise_fine") if "c%d_%s" % (ci, k) in g}
+            for m in (mc, mf):
+                m.zero_grad(set_to_none=True)
+            out = hip.train_utils.run_one_iter_of_nerf(16, 16, float(g["hwf"][2]), mc, mf, rays, opts, sid, mode="train", scene_config=scfg,
+                                                       randoms=rnd)
+            loss = torch.nn.functional.mse_loss(out[0], target) + torch.nn.functional.mse_loss(out[3], target)
+            loss.backward()
+            for tag, m in (("coarse", mc), ("fine", mf)):
+                got, ref = _decoder_grad_blob(m), gd["c%d_%s_grad" % (ci, tag)]
+                assert got.shape == ref.shape
+                rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+                # coarse: identical depths on both sides -> fp32 summation order only; fine: depths regenerated (sample_pdf conditioning)
+                assert rel < (1e-4 if tag == "coarse" else 1e-2), "case %d %s decoder %s: relative L2 error %.2e" % (ci, tag, what, rel)
+                assert np.abs(got - ref).max() <= (1e-4 if tag == "coarse" else 3e-2) * np.abs(ref).max()
+            p0 = mc.planes_[hip.models.get_plane_name(sid, 0)]
+            if "planes" in what:
+                ref0 = g["c%d_grad_plane0" % ci]
+                assert np.linalg.norm(N_(p0.grad) - ref0) / np.linalg.norm(ref0) < 1e-2
+            else:
+                assert p0.grad is None
+
+
+def test_decoder_gradients_vs_oracle_larger(hip, oracle):
+    """700 rays (not a multiple of the 256-ray tile: padding slots of the record must contribute exact zeros), 40+56 samples,
+    non-square planes; at the SAME fine depths the HIP weight gradients match the analytic double-precision oracle"""
+    g = load_golden("g11_grads.npz")
+    rng = np.random.default_rng(41)
+    planes = [rng.standard_normal((1, 48, 36, 44), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 10, 14), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes36_10"
+    mc, mf = _grad_models(hip, g, planes, sid, what=("decoder",))
+    N, nc, nf = 700, 40, 56
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(load_golden("g08_render.npz")["pose"]))
+    sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
+    batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    opts, scfg = make_options(nc, nf)
+    old = hip.train_utils.RECORD_RAYS
+    try:
+        results = []
+        for rec_rays in (old, 256):                      # one launch, then three ray blocks (256 + 256 + 188) through the record
+            hip.train_utils.RECORD_RAYS = rec_rays
+            for m in (mc, mf):
+                m.zero_grad(set_to_none=True)
+            out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+            z_fine = N_(out[3].grad_fn.saved["z_f"])
+            if not results:
+                gc = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+                gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+            ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+            results.append((_decoder_grad_blob(mc), _decoder_grad_blob(mf)))
+    finally:
+        hip.train_utils.RECORD_RAYS = old
+    sc = oracle.scene(planes, g["box"])
+    rays_np = oracle.pack_rays(N_(batch[0]), N_(batch[1]), 2.0, 6.0)
+    dec_c, dec_f = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    ref = oracle.render_backward_decoder(sc, dec_c, dec_f, rays_np, nc, nf, N_(gc), N_(gf), z_fine=z_fine)
+    for got in results:
+        for tag, a, b in zip(("coarse", "fine"), got, ref):
+            rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+            # ReLU masks of pre-activations within fp32 noise of zero flip between the fp32 kernel and the double oracle
+            assert rel < 2e-3, "%s decoder: relative L2 error %.2e" % (tag, rel)
+            assert np.abs(a - b).max() <= 5e-3 * np.abs(b).max()
+    for a, b in zip(results[0], results[1]):             # the blocked run differs from the single launch by summation order only
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+
+
+def test_decoder_weight_grad_contraction(hip):
+    """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI"""
+    capi = hip.capi
+    N, S = 300, 7                                        # 2 ray tiles x 7 samples = 3584 slots
+    n = capi.lib().nvsr_decoder_record_floats(N, S)
+    Pp = 2 * S * 256
+    assert n == Pp * 2308
+    g_ = torch.Generator(device="cpu").manual_seed(5)
+    rec = torch.randn(n, generator=g_, dtype=torch.float32)
+    rec_d = rec.to(DEV)
+    grad = torch.zeros(capi.DECODER_NATURAL_FLOATS, device=DEV)
+    capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())
+    capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())    # accumulates: twice the gradient
+    got = N_(grad) / 2
+    r = rec.double().numpy()
+    o = 0
+    def take(cols, k=1):
+        nonlocal o
+        a = r[o:o + k * cols * Pp].reshape(k, Pp, cols)
+        o += k * cols * Pp
+        return a
+    Xd, Hd, Gd, Xr, Hr, Gr, g4 = take(64)[0], take(128, 4), take(128, 4), take(192)[0], take(128, 4), take(128, 4), take(4)[0]
+    parts = []
+    for X, H, G, width, head in ((Xd, Hd, Gd, 48, g4[:, 3:4]), (Xr, Hr, Gr, 192, g4[:, :3])):
+        parts += [(G[0].T @ X[:, :width]).ravel(), G[0].sum(0)]
+        for l in range(1, 4):
+            parts += [(G[l].T @ H[l - 1]).ravel(), G[l].sum(0)]
+        parts += [(head.T @ H[3]).ravel(), head.sum(0)]
+    ref = np.concatenate(parts)
+    assert ref.size == got.size
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(Pp))     # sums of 3584 N(0,1) products in fp32
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
 
 
 def test_composite_backward_vs_autograd_formula(hip):

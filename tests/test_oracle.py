@@ -238,6 +238,32 @@ def test_plane_gradients_against_reference_autograd(oracle):
             assert np.abs(grads[d] - ref).max() <= 5e-3 * scale
 
 
+def test_decoder_gradients_against_reference_autograd(oracle):
+    """oracle d/d(decoder weights, biases) of both models vs torch.autograd through the reference's train step (g13; the step's
+    inputs live in g11)"""
+    g, gd = load_golden("g11_grads.npz"), load_golden("g13_decoder_grads.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    sc = oracle.scene(planes, g["box"])
+    dc, df = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    rays = oracle.pack_rays(g["rays"][0], g["rays"][1], 2.0, 6.0)
+    N = rays.shape[0]
+    for ci in range(int(g["n_cases"])):
+        assert float(gd["c%d_loss" % ci]) == float(g["c%d_loss" % ci])          # same step
+        nc, nf, perturb, std = g["c%d_params" % ci]
+        rnd = {k: g.get("c%d_%s" % (ci, k)) for k in ("t_rand", "u", "noise_coarse", "noise_fine")}
+        gc = 2.0 * (g["c%d_rgb_coarse" % ci] - g["target"]) / (3 * N)
+        gf = 2.0 * (g["c%d_rgb_fine" % ci] - g["target"]) / (3 * N)
+        got = oracle.render_backward_decoder(sc, dc, df, rays, int(nc), int(nf), gc, gf, perturb=bool(perturb), t_rand=rnd["t_rand"],
+                                             u=rnd["u"], noise_coarse=rnd["noise_coarse"], noise_fine=rnd["noise_fine"])
+        for tag, mine in zip(("coarse", "fine"), got):
+            ref = gd["c%d_%s_grad" % (ci, tag)]
+            assert mine.shape == ref.shape
+            rel = np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+            # the coarse decoder sees identical depths: tight; the fine one inherits the sample_pdf conditioning (see conftest)
+            assert rel < (2e-5 if tag == "coarse" else 2e-3), "case %d %s decoder: relative L2 error %.2e" % (ci, tag, rel)
+            assert np.abs(mine - ref).max() <= (1e-4 if tag == "coarse" else 5e-3) * np.abs(ref).max()
+
+
 def test_ndc_render_end_to_end(oracle):
     """forward-facing (LLFF-style) view: ndc_rays -> packed rays with the ORIGINAL directions as view directions
     (train_utils.py:213-218) -> two-pass render"""
