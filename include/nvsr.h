@@ -192,6 +192,39 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
 /* grad_natural [NVSR_DECODER_NATURAL_FLOATS] += gradient of this pass (float atomics: zero it before the first pass) */
 int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, float* grad_natural, nvsr_stream_t stream);
 
+
+/* ---- training: gradients of the super-resolution CNN ('SR' in nerf.train.what) -------------------------------------------
+ * torch.autograd through EDSR.forward (models.py:818-822), _Residual_Block.forward (:777-786), PlanesSR.forward (:884-926). */
+/* weights [Cout][Cin][3][3] -> fragments of the conv's data gradient (nvsr_conv3x3_packed_floats(Cout, Cin) floats) */
+int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed_dgrad, nvsr_stream_t stream);
+/* data gradient of nvsr_conv3x3 (epilogue 0): dy [Cout][H-2][W-2] -> dx [Cin][H][W] */
+int nvsr_conv3x3_dgrad(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, nvsr_stream_t stream);
+/* weight gradient: dw [Cout][Cin][3][3] += scale * sum_{y,x} dy[co][y][x] * x[ci][y+ky][x+kx];  x [Cin][H][W], dy [Cout][H-2][W-2];
+ * deterministic (fixed-order reduction of per-row-slab partial sums held in the workspace) */
+int64_t nvsr_conv3x3_wgrad_workspace_floats(int Cin, int H, int W, int Cout);
+int nvsr_conv3x3_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
+                       nvsr_stream_t stream);
+/* EDSR forward that keeps every layer's input in `acts` (nvsr_edsr_acts_floats floats) for nvsr_edsr_backward */
+int64_t nvsr_edsr_acts_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W);
+int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                            float* acts, nvsr_stream_t stream);
+int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
+int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream);
+int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W);
+/* d_out [Cout][Ho][Wo] -> grad_natural (state-dict order) += weight gradients, dx [Cin][H][W] (or NULL) = input gradient */
+int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
+                       int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, nvsr_stream_t stream);
+/* PlanesSR: forward that keeps the prepared input + activation record, and its backward.  d_lr (or NULL: LR plane detached,
+ * models.py:272) += gradient of the LR plane through the network input and the bilinear residual. */
+int64_t nvsr_planes_sr_keep_floats(int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi);
+int nvsr_planes_sr_train(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                         const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                         nvsr_stream_t stream);
+int64_t nvsr_planes_sr_backward_workspace_floats(int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi);
+int nvsr_planes_sr_backward(int C, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up, int pad,
+                            int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
+                            float* workspace, nvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

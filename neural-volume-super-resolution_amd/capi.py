@@ -78,6 +78,21 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_decoder_record_floats": ([_i64, _i], _i64),
     "nvsr_render_pass_backward_ex": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp], _i),
     "nvsr_decoder_weight_grad": ([_i64, _i, _vp, _vp, _vp], _i),
+    # super-resolution CNN backward (csrc/sr_bwd.hip)
+    "nvsr_pack_conv3x3_dgrad": ([_vp, _i, _i, _vp, _vp], _i),
+    "nvsr_conv3x3_dgrad": ([_vp, _i, _i, _i, _vp, _i, _vp, _vp], _i),
+    "nvsr_conv3x3_wgrad_workspace_floats": ([_i, _i, _i, _i], _i64),
+    "nvsr_conv3x3_wgrad": ([_vp, _vp, _i, _i, _i, _i, C.c_float, _vp, _vp, _vp], _i),
+    "nvsr_edsr_acts_floats": ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    "nvsr_edsr_forward_train": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "nvsr_edsr_packed_dgrad_floats": ([_i, _i, _i, _i, _i], _i64),
+    "nvsr_pack_edsr_dgrad": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "nvsr_edsr_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    "nvsr_edsr_backward": ([_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_planes_sr_keep_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr_train": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_planes_sr_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr_backward": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     # positional-encoding baseline (csrc/posenc.hip)
     "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),

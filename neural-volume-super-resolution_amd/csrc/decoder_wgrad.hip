@@ -180,7 +180,7 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
     if (slab < 256) slab = 256;
     const unsigned nslabs = (unsigned)((Pp + slab - 1) / slab);
     hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, Pp, (int)slab, grad_natural);
-    const int hslab = 1024;
+    const int hslab = 128;        // 4096 workgroups at 524k slots: the loop is one dependent load stream per thread
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((Pp + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
                        rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, Pp, hslab, grad_natural);
     return NVSR_CHECK_LAUNCH();

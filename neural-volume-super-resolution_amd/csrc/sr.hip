@@ -11,27 +11,30 @@
 // chunk.  A wave owns 2 co-blocks x 4 pixel-blocks (128 accumulator registers); a workgroup = 8 waves arranged
 // CO_WAVES x PX_WAVES: (4,2) = 256 channels x (8 rows x 32 cols) for the wide layers, (1,8) = 64 channels x (32 x 32) for the
 // narrow heads.  Epilogues fuse ReLU, the residual block's x0.1 + centre-cropped identity, and PixelShuffle(2).
-#include "nvsr_common.h"
+#include <type_traits>
+
+#include "sr_core.h"
 
 namespace nvsr {
 
 constexpr int CONV_TPB = 512;
 constexpr int CONV_WAVES = 8;
-constexpr int K_PER_CHUNK = 18;                 // MFMA k-steps per 4-channel chunk (36 k / 2)
-constexpr int FRAG_FLOATS = K_PER_CHUNK * 64;   // 1152 floats per (chunk, co-block)
 
-enum ConvEpilogue { EPI_NONE = 0, EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_PIXEL_SHUFFLE = 3 };
 
 struct ConvParams {
-    const float* in;      // [Cin][H][W]
+    const float* in;      // [Cin][H-2pad][W-2pad]
     const float* wpk;     // packed weights [chunk][cb][t][lane]
     float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
-    const float* skip;    // residual identity [Cout][H+2][W+2] (block input), EPI_RESIDUAL only
-    int Cin, Cout, H, W;
+    const float* skip;    // EPI_RESIDUAL: identity [Cout][H+2][W+2] (block input); EPI_MASK_SCALE: forward activation
+                          // [Cout][H-2][W-2] whose sign gates the result; EPI_ADD_CENTER: [Cout][H-6][W-6] added to the centre
+    int Cin, Cout, H, W;  // H, W = logical input size, INCLUDING the virtual zero border of `pad` pixels
     int ncb_total;        // padded co-blocks in wpk (multiple of 2)
     int nchunks;          // ceil(Cin/4)
     int epilogue;
+    int pad;              // 0, or 2 for the data gradient of a valid conv ("full" correlation with the flipped kernel)
 };
+
+__device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
 
 template <int CO_WAVES, int PX_WAVES>
 __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
     const int cw = wave / PX_WAVES, rg = wave % PX_WAVES;   // co-wave, pixel-row group
     const int Ho = p.H - 2, Wo = p.W - 2;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * ROWS, cg = blockIdx.z;
-    const long HW = (long)p.H * p.W;
+    const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
+    const long HW = (long)Hr * Wr;
 
     // per-thread source offsets of the patch elements it DMA-copies (spatial part; the channel part changes per chunk)
     int p_sp[P_ITERS], p_cl[P_ITERS];
@@ -60,7 +64,8 @@ __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
         const int e = (i * CONV_WAVES + wave) * 64 + lane;
         const int cl = e / (PR * PC), rem = e - cl * (PR * PC), r = rem / PC, c = rem - r * PC;
         p_cl[i] = (e < P_FLOATS) ? cl : -1;
-        p_sp[i] = min(y0 + r, p.H - 1) * p.W + min(x0 + c, p.W - 1);
+        const int yr = min(y0 + r, p.H - 1) - p.pad, xr = min(x0 + c, p.W - 1) - p.pad;
+        p_sp[i] = (yr >= 0 && yr < Hr && xr >= 0 && xr < Wr) ? yr * Wr + xr : -1;     // -1: virtual zero border
     }
     const float* wsrc = p.wpk + (long)cg * NCB * FRAG_FLOATS;
     const long wchunk_stride = (long)p.ncb_total * FRAG_FLOATS;
@@ -80,7 +85,8 @@ __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
         for (int i = 0; i < P_ITERS; ++i) {
             if (p_cl[i] >= 0) {
                 const int ci = min(chunk * 4 + p_cl[i], p.Cin - 1);   // padded channels carry zero weights
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + ci * HW + p_sp[i]),
+                const float* src = (p_sp[i] >= 0) ? p.in + ci * HW + p_sp[i] : g_zero_word;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(pl + (i * CONV_WAVES + wave) * 64), 4, 0, 0);
             }
         }
@@ -125,31 +131,50 @@ __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // (one fully unrolled copy per epilogue kind: with the kind tested inside, the unroller gives up and the accumulators are
+    //  indexed dynamically, i.e. go through scratch)
     const int x = x0 + j;
+    auto write_out = [&](auto kind) {
+        constexpr int EPI = decltype(kind)::value;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            const int y = y0 + rg * 4 + pb;
-            if (y >= Ho || x >= Wo) continue;
+            for (int pb = 0; pb < 4; ++pb) {
+                const int y = y0 + rg * 4 + pb;
+                const bool inside = y < Ho && x < Wo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = (cg * NCB + cw * 2 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co >= p.Cout) continue;
-                float v = acc[cb][pb][r];
-                if (p.epilogue == EPI_RELU) v = fmaxf(v, 0.0f);
-                if (p.epilogue == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
-                    v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
-                if (p.epilogue == EPI_PIXEL_SHUFFLE)
-                    p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
-                else
-                    p.out[((long)co * Ho + y) * Wo + x] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (cg * NCB + cw * 2 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (inside && co < p.Cout) {
+                        float v = acc[cb][pb][r];
+                        if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
+                        if (EPI == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
+                            v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
+                        if (EPI == EPI_MASK_SCALE)  // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
+                            v = (p.skip[((long)co * Ho + y) * Wo + x] > 0.0f) ? v * 0.1f : 0.0f;
+                        if (EPI == EPI_ADD_CENTER)  // backward of the cropped identity: the block's output gradient lands in the centre
+                            if (y >= 2 && y < Ho - 2 && x >= 2 && x < Wo - 2) v += p.skip[((long)co * (Ho - 4) + (y - 2)) * (Wo - 4) + (x - 2)];
+                        if (EPI == EPI_PIXEL_SHUFFLE)
+                            p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
+                        else
+                            p.out[((long)co * Ho + y) * Wo + x] = v;
+                    }
+                }
             }
-        }
+    };
+    switch (p.epilogue) {
+        case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
+        case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
+        case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
+        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
+        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
+        default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
+    }
 }
 
-// [Cout][Cin][3][3] -> [chunk][cb][t][lane]
-__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int nchunks) {
+// [Cout][Cin][3][3] -> [chunk][cb][t][lane].  transposed: the packed conv is the DATA GRADIENT of w's conv, i.e. it maps Cout
+// channels to Cin channels with w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]; (Cin, Cout) are then those of the packed conv.
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int nchunks, int transposed) {
     const long n = (long)nchunks * ncb * FRAG_FLOATS;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -157,7 +182,9 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
     const long rest = idx / FRAG_FLOATS;
     const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
     const int co = 32 * cb + (lane & 31), ci = 4 * chunk + t / 9 + 2 * (lane >> 5), tap = t % 9;
-    wpk[idx] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * 9 + tap] : 0.0f;
+    float v = 0.0f;
+    if (co < Cout && ci < Cin) v = transposed ? w[((long)ci * Cout + co) * 9 + (8 - tap)] : w[((long)co * Cin + ci) * 9 + tap];
+    wpk[idx] = v;
 }
 
 // PlanesSR input: crop with as much real context as available + replicate padding == clamped gather (models.py:906-914),
@@ -196,16 +223,11 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
     out[i] = diff[((long)c * Ho + dy) * Wo + dx] + res;
 }
 
-struct ConvLayer { int Cin, Cout; };
-
-static inline int conv_ncb(int Cout) { return (Cout + 63) / 64 * 2; }
-static inline int conv_nchunks(int Cin) { return (Cin + 3) / 4; }
-static inline int64_t conv_packed_floats(int Cin, int Cout) { return (int64_t)conv_nchunks(Cin) * conv_ncb(Cout) * FRAG_FLOATS; }
-
-static int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                       hipStream_t stream) {
+int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
+                hipStream_t stream, int pad) {
+    H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3) return NVSR_ERR_SHAPE;
-    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue};
+    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad};
     const int Ho = H - 2, Wo = W - 2;
     if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncb_total / 8);
@@ -215,16 +237,6 @@ static int launch_conv(const float* in, int Cin, int H, int W, const float* wpk,
         hipLaunchKernelGGL((conv3x3_kernel<1, 8>), grid, dim3(CONV_TPB), 0, stream, p);
     }
     return NVSR_CHECK_LAUNCH();
-}
-
-static void edsr_layers(int Cin, int Cout, int hid, int nblocks, int n_up, ConvLayer* L, int* n) {
-    int k = 0;
-    L[k++] = {Cin, hid};
-    for (int b = 0; b < 2 * nblocks; ++b) L[k++] = {hid, hid};
-    L[k++] = {hid, hid};
-    for (int u = 0; u < n_up; ++u) L[k++] = {hid, 4 * hid};
-    L[k++] = {hid, Cout};
-    *n = k;
 }
 
 }  // namespace nvsr
@@ -242,8 +254,28 @@ int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_str
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
     const int64_t n = conv_packed_floats(Cin, Cout);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout,
-                       conv_ncb(Cout), conv_nchunks(Cin));
+                       conv_ncb(Cout), conv_nchunks(Cin), 0);
     return NVSR_CHECK_LAUNCH();
+}
+
+/* weights [Cout][Cin][3][3] of a conv -> packed fragments of its data gradient (a Cout -> Cin conv with the flipped, transposed
+ * kernel); nvsr_conv3x3_packed_floats(Cout, Cin) floats */
+int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nvsr_stream_t stream) {
+    if (!w || !packed) return NVSR_ERR_NULL;
+    if (Cin < 1 || Cout < 1) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    const int64_t n = conv_packed_floats(Cout, Cin);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
+                       conv_ncb(Cin), conv_nchunks(Cout), 1);
+    return NVSR_CHECK_LAUNCH();
+}
+
+/* data gradient of nvsr_conv3x3 (epilogue 0): dy [Cout][H-2][W-2] -> dx [Cin][H][W]; packed_dgrad from nvsr_pack_conv3x3_dgrad */
+int nvsr_conv3x3_dgrad(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, nvsr_stream_t stream) {
+    if (!dy || !packed_dgrad || !dx) return NVSR_ERR_NULL;
+    if (!aligned16(packed_dgrad)) return NVSR_ERR_ALIGN;
+    if (H < 3 || W < 3) return NVSR_ERR_SHAPE;
+    return launch_conv(dy, Cout, H - 2, W - 2, packed_dgrad, Cin, EPI_NONE, nullptr, dx, (hipStream_t)stream, 2);
 }
 
 /* epilogue: 0 none, 1 ReLU, 2 residual (out = conv*0.1 + skip[..., 2:-2, 2:-2], skip = [Cout][H+2][W+2]), 3 PixelShuffle(2) */
@@ -338,22 +370,33 @@ int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed
     return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream);
 }
 
+/* ---- training forward: every layer's input is kept for the backward pass (sr_bwd.hip) ---------------------------------- */
+int64_t nvsr_edsr_acts_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W) {
+    EdsrPlan P;
+    if (edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return -1;
+    return P.acts_floats;
+}
+
+int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                            float* acts, nvsr_stream_t stream_) {
+    if (!x || !packed || !out || !acts) return NVSR_ERR_NULL;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    EdsrPlan P;
+    if (int e = edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return e;
+    const float* wp = packed;
+    for (int l = 0; l < P.n; ++l) {
+        const float* in = l ? acts + P.act_off[l] : x;
+        float* o = (l + 1 < P.n) ? acts + P.act_off[l + 1] : out;
+        const float* skip = (P.epi[l] == EPI_RESIDUAL) ? (l >= 2 ? acts + P.act_off[l - 1] : x) : nullptr;   // the block's input
+        if (int e = launch_conv(in, P.L[l].Cin, P.ih[l], P.iw[l], wp, P.L[l].Cout, P.epi[l], skip, o, (hipStream_t)stream_)) return e;
+        wp += conv_packed_floats(P.L[l].Cin, P.L[l].Cout);
+    }
+    return NVSR_OK;
+}
+
 /* PlanesSR.forward (models.py:884-926).  lr [C][R0][R1]; roi = NULL (full plane) or 4 HOST floats [[ymin,xmin],[ymax,xmax]] in
  * [-1,1]; pad = inner_model.required_padding, over = HR_overpadding; mean/std optional [C] (device).
  * out [C][sf*R0][sf*R1] (NaN outside the ROI).  workspace: nvsr_planes_sr_workspace_floats(...) floats. */
-static void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
-    lo[0] = lo[1] = 0; hi[0] = R0; hi[1] = R1;
-    if (!roi) return;
-    const int shape[2] = {R0, R1};
-    for (int a = 0; a < 2; ++a) {
-        const float mn = (float)shape[a] * (1.0f + roi[a]) / 2.0f, mx = (float)shape[a] * (1.0f + roi[2 + a]) / 2.0f;
-        int l = (int)floorf(mn), hh = (int)ceilf(mx);
-        l = l - 1 > 0 ? l - 1 : 0;
-        hh = hh + 1 < shape[a] ? hh + 1 : shape[a];
-        lo[a] = l; hi[a] = hh;
-    }
-}
-
 int64_t nvsr_planes_sr_workspace_floats(int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi) {
     int lo[2], hi[2];
     sr_roi(R0, R1, roi, lo, hi);
@@ -363,8 +406,36 @@ int64_t nvsr_planes_sr_workspace_floats(int Cc, int R0, int R1, int hid, int nbl
     return (int64_t)Cc * Hp * Wp + (int64_t)Cc * Ho * Wo + nvsr_edsr_workspace_floats(hid, nblocks, n_up, Hp, Wp);
 }
 
+/* floats kept between nvsr_planes_sr_train and nvsr_planes_sr_backward: the prepared network input + the activation record */
+int64_t nvsr_planes_sr_keep_floats(int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi) {
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int Hp = hi[0] - lo[0] + 2 * pad, Wp = hi[1] - lo[1] + 2 * pad;
+    const int64_t a = nvsr_edsr_acts_floats(Cc, Cc, hid, nblocks, n_up, Hp, Wp);
+    if (a < 0) return -1;
+    return ((int64_t)Cc * Hp * Wp + 3) / 4 * 4 + a;
+}
+
+static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                          const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                          nvsr_stream_t stream_);
+
 int nvsr_planes_sr(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* stdv, float* out, float* workspace, nvsr_stream_t stream_) {
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, nullptr, stream_);
+}
+
+/* nvsr_planes_sr that keeps what the backward needs in `keep` (nvsr_planes_sr_keep_floats floats); same workspace */
+int nvsr_planes_sr_train(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                         const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                         nvsr_stream_t stream_) {
+    if (!keep) return NVSR_ERR_NULL;
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, keep, stream_);
+}
+
+static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                          const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                          nvsr_stream_t stream_) {
     if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
     if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -376,14 +447,17 @@ int nvsr_planes_sr(const float* lr, int Cc, int R0, int R1, const float* packed,
     int Ho, Wo;
     if (int e = nvsr_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo)) return e;
     if (Ho != ch * sf + 2 * over || Wo != cw * sf + 2 * over) return NVSR_ERR_SHAPE;   // pad/over inconsistent with the net
-    float* xin = workspace;
-    float* diff = xin + (int64_t)Cc * Hp * Wp;
+    float* xin = keep ? keep : workspace;
+    float* diff = workspace + (int64_t)Cc * Hp * Wp;
     float* ews = diff + (int64_t)Cc * Ho * Wo;
     const int64_t n_in = (int64_t)Cc * Hp * Wp;
     hipLaunchKernelGGL(sr_prepare_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, lr, Cc, R0, R1, lo[0], lo[1], Hp, Wp,
                        pad, mean, stdv, xin);
     if (int e = NVSR_CHECK_LAUNCH()) return e;
-    if (int e = nvsr_edsr_forward(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
+    if (keep) {
+        if (int e = nvsr_edsr_forward_train(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, keep + ((int64_t)Cc * Hp * Wp + 3) / 4 * 4, stream_))
+            return e;
+    } else if (int e = nvsr_edsr_forward(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
                        lo[0], lo[1], hi[0], hi[1], out);

@@ -1,0 +1,371 @@
+// Backward of the feature-plane super-resolution CNN for gfx950 ('SR' in nerf.train.what, train_nerf.py:75-77).
+//
+// The reference differentiates EDSR.forward (models.py:818-822), _Residual_Block.forward (:777-786) and PlanesSR.forward (:884-926)
+// with torch.autograd (cuDNN conv backward-data / backward-filter).  Here:
+//   * data gradient of a valid 3x3 conv = the forward implicit-GEMM kernel of sr.hip run on dy with a virtual 2-pixel zero border and
+//     the flipped, transposed kernel (nvsr_pack_conv3x3_dgrad); the residual block's ReLU gate + x0.1 and its cropped identity are
+//     fused epilogues (EPI_MASK_SCALE, EPI_ADD_CENTER);
+//   * weight gradient dW[co][ci][ky][kx] = sum_{y,x} dy[co][y][x] * X[ci][y+ky][x+kx] is conv3x3_wgrad_kernel below: an MFMA
+//     contraction with the PIXELS as K.  One dy fragment (A) feeds the 9 taps, whose B fragments are the same LDS patch of X read at
+//     9 shifts.  Workgroups split the image rows; their partial sums go to a workspace and a second kernel reduces them in a fixed
+//     order (deterministic, no float atomics) into the natural [co][ci][3][3] layout;
+//   * PixelShuffle^T is an explicit re-layout kernel (0.1 % of the time of the convs around it).
+#include "sr_core.h"
+
+namespace nvsr {
+
+constexpr int WG_TPB = 256;                              // 4 waves; two workgroups per CU cover each other's barriers
+constexpr int WG_CO = 64, WG_CI = 64, WG_PX = 32;       // workgroup tile: 2 co-waves x 2 ci-waves, 32 pixels of one row per step
+constexpr int DY_STRIDE = WG_PX + 1;                     // odd strides: lanes (= channels) hit distinct LDS banks
+constexpr int X_ROW = WG_PX + 3, X_CI = 3 * X_ROW;       // 35, 105
+constexpr int DY_FLOATS = WG_CO * DY_STRIDE;             // 4224
+constexpr int X_FLOATS = WG_CI * X_CI;                   // 6720
+constexpr int DY_ITERS = WG_CO * WG_PX / WG_TPB;         // 8
+static_assert(WG_TPB == 256 && WG_CO == 64 && WG_CI == 64 && WG_PX == 32, "the tile-fill index arithmetic assumes this shape");
+
+struct WgradParams {
+    const float* dy;     // [Cout][Ho][Wo]
+    const float* x;      // [Cin][Ho+2][Wo+2]
+    float* partial;      // [nslab][9][Cout][Cin]
+    int Cin, Cout, Ho, Wo;
+    int rows_per_slab;
+};
+
+__global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
+    __shared__ float lds[DY_FLOATS + X_FLOATS];
+    float* dyt = lds;
+    float* xt = lds + DY_FLOATS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
+    const int cw = wave & 1, iw = wave >> 1;
+    const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = blockIdx.z;
+    const int W = p.Wo + 2;
+    const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
+    const int ya = slab * p.rows_per_slab, yb = min(ya + p.rows_per_slab, p.Ho);
+    const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
+    const int nsteps = (yb - ya) * nxc;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // Tile fill, 34 loads per thread and step.  Thread (t5 = tid>>5, c = tid&31) takes column c of rows t5, t5+8, ...:
+    //   dy : row = co (64 rows);  X body: row = (r, ci) r-major (192 rows), columns 0..31;  X halo: columns 32, 33 of the 192 rows.
+    // All index arithmetic is shifts and compile-time constants, so nothing per-element has to stay live across the MFMA loop.
+    constexpr int XB_ITERS = 3 * WG_CI / 8;   // 24
+    float rdy[DY_ITERS], rxb[XB_ITERS], rxh[2];
+    const int t5 = tid >> 5, c = tid & 31;
+    const int hrow = tid >> 1, hcol = WG_PX + (tid & 1);            // halo element of this thread: rows hrow and hrow + 128
+    auto fetch = [&](int step) {
+        const int y = ya + step / nxc, x0 = (step % nxc) * WG_PX;
+        const bool px_ok = x0 + c < p.Wo;
+        const float* dp = p.dy + (long)(co0 + t5) * HoWo + (long)y * p.Wo + x0 + c;
+#pragma unroll
+        for (int it = 0; it < DY_ITERS; ++it)
+            rdy[it] = (px_ok && co0 + t5 + 8 * it < p.Cout) ? dp[(long)(8 * it) * HoWo] : 0.0f;
+        // columns past the image edge only ever meet dy == 0: any finite value will do, so clamp the address
+        const float* xp = p.x + (long)(ci0 + t5) * HW + (long)y * W + min(x0 + c, W - 1);
+#pragma unroll
+        for (int it = 0; it < XB_ITERS; ++it) {
+            const int r = it / 8, cib = (it % 8) * 8;
+            rxb[it] = (ci0 + t5 + cib < p.Cin) ? xp[(long)cib * HW + r * W] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = hrow + 128 * k, r = row >> 6, ci = row & 63;
+            rxh[k] = (row < 3 * WG_CI && ci0 + ci < p.Cin) ? p.x[(long)(ci0 + ci) * HW + (long)(y + r) * W + min(x0 + hcol, W - 1)] : 0.0f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < DY_ITERS; ++it) dyt[(t5 + 8 * it) * DY_STRIDE + c] = rdy[it];
+#pragma unroll
+        for (int it = 0; it < XB_ITERS; ++it) xt[(t5 + (it % 8) * 8) * X_CI + (it / 8) * X_ROW + c] = rxb[it];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = hrow + 128 * k;
+            if (row < 3 * WG_CI) xt[(row & 63) * X_CI + (row >> 6) * X_ROW + hcol] = rxh[k];
+        }
+    };
+
+    if (nsteps > 0) fetch(0);
+    const float* A = dyt + (cw * 32 + i) * DY_STRIDE + kh;
+    const float* B = xt + (iw * 32 + i) * X_CI + kh;
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                       // everyone is done reading the previous tile
+        stage();
+        __syncthreads();
+        if (step + 1 < nsteps) fetch(step + 1);   // global loads fly under the MFMAs below
+#pragma unroll 4
+        for (int kk = 0; kk < WG_PX / 2; ++kk) {
+            const float a = A[2 * kk];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float b0 = B[ky * X_ROW + 2 * kk], b1 = B[ky * X_ROW + 2 * kk + 1], b2 = B[ky * X_ROW + 2 * kk + 2];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = co][col = ci]: lanes run along ci -> 128-byte rows of the [tap][co][ci] partial
+    const int ci = ci0 + iw * 32 + i;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < p.Cout) p.partial[(((long)slab * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][r];
+            }
+    }
+}
+
+// dw[co][ci][tap] += scale * sum_slab partial[slab][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslab, int Cout, int Cin, float scale, float* __restrict__ dw) {
+    const long n = 9L * Cout * Cin;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nslab; ++k) s += partial[k * n + idx];
+    const int t = (int)(idx / ((long)Cout * Cin));
+    const long cc = idx - (long)t * Cout * Cin;       // co * Cin + ci
+    dw[cc * 9 + t] += scale * s;
+}
+
+// PixelShuffle(2)^T: g [C][2h][2w] -> out [4C][h][w]
+__global__ void pixel_unshuffle_kernel(const float* __restrict__ g, int Cc, int h, int w, float* __restrict__ out) {
+    const long n = 4L * Cc * h * w;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int x = (int)(idx % w), y = (int)((idx / w) % h), c4 = (int)(idx / ((long)w * h));
+    out[idx] = g[((long)(c4 >> 2) * 2 * h + 2 * y + ((c4 >> 1) & 1)) * 2 * w + 2 * x + (c4 & 1)];
+}
+
+// PlanesSR backward, output side (models.py:915-923): d_out [C][sf R0][sf R1] -> d_diff [C][Ho][Wo] (zero in the over-padding
+// ring) and, when d_lr != NULL, the bilinear residual's share of d_lr (4 float atomics per HR pixel of the ROI)
+__global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int Cc, int R0, int R1, int sf, int lo0, int lo1, int hi0, int hi1,
+                                          int Ho, int Wo, int over, float* __restrict__ d_diff, float* __restrict__ d_lr) {
+    const long n = (long)Cc * Ho * Wo;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int dx = (int)(i % Wo), dy = (int)((i / Wo) % Ho), c = (int)(i / ((long)Wo * Ho));
+    const int ry = dy - over, rx = dx - over;                 // position inside the ROI, HR pixels
+    const int ch = (hi0 - lo0) * sf, cw = (hi1 - lo1) * sf;
+    if (ry < 0 || ry >= ch || rx < 0 || rx >= cw) { d_diff[i] = 0.0f; return; }
+    const int HR0 = R0 * sf, HR1 = R1 * sf;
+    const int oy = lo0 * sf + ry, ox = lo1 * sf + rx;
+    const float g = d_out[((long)c * HR0 + oy) * HR1 + ox];
+    d_diff[i] = g;
+    if (!d_lr) return;
+    const float sh = HR0 > 1 ? (float)(R0 - 1) / (float)(HR0 - 1) : 0.0f;
+    const float sw = HR1 > 1 ? (float)(R1 - 1) / (float)(HR1 - 1) : 0.0f;
+    const float fy = sh * (float)oy, fx = sw * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = (y0 < R0 - 1) ? 1 : 0, xp = (x0 < R1 - 1) ? 1 : 0;
+    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    float* q = d_lr + ((long)c * R0 + y0) * R1 + x0;
+    unsafeAtomicAdd(q, g * ly0 * lx0);
+    unsafeAtomicAdd(q + xp, g * ly0 * lx1);
+    unsafeAtomicAdd(q + (long)yp * R1, g * ly1 * lx0);
+    unsafeAtomicAdd(q + (long)yp * R1 + xp, g * ly1 * lx1);
+}
+
+// PlanesSR backward, input side: the clamped gather of sr_prepare_kernel transposed (replicate padding sums into the border texels)
+__global__ void sr_prepare_backward_kernel(const float* __restrict__ dxin, int Cc, int R0, int R1, int lo0, int lo1, int Hp, int Wp, int pad,
+                                           const float* __restrict__ stdv, float* __restrict__ d_lr) {
+    const long n = (long)Cc * Hp * Wp;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int xx = (int)(i % Wp), y = (int)((i / Wp) % Hp), c = (int)(i / ((long)Wp * Hp));
+    const int sy = min(max(lo0 - pad + y, 0), R0 - 1), sx = min(max(lo1 - pad + xx, 0), R1 - 1);
+    float v = dxin[i];
+    if (stdv) v /= stdv[c];
+    unsafeAtomicAdd(d_lr + ((long)c * R0 + sy) * R1 + sx, v);
+}
+
+static int wgrad_slabs(int Cin, int Cout, int Ho) {
+    const int tiles = ((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI);
+    int ns = (640 + tiles - 1) / tiles;          // ~2.5 workgroups per CU
+    if (ns > Ho) ns = Ho;
+    return ns < 1 ? 1 : ns;
+}
+static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho) { return (int64_t)wgrad_slabs(Cin, Cout, Ho) * 9 * Cout * Cin; }
+
+// dw += scale * dW(dy, x);  H, W = size of x
+static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* partial,
+                        hipStream_t stream) {
+    const int Ho = H - 2, Wo = W - 2;
+    if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
+    const int ns = wgrad_slabs(Cin, Cout, Ho);
+    WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns};
+    dim3 grid((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(WG_TPB), 0, stream, p);
+    const long n = 9L * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
+    return NVSR_CHECK_LAUNCH();
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" {
+
+int64_t nvsr_conv3x3_wgrad_workspace_floats(int Cin, int H, int W, int Cout) {
+    if (Cin < 1 || Cout < 1 || H < 3 || W < 3) return -1;
+    return wgrad_partial_floats(Cin, Cout, H - 2);
+}
+
+/* weight gradient of nvsr_conv3x3 (epilogue 0): dw [Cout][Cin][3][3] += scale * sum_{y,x} dy[co][y][x] x[ci][y+ky][x+kx] */
+int nvsr_conv3x3_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
+                       nvsr_stream_t stream) {
+    if (!dy || !x || !dw || !workspace) return NVSR_ERR_NULL;
+    if (Cin < 1 || Cout < 1 || H < 3 || W < 3) return NVSR_ERR_SHAPE;
+    return launch_wgrad(dy, x, Cin, H, W, Cout, scale, dw, workspace, (hipStream_t)stream);
+}
+
+/* every layer's data-gradient fragments, layer after layer in state-dict order */
+int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, int n_up) {
+    if (!edsr_geometry_ok(nblocks, n_up)) return -1;
+    ConvLayer L[EDSR_MAX_LAYERS]; int n;
+    edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
+    int64_t s = 0;
+    for (int i = 0; i < n; ++i) s += conv_packed_floats(L[i].Cout, L[i].Cin);
+    return s;
+}
+int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream) {
+    if (!natural || !packed_dgrad) return NVSR_ERR_NULL;
+    if (!edsr_geometry_ok(nblocks, n_up)) return NVSR_ERR_SHAPE;
+    ConvLayer L[EDSR_MAX_LAYERS]; int n;
+    edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
+    for (int i = 0; i < n; ++i) {
+        if (int e = nvsr_pack_conv3x3_dgrad(natural, L[i].Cin, L[i].Cout, packed_dgrad, stream)) return e;
+        natural += 9LL * L[i].Cin * L[i].Cout;
+        packed_dgrad += conv_packed_floats(L[i].Cout, L[i].Cin);
+    }
+    return NVSR_OK;
+}
+
+/* 3 gradient tensors + 1 un-shuffled gradient + the weight-gradient partial sums */
+int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W) {
+    EdsrPlan P;
+    if (edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return -1;
+    int64_t part = 0;
+    for (int l = 0; l < P.n; ++l) {
+        const int64_t f = wgrad_partial_floats(P.L[l].Cin, P.L[l].Cout, P.ih[l] - 2);
+        if (f > part) part = f;
+    }
+    const int64_t t = (P.max_tensor + 3) / 4 * 4;
+    return 4 * t + part;
+}
+
+/* Backward of nvsr_edsr_forward_train.  x, acts: the forward's input and activation record; d_out [Cout][Ho][Wo];
+ * grad_natural (state-dict order, nvsr_edsr_natural_floats) += weight gradients; dx [Cin][H][W] or NULL. */
+int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
+                       int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, nvsr_stream_t stream_) {
+    if (!x || !acts || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
+    if (!aligned16(packed_dgrad) || !aligned16(workspace)) return NVSR_ERR_ALIGN;
+    EdsrPlan P;
+    if (int e = edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return e;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t t = (P.max_tensor + 3) / 4 * 4;
+    float* buf[3] = {workspace, workspace + t, workspace + 2 * t};
+    float* unsh = workspace + 3 * t;
+    float* partial = workspace + 4 * t;
+    // per-layer offsets into the natural gradient blob and the packed data-gradient blob
+    int64_t goff[EDSR_MAX_LAYERS], poff[EDSR_MAX_LAYERS], go = 0, po = 0;
+    for (int l = 0; l < P.n; ++l) {
+        goff[l] = go; poff[l] = po;
+        go += 9LL * P.L[l].Cin * P.L[l].Cout;
+        po += conv_packed_floats(P.L[l].Cout, P.L[l].Cin);
+    }
+    auto input_of = [&](int l) { return l ? acts + P.act_off[l] : x; };
+    const float* g = d_out;       // gradient with respect to the output of layer l (after its epilogue)
+    int gi = -1;                   // index of g in buf (-1: the caller's d_out)
+    auto next_buf = [&](int a, int b) { for (int k = 0; k < 3; ++k) if (k != a && k != b) return k; return 0; };
+    int e;
+    for (int l = P.n - 1; l >= 0; --l) {
+        const int ci = P.L[l].Cin, co = P.L[l].Cout, ih = P.ih[l], iw = P.iw[l];
+        const bool need_dx = l > 0 || dx;
+        if (P.epi[l] == EPI_PIXEL_SHUFFLE) {           // g is [co/4][2(ih-2)][2(iw-2)]: undo the shuffle first
+            const long n = (long)co * (ih - 2) * (iw - 2);
+            hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, co / 4, ih - 2, iw - 2, unsh);
+            if ((e = NVSR_CHECK_LAUNCH())) return e;
+            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream))) return e;
+            const int o = next_buf(gi, -1);
+            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2))) return e;
+            g = buf[o]; gi = o;
+        } else if (P.epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
+            const float* t1 = input_of(l);             // relu(conv1(xb)), [hid][ih][iw]
+            const float* xb = input_of(l - 1);         // [hid][ih+2][iw+2]
+            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream))) return e;
+            const int o1 = next_buf(gi, -1);
+            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2))) return e;
+            const int l1 = l - 1;
+            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream))) return e;
+            const int o2 = next_buf(gi, o1);
+            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2))) return e;
+            g = buf[o2]; gi = o2;
+            --l;                                        // conv1 is done too
+        } else {                                        // plain conv (conv_input, conv_mid, conv_output)
+            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream))) return e;
+            if (need_dx) {
+                float* o = (l == 0) ? dx : buf[next_buf(gi, -1)];
+                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2))) return e;
+                if (l) { gi = next_buf(gi, -1); g = buf[gi]; }
+            }
+        }
+    }
+    return NVSR_OK;
+}
+
+/* 1 d_diff + the prepared-input gradient + the EDSR backward workspace */
+int64_t nvsr_planes_sr_backward_workspace_floats(int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi) {
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int Hp = hi[0] - lo[0] + 2 * pad, Wp = hi[1] - lo[1] + 2 * pad;
+    EdsrPlan P;
+    if (edsr_plan(Cc, Cc, hid, nblocks, n_up, Hp, Wp, &P)) return -1;
+    const int64_t w = nvsr_edsr_backward_workspace_floats(Cc, Cc, hid, nblocks, n_up, Hp, Wp);
+    return ((int64_t)Cc * P.Ho * P.Wo + 3) / 4 * 4 + ((int64_t)Cc * Hp * Wp + 3) / 4 * 4 + w;
+}
+
+/* Backward of nvsr_planes_sr_train.  d_out [C][sf R0][sf R1] (entries outside the ROI are ignored); grad_natural += EDSR weight
+ * gradients; d_lr [C][R0][R1] += gradient of the LR plane (network input + bilinear residual) or NULL when the LR plane is detached
+ * (models.py:272). */
+int nvsr_planes_sr_backward(int Cc, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up, int pad,
+                            int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
+                            float* workspace, nvsr_stream_t stream_) {
+    if (!keep || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int sf = 1 << n_up;
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int ch = hi[0] - lo[0], cw = hi[1] - lo[1];
+    const int Hp = ch + 2 * pad, Wp = cw + 2 * pad;
+    EdsrPlan P;
+    if (int e = edsr_plan(Cc, Cc, hid, nblocks, n_up, Hp, Wp, &P)) return e;
+    if (P.Ho != ch * sf + 2 * over || P.Wo != cw * sf + 2 * over) return NVSR_ERR_SHAPE;
+    const int64_t n_diff = (int64_t)Cc * P.Ho * P.Wo, n_in = (int64_t)Cc * Hp * Wp;
+    float* d_diff = workspace;
+    float* dxin = d_diff + (n_diff + 3) / 4 * 4;
+    float* ews = dxin + (n_in + 3) / 4 * 4;
+    hipLaunchKernelGGL(sr_finish_backward_kernel, dim3((unsigned)((n_diff + 255) / 256)), dim3(256), 0, stream, d_out, Cc, R0, R1, sf, lo[0],
+                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr);
+    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    const float* xin = keep;
+    const float* acts = keep + (n_in + 3) / 4 * 4;
+    if (int e = nvsr_edsr_backward(xin, Cc, Hp, Wp, acts, packed_dgrad, Cc, hid, nblocks, n_up, d_diff, grad_natural, d_lr ? dxin : nullptr, ews,
+                                   stream_))
+        return e;
+    if (d_lr) {
+        hipLaunchKernelGGL(sr_prepare_backward_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, dxin, Cc, R0, R1, lo[0], lo[1],
+                           Hp, Wp, pad, stdv, d_lr);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    return NVSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Host-side helpers shared by sr.hip (forward) and sr_bwd.hip (backward) -- not part of the public ABI.
+#pragma once
+#include <math.h>
+
+#include "nvsr_common.h"
+
+namespace nvsr {
+
+constexpr int K_PER_CHUNK = 18;                 // MFMA k-steps per 4-channel chunk (36 k / 2)
+constexpr int FRAG_FLOATS = K_PER_CHUNK * 64;   // 1152 floats per (chunk, co-block)
+
+// EPI_MASK_SCALE / EPI_ADD_CENTER are the two fused epilogues of a residual block's backward (sr_bwd.hip)
+enum ConvEpilogue { EPI_NONE = 0, EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_PIXEL_SHUFFLE = 3, EPI_MASK_SCALE = 4, EPI_ADD_CENTER = 5 };
+
+struct ConvLayer { int Cin, Cout; };
+
+inline int conv_ncb(int Cout) { return (Cout + 63) / 64 * 2; }
+inline int conv_nchunks(int Cin) { return (Cin + 3) / 4; }
+inline int64_t conv_packed_floats(int Cin, int Cout) { return (int64_t)conv_nchunks(Cin) * conv_ncb(Cout) * FRAG_FLOATS; }
+
+// conv_input, (conv1, conv2) x nblocks, conv_mid, n_up x up-conv, conv_output  (state-dict order, models.py:802-816)
+inline void edsr_layers(int Cin, int Cout, int hid, int nblocks, int n_up, ConvLayer* L, int* n) {
+    int k = 0;
+    L[k++] = {Cin, hid};
+    for (int b = 0; b < 2 * nblocks; ++b) L[k++] = {hid, hid};
+    L[k++] = {hid, hid};
+    for (int u = 0; u < n_up; ++u) L[k++] = {hid, 4 * hid};
+    L[k++] = {hid, Cout};
+    *n = k;
+}
+constexpr int EDSR_MAX_LAYERS = 600;
+inline bool edsr_geometry_ok(int nblocks, int n_up) { return nblocks >= 0 && nblocks <= 290 && n_up >= 0 && n_up <= 8; }
+
+// Geometry of one EDSR application to an [Cin][H][W] input: per layer the input size, the epilogue, and where the layer's input lives
+// in the activation record kept for the backward pass (layer 0 reads the caller's x).
+struct EdsrPlan {
+    int n;
+    ConvLayer L[EDSR_MAX_LAYERS];
+    int ih[EDSR_MAX_LAYERS], iw[EDSR_MAX_LAYERS];
+    int epi[EDSR_MAX_LAYERS];          // forward epilogue of layer l
+    int64_t act_off[EDSR_MAX_LAYERS];  // floats; input of layer l >= 1 inside the record
+    int64_t acts_floats;               // size of the record
+    int64_t max_tensor;                // largest activation (= largest gradient tensor) of the net, floats
+    int Ho, Wo;                        // output size
+};
+
+inline int edsr_plan(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W, EdsrPlan* P) {
+    if (!edsr_geometry_ok(nblocks, n_up) || Cin < 1 || Cout < 1 || hid < 1) return NVSR_ERR_SHAPE;
+    edsr_layers(Cin, Cout, hid, nblocks, n_up, P->L, &P->n);
+    int64_t h = H, w = W, off = 0, mx = 0;
+    for (int l = 0; l < P->n; ++l) {
+        if (h < 3 || w < 3 || h > 1 << 20 || w > 1 << 20) return NVSR_ERR_SHAPE;
+        P->ih[l] = (int)h; P->iw[l] = (int)w;
+        const bool in_blocks = l >= 1 && l <= 2 * nblocks;
+        const bool up = l > 2 * nblocks + 1 && l < P->n - 1;
+        P->epi[l] = in_blocks ? ((l & 1) ? EPI_RELU : EPI_RESIDUAL) : (up ? EPI_PIXEL_SHUFFLE : EPI_NONE);
+        int64_t oh = h - 2, ow = w - 2, oc = P->L[l].Cout;
+        if (up) { oh *= 2; ow *= 2; oc /= 4; }
+        const int64_t out_floats = oc * oh * ow;
+        if (out_floats > mx) mx = out_floats;
+        if (l + 1 < P->n) { P->act_off[l + 1] = off; off += (out_floats + 3) / 4 * 4; }
+        h = oh; w = ow;
+    }
+    P->act_off[0] = -1;
+    P->acts_floats = off;
+    P->max_tensor = mx;
+    P->Ho = (int)h; P->Wo = (int)w;
+    return NVSR_OK;
+}
+
+// PlanesSR's ROI arithmetic (models.py:902-905): roi = NULL (full plane) or [[ymin,xmin],[ymax,xmax]] in [-1,1] -> LR pixel bounds
+inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
+    lo[0] = lo[1] = 0; hi[0] = R0; hi[1] = R1;
+    if (!roi) return;
+    const int shape[2] = {R0, R1};
+    for (int a = 0; a < 2; ++a) {
+        const float mn = (float)shape[a] * (1.0f + roi[a]) / 2.0f, mx = (float)shape[a] * (1.0f + roi[2 + a]) / 2.0f;
+        int l = (int)floorf(mn), hh = (int)ceilf(mx);
+        l = l - 1 > 0 ? l - 1 : 0;
+        hh = hh + 1 < shape[a] ? hh + 1 : shape[a];
+        lo[a] = l; hi[a] = hh;
+    }
+}
+
+// H, W: size of the tensor in memory; pad: virtual zero border (the kernel sees (H+2pad) x (W+2pad)).  Defined in sr.hip.
+int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
+                hipStream_t stream, int pad = 0);
+
+}  // namespace nvsr

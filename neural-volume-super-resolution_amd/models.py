@@ -283,10 +283,39 @@ class TwoDimPlanesModel(nn.Module):
             _PLANE_CACHE[name] = hit
         return hit[1]
 
-    def native_scene(self):
-        """struct nvsr_scene for the current scene id (+ the tensors that must outlive the launch)."""
+    def training_planes(self, rays):
+        """The NCHW tensors a training step samples, as autograd sees them: the raw plane parameters, or -- where a plane is
+        super-resolved -- the output of PlanesSR on the region of interest the batch covers (models.py:270-284: the reference takes
+        the ROI of every point chunk; the bounding box of the ray segments [near, far] contains all of them, and the super-resolved
+        values do not depend on the ROI).  rays: packed [N,11]."""
+        names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
+        out, n_ends = [], None
+        for d, name in enumerate(names):
+            if not (d < self.num_density_planes and self._should_SR(name)):
+                out.append(self.planes_[name])
+                continue
+            saved = self.scene_coupler.scene_with_saved_plane(name, plane_not_scene=True) if self.scene_coupler is not None else name
+            if not self.SR_model.training:
+                out.append(self.SR_model(saved))                      # full plane, cached (models.py:277: ROI only in training)
+                continue
+            if n_ends is None:
+                box = self.box_coords[self.cur_id + ""].to(rays.device)
+                lo, rng = box[0, :3].float(), (box[1, :3] - box[0, :3]).float()
+                ends = torch.cat([rays[:, 0:3] + rays[:, 3:6] * rays[:, 6:7], rays[:, 0:3] + rays[:, 3:6] * rays[:, 7:8]], 0)
+                n_ends = 2 * (ends - lo) / rng - 1
+            m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().to(rays.device)[:, 1:]
+            grid = n_ends @ m                                         # [2N, (x, y)]
+            gmin, gmax = grid.min(0)[0], grid.max(0)[0]
+            roi = torch.stack([torch.stack([gmin[1], gmin[0]]), torch.stack([gmax[1], gmax[0]])], 0)   # rows (min, max), cols (y, x)
+            out.append(self.SR_model((saved, roi)))
+        return out
+
+    def native_scene(self, planes=None):
+        """struct nvsr_scene for the current scene id (+ the tensors that must outlive the launch).  planes: optional explicit
+        channel-last planes (the training path samples tensors that are part of the autograd graph)."""
         self._check_native_geometry()
-        planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
+        if planes is None:
+            planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
         sc = capi.Scene()
         for d, p in enumerate(planes):
             sc.planes[d] = p.data_ptr()
@@ -392,7 +421,31 @@ class EDSR(nn.Module):
             self._packed_cache = (key, packed)
         return self._packed_cache[1]
 
+    def natural_blob(self, differentiable=False):
+        """conv weights flattened in state-dict order (the layout nvsr_pack_edsr consumes and nvsr_edsr_backward fills)"""
+        return torch.cat([(w if differentiable else w.detach()).reshape(-1).float() for w in self.conv_weights()])
+
+    def packed_dgrad_weights(self):
+        """fragments of every layer's data gradient (flipped, transposed kernels), cached like packed_weights()"""
+        ws = self.conv_weights()
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        cache = getattr(self, "_packed_dgrad_cache", None)
+        if cache is None or cache[0] != key:
+            nat = self.natural_blob()
+            capi.require_cuda(nat)
+            packed = torch.empty(capi.lib().nvsr_edsr_packed_dgrad_floats(*self.geometry), dtype=torch.float32, device=nat.device)
+            capi.call("nvsr_pack_edsr_dgrad", capi.ptr(nat), *self.geometry, capi.ptr(packed), capi.stream())
+            cache = (key, packed)
+            self._packed_dgrad_cache = cache
+        return cache[1]
+
+    def wants_grad(self, *inputs):
+        return torch.is_grad_enabled() and (any(w.requires_grad for w in self.conv_weights()) or
+                                            any(t is not None and t.requires_grad for t in inputs))
+
     def forward(self, x):
+        if self.wants_grad(x):
+            return _EDSRFn.apply(self, x, self.natural_blob(differentiable=True))
         x = capi.f32c(x)
         lead = x.shape[:-3]
         assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
@@ -406,6 +459,81 @@ class EDSR(nn.Module):
         capi.call("nvsr_edsr_forward", capi.ptr(x), Cin, H, W, capi.ptr(self.packed_weights()), cout, hid, nb, n_up, capi.ptr(out),
                   capi.ptr(ws), capi.stream())
         return out
+
+
+class _EDSRFn(torch.autograd.Function):
+    """EDSR.forward with gradients for the conv weights (as one flat blob in state-dict order) and the input."""
+
+    @staticmethod
+    def forward(ctx, net, x, nat):
+        x = capi.f32c(x.detach())
+        lead = x.shape[:-3]
+        assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
+        Cin, H, W = x.shape[-3:]
+        cin, cout, hid, nb, n_up = net.geometry
+        assert Cin == cin
+        Ho, Wo = C.c_int(), C.c_int()
+        capi.call("nvsr_edsr_out_size", H, W, nb, n_up, C.byref(Ho), C.byref(Wo))
+        out = torch.empty(list(lead) + [cout, Ho.value, Wo.value], dtype=torch.float32, device=x.device)
+        acts = torch.empty(capi.lib().nvsr_edsr_acts_floats(cin, cout, hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
+        capi.call("nvsr_edsr_forward_train", capi.ptr(x), Cin, H, W, capi.ptr(net.packed_weights()), cout, hid, nb, n_up, capi.ptr(out),
+                  capi.ptr(acts), capi.stream())
+        ctx.net, ctx.x, ctx.acts = net, x, acts
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net, x = ctx.net, ctx.x
+        cin, cout, hid, nb, n_up = net.geometry
+        Cin, H, W = x.shape[-3:]
+        d_out = capi.f32c(d_out)
+        gnat = torch.zeros(capi.lib().nvsr_edsr_natural_floats(*net.geometry), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(capi.lib().nvsr_edsr_backward_workspace_floats(cin, cout, hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
+        capi.call("nvsr_edsr_backward", capi.ptr(x), Cin, H, W, capi.ptr(ctx.acts), capi.ptr(net.packed_dgrad_weights()), cout, hid, nb, n_up,
+                  capi.ptr(d_out), capi.ptr(gnat), capi.ptr(dx), capi.ptr(ws), capi.stream())
+        return None, dx, (gnat if ctx.needs_input_grad[2] else None)
+
+
+class _PlanesSRFn(torch.autograd.Function):
+    """PlanesSR.forward (crop + replicate pad -> EDSR -> + bilinear residual -> NaN canvas) with gradients for the EDSR weights and,
+    unless it is detached (models.py:272), the LR plane."""
+
+    @staticmethod
+    def forward(ctx, sr, lr_plane, nat, roi_c, mean, std):
+        lr = capi.f32c(lr_plane.detach())
+        Cc, R0, R1 = lr.shape[-3:]
+        cin, cout, hid, nb, n_up = sr.inner_model.geometry
+        pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+        lib = capi.lib()
+        nws = lib.nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+        nkeep = lib.nvsr_planes_sr_keep_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+        if nws < 0 or nkeep < 0:
+            raise capi.NvsrError("PlanesSR: region of interest too small for the network")
+        ws = torch.empty(nws, dtype=torch.float32, device=lr.device)
+        keep = torch.empty(nkeep, dtype=torch.float32, device=lr.device)
+        sf = sr.scale_factor
+        out = torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lr.device)
+        capi.call("nvsr_planes_sr_train", capi.ptr(lr), Cc, R0, R1, capi.ptr(sr.inner_model.packed_weights()), hid, nb, n_up, pad, over, roi_c,
+                  capi.ptr(mean), capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), capi.stream())
+        ctx.sr, ctx.keep, ctx.roi_c, ctx.std, ctx.dims = sr, keep, roi_c, std, (Cc, R0, R1)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sr = ctx.sr
+        Cc, R0, R1 = ctx.dims
+        cin, cout, hid, nb, n_up = sr.inner_model.geometry
+        pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+        d_out = capi.f32c(d_out)
+        dev = d_out.device
+        gnat = torch.zeros(capi.lib().nvsr_edsr_natural_floats(*sr.inner_model.geometry), dtype=torch.float32, device=dev)
+        d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(capi.lib().nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, ctx.roi_c), dtype=torch.float32,
+                         device=dev)
+        capi.call("nvsr_planes_sr_backward", Cc, R0, R1, capi.ptr(ctx.keep), capi.ptr(sr.inner_model.packed_dgrad_weights()), hid, nb, n_up, pad,
+                  over, ctx.roi_c, capi.ptr(ctx.std), capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr), capi.ptr(ws), capi.stream())
+        return None, d_lr, (gnat if ctx.needs_input_grad[2] else None), None, None, None
 
 
 class PlanesSR(nn.Module):
@@ -472,7 +600,8 @@ class PlanesSR(nn.Module):
             raise NotImplementedError("align_corners=False is not used by the planes model")
         if self.training and (self.input_noise > 0 or self.output_noise > 0):
             raise NotImplementedError("sr_input_noise / sr_output_noise are 0 in every shipped config")
-        lr = capi.f32c(self.LR_planes[plane_name].detach())
+        lr_src = self.LR_planes[plane_name]
+        lr = capi.f32c(lr_src.detach())
         Cc, R0, R1 = lr.shape[-3:]
         cin, cout, hid, nb, n_up = self.inner_model.geometry
         assert Cc == cin == cout
@@ -483,6 +612,9 @@ class PlanesSR(nn.Module):
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
+        if self.training and self.inner_model.wants_grad(lr_src):
+            # training: gradients for the EDSR weights and the (non-detached) LR plane; the result is never cached
+            return _PlanesSRFn.apply(self, lr_src, self.inner_model.natural_blob(differentiable=True), roi_c, mean, std)
         pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
         nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
         if nws < 0:

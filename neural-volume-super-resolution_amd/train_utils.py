@@ -175,26 +175,38 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
 
     for mdl in (model_coarse, model_fine):
         mdl.set_cur_scene_id(scene_id)
-    sc_c, keep_c = model_coarse.native_scene()
     packed_c = model_coarse.packed_decoder()
     packed_f = model_fine.packed_decoder() if Nf > 0 else None
-    if Nf > 0:
-        # both passes sample the same planes in the reference unless only the fine model super-resolves
-        sc_f, keep_f = model_fine.native_scene()
-        same = all(sc_c.planes[d] == sc_f.planes[d] for d in range(4))
-    else:
-        sc_f, keep_f, same = sc_c, keep_c, True
-
     top = model_fine if Nf > 0 else model_coarse
     dec_c_grad = _decoder_needs_grad(model_coarse)
     dec_f_grad = Nf > 0 and _decoder_needs_grad(model_fine)
-    if mode == "train" and N > 0 and (_planes_need_grad(top) or dec_c_grad or dec_f_grad):
-        # training path (mode == "train" only; evaluation never builds a graph): gradients flow to the planes of the current
-        # scene and / or to the decoder parameters of the two models, whichever require grad
-        if hasattr(model_fine, "SR_model") and not model_fine.skip_SR_:
-            raise NotImplementedError("gradients through the super-resolved planes (EDSR backward) are not implemented yet")
-        names = [models.get_plane_name(scene_id, d) for d in range(4)]
-        leaves = [top.planes_[n] for n in names]
+    sr_on = hasattr(top, "SR_model") and not top.skip_SR_
+    sr_grad = sr_on and torch.is_grad_enabled() and top.SR_model.training and \
+        top.SR_model.inner_model.wants_grad(*top.SR_model.LR_planes.values())
+    train_path = mode == "train" and N > 0 and (_planes_need_grad(top) or dec_c_grad or dec_f_grad or sr_grad)
+    if not (train_path and sr_on):       # (the SR training path builds its scene from the ROI planes below)
+        sc_c, keep_c = model_coarse.native_scene()
+        if Nf > 0:
+            # both passes sample the same planes in the reference unless only the fine model super-resolves
+            sc_f, keep_f = model_fine.native_scene()
+            same = all(sc_c.planes[d] == sc_f.planes[d] for d in range(4))
+        else:
+            sc_f, keep_f, same = sc_c, keep_c, True
+
+    if train_path:
+        # training path (mode == "train" only; evaluation never builds a graph): gradients flow to whatever requires grad among the
+        # planes of the current scene, the decoder parameters of the two models and -- through the super-resolved planes -- the SR
+        # network and its LR planes
+        if sr_on:
+            if Nf > 0 and not (hasattr(model_coarse, "SR_model") and not model_coarse.skip_SR_):
+                raise NotImplementedError("training with only one of the two models super-resolving")
+            leaves = top.training_planes(rays)
+            keep_f = [models.to_channel_last(p.detach()) for p in leaves]
+            sc_f, keep_f = top.native_scene(planes=keep_f)
+            sc_c, keep_c = sc_f, keep_f
+        else:
+            names = [models.get_plane_name(scene_id, d) for d in range(4)]
+            leaves = [top.planes_[n] for n in names]
         leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True

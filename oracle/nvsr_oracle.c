@@ -600,6 +600,244 @@ ORC_EXPORT void orc_planes_sr(const float* lr, int C, int R0, int R1, const floa
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the SR network (the reference: torch.autograd through EDSR.forward models.py:818-822, _Residual_Block.forward
+ * :777-786, PlanesSR.forward :884-926 when 'SR' is in nerf.train.what).  Pinned against tests/golden/g14_sr_grads.npz.
+ */
+/* backward of orc_conv3x3_valid: dy [Co,H-2,W-2] -> dx [Ci,H,W] (overwritten; may be NULL), dw [Co,Ci,3,3] += (double; may be NULL) */
+ORC_EXPORT void orc_conv3x3_valid_backward(const float* in, int Ci, int H, int W, const float* wgt, int Co, const float* dy, float* dx,
+                                           double* dw) {
+    const int Ho = H - 2, Wo = W - 2;
+    if (dx) {
+#pragma omp parallel
+        {
+            double* row = (double*)malloc(sizeof(double) * (size_t)W);
+#pragma omp for collapse(2) schedule(static)
+            for (int ci = 0; ci < Ci; ++ci)
+                for (int y = 0; y < H; ++y) {
+                    for (int x = 0; x < W; ++x) row[x] = 0;
+                    for (int co = 0; co < Co; ++co)
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int yo = y - ky;
+                            if (yo < 0 || yo >= Ho) continue;
+                            const float* gp = dy + ((size_t)co * Ho + yo) * Wo;
+                            const float* wp = wgt + (((size_t)co * Ci + ci) * 3 + ky) * 3;
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const double wv = wp[kx];
+                                for (int xo = 0; xo < Wo; ++xo) row[xo + kx] += wv * (double)gp[xo];
+                            }
+                        }
+                    float* op = dx + ((size_t)ci * H + y) * W;
+                    for (int x = 0; x < W; ++x) op[x] = (float)row[x];
+                }
+            free(row);
+        }
+    }
+    if (dw) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int co = 0; co < Co; ++co)
+            for (int ci = 0; ci < Ci; ++ci) {
+                double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int y = 0; y < Ho; ++y) {
+                    const float* gp = dy + ((size_t)co * Ho + y) * Wo;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float* ip = in + ((size_t)ci * H + (y + ky)) * W;
+                        for (int x = 0; x < Wo; ++x) {
+                            const double g = gp[x];
+                            a[ky * 3 + 0] += g * (double)ip[x];
+                            a[ky * 3 + 1] += g * (double)ip[x + 1];
+                            a[ky * 3 + 2] += g * (double)ip[x + 2];
+                        }
+                    }
+                }
+                double* q = dw + ((size_t)co * Ci + ci) * 9;
+                for (int t = 0; t < 9; ++t) q[t] += a[t];
+            }
+    }
+}
+
+/* d_out [Cout,Ho,Wo] -> d_blob (same order as the weights blob, overwritten) and dx [Cin,H,W] (may be NULL) */
+ORC_EXPORT void orc_edsr_backward(const float* x, int Cin, int H, int W, const float* blob, int Cout, int hid, int nblocks, int n_up,
+                                  const float* d_out, float* d_blob, float* dx) {
+    const int nl = 1 + 2 * nblocks + 1 + n_up + 1;
+    /* forward, keeping every conv input */
+    const float** in = (const float**)calloc((size_t)nl, sizeof(float*));
+    int* ih = (int*)calloc((size_t)nl, sizeof(int)); int* iw = (int*)calloc((size_t)nl, sizeof(int));
+    int* ci_ = (int*)calloc((size_t)nl, sizeof(int)); int* co_ = (int*)calloc((size_t)nl, sizeof(int));
+    const float** wl = (const float**)calloc((size_t)nl, sizeof(float*));
+    const float* p = blob;
+    int k = 0, h = H, w = W;
+    const float* cur = x;
+    #define ORC_LAYER(CI, CO) do { in[k] = cur; ih[k] = h; iw[k] = w; ci_[k] = (CI); co_[k] = (CO); wl[k] = p; p += 9 * (size_t)(CI) * (CO); } while (0)
+    {
+        ORC_LAYER(Cin, hid);
+        float* t = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, Cin, h, w, wl[k], hid, 0, t);
+        cur = t; h -= 2; w -= 2; ++k;
+    }
+    for (int b = 0; b < nblocks; ++b) {
+        const float* blk_in = cur;
+        ORC_LAYER(hid, hid);
+        float* t1 = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, wl[k], hid, 1, t1);
+        cur = t1; ++k; h -= 2; w -= 2;
+        ORC_LAYER(hid, hid);
+        float* t2 = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, wl[k], hid, 0, t2);
+        ++k; h -= 2; w -= 2;
+        for (int c = 0; c < hid; ++c)
+            for (int y = 0; y < h; ++y)
+                for (int xx = 0; xx < w; ++xx) {
+                    float* o = t2 + ((size_t)c * h + y) * w + xx;
+                    *o = *o * 0.1f + blk_in[((size_t)c * (h + 4) + y + 2) * (w + 4) + xx + 2];
+                }
+        cur = t2;
+    }
+    {
+        ORC_LAYER(hid, hid);
+        float* t = (float*)malloc(sizeof(float) * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, wl[k], hid, 0, t);
+        cur = t; h -= 2; w -= 2; ++k;
+    }
+    for (int u = 0; u < n_up; ++u) {
+        ORC_LAYER(hid, 4 * hid);
+        float* t = (float*)malloc(sizeof(float) * 4 * (size_t)hid * (h - 2) * (w - 2));
+        orc_conv3x3_valid(cur, hid, h, w, wl[k], 4 * hid, 0, t);
+        h -= 2; w -= 2; ++k;
+        float* sh = (float*)malloc(sizeof(float) * 4 * (size_t)hid * h * w);
+        orc_pixel_shuffle2(t, hid, h, w, sh);
+        free(t);
+        cur = sh; h *= 2; w *= 2;
+    }
+    ORC_LAYER(hid, Cout);
+    ++k;
+    #undef ORC_LAYER
+    /* backward */
+    const size_t nblob = (size_t)(p - blob);
+    double* dwd = (double*)calloc(nblob, sizeof(double));
+    float* g = (float*)malloc(sizeof(float) * (size_t)Cout * (h - 2) * (w - 2));
+    memcpy(g, d_out, sizeof(float) * (size_t)Cout * (h - 2) * (w - 2));
+    int l = nl - 1;
+    #define ORC_BACK(NEED_DX) do { \
+        float* gx = (NEED_DX) ? (float*)malloc(sizeof(float) * (size_t)ci_[l] * ih[l] * iw[l]) : NULL; \
+        orc_conv3x3_valid_backward(in[l], ci_[l], ih[l], iw[l], wl[l], co_[l], g, gx, dwd + (wl[l] - blob)); \
+        free(g); g = gx; } while (0)
+    ORC_BACK(1); --l;                                          /* conv_output */
+    for (int u = n_up - 1; u >= 0; --u) {                      /* PixelShuffle^T, then the up-conv */
+        const int hs = ih[l] - 2, ws = iw[l] - 2;              /* conv output size before the shuffle */
+        float* gu = (float*)malloc(sizeof(float) * 4 * (size_t)hid * hs * ws);
+        for (int c = 0; c < hid; ++c)
+            for (int y = 0; y < hs; ++y)
+                for (int xx = 0; xx < ws; ++xx)
+                    for (int i = 0; i < 2; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            gu[((size_t)(c * 4 + i * 2 + j) * hs + y) * ws + xx] = g[((size_t)c * 2 * hs + 2 * y + i) * 2 * ws + 2 * xx + j];
+        free(g); g = gu;
+        ORC_BACK(1); --l;
+    }
+    ORC_BACK(1); --l;                                          /* conv_mid */
+    for (int b = nblocks - 1; b >= 0; --b) {
+        /* y = 0.1 * conv2(relu(conv1(x))) + crop(x):  g = dL/dy [hid, hh, ww] */
+        const int hh = ih[l] - 2, ww = iw[l] - 2;
+        float* gy = (float*)malloc(sizeof(float) * (size_t)hid * hh * ww);
+        memcpy(gy, g, sizeof(float) * (size_t)hid * hh * ww);
+        for (size_t i = 0; i < (size_t)hid * hh * ww; ++i) g[i] *= 0.1f;
+        ORC_BACK(1);                                           /* conv2: g -> d t1 */
+        const float* t1 = in[l];
+        for (size_t i = 0; i < (size_t)hid * ih[l] * iw[l]; ++i) if (!(t1[i] > 0.0f)) g[i] = 0.0f;   /* ReLU */
+        --l;
+        ORC_BACK(1);                                           /* conv1: -> d x (block input) */
+        for (int c = 0; c < hid; ++c)
+            for (int y = 0; y < hh; ++y)
+                for (int xx = 0; xx < ww; ++xx) g[((size_t)c * ih[l] + y + 2) * iw[l] + xx + 2] += gy[((size_t)c * hh + y) * ww + xx];
+        free(gy);
+        --l;
+    }
+    ORC_BACK(dx != NULL);                                      /* conv_input */
+    #undef ORC_BACK
+    if (dx) { memcpy(dx, g, sizeof(float) * (size_t)Cin * H * W); free(g); }
+    for (size_t i = 0; i < nblob; ++i) d_blob[i] = (float)dwd[i];
+    free(dwd);
+    for (int i = 1; i < nl; ++i) free((void*)in[i]);
+    free(in); free(ih); free(iw); free(ci_); free(co_); free(wl);
+}
+
+/* backward of orc_planes_sr: d_out [C, sf*R0, sf*R1] (entries outside the ROI are ignored) -> d_blob (overwritten), d_lr [C,R0,R1]
+ * (overwritten; NULL = LR plane detached): through the network input (clamped gather, optional normalisation) and through the
+ * bilinear residual (models.py:858-859,917) */
+ORC_EXPORT void orc_planes_sr_backward(const float* lr, int C, int R0, int R1, const float* blob, int hid, int nblocks, int n_up,
+                                       int pad, int over, const float* roi, const float* mean, const float* std_, const float* d_out,
+                                       float* d_blob, float* d_lr) {
+    const int sf = 1 << n_up;
+    int lo[2] = {0, 0}, hi[2] = {R0, R1};
+    const int shape[2] = {R0, R1};
+    if (roi)
+        for (int a = 0; a < 2; ++a) {
+            const float mn = (float)shape[a] * (1.0f + roi[a]) / 2.0f, mx = (float)shape[a] * (1.0f + roi[2 + a]) / 2.0f;
+            int l = (int)floorf(mn), h = (int)ceilf(mx);
+            l = l - 1 > 0 ? l - 1 : 0;
+            h = h + 1 < shape[a] ? h + 1 : shape[a];
+            lo[a] = l; hi[a] = h;
+        }
+    const int ch = hi[0] - lo[0], cw = hi[1] - lo[1];
+    const int Hp = ch + 2 * pad, Wp = cw + 2 * pad;
+    float* x = (float*)malloc(sizeof(float) * (size_t)C * Hp * Wp);
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Hp; ++y) {
+            int sy = lo[0] - pad + y; sy = sy < 0 ? 0 : (sy > R0 - 1 ? R0 - 1 : sy);
+            for (int xx = 0; xx < Wp; ++xx) {
+                int sx = lo[1] - pad + xx; sx = sx < 0 ? 0 : (sx > R1 - 1 ? R1 - 1 : sx);
+                float v = lr[((size_t)c * R0 + sy) * R1 + sx];
+                if (mean) v = (v - mean[c]) / std_[c];
+                x[((size_t)c * Hp + y) * Wp + xx] = v;
+            }
+        }
+    int Ho, Wo;
+    orc_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo);
+    const size_t HRh = (size_t)R0 * sf, HRw = (size_t)R1 * sf;
+    float* d_diff = (float*)calloc((size_t)C * Ho * Wo, sizeof(float));
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < ch * sf; ++y)
+            for (int xx = 0; xx < cw * sf; ++xx)
+                d_diff[((size_t)c * Ho + y + over) * Wo + xx + over] = d_out[((size_t)c * HRh + (size_t)lo[0] * sf + y) * HRw + (size_t)lo[1] * sf + xx];
+    float* dxp = d_lr ? (float*)malloc(sizeof(float) * (size_t)C * Hp * Wp) : NULL;
+    orc_edsr_backward(x, C, Hp, Wp, blob, C, hid, nblocks, n_up, d_diff, d_blob, dxp);
+    free(x); free(d_diff);
+    if (!d_lr) return;
+    double* acc = (double*)calloc((size_t)C * R0 * R1, sizeof(double));
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Hp; ++y) {
+            int sy = lo[0] - pad + y; sy = sy < 0 ? 0 : (sy > R0 - 1 ? R0 - 1 : sy);
+            for (int xx = 0; xx < Wp; ++xx) {
+                int sx = lo[1] - pad + xx; sx = sx < 0 ? 0 : (sx > R1 - 1 ? R1 - 1 : sx);
+                double v = dxp[((size_t)c * Hp + y) * Wp + xx];
+                if (mean) v /= (double)std_[c];
+                acc[((size_t)c * R0 + sy) * R1 + sx] += v;
+            }
+        }
+    free(dxp);
+    /* residual path: bilinear x sf, align_corners=True, over the ROI */
+    const float shh = HRh > 1 ? (float)(R0 - 1) / (float)(HRh - 1) : 0.0f;
+    const float sww = HRw > 1 ? (float)(R1 - 1) / (float)(HRw - 1) : 0.0f;
+    for (int c = 0; c < C; ++c)
+        for (size_t oy = (size_t)lo[0] * sf; oy < (size_t)hi[0] * sf; ++oy) {
+            const float fy = shh * (float)oy;
+            const int y0 = (int)fy, yp = (y0 < R0 - 1) ? 1 : 0;
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+            for (size_t ox = (size_t)lo[1] * sf; ox < (size_t)hi[1] * sf; ++ox) {
+                const float fx = sww * (float)ox;
+                const int x0 = (int)fx, xp = (x0 < R1 - 1) ? 1 : 0;
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                const double g = d_out[((size_t)c * HRh + oy) * HRw + ox];
+                double* q = acc + ((size_t)c * R0 + y0) * R1 + x0;
+                q[0] += g * ly0 * lx0; q[xp] += g * ly0 * lx1;
+                q[(size_t)yp * R1] += g * ly1 * lx0; q[(size_t)yp * R1 + xp] += g * ly1 * lx1;
+            }
+        }
+    for (size_t i = 0; i < (size_t)C * R0 * R1; ++i) d_lr[i] = (float)acc[i];
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------
  * positional_encoding (nerf_helpers.py:552-575): [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
  */
 ORC_EXPORT void orc_positional_encoding(long P, int D, const float* x, int L, int include_input, float* out) {

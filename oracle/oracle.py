@@ -208,7 +208,7 @@ class Oracle:
 
     # -- feature-plane super-resolution -----------------------------------------------------------
     @staticmethod
-    def edsr_blob(sd, prefix="inner_model.", nblocks=None, n_up=2):
+    def edsr_keys(sd, prefix="inner_model.", n_up=2):
         keys = [prefix + "conv_input.weight"]
         b = 0
         while prefix + "residual.%d.conv1.weight" % b in sd:
@@ -216,7 +216,12 @@ class Oracle:
             b += 1
         keys += [prefix + "conv_mid.weight"] + [prefix + "upscale.%d.weight" % (2 * i) for i in range(n_up)]
         keys += [prefix + "conv_output.weight"]
-        return np.concatenate([np.asarray(sd[k], np.float32).ravel() for k in keys]), b
+        return keys
+
+    @staticmethod
+    def edsr_blob(sd, prefix="inner_model.", nblocks=None, n_up=2):
+        keys = Oracle.edsr_keys(sd, prefix, n_up)
+        return np.concatenate([np.asarray(sd[k], np.float32).ravel() for k in keys]), (len(keys) - 2 - n_up) // 2
 
     def conv3x3(self, x, w, relu=False):
         x, w = _f(x), _f(w)
@@ -225,6 +230,16 @@ class Oracle:
         out = np.empty((Co, H - 2, W - 2), np.float32)
         self.lib.orc_conv3x3_valid(_p(x), Ci, H, W, _p(w), Co, int(relu), _p(out))
         return out
+
+    def conv3x3_backward(self, x, w, dy):
+        """-> (dx [Ci,H,W], dw [Co,Ci,3,3]) of the valid 3x3 conv"""
+        x, w, dy = _f(x), _f(w), _f(dy)
+        Ci, H, W = x.shape[-3:]
+        Co = w.shape[0]
+        dx = np.empty((Ci, H, W), np.float32)
+        dw = np.zeros((Co, Ci, 3, 3), np.float64)
+        self.lib.orc_conv3x3_valid_backward(_p(x), Ci, H, W, _p(w), Co, _p(dy), _p(dx), dw.ctypes.data_as(C.POINTER(C.c_double)))
+        return dx, dw
 
     def edsr_forward(self, x, blob, Cout, hid, nblocks, n_up):
         x, blob = _f(x), _f(blob)
@@ -252,6 +267,27 @@ class Oracle:
         mean, std = (None if a is None else _f(a) for a in (mean, std))
         self.lib.orc_planes_sr(_p(lr), Cc, R0, R1, _p(blob), hid, nblocks, n_up, pad, over, _p(roi), _p(mean), _p(std), _p(out))
         return out
+
+    def edsr_backward(self, x, blob, Cout, hid, nblocks, n_up, d_out, want_dx=True):
+        """-> (d_blob [same order as blob], dx or None)"""
+        x, blob, d_out = _f(x), _f(blob), _f(d_out)
+        Cin, H, W = x.shape[-3:]
+        d_blob = np.empty_like(blob)
+        dx = np.empty((Cin, H, W), np.float32) if want_dx else None
+        self.lib.orc_edsr_backward(_p(x), Cin, H, W, _p(blob), Cout, hid, nblocks, n_up, _p(d_out), _p(d_blob), _p(dx))
+        return d_blob, dx
+
+    def planes_sr_backward(self, lr, blob, hid, nblocks, n_up, pad, over, d_out, roi=None, mean=None, std=None, want_dlr=True):
+        """-> (d_blob, d_lr or None); entries of d_out outside the ROI are ignored"""
+        lr, blob, d_out = _f(lr), _f(blob), _f(d_out)
+        Cc, R0, R1 = lr.shape[-3:]
+        roi = None if roi is None else _f(roi)
+        mean, std = (None if a is None else _f(a) for a in (mean, std))
+        d_blob = np.empty_like(blob)
+        d_lr = np.empty((Cc, R0, R1), np.float32) if want_dlr else None
+        self.lib.orc_planes_sr_backward(_p(lr), Cc, R0, R1, _p(blob), hid, nblocks, n_up, pad, over, _p(roi), _p(mean), _p(std), _p(d_out),
+                                        _p(d_blob), _p(d_lr))
+        return d_blob, d_lr
 
     # -- positional-encoding baseline ------------------------------------------------------------
     def positional_encoding(self, x, L=6, include_input=True):

@@ -21,6 +21,7 @@ Fixture index:
   g10_posenc.npz      positional_encoding, FlexibleNeRFModel   nerf_helpers.py:552-575, models.py:14-108
   g11_grads.npz       autograd of one train step wrt the planes (train_nerf.py:860-903)
   g12_ndc_render.npz  eval_nerf of a forward-facing (LLFF-style) view through NDC rays (train_utils.py:215-218)
+  g14_sr_grads.npz    autograd through EDSR / PlanesSR (full plane and ROI): weights, network input and LR plane ('SR' in what)
   g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
 """
 import os
@@ -717,9 +718,57 @@ def g13_decoder_grads():
     save("g13_decoder_grads.npz", **arrs)
 
 
+def g14_sr_grads():
+    """torch.autograd through the SR network of g09 (same seed -> same weights / LR plane): (1) EDSR alone, gradient of
+    sum(out * G) wrt every conv weight and the input; (2) PlanesSR.forward on the ROI (training path) and on the full plane,
+    gradient of sum(nan_to_zero(out) * G) wrt the weights and the (non-detached) LR plane."""
+    torch.manual_seed(9)
+    C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+    sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bilinear")
+    sr.align_corners = True
+    with torch.no_grad():
+        for p in sr.parameters():
+            p.mul_(10.0)
+    lr = torch.randn(1, C, R, R) * 0.5
+    g9 = np.load(os.path.join(HERE, "g09_edsr.npz"))
+    assert np.array_equal(g9["lr"], npy(lr)), "g14 must rebuild the g09 network"
+    keys = [k for k, _ in sr.inner_model.named_parameters()]
+    arrs = dict(cfg=np.array([C, hidden, nblocks, sf, R, sr.inner_model.required_padding, sr.HR_overpadding]))
+
+    def blob_grad():
+        return np.concatenate([npy(p.grad).reshape(-1) for _, p in sr.inner_model.named_parameters()]).astype(np.float32)
+
+    # (1) EDSR alone
+    torch.manual_seed(140)
+    x = torch.randn(1, C, 30, 26, requires_grad=True)
+    sr.train()
+    out = sr.inner_model(x)
+    G = torch.randn_like(out)
+    sr.zero_grad(set_to_none=True)
+    (out * G).sum().backward()
+    arrs.update(edsr_in=npy(x), edsr_gout=npy(G), edsr_gw=blob_grad(), edsr_gin=npy(x.grad))
+    # (2) PlanesSR: ROI (training) and full plane
+    roi = torch.tensor([[-0.35, -0.6], [0.2, 0.15]])
+    arrs["roi"] = npy(roi)
+    for tag, arg in (("roi", ("p", roi)), ("full", "p")):
+        lrp = nn.Parameter(lr.clone())
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lrp, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(arg)
+        Gp = torch.randn_like(out)
+        valid = ~torch.isnan(out)
+        (torch.where(valid, out, torch.zeros_like(out)) * Gp).sum().backward()
+        arrs.update({"sr_%s_gout" % tag: npy(Gp), "sr_%s_gw" % tag: blob_grad(), "sr_%s_glr" % tag: npy(lrp.grad),
+                     "sr_%s_valid_frac" % tag: np.array(float(valid.float().mean()))})
+        sr.clear_SR_planes(all_planes=True)
+    arrs["param_order"] = np.array(keys)
+    save("g14_sr_grads.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

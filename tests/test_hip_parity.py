@@ -442,6 +442,164 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
         np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi)))
 
 
+def test_conv3x3_backward_vs_oracle(hip, oracle):
+    """data and weight gradients of the valid 3x3 conv through the C ABI; sizes that exercise partial tiles in every dimension
+    (channels not multiples of 64, width not a multiple of 32, fewer rows than row slabs)"""
+    rng = np.random.default_rng(33)
+    capi = hip.capi
+    for Cin, Cout, H, W in [(48, 256, 21, 45), (256, 256, 14, 40), (256, 48, 37, 35), (70, 130, 9, 70), (5, 7, 3, 3), (64, 1024, 10, 12)]:
+        x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+        w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+        dy = rng.standard_normal((Cout, H - 2, W - 2), dtype=np.float32)
+        dx_ref, dw_ref = oracle.conv3x3_backward(x, w, dy)
+        xd, wd, dyd = T(x), T(w), T(dy)
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cout, Cin), device=DEV)
+        capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+        dx = torch.empty((Cin, H, W), device=DEV)
+        capi.call("nvsr_conv3x3_dgrad", capi.ptr(dyd), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), capi.stream())
+        # K = 9*Cout unit-variance products of magnitude 1/sqrt(9 Cin)
+        np.testing.assert_allclose(N_(dx), dx_ref, rtol=0, atol=3e-5 * max(1.0, np.sqrt(Cout / Cin)), err_msg="dgrad " + str((Cin, Cout, H, W)))
+        ws = torch.empty(capi.lib().nvsr_conv3x3_wgrad_workspace_floats(Cin, H, W, Cout), device=DEV)
+        dw = torch.full((Cout, Cin, 3, 3), 1.0, device=DEV)           # accumulates on top of what is there, scaled
+        capi.call("nvsr_conv3x3_wgrad", capi.ptr(dyd), capi.ptr(xd), Cin, H, W, Cout, 0.5, capi.ptr(dw), capi.ptr(ws), capi.stream())
+        got = (N_(dw) - 1.0) / 0.5
+        K = (H - 2) * (W - 2)
+        np.testing.assert_allclose(got, dw_ref, rtol=0, atol=2e-5 * np.sqrt(K) + 1e-5, err_msg="wgrad " + str((Cin, Cout, H, W)))
+        assert np.linalg.norm(got - dw_ref) / np.linalg.norm(dw_ref) < 2e-6
+        dw2 = torch.full((Cout, Cin, 3, 3), 1.0, device=DEV)          # deterministic: fixed-order reduction, no atomics
+        capi.call("nvsr_conv3x3_wgrad", capi.ptr(dyd), capi.ptr(xd), Cin, H, W, Cout, 0.5, capi.ptr(dw2), capi.ptr(ws), capi.stream())
+        assert torch.equal(dw, dw2)
+
+
+def _sr_grad_blob(sr):
+    return np.concatenate([N_(w.grad).reshape(-1) for w in sr.inner_model.conv_weights()])
+
+
+def _rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
+
+
+def test_sr_gradients_golden(hip):
+    """loss.backward() through EDSR / PlanesSR (ROI = training path, and full plane) vs torch.autograd through the reference (g14)"""
+    g9, g = load_golden("g09_edsr.npz"), load_golden("g14_sr_grads.npz")
+    sr, (Cc, hid, nblocks, sf, R, pad, over) = _sr_model(hip, g9)
+    sr.train()
+    x = T(g["edsr_in"]).requires_grad_(True)
+    out = sr.inner_model(x)
+    (out * T(g["edsr_gout"])).sum().backward()
+    assert _rel(_sr_grad_blob(sr), g["edsr_gw"]) < 2e-5
+    assert _rel(N_(x.grad), g["edsr_gin"]) < 2e-5
+    np.testing.assert_allclose(_sr_grad_blob(sr), g["edsr_gw"], rtol=0, atol=2e-5 * np.abs(g["edsr_gw"]).max())
+    for tag, roi in (("roi", T(g["roi"])), ("full", None)):
+        lr = torch.nn.Parameter(T(g9["lr"]))
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lr, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(("p", roi)) if roi is not None else sr("p")
+        assert out.requires_grad and "p" not in sr.SR_planes          # the training result is never cached
+        valid = ~torch.isnan(out)
+        assert abs(float(valid.float().mean()) - float(g["sr_%s_valid_frac" % tag])) < 1e-6
+        (torch.where(valid, out, torch.zeros_like(out)) * T(g["sr_%s_gout" % tag])).sum().backward()
+        assert _rel(_sr_grad_blob(sr), g["sr_%s_gw" % tag]) < 2e-5, tag
+        assert _rel(N_(lr.grad), g["sr_%s_glr" % tag]) < 2e-5, tag
+        np.testing.assert_allclose(N_(lr.grad), g["sr_%s_glr" % tag], rtol=0, atol=2e-5 * np.abs(g["sr_%s_glr" % tag]).max())
+    # LR plane detached (models.py:272): weights only
+    sr.clear_SR_planes(all_planes=True)
+    sr.set_LR_plane(T(g9["lr"]), id="p", save_interpolated=False)
+    sr.zero_grad(set_to_none=True)
+    out = sr("p")
+    (out * T(g["sr_full_gout"])).sum().backward()
+    assert _rel(_sr_grad_blob(sr), g["sr_full_gw"]) < 2e-5
+    # evaluation never builds a graph and is cached
+    sr.eval()
+    with torch.no_grad():
+        full = sr("p")
+    assert not full.requires_grad and sr("p") is full
+    np.testing.assert_allclose(N_(full), g9["sr_full"], rtol=0, atol=1e-5)
+
+
+def test_sr_gradients_vs_oracle_larger(hip, oracle):
+    """48 -> 48 channels, hidden 64, 3 blocks, x4, 34 x 46 input (hidden width 64 = one partial weight-gradient tile in ci and co)"""
+    rng = np.random.default_rng(51)
+    Cc, hid, nb, n_up, H, W = 48, 64, 3, 2, 34, 46
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, Cc, Cc, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr.train()
+    x = rng.standard_normal((1, Cc, H, W), dtype=np.float32)
+    xd = T(x).requires_grad_(True)
+    out = sr.inner_model(xd)
+    gout = rng.standard_normal(tuple(out.shape), dtype=np.float32)
+    (out * T(gout)).sum().backward()
+    blob = np.concatenate([N_(w).reshape(-1) for w in sr.inner_model.conv_weights()])
+    np.testing.assert_allclose(N_(out)[0], oracle.edsr_forward(x[0], blob, Cc, hid, nb, n_up), rtol=0, atol=2e-5)
+    gw, gx = oracle.edsr_backward(x[0], blob, Cc, hid, nb, n_up, gout[0])
+    assert _rel(_sr_grad_blob(sr), gw) < 2e-5 and _rel(N_(xd.grad)[0], gx) < 2e-5
+
+
+def test_train_step_through_super_resolved_planes(hip, oracle):
+    """SR refinement step (what: ['SR']): rays -> ROI -> PlanesSR(ROI) x3 -> render -> loss.backward() fills the EDSR weights' .grad;
+    oracle = its own SR forward, render backward wrt the HR planes, SR backward, chained on the host"""
+    g = load_golden("g08_render.npz")
+    rng = np.random.default_rng(61)
+    R, Rv, hid, nb = 24, 8, 16, 2
+    planes = [rng.standard_normal((1, 48, R, R), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, Rv, Rv), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes24_8"
+    mc, mf = _grad_models(hip, g, planes, sid, what=())
+    torch.manual_seed(6)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr.train()
+    for m in (mc, mf):
+        m.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    H = W = 12
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    sel = torch.from_numpy(rng.permutation(H * W)[:60]).to(DEV)     # a partial batch: its ROI does not cover the planes
+    batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    N, nc, nf = 60, 24, 24
+    opts, scfg = make_options(nc, nf)
+    out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+    z_fine = N_(out[3].grad_fn.saved["z_f"])
+    gc = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+    gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+    ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+    got = _sr_grad_blob(sr)
+    # --- oracle chain
+    blob = np.concatenate([N_(w).reshape(-1) for w in sr.inner_model.conv_weights()])
+    pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+    rays_np = oracle.pack_rays(N_(batch[0]), N_(batch[1]), 2.0, 6.0)
+    box = np.asarray(g["box"], np.float64)
+    ends = np.concatenate([rays_np[:, 0:3] + rays_np[:, 3:6] * rays_np[:, 6:7], rays_np[:, 0:3] + rays_np[:, 3:6] * rays_np[:, 7:8]], 0)
+    n_ends = (2 * (ends - box[0, :3].astype(np.float32)) / (box[1, :3] - box[0, :3]).astype(np.float32) - 1).astype(np.float32)
+    hr, rois = [], []
+    for d in range(3):
+        m = N_(mf.coord_projector.rot_mats_NON_LEARNED[d])[:, 1:]
+        grid = n_ends @ m
+        roi = np.array([[grid[:, 1].min(), grid[:, 0].min()], [grid[:, 1].max(), grid[:, 0].max()]], np.float32)
+        rois.append(roi)
+        hr.append(oracle.planes_sr(planes[d][0], blob, hid, nb, 2, pad, over, roi=roi))
+    assert all(np.isnan(h).any() for h in hr)                       # the ROI path really ran
+    hr_zero = [np.nan_to_num(h)[None] for h in hr] + [planes[3]]
+    sc = oracle.scene(hr_zero, g["box"])
+    dec_c, dec_f = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    o = oracle.render_rays(sc, dec_c, dec_f, rays_np, nc, nf)
+    np.testing.assert_allclose(N_(out[0]), o["rgb_coarse"], rtol=0, atol=3e-5)
+    gplanes = oracle.render_backward(sc, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, N_(gc), N_(gf), z_fine=z_fine)
+    ref = np.zeros_like(blob, dtype=np.float64)
+    for d in range(3):
+        gw, _ = oracle.planes_sr_backward(planes[d][0], blob, hid, nb, 2, pad, over, gplanes[d], roi=rois[d], want_dlr=False)
+        ref += gw
+    assert _rel(got, ref) < 5e-3, "SR weight gradient through the renderer: relative L2 error %.2e" % _rel(got, ref)
+    for m in (mc, mf):                                             # nothing else received a gradient
+        assert all(p_.grad is None for p_ in m.decoder_parameters()) and all(p_.grad is None for p_ in m.planes_.values())
+
+
 def test_render_through_super_resolved_planes(hip, oracle):
     """BASELINE config 3 in miniature: the fine model samples planes produced by PlanesSR(EDSR) (x4), the coarse model the LR
     planes (models.py:270-284, 289-310); oracle = its own planes_sr + render."""

@@ -195,6 +195,31 @@ def test_edsr_and_planes_sr(oracle):
     np.testing.assert_allclose(roi[m], ref[m], rtol=0, atol=1e-5)
 
 
+def _rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
+
+
+def test_sr_gradients_against_reference_autograd(oracle):
+    """oracle backward of EDSR / PlanesSR vs torch.autograd through the reference's modules (g14; network and LR plane of g09)"""
+    g9, g = load_golden("g09_edsr.npz"), load_golden("g14_sr_grads.npz")
+    Cc, hid, nblocks, sf, R, pad, over = [int(v) for v in g["cfg"]]
+    blob, _ = Oracle.edsr_blob(sd(g9, "sd."), n_up=2)
+    assert [str(k) for k in g["param_order"]] == [k[len("inner_model."):] for k in Oracle.edsr_keys(sd(g9, "sd."), n_up=2)]
+    gw, gx = oracle.edsr_backward(g["edsr_in"][0], blob, Cc, hid, nblocks, 2, g["edsr_gout"][0])
+    assert gw.shape == g["edsr_gw"].shape and gx.shape == g["edsr_gin"][0].shape
+    assert _rel(gw, g["edsr_gw"]) < 2e-6 and _rel(gx, g["edsr_gin"][0]) < 2e-6
+    np.testing.assert_allclose(gw, g["edsr_gw"], rtol=0, atol=2e-6 * np.abs(g["edsr_gw"]).max())
+    for tag, roi in (("roi", g["roi"]), ("full", None)):
+        d_out = np.nan_to_num(g["sr_%s_gout" % tag][0])
+        gw, glr = oracle.planes_sr_backward(g9["lr"][0], blob, hid, nblocks, 2, pad, over, d_out, roi=roi)
+        assert _rel(gw, g["sr_%s_gw" % tag]) < 2e-6, tag
+        assert _rel(glr, g["sr_%s_glr" % tag][0]) < 2e-6, tag
+        np.testing.assert_allclose(glr, g["sr_%s_glr" % tag][0], rtol=0, atol=2e-6 * np.abs(g["sr_%s_glr" % tag]).max())
+    # weights only (LR plane detached, models.py:272)
+    gw2, none = oracle.planes_sr_backward(g9["lr"][0], blob, hid, nblocks, 2, pad, over, d_out, want_dlr=False)
+    assert none is None and np.array_equal(gw2, gw)
+
+
 def test_positional_encoding_and_nerf_mlp(oracle):
     g = load_golden("g10_posenc.npz")
     np.testing.assert_allclose(oracle.positional_encoding(g["x"], 6, True), g["pe_L6"], rtol=0, atol=2e-6)
