@@ -69,6 +69,11 @@ int nvsr_pack_decoder(const float* natural, float* packed, nvsr_stream_t stream)
  * focal_x = get_focal(f,'H'), focal_y = get_focal(f,'W') as the reference names them (:539-540). */
 int nvsr_get_ray_bundle(int H, int W, double focal_x, double focal_y, const float* c2w, int padding, double offset,
                         float* ro, float* rd, nvsr_stream_t stream);
+/* The rays of N selected pixels only: get_ray_bundle(...)[row, col] as train() uses it (train_nerf.py:814,842-844: the reference
+ * generates all H*W rays every iteration, then gathers num_random_rays of them).  row_col [N,2] int32 (device); (row, col) may
+ * lie outside the image (padding).  Bit-identical to the corresponding rows of nvsr_get_ray_bundle. */
+int nvsr_get_ray_bundle_at(int H, int W, double focal_x, double focal_y, const float* c2w, double offset, int64_t N, const int32_t* row_col,
+                           float* ro, float* rd, nvsr_stream_t stream);
 /* ndc_rays (nerf_helpers.py:578-605) */
 int nvsr_ndc_rays(int H, int W, double focal, double near_, int64_t N, const float* ro, const float* rd, float* ro_out,
                   float* rd_out, nvsr_stream_t stream);

@@ -7,7 +7,7 @@ HIP kernels of csrc/ behind the C ABI of include/nvsr.h (bound with ctypes in ca
 streams.  There is no CPU fallback: without a GPU or without the built library every entry point raises.
 """
 from . import capi  # noqa: F401
-from . import nerf_helpers, volume_rendering_utils, train_utils, models, distributed, plane_store  # noqa: F401
+from . import nerf_helpers, volume_rendering_utils, train_utils, models, distributed, plane_store, training  # noqa: F401
 from .build import build_extension  # noqa: F401
 
-__all__ = ["capi", "nerf_helpers", "volume_rendering_utils", "train_utils", "models", "distributed", "plane_store", "build_extension"]
+__all__ = ["capi", "nerf_helpers", "volume_rendering_utils", "train_utils", "models", "distributed", "plane_store", "training", "build_extension"]

@@ -41,6 +41,7 @@ _PROTOS = {
     "nvsr_plane_from_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "nvsr_pack_decoder": ([_vp, _vp, _vp], _i),
     "nvsr_get_ray_bundle": ([_i, _i, _d, _d, _vp, _i, _d, _vp, _vp, _vp], _i),
+    "nvsr_get_ray_bundle_at": ([_i, _i, _d, _d, _vp, _d, _i64, _vp, _vp, _vp, _vp], _i),
     "nvsr_ndc_rays": ([_i, _i, _d, _d, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_pack_rays": ([_i64, _vp, _vp, _vp, _d, _d, _vp, _vp], _i),
     "nvsr_coarse_z": ([_i64, _i, _vp, _i, _vp, _vp, _vp], _i),

@@ -81,6 +81,24 @@ __global__ void ray_bundle_kernel(int H, int W, float fx, float fy, const float*
     }
 }
 
+// get_ray_bundle(...)[rows, cols] of train_nerf.py:814,842-844 without generating the other H*W - N rays: same arithmetic per
+// ray as ray_bundle_kernel (bit-identical), driven by the selected pixel coordinates
+__global__ void ray_bundle_at_kernel(int H, int W, float fx, float fy, const float* __restrict__ c2w, float off, long N,
+                                     const int* __restrict__ rc, float* __restrict__ ro, float* __restrict__ rd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int r = rc[2 * i], c = rc[2 * i + 1];
+    const float ii = __fadd_rn((float)c, off), jj = __fadd_rn((float)r, off);
+    const float d0 = __fdiv_rn(__fsub_rn(ii, (float)(W * 0.5)), fx);
+    const float d1 = -__fdiv_rn(__fsub_rn(jj, (float)(H * 0.5)), fy);
+    const float d2 = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rd[i * 3 + k] = __fadd_rn(__fadd_rn(__fadd_rn(0.0f, __fmul_rn(d0, c2w[k * 4 + 0])), __fmul_rn(d1, c2w[k * 4 + 1])), __fmul_rn(d2, c2w[k * 4 + 2]));
+        ro[i * 3 + k] = c2w[k * 4 + 3];
+    }
+}
+
 __global__ void ndc_rays_kernel(float sx, float sy, float nr, float two_near, float m_two_near, long N, const float* __restrict__ ro,
                                 const float* __restrict__ rd, float* __restrict__ ro_out, float* __restrict__ rd_out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,6 +339,16 @@ int nvsr_get_ray_bundle(int H, int W, double focal_x, double focal_y, const floa
     const int64_t n = (int64_t)(H + 2 * padding) * (W + 2 * padding);
     hipLaunchKernelGGL(ray_bundle_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, (float)focal_x,
                        (float)focal_y, c2w, padding, (float)offset, ro, rd);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_get_ray_bundle_at(int H, int W, double focal_x, double focal_y, const float* c2w, double offset, int64_t N, const int32_t* row_col,
+                           float* ro, float* rd, nvsr_stream_t stream) {
+    if (!c2w || !row_col || !ro || !rd) return NVSR_ERR_NULL;
+    if (H < 1 || W < 1 || N < 0) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(ray_bundle_at_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, H, W, (float)focal_x, (float)focal_y,
+                       c2w, (float)offset, (long)N, row_col, ro, rd);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -594,13 +594,14 @@ class PlanesSR(nn.Module):
             full_plane, plane_roi, plane_name = False, plane_name[1], plane_name[0]
         else:
             full_plane, plane_roi = True, None
-        if plane_name in self.SR_planes:
+        lr_src = self.LR_planes[plane_name]
+        differentiable = self.training and self.inner_model.wants_grad(lr_src)
+        if plane_name in self.SR_planes and not differentiable:      # (a cached plane carries no graph: never serve it to a training step)
             return self.SR_planes[plane_name]
         if not self.align_corners:
             raise NotImplementedError("align_corners=False is not used by the planes model")
         if self.training and (self.input_noise > 0 or self.output_noise > 0):
             raise NotImplementedError("sr_input_noise / sr_output_noise are 0 in every shipped config")
-        lr_src = self.LR_planes[plane_name]
         lr = capi.f32c(lr_src.detach())
         Cc, R0, R1 = lr.shape[-3:]
         cin, cout, hid, nb, n_up = self.inner_model.geometry
@@ -612,7 +613,7 @@ class PlanesSR(nn.Module):
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
-        if self.training and self.inner_model.wants_grad(lr_src):
+        if differentiable:
             # training: gradients for the EDSR weights and the (non-detached) LR plane; the result is never cached
             return _PlanesSRFn.apply(self, lr_src, self.inner_model.natural_blob(differentiable=True), roi_c, mean, std)
         pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)

@@ -1,0 +1,205 @@
+"""Train / evaluate step glue -- the computational core of the reference's `train()` and `evaluate()` closures
+(train_nerf.py:790-923 and :625-788), without its logging, dataset and checkpoint plumbing.
+
+What changes against the reference:
+  * rays of the selected pixels only are generated (`nvsr_get_ray_bundle_at`) -- the reference builds all H*W rays per iteration
+    and gathers `num_random_rays` of them (:814,:842-844); results are bit-identical;
+  * everything else is the reference's arithmetic in the reference's order: pixel selection with numpy's global RNG (:816-846),
+    coarse / fine MSE gating by `what2train` and `super_resolution.training.loss` (:884-891), virtual batches and per-module
+    optimizer gating (:848-853, :905-914), the SR-vs-no-SR double render and PSNR bookkeeping of `evaluate()` (:655-713)."""
+import numpy as np
+import torch
+
+from . import capi
+from .nerf_helpers import get_focal, img2mse, mse2psnr
+from .train_utils import eval_nerf, run_one_iter_of_nerf
+
+
+def downsampling_offset(ds_factor):
+    """train_nerf.py:610: sub-pixel offset of rays rendered for images that were down-sampled by ds_factor"""
+    return (ds_factor - 1) / (2 * ds_factor)
+
+
+def get_ray_bundle_at(height, width, focal_length, tform_cam2world, rows_cols, downsampling_offset=0.0):
+    """get_ray_bundle(height, width, focal, c2w, downsampling_offset=...)[rows, cols] -> (ray_origins [N,3], ray_directions [N,3])"""
+    c2w = capi.f32c(tform_cam2world)
+    rc = rows_cols.to(device=c2w.device, dtype=torch.int32).contiguous()
+    N = rc.shape[0]
+    ro = torch.empty((N, 3), dtype=torch.float32, device=c2w.device)
+    rd = torch.empty_like(ro)
+    if N == 0:
+        return ro, rd
+    capi.call("nvsr_get_ray_bundle_at", height, width, float(get_focal(focal_length, "H")), float(get_focal(focal_length, "W")),
+              capi.ptr(c2w), float(downsampling_offset), N, capi.ptr(rc), capi.ptr(ro), capi.ptr(rd), capi.stream())
+    return ro, rd
+
+
+def mse_loss(x, y, weights=None):
+    """train_nerf.py:618-623"""
+    if weights is None:
+        return torch.nn.functional.mse_loss(x, y)
+    return (torch.nn.functional.mse_loss(x, y, reduction="none").mean(1) * weights).mean()
+
+
+def avg_downsampling(pixels, ds_factor):
+    """train_nerf.py:614-616: average every rendered (ds x ds) patch into one pixel"""
+    return torch.mean(pixels.reshape(-1, ds_factor, ds_factor, 3), dim=(1, 2))
+
+
+def downsample_plane(plane, ds_factor, plane_interp, align_corners, antialias=False):
+    """nerf_helpers.py:498-499"""
+    return torch.nn.functional.interpolate(plane, scale_factor=1 / ds_factor, mode=plane_interp, align_corners=align_corners, antialias=antialias)
+
+
+def calc_im_inconsistency_loss(sr, ds_factor, plane_interp, align_corners=True, gt_lr=None, gt_hr=None):
+    """nerf_helpers.py:501-505"""
+    assert (gt_lr is None) ^ (gt_hr is None)
+    ref = gt_lr if gt_hr is None else downsample_plane(gt_hr, ds_factor, plane_interp, align_corners, antialias=True)
+    return torch.nn.functional.l1_loss(ref, downsample_plane(sr, ds_factor, plane_interp, align_corners, antialias=True))
+
+
+def select_training_pixels(img_target, num_random_rays, consistency_ds=None):
+    """train_nerf.py:816-846.  -> (rows_cols [N,2] int64 on img_target's device, target_s [n_targets, C]).
+    consistency_ds: None for an ordinary iteration; the coupler's ds_factor for an image-consistency iteration, where
+    num_random_rays // ds^2 LR pixels are drawn and each is expanded to its (ds x ds) patch of HR pixel coordinates."""
+    dev = img_target.device
+    h, w = img_target.shape[0], img_target.shape[1]
+    # `coords = stack(meshgrid_xy(arange(H), arange(W)), -1).reshape(-1, 2)` (:818-828) enumerates pixels COLUMN by column:
+    # coords[k] = (row k % H, col k // H); keeping that order keeps a seeded run on the reference's pixels
+    if consistency_ds is None:
+        n = min(h * w, num_random_rays)
+        flat = np.random.choice(h * w, size=(n), replace=False)
+        sel = torch.from_numpy(np.stack([flat % h, flat // h], -1)).to(dev)
+        return sel, img_target[sel[:, 0], sel[:, 1], :]
+    ds = int(consistency_ds)
+    n = min(h * w, num_random_rays // (ds ** 2))
+    flat = np.random.choice(h * w, size=(n), replace=False)
+    corners = torch.from_numpy(np.stack([flat % h, flat // h], -1)).to(dev)
+    target_s = img_target[corners[:, 0], corners[:, 1], :]
+    corners = ds * corners[:, None, None, :]
+    ar = torch.arange(ds, device=dev, dtype=corners.dtype)
+    rows = corners[..., :1] + ar.reshape(1, -1, 1, 1).repeat(1, 1, ds, 1)
+    cols = corners[..., 1:] + ar.reshape(1, 1, -1, 1).repeat(1, ds, 1, 1)
+    return torch.cat([rows, cols], -1).reshape(-1, 2), target_s
+
+
+class TrainStep:
+    """One optimisation iteration of train() for the planes model.
+
+    what2train  subset of {'LR_planes', 'decoder', 'SR'} (cfg.nerf.train.what, train_nerf.py:75-77)
+    optimizer   decoder optimizer or None;  SR_optimizer or None;  planes_optimizer: any object with zero_grad() / step() (the
+                reference's PlanesOptimizer, or a torch optimizer over the plane parameters) or None
+    sr_loss     cfg.super_resolution.training.loss in {'both', 'fine', 'coarse'} (:885,:889)"""
+
+    def __init__(self, model_coarse, model_fine, options, what2train, optimizer=None, SR_optimizer=None, planes_optimizer=None, SR_model=None,
+                 virtual_batch_size=1, rendering_loss_w=1.0, im_inconsistency_loss_w=None, sr_loss="both", ds_factor=1,
+                 separate_decoder_sr=False, grad_sync=None):
+        self.mc, self.mf, self.options = model_coarse, model_fine, options
+        self.what = set(what2train)
+        self.optimizer, self.SR_optimizer, self.planes_optimizer, self.SR_model = optimizer, SR_optimizer, planes_optimizer, SR_model
+        self.vbs = max(1, int(virtual_batch_size))
+        self.rendering_loss_w, self.im_inconsistency_loss_w = rendering_loss_w, im_inconsistency_loss_w
+        self.sr_loss, self.ds_factor, self.separate_decoder_sr = sr_loss, int(ds_factor), separate_decoder_sr
+        self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
+
+    def __call__(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
+                 im_consistency_iter=False, confinements=(), randoms=None):
+        first_v, last_v = it % self.vbs == 0, it % self.vbs == self.vbs - 1
+        if "SR" in self.what and self.SR_model is not None:
+            self.SR_model.train()
+        if "decoder" in self.what:
+            self.mc.train()
+            if self.mf is not None:
+                self.mf.train()
+        if im_consistency_iter:      # render in HR although the target image is LR (:806-811)
+            H, W, focal, cur_ds_factor = H * self.ds_factor, W * self.ds_factor, focal * self.ds_factor, cur_ds_factor // self.ds_factor
+        sel, target_s = select_training_pixels(img_target, num_random_rays, self.ds_factor if im_consistency_iter else None)
+        ro, rd = get_ray_bundle_at(H, W, focal, pose_target, sel, downsampling_offset=downsampling_offset(cur_ds_factor))
+        batch_rays = torch.stack([ro, rd], 0)
+        if first_v:
+            for o in (self.optimizer, self.SR_optimizer):
+                if o is not None:
+                    o.zero_grad()
+        if self.planes_optimizer is not None:
+            self.planes_optimizer.zero_grad()
+        if hasattr(self.mf, "SR_model") and sr_iter and "LR_planes" in self.what:
+            self.mf.SR_model.clear_SR_planes(all_planes=True)
+            self.mf.assign_LR_planes(scene=scene_id)
+        out = run_one_iter_of_nerf(H, W, focal, self.mc, self.mf, batch_rays, self.options, scene_id, mode="train", scene_config=scene_config,
+                                   randoms=randoms)
+        rgb_coarse, rgb_fine = out[0], out[3]
+        target = target_s[..., :3]
+        if im_consistency_iter:
+            rgb_coarse = avg_downsampling(rgb_coarse, self.ds_factor)
+            rgb_fine = None if rgb_fine is None else avg_downsampling(rgb_fine, self.ds_factor)
+        coarse_loss = fine_loss = None
+        trains_scene = bool(self.what & {"decoder", "LR_planes"})
+        if self.rendering_loss_w is not None:
+            if trains_scene or self.sr_loss != "fine":
+                coarse_loss = mse_loss(rgb_coarse, target)
+            if rgb_fine is not None and (trains_scene or self.sr_loss != "coarse"):
+                fine_loss = mse_loss(rgb_fine, target)
+        rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
+        psnr = None
+        if isinstance(rendering_loss, torch.Tensor) and not im_consistency_iter:
+            psnr = mse2psnr(rendering_loss.item())
+        loss = (self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w) * rendering_loss
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        if self.planes_optimizer is not None:
+            self.planes_optimizer.step()
+        if last_v:
+            if self.optimizer is not None:
+                decoder_step = "decoder" not in confinements
+                if "SR" in self.what and self.separate_decoder_sr:
+                    decoder_step &= not sr_iter
+                if decoder_step:
+                    self.optimizer.step()
+            if self.SR_optimizer is not None and sr_iter and "SR" not in confinements:
+                self.SR_optimizer.step()
+        return dict(loss=loss.item(), psnr=psnr, coarse_loss=None if coarse_loss is None else coarse_loss.item(),
+                    fine_loss=None if fine_loss is None else fine_loss.item())
+
+
+def evaluate_view(model_coarse, model_fine, options, scene_id, scene_config, img_target, pose_target, H, W, focal, cur_ds_factor=1,
+                  SR_model=None, sr_scene=False, ds_factor=1, im_inconsistency=False):
+    """One view of evaluate() (train_nerf.py:655-713): render; on an SR scene render again with the SR model bypassed as the
+    reference image, and report the SR PSNR gain.  -> dict of images and metrics (python floats)."""
+    for m in (model_coarse, model_fine, SR_model):
+        if m is not None:
+            m.eval()
+    with torch.no_grad():
+        from .nerf_helpers import get_ray_bundle
+        ro, rd = get_ray_bundle(H, W, focal, pose_target, downsampling_offset=downsampling_offset(cur_ds_factor))
+
+        def render_view():
+            rgb_c, _, _, rgb_f, _, _, rgb_sr, _, _ = eval_nerf(H, W, focal, model_coarse, model_fine, ro, rd, options, mode="validation",
+                                                             scene_id=scene_id, scene_config=scene_config)
+            return rgb_c, rgb_f, rgb_sr
+
+        rgb_coarse, rgb_fine, rgb_SR = render_view()
+        tgt = img_target[..., :3]
+        res = dict(loss=img2mse(rgb_fine[..., :3], tgt).item())
+        res["psnr"] = mse2psnr(res["loss"])
+        if sr_scene:
+            if im_inconsistency:
+                res["im_inconsistency"] = calc_im_inconsistency_loss(gt_hr=tgt.permute(2, 0, 1)[None], sr=rgb_fine[..., :3].permute(2, 0, 1)[None],
+                                                                     ds_factor=ds_factor, plane_interp="bilinear").item()
+            if SR_model is not None:
+                rgb_SR = 1 * rgb_fine
+                model_coarse.skip_SR(True)
+                model_fine.skip_SR(True)
+                rgb_coarse, rgb_fine, _ = render_view()          # the same view from the LR planes, as reference
+                model_coarse.skip_SR(False)
+                model_fine.skip_SR(False)
+            res["fine_loss"] = img2mse(rgb_fine[..., :3], tgt).item()
+            if SR_model is not None:
+                res["SR_psnr_gain"] = res["psnr"] - mse2psnr(res["fine_loss"])
+        else:
+            res["coarse_loss"] = img2mse(rgb_coarse[..., :3], tgt).item()
+            res["fine_loss"] = img2mse(rgb_fine[..., :3], tgt).item() if rgb_fine is not None else 0.0
+        if SR_model is not None:
+            SR_model.clear_SR_planes()       # evaluate() drops the cached super-resolved planes when it is done with a scene (:714-718)
+        res.update(rgb_coarse=rgb_coarse, rgb_fine=rgb_fine, rgb_SR=rgb_SR)
+        return res

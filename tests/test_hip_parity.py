@@ -921,3 +921,103 @@ def test_ndc_render_golden(hip):
     np.testing.assert_allclose(N_(img_c).reshape(-1, 3), g["rgb_coarse"], rtol=0, atol=3e-5)
     err = np.abs(N_(img_f).reshape(-1, 3) - g["rgb_fine"]).max(-1)
     assert np.mean(err <= 2e-4) >= 0.97 and psnr(N_(img_f).reshape(-1, 3), g["rgb_fine"]) >= 70.0, (np.mean(err <= 2e-4), err.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train() / evaluate() glue
+# ---------------------------------------------------------------------------------------------------------------------
+def test_ray_bundle_at_selected_pixels_bit_exact(hip):
+    """rays of selected pixels only == the same rows of the full bundle, bit for bit (train_nerf.py:814,842-844)"""
+    g = load_golden("g08_render.npz")
+    rng = np.random.default_rng(71)
+    for H, W, off in [(37, 53, 0.0), (100, 80, 0.4375)]:
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]), downsampling_offset=off)
+        sel = torch.from_numpy(np.stack([rng.integers(0, H, 500), rng.integers(0, W, 500)], -1)).to(DEV)
+        ro_s, rd_s = hip.training.get_ray_bundle_at(H, W, focal, T(g["pose"]), sel, downsampling_offset=off)
+        assert_bits_equal(N_(rd_s), N_(rd[sel[:, 0], sel[:, 1]]))
+        assert_bits_equal(N_(ro_s), N_(ro[sel[:, 0], sel[:, 1]]))
+    e = hip.training.get_ray_bundle_at(8, 8, 10.0, T(g["pose"]), torch.zeros((0, 2), dtype=torch.int64, device=DEV))
+    assert e[0].shape == (0, 3)
+
+
+def _gt_and_student(hip, g, sid, R=20, Rv=8, seed=81):
+    rng = np.random.default_rng(seed)
+    gt_planes = [rng.standard_normal((1, 48, R, R), dtype=np.float32) * 0.5 for _ in range(3)] + \
+                [rng.standard_normal((1, 48, Rv, Rv), dtype=np.float32) * 0.5]
+    noisy = [p + rng.standard_normal(p.shape, dtype=np.float32) * 0.3 for p in gt_planes]
+    return gt_planes, noisy
+
+
+def test_train_step_glue_reduces_loss(hip):
+    """TrainStep (train_nerf.py:790-923): planes + decoder trained against images rendered from ground-truth planes; the loss falls,
+    virtual batches gate the decoder optimizer, the planes optimizer steps every iteration"""
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    gt_planes, noisy = _gt_and_student(hip, g, sid)
+    H = W = 24
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24, perturb=True, noise=0.0)
+    gt_c, gt_f = _grad_models(hip, g, gt_planes, sid, what=())
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    with torch.no_grad():
+        img = hip.train_utils.eval_nerf(H, W, focal, gt_c, gt_f, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
+    mc, mf = _grad_models(hip, g, noisy, sid, what=("planes", "decoder"))
+    dec_params = list({id(p_): p_ for m in (mc, mf) for p_ in m.decoder_parameters()}.values())
+    opt = torch.optim.Adam(dec_params, lr=1e-4)
+    popt = torch.optim.Adam(list(mc.planes_.values()), lr=2e-2)
+    step = hip.training.TrainStep(mc, mf, opts, {"LR_planes", "decoder"}, optimizer=opt, planes_optimizer=popt, virtual_batch_size=2)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    w0 = mc.fc_alpha["0"].weight.detach().clone()
+    p0 = mc.planes_[hip.models.get_plane_name(sid, 0)].detach().clone()
+    r = step(0, img, pose, H, W, focal, 1, sid, scfg, 256)
+    assert torch.equal(mc.fc_alpha["0"].weight, w0)                      # first half of a virtual batch: no decoder step yet
+    assert not torch.equal(mc.planes_[hip.models.get_plane_name(sid, 0)], p0)   # the planes step every iteration (:904)
+    losses = [r["loss"]]
+    for it in range(1, 40):
+        losses.append(step(it, img, pose, H, W, focal, 1, sid, scfg, 256)["loss"])
+    assert not torch.equal(mc.fc_alpha["0"].weight, w0)
+    assert np.mean(losses[-8:]) < 0.5 * np.mean(losses[:4]), losses
+    assert r["psnr"] is not None and r["coarse_loss"] is not None and r["fine_loss"] is not None
+
+
+def test_sr_train_step_and_evaluate_view(hip):
+    """what = ['SR']: only the SR optimizer moves, only the fine loss is taken with loss: 'fine' (:885-889); evaluate_view renders the
+    SR scene twice (with and without the SR model) and reports the PSNR gain (:690-713)"""
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    gt_planes, noisy = _gt_and_student(hip, g, sid, seed=82)
+    H = W = 20
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24)
+    mc, mf = _grad_models(hip, g, noisy, sid, what=())
+    torch.manual_seed(8)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+    for m in (mc, mf):
+        m.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    for m in (mc, mf):
+        m.skip_SR(True)
+    with torch.no_grad():
+        img = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]   # target = the LR render
+    for m in (mc, mf):
+        m.skip_SR(False)
+    ev = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
+    assert ev["fine_loss"] == 0.0 and ev["rgb_SR"] is not None and ev["psnr"] < 50.0     # the no-SR render IS the target
+    assert abs(ev["SR_psnr_gain"] - (ev["psnr"] - 50.0)) < 1e-9                          # mse2psnr(0) = 50 dB by convention (:265-269)
+    sr_opt = torch.optim.Adam(sr.parameters(), lr=2e-3)
+    step = hip.training.TrainStep(mc, mf, opts, {"SR"}, SR_optimizer=sr_opt, SR_model=sr, sr_loss="fine")
+    np.random.seed(4)
+    first = None
+    for it in range(12):
+        r = step(it, img, pose, H, W, focal, 1, sid, scfg, 200, sr_iter=True)
+        assert r["coarse_loss"] is None and r["fine_loss"] is not None
+        first = first if first is not None else r["loss"]
+    sr.clear_SR_planes()
+    ev2 = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
+    assert ev2["loss"] < ev["loss"], (ev["loss"], ev2["loss"])           # the SR net learned to reproduce the target better
+    assert all(p_.grad is None for p_ in mc.decoder_parameters())

@@ -3,6 +3,7 @@ include/nvsr.h declares (no compute calls), and the product path refuses CPU ten
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -105,3 +106,35 @@ def test_plane_store_round_trip_and_backup_fallback(pkg, tmp_path):
     mf = M.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", num_planes_or_rot_mats=mc.rot_mats())
     ps.load_scene([mc, mf], str(tmp_path), sid, device="cpu")
     assert mc.planes_ is mf.planes_ and mc.cur_id == sid and torch.equal(mf.box_coords[sid], box)
+
+
+def test_select_training_pixels_follows_the_reference_enumeration():
+    """train_nerf.py:816-846: pixels are enumerated column by column (coords = stack(meshgrid_xy(arange(H), arange(W)), -1)), drawn
+    without replacement from numpy's global RNG; consistency iterations expand each LR pixel to its ds x ds HR patch"""
+    import nvsr_amd
+    from nvsr_amd.nerf_helpers import meshgrid_xy
+    import torch
+    h, w = 7, 5
+    img = torch.arange(h * w * 3, dtype=torch.float32).reshape(h, w, 3)
+    coords = torch.stack(meshgrid_xy(torch.arange(h), torch.arange(w)), dim=-1).reshape(-1, 2)
+    np.random.seed(11)
+    ref_idx = np.random.choice(h * w, size=(12), replace=False)
+    np.random.seed(11)
+    sel, tgt = nvsr_amd.training.select_training_pixels(img, 12)
+    assert torch.equal(sel, coords[ref_idx])
+    assert torch.equal(tgt, img[sel[:, 0], sel[:, 1]])
+    assert len({(int(a), int(b)) for a, b in sel}) == 12
+    sel_all, _ = nvsr_amd.training.select_training_pixels(img, 10 ** 6)           # capped at the image size
+    assert sel_all.shape[0] == h * w
+    np.random.seed(12)
+    ref_idx = np.random.choice(h * w, size=(40 // 4), replace=False)
+    np.random.seed(12)
+    sel, tgt = nvsr_amd.training.select_training_pixels(img, 40, consistency_ds=2)
+    assert sel.shape == (40, 2) and tgt.shape == (10, 3)
+    corners = coords[ref_idx]
+    patches = sel.reshape(10, 2, 2, 2)
+    assert torch.equal(patches[:, 0, 0], 2 * corners)
+    assert torch.equal(patches[:, 1, 0], 2 * corners + torch.tensor([1, 0]))     # rows vary first inside a patch, columns second
+    assert torch.equal(patches[:, 0, 1], 2 * corners + torch.tensor([0, 1]))
+    px = torch.rand(40, 3)
+    assert torch.allclose(nvsr_amd.training.avg_downsampling(px, 2), px.reshape(10, 4, 3).mean(1))
