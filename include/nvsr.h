@@ -158,6 +158,16 @@ int64_t nvsr_planes_sr_workspace_floats(int C, int R0, int R1, int hid, int nblo
 int nvsr_planes_sr(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* std_, float* out, float* workspace, nvsr_stream_t stream);
 
+/* Batched variants: B planes of equal size share every launch (a single 200^2 plane fills the 256 CUs for only 1.2-1.8 workgroup
+ * rounds per layer; the 3 position planes of a scene together for 3.6-5.4).  x [B][Cin][H][W] -> out [B][Cout][Ho][Wo];
+ * workspace = B * nvsr_edsr_workspace_floats(...).  nvsr_planes_sr_batch: lr / out are HOST arrays of B device pointers,
+ * workspace = B * nvsr_planes_sr_workspace_floats(...). */
+int nvsr_edsr_forward_batch(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                            float* out, float* workspace, nvsr_stream_t stream);
+int nvsr_planes_sr_batch(const float* const* lr, int B, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
+                         int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
+                         nvsr_stream_t stream);
+
 /* ---- positional-encoding baseline (MipNeRF_baseline.yml; not on the tri-plane path) ------------------------------------ */
 /* positional_encoding (nerf_helpers.py:552-575): x [P,D] -> [P, (include_input ? D : 0) + 2*D*L] = [x, sin(2^0 x), cos(2^0 x), ...] */
 int nvsr_positional_encoding(int64_t P, int D, const float* x, int L, int include_input, float* out, nvsr_stream_t stream);

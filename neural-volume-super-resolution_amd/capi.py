@@ -79,6 +79,8 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_decoder_record_floats": ([_i64, _i], _i64),
     "nvsr_render_pass_backward_ex": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp], _i),
     "nvsr_decoder_weight_grad": ([_i64, _i, _vp, _vp, _vp], _i),
+    "nvsr_edsr_forward_batch": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "nvsr_planes_sr_batch": ([C.POINTER(C.c_void_p), _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp], _i),
     # super-resolution CNN backward (csrc/sr_bwd.hip)
     "nvsr_pack_conv3x3_dgrad": ([_vp, _i, _i, _vp, _vp], _i),
     "nvsr_conv3x3_dgrad": ([_vp, _i, _i, _i, _vp, _i, _vp, _vp], _i),

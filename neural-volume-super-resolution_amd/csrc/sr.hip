@@ -32,6 +32,8 @@ struct ConvParams {
     int nchunks;          // ceil(Cin/4)
     int epilogue;
     int pad;              // 0, or 2 for the data gradient of a valid conv ("full" correlation with the flipped kernel)
+    int ncg;              // co-groups of the grid; blockIdx.z = batch * ncg + co-group
+    long in_bs, out_bs, skip_bs;   // floats between consecutive planes of a batch (the 3 planes of a scene share the weights)
 };
 
 __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
@@ -53,7 +55,10 @@ __global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int cw = wave / PX_WAVES, rg = wave % PX_WAVES;   // co-wave, pixel-row group
     const int Ho = p.H - 2, Wo = p.W - 2;
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * ROWS, cg = blockIdx.z;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * ROWS, cg = blockIdx.z % p.ncg, bi = blockIdx.z / p.ncg;
+    p.in += bi * p.in_bs;
+    p.out += bi * p.out_bs;
+    if (p.skip) p.skip += bi * p.skip_bs;
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
 
@@ -224,16 +229,22 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
 }
 
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad) {
+                hipStream_t stream, int pad, int batch) {
+    const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
-    if (H < 3 || W < 3) return NVSR_ERR_SHAPE;
-    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad};
+    if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
     const int Ho = H - 2, Wo = W - 2;
+    const long out_bs = (long)Cout * Ho * Wo;       // (PixelShuffle only permutes the Cout*Ho*Wo elements)
+    const long skip_bs = epilogue == EPI_RESIDUAL ? (long)Cout * (Ho + 4) * (Wo + 4)
+                         : epilogue == EPI_ADD_CENTER ? (long)Cout * (Ho - 4) * (Wo - 4) : out_bs;
+    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
     if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
-        dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncb_total / 8);
+        p.ncg = p.ncb_total / 8;
+        dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
         hipLaunchKernelGGL((conv3x3_kernel<4, 2>), grid, dim3(CONV_TPB), 0, stream, p);
     } else {
-        dim3 grid((Wo + 31) / 32, (Ho + 31) / 32, p.ncb_total / 2);
+        p.ncg = p.ncb_total / 2;
+        dim3 grid((Wo + 31) / 32, (Ho + 31) / 32, p.ncg * batch);
         hipLaunchKernelGGL((conv3x3_kernel<1, 8>), grid, dim3(CONV_TPB), 0, stream, p);
     }
     return NVSR_CHECK_LAUNCH();
@@ -331,43 +342,52 @@ int64_t nvsr_edsr_workspace_floats(int hid, int nblocks, int n_up, int H, int W)
     return 3 * mx;
 }
 
-int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
-                      float* workspace, nvsr_stream_t stream_) {
+/* B planes at once ([B][Cin][H][W] -> [B][Cout][Ho][Wo]): one launch per layer, the batch index rides in the grid.  A 256-channel
+ * layer of one 200^2 plane is only ~1.2-1.8 workgroup rounds on 256 CUs (28 % of the issue slots idle in the partial last round);
+ * the 3 position planes of a scene together run 3.6-5.4 rounds.  workspace: B * nvsr_edsr_workspace_floats floats. */
+int nvsr_edsr_forward_batch(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                            float* out, float* workspace, nvsr_stream_t stream_) {
     if (!x || !packed || !out || !workspace) return NVSR_ERR_NULL;
+    if (B < 1) return NVSR_ERR_SHAPE;
     int Ho, Wo;
     if (int e = nvsr_edsr_out_size(H, W, nblocks, n_up, &Ho, &Wo)) return e;
     hipStream_t stream = (hipStream_t)stream_;
-    const int64_t third = nvsr_edsr_workspace_floats(hid, nblocks, n_up, H, W) / 3;
+    const int64_t third = nvsr_edsr_workspace_floats(hid, nblocks, n_up, H, W) / 3 * B;
     float* bufs[3] = {workspace, workspace + third, workspace + 2 * third};
     const float* wp = packed;
     int h = H, w = W, e;
     // conv_input
     float* cur = bufs[0];
-    if ((e = launch_conv(x, Cin, h, w, wp, hid, EPI_NONE, nullptr, cur, stream))) return e;
+    if ((e = launch_conv(x, Cin, h, w, wp, hid, EPI_NONE, nullptr, cur, stream, 0, B))) return e;
     wp += conv_packed_floats(Cin, hid); h -= 2; w -= 2;
     int ci = 0;                                   // index of `cur` in bufs
     for (int b = 0; b < nblocks; ++b) {           // _Residual_Block (models.py:777-786)
         float* t1 = bufs[(ci + 1) % 3];
         float* t2 = bufs[(ci + 2) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_RELU, nullptr, t1, stream))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_RELU, nullptr, t1, stream, 0, B))) return e;
         wp += conv_packed_floats(hid, hid);
-        if ((e = launch_conv(t1, hid, h - 2, w - 2, wp, hid, EPI_RESIDUAL, cur, t2, stream))) return e;
+        if ((e = launch_conv(t1, hid, h - 2, w - 2, wp, hid, EPI_RESIDUAL, cur, t2, stream, 0, B))) return e;
         wp += conv_packed_floats(hid, hid);
         cur = t2; ci = (ci + 2) % 3; h -= 4; w -= 4;
     }
     {   // conv_mid
         float* t = bufs[(ci + 1) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_NONE, nullptr, t, stream))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_NONE, nullptr, t, stream, 0, B))) return e;
         wp += conv_packed_floats(hid, hid);
         cur = t; ci = (ci + 1) % 3; h -= 2; w -= 2;
     }
     for (int u = 0; u < n_up; ++u) {              // conv hid -> 4 hid + PixelShuffle(2), fused
         float* t = bufs[(ci + 1) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, 4 * hid, EPI_PIXEL_SHUFFLE, nullptr, t, stream))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, 4 * hid, EPI_PIXEL_SHUFFLE, nullptr, t, stream, 0, B))) return e;
         wp += conv_packed_floats(hid, 4 * hid);
         cur = t; ci = (ci + 1) % 3; h = (h - 2) * 2; w = (w - 2) * 2;
     }
-    return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream);
+    return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream, 0, B);
+}
+
+int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                      float* workspace, nvsr_stream_t stream_) {
+    return nvsr_edsr_forward_batch(x, 1, Cin, H, W, packed, Cout, hid, nblocks, n_up, out, workspace, stream_);
 }
 
 /* ---- training forward: every layer's input is kept for the backward pass (sr_bwd.hip) ---------------------------------- */
@@ -404,6 +424,44 @@ int64_t nvsr_planes_sr_workspace_floats(int Cc, int R0, int R1, int hid, int nbl
     int Ho, Wo;
     if (nvsr_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo)) return -1;
     return (int64_t)Cc * Hp * Wp + (int64_t)Cc * Ho * Wo + nvsr_edsr_workspace_floats(hid, nblocks, n_up, Hp, Wp);
+}
+
+/* B planes of the same size through the SR network in one batch (the 3 position planes of a scene, models.py:289-310).
+ * lr / out: HOST arrays of B device pointers.  workspace: B * nvsr_planes_sr_workspace_floats(...) floats. */
+int nvsr_planes_sr_batch(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
+                         int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
+                         nvsr_stream_t stream_) {
+    if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
+    if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
+    if (B < 1 || B > 64) return NVSR_ERR_SHAPE;
+    for (int b = 0; b < B; ++b)
+        if (!lr[b] || !out[b]) return NVSR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int sf = 1 << n_up;
+    int lo[2], hi[2];
+    sr_roi(R0, R1, roi, lo, hi);
+    const int ch = hi[0] - lo[0], cw = hi[1] - lo[1];
+    const int Hp = ch + 2 * pad, Wp = cw + 2 * pad;
+    int Ho, Wo;
+    if (int e = nvsr_edsr_out_size(Hp, Wp, nblocks, n_up, &Ho, &Wo)) return e;
+    if (Ho != ch * sf + 2 * over || Wo != cw * sf + 2 * over) return NVSR_ERR_SHAPE;
+    const int64_t n_in = (int64_t)Cc * Hp * Wp, n_diff = (int64_t)Cc * Ho * Wo;
+    float* xin = workspace;                       // [B][C][Hp][Wp]
+    float* diff = xin + B * n_in;                 // [B][C][Ho][Wo]
+    float* ews = diff + B * n_diff;
+    for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(sr_prepare_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, lr[b], Cc, R0, R1, lo[0], lo[1], Hp,
+                           Wp, pad, mean, stdv, xin + b * n_in);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    if (int e = nvsr_edsr_forward_batch(xin, B, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
+    const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
+    for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
+                           Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b]);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    return NVSR_OK;
 }
 
 /* floats kept between nvsr_planes_sr_train and nvsr_planes_sr_backward: the prepared network input + the activation record */

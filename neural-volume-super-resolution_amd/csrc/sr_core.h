@@ -83,7 +83,8 @@ inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
 }
 
 // H, W: size of the tensor in memory; pad: virtual zero border (the kernel sees (H+2pad) x (W+2pad)).  Defined in sr.hip.
+// batch: consecutive [C][H][W] planes in `in` / `skip` / `out`, all convolved with the same weights in one launch.
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad = 0);
+                hipStream_t stream, int pad = 0, int batch = 1);
 
 }  // namespace nvsr

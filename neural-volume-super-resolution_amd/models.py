@@ -315,6 +315,13 @@ class TwoDimPlanesModel(nn.Module):
         channel-last planes (the training path samples tensors that are part of the autograd graph)."""
         self._check_native_geometry()
         if planes is None:
+            if hasattr(self, "SR_model") and not self.skip_SR_ and not (self.SR_model.training and torch.is_grad_enabled()):
+                # evaluation: super-resolve every plane that needs it in one batched pass; _plane_source then hits the cache
+                names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]
+                names = [n for n in names if self._should_SR(n)]
+                if self.scene_coupler is not None:
+                    names = [self.scene_coupler.scene_with_saved_plane(n, plane_not_scene=True) for n in names]
+                self.SR_model.super_resolve_many(names)
             planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
         sc = capi.Scene()
         for d, p in enumerate(planes):
@@ -588,6 +595,36 @@ class PlanesSR(nn.Module):
             planes_2_clear += ["LR_planes", "residual_planes"]
         for attr in planes_2_clear:
             setattr(self, attr, {})
+
+    def super_resolve_many(self, plane_names):
+        """Full-plane, no-grad super-resolution of several equally sized planes in ONE batched pass (fills the cache `forward`
+        serves from).  The reference super-resolves the planes one by one on first use (models.py:270-284); the values are the
+        same, the batch keeps all 256 CUs busy."""
+        todo = [n for n in plane_names if n not in self.SR_planes]
+        if len(todo) < 2 or (self.training and (self.input_noise > 0 or self.output_noise > 0)):
+            return
+        lrs = [capi.f32c(self.LR_planes[n].detach()) for n in todo]
+        if len({tuple(t.shape[-3:]) for t in lrs}) != 1 or not self.align_corners:
+            return
+        Cc, R0, R1 = lrs[0].shape[-3:]
+        cin, cout, hid, nb, n_up = self.inner_model.geometry
+        mean = std = None
+        if hasattr(self, "planes_mean_NON_LEARNED"):
+            mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
+        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
+        B = len(todo)
+        nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None)
+        if nws < 0:
+            return
+        ws = torch.empty(B * nws, dtype=torch.float32, device=lrs[0].device)
+        sf = self.scale_factor
+        outs = [torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lrs[0].device) for _ in todo]
+        lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lrs])
+        out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
+        capi.call("nvsr_planes_sr_batch", lr_ptrs, B, Cc, R0, R1, capi.ptr(self.inner_model.packed_weights()), hid, nb, n_up, pad, over, None,
+                  capi.ptr(mean), capi.ptr(std), out_ptrs, capi.ptr(ws), capi.stream())
+        for n, o in zip(todo, outs):
+            self.SR_planes[n] = o
 
     def forward(self, plane_name):
         if isinstance(plane_name, tuple):
