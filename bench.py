@@ -3,10 +3,17 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): one "step" renders one 800x800 view (640 000 rays) of a synthetic Lego-like scene with
+Default workload (BASELINE.json configs[1]): one "step" renders one 800x800 view (640 000 rays) of a synthetic Lego-like scene with
 64 coarse + 128 fine samples per ray (256 decoder evaluations per ray) through the tri-plane decoder, planes 3 x 800^2 x 48 +
 32^2 x 48, everything resident in HBM before the timed region.  Weak scaling: every rank renders its own view of the same
 (replicated) scene; there is no data-path collective.  Prints ONE JSON line on rank 0.
+
+Other workloads of the same path (--workload; same JSON contract, their own metric):
+  train   BASELINE configs[3]: one optimisation step = 4096 random rays of one view, 64+64 samples, planes 200^2, gradients for the
+          planes AND both decoders, Adam; N > 1: every rank draws its own rays, gradients are averaged with one bucketed RCCL
+          all-reduce (planes 23 MB + decoders 1 MB) before the optimizer steps.
+  sr      BASELINE configs[2]'s SR stage: the 3 position planes of a scene 200^2 -> 800^2 through EDSR (hidden 256, 32 blocks, x4)
+          in one batched pass (20.2 TFLOP); N > 1: independent replicas (a scene's planes are SR'd once and cached).
 """
 import argparse
 import json
@@ -142,8 +149,168 @@ def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
             "evals_per_s": n * 256 / t}, psnr
 
 
+def _sync_time(dist, dev, fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def bench_train(args, nvsr_amd, dist, dev, rank, world):
+    """4096 rays / 64+64 / planes 200^2: forward + backward (planes + both decoders) + Adam"""
+    import ctypes as C
+    capi = nvsr_amd.capi
+    R, N, Nc, Nf = 200, 4096, 64, 64
+    mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0)
+    for m in (mc, mf):
+        for n, p in m.named_parameters():
+            p.requires_grad_("rot_mats" not in n)
+        m.train()
+    H = W = 800
+    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
+    opts, scfg = render_options(Nc, Nf, perturb=True, noise=0.2)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    target = torch.rand(H, W, 3, device=dev, generator=g)
+    dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
+    planes = list(mc.planes_.values())
+    opt, popt = torch.optim.Adam(dec, lr=5e-4), torch.optim.Adam(planes, lr=4e-3)
+    sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in planes + dec if p.grad is not None])) if world > 1 else None
+    def device_sampler(img, n_rays, consistency_ds=None):
+        # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the
+        # device: the host permutation of 640 000 indices costs more than the whole GPU step
+        flat = torch.randperm(img.shape[0] * img.shape[1], device=dev, generator=g)[:n_rays]
+        sel = torch.stack([flat % img.shape[0], flat // img.shape[0]], -1)
+        return sel, img[sel[:, 0], sel[:, 1], :]
+
+    step = nvsr_amd.training.TrainStep(mc, mf, opts, {"LR_planes", "decoder"}, optimizer=opt, planes_optimizer=popt, grad_sync=sync,
+                                       pixel_sampler=device_sampler)
+    np.random.seed(rank)
+    it = [0]
+
+    def one():
+        # the random draws of the train mode come from the device generator here: the reference draws them on the host, which on
+        # this box costs more than the whole GPU step
+        rnd = dict(t_rand=torch.rand(N, Nc, device=dev, generator=g), u=torch.rand(N, Nf, device=dev, generator=g),
+                   noise_coarse=0.2 * torch.randn(N, Nc, device=dev, generator=g), noise_fine=0.2 * torch.randn(N, Nc + Nf, device=dev, generator=g))
+        step(it[0], target, pose, H, W, focal, 1, sid, scfg, N, randoms=rnd)
+        it[0] += 1
+
+    elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
+    value = world * N * args.steps / elapsed
+    result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, planes + decoder gradients, Adam)", "value": value,
+              "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
+                                     "what = [LR_planes, decoder], Adam", "rays_per_step_per_gpu": N,
+                         "parallelism": "rays sharded by rank; one bucketed all-reduce of plane + decoder gradients per step"}}
+    if rank == 0:
+        # dominant kernel: backward of the fine pass (forward recompute + data gradient + record), S = 128
+        batch = torch.stack(nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, torch.randint(0, H, (N, 2), device=dev)), 0)
+        out = nvsr_amd.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        sv = out[3].grad_fn.saved
+        S = Nc + Nf
+        rays = nvsr_amd.train_utils.pack_rays(batch[0], batch[1], 2.0, 6.0)
+        g_raw = torch.randn(N, S, 4, device=dev) * 1e-3
+        sc, keep = mf.native_scene()
+        gpl = [torch.zeros_like(k) for k in keep]
+        gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
+        rec = torch.empty(capi.lib().nvsr_decoder_record_floats(N, S), device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in ev:
+            a.record()
+            capi.call("nvsr_render_pass_backward_ex", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
+                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), gptrs, capi.ptr(rec), capi.stream())
+            b.record()
+        torch.cuda.synchronize()
+        dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+        flops = 2 * FLOP_PER_EVAL * N * S          # forward recompute + transposed layers (the weight gradient is a separate kernel)
+        ach = flops / dt / 1e12
+        result["roofline"] = {"kernel": "render_pass_backward_kernel<record> (fine pass, S=128)", "bound": "mfma", "achieved": ach,
+                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                              "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.oracle import Oracle, decoder_blob
+            o = Oracle(f32=False)
+            pl = [mc.planes_[nvsr_amd.models.get_plane_name(sid, d)].detach().cpu().numpy() for d in range(4)]
+            osc = o.scene(pl, mc.box_coords[sid].numpy())
+            dc = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
+            df = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
+            n = 48
+            rn = rays[:n].cpu().numpy()
+            gg = np.full((n, 3), 1e-3, np.float32)
+            t0 = time.perf_counter()
+            o.render_rays(osc, dc, df, rn, Nc, Nf)
+            o.render_backward_decoder(osc, dc, df, rn, Nc, Nf, gg, gg)
+            t = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": n / t, "unit": "rays/s", "cores": 1, "kind": "port",
+                                      "sample": "%d rays of the same step (forward + analytic backward incl. decoder gradients), %.1f s, C "
+                                                "oracle, double accumulation, single thread" % (n, t)}
+        print(json.dumps(result), flush=True)
+
+
+def bench_sr(args, nvsr_amd, dist, dev, rank, world):
+    """3 planes 48 x 200^2 -> 48 x 800^2 through PlanesSR(EDSR hidden 256, 32 blocks, x4), one batched pass"""
+    torch.manual_seed(0)
+    M = nvsr_amd.models
+    sr = M.PlanesSR(M.EDSR, 4, 48, 48, {"model": {"hidden_size": 256, "n_blocks": 32}}, "bilinear").to(dev)
+    sr.eval()
+    names = ["p0", "p1", "p2"]
+    for n in names:
+        sr.set_LR_plane(torch.randn(1, 48, 200, 200, device=dev) * 0.5, id=n, save_interpolated=False)
+    flop_scene = 3 * 6.74e12                        # SURVEY.md 8a (a11)
+
+    def one():
+        sr.clear_SR_planes()
+        with torch.no_grad():
+            sr.super_resolve_many(names)
+
+    elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
+    value = world * 3 * args.steps / elapsed
+    result = {"metric": "super-resolved feature planes/sec (48ch 200^2 -> 800^2, EDSR hidden 256 x 32 blocks)", "value": value, "unit": "planes/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "PlanesSR full-plane pass over the 3 position planes of one scene (batched), LR 200^2 + 68 px replicate "
+                                     "padding -> HR 800^2", "planes_per_step_per_gpu": 3, "parallelism": "replicas only"}}
+    if rank == 0:
+        ach = flop_scene / (elapsed / args.steps) / 1e12
+        result["roofline"] = {"kernel": "conv3x3_kernel (70 launches per step)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                              "algorithmic_flop_per_step": flop_scene}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.oracle import Oracle
+            o = Oracle(f32=True)
+            x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
+            w = np.random.default_rng(1).standard_normal((256, 256, 3, 3), dtype=np.float32) * 0.01
+            o.conv3x3(x[:, :10, :10], w)
+            t0 = time.perf_counter()
+            o.conv3x3(x, w)
+            t = time.perf_counter() - t0
+            fl = 2 * 256 * 256 * 9 * 64 * 64
+            cores = os.cpu_count() or 1
+            result["cpu_baseline"] = {"value": (fl / t) / (flop_scene / 3), "unit": "planes/s", "cores": cores, "kind": "port",
+                                      "sample": "one 256->256 3x3 conv on a 66x66 tile (%.2f GFLOP, %.2f s, C oracle fp32 OpenMP %d threads), "
+                                                "scaled by FLOPs to a whole plane" % (fl / 1e9, t, cores)}
+        print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["render", "train", "sr"], default="render")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -166,6 +333,13 @@ def main():
 
     import nvsr_amd
     nvsr_amd.capi.lib()  # fail loudly if the HIP library is not built
+
+    if args.workload != "render":
+        (bench_train if args.workload == "train" else bench_sr)(args, nvsr_amd, dist, dev, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     H = W = args.res
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)

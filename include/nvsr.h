@@ -197,7 +197,7 @@ int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decod
  * torch.autograd's addmm backward (dW = delta^T @ input, db = sum delta) through models.py:169-195,395-421 becomes two calls:
  * the backward pass additionally RECORDS every layer's input and pre-activation gradient, then one contraction over all points
  * adds the weight / bias gradients into a blob in the natural (state-dict) order of nvsr_pack_decoder. */
-/* floats of the record workspace of one pass (9.2 KB per point; N rounded up to 256 rays) */
+/* floats of the record workspace of one pass (9.2 KB per point; N rounded up to 128 rays) */
 int64_t nvsr_decoder_record_floats(int64_t N, int S);
 /* nvsr_render_pass_backward with optional outputs: grad_planes may be NULL (planes frozen) or hold NULL entries (that plane
  * frozen); record may be NULL (decoder frozen) or a workspace of nvsr_decoder_record_floats(N, S) floats, fully overwritten */

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, lo
     const int per_wave = slab / 4;                                   // even (host guarantees slab % 8 == 0)
     long q0 = (long)blockIdx.x * slab + (long)wave * per_wave;
     long q1 = q0 + per_wave;
-    if (q1 > Pp) q1 = Pp;                                            // Pp is a multiple of 256: the range stays even
+    if (q1 > Pp) q1 = Pp;                                            // Pp is a multiple of 128: the range stays even
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)

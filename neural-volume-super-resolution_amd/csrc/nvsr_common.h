@@ -75,7 +75,7 @@ inline SceneDev to_dev(const nvsr_scene* s) {
 }
 
 // ---- activation / delta record of one backward pass (decoder-weight gradients) -------------------------------------------
-// Rows are "slots": slot q = tile * 256 + wave * 32 + (lane & 31) of render_pass_backward_kernel; padding rays hold zeros in G*/g4.
+// Rows are "slots": slot q = tile * 128 + wave * 32 + (lane & 31) of render_pass_backward_kernel; padding rays hold zeros in G*/g4.
 //   Xd [Pp][64]   density-decoder input (mean of the 3 position features; columns 48..63 zero)
 //   Hd [4][Pp][128]  post-ReLU output of density layer l          Gd [4][Pp][128]  dL/d(pre-activation of density layer l)
 //   Xr [Pp][192]  rgb-decoder input [f0|f1|f2|f_view]              Hr, Gr likewise for the rgb decoder
@@ -85,7 +85,8 @@ struct DecRecord {
     long Pp;
 };
 constexpr long DEC_RECORD_FLOATS_PER_SLOT = 64 + 4 * HID + 4 * HID + 4 * C + 4 * HID + 4 * HID + 4;   // 2308
-inline long record_slots(long N, int S) { return ((N + 255) / 256) * (long)S * 256; }
+constexpr int RECORD_TILE = 128;          // points per workgroup tile of render_pass_backward_kernel
+inline long record_slots(long N, int S) { return ((N + RECORD_TILE - 1) / RECORD_TILE) * (long)S * RECORD_TILE; }
 inline DecRecord make_record(float* base, long Pp) {
     DecRecord r;
     r.Pp = Pp;

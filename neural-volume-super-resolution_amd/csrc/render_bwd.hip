@@ -16,7 +16,10 @@
 
 namespace nvsr {
 
-constexpr int BTPB = 512;                 // 8 waves: 2 per SIMD, one workgroup per CU (137 KB of LDS)
+// 4 waves = ONE per SIMD: the step keeps ~430 registers live (two accumulator sets, features, 8 ReLU masks, the density branch's
+// input gradient while the rgb branch runs); at two waves per SIMD (256 registers) 160-190 of them spilled, and every spill reload is
+// a vector-memory access that queues behind the weight DMA in flight
+constexpr int BTPB = 256;
 constexpr int BNW = BTPB / 64;
 constexpr int BPTS = BNW * 32;
 constexpr int RAYB_FLOATS = 16;
@@ -172,7 +175,7 @@ __device__ __forceinline__ void record24(float* __restrict__ row, int h, const f
 
 // =====================================================================================================================
 template <bool RECORD>
-__global__ __launch_bounds__(BTPB, 2) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
+__global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                       const float* __restrict__ packed_bwd, long N, int S,
                                                                       const float* __restrict__ rays, const float* __restrict__ z,
                                                                       const float* __restrict__ g_raw, GradPlanes gp, DecRecord rec) {
@@ -486,7 +489,7 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    static_assert(BPTS == 256, "record slots are laid out for 256-point tiles");
+    static_assert(BPTS == RECORD_TILE, "record slots are laid out per tile of the backward kernel");
     const int64_t ntiles = ((N + BPTS - 1) / BPTS) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
     if (record) {

@@ -5,6 +5,7 @@ and state-dict keys, so checkpoints and the `PlanesOptimizer`-style wiring of th
 fused gather + MFMA decoder kernel (csrc/render.hip) on channel-last copies of the planes and a fragment-packed copy of the
 weights, both cached and refreshed when the source tensors change."""
 import ctypes as C
+import weakref
 from re import search
 
 import numpy as np
@@ -276,12 +277,13 @@ class TwoDimPlanesModel(nn.Module):
 
     def channel_last_plane(self, dim_num):
         name, src = self._plane_source(dim_num)
-        key = (src.data_ptr(), src._version, tuple(src.shape))
+        # keyed on the source tensor OBJECT (weakly) + its version counter: a data pointer is not an identity -- the allocator hands
+        # the address of a dropped super-resolved plane to the next one
         hit = _PLANE_CACHE.get(name)
-        if hit is None or hit[0] != key:
-            hit = (key, to_channel_last(src.detach()))
+        if hit is None or hit[0]() is not src or hit[1] != src._version:
+            hit = (weakref.ref(src), src._version, to_channel_last(src.detach()))
             _PLANE_CACHE[name] = hit
-        return hit[1]
+        return hit[2]
 
     def training_planes(self, rays):
         """The NCHW tensors a training step samples, as autograd sees them: the raw plane parameters, or -- where a plane is

@@ -93,7 +93,7 @@ class TrainStep:
 
     def __init__(self, model_coarse, model_fine, options, what2train, optimizer=None, SR_optimizer=None, planes_optimizer=None, SR_model=None,
                  virtual_batch_size=1, rendering_loss_w=1.0, im_inconsistency_loss_w=None, sr_loss="both", ds_factor=1,
-                 separate_decoder_sr=False, grad_sync=None):
+                 separate_decoder_sr=False, grad_sync=None, pixel_sampler=None):
         self.mc, self.mf, self.options = model_coarse, model_fine, options
         self.what = set(what2train)
         self.optimizer, self.SR_optimizer, self.planes_optimizer, self.SR_model = optimizer, SR_optimizer, planes_optimizer, SR_model
@@ -101,6 +101,7 @@ class TrainStep:
         self.rendering_loss_w, self.im_inconsistency_loss_w = rendering_loss_w, im_inconsistency_loss_w
         self.sr_loss, self.ds_factor, self.separate_decoder_sr = sr_loss, int(ds_factor), separate_decoder_sr
         self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
+        self.pixel_sampler = pixel_sampler or select_training_pixels   # (img_target, num_random_rays, consistency_ds) -> (rows_cols, target_s)
 
     def __call__(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
                  im_consistency_iter=False, confinements=(), randoms=None):
@@ -113,7 +114,7 @@ class TrainStep:
                 self.mf.train()
         if im_consistency_iter:      # render in HR although the target image is LR (:806-811)
             H, W, focal, cur_ds_factor = H * self.ds_factor, W * self.ds_factor, focal * self.ds_factor, cur_ds_factor // self.ds_factor
-        sel, target_s = select_training_pixels(img_target, num_random_rays, self.ds_factor if im_consistency_iter else None)
+        sel, target_s = self.pixel_sampler(img_target, num_random_rays, self.ds_factor if im_consistency_iter else None)
         ro, rd = get_ray_bundle_at(H, W, focal, pose_target, sel, downsampling_offset=downsampling_offset(cur_ds_factor))
         batch_rays = torch.stack([ro, rd], 0)
         if first_v:

@@ -792,7 +792,7 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
     old = hip.train_utils.RECORD_RAYS
     try:
         results = []
-        for rec_rays in (old, 256):                      # one launch, then three ray blocks (256 + 256 + 188) through the record
+        for rec_rays in (old, 256):                      # one launch, then three ray blocks (256 + 256 + 188 rays) through the record
             hip.train_utils.RECORD_RAYS = rec_rays
             for m in (mc, mf):
                 m.zero_grad(set_to_none=True)
@@ -822,9 +822,9 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
 def test_decoder_weight_grad_contraction(hip):
     """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI"""
     capi = hip.capi
-    N, S = 300, 7                                        # 2 ray tiles x 7 samples = 3584 slots
+    N, S = 300, 7                                        # 3 ray tiles of 128 x 7 samples = 2688 slots
     n = capi.lib().nvsr_decoder_record_floats(N, S)
-    Pp = 2 * S * 256
+    Pp = 3 * S * 128
     assert n == Pp * 2308
     g_ = torch.Generator(device="cpu").manual_seed(5)
     rec = torch.randn(n, generator=g_, dtype=torch.float32)
@@ -849,7 +849,7 @@ def test_decoder_weight_grad_contraction(hip):
         parts += [(head.T @ H[3]).ravel(), head.sum(0)]
     ref = np.concatenate(parts)
     assert ref.size == got.size
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(Pp))     # sums of 3584 N(0,1) products in fp32
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(Pp))     # sums of 2688 N(0,1) products in fp32
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
 
 
