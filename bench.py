@@ -230,11 +230,12 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         gpl = [torch.zeros_like(k) for k in keep]
         gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
         rec = torch.empty(capi.lib().nvsr_decoder_record_floats(N, S), device=dev)
+        vws = torch.empty(capi.lib().nvsr_view_grad_workspace_floats(N, S), device=dev)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         for a, b in ev:
             a.record()
             capi.call("nvsr_render_pass_backward_ex", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
-                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), gptrs, capi.ptr(rec), capi.stream())
+                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), gptrs, capi.ptr(rec), capi.ptr(vws), capi.stream())
             b.record()
         torch.cuda.synchronize()
         dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3

@@ -193,6 +193,14 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
 int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                               const float* rays, const float* z, const float* g_raw, float* const* grad_planes, nvsr_stream_t stream);
 
+/* Faster path when the decoder is frozen: the training forward publishes every layer's ReLU gate (gates: N*S*32 uint32, 128 B
+ * per point) and the backward runs the transposed layers only, without recomputing the forward. */
+int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                        float* raw, uint32_t* gates /* or NULL */, nvsr_stream_t stream);
+int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                    const float* rays, const float* z, const float* g_raw, const uint32_t* gates, float* const* grad_planes,
+                                    float* view_ws /* or NULL, see below */, nvsr_stream_t stream);
+
 /* ---- training: gradient with respect to the decoder parameters ('decoder' in nerf.train.what, train_nerf.py:75-77) ------
  * torch.autograd's addmm backward (dW = delta^T @ input, db = sum delta) through models.py:169-195,395-421 becomes two calls:
  * the backward pass additionally RECORDS every layer's input and pre-activation gradient, then one contraction over all points
@@ -203,7 +211,11 @@ int64_t nvsr_decoder_record_floats(int64_t N, int S);
  * frozen); record may be NULL (decoder frozen) or a workspace of nvsr_decoder_record_floats(N, S) floats, fully overwritten */
 int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                  const float* rays, const float* z, const float* g_raw, float* const* grad_planes, float* record,
-                                 nvsr_stream_t stream);
+                                 float* view_ws, nvsr_stream_t stream);
+/* view_ws (optional, nvsr_view_grad_workspace_floats(N, S) = N*S*48 floats): all samples of a ray hit the same 4 texels of the small
+ * view-direction plane; with the workspace their gradients are first written as plain rows and summed per ray, and only N*4*48
+ * atomics reach the plane (without it: N*S*4*48 atomics on 1 024 texels -- correct but 2x slower overall). */
+int64_t nvsr_view_grad_workspace_floats(int64_t N, int S);
 /* grad_natural [NVSR_DECODER_NATURAL_FLOATS] += gradient of this pass (float atomics: zero it before the first pass) */
 int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, float* grad_natural, nvsr_stream_t stream);
 

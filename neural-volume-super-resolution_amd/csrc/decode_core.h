@@ -127,6 +127,23 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
 }
 
+// ReLU that also publishes its gate: bit (ib&1)*16 + r of word ib>>1  <=>  acc[ib][r] > 0.  The two words go straight to global
+// memory (slot `layer` of the lane's 16-word record), so nothing stays live for them.
+__device__ __forceinline__ void relu_publish(f32x16 (&acc)[4], unsigned* __restrict__ rec, int layer) {
+    unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool on = acc[ib][r] > 0.0f;
+            acc[ib][r] = on ? acc[ib][r] : 0.0f;
+            if (ib < 2) m0 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            else m1 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+        }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};
+}
+
 // MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
 // wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
 // ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every
@@ -199,9 +216,11 @@ __device__ __forceinline__ const float* ring_issue(RingState& rs, int packed_off
 // vt: bilinear taps on the view-direction plane.  Must be called by all waves of the workgroup together (ring barriers).
 // No DMA is outstanding on entry or on exit.
 // Chunk order: RGB0.p0..p3, RGB1..3 (two halves each), DEN0, DEN1..3 (two halves each).
-template <int NWAVES>
+// MASKS: additionally write the 8 layers' ReLU gates to `gates` (this lane's 16 words: density layers 0..3, rgb layers 0..3) for
+// the mask-driven backward kernel, which then does not have to recompute the forward.
+template <int NWAVES, bool MASKS = false>
 __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, float px, float py, float pz, const Taps& vt,
-                                            float (&raw)[4]) {
+                                            float (&raw)[4], unsigned* __restrict__ gates = nullptr) {
     // Re-derive the per-lane address registers every step: left loop-invariant, hipcc hoists one 64-bit address per
     // DMA / LDS read out of the sample loop and spills them all.
     asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
@@ -261,7 +280,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1);
     gather24(sc.plane[3], vt, h, F);
     feat_layer(cur, F, lane, accA);
-    relu_inplace(accA);
+    if (MASKS) relu_publish(accA, gates, 4); else relu_inplace(accA);
     cur = nxt;
     // ---- rgb decoder layers 1..3 -> 3 ---------------------------------------------------------------------------------
     ring_sync();
@@ -282,7 +301,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 2 * HH);
     hidden_half<1>(cur, accA, lane, accB);
-    relu_inplace(accB);
+    if (MASKS) relu_publish(accB, gates, 5); else relu_inplace(accB);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 3 * HH);
@@ -292,7 +311,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 4 * HH);
     hidden_half<1>(cur, accB, lane, accA);
-    relu_inplace(accA);
+    if (MASKS) relu_publish(accA, gates, 6); else relu_inplace(accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 5 * HH);
@@ -302,7 +321,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     nxt = ring_issue<NWAVES, 24>(rs, P_DEN0);
     hidden_half<1>(cur, accA, lane, accB);
-    relu_inplace(accB);
+    if (MASKS) relu_publish(accB, gates, 7); else relu_inplace(accB);
 #if NVSR_ABLATE & 64
     const float stamp = raw[0];
 #endif
@@ -317,7 +336,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1);
     load_bias(small + S_BIAS + 0 * HID, h, accA);
     feat_layer(cur, D, lane, accA);
-    relu_inplace(accA);
+    if (MASKS) relu_publish(accA, gates, 0); else relu_inplace(accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + HH);
@@ -327,7 +346,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 2 * HH);
     hidden_half<1>(cur, accA, lane, accB);
-    relu_inplace(accB);
+    if (MASKS) relu_publish(accB, gates, 1); else relu_inplace(accB);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 3 * HH);
@@ -337,7 +356,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 4 * HH);
     hidden_half<1>(cur, accB, lane, accA);
-    relu_inplace(accA);
+    if (MASKS) relu_publish(accA, gates, 2); else relu_inplace(accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 5 * HH);
@@ -346,7 +365,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     cur = nxt;
     ring_sync();
     hidden_half<1>(cur, accA, lane, accB);
-    relu_inplace(accB);
+    if (MASKS) relu_publish(accB, gates, 3); else relu_inplace(accB);
     raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
 }
 

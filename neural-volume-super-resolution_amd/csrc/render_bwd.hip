@@ -154,6 +154,29 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
     __builtin_amdgcn_wave_barrier();
 }
 
+// View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
+// address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
+// gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.
+__device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* tile, float* __restrict__ gview, long ray_w0, long N, int S,
+                                                int s, int lane) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < C) {
+        for (int p = 0; p < 32; ++p)
+            if (ray_w0 + p < N) gview[((ray_w0 + p) * S + s) * C + lane] = tile[p * C + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct GradPlanes { float* p[4]; };
 
 // record helpers: one accumulator set (128 features x 32 points, C/D layout) -> rows [slot][128]; 32 B per lane pair and store,
@@ -178,7 +201,8 @@ template <bool RECORD>
 __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                       const float* __restrict__ packed_bwd, long N, int S,
                                                                       const float* __restrict__ rays, const float* __restrict__ z,
-                                                                      const float* __restrict__ g_raw, GradPlanes gp, DecRecord rec) {
+                                                                      const float* __restrict__ g_raw, GradPlanes gp, DecRecord rec,
+                                                                      float* __restrict__ gview) {
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<BNW>(rs);
@@ -362,13 +386,157 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
             layer0_T(cur, accB, lane, gF);
             cur = nxt;
             if (gp.p[d]) {                                            // (wave-uniform) planes frozen: nothing to scatter
-                const Taps t = (d < 3) ? pos_taps(d) : vt;
-                scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+                if (d == 3 && gview) {
+                    store_view_rows(gF, tile, gview, rb * BPTS + rs.wave * 32, N, S, s, lane);
+                } else {
+                    const Taps t = (d < 3) ? pos_taps(d) : vt;
+                    scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+                }
             }
         }
         rs.packed = packed;
     }
     ring_sync();
+}
+
+// =====================================================================================================================
+// Mask-driven variant: the training forward (decode_rays_kernel<true>) has already published every layer's ReLU gate, so this
+// kernel runs the transposed layers only (2 176 MFMAs per tile instead of 4 192) and its live state -- two accumulator sets, 16
+// gate words, the density branch's input gradient -- fits 256 registers: 8-wave workgroups, two waves per SIMD.
+// Used when the decoder is frozen (what: ['LR_planes'], Feature_Planes_Only.yml); decoder gradients need the record above.
+// =====================================================================================================================
+constexpr int MTPB = 512, MNW = MTPB / 64, MPTS = MNW * 32;
+constexpr int MBWD_LDS_FLOATS = LDS_FLOATS + MNW * TILE_FLOATS;
+static_assert(MBWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+__global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(SceneDev sc, const float* __restrict__ packed,
+                                                                            const float* __restrict__ packed_bwd, long N, int S,
+                                                                            const float* __restrict__ rays, const float* __restrict__ z,
+                                                                            const float* __restrict__ g_raw,
+                                                                            const unsigned* __restrict__ gates, GradPlanes gp,
+                                                                            float* __restrict__ gview) {
+    __shared__ __attribute__((aligned(16))) float lds[MBWD_LDS_FLOATS];
+    RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    decode_prologue<MNW>(rs);                    // head weights / biases of the FORWARD blob -> LDS
+    rs.packed = packed_bwd;
+    float* tile = lds + LDS_FLOATS + rs.wave * TILE_FLOATS;
+    const float* small = lds + 2 * SLOT_FLOATS;
+    const long nrb = (N + MPTS - 1) / MPTS;
+    const long ntiles = nrb * S;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+        const int lane = rs.lane, h = lane >> 5;
+        const long rb = tix / S;
+        const int s = (int)(tix - rb * S);
+        const long ray0 = rb * MPTS + rs.wave * 32 + (lane & 31);
+        const bool valid = ray0 < N;
+        const long ray = valid ? ray0 : N - 1;
+        const float* cur = ring_issue<MNW, 32>(rs, B_DEN_H);
+        const float* r = rays + ray * 11;
+        const float zc = z[ray * S + s];
+        f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const u32x4* gk = reinterpret_cast<const u32x4*>(gates + ((ray * S + s) * 2 + h) * 16);
+        const u32x4 k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3];
+        const Masks md[4] = {{{k0[0], k0[1]}}, {{k0[2], k0[3]}}, {{k1[0], k1[1]}}, {{k1[2], k1[3]}}};
+        const Masks mr[4] = {{{k2[0], k2[1]}}, {{k2[2], k2[3]}}, {{k3[0], k3[1]}}, {{k3[2], k3[3]}}};
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        const float n0 = norm_coord(__fadd_rn(r[0], __fmul_rn(r[3], zc)), sc.lo[0], sc.range[0]);
+        const float n1 = norm_coord(__fadd_rn(r[1], __fmul_rn(r[4], zc)), sc.lo[1], sc.range[1]);
+        const float n2 = norm_coord(__fadd_rn(r[2], __fmul_rn(r[5], zc)), sc.lo[2], sc.range[2]);
+        auto pos_taps = [&](int d) {
+            const float* M = sc.proj + 6 * d;
+            return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        };
+        f32x16 accA[4], accB[4];
+        const float* nxt;
+        // ---- density branch -> gD
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(small + S_ALPHA_W + (ib * 4 + q) * 8 + h * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
+            }
+        apply_mask(md[3], accA);
+        hidden_T<MNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
+        hidden_T<MNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
+        hidden_T<MNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
+        f32x16 gD[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = 0.0f;
+        ring_sync();
+        nxt = ring_issue<MNW, 32>(rs, B_RGB_H);
+        layer0_T(cur, accB, lane, gD);
+        cur = nxt;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);
+        // ---- rgb branch
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = (ib * 4 + q) * 8 + h * 4;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + o);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + HID + o);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + 2 * HID + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
+            }
+        apply_mask(mr[3], accA);
+        hidden_T<MNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
+        hidden_T<MNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
+        hidden_T<MNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f32x16 gF[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? gD[b][rr] : 0.0f;
+            ring_sync();
+            if (d < 3) nxt = ring_issue<MNW, 32>(rs, B_RGB0 + (d + 1) * 8192);
+            layer0_T(cur, accB, lane, gF);
+            cur = nxt;
+            if (gp.p[d]) {
+                if (d == 3 && gview) {
+                    store_view_rows(gF, tile, gview, rb * MPTS + rs.wave * 32, N, S, s, lane);
+                } else {
+                    const Taps t = (d < 3) ? pos_taps(d) : vt;
+                    scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+                }
+            }
+        }
+    }
+    ring_sync();
+}
+
+// one wave per ray: sum the ray's S gradient rows, then 4 taps x 48 channels of atomics into the view-direction plane
+__global__ __launch_bounds__(256) void view_reduce_scatter_kernel(SceneDev sc, long N, int S, const float* __restrict__ rays,
+                                                                  const float* __restrict__ gview, float* __restrict__ gplane) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + wave;
+    if (ray >= N) return;
+    const float* r = rays + ray * 11;
+    const Taps t = view_taps(sc, r[8], r[9], r[10]);
+    if (lane >= C) return;
+    const float* row = gview + ray * S * C + lane;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) { a0 += row[s * C]; a1 += row[(s + 1) * C]; a2 += row[(s + 2) * C]; a3 += row[(s + 3) * C]; }
+    for (; s < S; ++s) a0 += row[s * C];
+    const float v = (a0 + a1) + (a2 + a3);
+    unsafeAtomicAdd(gplane + t.o00 + lane, v * t.nw);
+    unsafeAtomicAdd(gplane + t.o01 + lane, v * t.ne);
+    unsafeAtomicAdd(gplane + t.o10 + lane, v * t.sw);
+    unsafeAtomicAdd(gplane + t.o11 + lane, v * t.se);
 }
 
 // =====================================================================================================================
@@ -474,9 +642,18 @@ int64_t nvsr_decoder_record_floats(int64_t N, int S) {
     return record_slots((long)N, S) * DEC_RECORD_FLOATS_PER_SLOT;
 }
 
+static int launch_view_reduce(const nvsr_scene* scene, int64_t N, int S, const float* rays, const float* view_ws, float* gplane,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(view_reduce_scatter_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, to_dev(scene), (long)N, S, rays, view_ws,
+                       gplane);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int64_t nvsr_view_grad_workspace_floats(int64_t N, int S) { return (N < 0 || S < 1) ? 0 : N * (int64_t)S * C; }
+
 int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                  const float* rays, const float* z, const float* g_raw, float* const* grad_planes, float* record,
-                                 nvsr_stream_t stream) {
+                                 float* view_ws, nvsr_stream_t stream) {
     if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw) return NVSR_ERR_NULL;
     if (!grad_planes && !record) return NVSR_ERR_NULL;
     GradPlanes gp;
@@ -495,12 +672,36 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
     if (record) {
         const DecRecord rec = make_record(record, record_slots((long)N, S));
         hipLaunchKernelGGL(render_pass_backward_kernel<true>, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene),
-                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, rec);
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, rec, view_ws);
     } else {
         hipLaunchKernelGGL(render_pass_backward_kernel<false>, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene),
-                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, DecRecord{});
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, DecRecord{}, view_ws);
     }
-    return NVSR_CHECK_LAUNCH();
+    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);
+    return NVSR_OK;
+}
+
+int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                    const float* rays, const float* z, const float* g_raw, const uint32_t* gates, float* const* grad_planes,
+                                    float* view_ws, nvsr_stream_t stream) {
+    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !gates || !grad_planes) return NVSR_ERR_NULL;
+    GradPlanes gp;
+    for (int d = 0; d < 4; ++d) {
+        if (!scene->planes[d]) return NVSR_ERR_NULL;
+        if (scene->ph[d] < 1 || scene->pw[d] < 1) return NVSR_ERR_SHAPE;
+        gp.p[d] = grad_planes[d];
+    }
+    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    const int64_t ntiles = ((N + MPTS - 1) / MPTS) * S;
+    const int64_t grid = ntiles < 1024 ? ntiles : 1024;
+    hipLaunchKernelGGL(render_pass_backward_gates_kernel, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
+                       packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws);
+    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);
+    return NVSR_OK;
 }
 
 int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
@@ -508,7 +709,7 @@ int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decod
     if (!grad_planes) return NVSR_ERR_NULL;
     for (int d = 0; d < 4; ++d)
         if (!grad_planes[d]) return NVSR_ERR_NULL;
-    return nvsr_render_pass_backward_ex(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, grad_planes, nullptr, stream);
+    return nvsr_render_pass_backward_ex(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, grad_planes, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -70,21 +70,25 @@ class _RenderRaysFn(torch.autograd.Function):
         capi_.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), cfg["lindisp"], capi.ptr(cfg["t_rand"]), capi.ptr(z_c), st)
         # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip,
         # the fused per-ray kernel would run 32 workgroups; raw is needed by the backward anyway
-        capi_.call("nvsr_decode_rays", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(raw_c), st)
+        # decoder frozen: the forward publishes its ReLU gates (128 B per point) and the backward skips the recomputation
+        gates_c = None if cfg["dec_c_grad"] else torch.empty((N, Nc, 32), dtype=torch.int32, device=dev)
+        capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(raw_c),
+                   capi.ptr(gates_c), st)
         capi_.call("nvsr_composite_rays", N, Nc, capi.ptr(raw_c), capi.ptr(z_c), capi.ptr(rays), capi.ptr(cfg["noise_c"]), cfg["white"],
                    capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None, st)
         outs = [rgb_c, disp_c, acc_c]
-        saved = dict(z_c=z_c, raw_c=raw_c)
+        saved = dict(z_c=z_c, raw_c=raw_c, gates_c=gates_c)
         if Nf > 0:
             z_f, raw_f = f(N, Nc + Nf), f(N, Nc + Nf, 4)
             rgb_f, disp_f, acc_f = f(N, 3), f(N), f(N)
             capi_.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(cfg["u"]), capi.ptr(z_f), st)
-            capi_.call("nvsr_decode_rays", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
-                       capi.ptr(raw_f), st)
+            gates_f = None if cfg["dec_f_grad"] else torch.empty((N, Nc + Nf, 32), dtype=torch.int32, device=dev)
+            capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
+                       capi.ptr(raw_f), capi.ptr(gates_f), st)
             capi_.call("nvsr_composite_rays", N, Nc + Nf, capi.ptr(raw_f), capi.ptr(z_f), capi.ptr(rays), capi.ptr(cfg["noise_f"]), cfg["white"],
                        capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None, st)
             outs += [rgb_f, disp_f, acc_f]
-            saved.update(z_f=z_f, raw_f=raw_f)
+            saved.update(z_f=z_f, raw_f=raw_f, gates_f=gates_f)
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
         ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 == 1])    # disparity: no gradient path implemented
         return tuple(outs)
@@ -102,7 +106,7 @@ class _RenderRaysFn(torch.autograd.Function):
         gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if need[5] else None
         gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if (need[6] and Nf > 0) else None
 
-        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec):
+        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec, gates):
             if (g_rgb is None and g_acc is None) or (gptrs is None and gdec is None):
                 return
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
@@ -110,23 +114,30 @@ class _RenderRaysFn(torch.autograd.Function):
             g_raw = torch.empty((N, S, 4), dtype=torch.float32, device=dev)
             capi.call("nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), cfg["white"],
                       capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), st)
+            # per-point rows of the view-direction plane's gradient (summed per ray before they touch the plane)
+            view_ws = torch.empty(N * S * capi.PLANE_CHANNELS, dtype=torch.float32, device=dev) if (gptrs is not None and need[4]) else None
             if gdec is None:
-                capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                          capi.ptr(z), capi.ptr(g_raw), gptrs, None, st)
+                if gates is not None:
+                    capi.call("nvsr_render_pass_backward_gates", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
+                              capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), st)
+                else:
+                    capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
+                              capi.ptr(z), capi.ptr(g_raw), gptrs, None, capi.ptr(view_ws), st)
                 return
             step = min(N, RECORD_RAYS)
             record = torch.empty(capi.lib().nvsr_decoder_record_floats(step, S), dtype=torch.float32, device=dev)
             for a in range(0, N, step):
                 n = min(step, N - a)
                 capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), n, S, capi.ptr(rays[a:]),
-                          capi.ptr(z[a:]), capi.ptr(g_raw[a:]), gptrs, capi.ptr(record), st)
+                          capi.ptr(z[a:]), capi.ptr(g_raw[a:]), gptrs, capi.ptr(record), capi.ptr(view_ws), st)
                 capi.call("nvsr_decoder_weight_grad", n, S, capi.ptr(record), capi.ptr(gdec), st)
 
         if cfg["coarse_grad"]:
-            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2], gdec_c)
+            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2], gdec_c,
+                     sv["gates_c"])
         if Nf > 0:
             one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
-                     gdec_f)
+                     gdec_f, sv["gates_f"])
         out = [None]
         for g in gplanes:
             out.append(None if g is None else models.from_channel_last(g))    # back to the reference's [1,C,H,W]
@@ -213,7 +224,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=int(bool(m.lindisp)), white=int(bool(m.white_background)), t_rand=t_rand, u=u,
                    noise_c=n_c, noise_f=n_f, scene_c=sc_c, scene_f=sc_f, keep=(keep_c, keep_f), packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
-                   plane_shapes=[tuple(k.shape) for k in keep_f], coarse_grad=coarse_grad)
+                   plane_shapes=[tuple(k.shape) for k in keep_f], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad, dec_f_grad=dec_f_grad)
         outs = _RenderRaysFn.apply(cfg, *leaves)
         if Nf > 0:
             return outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], None, None, None

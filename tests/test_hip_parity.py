@@ -819,6 +819,36 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
 
 
+def test_plane_gradients_gate_path_equals_recompute_path(hip):
+    """with the decoder frozen the backward is driven by the ReLU gates the forward published; with the decoder trained it
+    recomputes the forward: the plane gradients of the two kernels agree to float-atomic summation order"""
+    g = load_golden("g11_grads.npz")
+    rng = np.random.default_rng(91)
+    planes = [rng.standard_normal((1, 48, 40, 56), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 12, 12), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes40_12"
+    N, nc, nf = 700, 40, 56                                  # 700 rays: partial 256-ray and 128-ray tiles
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    res = []
+    for what in (("planes",), ("planes", "decoder")):
+        mc, mf = _grad_models(hip, g, planes, sid, what=what)
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(load_golden("g08_render.npz")["pose"]))
+        sel = torch.from_numpy(np.random.default_rng(92).permutation(H * W)[:N]).to(DEV)
+        batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        opts, scfg = make_options(nc, nf, white=True)
+        out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        saved = out[3].grad_fn.saved
+        assert (saved["gates_f"] is not None) == (what == ("planes",))
+        gc = T(np.random.default_rng(93).standard_normal((N, 3)).astype(np.float32) / N)
+        gf = T(np.random.default_rng(94).standard_normal((N, 3)).astype(np.float32) / N)
+        ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+        res.append([N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad) for d in range(4)])
+    for d in range(4):
+        rel = np.linalg.norm(res[0][d] - res[1][d]) / np.linalg.norm(res[1][d])
+        assert rel < (1e-5 if d < 3 else 2e-4), "plane %d: gate path vs recompute path %.2e" % (d, rel)
+
+
 def test_decoder_weight_grad_contraction(hip):
     """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI"""
     capi = hip.capi
