@@ -219,7 +219,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
                                      "what = [LR_planes, decoder], Adam", "rays_per_step_per_gpu": N,
                          "parallelism": "rays sharded by rank; one bucketed all-reduce of plane + decoder gradients per step"}}
     if rank == 0:
-        # dominant kernel: backward of the fine pass (forward recompute + data gradient + record), S = 128
+        # dominant kernel: gate-driven backward of the fine pass (transposed layers + plane scatter + gradient half of the record), S = 128
         batch = torch.stack(nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, torch.randint(0, H, (N, 2), device=dev)), 0)
         out = nvsr_amd.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
         sv = out[3].grad_fn.saved
@@ -229,20 +229,20 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         sc, keep = mf.native_scene()
         gpl = [torch.zeros_like(k) for k in keep]
         gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
-        rec = torch.empty(capi.lib().nvsr_decoder_record_floats(N, S), device=dev)
         vws = torch.empty(capi.lib().nvsr_view_grad_workspace_floats(N, S), device=dev)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         for a, b in ev:
             a.record()
-            capi.call("nvsr_render_pass_backward_ex", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
-                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), gptrs, capi.ptr(rec), capi.ptr(vws), capi.stream())
+            capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
+                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), capi.ptr(sv["gates_f"]), gptrs, capi.ptr(vws), capi.ptr(sv["rec_f"]),
+                      capi.stream())
             b.record()
         torch.cuda.synchronize()
         dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
-        flops = 2 * FLOP_PER_EVAL * N * S          # forward recompute + transposed layers (the weight gradient is a separate kernel)
+        flops = 139264 * 2 * N * S                 # the transposed layers: 2 176 MFMAs of 32x32x2 per 32 points = 139 264 MAC per point
         ach = flops / dt / 1e12
-        result["roofline"] = {"kernel": "render_pass_backward_kernel<record> (fine pass, S=128)", "bound": "mfma", "achieved": ach,
-                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        result["roofline"] = {"kernel": "render_pass_backward_gates_kernel<record> (fine pass, S=128; incl. its view-plane reduce)", "bound": "mfma",
+                              "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle, decoder_blob

@@ -196,16 +196,18 @@ int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decod
 /* Faster path when the decoder is frozen: the training forward publishes every layer's ReLU gate (gates: N*S*32 uint32, 128 B
  * per point) and the backward runs the transposed layers only, without recomputing the forward. */
 int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
-                        float* raw, uint32_t* gates /* or NULL */, nvsr_stream_t stream);
+                        float* raw, uint32_t* gates /* or NULL */, float* record /* or NULL; needs gates */, nvsr_stream_t stream);
 int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                     const float* rays, const float* z, const float* g_raw, const uint32_t* gates, float* const* grad_planes,
-                                    float* view_ws /* or NULL, see below */, nvsr_stream_t stream);
+                                    float* view_ws /* or NULL, see below */, float* record /* or NULL */, nvsr_stream_t stream);
 
 /* ---- training: gradient with respect to the decoder parameters ('decoder' in nerf.train.what, train_nerf.py:75-77) ------
  * torch.autograd's addmm backward (dW = delta^T @ input, db = sum delta) through models.py:169-195,395-421 becomes two calls:
  * the backward pass additionally RECORDS every layer's input and pre-activation gradient, then one contraction over all points
  * adds the weight / bias gradients into a blob in the natural (state-dict) order of nvsr_pack_decoder. */
-/* floats of the record workspace of one pass (9.2 KB per point; N rounded up to 128 rays) */
+/* floats of the record workspace of one pass (9.2 KB per point, one row per point: row = s * N + ray).  The half that the forward
+ * layers produce (layer inputs) is written either by nvsr_decode_rays_ex(record) at forward time or by the recomputing
+ * nvsr_render_pass_backward_ex(record); the gradient half by whichever backward entry receives the record. */
 int64_t nvsr_decoder_record_floats(int64_t N, int S);
 /* nvsr_render_pass_backward with optional outputs: grad_planes may be NULL (planes frozen) or hold NULL entries (that plane
  * frozen); record may be NULL (decoder frozen) or a workspace of nvsr_decoder_record_floats(N, S) floats, fully overwritten */

@@ -144,6 +144,23 @@ __device__ __forceinline__ void relu_publish(f32x16 (&acc)[4], unsigned* __restr
     *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};
 }
 
+// record helpers: one accumulator set (128 features x 32 points, C/D layout) -> rows [row][128]; 32 B per lane pair and store, the
+// wave's 16 stores fill 32 complete 512-byte rows
+__device__ __forceinline__ void record128(float* __restrict__ base, long q, int h, const f32x16 (&a)[4]) {
+    float* row = base + q * HID + 4 * h;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
+}
+// a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[24h ..]
+__device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i)
+        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+}
+
 // MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
 // wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
 // ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every
@@ -218,9 +235,12 @@ __device__ __forceinline__ const float* ring_issue(RingState& rs, int packed_off
 // Chunk order: RGB0.p0..p3, RGB1..3 (two halves each), DEN0, DEN1..3 (two halves each).
 // MASKS: additionally write the 8 layers' ReLU gates to `gates` (this lane's 16 words: density layers 0..3, rgb layers 0..3) for
 // the mask-driven backward kernel, which then does not have to recompute the forward.
-template <int NWAVES, bool MASKS = false>
+// RECORD: additionally write the inputs of every layer (plane features, post-ReLU activations) to row q of `rec` (lanes with
+// rec_ok == false, i.e. padding rays, skip the stores) for the decoder weight gradient.
+template <int NWAVES, bool MASKS = false, bool RECORD = false>
 __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, float px, float py, float pz, const Taps& vt,
-                                            float (&raw)[4], unsigned* __restrict__ gates = nullptr) {
+                                            float (&raw)[4], unsigned* __restrict__ gates = nullptr, const DecRecord* rec = nullptr,
+                                            long q = 0, bool rec_ok = false) {
     // Re-derive the per-lane address registers every step: left loop-invariant, hipcc hoists one 64-bit address per
     // DMA / LDS read out of the sample loop and spills them all.
     asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
@@ -246,6 +266,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
         const Taps t = make_taps(sc, 0, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[0], t, h, F);
     }
+    if (RECORD && rec_ok) record24(rec->Xr + q * (4 * C), h, F);
     ring_sync();
     const float* nxt = ring_issue<NWAVES, 24>(rs, P_RGB0 + P_PLANE_FLOATS);
     load_bias(small + S_BIAS + 4 * HID, h, accA);
@@ -260,6 +281,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
         const Taps t = make_taps(sc, 1, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[1], t, h, F);
     }
+    if (RECORD && rec_ok) record24(rec->Xr + q * (4 * C) + C, h, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
     feat_layer(cur, F, lane, accA);
@@ -271,16 +293,24 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
         const Taps t = make_taps(sc, 2, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         gather24(sc.plane[2], t, h, F);
     }
+    if (RECORD && rec_ok) record24(rec->Xr + q * (4 * C) + 2 * C, h, F);
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+    if (RECORD && rec_ok) {
+        record24(rec->Xd + q * 64, h, D);
+        *reinterpret_cast<f32x4*>(rec->Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(rec->Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     feat_layer(cur, F, lane, accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1);
     gather24(sc.plane[3], vt, h, F);
+    if (RECORD && rec_ok) record24(rec->Xr + q * (4 * C) + 3 * C, h, F);
     feat_layer(cur, F, lane, accA);
     if (MASKS) relu_publish(accA, gates, 4); else relu_inplace(accA);
+    if (RECORD && rec_ok) record128(rec->Hr + 0L * HID * rec->Pp, q, h, accA);
     cur = nxt;
     // ---- rgb decoder layers 1..3 -> 3 ---------------------------------------------------------------------------------
     ring_sync();
@@ -302,6 +332,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 2 * HH);
     hidden_half<1>(cur, accA, lane, accB);
     if (MASKS) relu_publish(accB, gates, 5); else relu_inplace(accB);
+    if (RECORD && rec_ok) record128(rec->Hr + 1L * HID * rec->Pp, q, h, accB);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 3 * HH);
@@ -312,6 +343,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 4 * HH);
     hidden_half<1>(cur, accB, lane, accA);
     if (MASKS) relu_publish(accA, gates, 6); else relu_inplace(accA);
+    if (RECORD && rec_ok) record128(rec->Hr + 2L * HID * rec->Pp, q, h, accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_RGB1 + 5 * HH);
@@ -322,6 +354,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 24>(rs, P_DEN0);
     hidden_half<1>(cur, accA, lane, accB);
     if (MASKS) relu_publish(accB, gates, 7); else relu_inplace(accB);
+    if (RECORD && rec_ok) record128(rec->Hr + 3L * HID * rec->Pp, q, h, accB);
 #if NVSR_ABLATE & 64
     const float stamp = raw[0];
 #endif
@@ -337,6 +370,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     load_bias(small + S_BIAS + 0 * HID, h, accA);
     feat_layer(cur, D, lane, accA);
     if (MASKS) relu_publish(accA, gates, 0); else relu_inplace(accA);
+    if (RECORD && rec_ok) record128(rec->Hd + 0L * HID * rec->Pp, q, h, accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + HH);
@@ -347,6 +381,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 2 * HH);
     hidden_half<1>(cur, accA, lane, accB);
     if (MASKS) relu_publish(accB, gates, 1); else relu_inplace(accB);
+    if (RECORD && rec_ok) record128(rec->Hd + 1L * HID * rec->Pp, q, h, accB);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 3 * HH);
@@ -357,6 +392,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 4 * HH);
     hidden_half<1>(cur, accB, lane, accA);
     if (MASKS) relu_publish(accA, gates, 2); else relu_inplace(accA);
+    if (RECORD && rec_ok) record128(rec->Hd + 2L * HID * rec->Pp, q, h, accA);
     cur = nxt;
     ring_sync();
     nxt = ring_issue<NWAVES, 32>(rs, P_DEN1 + 5 * HH);
@@ -366,6 +402,7 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     ring_sync();
     hidden_half<1>(cur, accA, lane, accB);
     if (MASKS) relu_publish(accB, gates, 3); else relu_inplace(accB);
+    if (RECORD && rec_ok) record128(rec->Hd + 3L * HID * rec->Pp, q, h, accB);
     raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
 }
 

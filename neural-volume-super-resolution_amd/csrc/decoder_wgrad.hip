@@ -30,14 +30,16 @@ constexpr int WG_TPB = 256;
 
 __device__ __forceinline__ f32x16 mfma32w(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-__global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, long Pp, int slab, float* __restrict__ grad) {
+// P = valid rows (may be odd: the second row of the last pair is then read as zero)
+__global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, long P, int slab, float* __restrict__ grad) {
     __shared__ __attribute__((aligned(16))) float tile[128 * 64];
     const WJob jb = jobs.j[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int per_wave = slab / 4;                                   // even (host guarantees slab % 8 == 0)
     long q0 = (long)blockIdx.x * slab + (long)wave * per_wave;
     long q1 = q0 + per_wave;
-    if (q1 > Pp) q1 = Pp;                                            // Pp is a multiple of 128: the range stays even
+    const bool odd_tail = q1 >= P && q0 < P && (P & 1);               // this wave owns the unpaired last row
+    if (q1 > (P & ~1L)) q1 = P & ~1L;
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -82,6 +84,20 @@ __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, lo
                 acc[a][1] = mfma32w(g[a], x[1], acc[a][1]);
                 bs[a] += g[a];
             }
+        }
+    }
+    if (odd_tail) {                                                   // row P-1 pairs with a zero row
+        f32x4 g = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        f32x2 x = f32x2{0.0f, 0.0f};
+        if (kh == 0) {
+            g = *reinterpret_cast<const f32x4*>(jb.G + (P - 1) * HID + 4 * i);
+            x = *reinterpret_cast<const f32x2*>(jb.X + (P - 1) * (long)jb.xstride + jb.col0 + 2 * i);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            acc[a][0] = mfma32w(g[a], x[0], acc[a][0]);
+            acc[a][1] = mfma32w(g[a], x[1], acc[a][1]);
+            bs[a] += g[a];
         }
     }
     // acc[a][b][r]: out = 4 * ((r&3) + 8(r>>2) + 4kh) + a,  in = 2i + b.   Sum the 4 waves in LDS (same element per lane in every wave).
@@ -153,8 +169,8 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
     if (!aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    const long Pp = record_slots((long)N, S);
-    const DecRecord rec = make_record(const_cast<float*>(record), Pp);
+    const DecRecord rec = make_record(const_cast<float*>(record), (long)N, S);
+    const long Pp = rec.Pp, P = rec.P;
     WJobs jobs;
     int n = 0;
     auto add = [&](const float* G, const float* X, int xstride, int col0, int w_off, int in_total, int b_off) {
@@ -175,13 +191,13 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
         }
     if (n != WJOBS) return NVSR_ERR_SHAPE;
     // slabs: ~32 per layer block keeps 512 workgroups in flight (2 per CU) while each block is flushed only 32 times
-    long slab = (Pp + 31) / 32;
+    long slab = (P + 31) / 32;
     slab = ((slab + 255) / 256) * 256;
     if (slab < 256) slab = 256;
-    const unsigned nslabs = (unsigned)((Pp + slab - 1) / slab);
-    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, Pp, (int)slab, grad_natural);
+    const unsigned nslabs = (unsigned)((P + slab - 1) / slab);
+    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, P, (int)slab, grad_natural);
     const int hslab = 128;        // 4096 workgroups at 524k slots: the loop is one dependent load stream per thread
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((Pp + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
-                       rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, Pp, hslab, grad_natural);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
+                       rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, P, hslab, grad_natural);
     return NVSR_CHECK_LAUNCH();
 }

@@ -74,22 +74,25 @@ inline SceneDev to_dev(const nvsr_scene* s) {
     return d;
 }
 
-// ---- activation / delta record of one backward pass (decoder-weight gradients) -------------------------------------------
-// Rows are "slots": slot q = tile * 128 + wave * 32 + (lane & 31) of render_pass_backward_kernel; padding rays hold zeros in G*/g4.
-//   Xd [Pp][64]   density-decoder input (mean of the 3 position features; columns 48..63 zero)
-//   Hd [4][Pp][128]  post-ReLU output of density layer l          Gd [4][Pp][128]  dL/d(pre-activation of density layer l)
-//   Xr [Pp][192]  rgb-decoder input [f0|f1|f2|f_view]              Hr, Gr likewise for the rgb decoder
-//   g4 [Pp][4]    dL/d raw (rgb, sigma)
+// ---- activation / delta record of one training pass (decoder-weight gradients) ---------------------------------------------
+// One row per decoded point, row q = s * N + ray (sample-major: the 32 rays of a wave at one sample are 32 consecutive rows, so a
+// half-wave stores whole 512-byte rows).  Arrays are allocated for Pp = N*S rounded up to 8 rows; rows >= N*S are never read.
+//   Xd [Pp][64]   density-decoder input (mean of the 3 position features; columns 48..63 zero)     } written by the pass that
+//   Hd [4][Pp][128]  post-ReLU output of density layer l;  Xr [Pp][192], Hr likewise for the rgb decoder } runs the FORWARD layers
+//   Gd / Gr [4][Pp][128]  dL/d(pre-activation of layer l);  g4 [Pp][4]  dL/d raw (rgb, sigma)        } written by the backward
 struct DecRecord {
     float *Xd, *Hd, *Gd, *Xr, *Hr, *Gr, *g4;
-    long Pp;
+    long Pp;   // allocated rows = stride between the per-layer arrays
+    long P;    // valid rows (N * S)
 };
 constexpr long DEC_RECORD_FLOATS_PER_SLOT = 64 + 4 * HID + 4 * HID + 4 * C + 4 * HID + 4 * HID + 4;   // 2308
-constexpr int RECORD_TILE = 128;          // points per workgroup tile of render_pass_backward_kernel
-inline long record_slots(long N, int S) { return ((N + RECORD_TILE - 1) / RECORD_TILE) * (long)S * RECORD_TILE; }
-inline DecRecord make_record(float* base, long Pp) {
+inline long record_rows(long N, int S) { return N * (long)S; }
+inline long record_alloc_rows(long N, int S) { return (record_rows(N, S) + 7) / 8 * 8; }
+inline DecRecord make_record(float* base, long N, int S) {
     DecRecord r;
+    const long Pp = record_alloc_rows(N, S);
     r.Pp = Pp;
+    r.P = record_rows(N, S);
     r.Xd = base;            base += 64 * Pp;
     r.Hd = base;            base += 4L * HID * Pp;
     r.Gd = base;            base += 4L * HID * Pp;

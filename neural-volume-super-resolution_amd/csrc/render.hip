@@ -50,10 +50,10 @@ __global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, co
 // fill the chip with one workgroup per 128 rays (training batches: 4096 rays = 32 workgroups): tiles are (ray block, sample)
 // pairs, so N*S/128 workgroup-steps are spread over the whole grid; nvsr_composite then consumes raw.
 // =====================================================================================================================
-template <bool MASKS>
+template <bool MASKS, bool RECORD>
 __global__ __launch_bounds__(TPB, 2) void decode_rays_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                              const float* __restrict__ rays, const float* __restrict__ z,
-                                                             float* __restrict__ raw_out, unsigned* __restrict__ gates) {
+                                                             float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<NWAVES>(rs);
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(TPB, 2) void decode_rays_kernel(SceneDev sc, const 
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes of the last ray block rewrite ray N-1's
         // record with identical values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
-        decode_step<NWAVES, MASKS>(sc, rs, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
-                                   __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl);
+        decode_step<NWAVES, MASKS, RECORD>(sc, rs, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
+                                           __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, &rec, (long)s * N + ray, valid);
         if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 }
@@ -253,24 +253,28 @@ int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, i
 
 int nvsr_decode_rays(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                      float* raw, nvsr_stream_t stream) {
-    return nvsr_decode_rays_ex(scene, packed_decoder, N, S, rays, z, raw, nullptr, stream);
+    return nvsr_decode_rays_ex(scene, packed_decoder, N, S, rays, z, raw, nullptr, nullptr, stream);
 }
 
 int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
-                        float* raw, uint32_t* gates, nvsr_stream_t stream) {
+                        float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
     if (int e = check_scene(scene)) return e;
     if (!packed_decoder || !rays || !z || !raw) return NVSR_ERR_NULL;
-    if (!aligned16(packed_decoder) || !aligned16(raw) || !aligned16(gates)) return NVSR_ERR_ALIGN;
+    if (!aligned16(packed_decoder) || !aligned16(raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-    if (gates)
-        hipLaunchKernelGGL(decode_rays_kernel<true>, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N, S,
-                           rays, z, raw, gates);
+    if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
+    if (record)
+        hipLaunchKernelGGL((decode_rays_kernel<true, true>), dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
+                           S, rays, z, raw, gates, make_record(record, (long)N, S));
+    else if (gates)
+        hipLaunchKernelGGL((decode_rays_kernel<true, false>), dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
+                           S, rays, z, raw, gates, DecRecord{});
     else
-        hipLaunchKernelGGL(decode_rays_kernel<false>, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N, S,
-                           rays, z, raw, (unsigned*)nullptr);
+        hipLaunchKernelGGL((decode_rays_kernel<false, false>), dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{});
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -179,23 +179,6 @@ __device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* 
 
 struct GradPlanes { float* p[4]; };
 
-// record helpers: one accumulator set (128 features x 32 points, C/D layout) -> rows [slot][128]; 32 B per lane pair and store,
-// the wave's 16 stores fill 32 complete 512-byte rows
-__device__ __forceinline__ void record128(float* __restrict__ base, long q, int h, const f32x16 (&a)[4]) {
-    float* row = base + q * HID + 4 * h;
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
-}
-// a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[col0 + 24h ..]
-__device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
-#pragma unroll
-    for (int i = 0; i < HALF_C / 4; ++i)
-        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
-}
-
 // =====================================================================================================================
 template <bool RECORD>
 __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev sc, const float* __restrict__ packed,
@@ -225,8 +208,9 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // padding rays: every gradient below becomes an exact zero
-        const long q = tix * BPTS + rs.wave * 32 + (lane & 31);      // record slot of this point
-        if (RECORD && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
+        const long q = (long)s * N + ray;                             // record row of this point
+        const bool rok = RECORD && valid;                             // padding rays write nothing
+        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         const f32x4 c0 = f32x4{r[0], r[1], r[2], r[3]}, c1 = f32x4{r[4], r[5], 0.0f, 0.0f};
         const float n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
         const float n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
@@ -247,7 +231,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         load_bias(small + S_BIAS + 4 * HID, h, accA);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
-        if (RECORD) record24(rec.Xr + q * (4 * C), h, F);
+        if (rok) record24(rec.Xr + q * (4 * C), h, F);
         feat_layer(cur, F, lane, accA);
         cur = nxt;
         ring_sync();
@@ -255,7 +239,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         gather24(sc.plane[1], pos_taps(1), h, F);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
-        if (RECORD) record24(rec.Xr + q * (4 * C) + C, h, F);
+        if (rok) record24(rec.Xr + q * (4 * C) + C, h, F);
         feat_layer(cur, F, lane, accA);
         cur = nxt;
         ring_sync();
@@ -263,7 +247,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         gather24(sc.plane[2], pos_taps(2), h, F);
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
-        if (RECORD) {
+        if (rok) {
             record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
             record24(rec.Xd + q * 64, h, D);
             *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -274,10 +258,10 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         ring_sync();
         nxt = ring_issue<BNW, 32>(rs, P_RGB1);
         gather24(sc.plane[3], vt, h, F);
-        if (RECORD) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
+        if (rok) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
         feat_layer(cur, F, lane, accA);
         mr[0] = relu_masks(accA);
-        if (RECORD) record128(rec.Hr, q, h, accA);
+        if (rok) record128(rec.Hr, q, h, accA);
         cur = nxt;
 #pragma unroll
         for (int l = 1; l <= 3; ++l) {                 // rgb layers 1..3 (ping-pong A -> B -> A -> B)
@@ -292,7 +276,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
             nxt = (l < 3) ? ring_issue<BNW, 32>(rs, P_RGB1 + l * P_HID_FLOATS) : ring_issue<BNW, 24>(rs, P_DEN0);
             hidden_half<1>(cur, in, lane, out);
             mr[l] = relu_masks(out);
-            if (RECORD) record128(rec.Hr + (long)l * HID * rec.Pp, q, h, out);
+            if (rok) record128(rec.Hr + (long)l * HID * rec.Pp, q, h, out);
             cur = nxt;
         }
         ring_sync();
@@ -300,7 +284,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         load_bias(small + S_BIAS + 0 * HID, h, accA);
         feat_layer(cur, D, lane, accA);
         md[0] = relu_masks(accA);
-        if (RECORD) record128(rec.Hd, q, h, accA);
+        if (rok) record128(rec.Hd, q, h, accA);
         cur = nxt;
 #pragma unroll
         for (int l = 1; l <= 3; ++l) {                 // density layers 1..3
@@ -315,7 +299,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
             if (l < 3) nxt = ring_issue<BNW, 32>(rs, P_DEN1 + l * P_HID_FLOATS);
             hidden_half<1>(cur, in, lane, out);
             md[l] = relu_masks(out);
-            if (RECORD) record128(rec.Hd + (long)l * HID * rec.Pp, q, h, out);
+            if (rok) record128(rec.Hd + (long)l * HID * rec.Pp, q, h, out);
             cur = nxt;
         }
 
@@ -332,13 +316,13 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
             }
         apply_mask(md[3], accA);
-        if (RECORD) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
+        if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
-        if (RECORD) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
+        if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<BNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
-        if (RECORD) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
+        if (rok) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
-        if (RECORD) record128(rec.Gd, q, h, accB);
+        if (rok) record128(rec.Gd, q, h, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -366,13 +350,13 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
             }
         apply_mask(mr[3], accA);
-        if (RECORD) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
+        if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
-        if (RECORD) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
+        if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<BNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
-        if (RECORD) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
+        if (rok) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<BNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
-        if (RECORD) record128(rec.Gr, q, h, accB);
+        if (rok) record128(rec.Gr, q, h, accB);
         // layer 0^T, one plane at a time, + gD/3 on the position planes, then scatter
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -409,12 +393,13 @@ constexpr int MTPB = 512, MNW = MTPB / 64, MPTS = MNW * 32;
 constexpr int MBWD_LDS_FLOATS = LDS_FLOATS + MNW * TILE_FLOATS;
 static_assert(MBWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
+template <bool RECORD>
 __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                             const float* __restrict__ packed_bwd, long N, int S,
                                                                             const float* __restrict__ rays, const float* __restrict__ z,
                                                                             const float* __restrict__ g_raw,
                                                                             const unsigned* __restrict__ gates, GradPlanes gp,
-                                                                            float* __restrict__ gview) {
+                                                                            float* __restrict__ gview, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) float lds[MBWD_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<MNW>(rs);                    // head weights / biases of the FORWARD blob -> LDS
@@ -438,6 +423,9 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const long q = (long)s * N + ray;                             // record row (the forward wrote X / H of the same row)
+        const bool rok = RECORD && valid;
+        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         const u32x4* gk = reinterpret_cast<const u32x4*>(gates + ((ray * S + s) * 2 + h) * 16);
         const u32x4 k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3];
         const Masks md[4] = {{{k0[0], k0[1]}}, {{k0[2], k0[3]}}, {{k1[0], k1[1]}}, {{k1[2], k1[3]}}};
@@ -462,9 +450,13 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
             }
         apply_mask(md[3], accA);
+        if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<MNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
+        if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<MNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
+        if (rok) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<MNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
+        if (rok) record128(rec.Gd, q, h, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -491,9 +483,13 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
             }
         apply_mask(mr[3], accA);
+        if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         hidden_T<MNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
+        if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
         hidden_T<MNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
+        if (rok) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         hidden_T<MNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
+        if (rok) record128(rec.Gr, q, h, accB);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             f32x16 gF[2];
@@ -639,7 +635,7 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
 
 int64_t nvsr_decoder_record_floats(int64_t N, int S) {
     if (N < 0 || S < 1) return 0;
-    return record_slots((long)N, S) * DEC_RECORD_FLOATS_PER_SLOT;
+    return record_alloc_rows((long)N, S) * DEC_RECORD_FLOATS_PER_SLOT;
 }
 
 static int launch_view_reduce(const nvsr_scene* scene, int64_t N, int S, const float* rays, const float* view_ws, float* gplane,
@@ -666,11 +662,10 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    static_assert(BPTS == RECORD_TILE, "record slots are laid out per tile of the backward kernel");
     const int64_t ntiles = ((N + BPTS - 1) / BPTS) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
     if (record) {
-        const DecRecord rec = make_record(record, record_slots((long)N, S));
+        const DecRecord rec = make_record(record, (long)N, S);
         hipLaunchKernelGGL(render_pass_backward_kernel<true>, dim3((unsigned)grid), dim3(BTPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gp, rec, view_ws);
     } else {
@@ -684,21 +679,26 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
 
 int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                     const float* rays, const float* z, const float* g_raw, const uint32_t* gates, float* const* grad_planes,
-                                    float* view_ws, nvsr_stream_t stream) {
-    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !gates || !grad_planes) return NVSR_ERR_NULL;
+                                    float* view_ws, float* record, nvsr_stream_t stream) {
+    if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !gates) return NVSR_ERR_NULL;
+    if (!grad_planes && !record) return NVSR_ERR_NULL;
     GradPlanes gp;
     for (int d = 0; d < 4; ++d) {
         if (!scene->planes[d]) return NVSR_ERR_NULL;
         if (scene->ph[d] < 1 || scene->pw[d] < 1) return NVSR_ERR_SHAPE;
-        gp.p[d] = grad_planes[d];
+        gp.p[d] = grad_planes ? grad_planes[d] : nullptr;
     }
-    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates)) return NVSR_ERR_ALIGN;
+    if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     const int64_t ntiles = ((N + MPTS - 1) / MPTS) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
-    hipLaunchKernelGGL(render_pass_backward_gates_kernel, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
-                       packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws);
+    if (record)
+        hipLaunchKernelGGL(render_pass_backward_gates_kernel<true>, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));
+    else
+        hipLaunchKernelGGL(render_pass_backward_gates_kernel<false>, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, DecRecord{});
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);
     return NVSR_OK;

@@ -46,7 +46,9 @@ def _reference_chunks(n_rays, options, mode, model_coarse, model_fine):
     return [(i, min(i + chunk, n_rays)) for i in range(0, n_rays, chunk)]
 
 
-RECORD_RAYS = 8192   # rays per backward launch when decoder gradients are wanted (bounds the record: 9.2 KB per point)
+RECORD_RAYS = 8192   # rays per backward launch of the RECOMPUTING decoder-gradient path (bounds its record: 9.2 KB per point)
+RECORD_FORWARD_MAX_POINTS = 1 << 21   # up to this many points of a pass (19 GB of record) the forward itself records the layer
+                                      # inputs and the backward never recomputes; beyond, the chunked recomputing path runs
 
 
 class _RenderRaysFn(torch.autograd.Function):
@@ -70,25 +72,32 @@ class _RenderRaysFn(torch.autograd.Function):
         capi_.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), cfg["lindisp"], capi.ptr(cfg["t_rand"]), capi.ptr(z_c), st)
         # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip,
         # the fused per-ray kernel would run 32 workgroups; raw is needed by the backward anyway
-        # decoder frozen: the forward publishes its ReLU gates (128 B per point) and the backward skips the recomputation
-        gates_c = None if cfg["dec_c_grad"] else torch.empty((N, Nc, 32), dtype=torch.int32, device=dev)
+        # the forward publishes its ReLU gates (128 B per point) so that the backward does not recompute it; when decoder gradients
+        # are wanted it also records every layer's input (9.2 KB per point) unless the pass is too large for that
+        def aux(S, dec_grad):
+            fwd_rec = dec_grad and N * S <= RECORD_FORWARD_MAX_POINTS
+            gates = torch.empty((N, S, 32), dtype=torch.int32, device=dev) if (fwd_rec or not dec_grad) else None
+            rec = torch.empty(capi.lib().nvsr_decoder_record_floats(N, S), dtype=torch.float32, device=dev) if fwd_rec else None
+            return gates, rec
+
+        gates_c, rec_c = aux(Nc, cfg["dec_c_grad"] and cfg["coarse_grad"])
         capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(raw_c),
-                   capi.ptr(gates_c), st)
+                   capi.ptr(gates_c), capi.ptr(rec_c), st)
         capi_.call("nvsr_composite_rays", N, Nc, capi.ptr(raw_c), capi.ptr(z_c), capi.ptr(rays), capi.ptr(cfg["noise_c"]), cfg["white"],
                    capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None, st)
         outs = [rgb_c, disp_c, acc_c]
-        saved = dict(z_c=z_c, raw_c=raw_c, gates_c=gates_c)
+        saved = dict(z_c=z_c, raw_c=raw_c, gates_c=gates_c, rec_c=rec_c)
         if Nf > 0:
             z_f, raw_f = f(N, Nc + Nf), f(N, Nc + Nf, 4)
             rgb_f, disp_f, acc_f = f(N, 3), f(N), f(N)
             capi_.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(cfg["u"]), capi.ptr(z_f), st)
-            gates_f = None if cfg["dec_f_grad"] else torch.empty((N, Nc + Nf, 32), dtype=torch.int32, device=dev)
+            gates_f, rec_f = aux(Nc + Nf, cfg["dec_f_grad"])
             capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
-                       capi.ptr(raw_f), capi.ptr(gates_f), st)
+                       capi.ptr(raw_f), capi.ptr(gates_f), capi.ptr(rec_f), st)
             capi_.call("nvsr_composite_rays", N, Nc + Nf, capi.ptr(raw_f), capi.ptr(z_f), capi.ptr(rays), capi.ptr(cfg["noise_f"]), cfg["white"],
                        capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None, st)
             outs += [rgb_f, disp_f, acc_f]
-            saved.update(z_f=z_f, raw_f=raw_f, gates_f=gates_f)
+            saved.update(z_f=z_f, raw_f=raw_f, gates_f=gates_f, rec_f=rec_f)
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
         ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 == 1])    # disparity: no gradient path implemented
         return tuple(outs)
@@ -106,7 +115,7 @@ class _RenderRaysFn(torch.autograd.Function):
         gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if need[5] else None
         gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if (need[6] and Nf > 0) else None
 
-        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec, gates):
+        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec, gates, fwd_rec):
             if (g_rgb is None and g_acc is None) or (gptrs is None and gdec is None):
                 return
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
@@ -116,10 +125,16 @@ class _RenderRaysFn(torch.autograd.Function):
                       capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), st)
             # per-point rows of the view-direction plane's gradient (summed per ray before they touch the plane)
             view_ws = torch.empty(N * S * capi.PLANE_CHANNELS, dtype=torch.float32, device=dev) if (gptrs is not None and need[4]) else None
+            if gdec is not None and fwd_rec is not None:
+                # the forward recorded the layer inputs: gate-driven backward adds the gradient half, then the contraction
+                capi.call("nvsr_render_pass_backward_gates", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
+                          capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(fwd_rec), st)
+                capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(fwd_rec), capi.ptr(gdec), st)
+                return
             if gdec is None:
                 if gates is not None:
                     capi.call("nvsr_render_pass_backward_gates", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                              capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), st)
+                              capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), None, st)
                 else:
                     capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
                               capi.ptr(z), capi.ptr(g_raw), gptrs, None, capi.ptr(view_ws), st)
@@ -134,10 +149,10 @@ class _RenderRaysFn(torch.autograd.Function):
 
         if cfg["coarse_grad"]:
             one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2], gdec_c,
-                     sv["gates_c"])
+                     sv["gates_c"], sv["rec_c"])
         if Nf > 0:
             one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
-                     gdec_f, sv["gates_f"])
+                     gdec_f, sv["gates_f"], sv["rec_f"])
         out = [None]
         for g in gplanes:
             out.append(None if g is None else models.from_channel_last(g))    # back to the reference's [1,C,H,W]

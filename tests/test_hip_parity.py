@@ -789,11 +789,12 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
     sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
     batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
     opts, scfg = make_options(nc, nf)
-    old = hip.train_utils.RECORD_RAYS
+    old, old_max = hip.train_utils.RECORD_RAYS, hip.train_utils.RECORD_FORWARD_MAX_POINTS
     try:
         results = []
-        for rec_rays in (old, 256):                      # one launch, then three ray blocks (256 + 256 + 188 rays) through the record
-            hip.train_utils.RECORD_RAYS = rec_rays
+        # (1) the forward records, gate-driven backward; (2) recomputing backward, one launch; (3) recomputing, 256 + 256 + 188 rays
+        for rec_rays, fwd_max in ((old, old_max), (old, 0), (256, 0)):
+            hip.train_utils.RECORD_RAYS, hip.train_utils.RECORD_FORWARD_MAX_POINTS = rec_rays, fwd_max
             for m in (mc, mf):
                 m.zero_grad(set_to_none=True)
             out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
@@ -803,8 +804,9 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
                 gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
             ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
             results.append((_decoder_grad_blob(mc), _decoder_grad_blob(mf)))
+            assert (out[3].grad_fn.saved["rec_f"] is not None) == (fwd_max > 0)
     finally:
-        hip.train_utils.RECORD_RAYS = old
+        hip.train_utils.RECORD_RAYS, hip.train_utils.RECORD_FORWARD_MAX_POINTS = old, old_max
     sc = oracle.scene(planes, g["box"])
     rays_np = oracle.pack_rays(N_(batch[0]), N_(batch[1]), 2.0, 6.0)
     dec_c, dec_f = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
@@ -815,8 +817,9 @@ def test_decoder_gradients_vs_oracle_larger(hip, oracle):
             # ReLU masks of pre-activations within fp32 noise of zero flip between the fp32 kernel and the double oracle
             assert rel < 2e-3, "%s decoder: relative L2 error %.2e" % (tag, rel)
             assert np.abs(a - b).max() <= 5e-3 * np.abs(b).max()
-    for a, b in zip(results[0], results[1]):             # the blocked run differs from the single launch by summation order only
-        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
+    for other in results[1:]:                            # the three paths differ by summation order only
+        for a, b in zip(results[0], other):
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5
 
 
 def test_plane_gradients_gate_path_equals_recompute_path(hip):
@@ -837,7 +840,12 @@ def test_plane_gradients_gate_path_equals_recompute_path(hip):
         sel = torch.from_numpy(np.random.default_rng(92).permutation(H * W)[:N]).to(DEV)
         batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
         opts, scfg = make_options(nc, nf, white=True)
-        out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        old_max = hip.train_utils.RECORD_FORWARD_MAX_POINTS
+        hip.train_utils.RECORD_FORWARD_MAX_POINTS = 0        # decoder gradients through the RECOMPUTING kernel in this test
+        try:
+            out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        finally:
+            hip.train_utils.RECORD_FORWARD_MAX_POINTS = old_max
         saved = out[3].grad_fn.saved
         assert (saved["gates_f"] is not None) == (what == ("planes",))
         gc = T(np.random.default_rng(93).standard_normal((N, 3)).astype(np.float32) / N)
@@ -850,37 +858,41 @@ def test_plane_gradients_gate_path_equals_recompute_path(hip):
 
 
 def test_decoder_weight_grad_contraction(hip):
-    """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI"""
+    """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI; an even
+    and an odd number of rows (rows are consumed in pairs; allocation is rounded up to 8 rows that must be ignored)"""
     capi = hip.capi
-    N, S = 300, 7                                        # 3 ray tiles of 128 x 7 samples = 2688 slots
-    n = capi.lib().nvsr_decoder_record_floats(N, S)
-    Pp = 3 * S * 128
-    assert n == Pp * 2308
-    g_ = torch.Generator(device="cpu").manual_seed(5)
-    rec = torch.randn(n, generator=g_, dtype=torch.float32)
-    rec_d = rec.to(DEV)
-    grad = torch.zeros(capi.DECODER_NATURAL_FLOATS, device=DEV)
-    capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())
-    capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())    # accumulates: twice the gradient
-    got = N_(grad) / 2
-    r = rec.double().numpy()
-    o = 0
-    def take(cols, k=1):
-        nonlocal o
-        a = r[o:o + k * cols * Pp].reshape(k, Pp, cols)
-        o += k * cols * Pp
-        return a
-    Xd, Hd, Gd, Xr, Hr, Gr, g4 = take(64)[0], take(128, 4), take(128, 4), take(192)[0], take(128, 4), take(128, 4), take(4)[0]
-    parts = []
-    for X, H, G, width, head in ((Xd, Hd, Gd, 48, g4[:, 3:4]), (Xr, Hr, Gr, 192, g4[:, :3])):
-        parts += [(G[0].T @ X[:, :width]).ravel(), G[0].sum(0)]
-        for l in range(1, 4):
-            parts += [(G[l].T @ H[l - 1]).ravel(), G[l].sum(0)]
-        parts += [(head.T @ H[3]).ravel(), head.sum(0)]
-    ref = np.concatenate(parts)
-    assert ref.size == got.size
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(Pp))     # sums of 2688 N(0,1) products in fp32
-    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
+    for N, S in ((300, 7), (301, 7)):
+        P = N * S
+        Pp = (P + 7) // 8 * 8
+        n = capi.lib().nvsr_decoder_record_floats(N, S)
+        assert n == Pp * 2308
+        g_ = torch.Generator(device="cpu").manual_seed(5 + N)
+        rec = torch.randn(n, generator=g_, dtype=torch.float32)
+        rec_d = rec.to(DEV)
+        grad = torch.zeros(capi.DECODER_NATURAL_FLOATS, device=DEV)
+        capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())
+        capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())    # accumulates: twice the gradient
+        got = N_(grad) / 2
+        r = rec.double().numpy()
+        o = 0
+
+        def take(cols, k=1):
+            nonlocal o
+            a = r[o:o + k * cols * Pp].reshape(k, Pp, cols)[:, :P]      # rows >= P are allocation padding
+            o += k * cols * Pp
+            return a
+
+        Xd, Hd, Gd, Xr, Hr, Gr, g4 = take(64)[0], take(128, 4), take(128, 4), take(192)[0], take(128, 4), take(128, 4), take(4)[0]
+        parts = []
+        for X, H, G, width, head in ((Xd, Hd, Gd, 48, g4[:, 3:4]), (Xr, Hr, Gr, 192, g4[:, :3])):
+            parts += [(G[0].T @ X[:, :width]).ravel(), G[0].sum(0)]
+            for l in range(1, 4):
+                parts += [(G[l].T @ H[l - 1]).ravel(), G[l].sum(0)]
+            parts += [(head.T @ H[3]).ravel(), head.sum(0)]
+        ref = np.concatenate(parts)
+        assert ref.size == got.size
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(P))     # sums of ~2100 N(0,1) products in fp32
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
 
 
 def test_composite_backward_vs_autograd_formula(hip):
