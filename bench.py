@@ -239,7 +239,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
             b.record()
         torch.cuda.synchronize()
         dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
-        flops = 139264 * 2 * N * S                 # the transposed layers: 2 176 MFMAs of 32x32x2 per 32 points = 139 264 MAC per point
+        flops = FLOP_PER_EVAL * N * S              # the transposed layers move exactly the forward's 129 536 MAC per point
         ach = flops / dt / 1e12
         result["roofline"] = {"kernel": "render_pass_backward_gates_kernel<record> (fine pass, S=128; incl. its view-plane reduce)", "bound": "mfma",
                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
