@@ -29,21 +29,25 @@ def shard_rays(batch_rays, rank=None, world=None, group=None):
     return batch_rays[:, lo:hi], (lo, hi)
 
 
-def gather_rows(local, n_total, group=None):
-    """all_gather of per-rank row blocks of unequal length -> [n_total, ...] on every rank"""
+def gather_row_blocks(local, counts, group=None):
+    """all_gather of per-rank row blocks of unequal length (counts[r] rows on rank r) -> [sum(counts), ...] on every rank"""
     rank, world = world_info(group)
     if world == 1:
         return local
-    n_max = -(-n_total // world)
+    assert local.shape[0] == counts[rank]
+    n_max = max(counts)
     pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    out = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        out.append(parts[r][: hi - lo])
-    return torch.cat(out, 0)
+    return torch.cat([parts[r][: counts[r]] for r in range(world)], 0)
+
+
+def gather_rows(local, n_total, group=None):
+    """gather_row_blocks for the even split of shard_bounds(n_total)"""
+    rank, world = world_info(group)
+    counts = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+    return gather_row_blocks(local, counts, group)
 
 
 def render_image_sharded(height, width, focal, model_coarse, model_fine, ray_origins, ray_directions, options, scene_id, scene_config,
@@ -63,6 +67,41 @@ def render_image_sharded(height, width, focal, model_coarse, model_fine, ray_ori
     rgb_c = gather_rows(rgb_c, n, group).reshape(height, width, 3)
     rgb_f = None if rgb_f is None else gather_rows(rgb_f, n, group).reshape(height, width, 3)
     return rgb_c, rgb_f
+
+
+def band_roi(lo, hi, rows):
+    """Region of interest (PlanesSR's [[ymin, xmin], [ymax, xmax]] in [-1, 1]) whose pixel arithmetic (floor / ceil, then one pixel
+    of margin, models.py:902-905) covers LR rows [lo, hi) and all columns."""
+    return torch.tensor([[2.0 * (lo + 0.5) / rows - 1.0, -1.0], [2.0 * (hi - 0.5) / rows - 1.0, 1.0]], dtype=torch.float32)
+
+
+def super_resolve_planes_sharded(sr_model, plane_names, group=None, sr_fn=None):
+    """SR stage of a scene over the ranks: every rank super-resolves one horizontal band of every plane -- PlanesSR's own
+    ROI path supplies the 68-pixel LR halo the network's receptive field needs -- and ONE all_gather per plane assembles the HR planes
+    on all ranks (123 MB per 800^2 plane).  The result lands in `sr_model.SR_planes`, where the renderer finds it.
+    sr_fn(plane_name, roi) -> [1,C,sf*R0,sf*R1] (NaN outside the ROI); default: the model itself."""
+    rank, world = world_info(group)
+    if sr_fn is None:
+        def sr_fn(name, roi):
+            with torch.no_grad():
+                return sr_model((name, roi))
+    sf = sr_model.scale_factor
+    for name in plane_names:
+        if name in sr_model.SR_planes:
+            continue
+        R0 = sr_model.LR_planes[name].shape[-2]
+        if world == 1 or R0 < world:
+            with torch.no_grad():
+                sr_model(name)
+            continue
+        lo, hi = shard_bounds(R0, rank, world)
+        hr = sr_fn(name, band_roi(lo, hi, R0))
+        band = hr[0, :, lo * sf: hi * sf, :].permute(1, 0, 2).contiguous()        # [rows, C, W]: rows first for gather_rows
+        assert not torch.isnan(band).any(), "the ROI must cover the band"
+        counts = [sf * (shard_bounds(R0, r, world)[1] - shard_bounds(R0, r, world)[0]) for r in range(world)]
+        full = gather_row_blocks(band, counts, group)
+        sr_model.SR_planes[name] = full.permute(1, 0, 2).unsqueeze(0).contiguous()
+    return [sr_model.SR_planes[n] for n in plane_names]
 
 
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):

@@ -35,6 +35,30 @@ def _worker(rank, world, port, tmp):
     grads = [torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(rank + 1)), torch.full((70000,), float(rank + 1))]
     D.allreduce_gradients(grads, bucket_bytes=1 << 16)
     assert all(torch.allclose(g, torch.full_like(g, 1.5)) for g in grads)
+    # band-sharded SR stage: a stand-in SR function whose value depends on the HR position only (like the real net, whose output
+    # does not depend on the ROI), NaN outside the ROI it was asked for; R0 = 7 rows is not divisible by 2
+    sf, R0, R1 = 4, 7, 6
+    truth = torch.arange(3 * R0 * sf * R1 * sf, dtype=torch.float32).reshape(1, 3, R0 * sf, R1 * sf)
+
+    class FakeSR:
+        scale_factor = sf
+        LR_planes = {"a": torch.zeros(1, 3, R0, R1), "b": torch.zeros(1, 3, R0, R1)}
+        SR_planes = {}
+
+    def fake_sr(name, roi):
+        import math
+        lo = max(0, math.floor(R0 * (1 + float(roi[0, 0])) / 2) - 1)
+        hi = min(R0, math.ceil(R0 * (1 + float(roi[1, 0])) / 2) + 1)
+        out = torch.full_like(truth, float("nan"))
+        out[:, :, lo * sf: hi * sf] = truth[:, :, lo * sf: hi * sf] + (1000.0 if name == "b" else 0.0)
+        return out
+
+    got = D.super_resolve_planes_sharded(FakeSR, ["a", "b"], sr_fn=fake_sr)
+    assert torch.equal(got[0], truth) and torch.equal(got[1], truth + 1000.0) and sorted(FakeSR.SR_planes) == ["a", "b"]
+    lo, hi = D.shard_bounds(R0, rank, world)
+    roi = D.band_roi(lo, hi, R0)
+    import math
+    assert math.floor(R0 * (1 + float(roi[0, 0])) / 2) == lo and math.ceil(R0 * (1 + float(roi[1, 0])) / 2) == hi
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")

@@ -472,6 +472,29 @@ def test_planes_sr_batch_is_bit_identical_to_one_by_one(hip):
         assert torch.equal(out, one)
 
 
+def test_planes_sr_row_bands_equal_the_full_plane(hip):
+    """the band a rank computes in the sharded SR stage (distributed.super_resolve_planes_sharded: PlanesSR's ROI path with the
+    rows of distributed.band_roi) holds exactly the values of the full-plane pass -- the halo comes from real rows, not padding"""
+    torch.manual_seed(13)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 32, "n_blocks": 3}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr.eval()
+    R0, R1 = 45, 38
+    sr.set_LR_plane(torch.randn(1, 48, R0, R1, device=DEV) * 0.5, id="p", save_interpolated=False)
+    D = hip.distributed
+    with torch.no_grad():
+        full = sr("p")
+        for world in (2, 3):
+            for rank in range(world):
+                lo, hi = D.shard_bounds(R0, rank, world)
+                band = sr(("p", D.band_roi(lo, hi, R0).to(DEV)))
+                assert torch.equal(band[..., lo * 4: hi * 4, :], full[..., lo * 4: hi * 4, :])
+                assert not torch.isnan(band[..., lo * 4: hi * 4, :]).any()
+    assert D.super_resolve_planes_sharded(sr, ["p"])[0] is full          # world size 1: the plain cached path
+
+
 def test_conv3x3_backward_vs_oracle(hip, oracle):
     """data and weight gradients of the valid 3x3 conv through the C ABI; sizes that exercise partial tiles in every dimension
     (channels not multiples of 64, width not a multiple of 32, fewer rows than row slabs)"""
