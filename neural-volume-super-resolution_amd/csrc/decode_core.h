@@ -121,10 +121,28 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
 #if NVSR_ABLATE & 2
     return;
 #endif
+#if NVSR_RELU_PLAIN
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+#else
+    // Compare + select with the gate bits folded into two running words (exactly relu_publish minus its store).  The two words are
+    // never used; their serial or-chain is what matters: it makes hipcc process the 64 elements in order, and the step then spills
+    // ~20 VGPRs instead of ~80 (measured on render_pass_kernel; a plain v_max loop lets it interleave the four 16-register tuples of
+    // the layer boundary with the MFMA operands around it).  Costs 3 extra VALU ops per element.
+    unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool on = acc[ib][r] > 0.0f;
+            acc[ib][r] = on ? acc[ib][r] : 0.0f;
+            if (ib < 2) m0 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            else m1 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+        }
+    asm volatile("" :: "v"(m0), "v"(m1));
+#endif
 }
 
 // ReLU that also publishes its gate: bit (ib&1)*16 + r of word ib>>1  <=>  acc[ib][r] > 0.  The two words go straight to global
@@ -196,21 +214,39 @@ __device__ __forceinline__ void hidden_half(const float* wl, const f32x16 (&in)[
     mfma_groups<32>(wl, lane, acc, [&](int g, int j) { return in[2 * HALF + (g >> 4)][4 * ((g >> 2) & 3) + j]; });
 }
 
-// 128 -> 1 head on the VALU: each lane owns 64 of the 128 features of its point, the partner lane (l ^ 32) the rest
-__device__ __forceinline__ float head_dot(const float* w /*LDS packed [ib][q][h][j]*/, int h, const f32x16 (&in)[4]) {
+// 128 -> NH heads on the VALU: each lane owns 64 of the 128 features of its point, the partner lane (l ^ 32) the rest.  The weights
+// stream from LDS one (ib, q) group at a time with the next group prefetched and the order pinned: left to itself hipcc hoists all
+// 16 (x NH) ds_read_b128 of a head above the FMAs -- 64 live registers per head next to the 64 accumulators, which is what spilled
+// ~55 VGPRs per step in the fused kernels.  The per-head fmaf chain (ib, q, j ascending) is unchanged.
+template <int NH>
+__device__ __forceinline__ void head_dots(const float* w /*LDS packed [head][ib][q][h][j]*/, int h, const f32x16 (&in)[4], float (&out)[NH]) {
 #if NVSR_ABLATE & 8
-    return in[0][0] + in[1][1] + in[2][2] + in[3][3];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) out[k] = in[0][0] + in[1][1] + in[2][2] + in[3][3];
+    return;
 #endif
-    float s = 0.0f;
+    const float* wl = w + h * 4;
+    f32x4 cur[NH], nxt[NH];
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+    for (int k = 0; k < NH; ++k) { cur[k] = *reinterpret_cast<const f32x4*>(wl + k * HID); out[k] = 0.0f; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (ib * 4 + q) * 8 + h * 4);
+    for (int g = 0; g < 16; ++g) {                 // g = ib * 4 + q
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s = fmaf(in[ib][4 * q + j], wv[j], s);
+            for (int k = 0; k < NH; ++k) nxt[k] = *reinterpret_cast<const f32x4*>(wl + k * HID + (g + 1) * 8);
         }
-    return s + __shfl_xor(s, 32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < NH; ++k) out[k] = fmaf(in[g >> 2][4 * (g & 3) + j], cur[k][j], out[k]);
+#pragma unroll
+        for (int k = 0; k < NH; ++k) cur[k] = nxt[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NH; ++k) out[k] = out[k] + __shfl_xor(out[k], 32);
 }
 
 struct RingState {
@@ -359,7 +395,13 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     const float stamp = raw[0];
 #endif
 #pragma unroll
-    for (int c = 0; c < 3; ++c) raw[c] = head_dot(small + S_RGB_W + c * HID, h, accB) + small[S_HEAD_B + 1 + c];
+    for (int c = 0; c < 3; ++c) raw[c] = 0.0f;
+    {
+        float hd[3];
+        head_dots<3>(small + S_RGB_W, h, accB, hd);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) raw[c] = hd[c] + small[S_HEAD_B + 1 + c];
+    }
 #if NVSR_ABLATE & 64
     raw[1] = stamp;
 #endif
@@ -403,7 +445,11 @@ __device__ __forceinline__ void decode_step(const SceneDev& sc, RingState& rs, f
     hidden_half<1>(cur, accA, lane, accB);
     if (MASKS) relu_publish(accB, gates, 3); else relu_inplace(accB);
     if (RECORD && rec_ok) record128(rec->Hd + 3L * HID * rec->Pp, q, h, accB);
-    raw[3] = head_dot(small + S_ALPHA_W, h, accB) + small[S_HEAD_B];
+    {
+        float hd[1];
+        head_dots<1>(small + S_ALPHA_W, h, accB, hd);
+        raw[3] = hd[0] + small[S_HEAD_B];
+    }
 }
 
 // workgroup prologue: heads/biases -> LDS (plain copy; the first ring barrier publishes them), then the STAGGER: the two
