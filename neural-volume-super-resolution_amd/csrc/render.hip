@@ -15,6 +15,8 @@
 //     B-fragment registers (channel-last planes), blends in registers;
 //   * the render pass walks the samples of its 32 rays front to back, so transmittance is a running product in a register
 //     (the reference's exclusive cumprod, in the same order) and only per-ray results are written.
+#include <cstdlib>
+
 #include "decode_core.h"
 
 namespace nvsr {
@@ -217,6 +219,10 @@ __global__ void pack_decoder_kernel(const float* __restrict__ nat, float* __rest
 
 using namespace nvsr;
 
+extern "C" int nvsr_render_pass2_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                        const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
+                                        float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
+
 extern "C" {
 
 int nvsr_pack_decoder(const float* natural, float* packed, nvsr_stream_t stream) {
@@ -286,6 +292,8 @@ int nvsr_render_pass_ex(const nvsr_scene* scene, const float* packed_decoder, in
     if (!aligned16(packed_decoder) || (raw_out && !aligned16(raw_out))) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
+    if (N >= 16384 && !getenv("NVSR_RENDER_V1"))     // two-tiles-per-wave kernel (render2.hip); NVSR_RENDER_V1=1 selects the first-generation kernel
+        return nvsr_render_pass2_launch(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, stream);
     const int64_t grid = (N + PTS_PER_WG - 1) / PTS_PER_WG;
     if (grid > 0x7fffffff) return NVSR_ERR_SHAPE;
     hipLaunchKernelGGL(render_pass_kernel, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
