@@ -18,7 +18,21 @@
 
 #include "decode_core.h"
 
+#ifndef R2_STAMP
+#define R2_STAMP 0    // debug builds: raw_out[..., 0:2] of tile X = s_memtime cycles of the first hidden block pair
+#endif
+#ifndef R2_ABLATE
+#define R2_ABLATE 0      // timing experiments only: 1 no compositing, 2 no exposed Y epilogue, 4 no exposed prologue gather, 8 no ring barrier
+#endif
+
 namespace nvsr {
+
+__device__ __forceinline__ void ring2_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(R2_ABLATE & 8)
+    __syncthreads();
+#endif
+}
 
 constexpr int TPB2 = 256;                         // 4 waves, one per SIMD, one workgroup per CU
 constexpr int NW2 = TPB2 / 64;
@@ -127,7 +141,11 @@ __device__ __forceinline__ void gather_side(int g_, int j, const GatherJob& job,
     }
 }
 
-// act = ReLU(acc) (64 elements) over the first NG groups of a block, spread over the 4 slots of each group
+// act = ReLU(acc) (64 elements) over the first NG groups of a block, spread over the 4 slots of each group.
+// What hipcc makes of it: it copies each 16-register accumulator tuple to VGPRs right behind the tuple's last MFMA (s_nop 17 + 16
+// v_accvgpr_read, exposed) and the slots only do the v_max.  Forcing the read into the slot (inline-asm v_accvgpr_read with an "a"
+// operand) interleaves exactly as written -- and is SLOWER (257.2 vs 253.9 ms): a VALU read of the AGPR file between two MFMAs costs
+// the matrix pipe more than the exposed copy does.
 template <int NG>
 __device__ __forceinline__ void relu_side(int g, int j, const f32x16 (&acc)[4], f32x16 (&act)[4]) {
     constexpr int PER = (64 + 4 * NG - 1) / (4 * NG);      // elements per slot
@@ -279,14 +297,19 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
         // VGPR file overflows -- 125 spills, 268.7 vs 256.1 ms.)
         GatherJob job;
         job.plane = sc.plane[0]; job.t = pos_taps2(sc, 0, xn0, xn1, xn2);
+#if R2_ABLATE & 4
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) X.F[c] = job.t.nw * (float)c;
+#else
 #pragma unroll
         for (int g = 0; g < 24; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gather_side(g, j, job, h, rt, X.F);
+#endif
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
         load_bias2(small + S_BIAS + 4 * HID, h, X.acc);
-        ring_sync();
+        ring2_sync();
         const float* nxt = ring2_issue<48>(rs, P_RGB0 + 2 * P_PLANE_FLOATS);
 
         // ---- rgb layer 0 ---------------------------------------------------------------------------------------------------
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = div3(__fadd_rn(X.D[c], X.F[c]));
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_RGB1);
         // B5: X plane 2 | Y: gather plane 2
         job.plane = sc.plane[2]; job.t = pos_taps2(sc, 2, yn0, yn1, yn2);
@@ -338,17 +361,32 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
         // ---- hidden layers: rgb 1..3 (a chunk = a whole 128 x 128 layer) ------------------------------------------------------
         auto hb = [](const f32x16 (&in)[4]) { return [&in](int g, int j) { return in[g >> 4][4 * ((g >> 2) & 3) + j]; }; };
         // block pair of layer l: [X layer l | Y finishes layer l-1 and arms layer l]  [Y layer l | X finishes layer l, arms layer l+1]
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_RGB1 + P_HID_FLOATS);
+#if R2_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 5 * HID, h, Y.acc, bp); });
+#if R2_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         mfma_block<64>(cur, lane, Y.acc, hb(Y.act), [&](int g, int j) { relu_side<32>(g, j, X.acc, X.act); bias_side<32>(g, j, small + S_BIAS + 6 * HID, h, X.acc, bp); });
+#if R2_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_RGB1 + 2 * P_HID_FLOATS);
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 6 * HID, h, Y.acc, bp); });
         mfma_block<64>(cur, lane, Y.acc, hb(Y.act), [&](int g, int j) { relu_side<32>(g, j, X.acc, X.act); bias_side<32>(g, j, small + S_BIAS + 7 * HID, h, X.acc, bp); });
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<24>(rs, P_DEN0);
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 7 * HID, h, Y.acc, bp); });
         // Y rgb layer 3 | X: ReLU, rgb heads, bias of density layer 0
@@ -360,10 +398,13 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
         });
 #pragma unroll
         for (int c = 0; c < 3; ++c) X.raw[c] = (hx[c] + __shfl_xor(hx[c], 32)) + small[S_HEAD_B + 1 + c];
+#if R2_STAMP
+        X.raw[0] = (float)(st1 - st0); X.raw[1] = (float)(st2 - st1);
+#endif
         cur = nxt;
 
         // ---- density decoder -----------------------------------------------------------------------------------------------
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_DEN1);
         // X density layer 0 | Y: ReLU, rgb heads
         float hy[3] = {0.0f, 0.0f, 0.0f};
@@ -379,17 +420,17 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
             bias_side<12, 2>(g, j, small + S_BIAS + 1 * HID, h, X.acc, bp);
         });
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_DEN1 + P_HID_FLOATS);
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 1 * HID, h, Y.acc, bp); });
         mfma_block<64>(cur, lane, Y.acc, hb(Y.act), [&](int g, int j) { relu_side<32>(g, j, X.acc, X.act); bias_side<32>(g, j, small + S_BIAS + 2 * HID, h, X.acc, bp); });
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<64>(rs, P_DEN1 + 2 * P_HID_FLOATS);
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 2 * HID, h, Y.acc, bp); });
         mfma_block<64>(cur, lane, Y.acc, hb(Y.act), [&](int g, int j) { relu_side<32>(g, j, X.acc, X.act); bias_side<32>(g, j, small + S_BIAS + 3 * HID, h, X.acc, bp); });
         cur = nxt;
-        ring_sync();
+        ring2_sync();
         nxt = ring2_issue<48>(rs, P_RGB0);     // C0 of the NEXT sample into the slot every wave has just left (after the last sample: a harmless copy)
         mfma_block<64>(cur, lane, X.acc, hb(X.act), [&](int g, int j) { relu_side<32>(g, j, Y.acc, Y.act); bias_side<32>(g, j, small + S_BIAS + 3 * HID, h, Y.acc, bp); });
         // Y density layer 3 | X: ReLU, sigma head
@@ -401,20 +442,29 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
         X.raw[3] = (sx[0] + __shfl_xor(sx[0], 32)) + small[S_HEAD_B];
         cur = nxt;
         // ---- epilogue (exposed): Y's ReLU + sigma head, both tiles' compositing -----------------------------------------------
+#if R2_ABLATE & 2
+        Y.raw[3] = Y.acc[0][0];
+#else
 #pragma unroll
         for (int g = 0; g < 32; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) relu_side<32>(g, j, Y.acc, Y.act);
-        float sy[1] = {0.0f};
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { heads_side<1>(g, 0, small + S_ALPHA_W, h, Y.act, sy, hp1); heads_side<1>(g, 2, small + S_ALPHA_W, h, Y.act, sy, hp1); }
-        Y.raw[3] = (sy[0] + __shfl_xor(sy[0], 32)) + small[S_HEAD_B];
+        {
+            float hd[1];
+            head_dots<1>(small + S_ALPHA_W, h, Y.act, hd);      // (weights streamed with a pinned prefetch: nothing hides an LDS round trip here)
+            Y.raw[3] = hd[0] + small[S_HEAD_B];
+        }
+#endif
         if (raw_out && lane < 32) {
             if (validX) *reinterpret_cast<f32x4*>(raw_out + (rayX * S + s) * 4) = f32x4{X.raw[0], X.raw[1], X.raw[2], X.raw[3]};
             if (validY) *reinterpret_cast<f32x4*>(raw_out + (rayY * S + s) * 4) = f32x4{Y.raw[0], Y.raw[1], Y.raw[2], Y.raw[3]};
         }
+#if R2_ABLATE & 1
+        X.cr += X.raw[0] + X.raw[3]; Y.cr += Y.raw[0] + Y.raw[3];
+#else
         composite_sample(X, reinterpret_cast<const f32x4*>(rcX)[1][2], nzX, last);
         composite_sample(Y, reinterpret_cast<const f32x4*>(rcY)[1][2], nzY, last);
+#endif
         if (weights && lane < 32) {
             if (validX) weights[rayX * S + s] = X.raw[3];
             if (validY) weights[rayY * S + s] = Y.raw[3];
