@@ -385,7 +385,7 @@ def main():
         "decoder_evals_per_s_per_gpu": value * 256 / world,
     }
     if rank == 0:
-        # dominant kernel: fused fine render pass (192 of the 256 evaluations per ray)
+        # dominant kernel: fused fine render pass (192 of the 256 evaluations per ray), render2.hip
         rays = nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)
         N = rays.shape[0]
         import ctypes as C
@@ -406,7 +406,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and H == 800 and args.plane_res == 800:
             traffic = json.load(open(pmc)).get("traffic_bytes")
-        result["roofline"] = {"kernel": "render_pass_kernel (fine pass, S=192)", "bound": "mfma", "achieved": achieved,
+        result["roofline"] = {"kernel": "render_pass2_kernel (fine pass, S=192)", "bound": "mfma", "achieved": achieved,
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,
                               "algorithmic_gather_bytes_per_launch": GATHER_BYTES_PER_EVAL * N * 192}

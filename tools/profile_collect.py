@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(src, "pmc_%s" % c, "*", "*counter_collection.csv")):
         best = None
         for r in csv.DictReader(open(f)):
-            if "render_pass_kernel" not in r["Kernel_Name"] or r["Counter_Name"] != c:
+            if "render_pass" not in r["Kernel_Name"] or "backward" in r["Kernel_Name"] or r["Counter_Name"] != c:
                 continue
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             if best is None or dur > best[1]:
@@ -35,7 +35,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 if len(pm) == 2:
     fetch_kb, write_kb = pm["FETCH_SIZE"][0], pm["WRITE_SIZE"][0]
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
-    d = {"kernel": "render_pass_kernel (fine pass, S=192)",
+    d = {"kernel": "render_pass2_kernel (fine pass, S=192)",
          "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (two separate passes)",
          "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "kernel_ms_under_pmc": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]],
          "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
