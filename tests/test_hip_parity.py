@@ -956,6 +956,33 @@ def test_composite_backward_vs_autograd_formula(hip):
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale)
 
 
+def test_volume_render_radiance_field_is_differentiable(hip):
+    """the mirror of volume_render_radiance_field carries a gradient for the radiance field (rgb_map, acc_map), equal to float64
+    autograd of the same formula"""
+    rng = np.random.default_rng(23)
+    N, S = 19, 40
+    raw = rng.standard_normal((N, S, 4)).astype(np.float32)
+    z = np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1)
+    rd = rng.standard_normal((N, 3)).astype(np.float32)
+    g_rgb = rng.standard_normal((N, 3)).astype(np.float32)
+    g_acc = rng.standard_normal(N).astype(np.float32)
+    r = T(raw).requires_grad_(True)
+    rgb, disp, acc, w, depth = hip.volume_rendering_utils.volume_render_radiance_field(r, T(z), T(rd), white_background=True)
+    assert rgb.requires_grad and acc.requires_grad and not w.requires_grad
+    ((rgb * T(g_rgb)).sum() + (acc * T(g_acc)).sum()).backward()
+    r64 = torch.tensor(raw, dtype=torch.float64, requires_grad=True)
+    z64, rd64 = torch.tensor(z, dtype=torch.float64), torch.tensor(rd, dtype=torch.float64)
+    dists = torch.cat([z64[:, 1:] - z64[:, :-1], torch.full((N, 1), 1e10, dtype=torch.float64)], -1) * rd64.norm(dim=-1, keepdim=True)
+    alpha = 1.0 - torch.exp(-torch.relu(r64[..., 3]) * dists)
+    T_ = torch.cumprod(torch.cat([torch.ones(N, 1, dtype=torch.float64), (1.0 - alpha + 1e-10)[:, :-1]], -1), -1)
+    wt = alpha * T_
+    rgb64 = (wt[..., None] * torch.sigmoid(r64[..., :3])).sum(1) + (1.0 - wt.sum(-1))[:, None]
+    ((rgb64 * torch.tensor(g_rgb, dtype=torch.float64)).sum() + (wt.sum(-1) * torch.tensor(g_acc, dtype=torch.float64)).sum()).backward()
+    np.testing.assert_allclose(N_(rgb), rgb64.detach().numpy(), rtol=0, atol=2e-6)
+    ref = r64.grad.numpy()
+    np.testing.assert_allclose(N_(r.grad), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+
+
 def test_plane_gradients_vs_oracle_larger(hip, oracle):
     """600 rays, planes 40x56 (non-square) + view 12x12, 48+80 samples, white background: HIP backward vs the analytic oracle,
     first at the SAME fine depths (isolates the backward kernels), then end to end (depths regenerated by each side)."""
