@@ -956,6 +956,45 @@ def test_composite_backward_vs_autograd_formula(hip):
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale)
 
 
+def test_render_pass_generations_are_bit_identical(hip):
+    """second-generation fused kernel (two tiles per wave, render2.hip) == first generation, bit for bit, on every output: 20 011 rays
+    (partial last workgroup and a wave whose second tile is empty), 37 samples, density noise, white background, weights / depth / raw"""
+    import ctypes as C
+    import os
+    g = load_golden("g08_render.npz")
+    capi = hip.capi
+    rng = np.random.default_rng(17)
+    planes = [rng.standard_normal((1, 48, 64, 48), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 8, 12), dtype=np.float32) * 0.5]
+    m, _ = build_model(hip, sd(g, "fine."), planes, g["box"])
+    for N in (20011, 16384 + 33):
+        S = 37
+        H, W = 150, 160
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+        rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)[:N].contiguous()
+        z = T(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1))
+        noise = T((rng.standard_normal((N, S)) * 0.3).astype(np.float32))
+        sc, keep = m.native_scene()
+        outs = []
+        for gen in ("1", None):
+            if gen:
+                os.environ["NVSR_RENDER_V1"] = gen
+            else:
+                os.environ.pop("NVSR_RENDER_V1", None)
+            o = dict(rgb=torch.full((N, 3), -7.0, device=DEV), disp=torch.full((N,), -7.0, device=DEV), acc=torch.full((N,), -7.0, device=DEV),
+                     w=torch.full((N, S), -7.0, device=DEV), depth=torch.full((N,), -7.0, device=DEV), raw=torch.full((N, S, 4), -7.0, device=DEV))
+            capi.call("nvsr_render_pass_ex", C.byref(sc), capi.ptr(m.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(noise), 1,
+                      capi.ptr(o["rgb"]), capi.ptr(o["disp"]), capi.ptr(o["acc"]), capi.ptr(o["w"]), capi.ptr(o["depth"]), capi.ptr(o["raw"]),
+                      capi.stream())
+            torch.cuda.synchronize()
+            outs.append(o)
+        os.environ.pop("NVSR_RENDER_V1", None)
+        for k in outs[0]:
+            assert_bits_equal(N_(outs[0][k]), N_(outs[1][k]))
+            assert not (N_(outs[1][k]) == -7.0).all()
+
+
 def test_volume_render_radiance_field_is_differentiable(hip):
     """the mirror of volume_render_radiance_field carries a gradient for the radiance field (rgb_map, acc_map), equal to float64
     autograd of the same formula"""
