@@ -32,6 +32,8 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     """nerf_helpers.py:578-605"""
     ro, rd = capi.f32c(rays_o), capi.f32c(rays_d)
     o, d = torch.empty_like(ro), torch.empty_like(rd)
+    if ro.numel() == 0:
+        return o, d
     capi.call("nvsr_ndc_rays", H, W, float(focal), float(near), ro.numel() // 3, capi.ptr(ro), capi.ptr(rd), capi.ptr(o),
               capi.ptr(d), capi.stream())
     return o, d

@@ -281,6 +281,8 @@ def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None
         from .nerf_helpers import ndc_rays
         ro, rd = ndc_rays(H, W, focal, 1.0, ro, rd)
     rays = torch.empty((N, 11), dtype=torch.float32, device=ro.device)
+    if N == 0:
+        return rays
     capi.call("nvsr_pack_rays", N, capi.ptr(ro), capi.ptr(rd), capi.ptr(view_src), float(near), float(far), capi.ptr(rays), capi.stream())
     return rays
 

@@ -956,6 +956,39 @@ def test_composite_backward_vs_autograd_formula(hip):
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale)
 
 
+def test_coarse_only_training_and_empty_batches(hip, oracle):
+    """BASELINE config 1 shape (num_fine = 0): the train step has one pass only; empty ray batches are legal everywhere"""
+    g = load_golden("g11_grads.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    sid = "lego_DS8_PlRes16_8"
+    mc, mf = _grad_models(hip, g, planes, sid, what=("planes", "decoder"))
+    rays = T(g["rays"])
+    N = rays.shape[1]
+    opts, scfg = make_options(24, 0)
+    out = hip.train_utils.run_one_iter_of_nerf(16, 16, float(g["hwf"][2]), mc, mf, rays, opts, sid, mode="train", scene_config=scfg, randoms={})
+    assert out[3] is None and out[0].requires_grad
+    gc = T(np.random.default_rng(3).standard_normal((N, 3)).astype(np.float32) / N)
+    (out[0] * gc).sum().backward()
+    sc = oracle.scene(planes, g["box"])
+    dc, df = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+    rays_np = oracle.pack_rays(g["rays"][0], g["rays"][1], 2.0, 6.0)
+    ref_p = oracle.render_backward(sc, [p.shape for p in planes], dc, df, rays_np, 24, 0, N_(gc), None)
+    ref_d, _ = oracle.render_backward_decoder(sc, dc, df, rays_np, 24, 0, N_(gc), None)
+    for d in range(4):
+        got = N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad)[0]
+        assert np.linalg.norm(got - ref_p[d]) / np.linalg.norm(ref_p[d]) < (2e-3 if d < 3 else 5e-3)
+    assert np.linalg.norm(_decoder_grad_blob(mc) - ref_d) / np.linalg.norm(ref_d) < 2e-3
+    assert all(p_.grad is None for p_ in mf.decoder_parameters())          # the fine model never ran
+    # empty batches
+    empty = rays[:, :0]
+    for mode in ("train", "validation"):
+        o = hip.train_utils.run_one_iter_of_nerf(16, 16, 10.0, mc, mf, empty, opts, sid, mode=mode, scene_config=scfg, randoms={})
+        assert o[0].shape == (0, 3) and o[2].shape == (0,)
+    opts2, _ = make_options(8, 8)
+    o = hip.train_utils.run_one_iter_of_nerf(16, 16, 10.0, mc, mf, empty, opts2, sid, mode="validation", scene_config=scfg)
+    assert o[3].shape == (0, 3)
+
+
 def test_render_pass_generations_are_bit_identical(hip):
     """second-generation fused kernel (two tiles per wave, render2.hip) == first generation, bit for bit, on every output: 20 011 rays
     (partial last workgroup and a wave whose second tile is empty), 37 samples, density noise, white background, weights / depth / raw"""
