@@ -989,6 +989,36 @@ def test_coarse_only_training_and_empty_batches(hip, oracle):
     assert o[3].shape == (0, 3)
 
 
+def test_ray_block_loop_matches_a_single_launch(hip):
+    """run_one_iter_of_nerf splits batches beyond MAX_RAYS_PER_LAUNCH into ray blocks (the reference's ray-chunk loop, train_utils.py:
+    228-247); rays are independent, so the blocked result is bit-identical -- also with train-mode random inputs, which are sliced per block"""
+    g = load_golden("g08_render.npz")
+    planes = [g["plane%d" % d] for d in range(4)]
+    mc, sid = build_model(hip, sd(g, "coarse."), planes, g["box"], sid="lego_DS8_PlRes32_8")
+    mf, _ = build_model(hip, sd(g, "fine."), planes, g["box"], sid=sid)
+    mf.planes_ = mc.planes_
+    H = W = 50
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    batch = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    N = H * W
+    opts, scfg = make_options(16, 24, perturb=True, noise=0.1)
+    gen = torch.Generator().manual_seed(5)
+    rnd = dict(t_rand=torch.rand(N, 16, generator=gen), u=torch.rand(N, 24, generator=gen), noise_coarse=0.1 * torch.randn(N, 16, generator=gen),
+               noise_fine=0.1 * torch.randn(N, 40, generator=gen))
+    old = hip.train_utils.MAX_RAYS_PER_LAUNCH
+    try:
+        with torch.no_grad():
+            one = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms=rnd)
+            hip.train_utils.MAX_RAYS_PER_LAUNCH = 777           # 2500 rays -> blocks of 777, 777, 777, 169
+            blk = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms=rnd)
+    finally:
+        hip.train_utils.MAX_RAYS_PER_LAUNCH = old
+    for a, b in zip(one[:6], blk[:6]):
+        assert a.shape == b.shape
+        assert_bits_equal(N_(a), N_(b))
+
+
 def test_render_pass_generations_are_bit_identical(hip):
     """second-generation fused kernel (two tiles per wave, render2.hip) == first generation, bit for bit, on every output: 20 011 rays
     (partial last workgroup and a wave whose second tile is empty), 37 samples, density noise, white background, weights / depth / raw"""
