@@ -12,7 +12,7 @@
 //   3. transposes the feature gradients of one plane at a time through a per-wave LDS tile ([point][48 channels]) and adds
 //      them into the channel-last gradient plane with one global_atomic_add_f32 wave-instruction per (point, tap): 48 lanes =
 //      192 contiguous bytes, the fast shape of float atomics (one-lane-per-row scatter is ~17x slower, MI355X_MICROARCH.md).
-#include "decode_core.h"
+#include "bwd_core.h"
 
 namespace nvsr {
 
@@ -23,19 +23,8 @@ constexpr int BTPB = 256;
 constexpr int BNW = BTPB / 64;
 constexpr int BPTS = BNW * 32;
 constexpr int RAYB_FLOATS = 16;
-constexpr int TILE_FLOATS = 32 * C;       // per-wave transposition tile [32 points][48 channels]
 constexpr int BWD_LDS_FLOATS = LDS_FLOATS + BPTS * RAYB_FLOATS + BNW * TILE_FLOATS;   // (the RAYB region is unused padding now)
 static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-
-// ---- transposed-weight blob ("packed_bwd"), in consumption order ------------------------------------------------------------
-//   hidden^T layer (16384 floats): [kb][q][ib][lane][j] = W[32kb + 8q + 4h + j][32ib + (lane&31)]        (W = [out][in])
-//   layer-0^T of one plane (8192 floats): [kb][q][ib 2][lane][j] = W0[32kb + 8q + 4h + j][48p + 32ib + (lane&31)], 0 for channel >= 48
-constexpr int B_DEN_H = 0;                               // density L3^T, L2^T, L1^T
-constexpr int B_DEN0 = B_DEN_H + 3 * P_HID_FLOATS;       // 49152
-constexpr int B_RGB_H = B_DEN0 + 8192;                   // 57344: rgb L3^T, L2^T, L1^T
-constexpr int B_RGB0 = B_RGB_H + 3 * P_HID_FLOATS;       // 106496: planes 0..3
-constexpr int B_TOTAL = B_RGB0 + 4 * 8192;               // 139264
-static_assert(B_TOTAL == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
 
 __global__ void pack_decoder_bwd_kernel(const float* __restrict__ nat, float* __restrict__ packed) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,7 +51,6 @@ __global__ void pack_decoder_bwd_kernel(const float* __restrict__ nat, float* __
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------------
-struct Masks { unsigned m[2]; };   // bit (ib&1)*16 + r of m[ib>>1]  <=>  post-ReLU activation acc[ib][r] > 0
 
 __device__ __forceinline__ Masks relu_masks(f32x16 (&acc)[4]) {
     Masks k{{0u, 0u}};
@@ -177,7 +165,6 @@ __device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* 
     __builtin_amdgcn_wave_barrier();
 }
 
-struct GradPlanes { float* p[4]; };
 
 // =====================================================================================================================
 template <bool RECORD>

@@ -13,7 +13,7 @@ rays=nvsr_amd.train_utils.pack_rays(ro,rd,2.0,6.0)
 z=torch.sort(torch.rand(N,S,device=dev)*4+2,-1)[0].contiguous()
 raw=torch.empty(N,S,4,device=dev); gates=torch.empty(N,S,32,dtype=torch.int32,device=dev)
 sc,keep=mf.native_scene()
-capi.call("nvsr_decode_rays_ex",C.byref(sc),capi.ptr(mf.packed_decoder()),N,S,capi.ptr(rays),capi.ptr(z),capi.ptr(raw),capi.ptr(gates),capi.stream())
+capi.call("nvsr_decode_rays_ex",C.byref(sc),capi.ptr(mf.packed_decoder()),N,S,capi.ptr(rays),capi.ptr(z),capi.ptr(raw),capi.ptr(gates),None,capi.stream())
 g_raw=torch.randn(N,S,4,device=dev)*1e-3
 gpl=[torch.zeros_like(k) for k in keep]
 vws=torch.empty(N*S*48,device=dev)
@@ -23,14 +23,13 @@ def run(mask,label,use_ws=False):
     for i in range(4):
         a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
         a.record()
-        capi.call("nvsr_render_pass_backward_gates",C.byref(sc),capi.ptr(mf.packed_decoder()),capi.ptr(mf.packed_decoder_bwd()),N,S,capi.ptr(rays),capi.ptr(z),capi.ptr(g_raw),capi.ptr(gates),gptrs,capi.stream())
+        capi.call("nvsr_render_pass_backward_gates",C.byref(sc),capi.ptr(mf.packed_decoder()),capi.ptr(mf.packed_decoder_bwd()),N,S,capi.ptr(rays),capi.ptr(z),capi.ptr(g_raw),capi.ptr(gates),gptrs,capi.ptr(vws) if use_ws else None,None,capi.stream())
         b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     print("%-28s %.3f ms"%(label,min(ts)))
 run([0,0,0,0],"no scatter")
-run([0,0,0,1],"view plane only")
+run([0,0,0,1],"view plane only (atomics)")
 run([1,0,0,0],"one position plane")
 run([1,1,1,0],"3 position planes")
-run([1,1,1,1],"all")
-# same with sorted rays (coherent image tile) to see the contention effect
+run([1,1,1,1],"all (view by atomics)")
 run([0,0,0,1],"view plane only, row ws",True)
 run([1,1,1,1],"all, row ws",True)
