@@ -17,8 +17,9 @@
 
 namespace nvsr {
 
-constexpr int CONV_TPB = 512;
-constexpr int CONV_WAVES = 8;
+#ifndef NVSR_CONV_WIDE_4x1
+#define NVSR_CONV_WIDE_4x1 1     // 256-channel layers: 1 = two independent 4-wave workgroups per CU (4 rows each), 0 = one 8-wave workgroup (8 rows)
+#endif
 
 
 struct ConvParams {
@@ -39,7 +40,8 @@ struct ConvParams {
 __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
 
 template <int CO_WAVES, int PX_WAVES>
-__global__ __launch_bounds__(CONV_TPB, 2) void conv3x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(ConvParams p) {
+    constexpr int CONV_WAVES = CO_WAVES * PX_WAVES, CONV_TPB = CONV_WAVES * 64;
     constexpr int NCB = CO_WAVES * 2;            // co-blocks per workgroup
     constexpr int ROWS = PX_WAVES * 4;           // output rows per workgroup tile
     constexpr int PR = ROWS + 2, PC = 34;        // input patch rows / cols (halo)
@@ -241,11 +243,17 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
         p.ncg = p.ncb_total / 8;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
-        hipLaunchKernelGGL((conv3x3_kernel<4, 2>), grid, dim3(CONV_TPB), 0, stream, p);
+#if NVSR_CONV_WIDE_4x1
+        // two independent 4-wave workgroups per CU (2 x 80 KB of LDS): one's chunk barrier is covered by the other's MFMAs
+        grid.y = (Ho + 3) / 4;
+        hipLaunchKernelGGL((conv3x3_kernel<4, 1>), grid, dim3(256), 0, stream, p);
+#else
+        hipLaunchKernelGGL((conv3x3_kernel<4, 2>), grid, dim3(512), 0, stream, p);
+#endif
     } else {
         p.ncg = p.ncb_total / 2;
         dim3 grid((Wo + 31) / 32, (Ho + 31) / 32, p.ncg * batch);
-        hipLaunchKernelGGL((conv3x3_kernel<1, 8>), grid, dim3(CONV_TPB), 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_kernel<1, 8>), grid, dim3(512), 0, stream, p);
     }
     return NVSR_CHECK_LAUNCH();
 }
