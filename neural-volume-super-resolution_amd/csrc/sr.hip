@@ -39,11 +39,13 @@ struct ConvParams {
 
 __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
 
-template <int CO_WAVES, int PX_WAVES>
+// PB = output rows (32-pixel blocks) per wave: 4 by default; the launcher picks 3 or 2 for a layer whose tile count would otherwise leave most
+// of the last workgroup round empty (a ~270^2 plane is 1.2 rounds of 4-row tiles on 512 workgroup slots, but 1.0 rounds of 3-row tiles... )
+template <int CO_WAVES, int PX_WAVES, int PB = 4>
 __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(ConvParams p) {
     constexpr int CONV_WAVES = CO_WAVES * PX_WAVES, CONV_TPB = CONV_WAVES * 64;
     constexpr int NCB = CO_WAVES * 2;            // co-blocks per workgroup
-    constexpr int ROWS = PX_WAVES * 4;           // output rows per workgroup tile
+    constexpr int ROWS = PX_WAVES * PB;          // output rows per workgroup tile
     constexpr int PR = ROWS + 2, PC = 34;        // input patch rows / cols (halo)
     constexpr int P_FLOATS = 4 * PR * PC;
     constexpr int P_PAD = (P_FLOATS + 63) / 64 * 64;
@@ -99,11 +101,11 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][PB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
@@ -114,21 +116,21 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
         __syncthreads();                      // chunk landed for everyone; the other buffer is free
         if (chunk + 1 < p.nchunks) issue(chunk + 1, buf ^ 1);
         const float* wl = lds + buf * BUF + (cw * 2) * FRAG_FLOATS + lane;
-        const float* pl = lds + buf * BUF + W_FLOATS + (rg * 4) * PC + j;
+        const float* pl = lds + buf * BUF + W_FLOATS + (rg * PB) * PC + j;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {      // lane half h works on channel c2 + 2h of the chunk
             const float* pc = pl + (c2 + 2 * h) * (PR * PC);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                float b[6];
+                float b[PB + 2];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) b[r] = pc[r * PC + kx];
+                for (int r = 0; r < PB + 2; ++r) b[r] = pc[r * PC + kx];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int t = c2 * 9 + ky * 3 + kx;
                     const float a0 = wl[t * 64], a1 = wl[FRAG_FLOATS + t * 64];
 #pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) {
+                    for (int pb = 0; pb < PB; ++pb) {
                         acc[0][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[pb + ky], acc[0][pb], 0, 0, 0);
                         acc[1][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[pb + ky], acc[1][pb], 0, 0, 0);
                     }
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                const int y = y0 + rg * 4 + pb;
+            for (int pb = 0; pb < PB; ++pb) {
+                const int y = y0 + rg * PB + pb;
                 const bool inside = y < Ho && x < Wo;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -244,9 +246,20 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         p.ncg = p.ncb_total / 8;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
 #if NVSR_CONV_WIDE_4x1
-        // two independent 4-wave workgroups per CU (2 x 80 KB of LDS): one's chunk barrier is covered by the other's MFMAs
-        grid.y = (Ho + 3) / 4;
-        hipLaunchKernelGGL((conv3x3_kernel<4, 1>), grid, dim3(256), 0, stream, p);
+        // two independent 4-wave workgroups per CU (2 x 80 KB of LDS): one's chunk barrier is covered by the other's MFMAs.
+        // Rows per tile: all tiles of a launch take the same time, so the launch costs ceil(tiles / 512 slots) rounds of `rows` row-times;
+        // pick the row count (4, 3 or 2; fewer rows amortise the weight reads a little worse: +3 % per row dropped) with the cheapest total
+        int best_pb = 4;
+        double best_cost = 1e300;
+        for (int pb = 4; pb >= 2; --pb) {
+            const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+            const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
+            if (cost < best_cost) { best_cost = cost; best_pb = pb; }
+        }
+        grid.y = (Ho + best_pb - 1) / best_pb;
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_kernel<4, 1, 4>), grid, dim3(256), 0, stream, p);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_kernel<4, 1, 3>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<4, 1, 2>), grid, dim3(256), 0, stream, p);
 #else
         hipLaunchKernelGGL((conv3x3_kernel<4, 2>), grid, dim3(512), 0, stream, p);
 #endif
