@@ -89,7 +89,13 @@ __device__ __forceinline__ void relu_side(int g, int j, const f32x16 (&acc)[4], 
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int r = (g * 4 + j) * PER + k;
-        if (g < NG && r < 64) act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15], 0.0f);
+        if (g < NG && r < 64) {
+            // one v_max: written as fmaxf, hipcc first canonicalises the operand (v_max x, x, x) -- and a VALU instruction in an MFMA
+            // shadow is not free: measured (tools/mfma_ubench.hip), every one adds its ~4 issue cycles to the MFMA stream
+            float o;
+            asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(acc[r >> 4][r & 15]));
+            act[r >> 4][r & 15] = o;
+        }
     }
 }
 // bias -> accumulator init: one ds_read_b128 per group from group G0 on (PER per group in short blocks), read in slot 0, written to the
