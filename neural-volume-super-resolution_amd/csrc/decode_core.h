@@ -126,11 +126,9 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
-#else
-    // Compare + select with the gate bits folded into two running words (exactly relu_publish minus its store).  The two words are
-    // never used; their serial or-chain is what matters: it makes hipcc process the 64 elements in order, and the step then spills
-    // ~20 VGPRs instead of ~80 (measured on render_pass_kernel; a plain v_max loop lets it interleave the four 16-register tuples of
-    // the layer boundary with the MFMA operands around it).  Costs 3 extra VALU ops per element.
+#elif NVSR_RELU_GATEFORM
+    // Compare + select with the gate bits folded into two running words (exactly relu_publish minus its store): the serial or-chain makes
+    // hipcc process the 64 elements in order, and the step spills ~20 VGPRs instead of ~80 -- at the price of 3 extra VALU ops per element.
     unsigned m0 = 0u, m1 = 0u;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -142,6 +140,14 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
             else m1 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
         }
     asm volatile("" :: "v"(m0), "v"(m1));
+#else
+    // One v_max per element, in place, as volatile inline asm: no operand canonicalisation (fmaxf costs a second v_max) and a fixed order,
+    // which is what keeps hipcc from interleaving the four accumulator tuples with the MFMA operands around them.  Every VALU instruction
+    // costs its ~4 issue cycles even next to MFMAs (tools/mfma_ubench.hip), so the instruction count matters here.
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("v_max_f32 %0, 0, %0" : "+v"(acc[ib][r]));
 #endif
 }
 
