@@ -347,11 +347,61 @@ class TwoDimPlanesModel(nn.Module):
         P = x.numel() // 6
         if P == 0:
             return torch.empty(list(x.shape[:-1]) + [4], dtype=torch.float32, device=x.device)
+        if self.training and torch.is_grad_enabled() and not (hasattr(self, "SR_model") and not self.skip_SR_):
+            names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
+            planes = [self.planes_[n] for n in names]
+            dec = any(p.requires_grad for p in self.decoder_parameters())
+            if dec or any(p.requires_grad for p in planes):
+                # run_network's differentiable model call (train_utils.py:15-64): gradients for the planes and the decoder
+                out = _DecodePointsFn.apply(self, x.reshape(P, 6), *planes, self.natural_blob(differentiable=True) if dec else None)
+                return out.reshape(list(x.shape[:-1]) + [4])
         sc, keep = self.native_scene()
         packed = self.packed_decoder()
         out = torch.empty((P, 4), dtype=torch.float32, device=x.device)
         capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
         return out.reshape(list(x.shape[:-1]) + [4])
+
+
+class _DecodePointsFn(torch.autograd.Function):
+    """TwoDimPlanesModel.forward on a list of points with gradients for the planes and the decoder.  The points are handed to the
+    ray-tiled training kernels as one-sample rays (origin = point, direction = 0, depth = 0): decode with published ReLU gates (+ the
+    layer-input record when the decoder trains), gate-driven backward, weight-gradient contraction."""
+
+    @staticmethod
+    def forward(ctx, model, x, p0, p1, p2, pv, nat):
+        P, dev = x.shape[0], x.device
+        rays = torch.zeros((P, 11), dtype=torch.float32, device=dev)
+        rays[:, 0:3] = x[:, 0:3]
+        rays[:, 8:11] = x[:, 3:6]
+        z = torch.zeros((P, 1), dtype=torch.float32, device=dev)
+        planes_cl = [to_channel_last(p.detach()) for p in (p0, p1, p2, pv)]
+        sc, keep = model.native_scene(planes=planes_cl)
+        raw = torch.empty((P, 1, 4), dtype=torch.float32, device=dev)
+        gates = torch.empty((P, 1, 32), dtype=torch.int32, device=dev)
+        rec = torch.empty(capi.lib().nvsr_decoder_record_floats(P, 1), dtype=torch.float32, device=dev) if nat is not None else None
+        capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(model.packed_decoder()), P, 1, capi.ptr(rays), capi.ptr(z), capi.ptr(raw),
+                  capi.ptr(gates), capi.ptr(rec), capi.stream())
+        ctx.model, ctx.state = model, (sc, keep, rays, z, gates, rec)
+        return raw.reshape(P, 4)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        model = ctx.model
+        sc, keep, rays, z, gates, rec = ctx.state
+        P, dev = rays.shape[0], rays.device
+        need = ctx.needs_input_grad
+        g_raw = capi.f32c(g_out).reshape(P, 1, 4)
+        gplanes = [torch.zeros_like(k) if need[2 + d] else None for d, k in enumerate(keep)]
+        gptrs = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gplanes]) if any(need[2:6]) else None
+        if gptrs is None and rec is None:
+            return (None,) * 7
+        capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(model.packed_decoder()), capi.ptr(model.packed_decoder_bwd()), P, 1,
+                  capi.ptr(rays), capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, None, capi.ptr(rec), capi.stream())
+        gnat = None
+        if rec is not None and need[6]:
+            gnat = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
+            capi.call("nvsr_decoder_weight_grad", P, 1, capi.ptr(rec), capi.ptr(gnat), capi.stream())
+        return (None, None) + tuple(None if g is None else from_channel_last(g) for g in gplanes) + (gnat,)
 
 
 # =======================================================================================================================

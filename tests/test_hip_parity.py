@@ -956,6 +956,61 @@ def test_composite_backward_vs_autograd_formula(hip):
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale)
 
 
+def test_model_call_is_differentiable_vs_torch_reference(hip):
+    """TwoDimPlanesModel.forward(points) in training mode carries gradients for the planes and the decoder; reference = the same op
+    in plain PyTorch fp32 on the GPU (grid_sample + linear layers, autograd)"""
+    import torch.nn.functional as F
+    g = load_golden("g11_grads.npz")
+    rng = np.random.default_rng(77)
+    planes = [rng.standard_normal((1, 48, 20, 28), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 9, 11), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes20_9"
+    mc, _ = _grad_models(hip, g, planes, sid, what=("planes", "decoder"))
+    P = 1000                                    # ragged against the 128- and 256-point tiles
+    x = np.concatenate([rng.uniform(-4.2, 4.2, (P, 3)), rng.standard_normal((P, 3))], -1).astype(np.float32)
+    x[:, 3:] /= np.linalg.norm(x[:, 3:], axis=-1, keepdims=True)
+    G = T(rng.standard_normal((P, 4)).astype(np.float32))
+    out = mc(T(x))
+    assert out.requires_grad
+    (out * G).sum().backward()
+    got_planes = [N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad) for d in range(4)]
+    got_dec = _decoder_grad_blob(mc)
+    # ---- torch reference
+    box = torch.as_tensor(g["box"], dtype=torch.float64)
+    pl = [T(p).requires_grad_(True) for p in planes]
+    sdc = {k: T(v).requires_grad_(True) for k, v in sd(g, "coarse.").items() if "rot_mats" not in k}
+    xt = T(x)
+    az = torch.atan2(xt[:, 4], xt[:, 3]); el = torch.atan2(xt[:, 5], torch.sqrt(xt[:, 3] ** 2 + xt[:, 4] ** 2))
+    x5 = torch.cat([xt[:, :3], az[:, None], el[:, None]], -1)
+    n5 = 2 * (x5 - box[0].float().to(DEV)) / (box[1] - box[0]).float().to(DEV) - 1
+    rot = [N_(mc.coord_projector.rot_mats_NON_LEARNED[d])[:, 1:] for d in range(3)]
+    feats = []
+    for d in range(3):
+        grid = (n5[:, :3] @ T(rot[d])).reshape(1, P, 1, 2)
+        feats.append(F.grid_sample(pl[d], grid, mode="bilinear", align_corners=True, padding_mode="border")[0, :, :, 0].t())
+    fv = F.grid_sample(pl[3], n5[:, 3:].reshape(1, P, 1, 2), mode="bilinear", align_corners=True, padding_mode="border")[0, :, :, 0].t()
+    hden = torch.stack(feats, 0).mean(0)
+    for l in range(4):
+        hden = torch.relu(F.linear(hden, sdc["density_dec.0.%d.weight" % l], sdc["density_dec.0.%d.bias" % l]))
+    sigma = F.linear(hden, sdc["fc_alpha.0.weight"], sdc["fc_alpha.0.bias"])
+    hrgb = torch.cat(feats + [fv], -1)
+    for l in range(4):
+        hrgb = torch.relu(F.linear(hrgb, sdc["rgb_dec.0.%d.weight" % l], sdc["rgb_dec.0.%d.bias" % l]))
+    rgb = F.linear(hrgb, sdc["fc_rgb.0.weight"], sdc["fc_rgb.0.bias"])
+    ref = torch.cat([rgb, sigma], -1)
+    np.testing.assert_allclose(N_(out), N_(ref), rtol=0, atol=3e-5)
+    (ref * G).sum().backward()
+    for d in range(4):
+        r = N_(pl[d].grad)
+        assert np.linalg.norm(got_planes[d] - r) / np.linalg.norm(r) < 2e-4, "plane %d" % d
+    keys = ["density_dec.0.%d" % i for i in range(4)] + ["fc_alpha.0"] + ["rgb_dec.0.%d" % i for i in range(4)] + ["fc_rgb.0"]
+    ref_dec = np.concatenate([N_(sdc[k + "." + leaf].grad).reshape(-1) for k in keys for leaf in ("weight", "bias")])
+    assert np.linalg.norm(got_dec - ref_dec) / np.linalg.norm(ref_dec) < 2e-4
+    # evaluation mode / no_grad: the plain inference kernel, no graph
+    mc.eval()
+    assert not mc(T(x)).requires_grad
+
+
 def test_coarse_only_training_and_empty_batches(hip, oracle):
     """BASELINE config 1 shape (num_fine = 0): the train step has one pass only; empty ray batches are legal everywhere"""
     g = load_golden("g11_grads.npz")
