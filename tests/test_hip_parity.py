@@ -594,6 +594,44 @@ def test_sr_gradients_vs_oracle_larger(hip, oracle):
     assert _rel(_sr_grad_blob(sr), gw) < 1e-4 and _rel(N_(xd.grad)[0], gx) < 1e-4
 
 
+def test_edsr_forward_backward_vs_torch_reference(hip):
+    """EDSR forward + gradients (all conv weights, input) against the same network written with torch.nn.functional on the GPU
+    (conv2d / relu / pixel_shuffle, fp32 autograd): an independent reference next to the C oracle"""
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    Cc, hid, nb = 48, 64, 4
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, Cc, Cc, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr.train()
+    net = sr.inner_model
+    x = torch.randn(1, Cc, 44, 61, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    out = net(xa)
+    Gm = torch.randn_like(out)
+    (out * Gm).sum().backward()
+    got_w = [w.grad.clone() for w in net.conv_weights()]
+    # reference
+    ws = [w.detach().clone().requires_grad_(True) for w in net.conv_weights()]
+    xb = x.clone().requires_grad_(True)
+    k = 0
+    h = F.conv2d(xb, ws[k]); k += 1
+    for b in range(nb):
+        t = F.conv2d(F.relu(F.conv2d(h, ws[k])), ws[k + 1]); k += 2
+        h = t * 0.1 + h[..., 2:-2, 2:-2]
+    h = F.conv2d(h, ws[k]); k += 1
+    for u in range(2):
+        h = F.pixel_shuffle(F.conv2d(h, ws[k]), 2); k += 1
+    ref = F.conv2d(h, ws[k])
+    assert k == len(ws) - 1 and tuple(ref.shape) == tuple(out.shape)
+    np.testing.assert_allclose(N_(out), N_(ref), rtol=0, atol=3e-5)
+    (ref * Gm).sum().backward()
+    for i, (a, b) in enumerate(zip(got_w, ws)):
+        assert _rel(N_(a), N_(b.grad)) < 1e-4, "conv weight %d" % i
+    assert _rel(N_(xa.grad), N_(xb.grad)) < 1e-4
+
+
 def test_train_step_through_super_resolved_planes(hip, oracle):
     """SR refinement step (what: ['SR']): rays -> ROI -> PlanesSR(ROI) x3 -> render -> loss.backward() fills the EDSR weights' .grad;
     oracle = its own SR forward, render backward wrt the HR planes, SR backward, chained on the host"""
