@@ -1049,6 +1049,92 @@ def test_model_call_is_differentiable_vs_torch_reference(hip):
     assert not mc(T(x)).requires_grad
 
 
+def _torch_decoder(hip, model, planes_t, state, box, x):
+    """TwoDimPlanesModel.forward in plain PyTorch (grid_sample + linear layers) for [P,6] points"""
+    import torch.nn.functional as F
+    P = x.shape[0]
+    az = torch.atan2(x[:, 4], x[:, 3]); el = torch.atan2(x[:, 5], torch.sqrt(x[:, 3] ** 2 + x[:, 4] ** 2))
+    x5 = torch.cat([x[:, :3], az[:, None], el[:, None]], -1)
+    n5 = 2 * (x5 - box[0].float().to(DEV)) / (box[1] - box[0]).float().to(DEV) - 1
+    feats = []
+    for d in range(3):
+        rot = model.coord_projector.rot_mats_NON_LEARNED[d].detach()[:, 1:]
+        grid = (n5[:, :3] @ rot).reshape(1, P, 1, 2)
+        feats.append(F.grid_sample(planes_t[d], grid, mode="bilinear", align_corners=True, padding_mode="border")[0, :, :, 0].t())
+    fv = F.grid_sample(planes_t[3], n5[:, 3:].reshape(1, P, 1, 2), mode="bilinear", align_corners=True, padding_mode="border")[0, :, :, 0].t()
+    hden = torch.stack(feats, 0).mean(0)
+    for l in range(4):
+        hden = torch.relu(F.linear(hden, state["density_dec.0.%d.weight" % l], state["density_dec.0.%d.bias" % l]))
+    sigma = F.linear(hden, state["fc_alpha.0.weight"], state["fc_alpha.0.bias"])
+    hrgb = torch.cat(feats + [fv], -1)
+    for l in range(4):
+        hrgb = torch.relu(F.linear(hrgb, state["rgb_dec.0.%d.weight" % l], state["rgb_dec.0.%d.bias" % l]))
+    return torch.cat([F.linear(hrgb, state["fc_rgb.0.weight"], state["fc_rgb.0.bias"]), sigma], -1)
+
+
+def test_render_step_vs_torch_reference(hip):
+    """3 000 rays, 48 + 96 samples: the whole predict_and_render_radiance chain restated with torch ops on the GPU (linspace depths,
+    grid_sample decoder, cumprod compositing, cumsum / searchsorted inverse-CDF sampling, sort) against run_one_iter_of_nerf; forward
+    and the gradient of a random linear functional of both images with respect to the planes"""
+    g = load_golden("g11_grads.npz")
+    rng = np.random.default_rng(55)
+    planes = [rng.standard_normal((1, 48, 48, 40), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 12, 10), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes48_12"
+    mc, mf = _grad_models(hip, g, planes, sid, what=("planes",))
+    N, nc, nf = 3000, 48, 96
+    H = W = 64
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(load_golden("g08_render.npz")["pose"]))
+    sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
+    ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+    opts, scfg = make_options(nc, nf)
+    out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, torch.stack([ro, rd], 0), opts, sid, mode="train", scene_config=scfg, randoms={})
+    gc, gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N), T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+    ((out[0] * gc).sum() + (out[3] * gf).sum()).backward()
+    got = [N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad) for d in range(4)]
+    # ---- reference chain
+    box = torch.as_tensor(g["box"], dtype=torch.float64)
+    pl = [T(p).requires_grad_(True) for p in planes]
+    st_c = {k: T(v) for k, v in sd(g, "coarse.").items()}
+    st_f = {k: T(v) for k, v in sd(g, "fine.").items()}
+    vd = rd / rd.norm(dim=-1, keepdim=True)
+
+    def render(model, st, z):
+        pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
+        x = torch.cat([pts, vd[:, None, :].expand_as(pts)], -1).reshape(-1, 6)
+        raw = _torch_decoder(hip, model, pl, st, box, x).reshape(N, -1, 4)
+        dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((N, 1), 1e10, device=DEV)], -1) * rd.norm(dim=-1, keepdim=True)
+        alpha = 1.0 - torch.exp(-torch.relu(raw[..., 3]) * dists)
+        Tr = torch.cumprod(torch.cat([torch.ones(N, 1, device=DEV), (1.0 - alpha + 1e-10)[:, :-1]], -1), -1)
+        w = alpha * Tr
+        return (w[..., None] * torch.sigmoid(raw[..., :3])).sum(1), w
+
+    t = torch.linspace(0.0, 1.0, nc, device=DEV)
+    z_c = (2.0 * (1.0 - t) + 6.0 * t).expand(N, nc)
+    rgb_c, w_c = render(mc, st_c, z_c)
+    with torch.no_grad():
+        z_mid = 0.5 * (z_c[:, 1:] + z_c[:, :-1])
+        wts = w_c[:, 1:-1] + 1e-5
+        cdf = torch.cat([torch.zeros(N, 1, device=DEV), torch.cumsum(wts / wts.sum(-1, keepdim=True), -1)], -1)
+        u = torch.linspace(0.0, 1.0, nf, device=DEV).expand(N, nf).contiguous()
+        inds = torch.searchsorted(cdf, u, right=True)
+        below, above = torch.clamp(inds - 1, min=0), torch.clamp(inds, max=cdf.shape[-1] - 1)
+        c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+        b0, b1 = torch.gather(z_mid, 1, below), torch.gather(z_mid, 1, above)
+        den = c1 - c0
+        den = torch.where(den < 1e-5, torch.ones_like(den), den)
+        z_f = torch.sort(torch.cat([z_c, b0 + (u - c0) / den * (b1 - b0)], -1), -1)[0]
+    rgb_f, _ = render(mf, st_f, z_f)
+    np.testing.assert_allclose(N_(out[0]), N_(rgb_c), rtol=0, atol=3e-5)
+    err = (out[3] - rgb_f).abs().max(-1)[0]
+    assert float((err <= 2e-4).float().mean()) >= 0.98 and psnr(N_(out[3]), N_(rgb_f)) >= 70.0
+    ((rgb_c * gc).sum() + (rgb_f * gf).sum()).backward()
+    for d in range(4):
+        r = N_(pl[d].grad)
+        assert np.linalg.norm(got[d] - r) / np.linalg.norm(r) < 1e-2, "plane %d" % d
+
+
 def test_coarse_only_training_and_empty_batches(hip, oracle):
     """BASELINE config 1 shape (num_fine = 0): the train step has one pass only; empty ray batches are legal everywhere"""
     g = load_golden("g11_grads.npz")
