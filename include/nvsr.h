@@ -40,7 +40,9 @@ typedef enum {
 #define NVSR_DEC_CHANNELS 128
 #define NVSR_DEC_LAYERS 4
 #define NVSR_DECODER_NATURAL_FLOATS 130564 /* state-dict order, see nvsr_pack_decoder */
-#define NVSR_DECODER_PACKED_FLOATS 130576  /* MFMA-fragment order + biases/heads */
+#define NVSR_DECODER_PACKED_F32_FLOATS 130576 /* f32 MFMA-fragment order + biases/heads */
+/* packed blob = [f32 fragments + biases/heads][bf16 fragments, 3 limbs per weight][bf16 fragments, 2 limbs per weight] (32-bit words) */
+#define NVSR_DECODER_PACKED_FLOATS 453136
 #define NVSR_DECODER_PACKED_BWD_FLOATS 139264 /* transposed layers for the backward pass, see nvsr_pack_decoder_bwd */
 
 /* One scene = 3 position planes + 1 view-direction plane, CHANNEL-LAST [H][W][48] (192 B per texel), the per-scene
@@ -54,6 +56,20 @@ typedef struct nvsr_scene {
 } nvsr_scene;
 
 int nvsr_version(void);
+
+/* Arithmetic of the decoder GEMMs inside the fused render pass (nvsr_render_pass*, N >= 16384 rays).  Inputs, outputs, accumulation
+ * and everything outside the GEMMs are f32 in every mode.
+ *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products
+ *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs, 6 of the 9 limb products on v_mfma_f32_32x32x16_bf16
+ *                     (dropped terms <= 2^-24 |w||x| per product: f32-grade), 2.7x the f32 matrix rate
+ *   NVSR_ARITH_BF16X2 2 limbs (16 significant bits per operand), 3 products, 5.3x
+ * Process-wide; the initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | bf16x2. */
+#define NVSR_ARITH_F32 0
+#define NVSR_ARITH_BF16X2 2
+#define NVSR_ARITH_BF16X3 3
+#define NVSR_ARITH_DEFAULT NVSR_ARITH_F32
+int nvsr_get_decoder_arithmetic(void);
+int nvsr_set_decoder_arithmetic(int mode);
 
 /* ---- data layout ------------------------------------------------------------------------------------------------ */
 /* [C,H,W] (reference plane layout, models.py:436-439) -> channel-last [H,W,C]; and back. */

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("NVSR_HIP_LIB", _DEFAULT_LIB_PATH)
 PLANE_CHANNELS = 48
 DEC_CHANNELS = 128
 DECODER_NATURAL_FLOATS = 130564
-DECODER_PACKED_FLOATS = 130576
+DECODER_PACKED_FLOATS = 453136
 DECODER_PACKED_BWD_FLOATS = 139264
 
 _STATUS = {1: "NVSR_ERR_SHAPE (argument out of the supported range)", 2: "NVSR_ERR_LAUNCH (kernel launch failed)",
@@ -37,6 +37,8 @@ class Scene(C.Structure):
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _PROTOS = {
     "nvsr_version": ([], C.c_int),
+    "nvsr_get_decoder_arithmetic": ([], C.c_int),
+    "nvsr_set_decoder_arithmetic": ([_i], _i),
     "nvsr_plane_to_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "nvsr_plane_from_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "nvsr_pack_decoder": ([_vp, _vp, _vp], _i),
@@ -105,6 +107,19 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
 }
 
 _lib = None
+
+
+ARITHMETIC = {"f32": 0, "bf16x2": 2, "bf16x3": 3}
+
+
+def set_decoder_arithmetic(mode):
+    """Arithmetic of the decoder GEMMs inside the fused render pass: 'f32' | 'bf16x3' | 'bf16x2' (include/nvsr.h, NVSR_ARITH_*)."""
+    call("nvsr_set_decoder_arithmetic", ARITHMETIC[mode])
+
+
+def get_decoder_arithmetic():
+    code = lib().nvsr_get_decoder_arithmetic()
+    return {v: k for k, v in ARITHMETIC.items()}[code]
 
 
 def exported_symbols():

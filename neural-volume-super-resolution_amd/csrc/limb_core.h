@@ -1,0 +1,148 @@
+// f32 GEMM on the bf16 matrix pipe: operands split into bf16 limbs (render3.hip).
+//
+// v_mfma_f32_32x32x2_f32 retires 32 MAC / cycle / SIMD, v_mfma_f32_32x32x16_bf16 512.  An f32 value is EXACTLY the sum of three bf16
+// values taken by truncation (8 + 8 + 8 significant bits):  x = xh + xm + xl, and a product of two bf16 values is exact in f32.  So
+//     W x  =  Wh(xh + xm + xl) + Wm(xh + xm) + Wl xh   +  [Wm xl + Wl xm + Wl xl]
+// where the bracket is <= 2^-24 |W||x| per product, the size of one f32 rounding: six bf16 MFMAs with f32 accumulation give an f32-grade
+// product at 16/6 = 2.7x the rate of the f32 MFMA (LIMBS = 3).  LIMBS = 2 keeps 16 bits per operand (second limb rounded to nearest,
+// 3 products, error <= 2^-15 |W||x| per product) at 5.3x.
+//
+// Fragment layout: A = weights [32 out x 16 in], B = activations [16 in x 32 points].  Lane l = (m | n = l & 31, h = l >> 5) holds the
+// 8 k-values 8h .. 8h+7 of its row / column as 4 words {bf16 k even (low half), bf16 k odd (high half)}.  The C/D layout of a 32x32
+// tile (register r of lane (n, h) = row 8(r>>2) + 4h + (r&3)) makes the 8 registers acc[ib][8q .. 8q+7] of a lane the B operand of
+// K-block (ib, q) of the next layer once the weights are packed with the same k-order -- layers chain through registers.
+#pragma once
+#include "decode_core.h"
+
+namespace nvsr {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int limb_products(int limbs) { return limbs == 3 ? 6 : 3; }
+// product p of a (weight limb, activation limb) set, small terms first
+constexpr int limb_w(int limbs, int p) { return limbs == 3 ? (p < 3 ? 0 : p < 5 ? 1 : 2) : (p < 2 ? 0 : 1); }
+constexpr int limb_x(int limbs, int p) { return limbs == 3 ? (p == 0 ? 2 : p == 1 ? 1 : p == 2 ? 0 : p == 3 ? 1 : 0) : (p == 0 ? 1 : 0); }
+
+// K-blocks (16 input channels each) of the decoder in consumption order
+constexpr int KB_RGB0 = 0;          // 4 planes x 3
+constexpr int KB_RGB1 = 12;         // 3 layers x 8
+constexpr int KB_DEN0 = 36;         // 3
+constexpr int KB_DEN1 = 39;         // 3 layers x 8
+constexpr int KB_TOTAL = 63;
+constexpr int kb_words(int limbs) { return 4 * limbs * 256; }                 // [ob 0..3][limb][lane][4 words]
+constexpr int P_LIMB3 = NVSR_DECODER_PACKED_F32_FLOATS;                       // fragment regions behind the f32 blob
+constexpr int P_LIMB2 = P_LIMB3 + KB_TOTAL * kb_words(3);
+static_assert(P_LIMB2 + KB_TOTAL * kb_words(2) == NVSR_DECODER_PACKED_FLOATS, "packed blob size");
+constexpr int limb_region(int limbs) { return limbs == 3 ? P_LIMB3 : P_LIMB2; }
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// {bf16 trunc(e1), bf16 trunc(e0)}: the high halves of two f32 registers in one v_perm_b32
+__device__ __forceinline__ unsigned trunc_pair(float e1, float e0) {
+    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+// x minus its leading 8 significant bits (exact)
+__device__ __forceinline__ float limb_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ unsigned round_pair(float e1, float e0) {          // v_cvt_pk_bf16_f32, round to nearest even
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{e0, e1}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int LIMBS> struct Limbs { u32x4 v[LIMBS]; };
+struct SplitPend { float r0, r1; };
+
+// The split of a K-block's 8 values get(0..7) into limbs, cut into 4 * NP slices (NP = products per fragment pair = MFMAs of one
+// output block): pair j = slice / NP handles values 2j, 2j+1 -> word j of every limb.  <= 3 VALU per slice.
+template <int LIMBS, class Get>
+__device__ __forceinline__ void split_slice(int slice, Get get, Limbs<LIMBS>& out, SplitPend& p) {
+    constexpr int NP = limb_products(LIMBS);
+    const int j = slice / NP, st = slice % NP;
+    if (j >= 4) return;
+    if (LIMBS == 3) {
+        if (st == 0) { out.v[0][j] = trunc_pair(get(2 * j + 1), get(2 * j)); p.r0 = limb_rest(get(2 * j)); }
+        if (st == 1) { p.r1 = limb_rest(get(2 * j + 1)); }
+        if (st == 2) { out.v[1][j] = trunc_pair(p.r1, p.r0); }
+        if (st == 3) { p.r0 = limb_rest(p.r0); }
+        if (st == 4) { p.r1 = limb_rest(p.r1); }
+        if (st == 5) { out.v[2][j] = trunc_pair(p.r1, p.r0); }
+    } else {
+        if (st == 0) { out.v[0][j] = trunc_pair(get(2 * j + 1), get(2 * j)); p.r0 = limb_rest(get(2 * j)); }
+        if (st == 1) { p.r1 = limb_rest(get(2 * j + 1)); }
+        if (st == 2) { out.v[1][j] = round_pair(p.r1, p.r0); }
+    }
+}
+template <int LIMBS, class Get>
+__device__ __forceinline__ void split_all(Get get, Limbs<LIMBS>& out) {
+    SplitPend p;
+#pragma unroll
+    for (int s = 0; s < 4 * limb_products(LIMBS); ++s) split_slice<LIMBS>(s, get, out, p);
+}
+
+// steps [0, NSTEPS) of a piece of side work spread evenly over the slots [S0, S1) of a block
+template <int NSTEPS, int S0, int S1, class F>
+__device__ __forceinline__ void spread(int slot, F f) {
+    constexpr int NS = S1 - S0, PER = (NSTEPS + NS - 1) / NS + 1;
+    if (slot < S0 || slot >= S1) return;
+    const int a = (slot - S0) * NSTEPS / NS, b = (slot - S0 + 1) * NSTEPS / NS;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (a + k < b) f(a + k);
+}
+
+struct NoTail {};
+
+// One block: acc[0..3] (+)= W[chunk K-blocks 0..NKB-1] x (limbs of the source), 4 * NKB * NP MFMAs.
+//   cur   : limbs of K-block 0 on entry; on exit the limbs the tail produced (the next block's K-block 0) -- unchanged without a tail
+//   fa    : A fragments of (K-block 0, output block 0); LOAD_FIRST reads them here, otherwise they come from the previous block on the
+//           same chunk, whose last slots prefetch them (the fragment index wraps around)
+//   src(kb, i): value i of K-block kb of this block (read when K-block kb - 1 is being multiplied)
+//   side(slot): the other tile's work, slot = ((kb * 4 + ob) * NP + p)
+//   tail(slice, nxt): 4 * NP slices during the last K-block, to split the next block's first K-block into nxt
+template <int LIMBS, int NKB, bool ZERO, bool LOAD_FIRST, class Src, class Side, class Tail>
+__device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 (&acc)[4], Limbs<LIMBS>& cur, Limbs<LIMBS>& fa, Src src,
+                                           Side side, Tail tail) {
+    constexpr int NP = limb_products(LIMBS), NQ = NKB * 4;
+    constexpr bool HAS_TAIL = !std::is_same<Tail, NoTail>::value;
+    const u32x4* wv = reinterpret_cast<const u32x4*>(wl) + lane;
+    if (LOAD_FIRST) {
+#pragma unroll
+        for (int t = 0; t < LIMBS; ++t) fa.v[t] = wv[t * 64];
+    }
+    SplitPend sp;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        Limbs<LIMBS> nxt;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            Limbs<LIMBS> fn;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int q = kb * 4 + ob;
+                if (ZERO && kb == 0 && p == 0) {
+                    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[ob] = mfma_bf16(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], zero);
+                } else {
+                    acc[ob] = mfma_bf16(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], acc[ob]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < LIMBS) fn.v[p] = wv[(((q + 1) % NQ) * LIMBS + p) * 64];
+                if (kb + 1 < NKB) split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);
+                side(q * NP + p);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < LIMBS; ++t) fa.v[t] = fn.v[t];
+        }
+        if (kb + 1 < NKB || HAS_TAIL) {
+#pragma unroll
+            for (int t = 0; t < LIMBS; ++t) cur.v[t] = nxt.v[t];
+        }
+    }
+}
+
+}  // namespace nvsr

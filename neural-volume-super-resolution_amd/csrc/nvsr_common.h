@@ -50,7 +50,7 @@ constexpr int S_ALPHA_W = 8 * HID;                              // 1024
 constexpr int S_RGB_W = S_ALPHA_W + HID;                        // 1152
 constexpr int S_HEAD_B = S_RGB_W + 3 * HID;                     // 1536: alpha_b, rgb_b[3]
 constexpr int SMALL_FLOATS = 1552;                              // padded to a multiple of 16 B
-static_assert(P_SMALL + SMALL_FLOATS == NVSR_DECODER_PACKED_FLOATS, "packed blob size");
+static_assert(P_SMALL + SMALL_FLOATS == NVSR_DECODER_PACKED_F32_FLOATS, "packed blob size");
 
 struct SceneDev {
     const float* plane[4];

@@ -17,6 +17,8 @@
 //     (the reference's exclusive cumprod, in the same order) and only per-ray results are written.
 #include <cstdlib>
 
+#include <cstring>
+
 #include "decode_core.h"
 
 namespace nvsr {
@@ -181,7 +183,7 @@ __device__ __forceinline__ int bias_src(int layer, int f) {
 
 __global__ void pack_decoder_kernel(const float* __restrict__ nat, float* __restrict__ packed) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NVSR_DECODER_PACKED_FLOATS) return;
+    if (idx >= NVSR_DECODER_PACKED_F32_FLOATS) return;
     int src = -1;
     if (idx < P_SMALL) {
         const int j = idx & 3, lane = (idx >> 2) & 63, ib = (idx >> 8) & 3;
@@ -222,15 +224,40 @@ using namespace nvsr;
 extern "C" int nvsr_render_pass2_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                         const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
                                         float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
+extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                        const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
+                                        float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
+extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packed, nvsr_stream_t stream);
+
+// arithmetic of the fused render pass (process-wide): -1 = not yet read from the environment
+static int g_decoder_arithmetic = -1;
 
 extern "C" {
+
+int nvsr_get_decoder_arithmetic(void) {
+    if (g_decoder_arithmetic < 0) {
+        const char* e = getenv("NVSR_DECODER_ARITHMETIC");
+        g_decoder_arithmetic = NVSR_ARITH_DEFAULT;
+        if (e && !strcmp(e, "f32")) g_decoder_arithmetic = NVSR_ARITH_F32;
+        if (e && !strcmp(e, "bf16x3")) g_decoder_arithmetic = NVSR_ARITH_BF16X3;
+        if (e && !strcmp(e, "bf16x2")) g_decoder_arithmetic = NVSR_ARITH_BF16X2;
+    }
+    return g_decoder_arithmetic;
+}
+
+int nvsr_set_decoder_arithmetic(int mode) {
+    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_BF16X2) return NVSR_ERR_SHAPE;
+    g_decoder_arithmetic = mode;
+    return NVSR_OK;
+}
 
 int nvsr_pack_decoder(const float* natural, float* packed, nvsr_stream_t stream) {
     if (!natural || !packed) return NVSR_ERR_NULL;
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
-    const int n = NVSR_DECODER_PACKED_FLOATS;
+    const int n = NVSR_DECODER_PACKED_F32_FLOATS;
     hipLaunchKernelGGL(pack_decoder_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, packed);
-    return NVSR_CHECK_LAUNCH();
+    if (hipGetLastError() != hipSuccess) return NVSR_ERR_LAUNCH;
+    return nvsr_pack_decoder_limbs_launch(natural, packed, stream);
 }
 
 static int check_scene(const nvsr_scene* s) {
@@ -292,8 +319,12 @@ int nvsr_render_pass_ex(const nvsr_scene* scene, const float* packed_decoder, in
     if (!aligned16(packed_decoder) || (raw_out && !aligned16(raw_out))) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    if (N >= 16384 && !getenv("NVSR_RENDER_V1"))     // two-tiles-per-wave kernel (render2.hip); NVSR_RENDER_V1=1 selects the first-generation kernel
+    if (N >= 16384 && !getenv("NVSR_RENDER_V1")) {   // two-tiles-per-wave kernels; NVSR_RENDER_V1=1 selects the first-generation kernel
+        const int arith = nvsr_get_decoder_arithmetic();
+        if (arith != NVSR_ARITH_F32)                 // bf16-limb matrix pipe (render3.hip)
+            return nvsr_render_pass3_launch(arith, scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, stream);
         return nvsr_render_pass2_launch(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, stream);
+    }
     const int64_t grid = (N + PTS_PER_WG - 1) / PTS_PER_WG;
     if (grid > 0x7fffffff) return NVSR_ERR_SHAPE;
     hipLaunchKernelGGL(render_pass_kernel, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,

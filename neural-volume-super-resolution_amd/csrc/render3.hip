@@ -1,0 +1,427 @@
+// Fused render pass, third generation: the decoder GEMMs on the bf16 matrix pipe with every f32 operand split into bf16 limbs
+// (limb_core.h) -- f32-grade products at 2.7x (3 limbs) or 16-bit operands at 5.3x (2 limbs) the rate of v_mfma_f32_32x32x2_f32.
+//
+// Same skeleton as render2.hip: one wave per SIMD owns two 32-point tiles X and Y; while the matrix pipe multiplies one tile, the other
+// tile's gathers / bias + ReLU / heads are issued in the gaps.  What changes with a 32-cycle MFMA: a gap hides ~5 single-issue
+// instructions (measured, tools/limb_ubench.hip: 32.5 cycles per MFMA bare, 34.4 with the limb split of the next K-block in the gaps,
+// 35.4 with 3 more VALU per gap, 42 with 5 more), so all side work is cut into slices of <= 3 VALU and spread over the slots of a block.
+//
+// Per sample and tile: 63 K-blocks (16 input channels) x 4 output blocks x NP MFMAs; weights stream through a 2-slot LDS ring in 17
+// chunks (a plane's share of a feature layer = 3 K-blocks, half a hidden layer = 4), 12 * LIMBS KB per K-block.
+// Biases are not preloaded into the accumulators: the first MFMA of a layer takes C = 0 and act = max(acc + bias, 0).
+#include <type_traits>
+#include <utility>
+
+#include "limb_core.h"
+#include "side_work.h"
+
+#ifndef R3_TAPS
+#define R3_TAPS 4
+#endif
+namespace nvsr {
+
+constexpr int RAY3_FLOATS = 16;
+template <int LIMBS>
+struct Lds3 {
+    static constexpr int SLOT = 4 * kb_words(LIMBS);                 // words: 48 KB (3 limbs) / 32 KB
+    static constexpr int SMALL = 2 * SLOT;
+    static constexpr int RAYS = SMALL + SMALL_FLOATS;
+    static constexpr int TOTAL = RAYS + RAYS2 * RAY3_FLOATS;
+};
+static_assert(Lds3<3>::TOTAL * 4 <= 160 * 1024, "LDS budget");
+
+struct Tile3 {
+    f32x16 acc[4];   // layer accumulators (AGPRs), written by MFMAs only
+    f32x16 act[4];   // max(acc + bias, 0) of the finished layer (VGPRs)
+    float D[HALF_C], F[HALF_C];
+    float T, cr, cg, cb, dep, ac, zc, zn;
+    float raw[4];
+};
+
+// four tap buffers (96 registers; the activation sets are dead while planes are gathered): every load of a gather is issued in the
+// first slots of a block and blended in its last quarter
+struct RawTaps4 { f32x4 r[4][HALF_C / 4]; };
+constexpr int GATHER_STEPS = 12 + HALF_C;
+__device__ __forceinline__ void gather4_load(int k, const GatherJob& job, int h, RawTaps4& rt) {           // k 0..11: tap k/3, 2 loads
+    const int tap = k / 3, i0 = 2 * (k % 3);
+    const int off = tap == 0 ? job.t.o00 : tap == 1 ? job.t.o01 : tap == 2 ? job.t.o10 : job.t.o11;
+    const f32x4* p = reinterpret_cast<const f32x4*>(job.plane + off + HALF_C * h);
+    rt.r[tap][i0] = p[i0];
+    rt.r[tap][i0 + 1] = p[i0 + 1];
+}
+__device__ __forceinline__ void gather4_blend(int c, const GatherJob& job, const RawTaps4& rt, float (&F)[HALF_C]) {   // channel c
+    const int i = c >> 2, j = c & 3;
+    F[c] = fmaf(rt.r[3][i][j], job.t.se, fmaf(rt.r[2][i][j], job.t.sw, fmaf(rt.r[1][i][j], job.t.ne, rt.r[0][i][j] * job.t.nw)));
+}
+
+// act = max(acc + bias, 0): 64 elements in 68 steps (a bias quad is read 4 steps before its first use)
+constexpr int RELU_STEPS = 68;
+struct BiasPend4 { f32x4 v[2]; };
+__device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, const f32x16 (&acc)[4], f32x16 (&act)[4], BiasPend4& pend) {
+    if ((k & 3) == 0 && k < 64) pend.v[(k >> 2) & 1] = *reinterpret_cast<const f32x4*>(bias + (k >> 2) * 8 + h * 4);
+    if (k >= 4) {
+        const int r = k - 4;
+        act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15] + pend.v[(r >> 2) & 1][r & 3], 0.0f);
+    }
+}
+
+template <int LIMBS>
+struct Ring3 {
+    const unsigned* blob;   // fragment region of the packed blob
+    unsigned* lds;
+    int slot;
+    int wave, lane;
+    unsigned voff;
+};
+template <int LIMBS, int NKB>
+__device__ __forceinline__ const unsigned* ring3_issue(Ring3<LIMBS>& rs, int kb0) {
+    unsigned* dst = rs.lds + rs.slot * Lds3<LIMBS>::SLOT;
+    stage_chunk<NW2, NKB * 4 * LIMBS>(reinterpret_cast<const float*>(rs.blob + kb0 * kb_words(LIMBS)), reinterpret_cast<float*>(dst), rs.voff, rs.wave);
+    rs.slot ^= 1;
+    return dst;
+}
+
+// =====================================================================================================================
+template <int LIMBS>
+__global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                              const float* __restrict__ rays, const float* __restrict__ z,
+                                                              const float* __restrict__ noise, int white,
+                                                              float* __restrict__ rgb, float* __restrict__ disp,
+                                                              float* __restrict__ acc, float* __restrict__ weights,
+                                                              float* __restrict__ depth, float* __restrict__ raw_out) {
+    using L = Lds3<LIMBS>;
+    constexpr int NP = limb_products(LIMBS);
+    constexpr int NSF = 3 * 4 * NP, NSH = 4 * 4 * NP;          // slots of a feature block / of half a hidden layer
+    __shared__ __attribute__((aligned(16))) unsigned lds[L::TOTAL];
+    Ring3<LIMBS> rs{reinterpret_cast<const unsigned*>(packed) + limb_region(LIMBS), lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63),
+                    (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    float* ldsf = reinterpret_cast<float*>(lds);
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) ldsf[L::SMALL + i] = packed[P_SMALL + i];
+    const float* small = ldsf + L::SMALL;
+
+    const int lane0 = rs.lane;
+    const long base = (long)blockIdx.x * RAYS2 + rs.wave * 64 + (lane0 & 31);
+    long rayX = base, rayY = base + 32;
+    const bool validX = rayX < N, validY = rayY < N;
+    if (!validX) rayX = N - 1;
+    if (!validY) rayY = N - 1;
+    float* rcX = ldsf + L::RAYS + (rs.wave * 64 + (lane0 & 31)) * RAY3_FLOATS;
+    float* rcY = rcX + 32 * RAY3_FLOATS;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* r = rays + (k ? rayY : rayX) * 11;
+        float* rc = k ? rcY : rcX;
+        const float dx = r[3], dy = r[4], dz = r[5];
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        if (lane0 < 32) {
+            reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], dx};
+            reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, 0.0f};
+            reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
+            reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
+        }
+    }
+    const float* zX = z + rayX * S;
+    const float* zY = z + rayY * S;
+
+    Tile3 X, Y;
+    X.T = Y.T = 1.0f;
+    X.cr = X.cg = X.cb = X.dep = X.ac = 0.0f;
+    Y.cr = Y.cg = Y.cb = Y.dep = Y.ac = 0.0f;
+    X.zc = zX[0]; Y.zc = zY[0];
+    RawTaps4 rt;
+    RawTaps2 rt2;
+
+    auto point_norm = [&](const float* rc, float zc, float& n0, float& n1, float& n2) {
+        const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
+        n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
+        n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
+        n2 = norm_coord(__fadd_rn(c0[2], __fmul_rn(c1[1], zc)), sc.lo[2], sc.range[2]);
+    };
+    auto view_job = [&](const float* rc) {
+        const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
+        GatherJob j;
+        j.plane = sc.plane[3];
+        j.t.o00 = __float_as_int(c2[0]); j.t.o01 = __float_as_int(c2[1]); j.t.o10 = __float_as_int(c2[2]); j.t.o11 = __float_as_int(c2[3]);
+        j.t.nw = c3[0]; j.t.ne = c3[1]; j.t.sw = c3[2]; j.t.se = c3[3];
+        return j;
+    };
+
+    Limbs<LIMBS> cur, fa;
+    const unsigned* cw = ring3_issue<LIMBS, 3>(rs, KB_RGB0);      // chunk 0 of sample 0; every later one is issued during the previous sample
+    for (int s = 0; s < S; ++s) {
+        asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+        const int lane = rs.lane, h = lane >> 5;
+        const bool last = (s + 1 == S);
+        X.zn = last ? 0.0f : zX[s + 1];
+        Y.zn = last ? 0.0f : zY[s + 1];
+        const float nzX = noise ? noise[rayX * S + s] : 0.0f;
+        const float nzY = noise ? noise[rayY * S + s] : 0.0f;
+        float xn0, xn1, xn2, yn0, yn1, yn2;
+        point_norm(rcX, X.zc, xn0, xn1, xn2);
+        point_norm(rcY, Y.zc, yn0, yn1, yn2);
+        BiasPend4 bp;
+        HeadPend<3> hp3;
+        HeadPend<1> hp1;
+        SplitPend tp;
+        GatherJob job;
+
+        // side-work pieces
+        auto gather = [&](Tile3& t) {                                          // the whole gather of `job` into t.F inside a feature block
+            return [&](int slot) {
+#if R3_TAPS == 4
+                spread<12, 0, NSF / 6>(slot, [&](int k) { gather4_load(k, job, h, rt); });
+                spread<HALF_C, 3 * NSF / 4, NSF>(slot, [&](int c) { gather4_blend(c, job, rt, t.F); });
+#else
+                spread<96, 0, NSF>(slot, [&](int k) { gather_side(k >> 2, k & 3, job, h, rt2, t.F); });
+#endif
+            };
+        };
+        auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
+        auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
+        auto split_feat = [&](const float (&f)[HALF_C]) { split_all<LIMBS>([&f](int i) { return f[i]; }, cur); };
+        // tail: split K-block kb of t.act into the limbs the next block starts with
+        auto tail_of = [&](const f32x16 (&a)[4], int kb) {
+            return [&a, kb, &tp](int slice, Limbs<LIMBS>& nxt) { split_slice<LIMBS>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+        };
+        auto none = [](int) {};
+
+        // ---- prologue (exposed): plane 0 of X gathered and blended; chunk 0 has been in flight since the previous sample's last chunk
+        job.plane = sc.plane[0]; job.t = pos_taps2(sc, 0, xn0, xn1, xn2);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gather4_load(k, job, h, rt);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) gather4_blend(c, job, rt, X.F);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
+        ring2_sync();
+        const unsigned* nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 3);
+
+        // ---- rgb layer 0: 4 planes x (X block, Y block) -----------------------------------------------------------------------
+        // X plane 0 | Y: gather plane 0
+        job.plane = sc.plane[0]; job.t = pos_taps2(sc, 0, yn0, yn1, yn2);
+        split_feat(X.F);
+        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) Y.D[c] = Y.F[c];
+        // Y plane 0 | X: gather plane 1
+        job.plane = sc.plane[1]; job.t = pos_taps2(sc, 1, xn0, xn1, xn2);
+        split_feat(Y.F);
+        limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) X.D[c] = __fadd_rn(X.D[c], X.F[c]);
+        cw = nw;
+        ring2_sync();
+        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 6);
+        // X plane 1 | Y: gather plane 1
+        job.plane = sc.plane[1]; job.t = pos_taps2(sc, 1, yn0, yn1, yn2);
+        split_feat(X.F);
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) Y.D[c] = __fadd_rn(Y.D[c], Y.F[c]);
+        // Y plane 1 | X: gather plane 2, D = (D + F) / 3   (combine_pos_planes 'avg', models.py:358-359)
+        job.plane = sc.plane[2]; job.t = pos_taps2(sc, 2, xn0, xn1, xn2);
+        split_feat(Y.F);
+        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) X.D[c] = div3(__fadd_rn(X.D[c], X.F[c]));
+        cw = nw;
+        ring2_sync();
+        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 9);
+        // X plane 2 | Y: gather plane 2
+        job.plane = sc.plane[2]; job.t = pos_taps2(sc, 2, yn0, yn1, yn2);
+        split_feat(X.F);
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) Y.D[c] = div3(__fadd_rn(Y.D[c], Y.F[c]));
+        // Y plane 2 | X: gather view plane
+        job = view_job(rcX);
+        split_feat(Y.F);
+        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
+        cw = nw;
+        ring2_sync();
+        nw = ring3_issue<LIMBS, 4>(rs, KB_RGB1);
+        // X view plane | Y: gather view plane
+        job = view_job(rcY);
+        split_feat(X.F);
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+        // Y view plane | X: act = max(acc + bias, 0); tail: limbs of X's K-block 0
+        split_feat(Y.F);
+        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F),
+                                           [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp); }); },
+                                           tail_of(X.act, 0));
+        cw = nw;
+
+        // ---- hidden layers.  Layer l of a decoder = chunks a (K-blocks 0..3), b (4..7):
+        //   X a | Y: act of layer l-1; tail Y kb 0        Y a | tail X kb 4        X b | tail Y kb 4        Y b | X: act of layer l; tail X kb 0
+        auto relu_side = [&](Tile3& t, int bias_vec) {
+            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp); }); };
+        };
+        // hidden layer with bias vectors: vprev (layer l-1, finishing Y) and vthis (layer l, finishing X); kbn = next chunk to issue (two per layer)
+#define NVSR_HIDDEN_LAYER(VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                              \
+        ring2_sync();                                                                                                               \
+        nw = ring3_issue<LIMBS, NKB_A>(rs, KB_NEXT_A);                                                                              \
+        limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0), relu_side(Y, VPREV), tail_of(Y.act, 0));         \
+        limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
+        cw = nw;                                                                                                                    \
+        ring2_sync();                                                                                                               \
+        nw = ring3_issue<LIMBS, NKB_B>(rs, KB_NEXT_B);                                                                              \
+        limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4), none, tail_of(Y.act, 4));                        \
+        X_B_SIDE;                                                                                                                   \
+        cw = nw;
+
+        // rgb layers 1, 2: Y b | X relu, tail X kb 0
+#define NVSR_YB_PLAIN(VTHIS) limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, VTHIS), tail_of(X.act, 0))
+        NVSR_HIDDEN_LAYER(4, 5, KB_RGB1 + 4, 4, KB_RGB1 + 8, 4, NVSR_YB_PLAIN(5))
+        NVSR_HIDDEN_LAYER(5, 6, KB_RGB1 + 12, 4, KB_RGB1 + 16, 4, NVSR_YB_PLAIN(6))
+        // rgb layer 3: Y b | X relu (no tail: X continues with the density decoder from X.D)
+        NVSR_HIDDEN_LAYER(6, 7, KB_RGB1 + 20, 4, KB_DEN0, 3,
+                          (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, 7), NoTail{})))
+
+        // ---- density layer 0 (from D) -------------------------------------------------------------------------------------------
+        ring2_sync();
+        nw = ring3_issue<LIMBS, 4>(rs, KB_DEN1);
+        // X density 0 | Y: act of rgb layer 3; X: rgb heads
+        float hx[3] = {0.0f, 0.0f, 0.0f};
+        split_feat(X.D);
+        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.D),
+                                         [&](int slot) {
+                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp); });
+                                             spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
+                                         },
+                                         NoTail{});
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X.raw[c] = (hx[c] + __shfl_xor(hx[c], 32)) + small[S_HEAD_B + 1 + c];
+        // Y density 0 | Y: rgb heads, then X: act of density layer 0; tail X kb 0
+        float hy[3] = {0.0f, 0.0f, 0.0f};
+        split_feat(Y.D);
+        limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.D),
+                                          [&](int slot) {
+                                              spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
+                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp); });
+                                          },
+                                          tail_of(X.act, 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Y.raw[c] = (hy[c] + __shfl_xor(hy[c], 32)) + small[S_HEAD_B + 1 + c];
+        cw = nw;
+
+        // ---- density layers 1..3 -------------------------------------------------------------------------------------------------
+        NVSR_HIDDEN_LAYER(0, 1, KB_DEN1 + 4, 4, KB_DEN1 + 8, 4, NVSR_YB_PLAIN(1))
+        NVSR_HIDDEN_LAYER(1, 2, KB_DEN1 + 12, 4, KB_DEN1 + 16, 4, NVSR_YB_PLAIN(2))
+        // density layer 3: the chunk issued last is chunk 0 of the NEXT sample (after the last sample: a harmless copy);
+        // Y b | X: act, then the sigma head
+        float sx[1] = {0.0f};
+        NVSR_HIDDEN_LAYER(2, 3, KB_DEN1 + 20, 4, KB_RGB0, 3,
+                          (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4),
+                                                              [&](int slot) {
+                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp); });
+                                                                  spread<64, NSH / 2, NSH>(slot, [&](int k) { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
+                                                              },
+                                                              NoTail{})))
+#undef NVSR_HIDDEN_LAYER
+#undef NVSR_YB_PLAIN
+        X.raw[3] = (sx[0] + __shfl_xor(sx[0], 32)) + small[S_HEAD_B];
+
+        // ---- epilogue (exposed): Y's last activation + sigma head, both tiles' compositing -----------------------------------------
+#pragma unroll
+        for (int k = 0; k < RELU_STEPS; ++k) relu_bias_step(k, small + S_BIAS + 3 * HID, h, Y.acc, Y.act, bp);
+        {
+            float hd[1];
+            head_dots<1>(small + S_ALPHA_W, h, Y.act, hd);
+            Y.raw[3] = hd[0] + small[S_HEAD_B];
+        }
+        if (raw_out && lane < 32) {
+            if (validX) *reinterpret_cast<f32x4*>(raw_out + (rayX * S + s) * 4) = f32x4{X.raw[0], X.raw[1], X.raw[2], X.raw[3]};
+            if (validY) *reinterpret_cast<f32x4*>(raw_out + (rayY * S + s) * 4) = f32x4{Y.raw[0], Y.raw[1], Y.raw[2], Y.raw[3]};
+        }
+        composite_sample(X, reinterpret_cast<const f32x4*>(rcX)[1][2], nzX, last);
+        composite_sample(Y, reinterpret_cast<const f32x4*>(rcY)[1][2], nzY, last);
+        if (weights && lane < 32) {
+            if (validX) weights[rayX * S + s] = X.raw[3];
+            if (validY) weights[rayY * S + s] = Y.raw[3];
+        }
+        X.zc = X.zn; Y.zc = Y.zn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the copy issued for a sample after the last one must land before the wave ends
+
+    if (rs.lane < 32) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const Tile3& t = k ? Y : X;
+            const long ray = k ? rayY : rayX;
+            if (!(k ? validY : validX)) continue;
+            float cr = t.cr, cg = t.cg, cb = t.cb;
+            const float q = t.dep / t.ac;                       // NaN when acc == 0, like torch.max(1e-10, nan)
+            disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+            if (white) { const float bg = 1.0f - t.ac; cr += bg; cg += bg; cb += bg; }
+            rgb[ray * 3 + 0] = cr; rgb[ray * 3 + 1] = cg; rgb[ray * 3 + 2] = cb;
+            acc[ray] = t.ac;
+            if (depth) depth[ray] = t.dep;
+        }
+    }
+}
+
+// ---- natural blob -> bf16 limb fragments (the tail of the packed blob) -----------------------------------------------------------
+template <int LIMBS>
+__global__ void pack_decoder_limbs_kernel(const float* __restrict__ nat, unsigned* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KB_TOTAL * kb_words(LIMBS)) return;
+    const int w = idx & 3, lane = (idx >> 2) & 63, frag = (idx >> 8) % (4 * LIMBS), rec = idx / kb_words(LIMBS);
+    const int t = frag % LIMBS, ob = frag / LIMBS;
+    const int i = 32 * ob + (lane & 31), h = lane >> 5;
+    unsigned word = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = 2 * w + half;
+        int src;
+        if (rec < KB_RGB1) {
+            src = N_RGB_W0 + i * (4 * C) + C * (rec / 3) + HALF_C * h + 8 * (rec % 3) + e;
+        } else if (rec >= KB_DEN0 && rec < KB_DEN1) {
+            src = N_DEN_W0 + i * C + HALF_C * h + 8 * (rec - KB_DEN0) + e;
+        } else {
+            const bool is_rgb = rec < KB_DEN0;
+            const int r = rec - (is_rgb ? KB_RGB1 : KB_DEN1), l = r / 8, kb = r % 8;
+            const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
+            src = (is_rgb ? N_RGB_W1 : N_DEN_W1) + l * N_HID_STRIDE + i * HID + k;
+        }
+        float v = nat[src];
+        unsigned bits;
+        if (LIMBS == 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k == t) bits = __float_as_uint(v) >> 16;
+                v = limb_rest(v);
+            }
+        } else {
+            bits = (t == 0) ? (__float_as_uint(v) >> 16) : (round_pair(0.0f, limb_rest(v)) & 0xffffu);
+        }
+        word |= bits << (16 * half);
+    }
+    out[idx] = word;
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packed, nvsr_stream_t stream) {
+    unsigned* out = reinterpret_cast<unsigned*>(packed);
+    const int n3 = KB_TOTAL * kb_words(3), n2 = KB_TOTAL * kb_words(2);
+    hipLaunchKernelGGL(pack_decoder_limbs_kernel<3>, dim3((n3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, out + P_LIMB3);
+    hipLaunchKernelGGL(pack_decoder_limbs_kernel<2>, dim3((n2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, out + P_LIMB2);
+    return NVSR_CHECK_LAUNCH();
+}
+
+extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                        const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
+                                        float* weights, float* depth, float* raw_out, nvsr_stream_t stream) {
+    const int64_t grid = (N + RAYS2 - 1) / RAYS2;
+    if (grid > 0x7fffffff || (limbs != 2 && limbs != 3)) return NVSR_ERR_SHAPE;
+    if (limbs == 3)
+        hipLaunchKernelGGL(render_pass3_kernel<3>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
+                           S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);
+    else
+        hipLaunchKernelGGL(render_pass3_kernel<2>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
+                           S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);
+    return NVSR_CHECK_LAUNCH();
+}
