@@ -67,7 +67,7 @@ int nvsr_version(void);
 #define NVSR_ARITH_F32 0
 #define NVSR_ARITH_BF16X2 2
 #define NVSR_ARITH_BF16X3 3
-#define NVSR_ARITH_DEFAULT NVSR_ARITH_F32
+#define NVSR_ARITH_DEFAULT NVSR_ARITH_BF16X3
 int nvsr_get_decoder_arithmetic(void);
 int nvsr_set_decoder_arithmetic(int mode);
 

@@ -36,6 +36,7 @@ def _compile_one(hipcc, src, verbose):
     if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + PER_FILE_FLAGS.get(os.path.basename(src), [])
+    flags += os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", "").split()       # experiments (e.g. -DR3_STAMP=1); use with build_extension(force=True)
     cmd = [hipcc] + flags + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd))

@@ -15,8 +15,21 @@
 #include "limb_core.h"
 #include "side_work.h"
 
-#ifndef R3_TAPS
-#define R3_TAPS 4
+#ifndef R3_STAMP
+#define R3_STAMP 0    // debug builds: raw_out[ray, s = 0..1, :] of tile X = cycles per sample spent in 7 sections of the step (tools/limb_stamp.py)
+#endif
+#if R3_STAMP == 3
+#define R3_MARK(i)
+#define R3_MARKB(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+#define R3_RESET { tprev = __builtin_amdgcn_s_memtime(); }
+#elif R3_STAMP
+#define R3_MARKB(i)
+#define R3_RESET
+#define R3_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define R3_MARK(i)
+#define R3_MARKB(i)
+#define R3_RESET
 #endif
 namespace nvsr {
 
@@ -34,6 +47,7 @@ struct Tile3 {
     f32x16 acc[4];   // layer accumulators (AGPRs), written by MFMAs only
     f32x16 act[4];   // max(acc + bias, 0) of the finished layer (VGPRs)
     float D[HALF_C], F[HALF_C];
+    float V[HALF_C];  // view-plane features: the same for every sample of a ray, gathered once
     float T, cr, cg, cb, dep, ac, zc, zn;
     float raw[4];
 };
@@ -42,8 +56,16 @@ struct Tile3 {
 // first slots of a block and blended in its last quarter
 struct RawTaps4 { f32x4 r[4][HALF_C / 4]; };
 constexpr int GATHER_STEPS = 12 + HALF_C;
+#ifndef R3_ABLATE
+#define R3_ABLATE 0   // timing experiments: 1 no gather loads
+#endif
 __device__ __forceinline__ void gather4_load(int k, const GatherJob& job, int h, RawTaps4& rt) {           // k 0..11: tap k/3, 2 loads
     const int tap = k / 3, i0 = 2 * (k % 3);
+#if R3_ABLATE & 1
+    rt.r[tap][i0] = f32x4{job.t.nw, job.t.ne, job.t.sw, job.t.se};
+    rt.r[tap][i0 + 1] = f32x4{job.t.se, job.t.ne, job.t.sw, job.t.nw};
+    return;
+#endif
     const int off = tap == 0 ? job.t.o00 : tap == 1 ? job.t.o01 : tap == 2 ? job.t.o10 : job.t.o11;
     const f32x4* p = reinterpret_cast<const f32x4*>(job.plane + off + HALF_C * h);
     rt.r[tap][i0] = p[i0];
@@ -52,6 +74,52 @@ __device__ __forceinline__ void gather4_load(int k, const GatherJob& job, int h,
 __device__ __forceinline__ void gather4_blend(int c, const GatherJob& job, const RawTaps4& rt, float (&F)[HALF_C]) {   // channel c
     const int i = c >> 2, j = c & 3;
     F[c] = fmaf(rt.r[3][i][j], job.t.se, fmaf(rt.r[2][i][j], job.t.sw, fmaf(rt.r[1][i][j], job.t.ne, rt.r[0][i][j] * job.t.nw)));
+}
+
+// Rolling gather.  Block j issues the 24 loads of gather j, one per 3 of the block's 72 virtual steps (a wave64 dwordx4 load with 64
+// distinct addresses holds the vector-memory issue for ~80 cycles while the 4 waves of a CU gather together: issued back to back they stall
+// the MFMA stream), tap by tap (the 6 loads of a tap read the same cache lines).  The blend is accumulated per tap,
+//     F = T0 nw;  F = fma(T1, ne, F);  F = fma(T2, sw, F);  F = fma(T3, se, F)          (the same operations as gather24)
+// 54 steps behind the loads: pass 0 of gather j in the last quarter of block j, passes 1..3 in the first three quarters of block j + 1,
+// each just before the next gather's loads of that tap reuse the registers.
+template <int NS, bool LOADS, bool BLENDS>
+__device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float (&Fl)[HALF_C], const GatherJob& jb, float (&Fb)[HALF_C], int h,
+                                            RawTaps4& rt) {
+    spread<72, 0, NS>(slot, [&](int v) {
+        if (LOADS && v % 3 == 0) {
+            const int tap = (v / 3) / 6, piece = (v / 3) % 6;
+#if R3_ABLATE & 1
+            rt.r[tap][piece] = f32x4{jl.t.nw, jl.t.ne, jl.t.sw, jl.t.se};
+#else
+            int off = tap == 0 ? jl.t.o00 : tap == 1 ? jl.t.o01 : tap == 2 ? jl.t.o10 : jl.t.o11;
+#if R3_ABLATE & 2
+            off = __builtin_amdgcn_readfirstlane(off);          // every lane reads the first ray's texel (timing experiment)
+#endif
+#if R3_ABLATE & 4
+            off = off & 0xffff;                                  // all gathers inside the first 256 KB of the plane (timing experiment)
+            off -= off % 48;
+#endif
+            rt.r[tap][piece] = reinterpret_cast<const f32x4*>(jl.plane + off + HALF_C * h)[piece];
+#endif
+        }
+        const int w = v / 18, u = v % 18;
+#pragma unroll
+        for (int c = (u * 4) / 3; c < ((u + 1) * 4) / 3; ++c) {                         // 24 channels over the 18 steps of a quarter
+            if (LOADS && w == 3) Fl[c] = rt.r[0][c >> 2][c & 3] * jl.t.nw;
+            if (BLENDS && w < 3) Fb[c] = fmaf(rt.r[w + 1][c >> 2][c & 3], w == 0 ? jb.t.ne : w == 1 ? jb.t.sw : jb.t.se, Fb[c]);
+        }
+    });
+}
+
+// ring wait with N younger vector-memory operations allowed in flight (vmcnt counts in issue order: the chunk issued before them has landed)
+template <int N>
+__device__ __forceinline__ void ring3_sync() {
+#if R3_ABLATE & 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+    __syncthreads();
 }
 
 // act = max(acc + bias, 0): 64 elements in 68 steps (a bias quad is read 4 steps before its first use)
@@ -65,9 +133,12 @@ __device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, 
     }
 }
 
+// Weight ring.  The chunks are copied with `buffer_load_dwordx4 ... lds` (MUBUF LDS-DMA), not with global_load_lds: hipcc's wait-count
+// pass treats the FLAT-encoded form as an access to both memories ("pending flat") and answers the first vector-memory dependence after
+// it with s_waitcnt vmcnt(0) -- which here would wait for the chunk just issued and for every gather load in flight.
 template <int LIMBS>
 struct Ring3 {
-    const unsigned* blob;   // fragment region of the packed blob
+    __amdgpu_buffer_rsrc_t rsrc;   // fragment region of the packed blob
     unsigned* lds;
     int slot;
     int wave, lane;
@@ -76,7 +147,12 @@ struct Ring3 {
 template <int LIMBS, int NKB>
 __device__ __forceinline__ const unsigned* ring3_issue(Ring3<LIMBS>& rs, int kb0) {
     unsigned* dst = rs.lds + rs.slot * Lds3<LIMBS>::SLOT;
-    stage_chunk<NW2, NKB * 4 * LIMBS>(reinterpret_cast<const float*>(rs.blob + kb0 * kb_words(LIMBS)), reinterpret_cast<float*>(dst), rs.voff, rs.wave);
+    constexpr int BLOCKS = NKB * 4 * LIMBS;                 // 1-KiB pieces, NW2 per round
+    static_assert(BLOCKS % NW2 == 0, "chunk must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < BLOCKS / NW2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
+                                             (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
     rs.slot ^= 1;
     return dst;
 }
@@ -93,8 +169,8 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
     constexpr int NP = limb_products(LIMBS);
     constexpr int NSF = 3 * 4 * NP, NSH = 4 * 4 * NP;          // slots of a feature block / of half a hidden layer
     __shared__ __attribute__((aligned(16))) unsigned lds[L::TOTAL];
-    Ring3<LIMBS> rs{reinterpret_cast<const unsigned*>(packed) + limb_region(LIMBS), lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63),
-                    (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    Ring3<LIMBS> rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LIMBS)), 0, KB_TOTAL * kb_words(LIMBS) * 4, 0x00020000),
+                    lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) ldsf[L::SMALL + i] = packed[P_SMALL + i];
     const float* small = ldsf + L::SMALL;
@@ -130,7 +206,6 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
     Y.cr = Y.cg = Y.cb = Y.dep = Y.ac = 0.0f;
     X.zc = zX[0]; Y.zc = zY[0];
     RawTaps4 rt;
-    RawTaps2 rt2;
 
     auto point_norm = [&](const float* rc, float zc, float& n0, float& n1, float& n2) {
         const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
@@ -147,14 +222,31 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         return j;
     };
 
+    __syncthreads();   // the ray cache is written by lanes 0..31 and read by all 64: without a barrier hipcc moves the reads of the upper
+                       // half above the writes (per lane there is no dependence)
+    // The view-plane features (project_viewdir, models.py:312-326) depend on the ray only: gathered once.  They open every sample's rgb
+    // layer 0, so that the first plane gathers of a sample have two blocks to land in.
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        Tile3& t = k2 ? Y : X;
+        const GatherJob vj = view_job(k2 ? rcY : rcX);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gather4_load(k, vj, lane0 >> 5, rt);
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) gather4_blend(c, vj, rt, t.V);
+    }
     Limbs<LIMBS> cur, fa;
+#if R3_STAMP
+    float stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     const unsigned* cw = ring3_issue<LIMBS, 3>(rs, KB_RGB0);      // chunk 0 of sample 0; every later one is issued during the previous sample
     for (int s = 0; s < S; ++s) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
         const bool last = (s + 1 == S);
-        X.zn = last ? 0.0f : zX[s + 1];
-        Y.zn = last ? 0.0f : zY[s + 1];
+        X.zn = zX[last ? s : s + 1];                           // (unconditional loads: ring3_sync<2> below counts them)
+        Y.zn = zY[last ? s : s + 1];
         const float nzX = noise ? noise[rayX * S + s] : 0.0f;
         const float nzY = noise ? noise[rayY * S + s] : 0.0f;
         float xn0, xn1, xn2, yn0, yn1, yn2;
@@ -164,19 +256,8 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         HeadPend<3> hp3;
         HeadPend<1> hp1;
         SplitPend tp;
-        GatherJob job;
 
         // side-work pieces
-        auto gather = [&](Tile3& t) {                                          // the whole gather of `job` into t.F inside a feature block
-            return [&](int slot) {
-#if R3_TAPS == 4
-                spread<12, 0, NSF / 6>(slot, [&](int k) { gather4_load(k, job, h, rt); });
-                spread<HALF_C, 3 * NSF / 4, NSF>(slot, [&](int c) { gather4_blend(c, job, rt, t.F); });
-#else
-                spread<96, 0, NSF>(slot, [&](int k) { gather_side(k >> 2, k & 3, job, h, rt2, t.F); });
-#endif
-            };
-        };
         auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
         auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
         auto split_feat = [&](const float (&f)[HALF_C]) { split_all<LIMBS>([&f](int i) { return f[i]; }, cur); };
@@ -186,71 +267,78 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         };
         auto none = [](int) {};
 
-        // ---- prologue (exposed): plane 0 of X gathered and blended; chunk 0 has been in flight since the previous sample's last chunk
-        job.plane = sc.plane[0]; job.t = pos_taps2(sc, 0, xn0, xn1, xn2);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gather4_load(k, job, h, rt);
-#pragma unroll
-        for (int c = 0; c < HALF_C; ++c) gather4_blend(c, job, rt, X.F);
+        // ---- rgb layer 0: (view plane, planes 0..2) x (X block, Y block).  The gathers roll through the blocks (gather_roll): the block that
+        // multiplies plane p - 1 of a tile loads plane p of the same tile, the next block blends it.
+        GatherJob ja, jb;
+        R3_MARK(0)      // loop top
+        ring3_sync<2>();                                         // chunk 0 (issued during the previous sample) -- younger: the two z loads above
+        const unsigned* nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 3);
+        R3_MARK(1)      // first ring wait
+        R3_RESET
+#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS>(slot, JL, TL.F, JB, TB.F, h, rt); }
+        // X view | loads X plane 0
+        ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2);
+        split_feat(X.V);
+        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL(X, ja, Y, jb, true, false), NoTail{});
+        R3_MARKB(0)
+        // Y view | blends X plane 0, loads Y plane 0
+        jb.plane = sc.plane[0]; jb.t = pos_taps2(sc, 0, yn0, yn1, yn2);
+        split_feat(Y.V);
+        limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.V), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        R3_MARKB(1)
+        cw = nw;
+        ring3_sync<48>();                                        // younger than the chunk: the 2 x 24 gather loads of the two blocks
+        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 6);
+        // X plane 0 | blends Y plane 0, loads X plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
-        ring2_sync();
-        const unsigned* nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 3);
-
-        // ---- rgb layer 0: 4 planes x (X block, Y block) -----------------------------------------------------------------------
-        // X plane 0 | Y: gather plane 0
-        job.plane = sc.plane[0]; job.t = pos_taps2(sc, 0, yn0, yn1, yn2);
+        ja.plane = sc.plane[1]; ja.t = pos_taps2(sc, 1, xn0, xn1, xn2);
         split_feat(X.F);
-        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        R3_MARKB(2)
+        // Y plane 0 | blends X plane 1, loads Y plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = Y.F[c];
-        // Y plane 0 | X: gather plane 1
-        job.plane = sc.plane[1]; job.t = pos_taps2(sc, 1, xn0, xn1, xn2);
+        jb.plane = sc.plane[1]; jb.t = pos_taps2(sc, 1, yn0, yn1, yn2);
         split_feat(Y.F);
-        limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
+        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        R3_MARKB(3)
+        cw = nw;
+        ring3_sync<48>();
+        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 9);
+        // X plane 1 | blends Y plane 1, loads X plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = __fadd_rn(X.D[c], X.F[c]);
-        cw = nw;
-        ring2_sync();
-        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 6);
-        // X plane 1 | Y: gather plane 1
-        job.plane = sc.plane[1]; job.t = pos_taps2(sc, 1, yn0, yn1, yn2);
+        ja.plane = sc.plane[2]; ja.t = pos_taps2(sc, 2, xn0, xn1, xn2);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        R3_MARKB(4)
+        // Y plane 1 | blends X plane 2, loads Y plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = __fadd_rn(Y.D[c], Y.F[c]);
-        // Y plane 1 | X: gather plane 2, D = (D + F) / 3   (combine_pos_planes 'avg', models.py:358-359)
-        job.plane = sc.plane[2]; job.t = pos_taps2(sc, 2, xn0, xn1, xn2);
+        jb.plane = sc.plane[2]; jb.t = pos_taps2(sc, 2, yn0, yn1, yn2);
         split_feat(Y.F);
-        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
+        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        R3_MARKB(5)
+        cw = nw;
+        ring3_sync<48>();
+        nw = ring3_issue<LIMBS, 4>(rs, KB_RGB1);
+        // X plane 2 | blends Y plane 2;  D = (D + F) / 3   (combine_pos_planes 'avg', models.py:358-359)
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = div3(__fadd_rn(X.D[c], X.F[c]));
-        cw = nw;
-        ring2_sync();
-        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 9);
-        // X plane 2 | Y: gather plane 2
-        job.plane = sc.plane[2]; job.t = pos_taps2(sc, 2, yn0, yn1, yn2);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, false, true), NoTail{});
+        R3_MARKB(6)
+        // Y plane 2 | X: act = max(acc + bias, 0); tail: limbs of X's K-block 0
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = div3(__fadd_rn(Y.D[c], Y.F[c]));
-        // Y plane 2 | X: gather view plane
-        job = view_job(rcX);
-        split_feat(Y.F);
-        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), gather(X), NoTail{});
-        cw = nw;
-        ring2_sync();
-        nw = ring3_issue<LIMBS, 4>(rs, KB_RGB1);
-        // X view plane | Y: gather view plane
-        job = view_job(rcY);
-        split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), gather(Y), NoTail{});
-        // Y view plane | X: act = max(acc + bias, 0); tail: limbs of X's K-block 0
         split_feat(Y.F);
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F),
                                            [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp); }); },
                                            tail_of(X.act, 0));
+        R3_MARKB(7)
         cw = nw;
+        R3_MARK(2)      // rgb layer 0
 
         // ---- hidden layers.  Layer l of a decoder = chunks a (K-blocks 0..3), b (4..7):
         //   X a | Y: act of layer l-1; tail Y kb 0        Y a | tail X kb 4        X b | tail Y kb 4        Y b | X: act of layer l; tail X kb 0
@@ -258,10 +346,10 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
             return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp); }); };
         };
         // hidden layer with bias vectors: vprev (layer l-1, finishing Y) and vthis (layer l, finishing X); kbn = next chunk to issue (two per layer)
-#define NVSR_HIDDEN_LAYER(VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                              \
-        ring2_sync();                                                                                                               \
+#define NVSR_HIDDEN_LAYER_(SYNC, XA_SIDE, VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                \
+        SYNC;                                                                                                                       \
         nw = ring3_issue<LIMBS, NKB_A>(rs, KB_NEXT_A);                                                                              \
-        limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0), relu_side(Y, VPREV), tail_of(Y.act, 0));         \
+        limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0), XA_SIDE, tail_of(Y.act, 0));                      \
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
         cw = nw;                                                                                                                    \
         ring2_sync();                                                                                                               \
@@ -270,14 +358,16 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         X_B_SIDE;                                                                                                                   \
         cw = nw;
 
+#define NVSR_HIDDEN_LAYER(VPREV, ...) NVSR_HIDDEN_LAYER_(ring2_sync(), relu_side(Y, VPREV), VPREV, __VA_ARGS__)
         // rgb layers 1, 2: Y b | X relu, tail X kb 0
-#define NVSR_YB_PLAIN(VTHIS) limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, VTHIS), tail_of(X.act, 0))
+#define NVSR_YB_PLAIN(VTHIS) (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, VTHIS), tail_of(X.act, 0)))
         NVSR_HIDDEN_LAYER(4, 5, KB_RGB1 + 4, 4, KB_RGB1 + 8, 4, NVSR_YB_PLAIN(5))
         NVSR_HIDDEN_LAYER(5, 6, KB_RGB1 + 12, 4, KB_RGB1 + 16, 4, NVSR_YB_PLAIN(6))
         // rgb layer 3: Y b | X relu (no tail: X continues with the density decoder from X.D)
         NVSR_HIDDEN_LAYER(6, 7, KB_RGB1 + 20, 4, KB_DEN0, 3,
                           (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, 7), NoTail{})))
 
+        R3_MARK(3)      // rgb layers 1..3
         // ---- density layer 0 (from D) -------------------------------------------------------------------------------------------
         ring2_sync();
         nw = ring3_issue<LIMBS, 4>(rs, KB_DEN1);
@@ -305,6 +395,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         for (int c = 0; c < 3; ++c) Y.raw[c] = (hy[c] + __shfl_xor(hy[c], 32)) + small[S_HEAD_B + 1 + c];
         cw = nw;
 
+        R3_MARK(4)      // density layer 0
         // ---- density layers 1..3 -------------------------------------------------------------------------------------------------
         NVSR_HIDDEN_LAYER(0, 1, KB_DEN1 + 4, 4, KB_DEN1 + 8, 4, NVSR_YB_PLAIN(1))
         NVSR_HIDDEN_LAYER(1, 2, KB_DEN1 + 12, 4, KB_DEN1 + 16, 4, NVSR_YB_PLAIN(2))
@@ -319,8 +410,11 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
                                                               },
                                                               NoTail{})))
 #undef NVSR_HIDDEN_LAYER
+#undef NVSR_HIDDEN_LAYER_
+#undef NVSR_ROLL
 #undef NVSR_YB_PLAIN
         X.raw[3] = (sx[0] + __shfl_xor(sx[0], 32)) + small[S_HEAD_B];
+        R3_MARK(5)      // density layers 1..3
 
         // ---- epilogue (exposed): Y's last activation + sigma head, both tiles' compositing -----------------------------------------
 #pragma unroll
@@ -341,7 +435,13 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
             if (validY) weights[rayY * S + s] = Y.raw[3];
         }
         X.zc = X.zn; Y.zc = Y.zn;
+        R3_MARK(6)      // epilogue
     }
+#if R3_STAMP
+    if (raw_out && rs.lane < 32 && validX) {
+        for (int i = 0; i < 8; ++i) raw_out[(rayX * S + (i >> 2)) * 4 + (i & 3)] = stamp[i] / (float)S;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the copy issued for a sample after the last one must land before the wave ends
 
     if (rs.lane < 32) {
@@ -375,7 +475,8 @@ __global__ void pack_decoder_limbs_kernel(const float* __restrict__ nat, unsigne
         const int e = 2 * w + half;
         int src;
         if (rec < KB_RGB1) {
-            src = N_RGB_W0 + i * (4 * C) + C * (rec / 3) + HALF_C * h + 8 * (rec % 3) + e;
+            const int plane = rec < 3 ? 3 : rec / 3 - 1;          // consumption order: view plane, then planes 0..2
+            src = N_RGB_W0 + i * (4 * C) + C * plane + HALF_C * h + 8 * (rec % 3) + e;
         } else if (rec >= KB_DEN0 && rec < KB_DEN1) {
             src = N_DEN_W0 + i * C + HALF_C * h + 8 * (rec - KB_DEN0) + e;
         } else {

@@ -70,6 +70,9 @@ def build_model(hip, state, planes, box, sid="lego_DS8_PlRes32_8"):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+DEFAULT_ARITHMETIC = "bf16x3"      # include/nvsr.h: NVSR_ARITH_DEFAULT
+
+
 def test_library_loaded_and_version(hip):
     assert hip.capi.lib().nvsr_version() >= 100
 
@@ -1219,6 +1222,7 @@ def test_render_pass_generations_are_bit_identical(hip):
         noise = T((rng.standard_normal((N, S)) * 0.3).astype(np.float32))
         sc, keep = m.native_scene()
         outs = []
+        capi.set_decoder_arithmetic("f32")       # the two f32-MFMA generations; the bf16-limb kernel has its own test below
         for gen in ("1", None):
             if gen:
                 os.environ["NVSR_RENDER_V1"] = gen
@@ -1232,9 +1236,110 @@ def test_render_pass_generations_are_bit_identical(hip):
             torch.cuda.synchronize()
             outs.append(o)
         os.environ.pop("NVSR_RENDER_V1", None)
+        capi.set_decoder_arithmetic(DEFAULT_ARITHMETIC)
         for k in outs[0]:
             assert_bits_equal(N_(outs[0][k]), N_(outs[1][k]))
             assert not (N_(outs[1][k]) == -7.0).all()
+
+
+def _limbs_of(words, limbs):
+    """packed fragment words [.., 4] uint32 -> the bf16 values (as float64) of both halves"""
+    lo = (words & 0xffff).astype(np.uint32) << 16
+    hi = (words & 0xffff0000).astype(np.uint32)
+    return lo.view(np.float32).astype(np.float64), hi.view(np.float32).astype(np.float64)
+
+
+def test_limb_fragments_reproduce_the_weights(hip):
+    """packed blob, bf16-limb regions (include/nvsr.h, csrc/limb_core.h): the 3 limbs of every weight sum to the f32 weight EXACTLY;
+    the 2 limbs to within 2^-16 |w|; fragment order = [K-block][out block][limb][lane][word] with the k-order of the C/D register layout"""
+    g = load_golden("g08_render.npz")
+    rng = np.random.default_rng(5)
+    planes = [rng.standard_normal((1, 48, 8, 8), dtype=np.float32) for _ in range(4)]
+    m, _ = build_model(hip, sd(g, "fine."), planes, g["box"])
+    nat = N_(m.natural_blob())
+    packed = N_(m.packed_decoder()).view(np.uint32)
+    assert packed.size == hip.capi.DECODER_PACKED_FLOATS
+    F32 = 130576
+    KB = 63
+    for limbs, base in ((3, F32), (2, F32 + KB * 3072)):
+        fr = packed[base:base + KB * 4 * limbs * 256].reshape(KB, 4, limbs, 64, 4)          # [rec][ob][limb][lane][word]
+        lo, hi = _limbs_of(fr, limbs)
+        w = np.stack([lo, hi], -1).sum(2)                                                   # [rec][ob][lane][word][half]: limb sum
+        lane = np.arange(64)
+        mrow, h = lane & 31, lane >> 5
+        for rec in (0, 2, 3, 11, 12, 19, 35, 36, 38, 39, 62):
+            for ob in range(4):
+                i = 32 * ob + mrow                                                          # output channel per lane
+                e = 2 * np.arange(4)[None, :, None] + np.arange(2)[None, None, :]           # element index [1][word][half]
+                if rec < 12:
+                    plane = 3 if rec < 3 else rec // 3 - 1
+                    src = 55937 + i[:, None, None] * 192 + 48 * plane + 24 * h[:, None, None] + 8 * (rec % 3) + e
+                elif 36 <= rec < 39:
+                    src = 0 + i[:, None, None] * 48 + 24 * h[:, None, None] + 8 * (rec - 36) + e
+                else:
+                    rgb = rec < 36
+                    r = rec - (12 if rgb else 39)
+                    layer, kb = r // 8, r % 8
+                    k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h[:, None, None] + (e & 3)
+                    src = (80641 if rgb else 6272) + layer * 16512 + i[:, None, None] * 128 + k
+                ref = nat[src].astype(np.float64)
+                got = w[rec, ob]
+                if limbs == 3:
+                    assert np.array_equal(got, ref), (rec, ob)
+                else:
+                    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -16 + 1e-45), (rec, ob)
+
+
+def test_render_pass_limb_arithmetic(hip, oracle):
+    """nvsr_render_pass with the decoder GEMMs on the bf16 matrix pipe (render3.hip): 3 limbs per operand = f32-grade products
+    (tolerances of the f32 kernels), 2 limbs = 16-bit operands (stated looser tolerance); against the f32-MFMA kernel and the oracle.
+    20 011 rays (partial last workgroup, a wave whose second tile is empty), 37 samples, density noise, white background."""
+    import ctypes as C
+    g = load_golden("g08_render.npz")
+    capi = hip.capi
+    rng = np.random.default_rng(23)
+    planes = [rng.standard_normal((1, 48, 64, 48), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 8, 12), dtype=np.float32) * 0.5]
+    m, _ = build_model(hip, sd(g, "fine."), planes, g["box"])
+    N, S = 20011, 37
+    H, W = 150, 160
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)[:N].contiguous()
+    z = T(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1))
+    noise = T((rng.standard_normal((N, S)) * 0.3).astype(np.float32))
+    sc, keep = m.native_scene()
+    res = {}
+    try:
+        for mode in ("f32", "bf16x3", "bf16x2"):
+            capi.set_decoder_arithmetic(mode)
+            assert capi.get_decoder_arithmetic() == mode
+            o = dict(rgb=torch.full((N, 3), -7.0, device=DEV), disp=torch.full((N,), -7.0, device=DEV), acc=torch.full((N,), -7.0, device=DEV),
+                     w=torch.full((N, S), -7.0, device=DEV), depth=torch.full((N,), -7.0, device=DEV), raw=torch.full((N, S, 4), -7.0, device=DEV))
+            capi.call("nvsr_render_pass_ex", C.byref(sc), capi.ptr(m.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(noise), 1,
+                      capi.ptr(o["rgb"]), capi.ptr(o["disp"]), capi.ptr(o["acc"]), capi.ptr(o["w"]), capi.ptr(o["depth"]), capi.ptr(o["raw"]),
+                      capi.stream())
+            torch.cuda.synchronize()
+            res[mode] = {k: N_(v).astype(np.float64) for k, v in o.items()}
+    finally:
+        capi.set_decoder_arithmetic(DEFAULT_ARITHMETIC)
+    for k, v in res["bf16x3"].items():
+        assert not (v == -7.0).any(), k
+    scale = np.abs(res["f32"]["raw"]).max()
+    # stated tolerances: 3 limbs -- the f32 kernels' own (2e-5 on pixels); 2 limbs -- 1e-3 on pixels, 2e-4 of the range on decoder outputs
+    for mode, t_raw, t_pix in (("bf16x3", 1e-5, 2e-5), ("bf16x2", 2e-4, 1e-3)):
+        assert np.abs(res[mode]["raw"] - res["f32"]["raw"]).max() <= t_raw * scale, mode
+        for k in ("rgb", "acc", "w"):
+            assert np.abs(res[mode][k] - res["f32"][k]).max() <= t_pix, (mode, k)
+    # the oracle on a subset of the rays
+    ids = rng.choice(N, 600, replace=False)
+    osc = oracle.scene(planes, g["box"])
+    dec = oracle.decoder(decoder_blob(sd(g, "fine.")))
+    fo = oracle.render_given_z(osc, dec, N_(rays)[ids], N_(z)[ids], noise=N_(noise)[ids], white_background=True, want_raw=True)
+    ok = ~_excluded_last_sigma(fo["raw"][:, -1, 3] + N_(noise)[ids][:, -1])
+    for mode, tol in (("f32", 2e-5), ("bf16x3", 2e-5), ("bf16x2", 1e-3)):
+        np.testing.assert_allclose(res[mode]["rgb"][ids][ok], fo["rgb"][ok], rtol=0, atol=tol, err_msg=mode)
+        np.testing.assert_allclose(res[mode]["acc"][ids][ok], fo["acc"][ok], rtol=0, atol=tol, err_msg=mode)
 
 
 def test_volume_render_radiance_field_is_differentiable(hip):

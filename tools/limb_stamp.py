@@ -1,0 +1,46 @@
+"""Cycle stamps of render3.hip's step sections.  Run on the GPU box:
+   NVSR_EXTRA_HIPCC_FLAGS=-DR3_STAMP=1 python tools/limb_stamp.py   (rebuilds the library with the stamps compiled in)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nvsr_amd as hip
+hip.build_extension(force=True)
+from bench import make_synthetic_scene
+
+capi = hip.capi
+dev = "cuda:0"
+mc, mf, sid, pose = make_synthetic_scene(dev, plane_res=800, view_res=32, seed=0)
+H = W = 800
+focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0).contiguous()
+N, S = rays.shape[0], 192
+rng = np.random.default_rng(17)
+z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), device=dev)
+sc, keep = mf.native_scene()
+packed = mf.packed_decoder()
+names = ["top+gather", "ring wait", "rgb0", "rgb1-3", "den0", "den1-3", "epilogue"]
+if "R3_STAMP=3" in os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", ""):
+    names = ["B0 X view", "B1 Y view", "B2 X p0", "B3 Y p0", "B4 X p1", "B5 Y p1", "B6 X p2"]
+for mode in sys.argv[1:] or ["bf16x3", "bf16x2"]:
+    capi.set_decoder_arithmetic(mode)
+    o = dict(rgb=torch.empty((N, 3), device=dev), disp=torch.empty((N,), device=dev), acc=torch.empty((N,), device=dev), raw=torch.zeros((N, S, 4), device=dev))
+    for rep in range(2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        capi.call("nvsr_render_pass_ex", C.byref(sc), capi.ptr(packed), N, S, capi.ptr(rays), capi.ptr(z), None, 0,
+                  capi.ptr(o["rgb"]), capi.ptr(o["disp"]), capi.ptr(o["acc"]), None, None, capi.ptr(o["raw"]), capi.stream())
+        b.record(); torch.cuda.synchronize()
+    st = o["raw"][:, :2, :].reshape(N, 8)[:, :7].cpu().numpy()
+    # one lane per tile X: rays 0..31 of each 64
+    sel = (np.arange(N) % 64) < 32
+    st = st[sel]
+    tot = st.sum(1)
+    print("%s: %.2f ms; cycles per sample-step: total mean %.0f (min %.0f max %.0f)" % (mode, a.elapsed_time(b), tot.mean(), tot.min(), tot.max()))
+    for i, n in enumerate(names):
+        print("   %-12s %8.0f  %5.1f %%" % (n, st[:, i].mean(), 100 * st[:, i].mean() / tot.mean()))
