@@ -31,6 +31,17 @@ if ROOT not in sys.path:
 FLOP_PER_EVAL = 259072          # 129 536 MAC per decoded point
 GATHER_BYTES_PER_EVAL = 3072    # 16 texels x 48 ch x 4 B
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16 in 32 clk) x 2.4 GHz
+# Arithmetic of the fused render pass (include/nvsr.h NVSR_ARITH_*): kernel, executed MFMA work per algorithmic FLOP, pipe peak.
+# The roofline peak of a limb mode is the bf16 pipe's dense peak divided by the bf16 products it spends per f32 product.
+ARITHMETIC = {
+    "f32": {"kernel": "render_pass2_kernel", "products": 1, "pipe_peak": PEAK_F32_MFMA_TFLOPS,
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
+    "bf16x3": {"kernel": "render_pass3_kernel<3>", "products": 6, "pipe_peak": PEAK_BF16_MFMA_TFLOPS,
+               "dtype": "f32 (GEMM operands split exactly into 3 bf16 limbs, 6 of 9 limb products on v_mfma_f32_32x32x16_bf16, f32 accumulation)"},
+    "bf16x2": {"kernel": "render_pass3_kernel<2>", "products": 3, "pipe_peak": PEAK_BF16_MFMA_TFLOPS,
+               "dtype": "f32 storage, GEMM operands rounded to 2 bf16 limbs (16 significant bits), f32 accumulation"},
+}
 CAMERA_ANGLE_X = 0.6911112
 
 
@@ -318,6 +329,7 @@ def main():
     ap.add_argument("--res", type=int, default=800, help="image side (default 800 = BASELINE config)")
     ap.add_argument("--plane-res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -374,11 +386,13 @@ def main():
 
     rays_per_step = H * W
     value = world * rays_per_step * args.steps / elapsed
+    mode = nvsr_amd.capi.get_decoder_arithmetic()
+    arith = ARITHMETIC[mode]
     result = {
         "metric": "rendered rays/sec (64+128 samples) at 800x800 Lego-like view",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": arith["dtype"], "data": "synthetic", "decoder_arithmetic": mode,
         "config": {"workload": "Blender-'lego'-like %dx%d view, 64 coarse + 128 fine samples, tri-plane decoder (3x%d^2x48 + 32^2x48 planes, "
                                "4+4x128 MLP), 1 view per GPU per step" % (H, W, args.plane_res),
                    "rays_per_step_per_gpu": rays_per_step, "decoder_evals_per_ray": 256, "parallelism": "rays sharded by view, no collective"},
@@ -406,10 +420,31 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and H == 800 and args.plane_res == 800:
             traffic = json.load(open(pmc)).get("traffic_bytes")
-        result["roofline"] = {"kernel": "render_pass2_kernel (fine pass, S=192)", "bound": "mfma", "achieved": achieved,
-                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        if traffic is not None and json.load(open(pmc)).get("decoder_arithmetic", "f32") != mode:
+            traffic = None                            # counters of another kernel
+        peak = arith["pipe_peak"] / arith["products"]
+        result["roofline"] = {"kernel": "%s (fine pass, S=192)" % arith["kernel"], "bound": "mfma", "achieved": achieved,
+                              "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,
-                              "algorithmic_gather_bytes_per_launch": GATHER_BYTES_PER_EVAL * N * 192}
+                              "algorithmic_gather_bytes_per_launch": GATHER_BYTES_PER_EVAL * N * 192,
+                              "peak_note": "algorithmic f32 FLOP; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
+                                           % (arith["pipe_peak"], arith["products"]),
+                              "executed_mfma_tflops": achieved * arith["products"], "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        if world == 1 and not args.no_modes:
+            # the same frame in the other arithmetic modes (2 steps each), so that every number of this line can be re-based
+            modes = {}
+            for m2 in ("f32", "bf16x3", "bf16x2"):
+                nvsr_amd.capi.set_decoder_arithmetic(m2)
+                step(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t_frame = (time.perf_counter() - t1) / 2
+                modes[m2] = {"rays_per_s": rays_per_step / t_frame, "ms_per_step": 1e3 * t_frame,
+                             "fine_pass_kernel_ms": 1e3 * time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine, reps=2)}
+            nvsr_amd.capi.set_decoder_arithmetic(mode)
+            result["arithmetic_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
             cb, psnr = cpu_baseline(nvsr_amd, mc, mf, sid, rays, bufs[3])
             result["cpu_baseline"] = cb

@@ -18,18 +18,30 @@
 #ifndef R3_STAMP
 #define R3_STAMP 0    // debug builds: raw_out[ray, s = 0..1, :] of tile X = cycles per sample spent in 7 sections of the step (tools/limb_stamp.py)
 #endif
-#if R3_STAMP == 3
+#if R3_STAMP == 4
+#define R3_MARK(i)
+#define R3_MARKB(i)
+#define R3_RESET
+#define R3_MARKH(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+#define R3_RESETH { tprev = __builtin_amdgcn_s_memtime(); }
+#elif R3_STAMP == 3
+#define R3_MARKH(i)
+#define R3_RESETH
 #define R3_MARK(i)
 #define R3_MARKB(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
 #define R3_RESET { tprev = __builtin_amdgcn_s_memtime(); }
 #elif R3_STAMP
 #define R3_MARKB(i)
 #define R3_RESET
+#define R3_MARKH(i)
+#define R3_RESETH
 #define R3_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define R3_MARK(i)
 #define R3_MARKB(i)
 #define R3_RESET
+#define R3_MARKH(i)
+#define R3_RESETH
 #endif
 namespace nvsr {
 
@@ -347,15 +359,23 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         };
         // hidden layer with bias vectors: vprev (layer l-1, finishing Y) and vthis (layer l, finishing X); kbn = next chunk to issue (two per layer)
 #define NVSR_HIDDEN_LAYER_(SYNC, XA_SIDE, VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                \
+        R3_RESETH                                                                                                                   \
         SYNC;                                                                                                                       \
+        R3_MARKH(0)                                                                                                                 \
         nw = ring3_issue<LIMBS, NKB_A>(rs, KB_NEXT_A);                                                                              \
+        R3_MARKH(1)                                                                                                                 \
         limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0), XA_SIDE, tail_of(Y.act, 0));                      \
+        R3_MARKH(2)                                                                                                                 \
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
+        R3_MARKH(3)                                                                                                                 \
         cw = nw;                                                                                                                    \
         ring2_sync();                                                                                                               \
         nw = ring3_issue<LIMBS, NKB_B>(rs, KB_NEXT_B);                                                                              \
+        R3_MARKH(4)                                                                                                                 \
         limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4), none, tail_of(Y.act, 4));                        \
+        R3_MARKH(5)                                                                                                                 \
         X_B_SIDE;                                                                                                                   \
+        R3_MARKH(6)                                                                                                                 \
         cw = nw;
 
 #define NVSR_HIDDEN_LAYER(VPREV, ...) NVSR_HIDDEN_LAYER_(ring2_sync(), relu_side(Y, VPREV), VPREV, __VA_ARGS__)

@@ -25,6 +25,8 @@ z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), d
 sc, keep = mf.native_scene()
 packed = mf.packed_decoder()
 names = ["top+gather", "ring wait", "rgb0", "rgb1-3", "den0", "den1-3", "epilogue"]
+if "R3_STAMP=4" in os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", ""):
+    names = ["sync a (x6)", "issue a", "X a (Y relu)", "Y a", "sync+issue b", "X b", "Y b (X relu)"]
 if "R3_STAMP=3" in os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", ""):
     names = ["B0 X view", "B1 Y view", "B2 X p0", "B3 Y p0", "B4 X p1", "B5 Y p1", "B6 X p2"]
 for mode in sys.argv[1:] or ["bf16x3", "bf16x2"]:

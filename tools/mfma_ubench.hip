@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
                     if (j == 0) { const f32x4 an = wv[((g + 1) & 63) * 64]; side[15] += an[0]; a = (j == 3) ? an : a; nexta = an; }
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        const int e = (4 * g + j) & 15;
+                        const int e = (4 * g + j + 5 * v) & 15;          // independent fillers (a chain on one register prices latency)
                         if (MODE == 4) side[e] = fmaxf(acc2[(g >> 2) & 3][e], side[e]);
-                        else side[e] = fmaxf(side[e] * 1.0001f, side[(e + 1) & 15]);
+                        // volatile asm: a plain C++ expression here is moved OUT of the MFMA gaps by hipcc (it is independent of the MFMAs and
+                        // sched_barrier only binds the machine scheduler), which then measures exposed VALU time, not VALU in a shadow
+                        else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(side[e]) : "v"(side[(e + 1) & 15]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -112,7 +114,9 @@ int main() {
         run<2>("ds_read x4 per 16", blocks);
         run<3, 2>("+2 VALU per MFMA", blocks);
         run<3, 6>("+6 VALU per MFMA", blocks);
+        run<3, 10>("+10 VALU per MFMA", blocks);
         run<3, 12>("+12 VALU per MFMA", blocks);
+        run<3, 14>("+14 VALU per MFMA", blocks);
         run<4, 1>("+1 VALU reading 2nd acc set", blocks);
     }
     return 0;
