@@ -126,7 +126,7 @@ __device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float
 // ring wait with N younger vector-memory operations allowed in flight (vmcnt counts in issue order: the chunk issued before them has landed)
 template <int N>
 __device__ __forceinline__ void ring3_sync() {
-#if R3_ABLATE & 1
+#if R3_ABLATE & 9
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -169,6 +169,28 @@ __device__ __forceinline__ const unsigned* ring3_issue(Ring3<LIMBS>& rs, int kb0
     return dst;
 }
 
+// The same copy issued piece by piece from the gaps of the block that follows the ring wait: a chunk is 36-48 KB, the 4 waves push it
+// through the texture path at its 64 B/clk -- issued as a burst that is ~700 cycles in which the wave issues nothing else (12 chunks of
+// hidden layers per sample: 8 k cycles); one piece every third gap overlaps with the MFMAs.
+template <int LIMBS>
+__device__ __forceinline__ unsigned* ring3_take(Ring3<LIMBS>& rs) {
+    unsigned* dst = rs.lds + rs.slot * Lds3<LIMBS>::SLOT;
+    rs.slot ^= 1;
+    return dst;
+}
+template <int LIMBS, int NKB>
+__device__ __forceinline__ void dma_side(int slot, const Ring3<LIMBS>& rs, unsigned* dst, int kb0) {
+    constexpr int PIECES = NKB * LIMBS;                     // per wave
+    if (slot % 3 == 2 && slot / 3 < PIECES) {
+        const int i = slot / 3;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
+                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+    }
+}
+// the last piece of a chunk is issued in slot 3 * PIECES - 1 <= 35 of a block that also issues a gather: at least 12 of that gather's loads
+// and the 24 of the next block's are younger
+constexpr int YOUNGER_THAN_CHUNK = 32;
+
 // =====================================================================================================================
 template <int LIMBS>
 __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
@@ -188,7 +210,11 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
     const float* small = ldsf + L::SMALL;
 
     const int lane0 = rs.lane;
-    const long base = (long)blockIdx.x * RAYS2 + rs.wave * 64 + (lane0 & 31);
+    // XCD-aware ray blocks: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.  Give XCD x the x-th contiguous
+    // eighth of the ray blocks, so that the workgroups that share an L2 render neighbouring image rows (their taps share texels).
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, per = nblk >> 3, rem = nblk & 7u;
+    const unsigned blk = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const long base = (long)blk * RAYS2 + rs.wave * 64 + (lane0 & 31);
     long rayX = base, rayY = base + 32;
     const bool validX = rayX < N, validY = rayY < N;
     if (!validX) rayX = N - 1;
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
     float stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-    const unsigned* cw = ring3_issue<LIMBS, 3>(rs, KB_RGB0);      // chunk 0 of sample 0; every later one is issued during the previous sample
+    unsigned* cw = const_cast<unsigned*>(ring3_issue<LIMBS, 3>(rs, KB_RGB0));      // chunk 0 of sample 0; every later one is issued during the previous sample
     for (int s = 0; s < S; ++s) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
@@ -284,14 +310,16 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         GatherJob ja, jb;
         R3_MARK(0)      // loop top
         ring3_sync<2>();                                         // chunk 0 (issued during the previous sample) -- younger: the two z loads above
-        const unsigned* nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 3);
+        unsigned* nw = ring3_take(rs);
         R3_MARK(1)      // first ring wait
         R3_RESET
 #define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS>(slot, JL, TL.F, JB, TB.F, h, rt); }
+#define NVSR_ROLL_DMA(TL, JL, TB, JB, LOADS, BLENDS, NKB, KB0) \
+        [&](int slot) { gather_roll<NSF, LOADS, BLENDS>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
         // X view | loads X plane 0
         ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2);
         split_feat(X.V);
-        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL(X, ja, Y, jb, true, false), NoTail{});
+        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL_DMA(X, ja, Y, jb, true, false, 3, KB_RGB0 + 3), NoTail{});
         R3_MARKB(0)
         // Y view | blends X plane 0, loads Y plane 0
         jb.plane = sc.plane[0]; jb.t = pos_taps2(sc, 0, yn0, yn1, yn2);
@@ -299,14 +327,14 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.V), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(1)
         cw = nw;
-        ring3_sync<48>();                                        // younger than the chunk: the 2 x 24 gather loads of the two blocks
-        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 6);
+        ring3_sync<YOUNGER_THAN_CHUNK>();
+        nw = ring3_take(rs);
         // X plane 0 | blends Y plane 0, loads X plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
         ja.plane = sc.plane[1]; ja.t = pos_taps2(sc, 1, xn0, xn1, xn2);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 6), NoTail{});
         R3_MARKB(2)
         // Y plane 0 | blends X plane 1, loads Y plane 1
 #pragma unroll
@@ -316,14 +344,14 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(3)
         cw = nw;
-        ring3_sync<48>();
-        nw = ring3_issue<LIMBS, 3>(rs, KB_RGB0 + 9);
+        ring3_sync<YOUNGER_THAN_CHUNK>();
+        nw = ring3_take(rs);
         // X plane 1 | blends Y plane 1, loads X plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = __fadd_rn(X.D[c], X.F[c]);
         ja.plane = sc.plane[2]; ja.t = pos_taps2(sc, 2, xn0, xn1, xn2);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 9), NoTail{});
         R3_MARKB(4)
         // Y plane 1 | blends X plane 2, loads Y plane 2
 #pragma unroll
@@ -333,13 +361,13 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(5)
         cw = nw;
-        ring3_sync<48>();
-        nw = ring3_issue<LIMBS, 4>(rs, KB_RGB1);
+        ring3_sync<YOUNGER_THAN_CHUNK>();
+        nw = ring3_take(rs);
         // X plane 2 | blends Y plane 2;  D = (D + F) / 3   (combine_pos_planes 'avg', models.py:358-359)
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = div3(__fadd_rn(X.D[c], X.F[c]));
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, false, true), NoTail{});
+        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, false, true, 4, KB_RGB1), NoTail{});
         R3_MARKB(6)
         // Y plane 2 | X: act = max(acc + bias, 0); tail: limbs of X's K-block 0
 #pragma unroll
@@ -362,17 +390,19 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         R3_RESETH                                                                                                                   \
         SYNC;                                                                                                                       \
         R3_MARKH(0)                                                                                                                 \
-        nw = ring3_issue<LIMBS, NKB_A>(rs, KB_NEXT_A);                                                                              \
+        nw = ring3_take(rs);                                                                                                        \
         R3_MARKH(1)                                                                                                                 \
-        limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0), XA_SIDE, tail_of(Y.act, 0));                      \
+        limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0),                                                   \
+                                         [&](int slot) { (XA_SIDE)(slot); dma_side<LIMBS, NKB_A>(slot, rs, nw, KB_NEXT_A); }, tail_of(Y.act, 0)); \
         R3_MARKH(2)                                                                                                                 \
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
         R3_MARKH(3)                                                                                                                 \
         cw = nw;                                                                                                                    \
         ring2_sync();                                                                                                               \
-        nw = ring3_issue<LIMBS, NKB_B>(rs, KB_NEXT_B);                                                                              \
+        nw = ring3_take(rs);                                                                                                        \
         R3_MARKH(4)                                                                                                                 \
-        limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4), none, tail_of(Y.act, 4));                        \
+        limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4),                                                  \
+                                          [&](int slot) { dma_side<LIMBS, NKB_B>(slot, rs, nw, KB_NEXT_B); }, tail_of(Y.act, 4));   \
         R3_MARKH(5)                                                                                                                 \
         X_B_SIDE;                                                                                                                   \
         R3_MARKH(6)                                                                                                                 \
@@ -390,7 +420,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
         R3_MARK(3)      // rgb layers 1..3
         // ---- density layer 0 (from D) -------------------------------------------------------------------------------------------
         ring2_sync();
-        nw = ring3_issue<LIMBS, 4>(rs, KB_DEN1);
+        nw = ring3_take(rs);
         // X density 0 | Y: act of rgb layer 3; X: rgb heads
         float hx[3] = {0.0f, 0.0f, 0.0f};
         split_feat(X.D);
@@ -398,6 +428,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
                                          [&](int slot) {
                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp); });
                                              spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
+                                             dma_side<LIMBS, 4>(slot, rs, nw, KB_DEN1);
                                          },
                                          NoTail{});
 #pragma unroll
@@ -432,6 +463,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
 #undef NVSR_HIDDEN_LAYER
 #undef NVSR_HIDDEN_LAYER_
 #undef NVSR_ROLL
+#undef NVSR_ROLL_DMA
 #undef NVSR_YB_PLAIN
         X.raw[3] = (sx[0] + __shfl_xor(sx[0], 32)) + small[S_HEAD_B];
         R3_MARK(5)      // density layers 1..3
