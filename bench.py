@@ -293,16 +293,34 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
 
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
     value = world * 3 * args.steps / elapsed
+    mode = nvsr_amd.capi.get_conv_arithmetic()
+    arith = ARITHMETIC[mode]
     result = {"metric": "super-resolved feature planes/sec (48ch 200^2 -> 800^2, EDSR hidden 256 x 32 blocks)", "value": value, "unit": "planes/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "scaling": "weak", "vs_baseline": None, "dtype": arith["dtype"], "data": "synthetic", "conv_arithmetic": mode,
               "config": {"workload": "PlanesSR full-plane pass over the 3 position planes of one scene (batched), LR 200^2 + 68 px replicate "
                                      "padding -> HR 800^2", "planes_per_step_per_gpu": 3, "parallelism": "replicas only"}}
     if rank == 0:
         ach = flop_scene / (elapsed / args.steps) / 1e12
-        result["roofline"] = {"kernel": "conv3x3_kernel (70 launches per step)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                              "algorithmic_flop_per_step": flop_scene}
+        peak = arith["pipe_peak"] / arith["products"]
+        kname = "conv3x3_kernel" if mode == "f32" else "conv3x3_limb_kernel (69 of the 70 launches; the 256->48 output conv stays on conv3x3_kernel, 2.5 % of the FLOP)"
+        result["roofline"] = {"kernel": "%s (70 launches per step)" % kname, "bound": "mfma", "achieved": ach, "peak": peak,
+                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "algorithmic_flop_per_step": flop_scene,
+                              "peak_note": "algorithmic f32 FLOP over the whole step; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
+                                           % (arith["pipe_peak"], arith["products"]),
+                              "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
+        if world == 1 and not args.no_modes:
+            modes = {}
+            for m2 in ("f32", "bf16x3"):
+                nvsr_amd.capi.set_conv_arithmetic(m2)
+                one(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    one()
+                torch.cuda.synchronize()
+                modes[m2] = {"planes_per_s": 3 * 2 / (time.perf_counter() - t1), "ms_per_step": 1e3 * (time.perf_counter() - t1) / 2}
+            nvsr_amd.capi.set_conv_arithmetic(mode)
+            result["arithmetic_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
             o = Oracle(f32=True)

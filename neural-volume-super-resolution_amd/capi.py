@@ -39,6 +39,8 @@ _PROTOS = {
     "nvsr_version": ([], C.c_int),
     "nvsr_get_decoder_arithmetic": ([], C.c_int),
     "nvsr_set_decoder_arithmetic": ([_i], _i),
+    "nvsr_get_conv_arithmetic": ([], C.c_int),
+    "nvsr_set_conv_arithmetic": ([_i], _i),
     "nvsr_plane_to_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "nvsr_plane_from_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "nvsr_pack_decoder": ([_vp, _vp, _vp], _i),
@@ -120,6 +122,15 @@ def set_decoder_arithmetic(mode):
 def get_decoder_arithmetic():
     code = lib().nvsr_get_decoder_arithmetic()
     return {v: k for k, v in ARITHMETIC.items()}[code]
+
+
+def set_conv_arithmetic(mode):
+    """Arithmetic of the wide 3x3 conv layers of the SR network: 'f32' | 'bf16x3'."""
+    call("nvsr_set_conv_arithmetic", ARITHMETIC[mode])
+
+
+def get_conv_arithmetic():
+    return {v: k for k, v in ARITHMETIC.items()}[lib().nvsr_get_conv_arithmetic()]
 
 
 def exported_symbols():

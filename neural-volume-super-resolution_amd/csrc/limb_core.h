@@ -21,10 +21,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int limb_products(int limbs) { return limbs == 3 ? 6 : 3; }
+// (always_inline: inside a very large kernel the inliner otherwise leaves these as CALLS, and an operand index that is not a compile-time
+//  constant turns every fragment selection into a chain of v_cndmask over a merged register array)
+#define NVSR_CX __host__ __device__ __attribute__((always_inline)) constexpr
+NVSR_CX int limb_products(int limbs) { return limbs == 3 ? 6 : 3; }
 // product p of a (weight limb, activation limb) set, small terms first
-constexpr int limb_w(int limbs, int p) { return limbs == 3 ? (p < 3 ? 0 : p < 5 ? 1 : 2) : (p < 2 ? 0 : 1); }
-constexpr int limb_x(int limbs, int p) { return limbs == 3 ? (p == 0 ? 2 : p == 1 ? 1 : p == 2 ? 0 : p == 3 ? 1 : 0) : (p == 0 ? 1 : 0); }
+NVSR_CX int limb_w(int limbs, int p) { return limbs == 3 ? (p < 3 ? 0 : p < 5 ? 1 : 2) : (p < 2 ? 0 : 1); }
+NVSR_CX int limb_x(int limbs, int p) { return limbs == 3 ? (p == 0 ? 2 : p == 1 ? 1 : p == 2 ? 0 : p == 3 ? 1 : 0) : (p == 0 ? 1 : 0); }
 
 // K-blocks (16 input channels each) of the decoder in consumption order
 constexpr int KB_RGB0 = 0;          // 4 planes x 3
@@ -80,6 +83,19 @@ __device__ __forceinline__ void split_all(Get get, Limbs<LIMBS>& out) {
     SplitPend p;
 #pragma unroll
     for (int s = 0; s < 4 * limb_products(LIMBS); ++s) split_slice<LIMBS>(s, get, out, p);
+}
+
+// straight-line 3-limb split of 8 values (the sliced form above is for MFMA gaps)
+__device__ __forceinline__ void split8(const float (&e)[8], Limbs<3>& out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0 = e[2 * j], r1 = e[2 * j + 1];
+        out.v[0][j] = trunc_pair(r1, r0);
+        r0 = limb_rest(r0); r1 = limb_rest(r1);
+        out.v[1][j] = trunc_pair(r1, r0);
+        r0 = limb_rest(r0); r1 = limb_rest(r1);
+        out.v[2][j] = trunc_pair(r1, r0);
+    }
 }
 
 // steps [0, NSTEPS) of a piece of side work spread evenly over the slots [S0, S1) of a block

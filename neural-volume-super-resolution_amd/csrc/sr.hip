@@ -13,6 +13,10 @@
 // narrow heads.  Epilogues fuse ReLU, the residual block's x0.1 + centre-cropped identity, and PixelShuffle(2).
 #include <type_traits>
 
+#include <cstdlib>
+#include <cstring>
+
+#include "limb_core.h"
 #include "sr_core.h"
 
 namespace nvsr {
@@ -25,6 +29,7 @@ namespace nvsr {
 struct ConvParams {
     const float* in;      // [Cin][H-2pad][W-2pad]
     const float* wpk;     // packed weights [chunk][cb][t][lane]
+    const unsigned* wpk_limb;   // bf16-limb fragments behind them (conv_limb_eligible layers), else NULL
     float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
     const float* skip;    // EPI_RESIDUAL: identity [Cout][H+2][W+2] (block input); EPI_MASK_SCALE: forward activation
                           // [Cout][H-2][W-2] whose sign gates the result; EPI_ADD_CENTER: [Cout][H-6][W-6] added to the centre
@@ -38,6 +43,49 @@ struct ConvParams {
 };
 
 __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
+
+// Epilogue shared by the conv kernels: acc[cb][pb] = 32 output channels (co0 + 32 cb + C/D row) x the 32 pixels of output row y0 + pb.
+// (one fully unrolled copy per epilogue kind: with the kind tested inside, the unroller gives up and the accumulators are
+//  indexed dynamically, i.e. go through scratch)
+template <int PB>
+__device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16 (&acc)[2][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
+    auto write_out = [&](auto kind) {
+        constexpr int EPI = decltype(kind)::value;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int y = y0 + pb;
+                const bool inside = y < Ho && x < Wo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (inside && co < p.Cout) {
+                        float v = acc[cb][pb][r];
+                        if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
+                        if (EPI == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
+                            v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
+                        if (EPI == EPI_MASK_SCALE)  // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
+                            v = (p.skip[((long)co * Ho + y) * Wo + x] > 0.0f) ? v * 0.1f : 0.0f;
+                        if (EPI == EPI_ADD_CENTER)  // backward of the cropped identity: the block's output gradient lands in the centre
+                            if (y >= 2 && y < Ho - 2 && x >= 2 && x < Wo - 2) v += p.skip[((long)co * (Ho - 4) + (y - 2)) * (Wo - 4) + (x - 2)];
+                        if (EPI == EPI_PIXEL_SHUFFLE)
+                            p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
+                        else
+                            p.out[((long)co * Ho + y) * Wo + x] = v;
+                    }
+                }
+            }
+    };
+    switch (p.epilogue) {
+        case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
+        case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
+        case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
+        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
+        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
+        default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
+    }
+}
 
 // PB = output rows (32-pixel blocks) per wave: 4 by default; the launcher picks 3 or 2 for a layer whose tile count would otherwise leave most
 // of the last workgroup round empty (a ~270^2 plane is 1.2 rounds of 4-row tiles on 512 workgroup slots, but 1.0 rounds of 3-row tiles... )
@@ -139,46 +187,156 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
-    // (one fully unrolled copy per epilogue kind: with the kind tested inside, the unroller gives up and the accumulators are
-    //  indexed dynamically, i.e. go through scratch)
-    const int x = x0 + j;
-    auto write_out = [&](auto kind) {
-        constexpr int EPI = decltype(kind)::value;
+    conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, (cg * NCB + cw * 2) * 32, h, Ho, Wo);
+}
+
+// ---- the same conv on the bf16 matrix pipe: f32 operands as 3 exact bf16 limbs (limb_core.h), 6 MFMAs per product block -------------
+// Workgroup = 4 waves = 256 output channels (2 co-blocks per wave) x PB output rows x 32 pixels; input channels stream 16 at a time
+// (one K-block per tap).  The input patch is split into limbs ONCE when it is staged -- every staged value feeds 9 taps x 8 co-blocks --
+// and kept in LDS as [limb][row][col][octet][8 bf16], so a B operand (8 channels of one pixel) is one conflict-free ds_read_b128.
+// Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
+template <int PB>
+__global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
+    constexpr int PR = PB + 2, PC = 34;
+    constexpr int ITEMS = 2 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
+    constexpr int IT = (ITEMS + 255) / 256;
+    constexpr int LIMB_WORDS = PR * PC * 2 * 4;           // one limb of the patch
+    constexpr int BUF = 3 * LIMB_WORDS;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int Ho = p.H - 2, Wo = p.W - 2;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * PB, cg = blockIdx.z % p.ncg, bi = blockIdx.z / p.ncg;
+    p.in += bi * p.in_bs;
+    p.out += bi * p.out_bs;
+    if (p.skip) p.skip += bi * p.skip_bs;
+    const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
+    const long HW = (long)Hr * Wr;
+
+    // staging items: every load is unconditional (clamped source, uniform channel base + one 32-bit lane offset); border pixels and the
+    // threads past the last item are handled by ONE select / ONE store predicate per item
+    int voff[IT], sl[IT];
+    bool inside[IT], item[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 256 + tid;
+        item[i] = e < ITEMS;
+        const int ee = item[i] ? e : 0;
+        const int o = ee / (PR * PC), rem = ee - o * (PR * PC), r = rem / PC, c = rem - r * PC;
+        const int yr = min(y0 + r, p.H - 1) - p.pad, xr = min(x0 + c, p.W - 1) - p.pad;
+        inside[i] = yr >= 0 && yr < Hr && xr >= 0 && xr < Wr;
+        voff[i] = o * 8 * (int)HW + (inside[i] ? yr * Wr + xr : 0);
+        sl[i] = ((r * PC + c) * 2 + o) * 4;
+    }
+    float st[IT][8];
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* cbase = p.in + (long)(chunk * 16 + k) * HW;        // wave-uniform
+#pragma unroll
+            for (int i = 0; i < IT; ++i) st[i][k] = cbase[voff[i]];
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            Limbs<3> L;
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = inside[i] ? st[i][k] : 0.0f;
+            split8(e, L);
+            if (item[i]) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(lds + buf * BUF + t * LIMB_WORDS + sl[i]) = L.v[t];
+            }
+        }
+    };
+
+    f32x16 acc[2][PB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nchunks = p.Cin / 16;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wpk_limb) + ((long)(cg * 8 + wave_u * 2) * 27) * 64;   // wave-uniform
+    const long wchunk = (long)p.ncb_total * 27 * 64;        // u32x4 per chunk
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) gload(chunk + 1);          // in flight during this chunk's MFMAs
+        const u32x4* wa = wbase + chunk * wchunk;
+        const unsigned* pl = lds + buf * BUF + (j * 2 + h) * 4;
+        // A fragments one tap ahead (the sched_barriers keep hipcc from hoisting every load of the chunk to its top: 95+ spills)
+        u32x4 A[2][3], An[2][3];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                const int y = y0 + rg * PB + pb;
-                const bool inside = y < Ho && x < Wo;
+            for (int t = 0; t < 3; ++t) A[cb][t] = wa[((cb * 9 + 0) * 3 + t) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = (cg * NCB + cw * 2 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (inside && co < p.Cout) {
-                        float v = acc[cb][pb][r];
-                        if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
-                        if (EPI == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
-                            v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
-                        if (EPI == EPI_MASK_SCALE)  // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
-                            v = (p.skip[((long)co * Ho + y) * Wo + x] > 0.0f) ? v * 0.1f : 0.0f;
-                        if (EPI == EPI_ADD_CENTER)  // backward of the cropped identity: the block's output gradient lands in the centre
-                            if (y >= 2 && y < Ho - 2 && x >= 2 && x < Wo - 2) v += p.skip[((long)co * (Ho - 4) + (y - 2)) * (Wo - 4) + (x - 2)];
-                        if (EPI == EPI_PIXEL_SHUFFLE)
-                            p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
-                        else
-                            p.out[((long)co * Ho + y) * Wo + x] = v;
-                    }
-                }
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * 3 + t) * 64 + lane];
             }
-    };
-    switch (p.epilogue) {
-        case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
-        case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
-        case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
-        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
-        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
-        default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                u32x4 B[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((pb + ky) * PC + kx) * 8);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc[cb][pb] = mfma_bf16(A[cb][limb_w(3, q)], B[limb_x(3, q)], acc[cb][pb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) A[cb][t] = An[cb][t];
+            }
+        }
+        if (chunk + 1 < nchunks) sstore(buf ^ 1);
+        __syncthreads();
     }
+    conv_write_out<PB>(p, acc, x0 + j, y0, (cg * 8 + wave * 2) * 32, h, Ho, Wo);
+}
+
+// limb fragments of a conv's weights: [chunk of 16 ci][cb][tap][limb][lane][4 words]; lane (co = 32 cb + (l & 31), h = l >> 5) holds
+// the 8 input channels 16 chunk + 8 h + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
+__global__ void pack_conv_limbs_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int ncb, int transposed) {
+    const long n = (long)(Cin / 16) * ncb * CL_FRAG_WORDS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % 3), tap = (int)((idx / 768) % 9);
+    const long rest = idx / CL_FRAG_WORDS;
+    const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
+    const int co = 32 * cb + (lane & 31), h = lane >> 5;
+    unsigned word = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int ci = 16 * chunk + 8 * h + 2 * wd + half;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) v = transposed ? w[((long)ci * Cout + co) * 9 + (8 - tap)] : w[((long)co * Cin + ci) * 9 + tap];
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == t) bits = __float_as_uint(v) >> 16;
+            v = limb_rest(v);
+        }
+        word |= bits << (16 * half);
+    }
+    out[idx] = word;
 }
 
 // [Cout][Cin][3][3] -> [chunk][cb][t][lane].  transposed: the packed conv is the DATA GRADIENT of w's conv, i.e. it maps Cout
@@ -232,6 +390,23 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
     out[i] = diff[((long)c * Ho + dy) * Wo + dx] + res;
 }
 
+// arithmetic of the eligible conv layers (process-wide): -1 = not yet read from the environment
+static int g_conv_arithmetic = -1;
+extern "C" int nvsr_get_conv_arithmetic(void) {
+    if (g_conv_arithmetic < 0) {
+        const char* e = getenv("NVSR_CONV_ARITHMETIC");
+        g_conv_arithmetic = NVSR_CONV_ARITH_DEFAULT;
+        if (e && !strcmp(e, "f32")) g_conv_arithmetic = NVSR_ARITH_F32;
+        if (e && !strcmp(e, "bf16x3")) g_conv_arithmetic = NVSR_ARITH_BF16X3;
+    }
+    return g_conv_arithmetic;
+}
+extern "C" int nvsr_set_conv_arithmetic(int mode) {
+    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    g_conv_arithmetic = mode;
+    return NVSR_OK;
+}
+
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad, int batch) {
     const long in_bs = (long)Cin * H * W;
@@ -241,7 +416,26 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     const long out_bs = (long)Cout * Ho * Wo;       // (PixelShuffle only permutes the Cout*Ho*Wo elements)
     const long skip_bs = epilogue == EPI_RESIDUAL ? (long)Cout * (Ho + 4) * (Wo + 4)
                          : epilogue == EPI_ADD_CENTER ? (long)Cout * (Ho - 4) * (Wo - 4) : out_bs;
-    ConvParams p{in, wpk, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    const unsigned* wlimb = conv_limb_eligible(Cin, Cout) ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) : nullptr;
+    ConvParams p{in, wpk, wlimb, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    if (wlimb && nvsr_get_conv_arithmetic() != NVSR_ARITH_F32) {
+        // bf16-limb kernel: 4-wave workgroups of 256 output channels x PB rows x 32 pixels; same choice of the row count as below
+        p.ncg = p.ncb_total / 8;
+        dim3 grid((Wo + 31) / 32, 1, p.ncg * batch);
+        int best_pb = 4;
+        double best_cost = 1e300;
+        for (int pb = 4; pb >= 2; --pb) {
+            const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+            const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
+            if (cost < best_cost) { best_cost = cost; best_pb = pb; }
+        }
+        if (const char* e = getenv("NVSR_CONV_LIMB_PB")) best_pb = atoi(e);       // experiments
+        grid.y = (Ho + best_pb - 1) / best_pb;
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb_kernel<4>), grid, dim3(256), 0, stream, p);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb_kernel<3>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_limb_kernel<2>), grid, dim3(256), 0, stream, p);
+        return NVSR_CHECK_LAUNCH();
+    }
     if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
         p.ncg = p.ncb_total / 8;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
@@ -284,9 +478,12 @@ int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_str
     if (!w || !packed) return NVSR_ERR_NULL;
     if (Cin < 1 || Cout < 1) return NVSR_ERR_SHAPE;
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
-    const int64_t n = conv_packed_floats(Cin, Cout);
+    const int64_t n = conv_packed_f32_floats(Cin, Cout);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout,
                        conv_ncb(Cout), conv_nchunks(Cin), 0);
+    if (const int64_t nl = conv_packed_limb_words(Cin, Cout))
+        hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           reinterpret_cast<unsigned*>(packed + n), Cin, Cout, conv_ncb(Cout), 0);
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -296,9 +493,12 @@ int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nv
     if (!w || !packed) return NVSR_ERR_NULL;
     if (Cin < 1 || Cout < 1) return NVSR_ERR_SHAPE;
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
-    const int64_t n = conv_packed_floats(Cout, Cin);
+    const int64_t n = conv_packed_f32_floats(Cout, Cin);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        conv_ncb(Cin), conv_nchunks(Cout), 1);
+    if (const int64_t nl = conv_packed_limb_words(Cout, Cin))
+        hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           reinterpret_cast<unsigned*>(packed + n), Cout, Cin, conv_ncb(Cin), 1);
     return NVSR_CHECK_LAUNCH();
 }
 

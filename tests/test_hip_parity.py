@@ -425,24 +425,44 @@ def test_edsr_and_planes_sr_golden(hip):
 
 
 def test_conv3x3_shapes_vs_oracle(hip, oracle):
-    """channel counts that exercise both workgroup shapes and the padding of Cin/Cout (48->256, 256->256, 256->48, 16->64 shuffle)"""
+    """channel counts that exercise both workgroup shapes and the padding of Cin/Cout (48->256, 256->256, 256->48, 16->64 shuffle,
+    256->1024 shuffle), in both arithmetic modes (the wide layers run on the bf16-limb kernel by default: f32-grade products, the same
+    tolerance; the others always on the f32 kernel)"""
     rng = np.random.default_rng(3)
     capi = hip.capi
-    for Cin, Cout, H, W, epi in [(48, 256, 21, 45, 0), (256, 256, 14, 40, 1), (256, 48, 37, 35, 0), (16, 64, 9, 70, 3), (5, 7, 3, 3, 0)]:
-        x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+    assert capi.get_conv_arithmetic() == "bf16x3"
+    try:
+        for Cin, Cout, H, W, epi in [(48, 256, 21, 45, 0), (256, 256, 14, 40, 1), (256, 48, 37, 35, 0), (16, 64, 9, 70, 3), (5, 7, 3, 3, 0),
+                                     (256, 1024, 9, 37, 3), (256, 256, 5, 131, 0)]:
+            x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+            w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+            xd, wd = T(x), T(w)
+            pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cin, Cout), device=DEV)
+            capi.call("nvsr_pack_conv3x3", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+            ref = oracle.conv3x3(x, w, relu=(epi == 1))
+            if epi == 3:
+                ref = ref.reshape(Cout // 4, 2, 2, H - 2, W - 2).transpose(0, 3, 1, 4, 2).reshape(Cout // 4, 2 * (H - 2), 2 * (W - 2))
+            for mode in ("bf16x3", "f32"):
+                capi.set_conv_arithmetic(mode)
+                out = torch.full(ref.shape, -7.0, device=DEV)
+                capi.call("nvsr_conv3x3", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, None, capi.ptr(out), capi.stream())
+                # unit-variance data: fp32 accumulation over K = 9*Cin terms, |out| up to ~4  ->  ~sqrt(K)*2^-24*|out|
+                np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi, mode)))
+        # data gradient of a wide layer (the same kernels with a virtual zero border and the flipped, transposed weights)
+        Cin, Cout, H, W = 256, 256, 11, 38
         w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
-        xd, wd = T(x), T(w)
-        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cin, Cout), device=DEV)
-        capi.call("nvsr_pack_conv3x3", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
-        ref = oracle.conv3x3(x, w, relu=(epi == 1))
-        if epi == 3:
-            out = torch.empty((Cout // 4, 2 * (H - 2), 2 * (W - 2)), device=DEV)
-            ref = ref.reshape(Cout // 4, 2, 2, H - 2, W - 2).transpose(0, 3, 1, 4, 2).reshape(Cout // 4, 2 * (H - 2), 2 * (W - 2))
-        else:
-            out = torch.empty((Cout, H - 2, W - 2), device=DEV)
-        capi.call("nvsr_conv3x3", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, None, capi.ptr(out), capi.stream())
-        # unit-variance data: fp32 accumulation over K = 9*Cin terms, |out| up to ~4  ->  ~sqrt(K)*2^-24*|out|
-        np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi)))
+        dy = rng.standard_normal((Cout, H - 2, W - 2), dtype=np.float32)
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cout, Cin), device=DEV)
+        capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(T(w)), Cin, Cout, capi.ptr(pk), capi.stream())
+        wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
+        ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
+        for mode in ("bf16x3", "f32"):
+            capi.set_conv_arithmetic(mode)
+            dx = torch.full((Cin, H, W), -7.0, device=DEV)
+            capi.call("nvsr_conv3x3_dgrad", capi.ptr(T(dy)), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), capi.stream())
+            np.testing.assert_allclose(N_(dx), ref, rtol=0, atol=3e-5, err_msg="dgrad " + mode)
+    finally:
+        capi.set_conv_arithmetic("bf16x3")
 
 
 def test_planes_sr_batch_is_bit_identical_to_one_by_one(hip):
