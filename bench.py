@@ -303,7 +303,7 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
     if rank == 0:
         ach = flop_scene / (elapsed / args.steps) / 1e12
         peak = arith["pipe_peak"] / arith["products"]
-        kname = "conv3x3_kernel" if mode == "f32" else "conv3x3_limb_kernel (69 of the 70 launches; the 256->48 output conv stays on conv3x3_kernel, 2.5 % of the FLOP)"
+        kname = "conv3x3_kernel" if mode == "f32" else "conv3x3_limb_kernel"
         result["roofline"] = {"kernel": "%s (70 launches per step)" % kname, "bound": "mfma", "achieved": ach, "peak": peak,
                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "algorithmic_flop_per_step": flop_scene,
                               "peak_note": "algorithmic f32 FLOP over the whole step; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"

@@ -195,9 +195,12 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // (one K-block per tap).  The input patch is split into limbs ONCE when it is staged -- every staged value feeds 9 taps x 8 co-blocks --
 // and kept in LDS as [limb][row][col][octet][8 bf16], so a B operand (8 channels of one pixel) is one conflict-free ds_read_b128.
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
-template <int PB>
+// CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
+// take the same 2 output blocks of 4 consecutive groups of PB rows.
+template <int PB, int CO_WAVES = 4>
 __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
-    constexpr int PR = PB + 2, PC = 34;
+    constexpr int PX_WAVES = 4 / CO_WAVES, ROWS = PX_WAVES * PB;
+    constexpr int PR = ROWS + 2, PC = 34;
     constexpr int ITEMS = 2 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
     constexpr int IT = (ITEMS + 255) / 256;
     constexpr int LIMB_WORDS = PR * PC * 2 * 4;           // one limb of the patch
@@ -206,12 +209,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int Ho = p.H - 2, Wo = p.W - 2;
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * PB, cg = blockIdx.z % p.ncg, bi = blockIdx.z / p.ncg;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * ROWS, cg = blockIdx.z % p.ncg, bi = blockIdx.z / p.ncg;
     p.in += bi * p.in_bs;
     p.out += bi * p.out_bs;
     if (p.skip) p.skip += bi * p.skip_bs;
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int cw = wave_u / PX_WAVES, rg = wave_u % PX_WAVES;   // co-wave, pixel-row group
+    const int cb0 = (cg * CO_WAVES + cw) * 2;                   // first of this wave's two output blocks
 
     // staging items: every load is unconditional (clamped source, uniform channel base + one 32-bit lane offset); border pixels and the
     // threads past the last item are handled by ONE select / ONE store predicate per item
@@ -261,8 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const int nchunks = p.Cin / 16;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wpk_limb) + ((long)(cg * 8 + wave_u * 2) * 27) * 64;   // wave-uniform
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wpk_limb) + ((long)cb0 * 27) * 64;   // wave-uniform
     const long wchunk = (long)p.ncb_total * 27 * 64;        // u32x4 per chunk
     gload(0);
     sstore(0);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
             for (int pb = 0; pb < PB; ++pb) {
                 u32x4 B[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((pb + ky) * PC + kx) * 8);
+                for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + pb + ky) * PC + kx) * 8);
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out<PB>(p, acc, x0 + j, y0, (cg * 8 + wave * 2) * 32, h, Ho, Wo);
+    conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);
 }
 
 // limb fragments of a conv's weights: [chunk of 16 ci][cb][tap][limb][lane][4 words]; lane (co = 32 cb + (l & 31), h = l >> 5) holds
@@ -418,6 +423,13 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                          : epilogue == EPI_ADD_CENTER ? (long)Cout * (Ho - 4) * (Wo - 4) : out_bs;
     const unsigned* wlimb = conv_limb_eligible(Cin, Cout) ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) : nullptr;
     ConvParams p{in, wpk, wlimb, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    if (wlimb && nvsr_get_conv_arithmetic() != NVSR_ARITH_F32 && p.ncb_total == 2) {
+        // narrow layer: 4 waves x 2 rows each of the same 64 output channels
+        p.ncg = 1;
+        dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
+        hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
+        return NVSR_CHECK_LAUNCH();
+    }
     if (wlimb && nvsr_get_conv_arithmetic() != NVSR_ARITH_F32) {
         // bf16-limb kernel: 4-wave workgroups of 256 output channels x PB rows x 32 pixels; same choice of the row count as below
         p.ncg = p.ncb_total / 8;

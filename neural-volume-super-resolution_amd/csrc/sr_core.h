@@ -17,10 +17,10 @@ struct ConvLayer { int Cin, Cout; };
 inline int conv_ncb(int Cout) { return (Cout + 63) / 64 * 2; }
 inline int conv_nchunks(int Cin) { return (Cin + 3) / 4; }
 inline int64_t conv_packed_f32_floats(int Cin, int Cout) { return (int64_t)conv_nchunks(Cin) * conv_ncb(Cout) * FRAG_FLOATS; }
-// bf16-limb fragments (sr.hip, conv3x3_limb_kernel): layers with Cin % 16 == 0 and a multiple of 256 output channels carry, behind the f32
+// bf16-limb fragments (sr.hip, conv3x3_limb_kernel): layers with Cin % 16 == 0 and a multiple of 256 (or at most 64) output channels carry, behind the f32
 // fragments, [chunk of 16 input channels][co-block][tap 0..8][limb 0..2][lane][4 words] = 6912 words per (chunk, co-block)
 constexpr int CL_FRAG_WORDS = 9 * 3 * 256;
-inline bool conv_limb_eligible(int Cin, int Cout) { return Cin % 16 == 0 && conv_ncb(Cout) % 8 == 0; }
+inline bool conv_limb_eligible(int Cin, int Cout) { return Cin % 16 == 0 && (conv_ncb(Cout) % 8 == 0 || conv_ncb(Cout) == 2); }
 inline int64_t conv_packed_limb_words(int Cin, int Cout) {
     return conv_limb_eligible(Cin, Cout) ? (int64_t)(Cin / 16) * conv_ncb(Cout) * CL_FRAG_WORDS : 0;
 }
