@@ -10,7 +10,10 @@
 //     9 shifts.  Workgroups split the image rows; their partial sums go to a workspace and a second kernel reduces them in a fixed
 //     order (deterministic, no float atomics) into the natural [co][ci][3][3] layout;
 //   * PixelShuffle^T is an explicit re-layout kernel (0.1 % of the time of the convs around it).
+#include "limb_core.h"
 #include "sr_core.h"
+
+extern "C" int nvsr_get_conv_arithmetic(void);
 
 namespace nvsr {
 
@@ -122,6 +125,129 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p)
     }
 }
 
+// ---- the same contraction on the bf16 matrix pipe (3 exact bf16 limbs per f32 operand, limb_core.h) ---------------------------------
+// Both operands are activations here, so both are split when they are staged: dy as [limb][co][40 px] and X as [limb][ci][3 rows][40 px]
+// bf16 (20-word rows: conflict-free ds_read_b128 for 16 consecutive channels), 8 consecutive pixels = one operand fragment.  A K-block is
+// 16 pixels of the row; the three kx taps of an X row come from ONE 5-word read: words 0..3, words 1..4, and their 16-bit funnel shift.
+constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels
+constexpr int WL_DY_WORDS = WG_CO * WL_ROW;               // one limb of dy
+constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
+constexpr int WL_X_OCTETS = WG_CI * 3 * 5;                // 960 groups of 8 pixels
+constexpr int WL_X_ITERS = (WL_X_OCTETS + WG_TPB - 1) / WG_TPB;   // 4
+
+__global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
+    unsigned* dyl = lds;                                  // [limb][co][WL_ROW]
+    unsigned* xl = lds + 3 * WL_DY_WORDS;                 // [limb][ci][row][WL_ROW]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
+    const int cw = wave & 1, iw = wave >> 1;
+    const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = blockIdx.z;
+    const int W = p.Wo + 2;
+    const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
+    const int ya = slab * p.rows_per_slab, yb = min(ya + p.rows_per_slab, p.Ho);
+    const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
+    const int nsteps = (yb - ya) * nxc;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // staging: thread -> (dy row tid >> 2, pixel octet tid & 3) and up to 4 X octets e = tid + 256 k -> (ci, row, octet) = (e / 15, e % 15 / 5, e % 5)
+    float rdy[8], rx[WL_X_ITERS][8];
+    const int dco = tid >> 2, doct = tid & 3;
+    int xci[WL_X_ITERS], xr[WL_X_ITERS], xo[WL_X_ITERS];
+#pragma unroll
+    for (int k = 0; k < WL_X_ITERS; ++k) {
+        const int e = min(tid + WG_TPB * k, WL_X_OCTETS - 1);
+        xci[k] = e / 15; xr[k] = (e % 15) / 5; xo[k] = e % 5;
+    }
+    auto fetch = [&](int step) {
+        const int y = ya + step / nxc, x0 = (step % nxc) * WG_PX;
+        const float* dp = p.dy + (long)min(co0 + dco, p.Cout - 1) * HoWo + (long)y * p.Wo;
+        const bool co_ok = co0 + dco < p.Cout;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = x0 + 8 * doct + k;
+            const float v = dp[min(px, p.Wo - 1)];
+            rdy[k] = (co_ok && px < p.Wo) ? v : 0.0f;       // pixels past the row's end and padded channels contribute nothing
+        }
+#pragma unroll
+        for (int q = 0; q < WL_X_ITERS; ++q) {
+            const bool ci_ok = ci0 + xci[q] < p.Cin;
+            const float* xp = p.x + (long)min(ci0 + xci[q], p.Cin - 1) * HW + (long)(y + xr[q]) * W;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = xp[min(x0 + 8 * xo[q] + k, W - 1)];   // columns past the edge only ever meet dy == 0: any finite value will do
+                rx[q][k] = ci_ok ? v : 0.0f;
+            }
+        }
+    };
+    auto stage = [&]() {
+        Limbs<3> L;
+        split8(rdy, L);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(dyl + t * WL_DY_WORDS + dco * WL_ROW + doct * 4) = L.v[t];
+#pragma unroll
+        for (int q = 0; q < WL_X_ITERS; ++q) {
+            split8(rx[q], L);
+            if (tid + WG_TPB * q < WL_X_OCTETS) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    *reinterpret_cast<u32x4*>(xl + t * WL_X_WORDS + (xci[q] * 3 + xr[q]) * WL_ROW + xo[q] * 4) = L.v[t];
+            }
+        }
+    };
+
+    if (nsteps > 0) fetch(0);
+    const unsigned* Ap = dyl + (cw * 32 + i) * WL_ROW + kh * 4;
+    const unsigned* Bp = xl + ((iw * 32 + i) * 3) * WL_ROW + kh * 4;
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                       // everyone is done reading the previous tile
+        stage();
+        __syncthreads();
+        if (step + 1 < nsteps) fetch(step + 1);   // global loads fly under the MFMAs below
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 A[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) A[t] = *reinterpret_cast<const u32x4*>(Ap + t * WL_DY_WORDS + kb * 8);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                u32x4 B0[3], B1[3], B2[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned* bp = Bp + t * WL_X_WORDS + ky * WL_ROW + kb * 8;
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(bp);
+                    const unsigned w4 = bp[4];
+                    B0[t] = w;
+                    B2[t] = u32x4{w[1], w[2], w[3], w4};
+                    B1[t] = u32x4{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                                  __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc[ky * 3 + 0] = mfma_bf16(A[limb_w(3, q)], B0[limb_x(3, q)], acc[ky * 3 + 0]);
+                    acc[ky * 3 + 1] = mfma_bf16(A[limb_w(3, q)], B1[limb_x(3, q)], acc[ky * 3 + 1]);
+                    acc[ky * 3 + 2] = mfma_bf16(A[limb_w(3, q)], B2[limb_x(3, q)], acc[ky * 3 + 2]);
+                }
+            }
+        }
+    }
+    // D[row = co][col = ci]: lanes run along ci -> 128-byte rows of the [tap][co][ci] partial
+    const int ci = ci0 + iw * 32 + i;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < p.Cout) p.partial[(((long)slab * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][r];
+            }
+    }
+}
+
 // dw[co][ci][tap] += scale * sum_slab partial[slab][tap][co][ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslab, int Cout, int Cin, float scale, float* __restrict__ dw) {
     const long n = 9L * Cout * Cin;
@@ -201,7 +327,8 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     const int ns = wgrad_slabs(Cin, Cout, Ho);
     WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns};
     dim3 grid((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(WG_TPB), 0, stream, p);
+    if (nvsr_get_conv_arithmetic() != NVSR_ARITH_F32) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, grid, dim3(WG_TPB), 0, stream, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(WG_TPB), 0, stream, p);
     const long n = 9L * Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
     return NVSR_CHECK_LAUNCH();
