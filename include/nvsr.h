@@ -70,8 +70,9 @@ int nvsr_version(void);
 #define NVSR_ARITH_DEFAULT NVSR_ARITH_BF16X3
 int nvsr_get_decoder_arithmetic(void);
 int nvsr_set_decoder_arithmetic(int mode);
-/* Same for the 3x3 convolutions of the SR network (forward and data gradient; layers with Cin % 16 == 0 and a multiple of 256 output
- * channels -- every wide layer of EDSR(256); the others always use the f32 kernel): NVSR_ARITH_F32 or NVSR_ARITH_BF16X3.
+/* Same for the 3x3 convolutions of the SR network: forward and data gradient of the layers with Cin % 16 == 0 and a multiple of 256, or at
+ * most 64, output channels (every layer of EDSR(256); other shapes always use the f32 kernel), and every weight gradient:
+ * NVSR_ARITH_F32 or NVSR_ARITH_BF16X3.
  * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3. */
 #define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_BF16X3
 int nvsr_get_conv_arithmetic(void);

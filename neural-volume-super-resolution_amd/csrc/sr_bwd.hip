@@ -32,6 +32,7 @@ struct WgradParams {
     float* partial;      // [nslab][9][Cout][Cin]
     int Cin, Cout, Ho, Wo;
     int rows_per_slab;
+    int rows_per_slab_limb;   // conv3x3_wgrad_limb_kernel: slab = (32-pixel column chunk, range of this many rows)
 };
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
@@ -132,8 +133,6 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p)
 constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels
 constexpr int WL_DY_WORDS = WG_CO * WL_ROW;               // one limb of dy
 constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
-constexpr int WL_X_OCTETS = WG_CI * 3 * 5;                // 960 groups of 8 pixels
-constexpr int WL_X_ITERS = (WL_X_OCTETS + WG_TPB - 1) / WG_TPB;   // 4
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
@@ -144,9 +143,9 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
     const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = blockIdx.z;
     const int W = p.Wo + 2;
     const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
-    const int ya = slab * p.rows_per_slab, yb = min(ya + p.rows_per_slab, p.Ho);
     const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
-    const int nsteps = (yb - ya) * nxc;
+    const int x0 = (slab % nxc) * WG_PX;
+    const int ya = (slab / nxc) * p.rows_per_slab_limb, yb = min(ya + p.rows_per_slab_limb, p.Ho);
 
     f32x16 acc[9];
 #pragma unroll
@@ -154,18 +153,44 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // staging: thread -> (dy row tid >> 2, pixel octet tid & 3) and up to 4 X octets e = tid + 256 k -> (ci, row, octet) = (e / 15, e % 15 / 5, e % 5)
-    float rdy[8], rx[WL_X_ITERS][8];
+    // A workgroup walks DOWN one 32-pixel column chunk (slab = (chunk, row range)): consecutive steps share two of their three X rows,
+    // which stay in LDS (ring of 3 row slots, row ya + k in slot k % 3) -- a step stages dy and ONE new X row.
+    // staging: thread -> (dy row tid >> 2, pixel octet tid & 3); X octets e = tid + 256 k, k < 2 -> (ci, octet) = (e / 5, e % 5) of one row
+    const int rows = yb - ya;
+    float rdy[8], rx[2][8];
     const int dco = tid >> 2, doct = tid & 3;
-    int xci[WL_X_ITERS], xr[WL_X_ITERS], xo[WL_X_ITERS];
+    int xci1[2], xo1[2];
 #pragma unroll
-    for (int k = 0; k < WL_X_ITERS; ++k) {
-        const int e = min(tid + WG_TPB * k, WL_X_OCTETS - 1);
-        xci[k] = e / 15; xr[k] = (e % 15) / 5; xo[k] = e % 5;
+    for (int k = 0; k < 2; ++k) {
+        const int e = min(tid + WG_TPB * k, WG_CI * 5 - 1);
+        xci1[k] = e / 5; xo1[k] = e % 5;
     }
-    auto fetch = [&](int step) {
-        const int y = ya + step / nxc, x0 = (step % nxc) * WG_PX;
-        const float* dp = p.dy + (long)min(co0 + dco, p.Cout - 1) * HoWo + (long)y * p.Wo;
+    auto fetch_row = [&](int row) {                           // X row `row` of this chunk -> rx
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool ci_ok = ci0 + xci1[q] < p.Cin;
+            const float* xp = p.x + (long)min(ci0 + xci1[q], p.Cin - 1) * HW + (long)row * W;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = xp[min(x0 + 8 * xo1[q] + k, W - 1)];   // columns past the edge only ever meet dy == 0: any finite value will do
+                rx[q][k] = ci_ok ? v : 0.0f;
+            }
+        }
+    };
+    auto stage_row = [&](int slot) {                          // rx -> row slot `slot`
+        Limbs<3> L;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            split8(rx[q], L);
+            if (tid + WG_TPB * q < WG_CI * 5) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    *reinterpret_cast<u32x4*>(xl + t * WL_X_WORDS + (xci1[q] * 3 + slot) * WL_ROW + xo1[q] * 4) = L.v[t];
+            }
+        }
+    };
+    auto fetch = [&](int yr) {                                // what step yr adds: dy row ya + yr, X row ya + yr + 2
+        const float* dp = p.dy + (long)min(co0 + dco, p.Cout - 1) * HoWo + (long)(ya + yr) * p.Wo;
         const bool co_ok = co0 + dco < p.Cout;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -173,41 +198,33 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
             const float v = dp[min(px, p.Wo - 1)];
             rdy[k] = (co_ok && px < p.Wo) ? v : 0.0f;       // pixels past the row's end and padded channels contribute nothing
         }
-#pragma unroll
-        for (int q = 0; q < WL_X_ITERS; ++q) {
-            const bool ci_ok = ci0 + xci[q] < p.Cin;
-            const float* xp = p.x + (long)min(ci0 + xci[q], p.Cin - 1) * HW + (long)(y + xr[q]) * W;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = xp[min(x0 + 8 * xo[q] + k, W - 1)];   // columns past the edge only ever meet dy == 0: any finite value will do
-                rx[q][k] = ci_ok ? v : 0.0f;
-            }
-        }
-    };
-    auto stage = [&]() {
-        Limbs<3> L;
-        split8(rdy, L);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(dyl + t * WL_DY_WORDS + dco * WL_ROW + doct * 4) = L.v[t];
-#pragma unroll
-        for (int q = 0; q < WL_X_ITERS; ++q) {
-            split8(rx[q], L);
-            if (tid + WG_TPB * q < WL_X_OCTETS) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    *reinterpret_cast<u32x4*>(xl + t * WL_X_WORDS + (xci[q] * 3 + xr[q]) * WL_ROW + xo[q] * 4) = L.v[t];
-            }
-        }
+        fetch_row(ya + yr + 2);
     };
 
-    if (nsteps > 0) fetch(0);
     const unsigned* Ap = dyl + (cw * 32 + i) * WL_ROW + kh * 4;
     const unsigned* Bp = xl + ((iw * 32 + i) * 3) * WL_ROW + kh * 4;
-    for (int step = 0; step < nsteps; ++step) {
+    if (rows > 0) {
+        // prologue (exposed, once per workgroup): X rows ya, ya + 1
+        fetch_row(ya);
+        stage_row(0);
+        fetch_row(ya + 1);
+        stage_row(1);
+        fetch(0);
+    }
+    for (int yr = 0; yr < rows; ++yr) {
         __syncthreads();                       // everyone is done reading the previous tile
-        stage();
+        {
+            Limbs<3> L;
+            split8(rdy, L);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(dyl + t * WL_DY_WORDS + dco * WL_ROW + doct * 4) = L.v[t];
+        }
+        stage_row((yr + 2) % 3);
         __syncthreads();
-        if (step + 1 < nsteps) fetch(step + 1);   // global loads fly under the MFMAs below
+        if (yr + 1 < rows) fetch(yr + 1);      // global loads fly under the MFMAs below
+        int rowoff[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((yr + ky) % 3) * WL_ROW;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             u32x4 A[3];
@@ -215,10 +232,11 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
             for (int t = 0; t < 3; ++t) A[t] = *reinterpret_cast<const u32x4*>(Ap + t * WL_DY_WORDS + kb * 8);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
+                __builtin_amdgcn_sched_barrier(0);          // keep later rows' fragment reads out of this one (register pressure)
                 u32x4 B0[3], B1[3], B2[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const unsigned* bp = Bp + t * WL_X_WORDS + ky * WL_ROW + kb * 8;
+                    const unsigned* bp = Bp + t * WL_X_WORDS + rowoff[ky] + kb * 8;
                     const u32x4 w = *reinterpret_cast<const u32x4*>(bp);
                     const unsigned w4 = bp[4];
                     B0[t] = w;
@@ -317,17 +335,30 @@ static int wgrad_slabs(int Cin, int Cout, int Ho) {
     if (ns > Ho) ns = Ho;
     return ns < 1 ? 1 : ns;
 }
-static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho) { return (int64_t)wgrad_slabs(Cin, Cout, Ho) * 9 * Cout * Cin; }
+// limb kernel: slabs = column chunks x row ranges, about as many as above
+static int wgrad_row_ranges_limb(int Cin, int Cout, int Ho, int Wo) {
+    const int nxc = (Wo + WG_PX - 1) / WG_PX;
+    int nrr = (wgrad_slabs(Cin, Cout, Ho) + nxc - 1) / nxc;
+    if (nrr > Ho) nrr = Ho;
+    return nrr < 1 ? 1 : nrr;
+}
+static int wgrad_slabs_limb(int Cin, int Cout, int Ho, int Wo) { return wgrad_row_ranges_limb(Cin, Cout, Ho, Wo) * ((Wo + WG_PX - 1) / WG_PX); }
+static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho, int Wo) {
+    const int a = wgrad_slabs(Cin, Cout, Ho), b = wgrad_slabs_limb(Cin, Cout, Ho, Wo);
+    return (int64_t)(a > b ? a : b) * 9 * Cout * Cin;      // either kernel may run (nvsr_set_conv_arithmetic)
+}
 
 // dw += scale * dW(dy, x);  H, W = size of x
 static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* partial,
                         hipStream_t stream) {
     const int Ho = H - 2, Wo = W - 2;
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
-    const int ns = wgrad_slabs(Cin, Cout, Ho);
-    WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns};
+    const bool limb = nvsr_get_conv_arithmetic() != NVSR_ARITH_F32;
+    const int nrr = wgrad_row_ranges_limb(Cin, Cout, Ho, Wo);
+    const int ns = limb ? wgrad_slabs_limb(Cin, Cout, Ho, Wo) : wgrad_slabs(Cin, Cout, Ho);
+    WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, (Ho + nrr - 1) / nrr};
     dim3 grid((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns);
-    if (nvsr_get_conv_arithmetic() != NVSR_ARITH_F32) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, grid, dim3(WG_TPB), 0, stream, p);
+    if (limb) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, grid, dim3(WG_TPB), 0, stream, p);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(WG_TPB), 0, stream, p);
     const long n = 9L * Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
@@ -342,7 +373,7 @@ extern "C" {
 
 int64_t nvsr_conv3x3_wgrad_workspace_floats(int Cin, int H, int W, int Cout) {
     if (Cin < 1 || Cout < 1 || H < 3 || W < 3) return -1;
-    return wgrad_partial_floats(Cin, Cout, H - 2);
+    return wgrad_partial_floats(Cin, Cout, H - 2, W - 2);
 }
 
 /* weight gradient of nvsr_conv3x3 (epilogue 0): dw [Cout][Cin][3][3] += scale * sum_{y,x} dy[co][y][x] x[ci][y+ky][x+kx] */
@@ -381,7 +412,7 @@ int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblo
     if (edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return -1;
     int64_t part = 0;
     for (int l = 0; l < P.n; ++l) {
-        const int64_t f = wgrad_partial_floats(P.L[l].Cin, P.L[l].Cout, P.ih[l] - 2);
+        const int64_t f = wgrad_partial_floats(P.L[l].Cin, P.L[l].Cout, P.ih[l] - 2, P.iw[l] - 2);
         if (f > part) part = f;
     }
     const int64_t t = (P.max_tensor + 3) / 4 * 4;
