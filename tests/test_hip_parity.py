@@ -467,32 +467,33 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
 
 def test_planes_sr_batch_is_bit_identical_to_one_by_one(hip):
     """the 3 position planes of a scene through the SR net in one batched pass == three separate passes, bit for bit"""
-    torch.manual_seed(12)
-    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 64, "n_blocks": 3}}, "bilinear").to(DEV)
-    with torch.no_grad():
-        for p_ in sr.parameters():
-            p_.mul_(10.0)
-    sr.eval()
-    names = ["a", "b", "c"]
-    for n in names:
-        sr.set_LR_plane(torch.randn(1, 48, 37, 29, device=DEV) * 0.5, id=n, save_interpolated=False)
-    with torch.no_grad():
-        single = [sr(n).clone() for n in names]
-        sr.clear_SR_planes()
-        sr.super_resolve_many(names)
-        assert sorted(sr.SR_planes) == names
-        for n, ref in zip(names, single):
-            assert sr(n) is sr.SR_planes[n] and torch.equal(sr(n), ref)
-        # EDSR entry point, batch of 2 against two single calls
-        capi = hip.capi
-        x = torch.randn(2, 48, 30, 41, device=DEV)
-        cin, cout, hid, nb, n_up = sr.inner_model.geometry
-        one = torch.stack([sr.inner_model(x[b:b + 1])[0] for b in range(2)])
-        out = torch.empty_like(one)
-        ws = torch.empty(2 * capi.lib().nvsr_edsr_workspace_floats(hid, nb, n_up, 30, 41), device=DEV)
-        capi.call("nvsr_edsr_forward_batch", capi.ptr(x), 2, 48, 30, 41, capi.ptr(sr.inner_model.packed_weights()), cout, hid, nb, n_up,
-                  capi.ptr(out), capi.ptr(ws), capi.stream())
-        assert torch.equal(out, one)
+    for hidden, blocks in ((64, 3), (256, 1)):          # narrow (<= 64 channels) and wide (256) workgroup shapes of the conv kernels
+        torch.manual_seed(12)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hidden, "n_blocks": blocks}}, "bilinear").to(DEV)
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.mul_(10.0)
+        sr.eval()
+        names = ["a", "b", "c"]
+        for n in names:
+            sr.set_LR_plane(torch.randn(1, 48, 37, 29, device=DEV) * 0.5, id=n, save_interpolated=False)
+        with torch.no_grad():
+            single = [sr(n).clone() for n in names]
+            sr.clear_SR_planes()
+            sr.super_resolve_many(names)
+            assert sorted(sr.SR_planes) == names
+            for n, ref in zip(names, single):
+                assert sr(n) is sr.SR_planes[n] and torch.equal(sr(n), ref)
+            # EDSR entry point, batch of 2 against two single calls
+            capi = hip.capi
+            x = torch.randn(2, 48, 30, 41, device=DEV)
+            cin, cout, hid, nb, n_up = sr.inner_model.geometry
+            one = torch.stack([sr.inner_model(x[b:b + 1])[0] for b in range(2)])
+            out = torch.empty_like(one)
+            ws = torch.empty(2 * capi.lib().nvsr_edsr_workspace_floats(hid, nb, n_up, 30, 41), device=DEV)
+            capi.call("nvsr_edsr_forward_batch", capi.ptr(x), 2, 48, 30, 41, capi.ptr(sr.inner_model.packed_weights()), cout, hid, nb, n_up,
+                      capi.ptr(out), capi.ptr(ws), capi.stream())
+            assert torch.equal(out, one)
 
 
 def test_planes_sr_row_bands_equal_the_full_plane(hip):
