@@ -1363,6 +1363,48 @@ def test_render_pass_limb_arithmetic(hip, oracle):
         np.testing.assert_allclose(res[mode]["acc"][ids][ok], fo["acc"][ok], rtol=0, atol=tol, err_msg=mode)
 
 
+def test_render_pass_limb_kernel_edge_shapes_and_repeatability(hip):
+    """bf16-limb render pass at the edges of its loop structure (1, 2 and 5 samples; a ray count that leaves a half-empty wave), without the
+    optional outputs, twice: bit-identical launch to launch (the weight ring and the counted vector-memory waits have no race) and within
+    the stated tolerance of the f32-MFMA kernel; rays whose last sigma is within the arithmetic's noise of zero excluded as everywhere"""
+    import ctypes as C
+    g = load_golden("g08_render.npz")
+    capi = hip.capi
+    rng = np.random.default_rng(31)
+    planes = [rng.standard_normal((1, 48, 40, 56), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 8, 12), dtype=np.float32) * 0.5]
+    m, _ = build_model(hip, sd(g, "fine."), planes, g["box"])
+    H, W = 150, 160
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    rays_all = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    sc, keep = m.native_scene()
+    try:
+        for N, S in ((16384 + 1, 1), (20000, 2), (23999, 5)):
+            rays = rays_all[:N].contiguous()
+            z = T(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1))
+            outs = {}
+            for mode in ("f32", "bf16x3", "bf16x3"):
+                capi.set_decoder_arithmetic(mode)
+                o = dict(rgb=torch.full((N, 3), -7.0, device=DEV), disp=torch.full((N,), -7.0, device=DEV), acc=torch.full((N,), -7.0, device=DEV),
+                         raw=torch.full((N, S, 4), -7.0, device=DEV))
+                capi.call("nvsr_render_pass_ex", C.byref(sc), capi.ptr(m.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), None, 0,
+                          capi.ptr(o["rgb"]), capi.ptr(o["disp"]), capi.ptr(o["acc"]), None, None, capi.ptr(o["raw"]) if mode == "f32" else None,
+                          capi.stream())
+                torch.cuda.synchronize()
+                if mode in outs:
+                    for k in ("rgb", "disp", "acc"):
+                        assert_bits_equal(N_(o[k]), N_(outs[mode][k]))
+                outs[mode] = o
+            ok = np.abs(N_(outs["f32"]["raw"])[:, -1, 3]) > 1e-4
+            assert ok.mean() > 0.9
+            for k in ("rgb", "acc"):
+                assert not (N_(outs["bf16x3"][k]) == -7.0).any()
+                np.testing.assert_allclose(N_(outs["bf16x3"][k])[ok], N_(outs["f32"][k])[ok], rtol=0, atol=1e-4, err_msg=str((N, S, k)))
+    finally:
+        capi.set_decoder_arithmetic(DEFAULT_ARITHMETIC)
+
+
 def test_volume_render_radiance_field_is_differentiable(hip):
     """the mirror of volume_render_radiance_field carries a gradient for the radiance field (rgb_map, acc_map), equal to float64
     autograd of the same formula"""
