@@ -176,7 +176,7 @@ def _sync_time(dist, dev, fn, warmup, steps):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -354,13 +354,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # NVSR_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- the N > 1 code path on a one-GPU box (tests/test_hip_parity.py);
+    # its numbers mean nothing.  The driver's runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("NVSR_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import nvsr_amd
     nvsr_amd.capi.lib()  # fail loudly if the HIP library is not built
@@ -398,7 +406,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -428,7 +436,7 @@ def main():
         sc, keep = mc.native_scene()
         capi.call("nvsr_render_rays", C.byref(sc), capi.ptr(mc.packed_decoder()), capi.ptr(mf.packed_decoder()), N, 64, 128, capi.ptr(rays),
                   0, 0, None, None, None, None, *[capi.ptr(b) for b in bufs], capi.ptr(ws), capi.stream())
-        z_fine = ws[2 * N * 64:].view(N, 192)
+        z_fine = ws[2 * N * 64: 2 * N * 64 + N * 192].view(N, 192)     # [z_c | w_c | z_f | (raw of the un-fused small-N path)]
         dt = time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine)
         flops = FLOP_PER_EVAL * N * 192
         achieved = flops / dt / 1e12

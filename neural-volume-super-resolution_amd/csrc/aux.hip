@@ -211,6 +211,44 @@ __device__ __forceinline__ void rank_sort_wave(const float* vals /*LDS[n]*/, int
     }
 }
 
+// sort(cat(a, b)) of two runs held in LDS (all = [a[0..na) | b[0..nb)]), same ranks as rank_sort_wave.  The coarse depths are always
+// non-decreasing (linspace, stratified jitter) and so are the inverse-CDF samples of a sorted u (perturb off): an element of a sorted run
+// has rank = its own index + a count in the other run, a binary search instead of n comparisons.  Run a sorted: a[i] -> i + #(b < a[i])
+// and b[j] -> #(a <= b[j]) + (j when b is sorted as well, else its rank among b).  Anything else (a NaN, a caller's unsorted depths)
+// takes the general rank sort.
+__device__ __forceinline__ void merge_sort_wave(const float* all /*LDS[na+nb]*/, int na, int nb, float* __restrict__ out, int lane) {
+    const float* a = all;
+    const float* b = all + na;
+    bool oka = true, okb = true;
+    for (int i = lane; i + 1 < na; i += 64) oka = oka && (a[i] <= a[i + 1]);
+    for (int j = lane; j + 1 < nb; j += 64) okb = okb && (b[j] <= b[j + 1]);
+    const bool sa = __builtin_amdgcn_ballot_w64(!oka) == 0, sb = __builtin_amdgcn_ballot_w64(!okb) == 0;
+    if (!sa) { rank_sort_wave(all, na + nb, out, lane); return; }
+    for (int i = lane; i < na; i += 64) {
+        const float v = a[i];
+        int cnt = 0;
+        if (sb) {
+            int lo = 0, hi = nb;                                   // first index with b[idx] >= v
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (b[mid] < v) lo = mid + 1; else hi = mid; }
+            cnt = lo;
+        } else {
+            for (int k = 0; k < nb; ++k) cnt += b[k] < v;
+        }
+        out[i + cnt] = v;
+    }
+    for (int j = lane; j < nb; j += 64) {
+        const float v = b[j];
+        int lo = 0, hi = na;                                       // first index with a[idx] > v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+        int rank = j;
+        if (!sb) {
+            rank = 0;
+            for (int k = 0; k < nb; ++k) { const float o = b[k]; rank += (o < v) || (o == v && k < j); }
+        }
+        out[lo + rank] = v;
+    }
+}
+
 __global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, const float* __restrict__ in, float* __restrict__ out) {
     __shared__ float vals[WPB][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -246,7 +284,7 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
                     cdf_s[wave], lane, [&](int j, float v) { all[Nc + j] = v; });
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    rank_sort_wave(all, Nc + Nf, zf + ray * (Nc + Nf), lane);
+    merge_sort_wave(all, Nc, Nf, zf + ray * (Nc + Nf), lane);
 }
 
 // ---- compositing: one wave per ray, samples across lanes, transmittance by a wave scan ------------------------------------

@@ -192,13 +192,15 @@ __device__ __forceinline__ void dma_side(int slot, const Ring3<LIMBS>& rs, unsig
 constexpr int YOUNGER_THAN_CHUNK = 32;
 
 // =====================================================================================================================
+// The body of both kernels below (one instantiation per LIMBS; the kernels are thin shells so that the coarse and the fine pass are two
+// symbols in a rocprofv3 kernel trace -- a second template parameter on one kernel trips hipcc's host pass over the LDS-DMA builtins).
 template <int LIMBS>
-__global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
-                                                              const float* __restrict__ rays, const float* __restrict__ z,
-                                                              const float* __restrict__ noise, int white,
-                                                              float* __restrict__ rgb, float* __restrict__ disp,
-                                                              float* __restrict__ acc, float* __restrict__ weights,
-                                                              float* __restrict__ depth, float* __restrict__ raw_out) {
+__device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const float* __restrict__ packed, long N, int S,
+                                                  const float* __restrict__ rays, const float* __restrict__ z,
+                                                  const float* __restrict__ noise, int white,
+                                                  float* __restrict__ rgb, float* __restrict__ disp,
+                                                  float* __restrict__ acc, float* __restrict__ weights,
+                                                  float* __restrict__ depth, float* __restrict__ raw_out) {
     using L = Lds3<LIMBS>;
     constexpr int NP = limb_products(LIMBS);
     constexpr int NSF = 3 * 4 * NP, NSH = 4 * 4 * NP;          // slots of a feature block / of half a hidden layer
@@ -513,6 +515,27 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
     }
 }
 
+// coarse pass: also writes the per-sample compositing weights (the input of the importance resampling)
+template <int LIMBS>
+__global__ __launch_bounds__(TPB2, 1) void render_pass3_coarse_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                                     const float* __restrict__ rays, const float* __restrict__ z,
+                                                                     const float* __restrict__ noise, int white,
+                                                                     float* __restrict__ rgb, float* __restrict__ disp,
+                                                                     float* __restrict__ acc, float* __restrict__ weights,
+                                                                     float* __restrict__ depth, float* __restrict__ raw_out) {
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, noise, white, rgb, disp, acc, weights, depth, raw_out);
+}
+// fine pass (or any pass whose weights are not wanted)
+template <int LIMBS>
+__global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                              const float* __restrict__ rays, const float* __restrict__ z,
+                                                              const float* __restrict__ noise, int white,
+                                                              float* __restrict__ rgb, float* __restrict__ disp,
+                                                              float* __restrict__ acc, float* __restrict__ depth,
+                                                              float* __restrict__ raw_out) {
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, noise, white, rgb, disp, acc, nullptr, depth, raw_out);
+}
+
 // ---- natural blob -> bf16 limb fragments (the tail of the packed blob) -----------------------------------------------------------
 template <int LIMBS>
 __global__ void pack_decoder_limbs_kernel(const float* __restrict__ nat, unsigned* __restrict__ out) {
@@ -570,11 +593,14 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
                                         float* weights, float* depth, float* raw_out, nvsr_stream_t stream) {
     const int64_t grid = (N + RAYS2 - 1) / RAYS2;
     if (grid > 0x7fffffff || (limbs != 2 && limbs != 3)) return NVSR_ERR_SHAPE;
-    if (limbs == 3)
-        hipLaunchKernelGGL(render_pass3_kernel<3>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
-                           S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);
-    else
-        hipLaunchKernelGGL(render_pass3_kernel<2>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
-                           S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);
+#define NVSR_LAUNCH3(LIMBS_)                                                                                                               \
+    if (weights)                                                                                                                           \
+        hipLaunchKernelGGL(render_pass3_coarse_kernel<LIMBS_>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene),    \
+                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);               \
+    else                                                                                                                                   \
+        hipLaunchKernelGGL(render_pass3_kernel<LIMBS_>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene),           \
+                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, depth, raw_out)
+    if (limbs == 3) { NVSR_LAUNCH3(3); } else { NVSR_LAUNCH3(2); }
+#undef NVSR_LAUNCH3
     return NVSR_CHECK_LAUNCH();
 }

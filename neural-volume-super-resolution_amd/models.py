@@ -329,15 +329,29 @@ class TwoDimPlanesModel(nn.Module):
         for d, p in enumerate(planes):
             sc.planes[d] = p.data_ptr()
             sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
-        box = self.box_coords[self.cur_id + ""].detach().double().cpu().numpy()
+        # box and projection matrices as host floats: read back once per version (a device-to-host copy drains the queue, and this runs
+        # for every pass of every training iteration)
+        box_t = self.box_coords[self.cur_id + ""]
+        rots = [self.coord_projector.rot_mats_NON_LEARNED[d] for d in range(3)]
+        key = (self.cur_id, box_t.data_ptr(), box_t._version) + tuple((r.data_ptr(), r._version) for r in rots)
+        cache = self.__dict__.get("_scene_consts")
+        if cache is None or cache[0] != key:
+            box = box_t.detach().double().cpu().numpy()
+            lo = [np.float32(box[0, i]) for i in range(5)]
+            rng = [np.float32(box[1, i] - box[0, i]) for i in range(5)]   # subtraction in double, then cast (models.py:264-265)
+            proj = []
+            for r in rots:
+                m = r.detach().float().cpu().numpy()[:, 1:]
+                proj.append([float(m[k, c]) for k in range(3) for c in range(2)])
+            cache = (key, lo, rng, proj)
+            self.__dict__["_scene_consts"] = cache
+        _, lo, rng, proj = cache
         for i in range(5):
-            sc.lo[i] = np.float32(box[0, i])
-            sc.range[i] = np.float32(box[1, i] - box[0, i])   # subtraction in double, then cast (models.py:264-265)
+            sc.lo[i] = lo[i]
+            sc.range[i] = rng[i]
         for d in range(3):
-            m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().cpu().numpy()[:, 1:]
-            for k in range(3):
-                for c in range(2):
-                    sc.proj[d][k * 2 + c] = float(m[k, c])
+            for j in range(6):
+                sc.proj[d][j] = proj[d][j]
         return sc, planes
 
     def forward(self, x):

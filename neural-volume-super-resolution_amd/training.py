@@ -7,6 +7,8 @@ What changes against the reference:
   * everything else is the reference's arithmetic in the reference's order: pixel selection with numpy's global RNG (:816-846),
     coarse / fine MSE gating by `what2train` and `super_resolution.training.loss` (:884-891), virtual batches and per-module
     optimizer gating (:848-853, :905-914), the SR-vs-no-SR double render and PSNR bookkeeping of `evaluate()` (:655-713)."""
+from collections.abc import Mapping
+
 import numpy as np
 import torch
 
@@ -83,6 +85,55 @@ def select_training_pixels(img_target, num_random_rays, consistency_ds=None):
     return torch.cat([rows, cols], -1).reshape(-1, 2), target_s
 
 
+class StepMetrics(Mapping):
+    """loss / psnr / coarse_loss / fine_loss of one iteration, with the reference's keys and python-float values.
+
+    The reference reads them with `.item()` in the middle of the iteration (train_nerf.py:893-921): the host waits for the forward pass
+    before it may enqueue the backward pass, and again for the optimizer before the next iteration -- on this GPU that leaves the queue
+    empty for ~15 % of a 10 ms step.  Here the scalars are gathered on the device after the optimizer steps are enqueued and copied to
+    pinned host memory on the step's stream; the first read of a value waits for that copy.  A loop that logs every k-th iteration
+    never waits on the others."""
+
+    KEYS = ("loss", "psnr", "coarse_loss", "fine_loss")
+
+    def __init__(self, loss, rendering_loss, coarse_loss, fine_loss, with_psnr):
+        self._present = dict(loss=True, psnr=with_psnr and isinstance(rendering_loss, torch.Tensor), coarse_loss=coarse_loss is not None,
+                             fine_loss=fine_loss is not None)
+        src = [loss, rendering_loss, coarse_loss, fine_loss]
+        dev = loss.device
+        vals = torch.stack([(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
+                             else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in src])
+        if dev.type == "cuda":
+            self._host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+            self._host.copy_(vals, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = vals, None
+        self._vals = None
+
+    def _read(self):
+        if self._vals is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._vals = self._host.tolist()
+        return self._vals
+
+    def __getitem__(self, k):
+        if k not in self._present:
+            raise KeyError(k)
+        if not self._present[k]:
+            return None
+        v = self._read()
+        return mse2psnr(v[1]) if k == "psnr" else v[self.KEYS.index(k)]
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
+
+
 class TrainStep:
     """One optimisation iteration of train() for the planes model.
 
@@ -141,9 +192,6 @@ class TrainStep:
             if rgb_fine is not None and (trains_scene or self.sr_loss != "coarse"):
                 fine_loss = mse_loss(rgb_fine, target)
         rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
-        psnr = None
-        if isinstance(rendering_loss, torch.Tensor) and not im_consistency_iter:
-            psnr = mse2psnr(rendering_loss.item())
         loss = (self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w) * rendering_loss
         loss.backward()
         if self.grad_sync is not None:
@@ -159,8 +207,7 @@ class TrainStep:
                     self.optimizer.step()
             if self.SR_optimizer is not None and sr_iter and "SR" not in confinements:
                 self.SR_optimizer.step()
-        return dict(loss=loss.item(), psnr=psnr, coarse_loss=None if coarse_loss is None else coarse_loss.item(),
-                    fine_loss=None if fine_loss is None else fine_loss.item())
+        return StepMetrics(loss, rendering_loss, coarse_loss, fine_loss, with_psnr=not im_consistency_iter)
 
 
 def evaluate_view(model_coarse, model_fine, options, scene_id, scene_config, img_target, pose_target, H, W, focal, cur_ds_factor=1,

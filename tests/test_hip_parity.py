@@ -295,6 +295,36 @@ def test_importance_resample_vs_oracle(hip, oracle):
             assert np.isin(z[r], zf[r]).all()
 
 
+def test_importance_resample_merge_paths_bit_identical(hip):
+    """The fused kernel ranks the elements of a sorted run by binary search (merge_sort_wave); whichever path a ray takes -- both runs
+    sorted, only the coarse depths sorted, neither (a caller's unsorted depths), ties between and inside the runs, odd sizes -- the
+    result is bit for bit torch.sort(cat(z, sample_pdf(...))) as the separate kernels (general rank sort) produce it."""
+    capi = hip.capi
+    rng = np.random.default_rng(11)
+    for (N, Nc, Nf) in ((1537, 64, 128), (130, 33, 77), (64, 3, 1), (257, 256, 256)):
+        z = np.sort(rng.uniform(2, 6, (N, Nc)).astype(np.float32), -1)
+        z[1::5, Nc // 2:] = z[1::5, Nc // 2 - 1:Nc // 2]              # runs of equal coarse depths
+        w = (rng.uniform(0, 1, (N, Nc)) ** 4).astype(np.float32)
+        w[::3] = 0.0                                                  # flat pdf: samples land exactly on bin edges / coarse mids
+        z_unsorted = rng.permuted(z, axis=-1)
+        u_rand = rng.uniform(0, 1, (N, Nf)).astype(np.float32)
+        u_ties = np.repeat(u_rand[:, : (Nf + 1) // 2], 2, axis=-1)[:, :Nf].copy()   # duplicated samples, unsorted
+        for zz in (z, z_unsorted):
+            for u in (None, u_rand, u_ties):
+                z_d, w_d, u_d = T(zz), T(w), (None if u is None else T(u))
+                zf = torch.empty((N, Nc + Nf), device=DEV)
+                capi.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_d), capi.ptr(w_d), capi.ptr(u_d), capi.ptr(zf), capi.stream())
+                zm = (0.5 * (z_d[:, 1:] + z_d[:, :-1])).contiguous()
+                wi = w_d[:, 1:-1].contiguous()
+                smp = torch.empty((N, Nf), device=DEV)
+                capi.call("nvsr_sample_pdf", N, Nc - 1, Nf, capi.ptr(zm), capi.ptr(wi), capi.ptr(u_d), capi.ptr(smp), capi.stream())
+                cat = torch.cat([z_d, smp], -1).contiguous()
+                ref = torch.empty_like(cat)
+                capi.call("nvsr_sort_rows", N, Nc + Nf, capi.ptr(cat), capi.ptr(ref), capi.stream())
+                assert torch.equal(zf, ref)
+                assert torch.equal(ref, torch.sort(cat, -1).values)
+
+
 def test_full_size_frame_properties_and_oracle_subset(hip, oracle):
     """BASELINE config 2 at full size: 800x800 rays, 64+128 samples, planes 800^2 (+32^2 view plane).
     Size-independent properties on the whole frame + the oracle, stage by stage, on a seeded subset of its rays."""
@@ -1555,6 +1585,10 @@ def test_train_step_glue_reduces_loss(hip):
     assert not torch.equal(mc.fc_alpha["0"].weight, w0)
     assert np.mean(losses[-8:]) < 0.5 * np.mean(losses[:4]), losses
     assert r["psnr"] is not None and r["coarse_loss"] is not None and r["fine_loss"] is not None
+    # the metrics are read lazily from pinned memory (training.StepMetrics): same keys and python floats as the reference's .item() calls
+    assert set(r) == {"loss", "psnr", "coarse_loss", "fine_loss"} and all(isinstance(v, float) for v in dict(r).values())
+    assert abs(r["loss"] - (r["coarse_loss"] + r["fine_loss"])) <= 1e-6 * r["loss"]
+    assert r["psnr"] == hip.nerf_helpers.mse2psnr(r["loss"])
 
 
 def test_sr_train_step_and_evaluate_view(hip):
@@ -1595,3 +1629,27 @@ def test_sr_train_step_and_evaluate_view(hip):
     ev2 = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
     assert ev2["loss"] < ev["loss"], (ev["loss"], ev2["loss"])           # the SR net learned to reproduce the target better
     assert all(p_.grad is None for p_ in mc.decoder_parameters())
+
+
+@pytest.mark.parametrize("workload", ["render", "train"])
+def test_bench_two_rank_rehearsal(workload):
+    """bench.py's N > 1 path (barriers, max-over-ranks timing, whole-job value, the gradient all-reduce of the train workload) launched
+    exactly as the driver launches it, with two ranks sharing this box's one GPU over gloo (NVSR_BENCH_REHEARSAL=1)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NVSR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+           "--res", "160", "--plane-res", "128", "--no-cpu-baseline", "--no-modes"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, "\n".join(l for l in p.stderr.splitlines() if "[rank" in l)[-4000:] or p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 prints ONE line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    per_gpu = r["config"]["rays_per_step_per_gpu"]
+    assert abs(r["value"] - 2 * per_gpu * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]   # whole-job aggregate over both ranks
+    assert "roofline" in r and "cpu_baseline" not in r

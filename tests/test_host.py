@@ -138,3 +138,18 @@ def test_select_training_pixels_follows_the_reference_enumeration():
     assert torch.equal(patches[:, 0, 1], 2 * corners + torch.tensor([0, 1]))
     px = torch.rand(40, 3)
     assert torch.allclose(nvsr_amd.training.avg_downsampling(px, 2), px.reshape(10, 4, 3).mean(1))
+
+
+def test_step_metrics_mapping_semantics():
+    """training.StepMetrics: the reference's four per-iteration scalars (train_nerf.py:893-921) as a read-only mapping of python floats;
+    a loss that was not taken reads as None (as the reference skips its write_scalar), psnr follows mse2psnr of the rendering loss"""
+    import nvsr_amd
+    from nvsr_amd.training import StepMetrics
+    c, f = torch.tensor(0.25), torch.tensor(0.5)
+    m = StepMetrics(2.0 * (c + f), c + f, c, f, with_psnr=True)
+    assert dict(m) == {"loss": 1.5, "psnr": nvsr_amd.nerf_helpers.mse2psnr(0.75), "coarse_loss": 0.25, "fine_loss": 0.5}
+    assert list(m) == ["loss", "psnr", "coarse_loss", "fine_loss"] and len(m) == 4
+    m = StepMetrics(f, f, None, f, with_psnr=False)            # SR iteration with loss: 'fine'; consistency iterations report no psnr
+    assert m["coarse_loss"] is None and m["psnr"] is None and m["fine_loss"] == 0.5 and m["loss"] == 0.5
+    with pytest.raises(KeyError):
+        m["nope"]
