@@ -9,9 +9,10 @@ Default workload (BASELINE.json configs[1]): one "step" renders one 800x800 view
 (replicated) scene; there is no data-path collective.  Prints ONE JSON line on rank 0.
 
 Other workloads of the same path (--workload; same JSON contract, their own metric):
-  train   BASELINE configs[3]: one optimisation step = 4096 random rays of one view, 64+64 samples, planes 200^2, gradients for the
-          planes AND both decoders, Adam; N > 1: every rank draws its own rays, gradients are averaged with one bucketed RCCL
-          all-reduce (planes 23 MB + decoders 1 MB) before the optimizer steps.
+  train   BASELINE configs[3] (Feature_Planes_Only.yml): one optimisation step = 4096 random rays of one view, 64+64 samples, planes
+          200^2, nerf.train.what = ['LR_planes'] (--train-what planes+decoder: both decoders train as well, TrainModels.yml), Adam;
+          N > 1: every rank draws its own rays, gradients are averaged with one bucketed RCCL all-reduce (planes 23 MB [+ decoders
+          1 MB]) before the optimizer steps.
   sr      BASELINE configs[2]'s SR stage: the 3 position planes of a scene 200^2 -> 800^2 through EDSR (hidden 256, 32 blocks, x4)
           in one batched pass (20.2 TFLOP); N > 1: independent replicas (a scene's planes are SR'd once and cached).
 """
@@ -125,6 +126,39 @@ def time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine, reps=3):
     return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
 
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws, reps=5):
+    """The bandwidth-bound helper kernels of the frame (ray generation, ray packing, coarse depths, importance resampling), each timed
+    alone with events on the launch stream: algorithmic bytes (inputs read once + outputs written once) / duration against the HBM peak."""
+    capi = nvsr_amd.capi
+    N = rays.shape[0]
+    z_c, w_c = ws[:N * 64], ws[N * 64: 2 * N * 64]
+    z_f = torch.empty(N * 192, device=rays.device)
+
+    def timed(fn):
+        fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
+
+    stages = {
+        "get_ray_bundle (ray_bundle_kernel)": (24 * N, lambda: nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)),
+        "pack_rays (pack_rays_kernel)": ((24 + 44) * N, lambda: nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)),
+        "coarse depths (coarse_z_kernel)": ((8 + 4 * 64) * N, lambda: capi.call("nvsr_coarse_z", N, 64, capi.ptr(rays), 0, None, capi.ptr(z_c), capi.stream())),
+        "sample_pdf + sort (importance_resample_kernel)": (4 * (64 + 64 + 192) * N, lambda: capi.call(
+            "nvsr_importance_resample", N, 64, 128, capi.ptr(z_c), capi.ptr(w_c), None, capi.ptr(z_f), capi.stream())),
+    }
+    out = {}
+    for name, (nbytes, fn) in stages.items():
+        dt = timed(fn)
+        out[name] = {"ms": dt * 1e3, "algorithmic_bytes": nbytes, "GB/s": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS}
+    return out
+
+
 def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
     """The oracle (plain-C port of the reference algorithm, fp32, OpenMP over all host cores) on a bounded sample of the same
     rays; also the PSNR of the GPU pixels against the (double-accumulating) checker on that sample."""
@@ -187,10 +221,11 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     import ctypes as C
     capi = nvsr_amd.capi
     R, N, Nc, Nf = 200, 4096, 64, 64
+    what = {"planes": {"LR_planes"}, "planes+decoder": {"LR_planes", "decoder"}}[args.train_what]
     mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0)
     for m in (mc, mf):
         for n, p in m.named_parameters():
-            p.requires_grad_("rot_mats" not in n)
+            p.requires_grad_("rot_mats" not in n and ("planes_" in n or "decoder" in what))
         m.train()
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
@@ -199,7 +234,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     target = torch.rand(H, W, 3, device=dev, generator=g)
     dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
     planes = list(mc.planes_.values())
-    opt, popt = torch.optim.Adam(dec, lr=5e-4), torch.optim.Adam(planes, lr=4e-3)
+    opt, popt = (torch.optim.Adam(dec, lr=5e-4) if "decoder" in what else None), torch.optim.Adam(planes, lr=4e-3)
     sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in planes + dec if p.grad is not None])) if world > 1 else None
     def device_sampler(img, n_rays, consistency_ds=None):
         # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the
@@ -208,8 +243,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         sel = torch.stack([flat % img.shape[0], flat // img.shape[0]], -1)
         return sel, img[sel[:, 0], sel[:, 1], :]
 
-    step = nvsr_amd.training.TrainStep(mc, mf, opts, {"LR_planes", "decoder"}, optimizer=opt, planes_optimizer=popt, grad_sync=sync,
-                                       pixel_sampler=device_sampler)
+    step = nvsr_amd.training.TrainStep(mc, mf, opts, what, optimizer=opt, planes_optimizer=popt, grad_sync=sync, pixel_sampler=device_sampler)
     np.random.seed(rank)
     it = [0]
 
@@ -223,12 +257,14 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
 
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
     value = world * N * args.steps / elapsed
-    result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, planes + decoder gradients, Adam)", "value": value,
+    label = "planes + decoder gradients" if "decoder" in what else "plane gradients (Feature_Planes_Only.yml: what = ['LR_planes'])"
+    result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, %s, Adam)" % label, "value": value,
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
-                                     "what = [LR_planes, decoder], Adam", "rays_per_step_per_gpu": N,
-                         "parallelism": "rays sharded by rank; one bucketed all-reduce of plane + decoder gradients per step"}}
+                                     "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
+                         "parallelism": "rays sharded by rank; one bucketed all-reduce of the %s per step"
+                                        % ("plane + decoder gradients" if "decoder" in what else "plane gradients (23 MB)")}}
     if rank == 0:
         # dominant kernel: gate-driven backward of the fine pass (transposed layers + plane scatter + gradient half of the record), S = 128
         batch = torch.stack(nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, torch.randint(0, H, (N, 2), device=dev)), 0)
@@ -245,14 +281,15 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         for a, b in ev:
             a.record()
             capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
-                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), capi.ptr(sv["gates_f"]), gptrs, capi.ptr(vws), capi.ptr(sv["rec_f"]),
+                      capi.ptr(rays), capi.ptr(sv["z_f"]), capi.ptr(g_raw), capi.ptr(sv["gates_f"]), gptrs, capi.ptr(vws), capi.ptr(sv.get("rec_f")),
                       capi.stream())
             b.record()
         torch.cuda.synchronize()
         dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
         flops = FLOP_PER_EVAL * N * S              # the transposed layers move exactly the forward's 129 536 MAC per point
         ach = flops / dt / 1e12
-        result["roofline"] = {"kernel": "render_pass_backward_gates_kernel<record> (fine pass, S=128; incl. its view-plane reduce)", "bound": "mfma",
+        result["roofline"] = {"kernel": "render_pass_backward_gates_kernel<%s> (fine pass, S=128; incl. its view-plane reduce)"
+                                        % ("record" if sv.get("rec_f") is not None else "no record"), "bound": "mfma",
                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:
@@ -267,11 +304,14 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
             gg = np.full((n, 3), 1e-3, np.float32)
             t0 = time.perf_counter()
             o.render_rays(osc, dc, df, rn, Nc, Nf)
-            o.render_backward_decoder(osc, dc, df, rn, Nc, Nf, gg, gg)
+            if "decoder" in what:
+                o.render_backward_decoder(osc, dc, df, rn, Nc, Nf, gg, gg)
+            else:
+                o.render_backward(osc, [p_.shape for p_ in pl], dc, df, rn, Nc, Nf, gg, gg)
             t = time.perf_counter() - t0
             result["cpu_baseline"] = {"value": n / t, "unit": "rays/s", "cores": 1, "kind": "port",
-                                      "sample": "%d rays of the same step (forward + analytic backward incl. decoder gradients), %.1f s, C "
-                                                "oracle, double accumulation, single thread" % (n, t)}
+                                      "sample": "%d rays of the same step (forward + analytic backward: %s), %.1f s, C "
+                                                "oracle, double accumulation, single thread" % (n, label, t)}
         print(json.dumps(result), flush=True)
 
 
@@ -341,6 +381,8 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["render", "train", "sr"], default="render")
+    ap.add_argument("--train-what", choices=["planes", "planes+decoder"], default="planes",
+                    help="--workload train: nerf.train.what (default = Feature_Planes_Only.yml, BASELINE configs[3])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -456,6 +498,13 @@ def main():
                               "peak_note": "algorithmic f32 FLOP; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
                                            % (arith["pipe_peak"], arith["products"]),
                               "executed_mfma_tflops": achieved * arith["products"], "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        # bandwidth-bound stages: the helper kernels alone, and the fused pass's plane sampling + compositing as the HBM traffic the
+        # counters saw (profiles/pmc_latest.json) over the live kernel time
+        result["hbm_stages"] = hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws)
+        if traffic is not None:
+            result["hbm_stages"]["plane sampling + compositing inside %s" % arith["kernel"]] = {
+                "ms": dt * 1e3, "hbm_bytes_pmc": traffic, "GB/s": traffic / dt / 1e9, "frac_of_hbm_peak": traffic / dt / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_gather_bytes": GATHER_BYTES_PER_EVAL * N * 192}
         if world == 1 and not args.no_modes:
             # the same frame in the other arithmetic modes (2 steps each), so that every number of this line can be re-based
             modes = {}

@@ -5,7 +5,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 out = {}
-for w in ("render", "train", "sr"):
+for w in ("render", "train", "train_dec", "sr"):
     f = os.path.join(src, "bench_%s.json" % w)
     if os.path.exists(f):
         line = [l for l in open(f).read().splitlines() if l.startswith("{")]

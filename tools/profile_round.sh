@@ -6,9 +6,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_render.json 2> $O/bench_render.err
 python3 $R/bench.py --workload train --steps 30 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
+python3 $R/bench.py --workload train --train-what planes+decoder --steps 30 --warmup 5 > $O/bench_train_dec.json 2> $O/bench_train_dec.err
 python3 $R/bench.py --workload sr --steps 3 --warmup 1 > $O/bench_sr.json 2> $O/bench_sr.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_render -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 $R/bench.py --workload train --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_dec -- python3 $R/bench.py --workload train --train-what planes+decoder --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sr -- python3 $R/bench.py --workload sr --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
