@@ -9,7 +9,7 @@
 // f32x4 of G (4 output rows of 4 MFMAs) and one f32x2 of X (2 input columns) for slot pair (q, q+1), so a half-wave reads whole
 // 512-byte / 256-byte rows.  A workgroup owns a [128 out x 64 in] block of one layer for a slab of slots; its 4 waves split the
 // slab, reduce through LDS and add the block into the gradient blob (state-dict order) with float atomics.
-#include "nvsr_common.h"
+#include "limb_core.h"
 
 namespace nvsr {
 
@@ -22,6 +22,7 @@ struct WJob {
     int w_off;          // weight [128][in_total] in the gradient blob
     int in_total;       // also the number of valid input columns
     int b_off;          // bias offset, or -1 when another block of the same layer owns it
+    int nb;             // limb kernel: 32-column blocks of this job (4: columns col0 .. col0+127, 2: col0 .. col0+63)
 };
 constexpr int WJOBS = 16;
 struct WJobs { WJob j[WJOBS]; };
@@ -129,6 +130,133 @@ __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, lo
     }
 }
 
+// ---- the same contraction on the bf16 matrix pipe (limb_core.h: both operands split exactly into 3 bf16 limbs, 6 products per block) ----
+// v_mfma_f32_32x32x16_bf16 takes 16 rows of the record per instruction: lane (i, h) holds rows q + 8h .. q + 8h + 7 of its output row /
+// input column, so it reads 8 f32x4 of G (outputs 4i .. 4i+3 -> the A operands of 4 output tiles) and 8 x NB floats of X (columns
+// NB i .. NB i + NB - 1 -> the B operands of NB column tiles) -- every row still a contiguous 512-byte read per half wave -- and splits
+// each operand once: 4 + NB splits (5.5 VALU per value) feed 4 * NB * 6 MFMAs.  With NB = 4 a wave owns the whole [128 x 128] block of a
+// hidden layer (256 accumulators, AGPRs; one wave per SIMD) and G is read once per layer; the two 64-column leftovers (density layer 0,
+// columns 128..191 of rgb layer 0) run with NB = 2.  The next 16 rows are loaded while the current ones are multiplied.
+template <int NB>
+__device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int slab, float* tile, float* __restrict__ grad) {
+    typedef float xvec __attribute__((ext_vector_type(NB)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int per_wave = slab / 4;                                   // a multiple of 64 (the host makes slab a multiple of 256)
+    const long q0 = (long)blockIdx.x * slab + (long)wave * per_wave;
+    long q1 = q0 + per_wave;
+    if (q1 > P) q1 = P;
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* gbase = jb.G + 4 * i;
+    const float* xbase = jb.X + jb.col0 + NB * i;
+    const long xs = jb.xstride;
+    f32x4 g[8], gn[8];
+    xvec x[8], xn[8];
+    // rows q + 8 kh + j, j = 0..7; rows >= P read as zero (the last, partial step of the pass)
+    auto load = [&](long q, f32x4 (&gg)[8], xvec (&xx)[8]) {
+        if (q + 16 <= P) {
+            const float* gp_ = gbase + (q + 8 * kh) * HID;
+            const float* xp = xbase + (q + 8 * kh) * xs;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gg[j] = *reinterpret_cast<const f32x4*>(gp_ + j * HID);
+                xx[j] = *reinterpret_cast<const xvec*>(xp + j * xs);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long row = q + 8 * kh + j;
+                const bool ok = row < P;
+                const long rr = ok ? row : P - 1;
+                gg[j] = *reinterpret_cast<const f32x4*>(gbase + rr * HID);
+                xx[j] = *reinterpret_cast<const xvec*>(xbase + rr * xs);
+                if (!ok) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gg[j][c] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) xx[j][c] = 0.0f;
+                }
+            }
+        }
+    };
+    auto multiply = [&](const f32x4 (&gg)[8], const xvec (&xx)[8]) {
+        Limbs<3> xb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = xx[j][b];
+            split8(e, xb[b]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e[j] = gg[j][a]; bs[a] += e[j]; }
+            Limbs<3> ga;
+            split8(e, ga);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int p_ = 0; p_ < 6; ++p_) acc[a][b] = mfma_bf16(ga.v[limb_w(3, p_)], xb[b].v[limb_x(3, p_)], acc[a][b]);
+        }
+    };
+    if (q0 < q1) {
+        load(q0, g, x);
+        for (long q = q0; q < q1; q += 16) {
+            const bool more = q + 16 < q1;
+            if (more) load(q + 16, gn, xn);          // in flight while the current 16 rows are multiplied
+            multiply(g, x);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[j] = gn[j]; x[j] = xn[j]; }
+            }
+        }
+    }
+    // acc[a][b][r]: out = 4 * ((r&3) + 8(r>>2) + 4kh) + a,  column = NB * i + b.   Sum the 4 waves in LDS (same element per lane in every wave).
+    constexpr int TW = 32 * NB;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int out = 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + a;
+                    xvec* t = reinterpret_cast<xvec*>(tile + out * TW + NB * i);
+                    xvec v;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) v[b] = acc[a][b][r];
+                    if (w > 0) v += *t;
+                    *t = v;
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < 128 * TW; idx += WG_TPB) {
+        const int out = idx / TW, col = jb.col0 + (idx % TW);
+        if (col < jb.in_total) unsafeAtomicAdd(grad + jb.w_off + out * jb.in_total + col, tile[idx]);
+    }
+    if (jb.b_off >= 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float v = bs[a] + __shfl_xor(bs[a], 32);
+            if (kh == 0) unsafeAtomicAdd(grad + jb.b_off + 4 * i + a, v);
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(WG_TPB, 1) void decoder_wgrad_limb_kernel(WJobs jobs, int job0, long P, int slab, float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) float tile[128 * 32 * NB];
+    wgrad_limb_block<NB>(jobs.j[job0 + blockIdx.y], P, slab, tile, grad);
+}
+
 // fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k]   (thread = feature f of one branch)
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
                                                          const float* __restrict__ g4, long Pp, int slab, float* __restrict__ grad) {
@@ -171,31 +299,54 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
     if (N == 0) return NVSR_OK;
     const DecRecord rec = make_record(const_cast<float*>(record), (long)N, S);
     const long Pp = rec.Pp, P = rec.P;
+    const long LP = (long)HID * Pp;
     WJobs jobs;
     int n = 0;
-    auto add = [&](const float* G, const float* X, int xstride, int col0, int w_off, int in_total, int b_off) {
-        jobs.j[n++] = WJob{G, X, xstride, col0, w_off, in_total, b_off};
+    auto add = [&](const float* G, const float* X, int xstride, int col0, int w_off, int in_total, int b_off, int nb) {
+        jobs.j[n++] = WJob{G, X, xstride, col0, w_off, in_total, b_off, nb};
     };
-    const long LP = (long)HID * Pp;
-    add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0);
-    for (int l = 1; l <= 3; ++l)
-        for (int c = 0; c < 2; ++c) {
-            const int w = N_DEN_W1 + (l - 1) * N_HID_STRIDE;
-            add(rec.Gd + l * LP, rec.Hd + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1);
+    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32) {
+        // limb kernels: the 7 whole [128 x 128] blocks, then the two 64-column leftovers
+        for (int l = 1; l <= 3; ++l) {
+            const int wd = N_DEN_W1 + (l - 1) * N_HID_STRIDE, wr = N_RGB_W1 + (l - 1) * N_HID_STRIDE;
+            add(rec.Gd + l * LP, rec.Hd + (l - 1) * LP, HID, 0, wd, HID, wd + HID * HID, 4);
+            add(rec.Gr + l * LP, rec.Hr + (l - 1) * LP, HID, 0, wr, HID, wr + HID * HID, 4);
         }
-    for (int c = 0; c < 3; ++c) add(rec.Gr, rec.Xr, 4 * C, 64 * c, N_RGB_W0, 4 * C, c == 0 ? N_RGB_B0 : -1);
-    for (int l = 1; l <= 3; ++l)
-        for (int c = 0; c < 2; ++c) {
-            const int w = N_RGB_W1 + (l - 1) * N_HID_STRIDE;
-            add(rec.Gr + l * LP, rec.Hr + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1);
-        }
-    if (n != WJOBS) return NVSR_ERR_SHAPE;
-    // slabs: ~32 per layer block keeps 512 workgroups in flight (2 per CU) while each block is flushed only 32 times
-    long slab = (P + 31) / 32;
-    slab = ((slab + 255) / 256) * 256;
-    if (slab < 256) slab = 256;
-    const unsigned nslabs = (unsigned)((P + slab - 1) / slab);
-    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, P, (int)slab, grad_natural);
+        add(rec.Gr, rec.Xr, 4 * C, 0, N_RGB_W0, 4 * C, N_RGB_B0, 4);
+        add(rec.Gr, rec.Xr, 4 * C, 128, N_RGB_W0, 4 * C, -1, 2);
+        add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0, 2);
+        // 7 whole blocks x 32 slabs = 224 workgroups (one 4-wave workgroup per CU, every block flushed 32 times), then the two 64-column
+        // blocks with 128 shorter slabs each
+        auto slab_for = [&](int per_block) {
+            long sl = (P + per_block - 1) / per_block;
+            return ((sl + 255) / 256) * 256;
+        };
+        const long s4 = slab_for(32), s2 = slab_for(128);
+        hipLaunchKernelGGL(decoder_wgrad_limb_kernel<4>, dim3((unsigned)((P + s4 - 1) / s4), 7), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, 0, P,
+                           (int)s4, grad_natural);
+        hipLaunchKernelGGL(decoder_wgrad_limb_kernel<2>, dim3((unsigned)((P + s2 - 1) / s2), 2), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, 7, P,
+                           (int)s2, grad_natural);
+    } else {
+        add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0, 2);
+        for (int l = 1; l <= 3; ++l)
+            for (int c = 0; c < 2; ++c) {
+                const int w = N_DEN_W1 + (l - 1) * N_HID_STRIDE;
+                add(rec.Gd + l * LP, rec.Hd + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1, 2);
+            }
+        for (int c = 0; c < 3; ++c) add(rec.Gr, rec.Xr, 4 * C, 64 * c, N_RGB_W0, 4 * C, c == 0 ? N_RGB_B0 : -1, 2);
+        for (int l = 1; l <= 3; ++l)
+            for (int c = 0; c < 2; ++c) {
+                const int w = N_RGB_W1 + (l - 1) * N_HID_STRIDE;
+                add(rec.Gr + l * LP, rec.Hr + (l - 1) * LP, HID, 64 * c, w, HID, c == 0 ? w + HID * HID : -1, 2);
+            }
+        if (n != WJOBS) return NVSR_ERR_SHAPE;
+        // slabs: ~32 per layer block keeps 512 workgroups in flight (2 per CU) while each block is flushed only 32 times
+        long slab = (P + 31) / 32;
+        slab = ((slab + 255) / 256) * 256;
+        if (slab < 256) slab = 256;
+        const unsigned nslabs = (unsigned)((P + slab - 1) / slab);
+        hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, P, (int)slab, grad_natural);
+    }
     const int hslab = 128;        // 4096 workgroups at 524k slots: the loop is one dependent load stream per thread
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
                        rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, P, hslab, grad_natural);

@@ -979,28 +979,37 @@ def test_decoder_weight_grad_contraction(hip):
     """nvsr_decoder_weight_grad alone: a synthetic record (random G / X / H / g4) against float64 matmuls, through the C ABI; an even
     and an odd number of rows (rows are consumed in pairs; allocation is rounded up to 8 rows that must be ignored)"""
     capi = hip.capi
-    for N, S in ((300, 7), (301, 7)):
+    # both kernels: exact-f32 MFMA (rows in pairs) and the default 3-limb bf16 MFMA (16 rows per step, [128 x 128] blocks); row counts that
+    # are / are not multiples of 16, one that spans several slabs per block; the allocation padding holds NaNs
+    for mode, N, S in (("f32", 300, 7), ("f32", 301, 7), ("bf16x3", 300, 7), ("bf16x3", 301, 7), ("bf16x3", 2, 8), ("bf16x3", 1101, 33),
+                       ("f32", 1101, 33)):
         P = N * S
         Pp = (P + 7) // 8 * 8
         n = capi.lib().nvsr_decoder_record_floats(N, S)
         assert n == Pp * 2308
         g_ = torch.Generator(device="cpu").manual_seed(5 + N)
         rec = torch.randn(n, generator=g_, dtype=torch.float32)
-        rec_d = rec.to(DEV)
-        grad = torch.zeros(capi.DECODER_NATURAL_FLOATS, device=DEV)
-        capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())
-        capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())    # accumulates: twice the gradient
-        got = N_(grad) / 2
-        r = rec.double().numpy()
+        r = rec.numpy()
         o = 0
 
         def take(cols, k=1):
             nonlocal o
-            a = r[o:o + k * cols * Pp].reshape(k, Pp, cols)[:, :P]      # rows >= P are allocation padding
+            a = r[o:o + k * cols * Pp].reshape(k, Pp, cols)
+            a[:, P:] = np.nan                                           # rows >= P are allocation padding: never read
             o += k * cols * Pp
-            return a
+            return a[:, :P].astype(np.float64)
 
         Xd, Hd, Gd, Xr, Hr, Gr, g4 = take(64)[0], take(128, 4), take(128, 4), take(192)[0], take(128, 4), take(128, 4), take(4)[0]
+        rec_d = rec.to(DEV)
+        grad = torch.zeros(capi.DECODER_NATURAL_FLOATS, device=DEV)
+        capi.set_decoder_arithmetic(mode)
+        try:
+            capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())
+            capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(rec_d), capi.ptr(grad), capi.stream())    # accumulates: twice the gradient
+        finally:
+            capi.set_decoder_arithmetic(DEFAULT_ARITHMETIC)
+        got = N_(grad) / 2
+
         parts = []
         for X, H, G, width, head in ((Xd, Hd, Gd, 48, g4[:, 3:4]), (Xr, Hr, Gr, 192, g4[:, :3])):
             parts += [(G[0].T @ X[:, :width]).ravel(), G[0].sum(0)]
@@ -1009,8 +1018,8 @@ def test_decoder_weight_grad_contraction(hip):
             parts += [(head.T @ H[3]).ravel(), head.sum(0)]
         ref = np.concatenate(parts)
         assert ref.size == got.size
-        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(P))     # sums of ~2100 N(0,1) products in fp32
-        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * np.sqrt(P))     # sums of P N(0,1) products in fp32
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5, mode
 
 
 def test_composite_backward_vs_autograd_formula(hip):
