@@ -8,6 +8,7 @@ streams.  There is no CPU fallback: without a GPU or without the built library e
 """
 from . import capi  # noqa: F401
 from . import nerf_helpers, volume_rendering_utils, train_utils, models, distributed, plane_store, training  # noqa: F401
+from . import load_blender, load_llff  # noqa: F401
 from .build import build_extension  # noqa: F401
 
-__all__ = ["capi", "nerf_helpers", "volume_rendering_utils", "train_utils", "models", "distributed", "plane_store", "training", "build_extension"]
+__all__ = ["capi", "nerf_helpers", "volume_rendering_utils", "train_utils", "models", "distributed", "plane_store", "training", "load_blender", "load_llff", "build_extension"]

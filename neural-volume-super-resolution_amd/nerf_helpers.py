@@ -116,3 +116,47 @@ class null_with:
 
     def __exit__(self, a, b, c):
         pass
+
+
+# ---- image files (the data format on the input side of the path) ---------------------------------------------
+def imread(path, with_alpha=False, **_ignored):
+    """nerf_helpers.py:256-260: 8-bit image file -> float32 [H,W,C] in [0,1]; RGBA is flattened to RGB with pixels of zero alpha
+    blacked out (the reference reads with imageio; PIL decodes the same 8-bit samples, gamma chunks ignored)."""
+    import numpy as np
+    from PIL import Image
+
+    with Image.open(path) as im:
+        if im.mode not in ("RGB", "RGBA"):
+            im = im.convert("RGBA" if "A" in im.getbands() else "RGB")
+        a = np.asarray(im)
+    if not with_alpha and a.shape[2] > 3:
+        a = a[..., :3] * (a[..., 3:] > 0)
+    return (a / 255.0).astype(np.float32)
+
+
+def calc_resize_crop_margins(im_shape, ds_factor):
+    """nerf_helpers.py:312-322: margins (rows, cols) to crop on every side so that both sides become multiples of ds_factor.  None only
+    when EVERY entry of im_shape divides -- the reference tests the channel count too, so for an [H,W,3] shape and an even factor the
+    result is [0, 0] rather than None; callers see that value (load_llff_data returns it), so it is kept."""
+    import numpy as np
+
+    if not any(v % ds_factor for v in im_shape):
+        return None
+    marg = np.zeros([2], np.int32)
+    for d in (0, 1):
+        while (im_shape[d] - 2 * marg[d]) % ds_factor:
+            marg[d] += 1
+    return marg
+
+
+def im_resize(image, scale_factor, degradation=None, fname=None):
+    """nerf_helpers.py:294-310 without the optional degradations: down-scaling by an integer factor with cv2.INTER_AREA, which for an
+    integer factor is the mean of every (factor x factor) block."""
+    if degradation is not None:
+        raise NotImplementedError("blur / noise degradations of the LR images are dataset preparation, outside the rendering path")
+    f = int(scale_factor)
+    assert all(v % f == 0 for v in image.shape[:2]), "Currently not supporting downscaling to an ambiguous size."
+    if f == 1:
+        return image
+    h, w = image.shape[0] // f, image.shape[1] // f
+    return image.reshape(h, f, w, f, -1).mean(axis=(1, 3)).astype(image.dtype).reshape((h, w) + image.shape[2:])

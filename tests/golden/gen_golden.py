@@ -23,6 +23,10 @@ Fixture index:
   g12_ndc_render.npz  eval_nerf of a forward-facing (LLFF-style) view through NDC rays (train_utils.py:215-218)
   g14_sr_grads.npz    autograd through EDSR / PlanesSR (full plane and ROI): weights, network input and LR plane ('SR' in what)
   g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
+  g15_loaders.npz     load_blender_data / load_llff_data on two tiny synthetic scenes (load_blender.py:232-332, load_llff.py:70-360).
+                      imageio and cv2 are absent here: the harness reads the PNGs with PIL and gives cv2.resize(INTER_AREA) its
+                      definition for integer factors (block mean), so the resampling itself is pinned by definition only; the JSON /
+                      poses_bounds parsing, splits, intrinsics, pose algebra, render paths and hold-out choice are the reference's.
 """
 import os
 import sys
@@ -766,9 +770,94 @@ def g14_sr_grads():
     save("g14_sr_grads.npz", **arrs)
 
 
+def g15_loaders():
+    import json
+    import shutil
+    import tempfile
+
+    from PIL import Image
+
+    def pil_imread(path, **kw):
+        with Image.open(path) as im:
+            return np.asarray(im)
+
+    def area_resize(img, dsize, interpolation=None):
+        w, h = dsize
+        fy, fx = img.shape[0] // h, img.shape[1] // w
+        assert fy * h == img.shape[0] and fx * w == img.shape[1]
+        return img.reshape(h, fy, w, fx, -1).mean(axis=(1, 3)).astype(img.dtype).reshape((h, w) + img.shape[2:])
+
+    sys.modules["imageio"].imread = pil_imread
+    sys.modules["cv2"].resize = area_resize
+    sys.modules["cv2"].INTER_AREA = 3
+    import load_blender as ref_blender
+    import load_llff as ref_llff
+
+    rng = np.random.default_rng(15)
+    arrs = {}
+    root = tempfile.mkdtemp(prefix="g15_")
+    try:
+        # ---- Blender layout: 3 train / 4 val / 2 test RGBA frames of 8 x 12 pixels ----
+        bdir = os.path.join(root, "toyscene")
+        counts = {"train": 3, "val": 4, "test": 2}
+        for split, n in counts.items():
+            os.makedirs(os.path.join(bdir, split))
+            frames = []
+            for k in range(n):
+                rgba = rng.integers(0, 256, (8, 12, 4), dtype=np.uint8)
+                rgba[..., 3] = np.where(rng.random((8, 12)) < 0.3, 0, rgba[..., 3])      # some fully transparent pixels
+                Image.fromarray(rgba, "RGBA").save(os.path.join(bdir, split, "r_%d.png" % k))
+                pose = ref_blender.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-60, 0)), 4.0)
+                frames.append({"file_path": "./%s/r_%d" % (split, k), "transform_matrix": pose.tolist()})
+                arrs["blender_%s_%d" % (split, k)] = rgba
+                arrs["blender_%s_%d_pose" % (split, k)] = np.asarray(pose)
+            with open(os.path.join(bdir, "transforms_%s.json" % split), "w") as fp:
+                json.dump({"camera_angle_x": 0.6911112, "frames": frames}, fp)
+        arrs["blender_counts"] = np.array([counts[s] for s in ("train", "val", "test")])
+        for tag, kw in (("a", dict(downsampling_factor=2, val_downsampling_factor=1, testskip=2, splits2use=["train", "val"])),
+                        ("b", dict(downsampling_factor=4, splits2use=["train", "val", "test"]))):
+            imgs, poses, render_poses, (H, W, focal, ds), i_split = ref_blender.load_blender_data(bdir, **kw)
+            for k, im in enumerate(imgs):
+                arrs["blender_%s_img%d" % (tag, k)] = npy(im)
+            arrs.update({"blender_%s_poses" % tag: npy(poses), "blender_%s_render_poses" % tag: npy(render_poses),
+                         "blender_%s_H" % tag: np.array(H), "blender_%s_W" % tag: np.array(W), "blender_%s_focal" % tag: np.array(focal),
+                         "blender_%s_ds" % tag: np.array(ds)})
+            for k, idx in enumerate(i_split):
+                arrs["blender_%s_split%d" % (tag, k)] = np.asarray(idx)
+        # ---- LLFF layout: 6 views of 14 x 18 RGB pixels (odd multiples: cropped to 12 x 16 for max_factor 4) ----
+        ldir = os.path.join(root, "toyfern")
+        os.makedirs(os.path.join(ldir, "images"))
+        n = 6
+        pb = np.zeros((n, 17))
+        for k in range(n):
+            rgb = rng.integers(0, 256, (14, 18, 3), dtype=np.uint8)
+            Image.fromarray(rgb, "RGB").save(os.path.join(ldir, "images", "view_%02d.png" % k))
+            arrs["llff_img_%d" % k] = rgb
+            q, _ = np.linalg.qr(rng.standard_normal((3, 3)) * 0.15 + np.eye(3))
+            m = np.concatenate([q, rng.uniform(-0.5, 0.5, (3, 1)), np.array([[14.0], [18.0], [21.0]])], 1)
+            pb[k, :15] = m.reshape(-1)
+            pb[k, 15:] = [rng.uniform(1.0, 1.5), rng.uniform(8.0, 12.0)]
+        np.save(os.path.join(ldir, "poses_bounds.npy"), pb)
+        arrs["llff_poses_bounds"] = pb
+        for tag, kw in (("fwd", dict(factor=2, base_factor=1, max_factor=4)),
+                        ("sph", dict(factor=4, base_factor=1, max_factor=4, spherify=True)),
+                        ("flat", dict(factor=2, base_factor=1, max_factor=2, path_zflat=True, bd_factor=None))):
+            if tag == "flat":        # the reference turns N_views into a float there, which numpy >= 1.18 rejects in linspace
+                _orig = ref_llff.render_path_spiral
+                ref_llff.render_path_spiral = lambda *a, **k: _orig(*a, **{**k, "N": int(k["N"])})
+            images, poses, bds, render_poses, i_test, (bf, marg) = ref_llff.load_llff_data(ldir, **kw)
+            arrs.update({"llff_%s_images" % tag: npy(images), "llff_%s_poses" % tag: npy(poses), "llff_%s_bds" % tag: np.asarray(bds),
+                         "llff_%s_render_poses" % tag: np.asarray(render_poses), "llff_%s_i_test" % tag: np.array(int(i_test)),
+                         "llff_%s_base_factor" % tag: np.array(bf),
+                         "llff_%s_margins" % tag: np.array([-1, -1]) if marg is None else np.asarray(marg)})
+    finally:
+        shutil.rmtree(root)
+    save("g15_loaders.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

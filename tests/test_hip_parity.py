@@ -1662,3 +1662,44 @@ def test_bench_two_rank_rehearsal(workload):
     per_gpu = r["config"]["rays_per_step_per_gpu"]
     assert abs(r["value"] - 2 * per_gpu * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]   # whole-job aggregate over both ranks
     assert "roofline" in r and "cpu_baseline" not in r
+
+
+def test_loaded_scenes_feed_the_render_path(hip, tmp_path):
+    """the data formats on the input side: a Blender-layout and an LLFF-layout scene loaded from disk drive
+    get_ray_bundle / eval_nerf directly -- per-image [H, W, focal] and the camera-to-world matrices as the loaders return them, NDC rays
+    for the forward-facing scene; and a train step draws its pixels from a loaded image"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host import _write_toy_scenes
+    from bench import make_synthetic_scene, render_options
+    g = load_golden("g15_loaders.npz")
+    bdir, ldir = _write_toy_scenes(g, str(tmp_path))
+    mc, mf, sid, _ = make_synthetic_scene(DEV, plane_res=32, view_res=8, seed=5)
+    imgs, poses, render_poses, (H, W, focal, ds), i_split = hip.load_blender.load_blender_data(bdir, downsampling_factor=2, splits2use=["train", "val"])
+    opts, scfg = render_options(16, 16)
+    k = int(i_split[0][0])
+    pose = poses[k].to(DEV)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H[k], W[k], focal[k], pose, downsampling_offset=hip.training.downsampling_offset(ds[k]))
+    out = hip.train_utils.eval_nerf(H[k], W[k], focal[k], mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    assert out[3].shape == imgs[k].shape and torch.isfinite(out[3]).all()
+    out = hip.train_utils.eval_nerf(H[k], W[k], focal[k], mc, mf, *hip.nerf_helpers.get_ray_bundle(H[k], W[k], focal[k], render_poses[7].float().to(DEV)),
+                                    opts, scene_id=sid, scene_config=scfg)
+    assert torch.isfinite(out[3]).all()
+    # one optimisation step on pixels of the loaded image
+    for m in (mc, mf):
+        for n_, p_ in m.named_parameters():
+            p_.requires_grad_("planes_" in n_)
+    popt = torch.optim.Adam(list(mc.planes_.values()), lr=1e-2)
+    topts, _ = render_options(16, 16, perturb=True, noise=0.0)
+    step = hip.training.TrainStep(mc, mf, topts, {"LR_planes"}, planes_optimizer=popt)
+    np.random.seed(0)
+    r = step(0, imgs[k].to(DEV), pose, H[k], W[k], focal[k], ds[k], sid, scfg, 16)
+    assert np.isfinite(r["loss"]) and r["psnr"] is not None
+    # LLFF: [H, W, focal] ride in the fifth column of every pose; forward-facing scenes render through NDC rays
+    images, lposes, bds, lrender, i_test, _ = hip.load_llff.load_llff_data(ldir, factor=2, base_factor=1, max_factor=4)
+    h, w, f = (float(v) for v in lposes[i_test, :3, -1])
+    c2w = lposes[i_test, :3, :4].to(DEV)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(int(h), int(w), f, c2w)
+    ndc_cfg = dict(no_ndc=False, near=0.0, far=1.0)
+    out = hip.train_utils.eval_nerf(int(h), int(w), f, mc, mf, ro, rd, opts, scene_id=sid, scene_config=ndc_cfg)
+    assert out[3].shape == images[i_test].shape and torch.isfinite(out[0]).all()

@@ -38,10 +38,13 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_mirror_exposes_reference_surface(pkg):
     for mod, names in {
-        "nerf_helpers": ["get_ray_bundle", "ndc_rays", "sample_pdf_2", "cumprod_exclusive", "get_minibatches", "meshgrid_xy"],
+        "nerf_helpers": ["get_ray_bundle", "ndc_rays", "sample_pdf_2", "cumprod_exclusive", "get_minibatches", "meshgrid_xy", "imread", "im_resize",
+                         "calc_resize_crop_margins"],
         "volume_rendering_utils": ["volume_render_radiance_field"],
         "train_utils": ["run_network", "predict_and_render_radiance", "run_one_iter_of_nerf", "eval_nerf"],
         "models": ["TwoDimPlanesModel", "CoordProjector", "create_plane", "get_plane_name", "get_scene_id"],
+        "load_blender": ["load_blender_data", "pose_spherical"],
+        "load_llff": ["load_llff_data", "recenter_poses", "spherify_poses", "render_path_spiral", "poses_avg"],
     }.items():
         for n in names:
             assert hasattr(getattr(pkg, mod), n), "%s.%s" % (mod, n)
@@ -153,3 +156,62 @@ def test_step_metrics_mapping_semantics():
     assert m["coarse_loss"] is None and m["psnr"] is None and m["fine_loss"] == 0.5 and m["loss"] == 0.5
     with pytest.raises(KeyError):
         m["nope"]
+
+
+def _write_toy_scenes(g, root):
+    """the two synthetic scenes of fixture g15 (tests/golden/gen_golden.py::g15_loaders), rebuilt from the stored pixels / poses"""
+    import json
+    from PIL import Image
+    bdir, ldir = os.path.join(root, "toyscene"), os.path.join(root, "toyfern")
+    for split, n in zip(("train", "val", "test"), g["blender_counts"]):
+        os.makedirs(os.path.join(bdir, split))
+        frames = []
+        for k in range(int(n)):
+            Image.fromarray(g["blender_%s_%d" % (split, k)], "RGBA").save(os.path.join(bdir, split, "r_%d.png" % k))
+            frames.append({"file_path": "./%s/r_%d" % (split, k), "transform_matrix": g["blender_%s_%d_pose" % (split, k)].tolist()})
+        with open(os.path.join(bdir, "transforms_%s.json" % split), "w") as fp:
+            json.dump({"camera_angle_x": 0.6911112, "frames": frames}, fp)
+    os.makedirs(os.path.join(ldir, "images"))
+    for k in range(g["llff_poses_bounds"].shape[0]):
+        Image.fromarray(g["llff_img_%d" % k], "RGB").save(os.path.join(ldir, "images", "view_%02d.png" % k))
+    np.save(os.path.join(ldir, "poses_bounds.npy"), g["llff_poses_bounds"])
+    return bdir, ldir
+
+
+def test_dataset_loaders_match_reference(pkg, tmp_path):
+    """load_blender_data / load_llff_data against the reference's outputs on the same files (fixture g15): splits,
+    per-image H / W / focal after down-scaling, poses, the 40-view orbit; LLFF axis swap, bound rescaling, recentring, spiral / spherical
+    render paths, hold-out view, crop margins"""
+    from conftest import load_golden
+    g = load_golden("g15_loaders.npz")
+    bdir, ldir = _write_toy_scenes(g, str(tmp_path))
+    for tag, kw in (("a", dict(downsampling_factor=2, val_downsampling_factor=1, testskip=2, splits2use=["train", "val"])),
+                    ("b", dict(downsampling_factor=4, splits2use=["train", "val", "test"]))):
+        imgs, poses, render_poses, (H, W, focal, ds), i_split = pkg.load_blender.load_blender_data(bdir, **kw)
+        assert len(imgs) == len(g["blender_%s_H" % tag])
+        for k, im in enumerate(imgs):
+            ref = g["blender_%s_img%d" % (tag, k)]
+            assert im.dtype == torch.float32 and tuple(im.shape) == ref.shape
+            np.testing.assert_allclose(im.numpy(), ref, rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(poses.numpy(), g["blender_%s_poses" % tag])
+        np.testing.assert_allclose(render_poses.numpy(), g["blender_%s_render_poses" % tag], rtol=0, atol=1e-12)
+        assert list(H) == list(g["blender_%s_H" % tag]) and list(W) == list(g["blender_%s_W" % tag]) and list(ds) == list(g["blender_%s_ds" % tag])
+        np.testing.assert_allclose(focal, g["blender_%s_focal" % tag], rtol=1e-15)
+        for k, idx in enumerate(i_split):
+            np.testing.assert_array_equal(idx, g["blender_%s_split%d" % (tag, k)])
+    paths = pkg.load_blender.load_blender_data(bdir, downsampling_factor=2, load_imgs=False)
+    assert all(isinstance(p_, str) and p_.endswith(".png") for p_ in paths[0]) and paths[3][0][0] == 4 and paths[3][1][0] == 6
+    for tag, kw in (("fwd", dict(factor=2, base_factor=1, max_factor=4)),
+                    ("sph", dict(factor=4, base_factor=1, max_factor=4, spherify=True)),
+                    ("flat", dict(factor=2, base_factor=1, max_factor=2, path_zflat=True, bd_factor=None))):
+        images, poses, bds, render_poses, i_test, (bf, marg) = pkg.load_llff.load_llff_data(ldir, **kw)
+        assert images.dtype == torch.float32 and poses.dtype == torch.float32 and render_poses.dtype == np.float32
+        np.testing.assert_allclose(images.numpy(), g["llff_%s_images" % tag], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(poses.numpy(), g["llff_%s_poses" % tag], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(bds, g["llff_%s_bds" % tag], rtol=1e-6)
+        np.testing.assert_allclose(render_poses, g["llff_%s_render_poses" % tag], rtol=1e-5, atol=1e-5)
+        assert int(i_test) == int(g["llff_%s_i_test" % tag]) and int(bf) == int(g["llff_%s_base_factor" % tag])
+        assert (marg is None and g["llff_%s_margins" % tag][0] < 0) or list(marg) == list(g["llff_%s_margins" % tag])
+    # the loaded intrinsics feed the ray generator unchanged: [H, W, focal] of an LLFF pose's fifth column
+    hwf = poses[0, :3, -1].tolist()
+    assert hwf[0] == images.shape[1] and hwf[1] == images.shape[2]
