@@ -26,7 +26,8 @@ def _stale():
 # Per-file flags.  render3.hip: the SLP vectorizer packs pairs of f32 operations out of different MFMA gaps into v_pk_* and, to do so,
 # re-schedules the whole block at IR level -- every pure instruction (the MFMAs included) sinks below the block's loads and
 # sched_barriers, the hand-placed interleave is gone and hundreds of registers spill.
-PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"]}
+# decode_limb.hip: same blocks, same reason (250 spilled registers with the vectorizer, none without).
+PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"], "decode_limb.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(CSRC, "_obj")
 
 

@@ -1,0 +1,233 @@
+// Training forward on the bf16 matrix pipe: decode_rays_kernel<MASKS, RECORD> (render.hip) with the decoder GEMMs in the exact 3-limb
+// arithmetic of limb_core.h -- raw [N,S,4] for a batch too small for one workgroup per ray block (4 096 training rays), the ReLU gates
+// the gate-driven backward consumes, and optionally the layer-input half of the weight-gradient record.
+//
+// The reference runs this as run_network -> TwoDimPlanesModel.forward under autograd (train_utils.py:15-64, models.py:381-421).
+//
+// Skeleton of the first-generation kernel, not of render3.hip: tiles are (ray block, sample) pairs, a wave owns ONE 32-point tile, and
+// the latency of its gathers, limb splits, bias + ReLU, gate words and record stores is covered by the wave of the OTHER workgroup on the
+// same SIMD -- two independent 4-wave workgroups per CU (own barriers, start-up stagger), which is why the weight ring is cut into
+// 36-KB slots (3 K-blocks of 16 input channels x 3 limbs x 4 output blocks): 2 x (2 x 36 KB + 6 KB) = 157 KB of LDS.  A plane's share
+// of a feature layer is one chunk, a hidden layer three (3 + 3 + 2 K-blocks): 23 chunks per step, each staged by MUBUF LDS-DMA one
+// chunk ahead.  Per step and tile 1 512 MFMAs (v_mfma_f32_32x32x16_bf16) instead of 2 016 v_mfma_f32_32x32x2_f32 of twice the length.
+#include <type_traits>
+
+#include "limb_core.h"
+
+namespace nvsr {
+
+constexpr int L3_TPB = 256, L3_WAVES = L3_TPB / 64, L3_PTS = L3_WAVES * 32;
+constexpr int L3_SLOT = 3 * kb_words(3);                      // words: 36 KB
+constexpr int L3_SMALL = 2 * L3_SLOT;
+constexpr int L3_LDS = L3_SMALL + SMALL_FLOATS;
+static_assert(2 * L3_LDS * 4 <= 160 * 1024, "two workgroups per CU");
+
+struct RingL {
+    __amdgpu_buffer_rsrc_t rsrc;   // 3-limb fragment region of the packed blob
+    unsigned* lds;
+    int slot;
+    int wave, lane;
+    unsigned voff;                 // wave * 1024 + lane * 16
+};
+
+// chunk = K-blocks kb0 .. kb0 + NKB - 1 -> the free slot, in 1-KiB pieces round-robin over the waves
+template <int NKB>
+__device__ __forceinline__ const unsigned* ringl_issue(RingL& rs, int kb0) {
+    unsigned* dst = rs.lds + rs.slot * L3_SLOT;
+    constexpr int PIECES = NKB * 4 * 3;
+    static_assert(PIECES % L3_WAVES == 0, "chunk must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < PIECES / L3_WAVES; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * L3_WAVES + rs.wave) * 256), 16,
+                                                 (int)rs.voff, kb0 * kb_words(3) * 4 + i * (L3_WAVES * 1024), 0, 0);
+    rs.slot ^= 1;
+    return dst;
+}
+__device__ __forceinline__ void ringl_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// act = max(acc + bias, 0)   (bias packed in accumulator-register order: [group of 4 registers][lane half][4])
+__device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* bias, int h, f32x16 (&act)[4]) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + g * 8 + h * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) act[g >> 2][4 * (g & 3) + j] = fmaxf(acc[g >> 2][4 * (g & 3) + j] + b[j], 0.0f);
+    }
+}
+// the layer's ReLU gate in relu_publish's format: bit (ib & 1) * 16 + r of word ib >> 1  <=>  pre-activation > 0
+__device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* __restrict__ rec, int layer) {
+    unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned bit = act[ib][r] > 0.0f ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            if (ib < 2) m0 |= bit; else m1 |= bit;
+        }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};
+}
+
+template <bool MASKS, bool RECORD>
+__device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, const float* small, float px, float py, float pz, const Taps& vt,
+                                                 float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok) {
+    asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));       // (see decode_step: keeps hipcc from hoisting per-lane addresses out of the tile loop)
+    const int lane = rs.lane, h = lane >> 5;
+    const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
+    const float n1 = norm_coord(py, sc.lo[1], sc.range[1]);
+    const float n2 = norm_coord(pz, sc.lo[2], sc.range[2]);
+    f32x16 acc[4], act[4];
+    float D[HALF_C], F[HALF_C];
+    Limbs<3> cur, fa;
+    auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
+    auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
+    auto none = [](int) {};
+    auto pos_taps = [&](int d) {
+        const float* M = sc.proj + 6 * d;
+        return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+    };
+    // Nothing moves across the end of a block: left alone hipcc hoists the next plane's 24 gather loads (96 registers) above the block's
+    // MFMAs -- good for latency, but with the accumulators, D, F and the limbs live it spills 120 registers; the other workgroup's wave on
+    // the SIMD covers the gather instead.
+    // (the asm takes the accumulators as operands: a bare memory clobber orders the loads but lets the MFMAs sink below them)
+#define L3_FENCE                                                                                    \
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");         \
+    __builtin_amdgcn_sched_barrier(0);
+    // one chunk: wait for it, start the copy of the next one, split the block's first K-block, multiply
+#define L3_BLOCK(NKB, ZERO, SRC, NEXT)                                                         \
+    {                                                                                          \
+        ringl_sync();                                                                          \
+        const unsigned* nw = NEXT;                                                             \
+        { auto s_ = SRC; split_all<3>([&](int i) { return s_(0, i); }, cur); }                 \
+        limb_block<3, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, NoTail{});           \
+        cw = nw;                                                                               \
+        L3_FENCE                                                                               \
+    }
+    // a hidden layer = 3 + 3 + 2 K-blocks of the previous activation; NEXT = the chunk that follows the layer
+#define L3_HIDDEN(KB0, NEXT)                                                                   \
+    L3_BLOCK(3, true, hid(act, 0), ringl_issue<3>(rs, (KB0) + 3))                              \
+    L3_BLOCK(3, false, hid(act, 3), ringl_issue<2>(rs, (KB0) + 6))                             \
+    L3_BLOCK(2, false, hid(act, 6), NEXT)
+    auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
+        bias_relu(acc, small + S_BIAS + vec * HID, h, act);
+        if (MASKS) publish_gates(act, gates, vec);
+        if (RECORD && rec_ok) record128(hrow, q, h, act);
+    };
+    const long LP = (long)HID * rec.Pp;
+
+    // ---- rgb layer 0: K = 192 in the limb blob's order [f_view | f0 | f1 | f2], one plane = one chunk ---------------------------------
+    const unsigned* cw = ringl_issue<3>(rs, KB_RGB0);
+    gather24(sc.plane[3], vt, h, F);
+    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
+    L3_BLOCK(3, true, feat(F), ringl_issue<3>(rs, KB_RGB0 + 3))
+    gather24(sc.plane[0], pos_taps(0), h, F);
+    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C), h, F);
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
+    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 6))
+    gather24(sc.plane[1], pos_taps(1), h, F);
+    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + C, h, F);
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
+    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 9))
+    gather24(sc.plane[2], pos_taps(2), h, F);
+    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
+    // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
+#pragma unroll
+    for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
+    if (RECORD && rec_ok) {
+        record24(rec.Xd + q * 64, h, D);
+        *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB1))
+    finish(4, rec.Hr);
+    // ---- rgb layers 1..3, rgb head ---------------------------------------------------------------------------------------------------
+    L3_HIDDEN(KB_RGB1, ringl_issue<3>(rs, KB_RGB1 + 8))
+    finish(5, rec.Hr + LP);
+    L3_HIDDEN(KB_RGB1 + 8, ringl_issue<3>(rs, KB_RGB1 + 16))
+    finish(6, rec.Hr + 2 * LP);
+    L3_HIDDEN(KB_RGB1 + 16, ringl_issue<3>(rs, KB_DEN0))
+    finish(7, rec.Hr + 3 * LP);
+    {
+        float hd[3];
+        head_dots<3>(small + S_RGB_W, h, act, hd);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) raw[c] = hd[c] + small[S_HEAD_B + 1 + c];
+    }
+    // ---- density decoder: 48 -> 128 x 4 -> 1 -----------------------------------------------------------------------------------------
+    L3_BLOCK(3, true, feat(D), ringl_issue<3>(rs, KB_DEN1))
+    finish(0, rec.Hd);
+    L3_HIDDEN(KB_DEN1, ringl_issue<3>(rs, KB_DEN1 + 8))
+    finish(1, rec.Hd + LP);
+    L3_HIDDEN(KB_DEN1 + 8, ringl_issue<3>(rs, KB_DEN1 + 16))
+    finish(2, rec.Hd + 2 * LP);
+    L3_HIDDEN(KB_DEN1 + 16, (const unsigned*)nullptr)
+    finish(3, rec.Hd + 3 * LP);
+    {
+        float hd[1];
+        head_dots<1>(small + S_ALPHA_W, h, act, hd);
+        raw[3] = hd[0] + small[S_HEAD_B];
+    }
+#undef L3_HIDDEN
+#undef L3_BLOCK
+#undef L3_FENCE
+}
+
+template <bool MASKS, bool RECORD>
+__global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                                    const float* __restrict__ rays, const float* __restrict__ z,
+                                                                    float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[L3_LDS];
+    RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(3)), 0, KB_TOTAL * kb_words(3) * 4, 0x00020000), lds, 0,
+             (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    float* ldsf = reinterpret_cast<float*>(lds);
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += L3_TPB) ldsf[L3_SMALL + i] = packed[P_SMALL + i];   // published by the first ring barrier
+    const float* small = ldsf + L3_SMALL;
+    // start-up stagger of the two workgroups of a CU (decode_prologue): the one in an odd wave slot starts half a phase late
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(64);
+    const long nrb = (N + L3_PTS - 1) / L3_PTS;
+    const long ntiles = nrb * S;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
+        const long rb = tile / S;
+        const int s = (int)(tile - rb * S);
+        long ray = rb * L3_PTS + rs.wave * 32 + (rs.lane & 31);
+        const bool valid = ray < N;
+        if (!valid) ray = N - 1;
+        const float* r = rays + ray * 11;
+        const float zc = z[ray * S + s];
+        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        float raw[4];
+        // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes of the last ray block rewrite ray N-1's record
+        unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
+        decode_step_limb<MASKS, RECORD>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
+                                        __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, (long)s * N + ray, valid);
+        if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+// nvsr_decode_rays_ex (render.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
+extern "C" int nvsr_decode_rays_limb_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                            const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
+    const int64_t ntiles = ((N + L3_PTS - 1) / L3_PTS) * S;
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (record)
+        hipLaunchKernelGGL((decode_rays_limb_kernel<true, true>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, z, raw, gates, make_record(record, (long)N, S));
+    else if (gates)
+        hipLaunchKernelGGL((decode_rays_limb_kernel<true, false>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, z, raw, gates, DecRecord{});
+    else
+        hipLaunchKernelGGL((decode_rays_limb_kernel<false, false>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{});
+    return NVSR_CHECK_LAUNCH();
+}

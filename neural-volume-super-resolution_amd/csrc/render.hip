@@ -228,6 +228,8 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
                                         const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
                                         float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
 extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packed, nvsr_stream_t stream);
+extern "C" int nvsr_decode_rays_limb_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                            const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream);
 
 // arithmetic of the fused render pass (process-wide): -1 = not yet read from the environment
 static int g_decoder_arithmetic = -1;
@@ -296,9 +298,12 @@ int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, in
     if (!aligned16(packed_decoder) || !aligned16(raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
+    if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
+    // bf16-limb matrix pipe (decode_limb.hip), always with 3 limbs: the gates and the record feed gradients
+    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32)
+        return nvsr_decode_rays_limb_launch(scene, packed_decoder, N, S, rays, z, raw, gates, record, stream);
     const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-    if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
     if (record)
         hipLaunchKernelGGL((decode_rays_kernel<true, true>), dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N,
                            S, rays, z, raw, gates, make_record(record, (long)N, S));
