@@ -43,7 +43,7 @@ typedef enum {
 #define NVSR_DECODER_PACKED_F32_FLOATS 130576 /* f32 MFMA-fragment order + biases/heads */
 /* packed blob = [f32 fragments + biases/heads][bf16 fragments, 3 limbs per weight][bf16 fragments, 2 limbs per weight] (32-bit words) */
 #define NVSR_DECODER_PACKED_FLOATS 453136
-#define NVSR_DECODER_PACKED_BWD_FLOATS 139264 /* transposed layers for the backward pass, see nvsr_pack_decoder_bwd */
+#define NVSR_DECODER_PACKED_BWD_FLOATS 348160 /* transposed layers for the backward pass (f32 fragments + bf16 limb fragments), see nvsr_pack_decoder_bwd */
 
 /* One scene = 3 position planes + 1 view-direction plane, CHANNEL-LAST [H][W][48] (192 B per texel), the per-scene
  * normalisation box (models.py:261-268) and the plane projections rot_mats[d][:,1:] (models.py:471-497). */

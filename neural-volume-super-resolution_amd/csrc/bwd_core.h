@@ -14,9 +14,81 @@ constexpr int B_DEN0 = B_DEN_H + 3 * P_HID_FLOATS;       // 49152
 constexpr int B_RGB_H = B_DEN0 + 8192;                   // 57344: rgb L3^T, L2^T, L1^T
 constexpr int B_RGB0 = B_RGB_H + 3 * P_HID_FLOATS;       // 106496: planes 0..3
 constexpr int B_TOTAL = B_RGB0 + 4 * 8192;               // 139264
-static_assert(B_TOTAL == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
 
 struct Masks { unsigned m[2]; };   // bit (ib&1)*16 + r of m[ib>>1]  <=>  post-ReLU activation acc[ib][r] > 0
 struct GradPlanes { float* p[4]; };
+
+// ---- the bf16-limb fragments of the same transposed layers (render_bwd_limb.hip), behind the f32 blob; 816 fragments of 256 words
+// ([lane][4 words of 2 bf16], limb_core.h) in consumption order, cut into 34 chunks of 24 fragments (24 KB):
+//   hidden^T layer: [K-block 8 (16 output features)][in-feature block 4][limb 3]        96 fragments = 4 chunks
+//   layer-0^T of one plane: [K-block 8][channel block 2][limb 3]                         48 fragments = 2 chunks
+//   order: density L3^T, L2^T, L1^T, density layer-0^T, rgb L3^T, L2^T, L1^T, rgb layer-0^T of planes 0..3
+constexpr int BL_FRAGS = 6 * 96 + 5 * 48;                // 816
+constexpr int BL_CHUNK_WORDS = 24 * 256;                 // 6144
+constexpr int BL_CHUNKS = BL_FRAGS / 24;                 // 34
+constexpr int BL_WORDS = BL_FRAGS * 256;                 // 208896
+static_assert(B_TOTAL + BL_WORDS == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
+
+__device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[ib][r] = ((k.m[ib >> 1] >> ((ib & 1) * 16 + r)) & 1u) ? g[ib][r] : 0.0f;
+}
+
+// feature gradients of one plane (acc2: rows c = 32b + (r&3) + 8(r>>2) + 4h) -> LDS tile [pt][48] -> atomics into the plane
+__device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
+                                              bool valid) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    // taps of an invalid (padding) ray carry zero weight
+    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    for (int p = 0; p < 32; ++p) {
+        const int o0 = __shfl(t.o00, p), o1 = __shfl(t.o01, p), o2 = __shfl(t.o10, p), o3 = __shfl(t.o11, p);
+        const float a0 = __shfl(w0, p), a1 = __shfl(w1, p), a2 = __shfl(w2, p), a3 = __shfl(w3, p);
+        if (lane < C) {
+            const float v = tile[p * C + lane];
+            unsafeAtomicAdd(gplane + o0 + lane, v * a0);
+            unsafeAtomicAdd(gplane + o1 + lane, v * a1);
+            unsafeAtomicAdd(gplane + o2 + lane, v * a2);
+            unsafeAtomicAdd(gplane + o3 + lane, v * a3);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
+// address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
+// gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.
+__device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* tile, float* __restrict__ gview, long ray_w0, long N, int S,
+                                                int s, int lane) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < C) {
+        for (int p = 0; p < 32; ++p)
+            if (ray_w0 + p < N) gview[((ray_w0 + p) * S + s) * C + lane] = tile[p * C + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+
 
 }  // namespace nvsr

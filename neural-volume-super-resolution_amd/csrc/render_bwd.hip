@@ -64,12 +64,6 @@ __device__ __forceinline__ Masks relu_masks(f32x16 (&acc)[4]) {
         }
     return k;
 }
-__device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[ib][r] = ((k.m[ib >> 1] >> ((ib & 1) * 16 + r)) & 1u) ? g[ib][r] : 0.0f;
-}
 __device__ __forceinline__ void zero_acc(f32x16 (&a)[4]) {
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -111,60 +105,6 @@ __device__ __forceinline__ void hidden_T(RingState& rs, const float*& cur, int n
     apply_mask(mk, gn);
     cur = nxt;
 }
-
-// feature gradients of one plane (acc2: rows c = 32b + (r&3) + 8(r>>2) + 4h) -> LDS tile [pt][48] -> atomics into the plane
-__device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
-                                              bool valid) {
-    const int h = lane >> 5, pt = lane & 31;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
-            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
-        }
-    __builtin_amdgcn_wave_barrier();
-    // taps of an invalid (padding) ray carry zero weight
-    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
-    for (int p = 0; p < 32; ++p) {
-        const int o0 = __shfl(t.o00, p), o1 = __shfl(t.o01, p), o2 = __shfl(t.o10, p), o3 = __shfl(t.o11, p);
-        const float a0 = __shfl(w0, p), a1 = __shfl(w1, p), a2 = __shfl(w2, p), a3 = __shfl(w3, p);
-        if (lane < C) {
-            const float v = tile[p * C + lane];
-            unsafeAtomicAdd(gplane + o0 + lane, v * a0);
-            unsafeAtomicAdd(gplane + o1 + lane, v * a1);
-            unsafeAtomicAdd(gplane + o2 + lane, v * a2);
-            unsafeAtomicAdd(gplane + o3 + lane, v * a3);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
-// address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
-// gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.
-__device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* tile, float* __restrict__ gview, long ray_w0, long N, int S,
-                                                int s, int lane) {
-    const int h = lane >> 5, pt = lane & 31;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (b == 1 && r >= 8) continue;
-            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
-        }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < C) {
-        for (int p = 0; p < 32; ++p)
-            if (ray_w0 + p < N) gview[((ray_w0 + p) * S + s) * C + lane] = tile[p * C + lane];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
 
 // =====================================================================================================================
 template <bool RECORD>
@@ -600,13 +540,22 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
 
 using namespace nvsr;
 
+// render_bwd_limb.hip
+extern "C" int nvsr_pack_decoder_bwd_limbs_launch(const float* natural, float* packed_bwd, nvsr_stream_t stream);
+extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
+                                                           int64_t N, int S, const float* rays, const float* z, const float* g_raw,
+                                                           const uint32_t* gates, float* const* grad_planes, float* view_ws, float* record,
+                                                           nvsr_stream_t stream);
+extern "C" int nvsr_get_decoder_arithmetic(void);
+
 extern "C" {
 
 int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t stream) {
     if (!natural || !packed_bwd) return NVSR_ERR_NULL;
     if (!aligned16(packed_bwd)) return NVSR_ERR_ALIGN;
     hipLaunchKernelGGL(pack_decoder_bwd_kernel, dim3((B_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural, packed_bwd);
-    return NVSR_CHECK_LAUNCH();
+    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    return nvsr_pack_decoder_bwd_limbs_launch(natural, packed_bwd, stream);      // the bf16-limb fragments behind the f32 ones
 }
 
 int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
@@ -678,6 +627,13 @@ int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
+    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32) {       // bf16-limb matrix pipe, always 3 limbs (render_bwd_limb.hip)
+        if (int e = nvsr_render_pass_backward_gates_limb_launch(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, gates, grad_planes,
+                                                                view_ws, record, stream))
+            return e;
+        if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);
+        return NVSR_OK;
+    }
     const int64_t ntiles = ((N + MPTS - 1) / MPTS) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
     if (record)

@@ -1,0 +1,321 @@
+// Gate-driven backward of the render pass on the bf16 matrix pipe: render_pass_backward_gates_kernel (render_bwd.hip) with the transposed
+// layers in the exact 3-limb arithmetic of limb_core.h.
+//
+// The reference obtains these gradients from torch.autograd through run_network / TwoDimPlanesModel.forward / grid_sample
+// (train_utils.py:185-282, models.py:381-421).
+//
+// D[in-feature 32-block][point] += W^T[in][out] * G[out][point]: A = limb fragments of W^T (the region behind the f32 blob of
+// nvsr_pack_decoder_bwd, bwd_core.h), B = the gradient of the layer above, split into limbs on the fly.  The C/D layout of one layer is the
+// B layout of the next one below, exactly as in the forward, so the chain runs through registers; the ReLU gate of the layer below is
+// applied to the finished accumulators.  Per tile 6 x 192 + 5 x 96 = 1 632 v_mfma_f32_32x32x16_bf16 instead of 2 176 f32 MFMAs of twice
+// the length.  Skeleton as in decode_limb.hip: a wave owns one 32-point tile of a (ray block, sample) pair, two independent 4-wave
+// workgroups per CU cover each other's splits, masks, transposes and atomics; the weights stream through a ring of two 24-KB slots
+// (2 K-blocks of a hidden layer / 4 of a plane's layer 0), 34 chunks per step.  Scatter into the planes, view-plane rows and the record of
+// the pre-activation gradients are those of the f32 kernel (bwd_core.h).
+#include <type_traits>
+
+#include "limb_core.h"
+#include "bwd_core.h"
+
+namespace nvsr {
+
+constexpr int BL_TPB = 256, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
+constexpr int BL_SMALL = 2 * BL_CHUNK_WORDS;
+constexpr int BL_TILES = BL_SMALL + SMALL_FLOATS;
+constexpr int BL_LDS = BL_TILES + BL_WAVES * TILE_FLOATS;
+static_assert(2 * BL_LDS * 4 <= 160 * 1024, "two workgroups per CU");
+
+// natural blob -> limb fragments of the transposed layers
+__global__ void pack_decoder_bwd_limbs_kernel(const float* __restrict__ nat, unsigned* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BL_WORDS) return;
+    const int w = idx & 3, lane = (idx >> 2) & 63, h = lane >> 5;
+    int f = idx >> 8;                                   // fragment
+    // region: 0 density hidden (3 x 96), 1 density layer 0 (48), 2 rgb hidden (3 x 96), 3 rgb layer 0 (4 x 48)
+    const bool rgb = f >= 3 * 96 + 48;
+    if (rgb) f -= 3 * 96 + 48;
+    const bool hidden = f < 3 * 96;
+    unsigned word = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = 2 * w + half;
+        float v = 0.0f;
+        if (hidden) {
+            const int li = f / 96, r = f % 96;          // li 0 -> layer 3, 1 -> layer 2, 2 -> layer 1
+            const int t_ob = r % 12, kb = r / 12, ob = t_ob / 3;
+            const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);       // output feature = the MFMA's K
+            const int m = 32 * ob + (lane & 31);                                                   // input feature = the row of W^T
+            v = nat[(rgb ? N_RGB_W1 : N_DEN_W1) + (2 - li) * N_HID_STRIDE + k * HID + m];
+        } else {
+            const int g = f - 3 * 96, p = g / 48, r = g % 48;
+            const int kb = r / 6, ob = (r % 6) / 3;
+            const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
+            const int c = 32 * ob + (lane & 31);
+            if (c < C) v = rgb ? nat[N_RGB_W0 + k * (4 * C) + C * p + c] : nat[N_DEN_W0 + k * C + c];
+        }
+        const int t = hidden ? (f % 96) % 3 : ((f - 3 * 96) % 48) % 3;
+        unsigned bits = 0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (l == t) bits = __float_as_uint(v) >> 16;
+            v = limb_rest(v);
+        }
+        word |= bits << (16 * half);
+    }
+    out[idx] = word;
+}
+
+struct RingB {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned* lds;
+    int slot;
+    int wave, lane;
+    unsigned voff;
+};
+__device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
+    // The chunk's byte offset and the slot go through an opaque asm: as compile-time constants of a call site they are loop-invariant,
+    // hipcc hoists the 204 scalar offsets / LDS addresses of a step out of the tile loop and spills them (one scratch reload per DMA).
+    int base = chunk * (BL_CHUNK_WORDS * 4), slot = rs.slot;
+    asm volatile("" : "+s"(base), "+s"(slot));
+    unsigned* dst = rs.lds + slot * BL_CHUNK_WORDS;
+#pragma unroll
+    for (int i = 0; i < 24 / BL_WAVES; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * BL_WAVES + rs.wave) * 256), 16,
+                                                 (int)rs.voff, base + i * (BL_WAVES * 1024), 0, 0);
+    rs.slot = slot ^ 1;
+    return dst;
+}
+__device__ __forceinline__ void ringb_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// acc2[ob] += W0^T fragments [K-block 4][channel block 2][limb 3] x limbs of src(kb, 0..7): 4 x 2 x 6 MFMAs
+template <class Src>
+__device__ __forceinline__ void limb_mm2(const unsigned* wl, int lane, f32x16 (&acc2)[2], Src src) {
+    const u32x4* wv = reinterpret_cast<const u32x4*>(wl) + lane;
+    Limbs<3> cur, fa;
+    split_all<3>([&](int i) { return src(0, i); }, cur);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) fa.v[t] = wv[t * 64];
+    SplitPend sp;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        Limbs<3> nxt;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            Limbs<3> fn;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const int q = kb * 2 + ob;
+                acc2[ob] = mfma_bf16(fa.v[limb_w(3, p)], cur.v[limb_x(3, p)], acc2[ob]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < 3) fn.v[p] = wv[(((q + 1) % 8) * 3 + p) * 64];
+                if (kb + 1 < 4) {
+                    split_slice<3>(2 * (ob * 6 + p), [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                    split_slice<3>(2 * (ob * 6 + p) + 1, [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fa.v[t] = fn.v[t];
+        }
+        if (kb + 1 < 4) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) cur.v[t] = nxt.v[t];
+        }
+    }
+}
+
+template <bool RECORD>
+__global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_kernel(SceneDev sc, const float* __restrict__ packed,
+                                                                                   const float* __restrict__ packed_bwd, long N, int S,
+                                                                                   const float* __restrict__ rays, const float* __restrict__ z,
+                                                                                   const float* __restrict__ g_raw,
+                                                                                   const unsigned* __restrict__ gates, GradPlanes gp,
+                                                                                   float* __restrict__ gview, DecRecord rec) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[BL_LDS];
+    RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL), 0, BL_WORDS * 4, 0x00020000), lds, 0,
+             (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    float* ldsf = reinterpret_cast<float*>(lds);
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += BL_TPB) ldsf[BL_SMALL + i] = packed[P_SMALL + i];   // head weights of the FORWARD blob
+    const float* small = ldsf + BL_SMALL;
+    float* tile = ldsf + BL_TILES + rs.wave * TILE_FLOATS;
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(64);
+    const long nrb = (N + BL_PTS - 1) / BL_PTS;
+    const long ntiles = nrb * S;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
+    auto none = [](int) {};
+
+    for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+        const int lane = rs.lane, h = lane >> 5;
+        const long rb = tix / S;
+        const int s = (int)(tix - rb * S);
+        const long ray0 = rb * BL_PTS + rs.wave * 32 + (lane & 31);
+        const bool valid = ray0 < N;
+        const long ray = valid ? ray0 : N - 1;
+        const unsigned* cw = ringb_issue(rs, 0);
+        const float* r = rays + ray * 11;
+        const float zc = z[ray * S + s];
+        f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const long q = (long)s * N + ray;                             // record row (the forward wrote X / H of the same row)
+        const bool rok = RECORD && valid;
+        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
+        // Everything below is re-read where it is used instead of being kept across the step (two accumulator sets, gD and the limbs
+        // already fill the 256 registers of a wave at two waves per SIMD): a layer's two gate words (slot 0..3 density, 4..7 rgb) ...
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_* gk = reinterpret_cast<const u32x2_*>(gates + ((ray * S + s) * 2 + h) * 16);
+        auto gate = [&](int slot) { const u32x2_ v = gk[slot]; return Masks{{v[0], v[1]}}; };
+        // ... and the taps of a plane, from the ray
+        auto pos_taps = [&](int d) {
+            const float n0 = norm_coord(__fadd_rn(r[0], __fmul_rn(r[3], zc)), sc.lo[0], sc.range[0]);
+            const float n1 = norm_coord(__fadd_rn(r[1], __fmul_rn(r[4], zc)), sc.lo[1], sc.range[1]);
+            const float n2 = norm_coord(__fadd_rn(r[2], __fmul_rn(r[5], zc)), sc.lo[2], sc.range[2]);
+            const float* M = sc.proj + 6 * d;
+            return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        };
+        f32x16 accA[4], accB[4];
+        Limbs<3> cur, fa;
+        // one chunk of a hidden^T layer (2 K-blocks): wait, start the next copy, split the first K-block of G, multiply
+#define BL_FENCE(ACC)                                                                                   \
+        asm volatile("" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]) : : "memory");         \
+        __builtin_amdgcn_sched_barrier(0);
+#define BL_HBLOCK(ZERO, G, KB0, GN, NEXT_CHUNK)                                                         \
+        {                                                                                               \
+            ringb_sync();                                                                               \
+            const unsigned* nw = ringb_issue(rs, NEXT_CHUNK);                                           \
+            { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); }              \
+            limb_block<3, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, NoTail{});           \
+            cw = nw;                                                                                    \
+            BL_FENCE(GN)                                                                                \
+        }
+        // gn = mask .* (W^T g): chunks C0 .. C0 + 3
+#define BL_HIDDEN_T(G, MK, GN, C0)                                                                      \
+        BL_HBLOCK(true, G, 0, GN, (C0) + 1)                                                             \
+        BL_HBLOCK(false, G, 2, GN, (C0) + 2)                                                            \
+        BL_HBLOCK(false, G, 4, GN, (C0) + 3)                                                            \
+        BL_HBLOCK(false, G, 6, GN, (C0) + 4)                                                            \
+        apply_mask(gate(MK), GN);
+        // acc2 += W0^T g: chunks C0, C0 + 1; LAST: no chunk follows in this step
+#define BL_LAYER0_T(G, ACC2, C0, LAST)                                                                  \
+        {                                                                                               \
+            ringb_sync();                                                                               \
+            const unsigned* nw = ringb_issue(rs, (C0) + 1);                                             \
+            limb_mm2(cw, lane, ACC2, hid(G, 0));                                                        \
+            cw = nw;                                                                                    \
+            asm volatile("" : "+v"(ACC2[0]), "+v"(ACC2[1]) : : "memory");                               \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            ringb_sync();                                                                               \
+            if (!(LAST)) nw = ringb_issue(rs, (C0) + 2);                                                \
+            limb_mm2(cw, lane, ACC2, hid(G, 4));                                                        \
+            cw = nw;                                                                                    \
+            asm volatile("" : "+v"(ACC2[0]), "+v"(ACC2[1]) : : "memory");                               \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+        }
+        // ---- density branch -> gD
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(small + S_ALPHA_W + (ib * 4 + qq) * 8 + h * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = wv[j] * graw[3];
+            }
+        apply_mask(gate(3), accA);
+        if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
+        BL_HIDDEN_T(accA, 2, accB, 0)
+        if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
+        BL_HIDDEN_T(accB, 1, accA, 4)
+        if (rok) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
+        BL_HIDDEN_T(accA, 0, accB, 8)
+        if (rok) record128(rec.Gd, q, h, accB);
+        f32x16 gD[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = 0.0f;
+        BL_LAYER0_T(accB, gD, 12, false)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);
+        // ---- rgb branch
+        asm volatile("" ::: "memory");
+        graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+        if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o = (ib * 4 + qq) * 8 + h * 4;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + o);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + HID + o);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(small + S_RGB_W + 2 * HID + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
+            }
+        apply_mask(gate(7), accA);
+        if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
+        BL_HIDDEN_T(accA, 6, accB, 14)
+        if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
+        BL_HIDDEN_T(accB, 5, accA, 18)
+        if (rok) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
+        BL_HIDDEN_T(accA, 4, accB, 22)
+        if (rok) record128(rec.Gr, q, h, accB);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f32x16 gF[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? gD[b][rr] : 0.0f;
+            BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
+            if (gp.p[d]) {
+                if (d == 3 && gview) {
+                    store_view_rows(gF, tile, gview, rb * BL_PTS + rs.wave * 32, N, S, s, lane);
+                } else {
+                    const Taps t = (d < 3) ? pos_taps(d) : view_taps(sc, r[8], r[9], r[10]);
+                    scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+                }
+            }
+        }
+#undef BL_LAYER0_T
+#undef BL_HIDDEN_T
+#undef BL_HBLOCK
+#undef BL_FENCE
+    }
+    ringb_sync();
+}
+
+}  // namespace nvsr
+
+using namespace nvsr;
+
+extern "C" int nvsr_pack_decoder_bwd_limbs_launch(const float* natural, float* packed_bwd, nvsr_stream_t stream) {
+    hipLaunchKernelGGL(pack_decoder_bwd_limbs_kernel, dim3((BL_WORDS + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural,
+                       reinterpret_cast<unsigned*>(packed_bwd) + B_TOTAL);
+    return NVSR_CHECK_LAUNCH();
+}
+
+// nvsr_render_pass_backward_gates (render_bwd.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
+extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
+                                                           int64_t N, int S, const float* rays, const float* z, const float* g_raw,
+                                                           const uint32_t* gates, float* const* grad_planes, float* view_ws, float* record,
+                                                           nvsr_stream_t stream) {
+    GradPlanes gp;
+    for (int d = 0; d < 4; ++d) gp.p[d] = grad_planes ? grad_planes[d] : nullptr;
+    const int64_t ntiles = ((N + BL_PTS - 1) / BL_PTS) * S;
+    const int64_t grid = ntiles < 2048 ? ntiles : 2048;
+    if (record)
+        hipLaunchKernelGGL(render_pass_backward_gates_limb_kernel<true>, dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));
+    else
+        hipLaunchKernelGGL(render_pass_backward_gates_limb_kernel<false>, dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, DecRecord{});
+    return NVSR_CHECK_LAUNCH();
+}
