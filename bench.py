@@ -260,7 +260,8 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     label = "planes + decoder gradients" if "decoder" in what else "plane gradients (Feature_Planes_Only.yml: what = ['LR_planes'])"
     result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, %s, Adam)" % label, "value": value,
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": ARITHMETIC["bf16x3" if capi.get_decoder_arithmetic() != "f32" else "f32"]["dtype"], "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
                          "parallelism": "rays sharded by rank; one bucketed all-reduce of the %s per step"
@@ -288,10 +289,15 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         dt = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
         flops = FLOP_PER_EVAL * N * S              # the transposed layers move exactly the forward's 129 536 MAC per point
         ach = flops / dt / 1e12
-        result["roofline"] = {"kernel": "render_pass_backward_gates_kernel<%s> (fine pass, S=128; incl. its view-plane reduce)"
-                                        % ("record" if sv.get("rec_f") is not None else "no record"), "bound": "mfma",
-                              "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                              "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops}
+        limb = capi.get_decoder_arithmetic() != "f32"        # the training kernels always use 3 limbs when the bf16 pipe is selected
+        peak = PEAK_BF16_MFMA_TFLOPS / 6 if limb else PEAK_F32_MFMA_TFLOPS
+        result["roofline"] = {"kernel": "render_pass_backward_gates_%skernel<%s> (fine pass, S=128; incl. its view-plane reduce)"
+                                        % ("limb_" if limb else "", "record" if sv.get("rec_f") is not None else "no record"), "bound": "mfma",
+                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                              "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,
+                              "peak_note": ("algorithmic f32 FLOP; peak = %.1f TFLOP/s dense bf16 / 6 MFMA products per f32 product" % PEAK_BF16_MFMA_TFLOPS)
+                                           if limb else "v_mfma_f32_32x32x2_f32 dense peak",
+                              "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle, decoder_blob
             o = Oracle(f32=False)
