@@ -1703,3 +1703,76 @@ def test_loaded_scenes_feed_the_render_path(hip, tmp_path):
     ndc_cfg = dict(no_ndc=False, near=0.0, far=1.0)
     out = hip.train_utils.eval_nerf(int(h), int(w), f, mc, mf, ro, rd, opts, scene_id=sid, scene_config=ndc_cfg)
     assert out[3].shape == images[i_test].shape and torch.isfinite(out[0]).all()
+
+
+def test_training_kernels_limb_vs_f32(hip):
+    """The training forward (raw, ReLU gates, layer-input record) and the gate-driven backward (plane gradients, view rows, gradient record)
+    in the default 3-limb arithmetic against the exact-f32 kernels on the same inputs, through the C ABI: ragged ray counts (a partial last
+    workgroup, a single ray), 1 / 3 / 37 samples.  Stated tolerances: raw and every record row within 1e-5 of the output range; gates equal
+    except where a pre-activation lies within that noise of zero (< 0.1 % of the bits); plane gradients 2e-5 relative L2 (float atomics
+    reorder sums); the forward is bit-identical launch to launch (its weight ring has no race)."""
+    import ctypes as C
+    g = load_golden("g08_render.npz")
+    capi = hip.capi
+    rng = np.random.default_rng(41)
+    planes = [rng.standard_normal((1, 48, 40, 56), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, 8, 12), dtype=np.float32) * 0.5]
+    m, _ = build_model(hip, sd(g, "fine."), planes, g["box"])
+    H, W = 40, 50
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    all_rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    sc, keep = m.native_scene()
+    lib = capi.lib()
+    for N, S in ((1, 1), (131, 3), (1000, 37)):
+        rays = all_rays[:N].contiguous()
+        z = T(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1))
+        g_raw = T((rng.standard_normal((N, S, 4)) * 1e-2).astype(np.float32))
+        nrec = lib.nvsr_decoder_record_floats(N, S)
+        res = {}
+        try:
+            for mode in ("f32", "bf16x3", "bf16x3"):
+                capi.set_decoder_arithmetic(mode)
+                raw = torch.full((N, S, 4), -7.0, device=DEV)
+                gates = torch.zeros(N * S * 32, dtype=torch.int32, device=DEV)
+                rec = torch.full((nrec,), float("nan"), device=DEV)
+                capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(m.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw),
+                          capi.ptr(gates), capi.ptr(rec), capi.stream())
+                fwd_rec = rec.clone()
+                gpl = [torch.zeros_like(k) for k in keep]
+                gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
+                vws = torch.zeros(lib.nvsr_view_grad_workspace_floats(N, S), device=DEV)
+                capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(m.packed_decoder()), capi.ptr(m.packed_decoder_bwd()), N, S,
+                          capi.ptr(rays), capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(vws), capi.ptr(rec), capi.stream())
+                torch.cuda.synchronize()
+                cur = dict(raw=N_(raw), gates=N_(gates), fwd_rec=N_(fwd_rec), rec=N_(rec), gpl=[N_(t).astype(np.float64) for t in gpl])
+                if mode in res:         # second launch in the same arithmetic
+                    assert np.array_equal(cur["raw"], res[mode]["raw"]) and np.array_equal(cur["gates"], res[mode]["gates"])
+                    assert np.array_equal(cur["fwd_rec"], res[mode]["fwd_rec"], equal_nan=True)
+                res[mode] = cur
+        finally:
+            capi.set_decoder_arithmetic(DEFAULT_ARITHMETIC)
+        a, b = res["f32"], res["bf16x3"]
+        assert not (b["raw"] == -7.0).any()
+        scale = max(1.0, np.abs(a["raw"]).max())
+        assert np.abs(a["raw"].astype(np.float64) - b["raw"]).max() <= 1e-5 * scale, (N, S)
+        flips = np.unpackbits((a["gates"] ^ b["gates"]).view(np.uint8)).sum()
+        assert flips <= 1e-3 * N * S * 8 * 128 + 2, (N, S, flips)
+        # record: rows < P of every array (the allocation padding is never written: still NaN in both)
+        P, Pp = N * S, (N * S + 7) // 8 * 8
+        assert np.array_equal(np.isnan(a["rec"]), np.isnan(b["rec"]))
+        o = 0
+        for cols, k in ((64, 1), (128, 4), (128, 4), (192, 1), (128, 4), (128, 4), (4, 1)):
+            for name in ("fwd_rec", "rec"):
+                x, y = (res[mm][name][o:o + k * cols * Pp].reshape(k, Pp, cols)[:, :P].astype(np.float64) for mm in ("f32", "bf16x3"))
+                if np.isnan(x).all():
+                    continue                     # the gradient half before the backward has run
+                if flips == 0:
+                    rng_ = max(1e-3, np.abs(x).max())
+                    assert np.abs(x - y).max() <= 1e-5 * rng_ + 1e-9, (N, S, name, cols)
+                else:                            # a flipped gate zeroes / releases whole gradient rows: compare in the L2 sense
+                    assert np.linalg.norm(x - y) <= 2e-3 * np.linalg.norm(x) + 1e-9, (N, S, name, cols)
+            o += k * cols * Pp
+        for d in range(4):
+            na = np.linalg.norm(a["gpl"][d])
+            assert np.linalg.norm(a["gpl"][d] - b["gpl"][d]) <= (2e-5 if flips == 0 else 2e-3) * na + 1e-12, (N, S, d)
