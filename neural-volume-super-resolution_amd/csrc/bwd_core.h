@@ -52,15 +52,25 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
     __builtin_amdgcn_wave_barrier();
     // taps of an invalid (padding) ray carry zero weight
     const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    // Point p's four texel offsets and weights are wave-uniform once read out of lane p: v_readlane into SGPRs, so that an atomic's
+    // address is (scalar texel base) + lane and its operand one v_mul by a scalar.  (With __shfl these were 8 ds_bpermute per point --
+    // 256 LDS round trips per plane -- plus 64-bit vector address arithmetic in front of every atomic.)
+#pragma unroll 8
     for (int p = 0; p < 32; ++p) {
-        const int o0 = __shfl(t.o00, p), o1 = __shfl(t.o01, p), o2 = __shfl(t.o10, p), o3 = __shfl(t.o11, p);
-        const float a0 = __shfl(w0, p), a1 = __shfl(w1, p), a2 = __shfl(w2, p), a3 = __shfl(w3, p);
+        float* const b0 = gplane + __builtin_amdgcn_readlane(t.o00, p);
+        float* const b1 = gplane + __builtin_amdgcn_readlane(t.o01, p);
+        float* const b2 = gplane + __builtin_amdgcn_readlane(t.o10, p);
+        float* const b3 = gplane + __builtin_amdgcn_readlane(t.o11, p);
+        const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), p));
+        const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), p));
+        const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w2), p));
+        const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), p));
         if (lane < C) {
             const float v = tile[p * C + lane];
-            unsafeAtomicAdd(gplane + o0 + lane, v * a0);
-            unsafeAtomicAdd(gplane + o1 + lane, v * a1);
-            unsafeAtomicAdd(gplane + o2 + lane, v * a2);
-            unsafeAtomicAdd(gplane + o3 + lane, v * a3);
+            unsafeAtomicAdd(b0 + lane, v * a0);
+            unsafeAtomicAdd(b1 + lane, v * a1);
+            unsafeAtomicAdd(b2 + lane, v * a2);
+            unsafeAtomicAdd(b3 + lane, v * a3);
         }
     }
     __builtin_amdgcn_wave_barrier();

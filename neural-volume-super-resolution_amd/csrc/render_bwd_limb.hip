@@ -14,6 +14,10 @@
 // the pre-activation gradients are those of the f32 kernel (bwd_core.h).
 #include <type_traits>
 
+#ifndef BL_ABLATE
+#define BL_ABLATE 0   // timing experiments only (wrong results): 1 no wait for the weight copies, 2 no gate masks, 4 no plane scatter / view rows,
+#endif                // 8 no splits outside the MFMA gaps (first K-block of a chunk)      (tools/bwd_limb_ablate.sh)
+
 #include "limb_core.h"
 #include "bwd_core.h"
 
@@ -86,7 +90,9 @@ __device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
     return dst;
 }
 __device__ __forceinline__ void ringb_sync() {
+#if !(BL_ABLATE & 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
         {                                                                                               \
             ringb_sync();                                                                               \
             const unsigned* nw = ringb_issue(rs, NEXT_CHUNK);                                           \
-            { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); }              \
+            if (!(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); } \
             limb_block<3, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, NoTail{});           \
             cw = nw;                                                                                    \
             BL_FENCE(GN)                                                                                \
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
         BL_HBLOCK(false, G, 2, GN, (C0) + 2)                                                            \
         BL_HBLOCK(false, G, 4, GN, (C0) + 3)                                                            \
         BL_HBLOCK(false, G, 6, GN, (C0) + 4)                                                            \
-        apply_mask(gate(MK), GN);
+        if (!(BL_ABLATE & 2)) apply_mask(gate(MK), GN);
         // acc2 += W0^T g: chunks C0, C0 + 1; LAST: no chunk follows in this step
 #define BL_LAYER0_T(G, ACC2, C0, LAST)                                                                  \
         {                                                                                               \
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? gD[b][rr] : 0.0f;
             BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
-            if (gp.p[d]) {
+            if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {
                     store_view_rows(gF, tile, gview, rb * BL_PTS + rs.wave * 32, N, S, s, lane);
                 } else {
