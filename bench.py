@@ -129,6 +129,17 @@ def time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine, reps=3):
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+def pmc_traffic(workload, dtype):
+    """HBM bytes of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_latest.json,
+    FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes) -- counters cannot be read from inside this process.  None when the passes were
+    taken with another arithmetic."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    e = json.load(open(path)).get(workload)
+    return e["traffic_bytes"] if e and e.get("arithmetic") == dtype else None
+
+
 def hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws, reps=5):
     """The bandwidth-bound helper kernels of the frame (ray generation, ray packing, coarse depths, importance resampling), each timed
     alone with events on the launch stream: algorithmic bytes (inputs read once + outputs written once) / duration against the HBM peak."""
@@ -293,7 +304,8 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if limb else PEAK_F32_MFMA_TFLOPS
         result["roofline"] = {"kernel": "render_pass_backward_gates_%skernel<%s> (fine pass, S=128; incl. its view-plane reduce)"
                                         % ("limb_" if limb else "", "record" if sv.get("rec_f") is not None else "no record"), "bound": "mfma",
-                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                              "traffic": pmc_traffic("train_dec" if "decoder" in what else "train", result["dtype"]),
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,
                               "peak_note": ("algorithmic f32 FLOP; peak = %.1f TFLOP/s dense bf16 / 6 MFMA products per f32 product" % PEAK_BF16_MFMA_TFLOPS)
                                            if limb else "v_mfma_f32_32x32x2_f32 dense peak",
@@ -351,7 +363,8 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
         peak = arith["pipe_peak"] / arith["products"]
         kname = "conv3x3_kernel" if mode == "f32" else "conv3x3_limb_kernel"
         result["roofline"] = {"kernel": "%s (70 launches per step)" % kname, "bound": "mfma", "achieved": ach, "peak": peak,
-                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "algorithmic_flop_per_step": flop_scene,
+                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic("sr", arith["dtype"]), "algorithmic_flop_per_step": flop_scene,
+                              "algorithmic_bytes_per_step": 3 * (173e6 + 2 * 4 * 256 * 270 * 270 * 66),     # weights once per plane + activations in / out of the 66 wide layers (approx.)
                               "peak_note": "algorithmic f32 FLOP over the whole step; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
                                            % (arith["pipe_peak"], arith["products"]),
                               "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}

@@ -257,12 +257,18 @@ __global__ __launch_bounds__(WG_TPB, 1) void decoder_wgrad_limb_kernel(WJobs job
     wgrad_limb_block<NB>(jobs.j[job0 + blockIdx.y], P, slab, tile, grad);
 }
 
-// fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k]   (thread = feature f of one branch)
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
-                                                         const float* __restrict__ g4, long Pp, int slab, float* __restrict__ grad) {
-    const int f = threadIdx.x & 127, rgb = threadIdx.x >> 7;
+// fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k].  Thread = feature f of one branch for one of the
+// workgroup's 4 row groups; the groups are summed through LDS, so a workgroup of 1024 threads adds its 516 partial sums once per 4 x slab
+// rows (every workgroup adds into the same 516 addresses: with one 256-thread workgroup per slab the adds of 4 096 workgroups queued up
+// on them).
+constexpr int HW_GROUPS = 4;
+__global__ __launch_bounds__(256 * HW_GROUPS) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
+                                                                     const float* __restrict__ g4, long Pp, int slab, float* __restrict__ grad) {
+    __shared__ float part[HW_GROUPS][256][3];
+    __shared__ float bsum[HW_GROUPS][2][3];
+    const int f = threadIdx.x & 127, rgb = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;
     const float* H = rgb ? Hr3 : Hd3;
-    const long q0 = (long)blockIdx.x * slab;
+    const long q0 = ((long)blockIdx.x * HW_GROUPS + grp) * slab;
     const long q1 = (q0 + slab < Pp) ? q0 + slab : Pp;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll 8
@@ -276,6 +282,15 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
             a0 = fmaf(g[3], hv, a0);
             s0 += g[3];
         }
+    }
+    part[grp][threadIdx.x & 255][0] = a0; part[grp][threadIdx.x & 255][1] = a1; part[grp][threadIdx.x & 255][2] = a2;
+    if (f == 0) { bsum[grp][rgb][0] = s0; bsum[grp][rgb][1] = s1; bsum[grp][rgb][2] = s2; }
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int g_ = 1; g_ < HW_GROUPS; ++g_) {
+        a0 += part[g_][threadIdx.x][0]; a1 += part[g_][threadIdx.x][1]; a2 += part[g_][threadIdx.x][2];
+        if (f == 0) { s0 += bsum[g_][rgb][0]; s1 += bsum[g_][rgb][1]; s2 += bsum[g_][rgb][2]; }
     }
     if (rgb) {
         unsafeAtomicAdd(grad + N_FCRGB_W + f, a0);
@@ -347,8 +362,8 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
         const unsigned nslabs = (unsigned)((P + slab - 1) / slab);
         hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, P, (int)slab, grad_natural);
     }
-    const int hslab = 128;        // 4096 workgroups at 524k slots: the loop is one dependent load stream per thread
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + hslab - 1) / hslab)), dim3(256), 0, (hipStream_t)stream,
-                       rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, P, hslab, grad_natural);
+    const int hslab = 128;        // rows per thread: 1 024 workgroups of 4 row groups at 524k rows
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + HW_GROUPS * hslab - 1) / (HW_GROUPS * hslab))), dim3(256 * HW_GROUPS), 0,
+                       (hipStream_t)stream, rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, P, hslab, grad_natural);
     return NVSR_CHECK_LAUNCH();
 }

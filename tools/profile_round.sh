@@ -14,6 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_dec -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sr -- python3 $R/bench.py --workload sr --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_train_$c -- python3 $R/bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_train_dec_$c -- python3 $R/bench.py --workload train --train-what planes+decoder --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_sr_$c -- python3 $R/bench.py --workload sr --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
 done
 # keep the merged-back payload small: drop the per-dispatch traces of the stats runs (the *_kernel_stats.csv summaries stay)
 find $O/stats_* -name "*kernel_trace.csv" -delete
