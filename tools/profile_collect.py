@@ -27,7 +27,7 @@ def counters(prefix, pick):
     """{counter: (value_kb, kernel_ms)} of the dispatch(es) `pick` selects: pick(rows of one counter) -> (value, ms)"""
     pm = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        for f in glob.glob(os.path.join(src, "%s%s" % (prefix, c), "*", "*counter_collection.csv")):
+        for f in sorted(glob.glob(os.path.join(src, "%s%s" % (prefix, c), "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:   # newest pass only
             rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
             got = pick(rows)
             if got:
