@@ -129,6 +129,11 @@ int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const flo
                    float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream);
 
 /* same with the ray directions taken from packed rays [N,11] (columns 3..5) */
+/* volume_render_radiance_field(..., mip_nerf=True) (volume_rendering_utils.py:19-26,41-42): raw [N,S,4] over the S intervals of the
+ * edges z [N,S+1] -- every interval finite (no 1e10 tail), depth_map integrates the interval mid-points */
+int nvsr_composite_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                       float* rgb, float* disp, float* acc, float* weights /* [N,S] or NULL */, float* depth /* or NULL */,
+                       nvsr_stream_t stream);
 int nvsr_composite_rays(int64_t N, int S, const float* raw, const float* z, const float* rays, const float* noise, int white_bkgd,
                         float* rgb, float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream);
 
@@ -211,6 +216,9 @@ int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t
 /* backward of volume_render_radiance_field (volume_rendering_utils.py:18-49): g_rgb [N,3], g_acc [N] or NULL -> g_raw [N,S,4]; S <= 512 */
 int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                             const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);
+/* the same for nvsr_composite_mip (z [N,S+1]) */
+int nvsr_composite_backward_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                                const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);
 /* backward of one decode pass: g_raw [N,S,4] -> grad_planes[4] (host array of 4 device pointers, CHANNEL-LAST like the scene's
  * planes, accumulated with float atomics: zero them first) */
 int nvsr_render_pass_backward(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,

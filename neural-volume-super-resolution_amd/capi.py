@@ -55,6 +55,7 @@ _PROTOS = {
     "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
     "nvsr_composite": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_rays": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_composite_mip": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_decode_rays": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_workspace_floats": ([_i64, _i, _i], _i64),
@@ -79,6 +80,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_render_pass_ex": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_pack_decoder_bwd": ([_vp, _vp, _vp], _i),
     "nvsr_composite_backward": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
+    "nvsr_composite_backward_mip": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass_backward": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp], _i),
     "nvsr_decode_rays_ex": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass_backward_gates": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp], _i),

@@ -291,13 +291,15 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
 __global__ __launch_bounds__(WPB * 64) void composite_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
                                                             const float* __restrict__ rd, int rd_stride, const float* __restrict__ noise, int white,
                                                             float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc,
-                                                            float* __restrict__ weights, float* __restrict__ depth) {
+                                                            float* __restrict__ weights, float* __restrict__ depth, int mip) {
+    // mip (volume_rendering_utils.py:19-26,41-42, the Mip-NeRF baseline's intervals): z holds S + 1 interval edges per ray, every sample has
+    // its own finite interval (no 1e10 tail) and the depth map integrates the interval mid-points
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * WPB + wave;
     if (ray >= N) return;
     const float d0 = rd[ray * rd_stride], d1 = rd[ray * rd_stride + 1], d2 = rd[ray * rd_stride + 2];
     const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
-    const float* zr = z + ray * S;
+    const float* zr = z + ray * (S + (mip ? 1 : 0));
     const f32x4* rr = reinterpret_cast<const f32x4*>(raw) + ray * S;
     float Tcarry = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, dep = 0.0f, ac = 0.0f;
     for (int base = 0; base < S; base += 64) {
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(WPB * 64) void composite_kernel(long N, int S, cons
         if (in) {
             zs = zr[s];
             rv = rr[s];
-            const float dist = __fmul_rn((s + 1 < S) ? __fsub_rn(zr[s + 1], zs) : 1e10f, nrm);
+            const float dist = __fmul_rn((mip || s + 1 < S) ? __fsub_rn(zr[s + 1], zs) : 1e10f, nrm);
+            if (mip) zs = __fmul_rn(0.5f, __fadd_rn(zs, zr[s + 1]));
             float sig = rv[3];
             if (noise) sig = __fadd_rn(sig, noise[ray * S + s]);
             sig = fmaxf(sig, 0.0f);
@@ -455,7 +458,19 @@ int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const flo
     if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rd, 3, noise,
-                       white_bkgd, rgb, disp, acc, weights, depth);
+                       white_bkgd, rgb, disp, acc, weights, depth, 0);
+    return NVSR_CHECK_LAUNCH();
+}
+
+/* mip_nerf=True: raw [N,S,4] over the S intervals of z [N,S+1] */
+int nvsr_composite_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd, float* rgb,
+                       float* disp, float* acc, float* weights, float* depth, nvsr_stream_t stream) {
+    if (!raw || !z || !rd || !rgb || !disp || !acc) return NVSR_ERR_NULL;
+    if (!aligned16(raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rd, 3, noise,
+                       white_bkgd, rgb, disp, acc, weights, depth, 1);
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -467,7 +482,7 @@ int nvsr_composite_rays(int64_t N, int S, const float* raw, const float* z, cons
     if (N < 0 || S < 1) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, S, raw, z, rays + 3, 11,
-                       noise, white_bkgd, rgb, disp, acc, weights, depth);
+                       noise, white_bkgd, rgb, disp, acc, weights, depth, 0);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -469,8 +469,9 @@ constexpr int CB_WPB = 4;
 __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
                                                                         const float* __restrict__ rd, const float* __restrict__ noise, int white,
                                                                         const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
-                                                                        float* __restrict__ g_raw) {
+                                                                        float* __restrict__ g_raw, int mip) {
     __shared__ float sT[CB_WPB][512], sA[CB_WPB][512], sG[CB_WPB][512];   // T_s, alpha_s, dL/dw_s
+    const int zp = S + (mip ? 1 : 0);                                      // mip: z holds S + 1 interval edges, no 1e10 tail
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * CB_WPB + wave;
     if (ray >= N) return;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
         float fac = 1.0f, alpha = 0.0f, gw = 0.0f;
         if (s < S) {
             const f32x4 rv = rr[s];
-            const float dist = ((s + 1 < S) ? (z[ray * S + s + 1] - z[ray * S + s]) : 1e10f) * nrm;
+            const float dist = ((mip || s + 1 < S) ? (z[ray * zp + s + 1] - z[ray * zp + s]) : 1e10f) * nrm;
             const float sig = fmaxf(rv[3] + (noise ? noise[ray * S + s] : 0.0f), 0.0f);
             alpha = 1.0f - expf(-sig * dist);
             fac = (1.0f - alpha) + 1e-10f;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
         scarry += __shfl(suf, 0);
         if (s < S) {
             const float g_alpha = T * gw - suffix / ((1.0f - alpha) + 1e-10f);
-            const float dist = ((s + 1 < S) ? (z[ray * S + s + 1] - z[ray * S + s]) : 1e10f) * nrm;
+            const float dist = ((mip || s + 1 < S) ? (z[ray * zp + s + 1] - z[ray * zp + s]) : 1e10f) * nrm;
             const float pre_sig = rv[3] + (noise ? noise[ray * S + s] : 0.0f);
             f32x4 o;
 #pragma unroll
@@ -565,7 +566,18 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
     if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
-                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw);
+                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw, 0);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_composite_backward_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                                const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream) {
+    if (!raw || !z || !rd || !g_rgb || !g_raw) return NVSR_ERR_NULL;
+    if (!aligned16(raw) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
+    if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
+                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw, 1);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -294,6 +294,37 @@ ORC_EXPORT void orc_composite(long N, int S, const float* raw, const float* z, c
                           white, rgb + 3 * i, disp + i, acc + i, weights ? weights + (size_t)i * S : NULL, depth + i);
 }
 
+/* mip_nerf=True branch (volume_rendering_utils.py:19-26,41-42): z [S+1] interval edges, no 1e10 tail, depth over the interval mid-points */
+ORC_EXPORT void orc_composite_mip(long N, int S, const float* raw, const float* z, const float* rd, const float* noise,
+                                  int white, float* rgb, float* disp, float* acc, float* weights, float* depth) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) {
+        const float* rw = raw + (size_t)i * S * 4;
+        const float* zz = z + (size_t)i * (S + 1);
+        const float* d3 = rd + 3 * i;
+        const float nrm = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+        float T = 1.0f, r = 0, g = 0, b = 0, dep = 0, ac = 0;
+        for (int s = 0; s < S; ++s) {
+            const float dist = (zz[s + 1] - zz[s]) * nrm;
+            float sig = rw[4 * s + 3] + (noise ? noise[(size_t)i * S + s] : 0.0f);
+            sig = sig > 0.0f ? sig : 0.0f;
+            const float alpha = 1.0f - expf(-sig * dist);
+            const float w = alpha * T;
+            T = T * (1.0f - alpha + 1e-10f);
+            if (weights) weights[(size_t)i * S + s] = w;
+            r += w * (1.0f / (1.0f + expf(-rw[4 * s + 0])));
+            g += w * (1.0f / (1.0f + expf(-rw[4 * s + 1])));
+            b += w * (1.0f / (1.0f + expf(-rw[4 * s + 2])));
+            dep += w * (0.5f * (zz[s] + zz[s + 1]));
+            ac += w;
+        }
+        { const float q = dep / ac; disp[i] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q)); }
+        if (white) { r += 1.0f - ac; g += 1.0f - ac; b += 1.0f - ac; }
+        rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b;
+        acc[i] = ac; depth[i] = dep;
+    }
+}
+
 ORC_EXPORT void orc_cumprod_exclusive(long N, int S, const float* in, float* out) {
     for (long i = 0; i < N; ++i) {
         float T = 1.0f;

@@ -15,7 +15,9 @@ _f32p = C.POINTER(C.c_float)
 
 def build(force=False):
     """Compile liborc.so / liborc_f32.so with gcc (oracle/Makefile)."""
-    if force or not all(os.path.exists(os.path.join(HERE, n)) for n in ("liborc.so", "liborc_f32.so")):
+    libs = [os.path.join(HERE, n) for n in ("liborc.so", "liborc_f32.so")]
+    src = os.path.join(HERE, "nvsr_oracle.c")
+    if force or not all(os.path.exists(l) and os.path.getmtime(l) >= os.path.getmtime(src) for l in libs):
         subprocess.check_call(["make", "-s", "-C", HERE] + (["-B"] if force else []))
 
 
@@ -112,15 +114,15 @@ class Oracle:
         return (out, feats, n5) if want_feats else out
 
     # -- compositing / sampling --------------------------------------------------------------
-    def composite(self, raw, z, rd, noise=None, white_background=False):
+    def composite(self, raw, z, rd, noise=None, white_background=False, mip_nerf=False):
         raw, z, rd = _f(raw), _f(z), _f(rd)
-        N, S = z.shape
+        N, S = z.shape[0], z.shape[1] - (1 if mip_nerf else 0)
         noise = None if noise is None else _f(noise)
         rgb = np.empty((N, 3), np.float32)
         disp, acc, depth = (np.empty(N, np.float32) for _ in range(3))
         w = np.empty((N, S), np.float32)
-        self.lib.orc_composite(C.c_long(N), S, _p(raw), _p(z), _p(rd), _p(noise), int(white_background),
-                               _p(rgb), _p(disp), _p(acc), _p(w), _p(depth))
+        fn = self.lib.orc_composite_mip if mip_nerf else self.lib.orc_composite
+        fn(C.c_long(N), S, _p(raw), _p(z), _p(rd), _p(noise), int(white_background), _p(rgb), _p(disp), _p(acc), _p(w), _p(depth))
         return rgb, disp, acc, w, depth
 
     def cumprod_exclusive(self, t):

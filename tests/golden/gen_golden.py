@@ -23,6 +23,7 @@ Fixture index:
   g12_ndc_render.npz  eval_nerf of a forward-facing (LLFF-style) view through NDC rays (train_utils.py:215-218)
   g14_sr_grads.npz    autograd through EDSR / PlanesSR (full plane and ROI): weights, network input and LR plane ('SR' in what)
   g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
+  g16_composite_mip.npz volume_render_radiance_field(mip_nerf=True) + its autograd wrt the radiance field (volume_rendering_utils.py:19-26,41-42)
   g15_loaders.npz     load_blender_data / load_llff_data on two tiny synthetic scenes (load_blender.py:232-332, load_llff.py:70-360).
                       imageio and cv2 are absent here: the harness reads the PNGs with PIL and gives cv2.resize(INTER_AREA) its
                       definition for integer factors (block mean), so the resampling itself is pinned by definition only; the JSON /
@@ -855,9 +856,31 @@ def g15_loaders():
     save("g15_loaders.npz", **arrs)
 
 
+def g16_composite_mip():
+    torch.manual_seed(16)
+    arrs = {}
+    for tag, (N, S, white) in {"a": (37, 24, False), "b": (5, 130, True)}.items():
+        raw = torch.randn(N, S, 4) * 2.0
+        raw[..., 3] = raw[..., 3] * 3.0 - 1.0
+        raw[1, :, 3] = -5.0                                            # an empty ray: acc = 0, disp = NaN
+        z = torch.sort(torch.rand(N, S + 1) * 4.0 + 2.0, -1).values    # S + 1 interval edges
+        rd = torch.randn(N, 3)
+        noise = torch.randn(N, S) * 0.3
+        g_rgb, g_acc = torch.randn(N, 3), torch.randn(N)
+        r = (raw.clone()).requires_grad_(True)
+        # the reference draws its own noise; add it to the density channel instead (same arithmetic: relu(raw + noise))
+        rin = torch.cat([r[..., :3], (r[..., 3] + noise)[..., None]], -1)
+        rgb, disp, acc, w, depth = vru.volume_render_radiance_field(rin, z, rd, radiance_field_noise_std=0.0, white_background=white, mip_nerf=True)
+        ((rgb * g_rgb).sum() + (acc * g_acc).sum()).backward()
+        arrs.update({tag + "_raw": npy(raw), tag + "_z": npy(z), tag + "_rd": npy(rd), tag + "_noise": npy(noise), tag + "_white": np.array(white),
+                     tag + "_rgb": npy(rgb), tag + "_disp": npy(disp), tag + "_acc": npy(acc), tag + "_weights": npy(w), tag + "_depth": npy(depth),
+                     tag + "_g_rgb": npy(g_rgb), tag + "_g_acc": npy(g_acc), tag + "_g_raw": npy(r.grad)})
+    save("g16_composite_mip.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

@@ -1776,3 +1776,26 @@ def test_training_kernels_limb_vs_f32(hip):
         for d in range(4):
             na = np.linalg.norm(a["gpl"][d])
             assert np.linalg.norm(a["gpl"][d] - b["gpl"][d]) <= (2e-5 if flips == 0 else 2e-3) * na + 1e-12, (N, S, d)
+
+
+def test_composite_mip_branch_golden_and_gradient(hip):
+    """volume_render_radiance_field(mip_nerf=True) -- the Mip-NeRF baseline's intervals (volume_rendering_utils.py:19-26,41-42) -- against the
+    reference's outputs and its autograd wrt the radiance field (fixture g16); 130 intervals = three 64-lane chunks per ray"""
+    g = load_golden("g16_composite_mip.npz")
+    for tag in ("a", "b"):
+        raw = T(g[tag + "_raw"]).requires_grad_(True)
+        out = hip.volume_rendering_utils.volume_render_radiance_field(raw, T(g[tag + "_z"]), T(g[tag + "_rd"]), white_background=bool(g[tag + "_white"]),
+                                                                      mip_nerf=True, noise=T(g[tag + "_noise"]))
+        rgb, disp, acc, w, depth = out
+        np.testing.assert_allclose(N_(rgb), g[tag + "_rgb"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(N_(acc), g[tag + "_acc"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(N_(w), g[tag + "_weights"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(N_(depth), g[tag + "_depth"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(N_(disp), g[tag + "_disp"], rtol=1e-5, atol=0, equal_nan=True)
+        ((rgb * T(g[tag + "_g_rgb"])).sum() + (acc * T(g[tag + "_g_acc"])).sum()).backward()
+        ref = g[tag + "_g_raw"]
+        assert np.abs(N_(raw.grad) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        with torch.no_grad():        # the no-graph path takes the same kernel
+            out2 = hip.volume_rendering_utils.volume_render_radiance_field(raw.detach(), T(g[tag + "_z"]), T(g[tag + "_rd"]),
+                                                                           white_background=bool(g[tag + "_white"]), mip_nerf=True, noise=T(g[tag + "_noise"]))
+        assert all(torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() for a, b in zip(out, out2))

@@ -308,3 +308,17 @@ def test_ndc_render_end_to_end(oracle):
     np.testing.assert_allclose(f["rgb"][ok], g["rgb_fine"][ok], rtol=0, atol=2e-5)
     err = np.abs(o["rgb_fine"] - g["rgb_fine"]).max(-1)
     assert np.mean(err <= 2e-4) >= 0.97 and psnr(o["rgb_fine"], g["rgb_fine"]) >= 70.0
+
+
+def test_composite_mip_golden(oracle):
+    """volume_render_radiance_field(mip_nerf=True): S + 1 interval edges, no 1e10 tail, depth over the interval mid-points (g16)"""
+    g = load_golden("g16_composite_mip.npz")
+    for tag in ("a", "b"):
+        rgb, disp, acc, w, depth = oracle.composite(g[tag + "_raw"], g[tag + "_z"], g[tag + "_rd"], noise=g[tag + "_noise"],
+                                                    white_background=bool(g[tag + "_white"]), mip_nerf=True)
+        np.testing.assert_allclose(rgb, g[tag + "_rgb"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(acc, g[tag + "_acc"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(w, g[tag + "_weights"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(depth, g[tag + "_depth"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(disp, g[tag + "_disp"], rtol=1e-5, atol=0, equal_nan=True)
+        assert np.isnan(g[tag + "_disp"]).any() or tag == "b"
