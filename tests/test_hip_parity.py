@@ -1640,7 +1640,7 @@ def test_sr_train_step_and_evaluate_view(hip):
     assert all(p_.grad is None for p_ in mc.decoder_parameters())
 
 
-@pytest.mark.parametrize("workload", ["render", "train"])
+@pytest.mark.parametrize("workload", ["render", "train", "sr"])
 def test_bench_two_rank_rehearsal(workload):
     """bench.py's N > 1 path (barriers, max-over-ranks timing, whole-job value, the gradient all-reduce of the train workload) launched
     exactly as the driver launches it, with two ranks sharing this box's one GPU over gloo (NVSR_BENCH_REHEARSAL=1)."""
@@ -1659,7 +1659,7 @@ def test_bench_two_rank_rehearsal(workload):
     assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 prints ONE line
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
-    per_gpu = r["config"]["rays_per_step_per_gpu"]
+    per_gpu = r["config"]["planes_per_step_per_gpu" if workload == "sr" else "rays_per_step_per_gpu"]
     assert abs(r["value"] - 2 * per_gpu * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]   # whole-job aggregate over both ranks
     assert "roofline" in r and "cpu_baseline" not in r
 
