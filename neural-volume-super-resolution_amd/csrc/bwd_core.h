@@ -76,6 +76,57 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same for a tile of 32 CONSECUTIVE SAMPLES OF ONE RAY (render_bwd_limb.hip): neighbouring samples of a ray mostly fall into the same
+// texel cell of a plane (a step along the ray is shorter than a texel at 128 samples over a 200^2 plane), so the contributions of a run of
+// samples with the same four texels are summed in registers and go out as ONE set of 4 atomics -- the float atomics are what the backward
+// pass is bound by.  Offsets and weights are wave-uniform per point (v_readlane), the run test is scalar.
+__device__ __forceinline__ void scatter_plane_runs(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
+                                                   bool valid) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    int c0 = -1, c1 = -1, c2 = -1, c3 = -1;                        // texels of the current run
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;              // this lane's channel, summed over the run
+    auto flush = [&]() {
+        if (c0 >= 0 && lane < C) {
+            unsafeAtomicAdd(gplane + c0 + lane, s0);
+            unsafeAtomicAdd(gplane + c1 + lane, s1);
+            unsafeAtomicAdd(gplane + c2 + lane, s2);
+            unsafeAtomicAdd(gplane + c3 + lane, s3);
+        }
+    };
+    // (Keeping four texel accumulators keyed by offset, so that a texel shared with the NEIGHBOURING cell survives the step as well, was
+    //  measured slower: 3.13 vs 2.87 ms per step -- 16 select / fma pairs per point and 25 more spilled registers cost more than the atomics
+    //  they save.)
+#pragma unroll 4
+    for (int p = 0; p < 32; ++p) {
+        const int o0 = __builtin_amdgcn_readlane(t.o00, p), o1 = __builtin_amdgcn_readlane(t.o01, p);
+        const int o2 = __builtin_amdgcn_readlane(t.o10, p), o3 = __builtin_amdgcn_readlane(t.o11, p);
+        const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), p));
+        const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), p));
+        const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w2), p));
+        const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), p));
+        if (o0 != c0 || o1 != c1 || o2 != c2 || o3 != c3) {        // (wave-uniform)
+            flush();
+            c0 = o0; c1 = o1; c2 = o2; c3 = o3;
+            s0 = s1 = s2 = s3 = 0.0f;
+        }
+        const float v = lane < C ? tile[p * C + lane] : 0.0f;
+        s0 = fmaf(v, a0, s0); s1 = fmaf(v, a1, s1); s2 = fmaf(v, a2, s2); s3 = fmaf(v, a3, s3);
+    }
+    flush();
+    __builtin_amdgcn_wave_barrier();
+}
+
 // View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
 // address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
 // gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.

@@ -8,8 +8,9 @@
 // nvsr_pack_decoder_bwd, bwd_core.h), B = the gradient of the layer above, split into limbs on the fly.  The C/D layout of one layer is the
 // B layout of the next one below, exactly as in the forward, so the chain runs through registers; the ReLU gate of the layer below is
 // applied to the finished accumulators.  Per tile 6 x 192 + 5 x 96 = 1 632 v_mfma_f32_32x32x16_bf16 instead of 2 176 f32 MFMAs of twice
-// the length.  Skeleton as in decode_limb.hip: a wave owns one 32-point tile of a (ray block, sample) pair, two independent 4-wave
-// workgroups per CU cover each other's splits, masks, transposes and atomics; the weights stream through a ring of two 24-KB slots
+// the length.  Skeleton as in decode_limb.hip, except that a wave's 32-point tile is 32 CONSECUTIVE SAMPLES OF ONE RAY (their texel cells
+// repeat, so the scatter merges runs of samples into one set of atomics); two independent 4-wave workgroups per CU cover each other's
+// splits, masks, transposes and atomics; the weights stream through a ring of two 24-KB slots
 // (2 K-blocks of a hidden layer / 4 of a plane's layer 0), 34 chunks per step.  Scatter into the planes, view-plane rows and the record of
 // the pre-activation gradients are those of the f32 kernel (bwd_core.h).
 #include <type_traits>
@@ -150,20 +151,23 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(64);
-    const long nrb = (N + BL_PTS - 1) / BL_PTS;
-    const long ntiles = nrb * S;
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    // A wave's tile = 32 CONSECUTIVE SAMPLES OF ONE RAY (not one sample of 32 rays as in the forward): neighbouring samples share texels,
+    // which lets the scatter merge their atomics (scatter_plane_runs), and the ray, its gates and dL/draw are contiguous per tile.
+    const int nsc = (S + 31) / 32;                                   // sample chunks per ray
+    const long nwt = N * nsc;                                        // wave tiles
+    const long ntiles = (nwt + BL_WAVES - 1) / BL_WAVES;
     auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
     auto none = [](int) {};
 
     for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
-        const long rb = tix / S;
-        const int s = (int)(tix - rb * S);
-        const long ray0 = rb * BL_PTS + rs.wave * 32 + (lane & 31);
-        const bool valid = ray0 < N;
-        const long ray = valid ? ray0 : N - 1;
+        const long wt = tix * BL_WAVES + rs.wave;
+        const long ray0 = wt / nsc;
+        const int s0 = (int)(wt - ray0 * nsc) * 32 + (lane & 31);
+        const bool valid = ray0 < N && s0 < S;
+        const long ray = ray0 < N ? ray0 : N - 1;
+        const int s = s0 < S ? s0 : S - 1;
         const unsigned* cw = ringb_issue(rs, 0);
         const float* r = rays + ray * 11;
         const float zc = z[ray * S + s];
@@ -283,10 +287,26 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
             BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
             if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {
-                    store_view_rows(gF, tile, gview, rb * BL_PTS + rs.wave * 32, N, S, s, lane);
+                    // rows [ray * S + s][48] of this ray's 32 samples (the per-ray sum is view_reduce_scatter_kernel's)
+                    const int hh = lane >> 5, pt = lane & 31;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) {
+                            if (b == 1 && rr >= 8) continue;
+                            tile[pt * C + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * hh] = gF[b][rr];
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < C && ray0 < N) {
+                        const int sb = s0 - (lane & 31);                // first sample of the tile (uniform: lane & 31 is this lane's offset)
+                        for (int p_ = 0; p_ < 32; ++p_)
+                            if (sb + p_ < S) gview[((long)ray * S + sb + p_) * C + lane] = tile[p_ * C + lane];
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 } else {
                     const Taps t = (d < 3) ? pos_taps(d) : view_taps(sc, r[8], r[9], r[10]);
-                    scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+                    scatter_plane_runs(gF, tile, t, gp.p[d], lane, valid);
                 }
             }
         }
@@ -315,7 +335,7 @@ extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* sce
                                                            nvsr_stream_t stream) {
     GradPlanes gp;
     for (int d = 0; d < 4; ++d) gp.p[d] = grad_planes ? grad_planes[d] : nullptr;
-    const int64_t ntiles = ((N + BL_PTS - 1) / BL_PTS) * S;
+    const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + BL_WAVES - 1) / BL_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
     const int64_t grid = ntiles < 2048 ? ntiles : 2048;
     if (record)
         hipLaunchKernelGGL(render_pass_backward_gates_limb_kernel<true>, dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
