@@ -4,7 +4,7 @@
 //
 // The reference runs this as run_network -> TwoDimPlanesModel.forward under autograd (train_utils.py:15-64, models.py:381-421).
 //
-// Skeleton of the first-generation kernel, not of render3.hip: tiles are (ray block, sample) pairs, a wave owns ONE 32-point tile, and
+// Skeleton of the first-generation kernel, not of render3.hip: a wave owns ONE 32-point tile (32 consecutive samples of one ray), and
 // the latency of its gathers, limb splits, bias + ReLU, gate words and record stores is covered by the wave of the OTHER workgroup on the
 // same SIMD -- two independent 4-wave workgroups per CU (own barriers, start-up stagger), which is why the weight ring is cut into
 // 36-KB slots (3 K-blocks of 16 input channels x 3 limbs x 4 output blocks): 2 x (2 x 36 KB + 6 KB) = 157 KB of LDS.  A plane's share
@@ -191,19 +191,23 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_sleep(64);
-    const long nrb = (N + L3_PTS - 1) / L3_PTS;
-    const long ntiles = nrb * S;
+    // A wave's tile = 32 CONSECUTIVE SAMPLES OF ONE RAY (like render_bwd_limb.hip): their bilinear taps fall into the same or neighbouring
+    // texel cells, so the 64 lanes of a gather load share cache lines (tools/gather_ubench.hip: 90 vs 30 GB/s per CU against 32 unrelated
+    // rays); the ray, its gates and raw rows are contiguous per tile.
+    const int nsc = (S + 31) / 32;                                     // sample chunks per ray
+    const long ntiles = (N * nsc + L3_WAVES - 1) / L3_WAVES;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
-        const long rb = tile / S;
-        const int s = (int)(tile - rb * S);
-        long ray = rb * L3_PTS + rs.wave * 32 + (rs.lane & 31);
-        const bool valid = ray < N;
-        if (!valid) ray = N - 1;
+        const long wt = tile * L3_WAVES + rs.wave;
+        const long ray0 = wt / nsc;
+        const int s0 = (int)(wt - ray0 * nsc) * 32 + (rs.lane & 31);
+        const bool valid = ray0 < N && s0 < S;
+        const long ray = ray0 < N ? ray0 : N - 1;
+        const int s = s0 < S ? s0 : S - 1;
         const float* r = rays + ray * 11;
         const float zc = z[ray * S + s];
         const Taps vt = view_taps(sc, r[8], r[9], r[10]);
         float raw[4];
-        // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes of the last ray block rewrite ray N-1's record
+        // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
         decode_step_limb<MASKS, RECORD>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
                                         __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, (long)s * N + ray, valid);
@@ -218,7 +222,7 @@ using namespace nvsr;
 // nvsr_decode_rays_ex (render.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
 extern "C" int nvsr_decode_rays_limb_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                             const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
-    const int64_t ntiles = ((N + L3_PTS - 1) / L3_PTS) * S;
+    const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + L3_WAVES - 1) / L3_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     if (record)
         hipLaunchKernelGGL((decode_rays_limb_kernel<true, true>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
