@@ -85,6 +85,10 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
     auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
     auto none = [](int) {};
+    SplitPend tp;
+    auto tail_of = [&tp](const f32x16 (&a)[4], int kb) {
+        return [&a, kb, &tp](int slice, Limbs<3>& nxt) { split_slice<3>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+    };
     auto pos_taps = [&](int d) {
         const float* M = sc.proj + 6 * d;
         return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
@@ -97,20 +101,29 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");         \
     __builtin_amdgcn_sched_barrier(0);
     // one chunk: wait for it, start the copy of the next one, split the block's first K-block, multiply
-#define L3_BLOCK(NKB, ZERO, SRC, NEXT)                                                         \
+    // (FIRST: the block's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
+#define L3_BLOCK_(NKB, ZERO, FIRST, SRC, NEXT, TAIL)                                           \
     {                                                                                          \
         ringl_sync();                                                                          \
         const unsigned* nw = NEXT;                                                             \
-        { auto s_ = SRC; split_all<3>([&](int i) { return s_(0, i); }, cur); }                 \
-        limb_block<3, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, NoTail{});           \
+        if (FIRST) { auto s_ = SRC; split_all<3>([&](int i) { return s_(0, i); }, cur); }      \
+        limb_block<3, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, TAIL);               \
         cw = nw;                                                                               \
         L3_FENCE                                                                               \
     }
+#define L3_BLOCK(NKB, ZERO, SRC, NEXT) L3_BLOCK_(NKB, ZERO, true, SRC, NEXT, NoTail{})
     // a hidden layer = 3 + 3 + 2 K-blocks of the previous activation; NEXT = the chunk that follows the layer
+#ifdef NVSR_NO_TAILS      // A/B switch (tools/): every block splits its first K-block itself
 #define L3_HIDDEN(KB0, NEXT)                                                                   \
     L3_BLOCK(3, true, hid(act, 0), ringl_issue<3>(rs, (KB0) + 3))                              \
     L3_BLOCK(3, false, hid(act, 3), ringl_issue<2>(rs, (KB0) + 6))                             \
     L3_BLOCK(2, false, hid(act, 6), NEXT)
+#else
+#define L3_HIDDEN(KB0, NEXT)                                                                   \
+    L3_BLOCK_(3, true, true, hid(act, 0), ringl_issue<3>(rs, (KB0) + 3), tail_of(act, 3))      \
+    L3_BLOCK_(3, false, false, hid(act, 3), ringl_issue<2>(rs, (KB0) + 6), tail_of(act, 6))    \
+    L3_BLOCK_(2, false, false, hid(act, 6), NEXT, NoTail{})
+#endif
     auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
         bias_relu(acc, small + S_BIAS + vec * HID, h, act);
         if (MASKS) publish_gates(act, gates, vec);
@@ -174,6 +187,7 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     }
 #undef L3_HIDDEN
 #undef L3_BLOCK
+#undef L3_BLOCK_
 #undef L3_FENCE
 }
 

@@ -191,26 +191,41 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
         };
         f32x16 accA[4], accB[4];
         Limbs<3> cur, fa;
+        SplitPend tp;
+        // tail of a block: split K-block kb of the same gradient into the limbs the next block starts with
+        auto tail_of = [&tp](const f32x16 (&a)[4], int kb) {
+            return [&a, kb, &tp](int slice, Limbs<3>& nxt) { split_slice<3>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+        };
         // one chunk of a hidden^T layer (2 K-blocks): wait, start the next copy, split the first K-block of G, multiply
 #define BL_FENCE(ACC)                                                                                   \
         asm volatile("" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]) : : "memory");         \
         __builtin_amdgcn_sched_barrier(0);
-#define BL_HBLOCK(ZERO, G, KB0, GN, NEXT_CHUNK)                                                         \
+        // (FIRST: the chunk's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
+#define BL_HBLOCK(ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL)                                            \
         {                                                                                               \
             ringb_sync();                                                                               \
             const unsigned* nw = ringb_issue(rs, NEXT_CHUNK);                                           \
-            if (!(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); } \
-            limb_block<3, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, NoTail{});           \
+            if (FIRST && !(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); } \
+            limb_block<3, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, TAIL);               \
             cw = nw;                                                                                    \
             BL_FENCE(GN)                                                                                \
         }
         // gn = mask .* (W^T g): chunks C0 .. C0 + 3
+#ifdef NVSR_NO_TAILS      // A/B switch (tools/): every block splits its first K-block itself
 #define BL_HIDDEN_T(G, MK, GN, C0)                                                                      \
-        BL_HBLOCK(true, G, 0, GN, (C0) + 1)                                                             \
-        BL_HBLOCK(false, G, 2, GN, (C0) + 2)                                                            \
-        BL_HBLOCK(false, G, 4, GN, (C0) + 3)                                                            \
-        BL_HBLOCK(false, G, 6, GN, (C0) + 4)                                                            \
+        BL_HBLOCK(true, true, G, 0, GN, (C0) + 1, NoTail{})                                             \
+        BL_HBLOCK(false, true, G, 2, GN, (C0) + 2, NoTail{})                                            \
+        BL_HBLOCK(false, true, G, 4, GN, (C0) + 3, NoTail{})                                            \
+        BL_HBLOCK(false, true, G, 6, GN, (C0) + 4, NoTail{})                                            \
         if (!(BL_ABLATE & 2)) apply_mask(gate(MK), GN);
+#else
+#define BL_HIDDEN_T(G, MK, GN, C0)                                                                      \
+        BL_HBLOCK(true, true, G, 0, GN, (C0) + 1, tail_of(G, 2))                                        \
+        BL_HBLOCK(false, false, G, 2, GN, (C0) + 2, tail_of(G, 4))                                      \
+        BL_HBLOCK(false, false, G, 4, GN, (C0) + 3, tail_of(G, 6))                                      \
+        BL_HBLOCK(false, false, G, 6, GN, (C0) + 4, NoTail{})                                           \
+        if (!(BL_ABLATE & 2)) apply_mask(gate(MK), GN);
+#endif
         // acc2 += W0^T g: chunks C0, C0 + 1; LAST: no chunk follows in this step
 #define BL_LAYER0_T(G, ACC2, C0, LAST)                                                                  \
         {                                                                                               \
