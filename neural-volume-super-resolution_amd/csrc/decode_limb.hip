@@ -224,7 +224,7 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
         decode_step_limb<MASKS, RECORD>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
-                                        __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, (long)s * N + ray, valid);
+                                        __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, record_row(ray, s, N, S), valid);
         if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 }

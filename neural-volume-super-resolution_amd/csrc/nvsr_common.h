@@ -103,6 +103,14 @@ inline DecRecord make_record(float* base, long N, int S) {
     return r;
 }
 
+// row of point (ray, s) in the weight-gradient record.  Every producer (the forward and backward kernels of both arithmetic modes) goes
+// through this one function; the consumers (decoder_wgrad.hip) sum over rows and do not care about their order.
+#ifdef NVSR_RECORD_SAMPLE_MAJOR        // A/B switch (tools/ab_flags.sh): the order the 32-rays-per-wave f32 kernels were written for
+__host__ __device__ inline long record_row(long ray, int s, long N, int S) { (void)S; return (long)s * N + ray; }
+#else                                  // ray-major: the 32 samples of a limb-kernel tile are 32 consecutive rows
+__host__ __device__ inline long record_row(long ray, int s, long N, int S) { (void)N; return ray * S + s; }
+#endif
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // torch.linspace(0, 1, n) element i in fp32 (symmetric two-sided form used by ATen's RangeFactories)

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TPB, 2) void decode_rays_kernel(SceneDev sc, const 
         // record with identical values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
         decode_step<NWAVES, MASKS, RECORD>(sc, rs, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
-                                           __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, &rec, (long)s * N + ray, valid);
+                                           __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, &rec, record_row(ray, s, N, S), valid);
         if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // padding rays: every gradient below becomes an exact zero
-        const long q = (long)s * N + ray;                             // record row of this point
+        const long q = record_row(ray, s, N, S);                             // record row of this point
         const bool rok = RECORD && valid;                             // padding rays write nothing
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         const f32x4 c0 = f32x4{r[0], r[1], r[2], r[3]}, c1 = f32x4{r[4], r[5], 0.0f, 0.0f};
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const long q = (long)s * N + ray;                             // record row (the forward wrote X / H of the same row)
+        const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         const u32x4* gk = reinterpret_cast<const u32x4*>(gates + ((ray * S + s) * 2 + h) * 16);

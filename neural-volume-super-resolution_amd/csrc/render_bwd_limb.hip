@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const long q = (long)s * N + ray;                             // record row (the forward wrote X / H of the same row)
+        const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
         // Everything below is re-read where it is used instead of being kept across the step (two accumulator sets, gD and the limbs
