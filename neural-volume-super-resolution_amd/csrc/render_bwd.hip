@@ -643,7 +643,8 @@ int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed
         if (int e = nvsr_render_pass_backward_gates_limb_launch(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, gates, grad_planes,
                                                                 view_ws, record, stream))
             return e;
-        if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);
+        // the limb kernel leaves one pre-summed row per (ray, 32-sample chunk) in view_ws
+        if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, (S + 31) / 32, rays, view_ws, gp.p[3], (hipStream_t)stream);
         return NVSR_OK;
     }
     const int64_t ntiles = ((N + MPTS - 1) / MPTS) * S;

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
             BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
             if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {
-                    // rows [ray * S + s][48] of this ray's 32 samples (the per-ray sum is view_reduce_scatter_kernel's)
+                    // every sample of the ray taps the same four view-plane texels: the tile's 32 gradient rows are summed here, ONE row
+                    // [ray * nsc + chunk][48] goes to the workspace and view_reduce_scatter_kernel adds a ray's nsc rows (padding samples
+                    // carry zero gradient)
                     const int hh = lane >> 5, pt = lane & 31;
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -314,9 +316,12 @@ __global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_ker
                         }
                     __builtin_amdgcn_wave_barrier();
                     if (lane < C && ray0 < N) {
-                        const int sb = s0 - (lane & 31);                // first sample of the tile (uniform: lane & 31 is this lane's offset)
-                        for (int p_ = 0; p_ < 32; ++p_)
-                            if (sb + p_ < S) gview[((long)ray * S + sb + p_) * C + lane] = tile[p_ * C + lane];
+                        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+#pragma unroll
+                        for (int p_ = 0; p_ < 32; p_ += 4) {
+                            v0 += tile[p_ * C + lane]; v1 += tile[(p_ + 1) * C + lane]; v2 += tile[(p_ + 2) * C + lane]; v3 += tile[(p_ + 3) * C + lane];
+                        }
+                        gview[wt * C + lane] = (v0 + v1) + (v2 + v3);            // wt = ray * nsc + chunk
                     }
                     __builtin_amdgcn_wave_barrier();
                 } else {
