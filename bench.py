@@ -69,7 +69,7 @@ def pose_spherical(theta, phi, radius):
     return c2w.astype(np.float32)
 
 
-def make_synthetic_scene(dev, plane_res=800, view_res=32, seed=0, theta=30.0):
+def make_synthetic_scene(dev, plane_res=800, view_res=32, seed=0, theta=30.0, channels_last=False):
     """Random-init decoder pair + random planes (no dataset / checkpoint is reachable), calibrated so that the density is
     neither empty nor saturated (SURVEY.md 7 'degenerate synthetic scenes')."""
     import nvsr_amd
@@ -84,7 +84,9 @@ def make_synthetic_scene(dev, plane_res=800, view_res=32, seed=0, theta=30.0):
     def smooth_plane(res):
         src = max(res // 8, 4)
         low = 0.7 * torch.randn(1, 48, src, src, device=dev)
-        return torch.nn.Parameter(torch.nn.functional.interpolate(low, size=(res, res), mode="bilinear", align_corners=True).contiguous())
+        p = torch.nn.functional.interpolate(low, size=(res, res), mode="bilinear", align_corners=True).contiguous()
+        # channels_last: the same [1,48,R,R] parameter in the kernels' native memory order (models.create_plane(channels_last=True))
+        return torch.nn.Parameter(p.contiguous(memory_format=torch.channels_last) if channels_last else p)
     mc, mf = mc.to(dev), mf.to(dev)
     planes = torch.nn.ParameterDict({M.get_plane_name(sid, d): smooth_plane(plane_res if d < 3 else view_res) for d in range(4)})
     box = torch.tensor([[-4.0, -4, -4, -np.pi, -np.pi / 2], [4, 4, 4, np.pi, np.pi / 2]], dtype=torch.float64)
@@ -233,7 +235,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     capi = nvsr_amd.capi
     R, N, Nc, Nf = 200, 4096, 64, 64
     what = {"planes": {"LR_planes"}, "planes+decoder": {"LR_planes", "decoder"}}[args.train_what]
-    mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0)
+    mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0, channels_last=not args.nchw_planes)
     for m in (mc, mf):
         for n, p in m.named_parameters():
             p.requires_grad_("rot_mats" not in n and ("planes_" in n or "decoder" in what))
@@ -275,6 +277,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
               "dtype": ARITHMETIC["bf16x3" if capi.get_decoder_arithmetic() != "f32" else "f32"]["dtype"], "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
+                         "plane_memory_format": "NCHW" if args.nchw_planes else "channels_last (same [1,48,R,R] parameters, native [H][W][C] memory)",
                          "parallelism": "rays sharded by rank; one bucketed all-reduce of the %s per step"
                                         % ("plane + decoder gradients" if "decoder" in what else "plane gradients (23 MB)")}}
     if rank == 0:
@@ -402,6 +405,9 @@ def main():
     ap.add_argument("--workload", choices=["render", "train", "sr"], default="render")
     ap.add_argument("--train-what", choices=["planes", "planes+decoder"], default="planes",
                     help="--workload train: nerf.train.what (default = Feature_Planes_Only.yml, BASELINE configs[3])")
+    ap.add_argument("--nchw-planes", action="store_true",
+                    help="--workload train: keep the plane parameters in the reference's NCHW memory order (a re-layout kernel per plane and step) "
+                         "instead of torch.channels_last, whose memory is the kernels' native [H][W][C] layout")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)

@@ -32,11 +32,20 @@ def get_scene_id(basedir, ds_factor, plane_res):
     return "%s_DS%d%s" % (basedir, ds_factor, "" if plane_res[0] is None else "_PlRes%d_%d" % (plane_res))
 
 
-def create_plane(resolution, num_plane_channels, init_STD):
-    """models.py:436-439 -- planes stay NCHW [1,C,H,W] at the interface, like the reference"""
+def create_plane(resolution, num_plane_channels, init_STD, channels_last=False):
+    """models.py:436-439 -- planes are [1,C,H,W] tensors at the interface, like the reference.  channels_last=True (extension) gives the
+    parameter torch's channels_last memory format: same shape, same indexing, same state-dict entry, but its memory IS the kernels'
+    native [H][W][C] layout -- no re-layout kernel per training step and no second copy of the planes (is_native_layout below)."""
     if not isinstance(resolution, list):
         resolution = [resolution, resolution]
-    return nn.Parameter(init_STD * torch.randn(size=[1, num_plane_channels, resolution[0], resolution[1]]))
+    p = init_STD * torch.randn(size=[1, num_plane_channels, resolution[0], resolution[1]])
+    return nn.Parameter(p.contiguous(memory_format=torch.channels_last) if channels_last else p)
+
+
+def is_native_layout(plane):
+    """a [1,C,H,W] float32 plane whose memory is already [H][W][C] (torch.channels_last)"""
+    return (plane.dim() == 4 and plane.shape[0] == 1 and plane.shape[1] > 1 and plane.dtype == torch.float32
+            and not plane.is_contiguous() and plane.is_contiguous(memory_format=torch.channels_last))
 
 
 class CoordProjector(nn.Module):
@@ -61,7 +70,9 @@ class CoordProjector(nn.Module):
 
 
 def to_channel_last(plane_nchw):
-    """[1,C,H,W] or [C,H,W] -> [H,W,C] through the re-layout kernel"""
+    """[1,C,H,W] or [C,H,W] -> [H,W,C] through the re-layout kernel; a channels_last plane is returned as a view of its own memory"""
+    if is_native_layout(plane_nchw):
+        return plane_nchw.permute(0, 2, 3, 1)[0]
     p = capi.f32c(plane_nchw)
     Cc, H, W = p.shape[-3:]
     out = torch.empty((H, W, Cc), dtype=torch.float32, device=p.device)
@@ -69,7 +80,10 @@ def to_channel_last(plane_nchw):
     return out
 
 
-def from_channel_last(plane_hwc):
+def from_channel_last(plane_hwc, like=None):
+    """[H,W,C] -> [1,C,H,W]; for a channels_last `like` (the plane the gradient belongs to) a view with that memory format, no kernel"""
+    if like is not None and is_native_layout(like) and plane_hwc.is_contiguous():
+        return plane_hwc.unsqueeze(0).permute(0, 3, 1, 2)
     p = capi.f32c(plane_hwc)
     H, W, Cc = p.shape
     out = torch.empty((1, Cc, H, W), dtype=torch.float32, device=p.device)
@@ -389,6 +403,7 @@ class _DecodePointsFn(torch.autograd.Function):
         rays[:, 8:11] = x[:, 3:6]
         z = torch.zeros((P, 1), dtype=torch.float32, device=dev)
         planes_cl = [to_channel_last(p.detach()) for p in (p0, p1, p2, pv)]
+        ctx.plane_srcs = (p0, p1, p2, pv)
         sc, keep = model.native_scene(planes=planes_cl)
         raw = torch.empty((P, 1, 4), dtype=torch.float32, device=dev)
         gates = torch.empty((P, 1, 32), dtype=torch.int32, device=dev)
@@ -415,7 +430,7 @@ class _DecodePointsFn(torch.autograd.Function):
         if rec is not None and need[6]:
             gnat = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
             capi.call("nvsr_decoder_weight_grad", P, 1, capi.ptr(rec), capi.ptr(gnat), capi.stream())
-        return (None, None) + tuple(None if g is None else from_channel_last(g) for g in gplanes) + (gnat,)
+        return (None, None) + tuple(None if g is None else from_channel_last(g, like=p_) for g, p_ in zip(gplanes, ctx.plane_srcs)) + (gnat,)
 
 
 # =======================================================================================================================

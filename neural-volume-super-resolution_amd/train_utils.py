@@ -154,8 +154,8 @@ class _RenderRaysFn(torch.autograd.Function):
             one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
                      gdec_f, sv["gates_f"], sv["rec_f"])
         out = [None]
-        for g in gplanes:
-            out.append(None if g is None else models.from_channel_last(g))    # back to the reference's [1,C,H,W]
+        for g, src in zip(gplanes, cfg["plane_leaves"]):
+            out.append(None if g is None else models.from_channel_last(g, like=src))    # back to the reference's [1,C,H,W]
         return tuple(out) + (gdec_c, gdec_f)
 
 
@@ -239,7 +239,8 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=int(bool(m.lindisp)), white=int(bool(m.white_background)), t_rand=t_rand, u=u,
                    noise_c=n_c, noise_f=n_f, scene_c=sc_c, scene_f=sc_f, keep=(keep_c, keep_f), packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
-                   plane_shapes=[tuple(k.shape) for k in keep_f], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad, dec_f_grad=dec_f_grad)
+                   plane_shapes=[tuple(k.shape) for k in keep_f], plane_leaves=leaves[:4], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
+                   dec_f_grad=dec_f_grad)
         outs = _RenderRaysFn.apply(cfg, *leaves)
         if Nf > 0:
             return outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], None, None, None

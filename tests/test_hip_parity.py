@@ -1799,3 +1799,34 @@ def test_composite_mip_branch_golden_and_gradient(hip):
             out2 = hip.volume_rendering_utils.volume_render_radiance_field(raw.detach(), T(g[tag + "_z"]), T(g[tag + "_rd"]),
                                                                            white_background=bool(g[tag + "_white"]), mip_nerf=True, noise=T(g[tag + "_noise"]))
         assert all(torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() for a, b in zip(out, out2))
+
+
+def test_channels_last_planes_are_used_in_place(hip):
+    """A plane parameter in torch.channels_last memory format IS the kernels' [H][W][C] layout: rendering and a train step give bit-identical
+    images / the same gradients as with the reference's NCHW parameters, the gradient comes back channels_last, and no copy is made"""
+    from bench import make_synthetic_scene, render_options
+    outs = {}
+    for cl in (False, True):
+        mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=48, view_res=8, seed=9, channels_last=cl)
+        H = W = 20
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+        opts, scfg = render_options(16, 16)
+        with torch.no_grad():
+            img = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
+        p0 = mc.planes_[hip.models.get_plane_name(sid, 0)]
+        assert hip.models.is_native_layout(p0) == cl
+        if cl:
+            assert hip.models.to_channel_last(p0.detach()).data_ptr() == p0.data_ptr()        # a view, not a copy
+        for m in (mc, mf):
+            for n_, p_ in m.named_parameters():
+                p_.requires_grad_("planes_" in n_)
+            m.train()
+        batch = torch.stack([ro.reshape(-1, 3)[:64], rd.reshape(-1, 3)[:64]], 0)
+        out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        (out[0].sum() + out[3].sum()).backward()
+        assert p0.grad.shape == p0.shape and hip.models.is_native_layout(p0.grad) == cl
+        outs[cl] = (img, [mc.planes_[hip.models.get_plane_name(sid, d)].grad.contiguous() for d in range(4)])
+    assert torch.equal(outs[False][0], outs[True][0])
+    for a, b in zip(outs[False][1], outs[True][1]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * float(a.abs().max()) + 1e-12)     # float atomics reorder sums
