@@ -215,3 +215,26 @@ def test_dataset_loaders_match_reference(pkg, tmp_path):
     # the loaded intrinsics feed the ray generator unchanged: [H, W, focal] of an LLFF pose's fifth column
     hwf = poses[0, :3, -1].tolist()
     assert hwf[0] == images.shape[1] and hwf[1] == images.shape[2]
+
+
+def test_bench_pixel_sampler_is_a_permutation_prefix():
+    """bench.sample_without_replacement: the n distinct values are exactly the draws in draw order with every repeat of an earlier draw
+    dropped (= a prefix of a uniform random permutation); small ranges fall back to randperm"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench import sample_without_replacement
+    g = torch.Generator().manual_seed(7)
+    total, n = 5000, 900                                  # small range: ~80 repeats among the first 900 draws
+    state = g.get_state()
+    out = sample_without_replacement(total, n, "cpu", g, margin=512)
+    g.set_state(state)
+    draws = torch.randint(0, total, (n + 512,), generator=g).tolist()
+    seen, ref = set(), []
+    for v in draws:
+        if v not in seen:
+            seen.add(v); ref.append(v)
+    assert out.tolist() == ref[:n] and len(set(out.tolist())) == n
+    full = sample_without_replacement(100, 100, "cpu", g)
+    assert sorted(full.tolist()) == list(range(100))
+    big = sample_without_replacement(640000, 4096, "cpu", g)
+    assert big.shape == (4096,) and len(set(big.tolist())) == 4096 and 0 <= int(big.min()) and int(big.max()) < 640000
