@@ -14,6 +14,10 @@
 
 #include "limb_core.h"
 
+#ifndef L3_ABLATE
+#define L3_ABLATE 0   // timing experiments only (wrong results): 1 no plane gathers, 2 no gate words, 4 no wait for the weight copies,
+#endif                // 8 no bias + ReLU                                                        (tools/ab_flags.sh)
+
 namespace nvsr {
 
 constexpr int L3_TPB = 256, L3_WAVES = L3_TPB / 64, L3_PTS = L3_WAVES * 32;
@@ -44,7 +48,9 @@ __device__ __forceinline__ const unsigned* ringl_issue(RingL& rs, int kb0) {
     return dst;
 }
 __device__ __forceinline__ void ringl_sync() {
+#if !(L3_ABLATE & 4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 
@@ -100,6 +106,11 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
 #define L3_FENCE                                                                                    \
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");         \
     __builtin_amdgcn_sched_barrier(0);
+#if L3_ABLATE & 1
+#define L3_GATHER(PLANE, TAPS, H_, F_) { const Taps t_ = TAPS; for (int c_ = 0; c_ < HALF_C; ++c_) F_[c_] = t_.nw * (float)(c_ + H_); }
+#else
+#define L3_GATHER(PLANE, TAPS, H_, F_) gather24(PLANE, TAPS, H_, F_);
+#endif
     // one chunk: wait for it, start the copy of the next one, split the block's first K-block, multiply
     // (FIRST: the block's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
 #define L3_BLOCK_(NKB, ZERO, FIRST, SRC, NEXT, TAIL)                                           \
@@ -125,28 +136,33 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     L3_BLOCK_(2, false, false, hid(act, 6), NEXT, NoTail{})
 #endif
     auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
-        bias_relu(acc, small + S_BIAS + vec * HID, h, act);
-        if (MASKS) publish_gates(act, gates, vec);
+        if (L3_ABLATE & 8) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) act[ib] = acc[ib];
+        } else {
+            bias_relu(acc, small + S_BIAS + vec * HID, h, act);
+        }
+        if (MASKS && !(L3_ABLATE & 2)) publish_gates(act, gates, vec);
         if (RECORD && rec_ok) record128(hrow, q, h, act);
     };
     const long LP = (long)HID * rec.Pp;
 
     // ---- rgb layer 0: K = 192 in the limb blob's order [f_view | f0 | f1 | f2], one plane = one chunk ---------------------------------
     const unsigned* cw = ringl_issue<3>(rs, KB_RGB0);
-    gather24(sc.plane[3], vt, h, F);
+    L3_GATHER(sc.plane[3], vt, h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
     L3_BLOCK(3, true, feat(F), ringl_issue<3>(rs, KB_RGB0 + 3))
-    gather24(sc.plane[0], pos_taps(0), h, F);
+    L3_GATHER(sc.plane[0], pos_taps(0), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C), h, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
     L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 6))
-    gather24(sc.plane[1], pos_taps(1), h, F);
+    L3_GATHER(sc.plane[1], pos_taps(1), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + C, h, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
     L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 9))
-    gather24(sc.plane[2], pos_taps(2), h, F);
+    L3_GATHER(sc.plane[2], pos_taps(2), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
 #pragma unroll
@@ -185,6 +201,7 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         head_dots<1>(small + S_ALPHA_W, h, act, hd);
         raw[3] = hd[0] + small[S_HEAD_B];
     }
+#undef L3_GATHER
 #undef L3_HIDDEN
 #undef L3_BLOCK
 #undef L3_BLOCK_
