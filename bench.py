@@ -406,20 +406,42 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
                 modes[m2] = {"planes_per_s": 3 * 2 / (time.perf_counter() - t1), "ms_per_step": 1e3 * (time.perf_counter() - t1) / 2}
             nvsr_amd.capi.set_conv_arithmetic(mode)
             result["arithmetic_modes"] = modes
+            # the SR *training* iteration of one plane (BASELINE configs[4]'s refinement: forward that keeps its activations, backward
+            # with data + weight gradients), full-plane region of interest
+            sr.train()
+            tf = tb = 0.0
+            for rep in range(3):
+                sr.clear_SR_planes()
+                sr.zero_grad(set_to_none=True)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                out_t = sr("p0")
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                out_t.sum().backward()
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                if rep:
+                    tf += (t1 - t0) / 2; tb += (t2 - t1) / 2
+            sr.eval()
+            sr.zero_grad(set_to_none=True)
+            result["sr_training_per_plane"] = {"forward_ms": 1e3 * tf, "backward_ms": 1e3 * tb,
+                                               "algorithmic_tflop": {"forward": 6.74, "backward": 13.48},
+                                               "achieved_tflops": {"forward": 6.74 / tf if tf else None, "backward": 13.48 / tb if tb else None}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
             o = Oracle(f32=True)
             x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
             w = np.random.default_rng(1).standard_normal((256, 256, 3, 3), dtype=np.float32) * 0.01
             o.conv3x3(x[:, :10, :10], w)
-            t0 = time.perf_counter()
             o.conv3x3(x, w)
-            t = time.perf_counter() - t0
             fl = 2 * 256 * 256 * 9 * 64 * 64
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 10.0 and reps < 20000:        # ~10 s of CPU work
+                o.conv3x3(x, w)
+                reps += 1
+            t = time.perf_counter() - t0
             cores = os.cpu_count() or 1
-            result["cpu_baseline"] = {"value": (fl / t) / (flop_scene / 3), "unit": "planes/s", "cores": cores, "kind": "port",
-                                      "sample": "one 256->256 3x3 conv on a 66x66 tile (%.2f GFLOP, %.2f s, C oracle fp32 OpenMP %d threads), "
-                                                "scaled by FLOPs to a whole plane" % (fl / 1e9, t, cores)}
+            result["cpu_baseline"] = {"value": (reps * fl / t) / (flop_scene / 3), "unit": "planes/s", "cores": cores, "kind": "port",
+                                      "sample": "%d x one 256->256 3x3 conv on a 66x66 tile (%.2f GFLOP each, %.1f s in total, C oracle fp32 OpenMP "
+                                                "%d threads), scaled by FLOPs to a whole plane" % (reps, fl / 1e9, t, cores)}
         print(json.dumps(result), flush=True)
 
 
