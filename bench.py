@@ -343,7 +343,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
             osc = o.scene(pl, mc.box_coords[sid].numpy())
             dc = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
             df = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
-            n = 48
+            n = 256                                  # ~10 s of single-threaded CPU work
             rn = rays[:n].cpu().numpy()
             gg = np.full((n, 3), 1e-3, np.float32)
             t0 = time.perf_counter()
