@@ -57,8 +57,10 @@ typedef struct nvsr_scene {
 
 int nvsr_version(void);
 
-/* Arithmetic of the decoder GEMMs inside the fused render pass (nvsr_render_pass*, N >= 16384 rays).  Inputs, outputs, accumulation
- * and everything outside the GEMMs are f32 in every mode.
+/* Arithmetic of the decoder GEMMs: the fused render pass (nvsr_render_pass*, N >= 16384 rays) and the training kernels
+ * (nvsr_decode_rays*, nvsr_render_pass_backward_gates, nvsr_decoder_weight_grad -- these use 3 limbs whenever a limb mode is selected:
+ * what feeds a gradient stays f32-grade; a forward and the backward that consumes its gates / record must run in the same setting).
+ * Inputs, outputs, accumulation and everything outside the GEMMs are f32 in every mode.
  *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products
  *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs, 6 of the 9 limb products on v_mfma_f32_32x32x16_bf16
  *                     (dropped terms <= 2^-24 |w||x| per product: f32-grade), 2.7x the f32 matrix rate
