@@ -33,7 +33,11 @@ __device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[ib][r] = ((k.m[ib >> 1] >> ((ib & 1) * 16 + r)) & 1u) ? g[ib][r] : 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            // gate bit sign-extended to 0 / ~0 (v_bfe_i32), then one v_and: 2 VALU per element instead of extract + compare + select
+            const int keep = __builtin_amdgcn_sbfe((int)k.m[ib >> 1], (ib & 1) * 16 + r, 1);
+            g[ib][r] = __int_as_float(__float_as_int(g[ib][r]) & keep);
+        }
 }
 
 // feature gradients of one plane (acc2: rows c = 32b + (r&3) + 8(r>>2) + 4h) -> LDS tile [pt][48] -> atomics into the plane
