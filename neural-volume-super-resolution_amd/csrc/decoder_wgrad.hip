@@ -9,6 +9,8 @@
 // f32x4 of G (4 output rows of 4 MFMAs) and one f32x2 of X (2 input columns) for slot pair (q, q+1), so a half-wave reads whole
 // 512-byte / 256-byte rows.  A workgroup owns a [128 out x 64 in] block of one layer for a slab of slots; its 4 waves split the
 // slab, reduce through LDS and add the block into the gradient blob (state-dict order) with float atomics.
+#include <cstdlib>
+
 #include "limb_core.h"
 
 namespace nvsr {
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, lo
 // NB i .. NB i + NB - 1 -> the B operands of NB column tiles) -- every row still a contiguous 512-byte read per half wave -- and splits
 // each operand once: 4 + NB splits (5.5 VALU per value) feed 4 * NB * 6 MFMAs.  With NB = 4 a wave owns the whole [128 x 128] block of a
 // hidden layer (256 accumulators, AGPRs; one wave per SIMD) and G is read once per layer; the two 64-column leftovers (density layer 0,
-// columns 128..191 of rgb layer 0) run with NB = 2.  The next 16 rows are loaded while the current ones are multiplied.
+// columns 128..191 of rgb layer 0) are padded to whole blocks (see the launcher).  The next 16 rows are loaded while the current ones are
+// multiplied.
 template <int NB>
 __device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int slab, float* tile, float* __restrict__ grad) {
     typedef float xvec __attribute__((ext_vector_type(NB)));
@@ -321,26 +324,24 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
         jobs.j[n++] = WJob{G, X, xstride, col0, w_off, in_total, b_off, nb};
     };
     if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32) {
-        // limb kernels: the 7 whole [128 x 128] blocks, then the two 64-column leftovers
+        // limb kernel: 9 [128 x 128] blocks
         for (int l = 1; l <= 3; ++l) {
             const int wd = N_DEN_W1 + (l - 1) * N_HID_STRIDE, wr = N_RGB_W1 + (l - 1) * N_HID_STRIDE;
             add(rec.Gd + l * LP, rec.Hd + (l - 1) * LP, HID, 0, wd, HID, wd + HID * HID, 4);
             add(rec.Gr + l * LP, rec.Hr + (l - 1) * LP, HID, 0, wr, HID, wr + HID * HID, 4);
         }
         add(rec.Gr, rec.Xr, 4 * C, 0, N_RGB_W0, 4 * C, N_RGB_B0, 4);
-        add(rec.Gr, rec.Xr, 4 * C, 128, N_RGB_W0, 4 * C, -1, 2);
-        add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0, 2);
-        // 7 whole blocks x 32 slabs = 224 workgroups (one 4-wave workgroup per CU, every block flushed 32 times), then the two 64-column
-        // blocks with 128 shorter slabs each
-        auto slab_for = [&](int per_block) {
-            long sl = (P + per_block - 1) / per_block;
-            return ((sl + 255) / 256) * 256;
-        };
-        const long s4 = slab_for(32), s2 = slab_for(128);
-        hipLaunchKernelGGL(decoder_wgrad_limb_kernel<4>, dim3((unsigned)((P + s4 - 1) / s4), 7), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, 0, P,
+        // The two 64-column leftovers (columns 128..191 of rgb layer 0, density layer 0) as whole [128 x 128] blocks too: their upper 64
+        // columns read past the row into the next row of the record (always inside the allocation: Xd is followed by Hd, Xr by Hr) and are
+        // dropped at the flush (col >= in_total) -- twice the MFMAs for those two blocks, but the contraction is bound by reading G, which
+        // each of them reads once either way, and 9 x 28 = 252 workgroups are one round of the chip.  (As a second, short launch of
+        // NB = 2 blocks they cost 0.19 ms per pass: 1.27 -> 1.14 ms for contraction + heads of a fine pass on the same box.)
+        add(rec.Gr, rec.Xr, 4 * C, 128, N_RGB_W0, 4 * C, -1, 4);
+        add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0, 4);
+        long s4 = (P + 27) / 28;
+        s4 = ((s4 + 255) / 256) * 256;
+        hipLaunchKernelGGL(decoder_wgrad_limb_kernel<4>, dim3((unsigned)((P + s4 - 1) / s4), 9), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, 0, P,
                            (int)s4, grad_natural);
-        hipLaunchKernelGGL(decoder_wgrad_limb_kernel<2>, dim3((unsigned)((P + s2 - 1) / s2), 2), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, 7, P,
-                           (int)s2, grad_natural);
     } else {
         add(rec.Gd, rec.Xd, 64, 0, N_DEN_W0, C, N_DEN_B0, 2);
         for (int l = 1; l <= 3; ++l)
