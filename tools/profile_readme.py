@@ -42,7 +42,7 @@ depths %s, inverse-CDF resampling + merge %s (2.75 ms with the O(n^2) rank sort 
 pass: %s of HBM traffic.
 Train steps over the round: planes + decoders 10.15 ms (`r01d`) -> 8.70 (`r01e`: no host wait inside the step, limb weight gradient) ->
 %.2f ms (limb forward / backward, run-merged atomics, ray-major record); planes only 4.89 -> %.2f ms.  Kernel split of the planes + decoder
-step (`%s_train_dec_kernel_stats.csv`): backward %s, forward %s, contraction %s + %s, heads %s.
+step (`%s_train_dec_kernel_stats.csv`): backward %s, forward %s, contraction %s, heads %s.
 
 """ % (tag, title, tag, tag, tag, tag,
        R["value"], R["ms_per_step"], R["roofline"]["kernel_ms"], kst("render", "render_pass3_kernel"), R["roofline"]["achieved"], 100 * R["roofline"]["frac"], PM["traffic_bytes"] / 1e9,
@@ -54,8 +54,7 @@ step (`%s_train_dec_kernel_stats.csv`): backward %s, forward %s, contraction %s 
        PM["sr"]["traffic_bytes"] / 1e9 / SR["ms_per_step"],
        tag, st("get_ray_bundle"), st("pack_rays"), st("coarse depths"), st("sample_pdf"), st("plane sampling"),
        TD["ms_per_step"], T["ms_per_step"], tag,
-       kst("train_dec", "backward_gates"), kst("train_dec", "decode_rays"), kst("train_dec", "wgrad_limb_kernel<4>"), kst("train_dec", "wgrad_limb_kernel<2>"),
-       kst("train_dec", "head_wgrad"))
+       kst("train_dec", "backward_gates"), kst("train_dec", "decode_rays"), kst("train_dec", "wgrad_limb_kernel<4>"), kst("train_dec", "head_wgrad"))
 path = P("r01_README.md")
 s = open(path).read()
 a = s.index("## %s (" % tag)
