@@ -59,22 +59,32 @@ int nvsr_version(void);
 
 /* Arithmetic of the decoder GEMMs: the fused render pass (nvsr_render_pass*, N >= 16384 rays) and the training kernels
  * (nvsr_decode_rays*, nvsr_render_pass_backward_gates, nvsr_decoder_weight_grad -- these use 3 limbs whenever a limb mode is selected:
- * what feeds a gradient stays f32-grade; a forward and the backward that consumes its gates / record must run in the same setting).
+ * what feeds a gradient stays close to f32; a forward and the backward that consumes its gates / record must run in the same mode).
  * Inputs, outputs, accumulation and everything outside the GEMMs are f32 in every mode.
- *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products
- *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs, 6 of the 9 limb products on v_mfma_f32_32x32x16_bf16
- *                     (dropped terms <= 2^-24 |w||x| per product: f32-grade), 2.7x the f32 matrix rate
- *   NVSR_ARITH_BF16X2 2 limbs (16 significant bits per operand), 3 products, 5.3x
- * Process-wide; the initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | bf16x2. */
+ *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation -- the reference's arithmetic
+ *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs (8 + 8 + 8 significant bits, by truncation), the products
+ *                     Wh(xh + xm + xl) + Wm(xh + xm) + Wl xh on v_mfma_f32_32x32x16_bf16, 2.7x the f32 matrix rate.  The three dropped
+ *                     products are bounded by |Wm xl| + |Wl xm| + |Wl xl| < (2^-23 + 2^-23 + 2^-30) |W||x|  (truncation limbs:
+ *                     |m| < 2^-8 |v|, |l| < 2^-16 |v| relative to the leading limb's binade, i.e. < 2^-7, 2^-15 of |v| at worst):
+ *                     about TWO f32 roundings per product in the worst case, and because truncated limbs carry the operand's sign the
+ *                     error is a one-sided bias of the sign of W x, which adds up over K instead of averaging out.  Measured worst case
+ *                     on adversarial operands (all mantissa bits set, K = 192): tests/test_hip_parity.py::test_limb_error_bound.
+ *                     NOT bit-grade f32; it is the default because every parity tolerance of the path (2e-5 on decoder outputs) holds.
+ *   NVSR_ARITH_BF16X2 2 limbs (16 significant bits per operand), 3 products, 5.3x; error <= 2^-15 |W||x| per product (opt-in)
+ * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
+ * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | bf16x2
+ * and which nvsr_set_decoder_arithmetic changes.  Nothing but that default is process-global: calls with explicit modes are re-entrant
+ * across threads and streams. */
+#define NVSR_ARITH_INHERIT (-1)
 #define NVSR_ARITH_F32 0
 #define NVSR_ARITH_BF16X2 2
 #define NVSR_ARITH_BF16X3 3
 #define NVSR_ARITH_DEFAULT NVSR_ARITH_BF16X3
 int nvsr_get_decoder_arithmetic(void);
 int nvsr_set_decoder_arithmetic(int mode);
-/* Same for the 3x3 convolutions of the SR network: forward and data gradient of the layers with Cin % 16 == 0 and a multiple of 256, or at
- * most 64, output channels (every layer of EDSR(256); other shapes always use the f32 kernel), and every weight gradient:
- * NVSR_ARITH_F32 or NVSR_ARITH_BF16X3.
+/* Same for the 3x3 convolutions of the SR network (process default + *_arith twins): forward and data gradient of the layers with
+ * Cin % 16 == 0 and a multiple of 256, or at most 64, output channels (every layer of EDSR(256); other shapes always use the f32 kernel),
+ * and every weight gradient: NVSR_ARITH_F32 or NVSR_ARITH_BF16X3 (same error bound as above).
  * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3. */
 #define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_BF16X3
 int nvsr_get_conv_arithmetic(void);
@@ -286,6 +296,52 @@ int64_t nvsr_planes_sr_backward_workspace_floats(int C, int R0, int R1, int hid,
 int nvsr_planes_sr_backward(int C, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up, int pad,
                             int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
                             float* workspace, nvsr_stream_t stream);
+
+/* ---- per-call arithmetic -----------------------------------------------------------------------------------------------------
+ * Twins of the entry points above that run decoder GEMMs or SR convolutions, with the arithmetic as an explicit argument
+ * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_BF16X2 (decoder forward only) | NVSR_ARITH_INHERIT).  Same arguments, same
+ * semantics; the un-suffixed entry points are these called with NVSR_ARITH_INHERIT.  A backward call must be given the mode of the
+ * forward whose gates / record / activations it consumes (the host mirror stores it with the autograd context).
+ * rows_per_tile (convolutions): 0 = the launcher's cost model, 2 | 3 | 4 = force that row-tile instantiation of the wide kernels
+ * (the results are identical; the parity tests force every instantiation). */
+int nvsr_render_pass_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                           const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                           float* raw_out /* or NULL */, int arithmetic, nvsr_stream_t stream);
+int nvsr_decode_rays_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                           float* raw, uint32_t* gates /* or NULL */, float* record /* or NULL */, int arithmetic, nvsr_stream_t stream);
+int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
+                           const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u,
+                           const float* noise_coarse, const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c,
+                           float* rgb_f, float* disp_f, float* acc_f, float* workspace, int arithmetic, nvsr_stream_t stream);
+int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                          const float* rays, const float* z, const float* g_raw, const uint32_t* gates,
+                                          float* const* grad_planes, float* view_ws, float* record, int arithmetic, nvsr_stream_t stream);
+int nvsr_decoder_weight_grad_arith(int64_t N, int S, const float* record, float* grad_natural, int arithmetic, nvsr_stream_t stream);
+int nvsr_conv3x3_arith(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
+                       int arithmetic, int rows_per_tile, nvsr_stream_t stream);
+int nvsr_conv3x3_dgrad_arith(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, int arithmetic,
+                             int rows_per_tile, nvsr_stream_t stream);
+int nvsr_conv3x3_wgrad_arith(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
+                             int arithmetic, nvsr_stream_t stream);
+int nvsr_edsr_forward_batch_arith(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                                  float* out, float* workspace, int arithmetic, nvsr_stream_t stream);
+int nvsr_edsr_forward_train_arith(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                                  float* out, float* acts, int arithmetic, nvsr_stream_t stream);
+int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid,
+                             int nblocks, int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, int arithmetic,
+                             nvsr_stream_t stream);
+int nvsr_planes_sr_arith(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                         const float* roi, const float* mean, const float* std_, float* out, float* workspace, int arithmetic,
+                         nvsr_stream_t stream);
+int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up,
+                               int pad, int over, const float* roi, const float* mean, const float* stdv, float* const* out,
+                               float* workspace, int arithmetic, nvsr_stream_t stream);
+int nvsr_planes_sr_train_arith(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                               const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                               int arithmetic, nvsr_stream_t stream);
+int nvsr_planes_sr_backward_arith(int C, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up,
+                                  int pad, int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural,
+                                  float* d_lr, float* workspace, int arithmetic, nvsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,8 +15,27 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+STAMP_PATH = LIB_PATH + ".flags"
+
+
+def _flag_stamp():
+    """what the library at LIB_PATH must have been built with: the compiler flags of every file + the experiment flags of the
+    environment.  Stored next to the library; a library whose stamp differs (e.g. an interrupted `NVSR_EXTRA_HIPCC_FLAGS=-DBL_ABLATE=...`
+    experiment, which produces WRONG results by design) is stale no matter how new it is."""
+    extra = os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", "").split()
+    return " ".join(HIPCC_FLAGS) + " | " + " ".join("%s:%s" % kv for kv in sorted((k, ",".join(v)) for k, v in PER_FILE_FLAGS.items())) + " | " + " ".join(extra)
+
+
+def _stamp_matches():
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read() == _flag_stamp()
+    except OSError:
+        return False
+
+
 def _stale():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not _stamp_matches():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")) + [os.path.abspath(__file__)]
@@ -28,13 +47,15 @@ def _stale():
 # sched_barriers, the hand-placed interleave is gone and hundreds of registers spill.
 # decode_limb.hip: same blocks, same reason (250 spilled registers with the vectorizer, none without).
 PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"], "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
-OBJ_DIR = os.path.join(CSRC, "_obj")
+OBJ_DIR = os.path.join(CSRC, "_obj")      # (of the product build; experiment variants use <out_path>.obj)
 
 
 def _compile_one(hipcc, src, verbose):
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
     deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")) + [os.path.abspath(__file__)]
-    if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+    stamp = obj + ".flags"
+    same_flags = os.path.exists(stamp) and open(stamp).read() == _flag_stamp()
+    if same_flags and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + PER_FILE_FLAGS.get(os.path.basename(src), [])
     flags += os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", "").split()       # experiments (e.g. -DR3_STAMP=1); use with build_extension(force=True)
@@ -42,11 +63,21 @@ def _compile_one(hipcc, src, verbose):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(obj + ".flags", "w") as f:
+        f.write(_flag_stamp())
     return obj
 
 
-def build_extension(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950: csrc/*.hip -> one object each (in parallel) -> libnvsr_hip.so.  Returns the library path."""
+def build_extension(force=False, verbose=False, out_path=None):
+    """hipcc --offload-arch=gfx950: csrc/*.hip -> one object each (in parallel) -> libnvsr_hip.so.  Returns the library path.
+    out_path: build an EXPERIMENT variant (NVSR_EXTRA_HIPCC_FLAGS) to another file, with its own object directory, and leave the product
+    library alone -- load it with NVSR_HIP_LIB=<out_path> (capi.py); tools/*.sh do this."""
+    global OBJ_DIR
+    if out_path is not None:
+        return _build_variant(out_path, verbose)
+    if os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", "").split() and not os.environ.get("NVSR_ALLOW_INPLACE_EXPERIMENT"):
+        raise RuntimeError("NVSR_EXTRA_HIPCC_FLAGS is set: experiment builds go to a separate file (build_extension(out_path=...) + "
+                           "NVSR_HIP_LIB), never over the product library")
     if not force and not _stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
@@ -63,4 +94,24 @@ def build_extension(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP_PATH, "w") as f:
+        f.write(_flag_stamp())
     return LIB_PATH
+
+
+def _build_variant(out_path, verbose):
+    """all sources with the current NVSR_EXTRA_HIPCC_FLAGS -> out_path (objects under <out_path>.obj/)"""
+    global OBJ_DIR
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    saved = OBJ_DIR
+    OBJ_DIR = os.path.abspath(out_path) + ".obj"
+    try:
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(lambda src: _compile_one(hipcc, src, verbose), sources()))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out_path])
+    finally:
+        OBJ_DIR = saved
+    return out_path

@@ -105,6 +105,23 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_planes_sr_train": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_planes_sr_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr_backward": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")
+    "nvsr_render_pass_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_decode_rays_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_render_rays_arith": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _i, _vp], _i),
+    "nvsr_render_pass_backward_gates_arith": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _i, _vp], _i),
+    "nvsr_decoder_weight_grad_arith": ([_i64, _i, _vp, _vp, _i, _vp], _i),
+    "nvsr_conv3x3_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp], _i),
+    "nvsr_conv3x3_dgrad_arith": ([_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp], _i),
+    "nvsr_conv3x3_wgrad_arith": ([_vp, _vp, _i, _i, _i, _i, C.c_float, _vp, _vp, _i, _vp], _i),
+    "nvsr_edsr_forward_batch_arith": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
+    "nvsr_edsr_forward_train_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
+    "nvsr_edsr_backward_arith": ([_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_planes_sr_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_planes_sr_batch_arith": ([C.POINTER(C.c_void_p), _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _i, _vp], _i),
+    "nvsr_planes_sr_train_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_planes_sr_backward_arith": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     # positional-encoding baseline (csrc/posenc.hip)
     "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
@@ -114,6 +131,27 @@ _lib = None
 
 
 ARITHMETIC = {"f32": 0, "bf16x2": 2, "bf16x3": 3}
+ARITH_INHERIT = -1
+
+
+def arith_code(mode):
+    """'f32' | 'bf16x3' | 'bf16x2' | None (= the process default) | an NVSR_ARITH_* code -> the int the *_arith entry points take"""
+    if mode is None:
+        return ARITH_INHERIT
+    if isinstance(mode, str):
+        return ARITHMETIC[mode]
+    return int(mode)
+
+
+def resolve_decoder_arithmetic(mode=None):
+    """the concrete NVSR_ARITH_* code a call made now with `mode` runs in (what a forward stores for its backward)"""
+    code = arith_code(mode)
+    return lib().nvsr_get_decoder_arithmetic() if code == ARITH_INHERIT else code
+
+
+def resolve_conv_arithmetic(mode=None):
+    code = arith_code(mode)
+    return lib().nvsr_get_conv_arithmetic() if code == ARITH_INHERIT else code
 
 
 def set_decoder_arithmetic(mode):

@@ -487,17 +487,18 @@ int nvsr_composite_rays(int64_t N, int S, const float* raw, const float* z, cons
 }
 
 int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf) {
-    const int64_t base = N * (int64_t)(2 * Nc + (Nf > 0 ? Nc + Nf : 0));
+    // z_c [N,Nc], w_c [N,Nc], z_f [N,Nc+Nf], each rounded up to 4 floats so that every sub-buffer (raw_ws included) stays 16-byte aligned
+    const int64_t base = 2 * round4(N * (int64_t)Nc) + (Nf > 0 ? round4(N * (int64_t)(Nc + Nf)) : 0);
     return base + (N < NVSR_FUSED_MIN_RAYS ? 4 * N * (int64_t)(Nc + (Nf > 0 ? Nf : 0)) : 0);   // + raw [N,S,4] for the un-fused path
 }
 
 static int render_one_pass(const nvsr_scene* scene, const float* packed, int64_t N, int S, const float* rays, const float* z,
                            const float* noise, int white, float* rgb, float* disp, float* acc, float* weights, float* raw_ws,
-                           nvsr_stream_t stream) {
+                           int arithmetic, nvsr_stream_t stream) {
     if (N >= NVSR_FUSED_MIN_RAYS)
-        return nvsr_render_pass(scene, packed, N, S, rays, z, noise, white, rgb, disp, acc, weights, nullptr, stream);
+        return nvsr_render_pass_arith(scene, packed, N, S, rays, z, noise, white, rgb, disp, acc, weights, nullptr, nullptr, arithmetic, stream);
     // few rays: one workgroup per 128 rays would leave most CUs idle -> tile over samples, composite separately
-    if (int e = nvsr_decode_rays(scene, packed, N, S, rays, z, raw_ws, stream)) return e;
+    if (int e = nvsr_decode_rays_arith(scene, packed, N, S, rays, z, raw_ws, nullptr, nullptr, arithmetic, stream)) return e;
     // rd = rays[:, 3:6]: the composite kernel reads rd with stride 3, so pass a strided view through a tiny repack
     return nvsr_composite_rays(N, S, raw_ws, z, rays, noise, white, rgb, disp, acc, weights, nullptr, stream);
 }
@@ -506,23 +507,32 @@ int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const 
                      const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u, const float* noise_coarse,
                      const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f,
                      float* workspace, nvsr_stream_t stream) {
+    return nvsr_render_rays_arith(scene, packed_coarse, packed_fine, N, Nc, Nf, rays, lindisp, white_bkgd, t_rand, u, noise_coarse, noise_fine,
+                                  rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, workspace, NVSR_ARITH_INHERIT, stream);
+}
+
+int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
+                           const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u, const float* noise_coarse,
+                           const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f,
+                           float* workspace, int arithmetic, nvsr_stream_t stream) {
     if (!workspace) return NVSR_ERR_NULL;
+    if (!aligned16(workspace)) return NVSR_ERR_ALIGN;
     if (N < 0 || Nc < 1 || Nf < 0) return NVSR_ERR_SHAPE;
     if (Nf > 0 && (Nc < 3 || Nc > 256 || Nf > 256)) return NVSR_ERR_SHAPE;
     if (Nf > 0 && (!packed_fine || !rgb_f || !disp_f || !acc_f)) return NVSR_ERR_NULL;
     if (N == 0) return NVSR_OK;
     float* z_c = workspace;
-    float* w_c = z_c + N * Nc;
-    float* z_f = w_c + N * Nc;
-    float* raw_ws = z_f + (Nf > 0 ? N * (int64_t)(Nc + Nf) : 0);
+    float* w_c = z_c + round4(N * (int64_t)Nc);
+    float* z_f = w_c + round4(N * (int64_t)Nc);
+    float* raw_ws = z_f + (Nf > 0 ? round4(N * (int64_t)(Nc + Nf)) : 0);
     int e = nvsr_coarse_z(N, Nc, rays, lindisp, t_rand, z_c, stream);
     if (e) return e;
     e = render_one_pass(scene, packed_coarse, N, Nc, rays, z_c, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, Nf > 0 ? w_c : nullptr,
-                        raw_ws, stream);
+                        raw_ws, arithmetic, stream);
     if (e || Nf <= 0) return e;
     e = nvsr_importance_resample(N, Nc, Nf, z_c, w_c, u, z_f, stream);
     if (e) return e;
-    return render_one_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, raw_ws, stream);
+    return render_one_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, raw_ws, arithmetic, stream);
 }
 
 }  // extern "C"

@@ -310,7 +310,13 @@ __global__ __launch_bounds__(256 * HW_GROUPS) void head_wgrad_kernel(const float
 
 using namespace nvsr;
 
+extern "C" int nvsr_internal_resolve_decoder_arith(int arithmetic);      // render.hip
 extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, float* grad_natural, nvsr_stream_t stream) {
+    return nvsr_decoder_weight_grad_arith(N, S, record, grad_natural, NVSR_ARITH_INHERIT, stream);
+}
+extern "C" int nvsr_decoder_weight_grad_arith(int64_t N, int S, const float* record, float* grad_natural, int arithmetic, nvsr_stream_t stream) {
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    if (arith < 0) return NVSR_ERR_SHAPE;
     if (!record || !grad_natural) return NVSR_ERR_NULL;
     if (!aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
@@ -323,7 +329,7 @@ extern "C" int nvsr_decoder_weight_grad(int64_t N, int S, const float* record, f
     auto add = [&](const float* G, const float* X, int xstride, int col0, int w_off, int in_total, int b_off, int nb) {
         jobs.j[n++] = WJob{G, X, xstride, col0, w_off, in_total, b_off, nb};
     };
-    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32) {
+    if (arith != NVSR_ARITH_F32) {
         // limb kernel: 9 [128 x 128] blocks
         for (int l = 1; l <= 3; ++l) {
             const int wd = N_DEN_W1 + (l - 1) * N_HID_STRIDE, wr = N_RGB_W1 + (l - 1) * N_HID_STRIDE;

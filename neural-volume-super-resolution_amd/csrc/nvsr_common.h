@@ -112,6 +112,7 @@ __host__ __device__ inline long record_row(long ray, int s, long N, int S) { (vo
 #endif
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t round4(int64_t n) { return (n + 3) / 4 * 4; }      // floats -> a multiple of 16 bytes
 
 // torch.linspace(0, 1, n) element i in fp32 (symmetric two-sided form used by ATen's RangeFactories)
 __host__ __device__ inline float linspace01(int i, int n) {

@@ -247,6 +247,12 @@ int nvsr_get_decoder_arithmetic(void) {
     return g_decoder_arithmetic;
 }
 
+/* NVSR_ARITH_INHERIT -> the process default; anything that is not a mode -> -1 */
+int nvsr_internal_resolve_decoder_arith(int arithmetic) {
+    if (arithmetic == NVSR_ARITH_INHERIT) return nvsr_get_decoder_arithmetic();
+    return (arithmetic == NVSR_ARITH_F32 || arithmetic == NVSR_ARITH_BF16X3 || arithmetic == NVSR_ARITH_BF16X2) ? arithmetic : -1;
+}
+
 int nvsr_set_decoder_arithmetic(int mode) {
     if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_BF16X2) return NVSR_ERR_SHAPE;
     g_decoder_arithmetic = mode;
@@ -288,11 +294,18 @@ int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, i
 
 int nvsr_decode_rays(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                      float* raw, nvsr_stream_t stream) {
-    return nvsr_decode_rays_ex(scene, packed_decoder, N, S, rays, z, raw, nullptr, nullptr, stream);
+    return nvsr_decode_rays_arith(scene, packed_decoder, N, S, rays, z, raw, nullptr, nullptr, NVSR_ARITH_INHERIT, stream);
 }
 
 int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                         float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
+    return nvsr_decode_rays_arith(scene, packed_decoder, N, S, rays, z, raw, gates, record, NVSR_ARITH_INHERIT, stream);
+}
+
+int nvsr_decode_rays_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                           float* raw, uint32_t* gates, float* record, int arithmetic, nvsr_stream_t stream) {
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    if (arith < 0) return NVSR_ERR_SHAPE;
     if (int e = check_scene(scene)) return e;
     if (!packed_decoder || !rays || !z || !raw) return NVSR_ERR_NULL;
     if (!aligned16(packed_decoder) || !aligned16(raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
@@ -300,7 +313,7 @@ int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, in
     if (N == 0) return NVSR_OK;
     if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
     // bf16-limb matrix pipe (decode_limb.hip), always with 3 limbs: the gates and the record feed gradients
-    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32)
+    if (arith != NVSR_ARITH_F32)
         return nvsr_decode_rays_limb_launch(scene, packed_decoder, N, S, rays, z, raw, gates, record, stream);
     const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
@@ -319,13 +332,21 @@ int nvsr_decode_rays_ex(const nvsr_scene* scene, const float* packed_decoder, in
 int nvsr_render_pass_ex(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                         const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
                         float* raw_out, nvsr_stream_t stream) {
+    return nvsr_render_pass_arith(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out,
+                                  NVSR_ARITH_INHERIT, stream);
+}
+
+int nvsr_render_pass_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                           const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                           float* raw_out, int arithmetic, nvsr_stream_t stream) {
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    if (arith < 0) return NVSR_ERR_SHAPE;
     if (int e = check_scene(scene)) return e;
     if (!packed_decoder || !rays || !z || !rgb || !disp || !acc) return NVSR_ERR_NULL;
     if (!aligned16(packed_decoder) || (raw_out && !aligned16(raw_out))) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     if (N >= 16384 && !getenv("NVSR_RENDER_V1")) {   // two-tiles-per-wave kernels; NVSR_RENDER_V1=1 selects the first-generation kernel
-        const int arith = nvsr_get_decoder_arithmetic();
         if (arith != NVSR_ARITH_F32)                 // bf16-limb matrix pipe (render3.hip)
             return nvsr_render_pass3_launch(arith, scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, stream);
         return nvsr_render_pass2_launch(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, stream);
@@ -340,7 +361,8 @@ int nvsr_render_pass_ex(const nvsr_scene* scene, const float* packed_decoder, in
 int nvsr_render_pass(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                      const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,
                      nvsr_stream_t stream) {
-    return nvsr_render_pass_ex(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, nullptr, stream);
+    return nvsr_render_pass_arith(scene, packed_decoder, N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, nullptr, NVSR_ARITH_INHERIT,
+                                  stream);
 }
 
 }  // extern "C"

@@ -547,7 +547,7 @@ extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* sce
                                                            int64_t N, int S, const float* rays, const float* z, const float* g_raw,
                                                            const uint32_t* gates, float* const* grad_planes, float* view_ws, float* record,
                                                            nvsr_stream_t stream);
-extern "C" int nvsr_get_decoder_arithmetic(void);
+extern "C" int nvsr_internal_resolve_decoder_arith(int arithmetic);      // render.hip
 
 extern "C" {
 
@@ -628,6 +628,15 @@ int nvsr_render_pass_backward_ex(const nvsr_scene* scene, const float* packed_de
 int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                     const float* rays, const float* z, const float* g_raw, const uint32_t* gates, float* const* grad_planes,
                                     float* view_ws, float* record, nvsr_stream_t stream) {
+    return nvsr_render_pass_backward_gates_arith(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, gates, grad_planes, view_ws, record,
+                                                 NVSR_ARITH_INHERIT, stream);
+}
+
+int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
+                                          const float* rays, const float* z, const float* g_raw, const uint32_t* gates,
+                                          float* const* grad_planes, float* view_ws, float* record, int arithmetic, nvsr_stream_t stream) {
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    if (arith < 0) return NVSR_ERR_SHAPE;
     if (!scene || !packed_decoder || !packed_bwd || !rays || !z || !g_raw || !gates) return NVSR_ERR_NULL;
     if (!grad_planes && !record) return NVSR_ERR_NULL;
     GradPlanes gp;
@@ -639,7 +648,7 @@ int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    if (nvsr_get_decoder_arithmetic() != NVSR_ARITH_F32) {       // bf16-limb matrix pipe, always 3 limbs (render_bwd_limb.hip)
+    if (arith != NVSR_ARITH_F32) {       // bf16-limb matrix pipe, always 3 limbs (render_bwd_limb.hip)
         if (int e = nvsr_render_pass_backward_gates_limb_launch(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, gates, grad_planes,
                                                                 view_ws, record, stream))
             return e;

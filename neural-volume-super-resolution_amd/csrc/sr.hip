@@ -412,8 +412,13 @@ extern "C" int nvsr_set_conv_arithmetic(int mode) {
     return NVSR_OK;
 }
 
+int conv_resolve_arith(int arith) { return arith == NVSR_ARITH_INHERIT ? nvsr_get_conv_arithmetic() : arith; }
+
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad, int batch) {
+                hipStream_t stream, int pad, int batch, ConvExec cx) {
+    const int arith = conv_resolve_arith(cx.arith);
+    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4)) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
@@ -423,14 +428,14 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                          : epilogue == EPI_ADD_CENTER ? (long)Cout * (Ho - 4) * (Wo - 4) : out_bs;
     const unsigned* wlimb = conv_limb_eligible(Cin, Cout) ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) : nullptr;
     ConvParams p{in, wpk, wlimb, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
-    if (wlimb && nvsr_get_conv_arithmetic() != NVSR_ARITH_F32 && p.ncb_total == 2) {
+    if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
         hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
-    if (wlimb && nvsr_get_conv_arithmetic() != NVSR_ARITH_F32) {
+    if (wlimb && arith != NVSR_ARITH_F32) {
         // bf16-limb kernel: 4-wave workgroups of 256 output channels x PB rows x 32 pixels; same choice of the row count as below
         p.ncg = p.ncb_total / 8;
         dim3 grid((Wo + 31) / 32, 1, p.ncg * batch);
@@ -441,7 +446,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
-        if (const char* e = getenv("NVSR_CONV_LIMB_PB")) best_pb = atoi(e);       // experiments
+        if (cx.rows) best_pb = cx.rows;
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb_kernel<4>), grid, dim3(256), 0, stream, p);
         else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb_kernel<3>), grid, dim3(256), 0, stream, p);
@@ -462,6 +467,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
+        if (cx.rows) best_pb = cx.rows;
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (best_pb == 4) hipLaunchKernelGGL((conv3x3_kernel<4, 1, 4>), grid, dim3(256), 0, stream, p);
         else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_kernel<4, 1, 3>), grid, dim3(256), 0, stream, p);
@@ -515,20 +521,28 @@ int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nv
 }
 
 /* data gradient of nvsr_conv3x3 (epilogue 0): dy [Cout][H-2][W-2] -> dx [Cin][H][W]; packed_dgrad from nvsr_pack_conv3x3_dgrad */
-int nvsr_conv3x3_dgrad(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, nvsr_stream_t stream) {
+int nvsr_conv3x3_dgrad_arith(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, int arithmetic,
+                             int rows_per_tile, nvsr_stream_t stream) {
     if (!dy || !packed_dgrad || !dx) return NVSR_ERR_NULL;
     if (!aligned16(packed_dgrad)) return NVSR_ERR_ALIGN;
     if (H < 3 || W < 3) return NVSR_ERR_SHAPE;
-    return launch_conv(dy, Cout, H - 2, W - 2, packed_dgrad, Cin, EPI_NONE, nullptr, dx, (hipStream_t)stream, 2);
+    return launch_conv(dy, Cout, H - 2, W - 2, packed_dgrad, Cin, EPI_NONE, nullptr, dx, (hipStream_t)stream, 2, 1, ConvExec{arithmetic, rows_per_tile});
+}
+int nvsr_conv3x3_dgrad(const float* dy, int Cin, int H, int W, const float* packed_dgrad, int Cout, float* dx, nvsr_stream_t stream) {
+    return nvsr_conv3x3_dgrad_arith(dy, Cin, H, W, packed_dgrad, Cout, dx, NVSR_ARITH_INHERIT, 0, stream);
 }
 
 /* epilogue: 0 none, 1 ReLU, 2 residual (out = conv*0.1 + skip[..., 2:-2, 2:-2], skip = [Cout][H+2][W+2]), 3 PixelShuffle(2) */
-int nvsr_conv3x3(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
-                 nvsr_stream_t stream) {
+int nvsr_conv3x3_arith(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
+                       int arithmetic, int rows_per_tile, nvsr_stream_t stream) {
     if (!in || !packed || !out) return NVSR_ERR_NULL;
     if (epilogue < 0 || epilogue > 3 || (epilogue == EPI_RESIDUAL && !skip) || (epilogue == EPI_PIXEL_SHUFFLE && Cout % 4)) return NVSR_ERR_SHAPE;
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
-    return launch_conv(in, Cin, H, W, packed, Cout, epilogue, skip, out, (hipStream_t)stream);
+    return launch_conv(in, Cin, H, W, packed, Cout, epilogue, skip, out, (hipStream_t)stream, 0, 1, ConvExec{arithmetic, rows_per_tile});
+}
+int nvsr_conv3x3(const float* in, int Cin, int H, int W, const float* packed, int Cout, int epilogue, const float* skip, float* out,
+                 nvsr_stream_t stream) {
+    return nvsr_conv3x3_arith(in, Cin, H, W, packed, Cout, epilogue, skip, out, NVSR_ARITH_INHERIT, 0, stream);
 }
 
 /* EDSR(in_channels=Cin, out_channels=Cout, hidden_size=hid, n_blocks, scale_factor=2^n_up, padding=0)  (models.py:789-822).
@@ -578,10 +592,11 @@ int64_t nvsr_edsr_workspace_floats(int hid, int nblocks, int n_up, int H, int W)
 /* B planes at once ([B][Cin][H][W] -> [B][Cout][Ho][Wo]): one launch per layer, the batch index rides in the grid.  A 256-channel
  * layer of one 200^2 plane is only ~1.2-1.8 workgroup rounds on 256 CUs (28 % of the issue slots idle in the partial last round);
  * the 3 position planes of a scene together run 3.6-5.4 rounds.  workspace: B * nvsr_edsr_workspace_floats floats. */
-int nvsr_edsr_forward_batch(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
-                            float* out, float* workspace, nvsr_stream_t stream_) {
+int nvsr_edsr_forward_batch_arith(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                                  float* out, float* workspace, int arithmetic, nvsr_stream_t stream_) {
     if (!x || !packed || !out || !workspace) return NVSR_ERR_NULL;
     if (B < 1) return NVSR_ERR_SHAPE;
+    const ConvExec cx{conv_resolve_arith(arithmetic), 0};
     int Ho, Wo;
     if (int e = nvsr_edsr_out_size(H, W, nblocks, n_up, &Ho, &Wo)) return e;
     hipStream_t stream = (hipStream_t)stream_;
@@ -591,36 +606,40 @@ int nvsr_edsr_forward_batch(const float* x, int B, int Cin, int H, int W, const 
     int h = H, w = W, e;
     // conv_input
     float* cur = bufs[0];
-    if ((e = launch_conv(x, Cin, h, w, wp, hid, EPI_NONE, nullptr, cur, stream, 0, B))) return e;
+    if ((e = launch_conv(x, Cin, h, w, wp, hid, EPI_NONE, nullptr, cur, stream, 0, B, cx))) return e;
     wp += conv_packed_floats(Cin, hid); h -= 2; w -= 2;
     int ci = 0;                                   // index of `cur` in bufs
     for (int b = 0; b < nblocks; ++b) {           // _Residual_Block (models.py:777-786)
         float* t1 = bufs[(ci + 1) % 3];
         float* t2 = bufs[(ci + 2) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_RELU, nullptr, t1, stream, 0, B))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_RELU, nullptr, t1, stream, 0, B, cx))) return e;
         wp += conv_packed_floats(hid, hid);
-        if ((e = launch_conv(t1, hid, h - 2, w - 2, wp, hid, EPI_RESIDUAL, cur, t2, stream, 0, B))) return e;
+        if ((e = launch_conv(t1, hid, h - 2, w - 2, wp, hid, EPI_RESIDUAL, cur, t2, stream, 0, B, cx))) return e;
         wp += conv_packed_floats(hid, hid);
         cur = t2; ci = (ci + 2) % 3; h -= 4; w -= 4;
     }
     {   // conv_mid
         float* t = bufs[(ci + 1) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_NONE, nullptr, t, stream, 0, B))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, hid, EPI_NONE, nullptr, t, stream, 0, B, cx))) return e;
         wp += conv_packed_floats(hid, hid);
         cur = t; ci = (ci + 1) % 3; h -= 2; w -= 2;
     }
     for (int u = 0; u < n_up; ++u) {              // conv hid -> 4 hid + PixelShuffle(2), fused
         float* t = bufs[(ci + 1) % 3];
-        if ((e = launch_conv(cur, hid, h, w, wp, 4 * hid, EPI_PIXEL_SHUFFLE, nullptr, t, stream, 0, B))) return e;
+        if ((e = launch_conv(cur, hid, h, w, wp, 4 * hid, EPI_PIXEL_SHUFFLE, nullptr, t, stream, 0, B, cx))) return e;
         wp += conv_packed_floats(hid, 4 * hid);
         cur = t; ci = (ci + 1) % 3; h = (h - 2) * 2; w = (w - 2) * 2;
     }
-    return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream, 0, B);
+    return launch_conv(cur, hid, h, w, wp, Cout, EPI_NONE, nullptr, out, stream, 0, B, cx);
+}
+int nvsr_edsr_forward_batch(const float* x, int B, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up,
+                            float* out, float* workspace, nvsr_stream_t stream_) {
+    return nvsr_edsr_forward_batch_arith(x, B, Cin, H, W, packed, Cout, hid, nblocks, n_up, out, workspace, NVSR_ARITH_INHERIT, stream_);
 }
 
 int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
                       float* workspace, nvsr_stream_t stream_) {
-    return nvsr_edsr_forward_batch(x, 1, Cin, H, W, packed, Cout, hid, nblocks, n_up, out, workspace, stream_);
+    return nvsr_edsr_forward_batch_arith(x, 1, Cin, H, W, packed, Cout, hid, nblocks, n_up, out, workspace, NVSR_ARITH_INHERIT, stream_);
 }
 
 /* ---- training forward: every layer's input is kept for the backward pass (sr_bwd.hip) ---------------------------------- */
@@ -632,7 +651,12 @@ int64_t nvsr_edsr_acts_floats(int Cin, int Cout, int hid, int nblocks, int n_up,
 
 int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
                             float* acts, nvsr_stream_t stream_) {
+    return nvsr_edsr_forward_train_arith(x, Cin, H, W, packed, Cout, hid, nblocks, n_up, out, acts, NVSR_ARITH_INHERIT, stream_);
+}
+int nvsr_edsr_forward_train_arith(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
+                                  float* acts, int arithmetic, nvsr_stream_t stream_) {
     if (!x || !packed || !out || !acts) return NVSR_ERR_NULL;
+    const ConvExec cx{conv_resolve_arith(arithmetic), 0};
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
     EdsrPlan P;
     if (int e = edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return e;
@@ -641,7 +665,7 @@ int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* 
         const float* in = l ? acts + P.act_off[l] : x;
         float* o = (l + 1 < P.n) ? acts + P.act_off[l + 1] : out;
         const float* skip = (P.epi[l] == EPI_RESIDUAL) ? (l >= 2 ? acts + P.act_off[l - 1] : x) : nullptr;   // the block's input
-        if (int e = launch_conv(in, P.L[l].Cin, P.ih[l], P.iw[l], wp, P.L[l].Cout, P.epi[l], skip, o, (hipStream_t)stream_)) return e;
+        if (int e = launch_conv(in, P.L[l].Cin, P.ih[l], P.iw[l], wp, P.L[l].Cout, P.epi[l], skip, o, (hipStream_t)stream_, 0, 1, cx)) return e;
         wp += conv_packed_floats(P.L[l].Cin, P.L[l].Cout);
     }
     return NVSR_OK;
@@ -664,6 +688,12 @@ int64_t nvsr_planes_sr_workspace_floats(int Cc, int R0, int R1, int hid, int nbl
 int nvsr_planes_sr_batch(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
                          int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
                          nvsr_stream_t stream_) {
+    return nvsr_planes_sr_batch_arith(lr, B, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, NVSR_ARITH_INHERIT,
+                                      stream_);
+}
+int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
+                               int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
+                               int arithmetic, nvsr_stream_t stream_) {
     if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
     if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
     if (B < 1 || B > 64) return NVSR_ERR_SHAPE;
@@ -687,7 +717,7 @@ int nvsr_planes_sr_batch(const float* const* lr, int B, int Cc, int R0, int R1, 
                            Wp, pad, mean, stdv, xin + b * n_in);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
-    if (int e = nvsr_edsr_forward_batch(xin, B, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
+    if (int e = nvsr_edsr_forward_batch_arith(xin, B, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, arithmetic, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
@@ -709,11 +739,16 @@ int64_t nvsr_planes_sr_keep_floats(int Cc, int R0, int R1, int hid, int nblocks,
 
 static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                           const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
-                          nvsr_stream_t stream_);
+                          int arithmetic, nvsr_stream_t stream_);
 
 int nvsr_planes_sr(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* stdv, float* out, float* workspace, nvsr_stream_t stream_) {
-    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, nullptr, stream_);
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, nullptr, NVSR_ARITH_INHERIT, stream_);
+}
+int nvsr_planes_sr_arith(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                         const float* roi, const float* mean, const float* stdv, float* out, float* workspace, int arithmetic,
+                         nvsr_stream_t stream_) {
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, nullptr, arithmetic, stream_);
 }
 
 /* nvsr_planes_sr that keeps what the backward needs in `keep` (nvsr_planes_sr_keep_floats floats); same workspace */
@@ -721,12 +756,18 @@ int nvsr_planes_sr_train(const float* lr, int Cc, int R0, int R1, const float* p
                          const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
                          nvsr_stream_t stream_) {
     if (!keep) return NVSR_ERR_NULL;
-    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, keep, stream_);
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, keep, NVSR_ARITH_INHERIT, stream_);
+}
+int nvsr_planes_sr_train_arith(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
+                               const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
+                               int arithmetic, nvsr_stream_t stream_) {
+    if (!keep) return NVSR_ERR_NULL;
+    return planes_sr_impl(lr, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, keep, arithmetic, stream_);
 }
 
 static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                           const float* roi, const float* mean, const float* stdv, float* out, float* workspace, float* keep,
-                          nvsr_stream_t stream_) {
+                          int arithmetic, nvsr_stream_t stream_) {
     if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
     if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -746,9 +787,9 @@ static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* 
                        pad, mean, stdv, xin);
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     if (keep) {
-        if (int e = nvsr_edsr_forward_train(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, keep + ((int64_t)Cc * Hp * Wp + 3) / 4 * 4, stream_))
+        if (int e = nvsr_edsr_forward_train_arith(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, keep + ((int64_t)Cc * Hp * Wp + 3) / 4 * 4, arithmetic, stream_))
             return e;
-    } else if (int e = nvsr_edsr_forward(xin, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, stream_)) return e;
+    } else if (int e = nvsr_edsr_forward_batch_arith(xin, 1, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, arithmetic, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
                        lo[0], lo[1], hi[0], hi[1], out);

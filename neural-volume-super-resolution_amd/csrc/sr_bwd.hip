@@ -13,7 +13,6 @@
 #include "limb_core.h"
 #include "sr_core.h"
 
-extern "C" int nvsr_get_conv_arithmetic(void);
 
 namespace nvsr {
 
@@ -350,10 +349,12 @@ static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho, int Wo) {
 
 // dw += scale * dW(dy, x);  H, W = size of x
 static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* partial,
-                        hipStream_t stream) {
+                        hipStream_t stream, int arith) {
     const int Ho = H - 2, Wo = W - 2;
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
-    const bool limb = nvsr_get_conv_arithmetic() != NVSR_ARITH_F32;
+    arith = conv_resolve_arith(arith);
+    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    const bool limb = arith != NVSR_ARITH_F32;
     const int nrr = wgrad_row_ranges_limb(Cin, Cout, Ho, Wo);
     const int ns = limb ? wgrad_slabs_limb(Cin, Cout, Ho, Wo) : wgrad_slabs(Cin, Cout, Ho);
     WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, (Ho + nrr - 1) / nrr};
@@ -377,11 +378,15 @@ int64_t nvsr_conv3x3_wgrad_workspace_floats(int Cin, int H, int W, int Cout) {
 }
 
 /* weight gradient of nvsr_conv3x3 (epilogue 0): dw [Cout][Cin][3][3] += scale * sum_{y,x} dy[co][y][x] x[ci][y+ky][x+kx] */
-int nvsr_conv3x3_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
-                       nvsr_stream_t stream) {
+int nvsr_conv3x3_wgrad_arith(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
+                             int arithmetic, nvsr_stream_t stream) {
     if (!dy || !x || !dw || !workspace) return NVSR_ERR_NULL;
     if (Cin < 1 || Cout < 1 || H < 3 || W < 3) return NVSR_ERR_SHAPE;
-    return launch_wgrad(dy, x, Cin, H, W, Cout, scale, dw, workspace, (hipStream_t)stream);
+    return launch_wgrad(dy, x, Cin, H, W, Cout, scale, dw, workspace, (hipStream_t)stream, arithmetic);
+}
+int nvsr_conv3x3_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* workspace,
+                       nvsr_stream_t stream) {
+    return nvsr_conv3x3_wgrad_arith(dy, x, Cin, H, W, Cout, scale, dw, workspace, NVSR_ARITH_INHERIT, stream);
 }
 
 /* every layer's data-gradient fragments, layer after layer in state-dict order */
@@ -423,7 +428,15 @@ int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblo
  * grad_natural (state-dict order, nvsr_edsr_natural_floats) += weight gradients; dx [Cin][H][W] or NULL. */
 int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
                        int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, nvsr_stream_t stream_) {
+    return nvsr_edsr_backward_arith(x, Cin, H, W, acts, packed_dgrad, Cout, hid, nblocks, n_up, d_out, grad_natural, dx, workspace,
+                                    NVSR_ARITH_INHERIT, stream_);
+}
+int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
+                             int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, int arithmetic,
+                             nvsr_stream_t stream_) {
     if (!x || !acts || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
+    const int arith = conv_resolve_arith(arithmetic);
+    const ConvExec cx{arith, 0};
     if (!aligned16(packed_dgrad) || !aligned16(workspace)) return NVSR_ERR_ALIGN;
     EdsrPlan P;
     if (int e = edsr_plan(Cin, Cout, hid, nblocks, n_up, H, W, &P)) return e;
@@ -451,27 +464,27 @@ int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts,
             const long n = (long)co * (ih - 2) * (iw - 2);
             hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, co / 4, ih - 2, iw - 2, unsh);
             if ((e = NVSR_CHECK_LAUNCH())) return e;
-            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream))) return e;
+            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith))) return e;
             const int o = next_buf(gi, -1);
-            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2))) return e;
+            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, cx))) return e;
             g = buf[o]; gi = o;
         } else if (P.epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
             const float* t1 = input_of(l);             // relu(conv1(xb)), [hid][ih][iw]
             const float* xb = input_of(l - 1);         // [hid][ih+2][iw+2]
-            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream))) return e;
+            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith))) return e;
             const int o1 = next_buf(gi, -1);
-            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2))) return e;
+            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, cx))) return e;
             const int l1 = l - 1;
-            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream))) return e;
+            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith))) return e;
             const int o2 = next_buf(gi, o1);
-            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2))) return e;
+            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, cx))) return e;
             g = buf[o2]; gi = o2;
             --l;                                        // conv1 is done too
         } else {                                        // plain conv (conv_input, conv_mid, conv_output)
-            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream))) return e;
+            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith))) return e;
             if (need_dx) {
                 float* o = (l == 0) ? dx : buf[next_buf(gi, -1)];
-                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2))) return e;
+                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2, 1, cx))) return e;
                 if (l) { gi = next_buf(gi, -1); g = buf[gi]; }
             }
         }
@@ -496,6 +509,12 @@ int64_t nvsr_planes_sr_backward_workspace_floats(int Cc, int R0, int R1, int hid
 int nvsr_planes_sr_backward(int Cc, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up, int pad,
                             int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
                             float* workspace, nvsr_stream_t stream_) {
+    return nvsr_planes_sr_backward_arith(Cc, R0, R1, keep, packed_dgrad, hid, nblocks, n_up, pad, over, roi, stdv, d_out, grad_natural, d_lr,
+                                         workspace, NVSR_ARITH_INHERIT, stream_);
+}
+int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up, int pad,
+                                  int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
+                                  float* workspace, int arithmetic, nvsr_stream_t stream_) {
     if (!keep || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
     hipStream_t stream = (hipStream_t)stream_;
     const int sf = 1 << n_up;
@@ -515,8 +534,8 @@ int nvsr_planes_sr_backward(int Cc, int R0, int R1, const float* keep, const flo
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     const float* xin = keep;
     const float* acts = keep + (n_in + 3) / 4 * 4;
-    if (int e = nvsr_edsr_backward(xin, Cc, Hp, Wp, acts, packed_dgrad, Cc, hid, nblocks, n_up, d_diff, grad_natural, d_lr ? dxin : nullptr, ews,
-                                   stream_))
+    if (int e = nvsr_edsr_backward_arith(xin, Cc, Hp, Wp, acts, packed_dgrad, Cc, hid, nblocks, n_up, d_diff, grad_natural, d_lr ? dxin : nullptr, ews,
+                                         arithmetic, stream_))
         return e;
     if (d_lr) {
         hipLaunchKernelGGL(sr_prepare_backward_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, dxin, Cc, R0, R1, lo[0], lo[1],

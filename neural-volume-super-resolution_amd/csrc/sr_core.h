@@ -92,7 +92,12 @@ inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
 
 // H, W: size of the tensor in memory; pad: virtual zero border (the kernel sees (H+2pad) x (W+2pad)).  Defined in sr.hip.
 // batch: consecutive [C][H][W] planes in `in` / `skip` / `out`, all convolved with the same weights in one launch.
+// ConvExec: per-call execution options of the convolutions (include/nvsr.h, the *_arith entry points).  arith = NVSR_ARITH_* or
+// NVSR_ARITH_INHERIT (the process default of nvsr_set_conv_arithmetic); rows = 0 (cost model) or 2 / 3 / 4 rows per workgroup tile of the wide
+// kernels (the parity tests force every instantiation).
+struct ConvExec { int arith = -1; int rows = 0; };
+int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad = 0, int batch = 1);
+                hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{});
 
 }  // namespace nvsr

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import capi
+from . import ops  # noqa: F401  (registers torch.ops.nvsr.*)
 
 
 def get_plane_name(scene_id, dimension):
@@ -73,31 +74,46 @@ def to_channel_last(plane_nchw):
     """[1,C,H,W] or [C,H,W] -> [H,W,C] through the re-layout kernel; a channels_last plane is returned as a view of its own memory"""
     if is_native_layout(plane_nchw):
         return plane_nchw.permute(0, 2, 3, 1)[0]
-    p = capi.f32c(plane_nchw)
-    Cc, H, W = p.shape[-3:]
-    out = torch.empty((H, W, Cc), dtype=torch.float32, device=p.device)
-    capi.call("nvsr_plane_to_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
-    return out
+    capi.require_cuda(plane_nchw)
+    return torch.ops.nvsr.plane_to_channel_last(plane_nchw)
 
 
 def from_channel_last(plane_hwc, like=None):
     """[H,W,C] -> [1,C,H,W]; for a channels_last `like` (the plane the gradient belongs to) a view with that memory format, no kernel"""
     if like is not None and is_native_layout(like) and plane_hwc.is_contiguous():
         return plane_hwc.unsqueeze(0).permute(0, 3, 1, 2)
-    p = capi.f32c(plane_hwc)
-    H, W, Cc = p.shape
-    out = torch.empty((1, Cc, H, W), dtype=torch.float32, device=p.device)
-    capi.call("nvsr_plane_from_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
-    return out
+    capi.require_cuda(plane_hwc)
+    return torch.ops.nvsr.plane_from_channel_last(plane_hwc)
 
 
-# plane name -> (source key, channel-last copy).  Shared by the coarse and the fine model, which sample the same planes
-# (the reference assigns one ParameterDict to both, models.py:601,707); refreshed when the source tensor changes.
+# plane name -> (weak reference to the source tensor, its version, channel-last copy or view).  Shared by the coarse and the fine model,
+# which sample the same planes (the reference assigns one ParameterDict to both, models.py:601,707); an entry is refreshed when the source
+# tensor changes and EVICTED when the source tensor dies (weakref callback), when its SR model clears its planes, and when a model moves to
+# another scene -- like the reference, only the current scene's planes stay resident (multi-scene runs would otherwise grow by 368 MB
+# per 800^2 scene and 5.9 GB per super-resolved scene).
 _PLANE_CACHE = {}
 
 
-def clear_plane_cache():
-    _PLANE_CACHE.clear()
+def clear_plane_cache(prefix=None, keep_scene=None):
+    """drop every cached channel-last plane; with `prefix` only the entries whose name starts with it; with `keep_scene` every entry that
+    does not belong to that scene id"""
+    if prefix is None and keep_scene is None:
+        _PLANE_CACHE.clear()
+        return
+    for name in list(_PLANE_CACHE):
+        if (prefix is not None and name.startswith(prefix)) or (keep_scene is not None and plane_name2scene(name.split("/")[0]) != keep_scene):
+            _PLANE_CACHE.pop(name, None)
+
+
+def _cache_plane(name, src):
+    def _evict(ref, name=name):
+        hit = _PLANE_CACHE.get(name)
+        if hit is not None and hit[0] is ref:
+            _PLANE_CACHE.pop(name, None)
+
+    hit = (weakref.ref(src, _evict), src._version, to_channel_last(src.detach()))
+    _PLANE_CACHE[name] = hit
+    return hit
 
 
 DECODER_KEYS = (
@@ -120,6 +136,10 @@ class TwoDimPlanesModel(nn.Module):
         self.box_coords = None
         self.use_viewdirs = use_viewdirs
         assert use_viewdirs or (viewdir_proj_combination is None and num_viewdir_plane_channels is None)
+        if point_coords_noise:
+            # models.py:291-293 jitters the normalised coordinates of every training-mode forward; the kernels do not implement it and a
+            # silently ignored regulariser would change training results
+            raise NotImplementedError("point_coords_noise != 0 is not implemented by the gfx950 kernels (0 in every shipped config)")
         self.point_coords_noise = point_coords_noise
         self.num_plane_channels = num_plane_channels
         if num_viewdir_plane_channels is None:
@@ -175,6 +195,10 @@ class TwoDimPlanesModel(nn.Module):
 
         self.skip_SR_ = False
         self._packed_cache = None  # (source key, packed blob)
+        # arithmetic of the decoder GEMMs for the calls made through this model: 'f32' | 'bf16x3' | 'bf16x2' | None = the process default
+        # (capi.set_decoder_arithmetic / NVSR_DECODER_ARITHMETIC).  Passed to every kernel launch explicitly; a training forward stores
+        # the mode it ran in and its backward uses that one.
+        self.arithmetic = None
 
     # ---- reference protocol ------------------------------------------------------------------------------------------
     def is_skip_layer(self, layer_num):
@@ -201,7 +225,24 @@ class TwoDimPlanesModel(nn.Module):
         assert not SR_viewdir, "Ceased supporting this option"
 
     def set_cur_scene_id(self, scene_id):
+        if getattr(self, "cur_id", None) is not None and scene_id != self.cur_id:
+            # only the current scene stays resident in the channel-last cache
+            keep = scene_id if self.scene_coupler is None else None
+            if keep is not None:
+                clear_plane_cache(keep_scene=keep)
         self.cur_id = scene_id
+
+    def invalidate(self):
+        """Forget every derived copy of the parameters (packed decoder blobs, channel-last planes of the current scene, host copies of the box).
+        The caches are keyed on (data_ptr, tensor._version); writes through `.data` (`p.data.copy_()`, `p.data = ...`) do NOT bump the
+        version, so code that updates parameters that way -- checkpoint loaders, the reference's planes2cpu -- must call this."""
+        self._packed_cache = None
+        self._packed_bwd_cache = None
+        self.__dict__.pop("_scene_consts", None)
+        if getattr(self, "planes_", None) is not None:
+            for k in self.planes_:
+                _PLANE_CACHE.pop(k, None)
+                _PLANE_CACHE.pop(k + "/SR", None)
 
     def skip_SR(self, skip):
         self.skip_SR_ = skip
@@ -209,6 +250,7 @@ class TwoDimPlanesModel(nn.Module):
     def planes2cpu(self):
         for p in self.planes_.values():
             p.data = p.data.to("cpu")
+        self.invalidate()
 
     def assign_LR_planes(self, scene=None):
         """models.py:426-434 (no plane down-sampling: `should_downsample` is always False in the supported configs)"""
@@ -251,10 +293,7 @@ class TwoDimPlanesModel(nn.Module):
         if self._packed_cache is None or self._packed_cache[0] != key:
             nat = self.natural_blob()
             capi.require_cuda(nat)
-            assert nat.numel() == capi.DECODER_NATURAL_FLOATS
-            packed = torch.empty(capi.DECODER_PACKED_FLOATS, dtype=torch.float32, device=nat.device)
-            capi.call("nvsr_pack_decoder", capi.ptr(nat), capi.ptr(packed), capi.stream())
-            self._packed_cache = (key, packed)
+            self._packed_cache = (key, torch.ops.nvsr.pack_decoder(nat))
         return self._packed_cache[1]
 
     def packed_decoder_bwd(self):
@@ -266,9 +305,7 @@ class TwoDimPlanesModel(nn.Module):
         if cache is None or cache[0] != key:
             nat = self.natural_blob()
             capi.require_cuda(nat)
-            packed = torch.empty(capi.DECODER_PACKED_BWD_FLOATS, dtype=torch.float32, device=nat.device)
-            capi.call("nvsr_pack_decoder_bwd", capi.ptr(nat), capi.ptr(packed), capi.stream())
-            cache = (key, packed)
+            cache = (key, torch.ops.nvsr.pack_decoder_bwd(nat))
             self._packed_bwd_cache = cache
         return cache[1]
 
@@ -295,8 +332,7 @@ class TwoDimPlanesModel(nn.Module):
         # the address of a dropped super-resolved plane to the next one
         hit = _PLANE_CACHE.get(name)
         if hit is None or hit[0]() is not src or hit[1] != src._version:
-            hit = (weakref.ref(src), src._version, to_channel_last(src.detach()))
-            _PLANE_CACHE[name] = hit
+            hit = _cache_plane(name, src)
         return hit[2]
 
     def training_planes(self, rays):
@@ -326,9 +362,10 @@ class TwoDimPlanesModel(nn.Module):
             out.append(self.SR_model((saved, roi)))
         return out
 
-    def native_scene(self, planes=None):
-        """struct nvsr_scene for the current scene id (+ the tensors that must outlive the launch).  planes: optional explicit
-        channel-last planes (the training path samples tensors that are part of the autograd graph)."""
+    def scene_args(self, planes=None):
+        """(planes, consts) of the current scene id as the torch.ops.nvsr operators take them: 4 channel-last planes + the 28 host floats
+        of struct nvsr_scene.  planes: optional explicit channel-last planes (the training path samples tensors that are part of the
+        autograd graph)."""
         self._check_native_geometry()
         if planes is None:
             if hasattr(self, "SR_model") and not self.skip_SR_ and not (self.SR_model.training and torch.is_grad_enabled()):
@@ -339,10 +376,6 @@ class TwoDimPlanesModel(nn.Module):
                     names = [self.scene_coupler.scene_with_saved_plane(n, plane_not_scene=True) for n in names]
                 self.SR_model.super_resolve_many(names)
             planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
-        sc = capi.Scene()
-        for d, p in enumerate(planes):
-            sc.planes[d] = p.data_ptr()
-            sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
         # box and projection matrices as host floats: read back once per version (a device-to-host copy drains the queue, and this runs
         # for every pass of every training iteration)
         box_t = self.box_coords[self.cur_id + ""]
@@ -357,16 +390,19 @@ class TwoDimPlanesModel(nn.Module):
             for r in rots:
                 m = r.detach().float().cpu().numpy()[:, 1:]
                 proj.append([float(m[k, c]) for k in range(3) for c in range(2)])
-            cache = (key, lo, rng, proj)
+            consts = [float(v) for v in lo] + [float(v) for v in rng] + [v for row in proj for v in row]
+            cache = (key, lo, rng, proj, consts)
             self.__dict__["_scene_consts"] = cache
-        _, lo, rng, proj = cache
-        for i in range(5):
-            sc.lo[i] = lo[i]
-            sc.range[i] = rng[i]
-        for d in range(3):
-            for j in range(6):
-                sc.proj[d][j] = proj[d][j]
-        return sc, planes
+        return list(planes), cache[4]
+
+    def native_scene(self, planes=None):
+        """struct nvsr_scene for the current scene id (+ the tensors that must outlive the launch) for direct C-ABI calls"""
+        planes, consts = self.scene_args(planes)
+        return ops._scene(planes, consts), planes
+
+    def arith(self):
+        """NVSR_ARITH_* code of this model's calls (-1 = the process default)"""
+        return capi.arith_code(self.arithmetic)
 
     def forward(self, x):
         """models.py:381-421: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb, sigma] (pre-activation)"""
@@ -381,12 +417,15 @@ class TwoDimPlanesModel(nn.Module):
             dec = any(p.requires_grad for p in self.decoder_parameters())
             if dec or any(p.requires_grad for p in planes):
                 # run_network's differentiable model call (train_utils.py:15-64): gradients for the planes and the decoder
+                # models.py:393 `np.random.randint(len(self.density_dec))`: the reference picks an ensemble member on every training-mode
+                # forward.  With ensemble_size == 1 (the only supported size) the call returns 0 WITHOUT drawing from NumPy's stream (a
+                # zero-width range consumes no state: tests/test_host.py::test_single_member_ensemble_draw_leaves_numpy_stream_alone), so
+                # the pixel selection of a seeded run (train_nerf.py:839) is unaffected; the call is kept for literal parity.
+                np.random.randint(self.ensemble_size)
                 out = _DecodePointsFn.apply(self, x.reshape(P, 6), *planes, self.natural_blob(differentiable=True) if dec else None)
                 return out.reshape(list(x.shape[:-1]) + [4])
-        sc, keep = self.native_scene()
-        packed = self.packed_decoder()
-        out = torch.empty((P, 4), dtype=torch.float32, device=x.device)
-        capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
+        planes, consts = self.scene_args()
+        out = torch.ops.nvsr.triplane_decode(planes, consts, self.packed_decoder(), x.reshape(P, 6))
         return out.reshape(list(x.shape[:-1]) + [4])
 
 
@@ -404,33 +443,26 @@ class _DecodePointsFn(torch.autograd.Function):
         z = torch.zeros((P, 1), dtype=torch.float32, device=dev)
         planes_cl = [to_channel_last(p.detach()) for p in (p0, p1, p2, pv)]
         ctx.plane_srcs = (p0, p1, p2, pv)
-        sc, keep = model.native_scene(planes=planes_cl)
-        raw = torch.empty((P, 1, 4), dtype=torch.float32, device=dev)
-        gates = torch.empty((P, 1, 32), dtype=torch.int32, device=dev)
-        rec = torch.empty(capi.lib().nvsr_decoder_record_floats(P, 1), dtype=torch.float32, device=dev) if nat is not None else None
-        capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(model.packed_decoder()), P, 1, capi.ptr(rays), capi.ptr(z), capi.ptr(raw),
-                  capi.ptr(gates), capi.ptr(rec), capi.stream())
-        ctx.model, ctx.state = model, (sc, keep, rays, z, gates, rec)
+        planes_cl, consts = model.scene_args(planes=planes_cl)
+        arith = capi.resolve_decoder_arithmetic(model.arithmetic)      # the backward runs in the mode the gates / record were made in
+        raw, gates, rec = torch.ops.nvsr.decode_rays(planes_cl, consts, model.packed_decoder(), rays, z, True, nat is not None, arith)
+        ctx.model, ctx.state = model, (planes_cl, consts, rays, z, gates, rec if nat is not None else None, arith)
         return raw.reshape(P, 4)
 
     @staticmethod
     def backward(ctx, g_out):
         model = ctx.model
-        sc, keep, rays, z, gates, rec = ctx.state
-        P, dev = rays.shape[0], rays.device
+        planes_cl, consts, rays, z, gates, rec, arith = ctx.state
+        P = rays.shape[0]
         need = ctx.needs_input_grad
-        g_raw = capi.f32c(g_out).reshape(P, 1, 4)
-        gplanes = [torch.zeros_like(k) if need[2 + d] else None for d, k in enumerate(keep)]
-        gptrs = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gplanes]) if any(need[2:6]) else None
-        if gptrs is None and rec is None:
+        need_planes = [bool(n) for n in need[2:6]]
+        if not any(need_planes) and rec is None:
             return (None,) * 7
-        capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(model.packed_decoder()), capi.ptr(model.packed_decoder_bwd()), P, 1,
-                  capi.ptr(rays), capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, None, capi.ptr(rec), capi.stream())
-        gnat = None
-        if rec is not None and need[6]:
-            gnat = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
-            capi.call("nvsr_decoder_weight_grad", P, 1, capi.ptr(rec), capi.ptr(gnat), capi.stream())
-        return (None, None) + tuple(None if g is None else from_channel_last(g, like=p_) for g, p_ in zip(gplanes, ctx.plane_srcs)) + (gnat,)
+        g_raw = capi.f32c(g_out).reshape(P, 1, 4)
+        gplanes = torch.ops.nvsr.decode_rays_backward(planes_cl, consts, model.packed_decoder(), model.packed_decoder_bwd(), rays, z, g_raw, gates,
+                                                      rec, need_planes, arith)
+        gnat = torch.ops.nvsr.decoder_weight_grad(rec, P, 1, arith) if (rec is not None and need[6]) else None
+        return (None, None) + tuple(from_channel_last(g, like=p_) if n else None for g, p_, n in zip(gplanes, ctx.plane_srcs, need_planes)) + (gnat,)
 
 
 # =======================================================================================================================
@@ -486,6 +518,15 @@ class EDSR(nn.Module):
         self.conv_output = nn.Conv2d(hidden_size, out_channels, kernel_size(), stride=1, padding=padding, bias=False)
         self.geometry = (in_channels, out_channels, hidden_size, n_blocks, int(math.log2(scale_factor)))
         self._packed_cache = None
+        self.arithmetic = None     # 'f32' | 'bf16x3' | None = the process default (capi.set_conv_arithmetic / NVSR_CONV_ARITHMETIC)
+
+    def invalidate(self):
+        """forget the packed weight blobs (needed after writes through `.data`, which do not bump a tensor's version counter)"""
+        self._packed_cache = None
+        self._packed_dgrad_cache = None
+
+    def arith(self):
+        return capi.arith_code(self.arithmetic)
 
     def conv_weights(self):
         ws = [self.conv_input.weight]
@@ -502,11 +543,7 @@ class EDSR(nn.Module):
         if self._packed_cache is None or self._packed_cache[0] != key:
             nat = torch.cat([w.detach().reshape(-1).float() for w in ws])
             capi.require_cuda(nat)
-            n = capi.lib().nvsr_edsr_packed_floats(*self.geometry)
-            assert nat.numel() == capi.lib().nvsr_edsr_natural_floats(*self.geometry) and n > 0
-            packed = torch.empty(n, dtype=torch.float32, device=nat.device)
-            capi.call("nvsr_pack_edsr", capi.ptr(nat), *self.geometry, capi.ptr(packed), capi.stream())
-            self._packed_cache = (key, packed)
+            self._packed_cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), False))
         return self._packed_cache[1]
 
     def natural_blob(self, differentiable=False):
@@ -521,9 +558,7 @@ class EDSR(nn.Module):
         if cache is None or cache[0] != key:
             nat = self.natural_blob()
             capi.require_cuda(nat)
-            packed = torch.empty(capi.lib().nvsr_edsr_packed_dgrad_floats(*self.geometry), dtype=torch.float32, device=nat.device)
-            capi.call("nvsr_pack_edsr_dgrad", capi.ptr(nat), *self.geometry, capi.ptr(packed), capi.stream())
-            cache = (key, packed)
+            cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), True))
             self._packed_dgrad_cache = cache
         return cache[1]
 
@@ -532,96 +567,17 @@ class EDSR(nn.Module):
                                             any(t is not None and t.requires_grad for t in inputs))
 
     def forward(self, x):
-        if self.wants_grad(x):
-            return _EDSRFn.apply(self, x, self.natural_blob(differentiable=True))
         x = capi.f32c(x)
         lead = x.shape[:-3]
         assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
-        Cin, H, W = x.shape[-3:]
-        cin, cout, hid, nb, n_up = self.geometry
-        assert Cin == cin
-        Ho, Wo = C.c_int(), C.c_int()
-        capi.call("nvsr_edsr_out_size", H, W, nb, n_up, C.byref(Ho), C.byref(Wo))
-        out = torch.empty(list(lead) + [cout, Ho.value, Wo.value], dtype=torch.float32, device=x.device)
-        ws = torch.empty(capi.lib().nvsr_edsr_workspace_floats(hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
-        capi.call("nvsr_edsr_forward", capi.ptr(x), Cin, H, W, capi.ptr(self.packed_weights()), cout, hid, nb, n_up, capi.ptr(out),
-                  capi.ptr(ws), capi.stream())
-        return out
-
-
-class _EDSRFn(torch.autograd.Function):
-    """EDSR.forward with gradients for the conv weights (as one flat blob in state-dict order) and the input."""
-
-    @staticmethod
-    def forward(ctx, net, x, nat):
-        x = capi.f32c(x.detach())
-        lead = x.shape[:-3]
-        assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
-        Cin, H, W = x.shape[-3:]
-        cin, cout, hid, nb, n_up = net.geometry
-        assert Cin == cin
-        Ho, Wo = C.c_int(), C.c_int()
-        capi.call("nvsr_edsr_out_size", H, W, nb, n_up, C.byref(Ho), C.byref(Wo))
-        out = torch.empty(list(lead) + [cout, Ho.value, Wo.value], dtype=torch.float32, device=x.device)
-        acts = torch.empty(capi.lib().nvsr_edsr_acts_floats(cin, cout, hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
-        capi.call("nvsr_edsr_forward_train", capi.ptr(x), Cin, H, W, capi.ptr(net.packed_weights()), cout, hid, nb, n_up, capi.ptr(out),
-                  capi.ptr(acts), capi.stream())
-        ctx.net, ctx.x, ctx.acts = net, x, acts
-        return out
-
-    @staticmethod
-    def backward(ctx, d_out):
-        net, x = ctx.net, ctx.x
-        cin, cout, hid, nb, n_up = net.geometry
-        Cin, H, W = x.shape[-3:]
-        d_out = capi.f32c(d_out)
-        gnat = torch.zeros(capi.lib().nvsr_edsr_natural_floats(*net.geometry), dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        ws = torch.empty(capi.lib().nvsr_edsr_backward_workspace_floats(cin, cout, hid, nb, n_up, H, W), dtype=torch.float32, device=x.device)
-        capi.call("nvsr_edsr_backward", capi.ptr(x), Cin, H, W, capi.ptr(ctx.acts), capi.ptr(net.packed_dgrad_weights()), cout, hid, nb, n_up,
-                  capi.ptr(d_out), capi.ptr(gnat), capi.ptr(dx), capi.ptr(ws), capi.stream())
-        return None, dx, (gnat if ctx.needs_input_grad[2] else None)
-
-
-class _PlanesSRFn(torch.autograd.Function):
-    """PlanesSR.forward (crop + replicate pad -> EDSR -> + bilinear residual -> NaN canvas) with gradients for the EDSR weights and,
-    unless it is detached (models.py:272), the LR plane."""
-
-    @staticmethod
-    def forward(ctx, sr, lr_plane, nat, roi_c, mean, std):
-        lr = capi.f32c(lr_plane.detach())
-        Cc, R0, R1 = lr.shape[-3:]
-        cin, cout, hid, nb, n_up = sr.inner_model.geometry
-        pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
-        lib = capi.lib()
-        nws = lib.nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
-        nkeep = lib.nvsr_planes_sr_keep_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
-        if nws < 0 or nkeep < 0:
-            raise capi.NvsrError("PlanesSR: region of interest too small for the network")
-        ws = torch.empty(nws, dtype=torch.float32, device=lr.device)
-        keep = torch.empty(nkeep, dtype=torch.float32, device=lr.device)
-        sf = sr.scale_factor
-        out = torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lr.device)
-        capi.call("nvsr_planes_sr_train", capi.ptr(lr), Cc, R0, R1, capi.ptr(sr.inner_model.packed_weights()), hid, nb, n_up, pad, over, roi_c,
-                  capi.ptr(mean), capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), capi.stream())
-        ctx.sr, ctx.keep, ctx.roi_c, ctx.std, ctx.dims = sr, keep, roi_c, std, (Cc, R0, R1)
-        return out
-
-    @staticmethod
-    def backward(ctx, d_out):
-        sr = ctx.sr
-        Cc, R0, R1 = ctx.dims
-        cin, cout, hid, nb, n_up = sr.inner_model.geometry
-        pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
-        d_out = capi.f32c(d_out)
-        dev = d_out.device
-        gnat = torch.zeros(capi.lib().nvsr_edsr_natural_floats(*sr.inner_model.geometry), dtype=torch.float32, device=dev)
-        d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        ws = torch.empty(capi.lib().nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, ctx.roi_c), dtype=torch.float32,
-                         device=dev)
-        capi.call("nvsr_planes_sr_backward", Cc, R0, R1, capi.ptr(ctx.keep), capi.ptr(sr.inner_model.packed_dgrad_weights()), hid, nb, n_up, pad,
-                  over, ctx.roi_c, capi.ptr(ctx.std), capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr), capi.ptr(ws), capi.stream())
-        return None, d_lr, (gnat if ctx.needs_input_grad[2] else None), None, None, None
+        x4 = x.reshape((1,) + tuple(x.shape[-3:]))
+        if self.wants_grad(x):
+            # gradients for the conv weights (through the flat state-dict-order blob) and the input: torch.ops.nvsr.edsr_train
+            out, _ = torch.ops.nvsr.edsr_train(x4, self.natural_blob(differentiable=True), self.packed_weights(), self.packed_dgrad_weights(),
+                                               list(self.geometry), capi.resolve_conv_arithmetic(self.arithmetic))
+        else:
+            out = torch.ops.nvsr.edsr(x4, self.packed_weights(), list(self.geometry), self.arith())
+        return out.reshape(tuple(lead) + tuple(out.shape[-3:]))
 
 
 class PlanesSR(nn.Module):
@@ -670,7 +626,14 @@ class PlanesSR(nn.Module):
         # `save_interpolated` cached the bilinear up-sampling on the CPU in the reference (models.py:874-875); the finish kernel
         # recomputes it on the fly, so there is nothing to store.
 
+    def invalidate(self):
+        """forget everything derived from the parameters / LR planes (see EDSR.invalidate): packed weights and super-resolved planes"""
+        self.inner_model.invalidate()
+        self.clear_SR_planes()
+
     def clear_SR_planes(self, all_planes=False):
+        for name in list(getattr(self, "SR_planes", {})):          # ... and their channel-last copies in the renderer's plane cache
+            _PLANE_CACHE.pop(name + "/SR", None)
         planes_2_clear = ["SR_planes"]
         if all_planes:
             planes_2_clear += ["LR_planes", "residual_planes"]
@@ -693,17 +656,10 @@ class PlanesSR(nn.Module):
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
         pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
-        B = len(todo)
-        nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None)
-        if nws < 0:
+        if capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None) < 0:
             return
-        ws = torch.empty(B * nws, dtype=torch.float32, device=lrs[0].device)
-        sf = self.scale_factor
-        outs = [torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lrs[0].device) for _ in todo]
-        lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lrs])
-        out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
-        capi.call("nvsr_planes_sr_batch", lr_ptrs, B, Cc, R0, R1, capi.ptr(self.inner_model.packed_weights()), hid, nb, n_up, pad, over, None,
-                  capi.ptr(mean), capi.ptr(std), out_ptrs, capi.ptr(ws), capi.stream())
+        outs = torch.ops.nvsr.planes_sr([t.reshape(Cc, R0, R1) for t in lrs], self.inner_model.packed_weights(), list(self.inner_model.geometry),
+                                        pad, over, None, mean, std, self.inner_model.arith())
         for n, o in zip(todo, outs):
             self.SR_planes[n] = o
 
@@ -724,25 +680,23 @@ class PlanesSR(nn.Module):
         Cc, R0, R1 = lr.shape[-3:]
         cin, cout, hid, nb, n_up = self.inner_model.geometry
         assert Cc == cin == cout
-        roi_c = None
+        roi = None
         if plane_roi is not None:
-            r = [float(v) for v in torch.as_tensor(plane_roi).detach().cpu().reshape(-1)]
-            roi_c = (C.c_float * 4)(*r)
+            roi = [float(v) for v in torch.as_tensor(plane_roi).detach().cpu().reshape(-1)]
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
+        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
+        geometry = list(self.inner_model.geometry)
         if differentiable:
             # training: gradients for the EDSR weights and the (non-detached) LR plane; the result is never cached
-            return _PlanesSRFn.apply(self, lr_src, self.inner_model.natural_blob(differentiable=True), roi_c, mean, std)
-        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
-        nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
-        if nws < 0:
-            raise capi.NvsrError("PlanesSR: region of interest too small for the network")
-        ws = torch.empty(nws, dtype=torch.float32, device=lr.device)
-        sf = self.scale_factor
-        out = torch.empty((1, Cc, R0 * sf, R1 * sf), dtype=torch.float32, device=lr.device)
-        capi.call("nvsr_planes_sr", capi.ptr(lr), Cc, R0, R1, capi.ptr(self.inner_model.packed_weights()), hid, nb, n_up, pad, over, roi_c,
-                  capi.ptr(mean), capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.stream())
+            net = self.inner_model
+            out, _ = torch.ops.nvsr.planes_sr_train(lr_src if lr_src.dtype == torch.float32 else lr_src.float(), net.natural_blob(differentiable=True),
+                                                    net.packed_weights(), net.packed_dgrad_weights(), geometry, pad, over, roi, mean, std,
+                                                    capi.resolve_conv_arithmetic(net.arithmetic))
+            return out
+        out = torch.ops.nvsr.planes_sr([lr.reshape(Cc, R0, R1)], self.inner_model.packed_weights(), geometry, pad, over, roi, mean, std,
+                                       self.inner_model.arith())[0]
         if full_plane:
             self.SR_planes[plane_name] = out      # kept on the GPU (the reference parks it on the CPU and re-uploads per call, :893,:925)
         return out

@@ -1,0 +1,659 @@
+"""`torch.ops.nvsr.*`: the hot path as PyTorch custom operators (torch.library) on top of the C ABI of include/nvsr.h.
+
+Every operator is a thin shell: it allocates the outputs, turns tensors into raw device pointers and calls ONE entry point of
+libnvsr_hip.so on the current stream (ctypes, capi.py) -- no arithmetic happens in Python.  Each has a fake (meta) implementation, so
+the operators trace under FakeTensor / torch.compile / torch.export, and the differentiable ones carry their backward as another
+operator of this library (`register_autograd`).  The host mirror (nerf_helpers / volume_rendering_utils / train_utils / models) is
+written against these operators; they are the product path, not a side door.
+
+Conventions
+  * a scene is passed as `planes` = 4 CHANNEL-LAST [H,W,48] tensors (position planes D0..D2, view-direction plane) and `consts` = 28
+    python floats: lo[5], range[5], proj[3][6] (struct nvsr_scene, include/nvsr.h);
+  * `arithmetic` is the NVSR_ARITH_* code of the decoder GEMMs / SR convolutions for THIS call (-1 = the process default): a per-call
+    argument, nothing global (capi.arith_code turns 'f32' / 'bf16x3' / 'bf16x2' / None into it);
+  * operators cannot return None: an output that was not asked for comes back as an empty tensor.
+
+Reference functions behind the operators: models.py:381-421 (decoder), train_utils.py:71-182 (render passes), volume_rendering_utils.py:6-51
+(compositing), nerf_helpers.py:668-702 (importance sampling), models.py:769-822,884-926 (EDSR / PlanesSR)."""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+from torch.library import custom_op
+
+from . import capi
+
+PC = capi.PLANE_CHANNELS
+# decoder-gradient record: up to this many points of a pass (19 GB of record) the forward itself records the layer inputs and the backward
+# never recomputes; beyond, the chunked recomputing path runs RECORD_RAYS rays at a time (train_utils re-exports both)
+RECORD_FORWARD_MAX_POINTS = 1 << 21
+RECORD_RAYS = 8192
+
+
+def _f(*shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _c(t):
+    """float32 + contiguous (None passes through): the kernels take dense row-major buffers"""
+    return None if t is None else capi.f32c(t)
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _scene(planes, consts):
+    """struct nvsr_scene from 4 channel-last planes + the 28 host constants"""
+    assert len(planes) == 4 and len(consts) == 28
+    sc = capi.Scene()
+    for d, p in enumerate(planes):
+        capi.require_cuda(p)
+        assert p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] == PC and p.is_contiguous(), "planes must be channel-last [H,W,48] f32"
+        sc.planes[d] = p.data_ptr()
+        sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
+    for i in range(5):
+        sc.lo[i] = consts[i]
+        sc.range[i] = consts[5 + i]
+    for d in range(3):
+        for j in range(6):
+            sc.proj[d][j] = consts[10 + 6 * d + j]
+    return sc
+
+
+def scene_consts(sc):
+    """the 28 floats of a capi.Scene (lo, range, proj) as the operators take them"""
+    return [float(sc.lo[i]) for i in range(5)] + [float(sc.range[i]) for i in range(5)] + [float(sc.proj[d][j]) for d in range(3) for j in range(6)]
+
+
+# =====================================================================================================================================
+# layout / packing
+# =====================================================================================================================================
+@custom_op("nvsr::plane_to_channel_last", mutates_args=(), device_types="cuda")
+def plane_to_channel_last(plane: Tensor) -> Tensor:
+    """[1,C,H,W] or [C,H,W] (reference layout, models.py:436-439) -> channel-last [H,W,C] copy"""
+    p = capi.f32c(plane)
+    Cc, H, W = p.shape[-3:]
+    out = _f(H, W, Cc, like=p)
+    capi.call("nvsr_plane_to_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
+    return out
+
+
+@plane_to_channel_last.register_fake
+def _(plane):
+    Cc, H, W = plane.shape[-3:]
+    return plane.new_empty((H, W, Cc), dtype=torch.float32)
+
+
+@custom_op("nvsr::plane_from_channel_last", mutates_args=(), device_types="cuda")
+def plane_from_channel_last(plane_hwc: Tensor) -> Tensor:
+    """channel-last [H,W,C] -> [1,C,H,W]"""
+    p = capi.f32c(plane_hwc)
+    H, W, Cc = p.shape
+    out = _f(1, Cc, H, W, like=p)
+    capi.call("nvsr_plane_from_channel_last", capi.ptr(p), capi.ptr(out), Cc, H, W, capi.stream())
+    return out
+
+
+@plane_from_channel_last.register_fake
+def _(plane_hwc):
+    H, W, Cc = plane_hwc.shape
+    return plane_hwc.new_empty((1, Cc, H, W), dtype=torch.float32)
+
+
+plane_to_channel_last.register_autograd(lambda ctx, g: torch.ops.nvsr.plane_from_channel_last(g).reshape(ctx.shape),
+                                        setup_context=lambda ctx, inputs, output: setattr(ctx, "shape", inputs[0].shape))
+plane_from_channel_last.register_autograd(lambda ctx, g: torch.ops.nvsr.plane_to_channel_last(g))
+
+
+@custom_op("nvsr::pack_decoder", mutates_args=(), device_types="cuda")
+def pack_decoder(natural: Tensor) -> Tensor:
+    """decoder parameters in state-dict order (models.py:169-195) -> MFMA-fragment blob of the forward kernels"""
+    nat = capi.f32c(natural)
+    assert nat.numel() == capi.DECODER_NATURAL_FLOATS
+    packed = _f(capi.DECODER_PACKED_FLOATS, like=nat)
+    capi.call("nvsr_pack_decoder", capi.ptr(nat), capi.ptr(packed), capi.stream())
+    return packed
+
+
+@pack_decoder.register_fake
+def _(natural):
+    return natural.new_empty((capi.DECODER_PACKED_FLOATS,), dtype=torch.float32)
+
+
+@custom_op("nvsr::pack_decoder_bwd", mutates_args=(), device_types="cuda")
+def pack_decoder_bwd(natural: Tensor) -> Tensor:
+    """-> fragments of the transposed layers (backward kernels)"""
+    nat = capi.f32c(natural)
+    assert nat.numel() == capi.DECODER_NATURAL_FLOATS
+    packed = _f(capi.DECODER_PACKED_BWD_FLOATS, like=nat)
+    capi.call("nvsr_pack_decoder_bwd", capi.ptr(nat), capi.ptr(packed), capi.stream())
+    return packed
+
+
+@pack_decoder_bwd.register_fake
+def _(natural):
+    return natural.new_empty((capi.DECODER_PACKED_BWD_FLOATS,), dtype=torch.float32)
+
+
+# =====================================================================================================================================
+# sampling helpers (train_utils.py:95-109,144-155; nerf_helpers.py:668-702)
+# =====================================================================================================================================
+@custom_op("nvsr::coarse_z", mutates_args=(), device_types="cuda")
+def coarse_z(rays: Tensor, Nc: int, lindisp: bool, t_rand: Optional[Tensor]) -> Tensor:
+    rays, t_rand = _c(rays), _c(t_rand)
+    N = rays.shape[0]
+    z = _f(N, Nc, like=rays)
+    if N:
+        capi.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), int(lindisp), capi.ptr(t_rand), capi.ptr(z), capi.stream())
+    return z
+
+
+@coarse_z.register_fake
+def _(rays, Nc, lindisp, t_rand):
+    return rays.new_empty((rays.shape[0], Nc))
+
+
+@custom_op("nvsr::importance_resample", mutates_args=(), device_types="cuda")
+def importance_resample(z_coarse: Tensor, weights: Tensor, Nf: int, u: Optional[Tensor]) -> Tensor:
+    """z_mid -> sample_pdf_2(z_mid, w[1:-1], Nf, det = (u is None)) -> sort(cat(z, samples)): [N, Nc+Nf]; no gradient (train_utils.py:153)"""
+    z_coarse, weights, u = _c(z_coarse), _c(weights), _c(u)
+    N, Nc = z_coarse.shape
+    z_f = _f(N, Nc + Nf, like=z_coarse)
+    if N:
+        capi.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_coarse), capi.ptr(weights), capi.ptr(u), capi.ptr(z_f), capi.stream())
+    return z_f
+
+
+@importance_resample.register_fake
+def _(z_coarse, weights, Nf, u):
+    return z_coarse.new_empty((z_coarse.shape[0], z_coarse.shape[1] + Nf))
+
+
+# =====================================================================================================================================
+# tri-plane decoder (models.py:381-421) and the render passes (train_utils.py:71-182)
+# =====================================================================================================================================
+@custom_op("nvsr::triplane_decode", mutates_args=(), device_types="cuda")
+def triplane_decode(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, x: Tensor) -> Tensor:
+    """TwoDimPlanesModel.forward on points: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb_raw, sigma_raw] (exact-f32 MFMA kernel)"""
+    x = _c(x)
+    sc = _scene(planes, consts)
+    P = x.shape[0]
+    out = _f(P, 4, like=x)
+    if P:
+        capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
+    return out
+
+
+@triplane_decode.register_fake
+def _(planes, consts, packed, x):
+    return x.new_empty((x.shape[0], 4))
+
+
+@custom_op("nvsr::render_pass", mutates_args=(), device_types="cuda")
+def render_pass(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, rays: Tensor, z: Tensor, noise: Optional[Tensor],
+                white: bool, want_weights: bool, arithmetic: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """run_network + model + volume_render_radiance_field of one pass, fused (no [N,S,*] tensor reaches HBM):
+    rays [N,11], z [N,S] -> rgb [N,3], disp [N], acc [N], weights [N,S] (empty unless want_weights)"""
+    rays, z, noise = _c(rays), _c(z), _c(noise)
+    sc = _scene(planes, consts)
+    N, S = z.shape
+    rgb, disp, acc = _f(N, 3, like=rays), _f(N, like=rays), _f(N, like=rays)
+    w = _f(N, S, like=rays) if want_weights else _f(0, like=rays)
+    if N:
+        capi.call("nvsr_render_pass_arith", C.byref(sc), capi.ptr(packed), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(noise), int(white),
+                  capi.ptr(rgb), capi.ptr(disp), capi.ptr(acc), capi.ptr(w) if want_weights else None, None, None, arithmetic, capi.stream())
+    return rgb, disp, acc, w
+
+
+@render_pass.register_fake
+def _(planes, consts, packed, rays, z, noise, white, want_weights, arithmetic):
+    N, S = z.shape
+    return rays.new_empty((N, 3)), rays.new_empty((N,)), rays.new_empty((N,)), rays.new_empty((N, S) if want_weights else (0,))
+
+
+@custom_op("nvsr::render_rays", mutates_args=(), device_types="cuda")
+def render_rays(planes: Sequence[Tensor], consts: Sequence[float], packed_coarse: Tensor, packed_fine: Optional[Tensor], rays: Tensor,
+                Nc: int, Nf: int, lindisp: bool, white: bool, t_rand: Optional[Tensor], u: Optional[Tensor], noise_coarse: Optional[Tensor],
+                noise_fine: Optional[Tensor], arithmetic: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """predict_and_render_radiance for a ray block (inference): coarse depths -> coarse pass -> importance resampling -> fine pass.
+    -> rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f (the fine ones empty when Nf == 0)"""
+    rays, t_rand, u, noise_coarse, noise_fine = _c(rays), _c(t_rand), _c(u), _c(noise_coarse), _c(noise_fine)
+    sc = _scene(planes, consts)
+    N = rays.shape[0]
+    rgb_c, disp_c, acc_c = _f(N, 3, like=rays), _f(N, like=rays), _f(N, like=rays)
+    if Nf > 0:
+        rgb_f, disp_f, acc_f = _f(N, 3, like=rays), _f(N, like=rays), _f(N, like=rays)
+    else:
+        rgb_f, disp_f, acc_f = _f(0, 3, like=rays), _f(0, like=rays), _f(0, like=rays)
+    if N:
+        ws = _f(capi.lib().nvsr_render_workspace_floats(N, Nc, Nf), like=rays)
+        capi.call("nvsr_render_rays_arith", C.byref(sc), capi.ptr(packed_coarse), capi.ptr(packed_fine), N, Nc, Nf, capi.ptr(rays), int(lindisp),
+                  int(white), capi.ptr(t_rand), capi.ptr(u), capi.ptr(noise_coarse), capi.ptr(noise_fine), capi.ptr(rgb_c), capi.ptr(disp_c),
+                  capi.ptr(acc_c), capi.ptr(rgb_f) if Nf > 0 else None, capi.ptr(disp_f) if Nf > 0 else None,
+                  capi.ptr(acc_f) if Nf > 0 else None, capi.ptr(ws), arithmetic, capi.stream())
+    return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f
+
+
+@render_rays.register_fake
+def _(planes, consts, packed_coarse, packed_fine, rays, Nc, Nf, lindisp, white, t_rand, u, noise_coarse, noise_fine, arithmetic):
+    N = rays.shape[0]
+    M = N if Nf > 0 else 0
+    e = rays.new_empty
+    return e((N, 3)), e((N,)), e((N,)), e((M, 3)), e((M,)), e((M,))
+
+
+@custom_op("nvsr::decode_rays", mutates_args=(), device_types="cuda")
+def decode_rays(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, rays: Tensor, z: Tensor, want_gates: bool,
+                want_record: bool, arithmetic: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """decoder outputs of every sample of every ray, tiled over (ray block, sample): raw [N,S,4]; with want_gates the ReLU gates of every
+    layer ([N,S,32] int32, 128 B per point) and with want_record the layer inputs (9.2 KB per point) the backward operators consume"""
+    rays, z = _c(rays), _c(z)
+    sc = _scene(planes, consts)
+    N, S = z.shape
+    raw = _f(N, S, 4, like=rays)
+    gates = torch.empty((N, S, 32) if (want_gates or want_record) else (0,), dtype=torch.int32, device=rays.device)
+    rec = _f(capi.lib().nvsr_decoder_record_floats(N, S) if want_record else 0, like=rays)
+    if N:
+        capi.call("nvsr_decode_rays_arith", C.byref(sc), capi.ptr(packed), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw),
+                  capi.ptr(_none_if_empty(gates)), capi.ptr(_none_if_empty(rec)), arithmetic, capi.stream())
+    return raw, gates, rec
+
+
+@decode_rays.register_fake
+def _(planes, consts, packed, rays, z, want_gates, want_record, arithmetic):
+    N, S = z.shape
+    nrec = capi.lib().nvsr_decoder_record_floats(int(N), int(S)) if want_record else 0      # (host-side size arithmetic of the library)
+    return (rays.new_empty((N, S, 4)), rays.new_empty((N, S, 32) if (want_gates or want_record) else (0,), dtype=torch.int32),
+            rays.new_empty((nrec,)))
+
+
+@custom_op("nvsr::decode_rays_backward", mutates_args=("record",), device_types="cuda")
+def decode_rays_backward(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, packed_bwd: Tensor, rays: Tensor, z: Tensor,
+                         g_raw: Tensor, gates: Tensor, record: Optional[Tensor], need: Sequence[bool], arithmetic: int) -> List[Tensor]:
+    """gate-driven backward of decode_rays: g_raw [N,S,4] -> gradient planes (channel-last, zeros where need[d] is False -> empty tensor);
+    with `record` (the forward's) the pre-activation gradients are added to it for decoder_weight_grad.  `arithmetic` must be the
+    forward's."""
+    rays, z, g_raw = _c(rays), _c(z), _c(g_raw)
+    sc = _scene(planes, consts)
+    N, S = z.shape
+    grads = [torch.zeros_like(p) if need[d] else _f(0, like=rays) for d, p in enumerate(planes)]
+    if N == 0 or (not any(need) and record is None):
+        return grads
+    gptrs = (C.c_void_p * 4)(*[g.data_ptr() if need[d] else None for d, g in enumerate(grads)]) if any(need) else None
+    # per-point rows of the view-direction plane's gradient (summed per ray before they touch the plane)
+    view_ws = _f(N * S * PC, like=rays) if (gptrs is not None and need[3]) else None
+    capi.call("nvsr_render_pass_backward_gates_arith", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays), capi.ptr(z),
+              capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(record), arithmetic, capi.stream())
+    return grads
+
+
+@decode_rays_backward.register_fake
+def _(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic):
+    return [torch.empty_like(p) if need[d] else rays.new_empty((0,)) for d, p in enumerate(planes)]
+
+
+@custom_op("nvsr::decode_rays_backward_recompute", mutates_args=(), device_types="cuda")
+def decode_rays_backward_recompute(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, packed_bwd: Tensor, rays: Tensor,
+                                   z: Tensor, g_raw: Tensor, need: Sequence[bool], want_decoder_grad: bool, arithmetic: int) -> List[Tensor]:
+    """backward of a decode pass that recomputes the forward (exact-f32 kernel), RECORD_RAYS rays at a time: the memory-bounded path for
+    decoder gradients of very large batches, and the path for passes that published no gates.
+    -> [g_plane0..3 (empty where not needed), g_natural (empty unless want_decoder_grad)]"""
+    rays, z, g_raw = _c(rays), _c(z), _c(g_raw)
+    sc = _scene(planes, consts)
+    N, S = z.shape
+    grads = [torch.zeros_like(p) if need[d] else _f(0, like=rays) for d, p in enumerate(planes)]
+    gnat = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=rays.device) if want_decoder_grad else _f(0, like=rays)
+    if N == 0 or (not any(need) and not want_decoder_grad):
+        return grads + [gnat]
+    gptrs = (C.c_void_p * 4)(*[g.data_ptr() if need[d] else None for d, g in enumerate(grads)]) if any(need) else None
+    view_ws = _f(N * S * PC, like=rays) if (gptrs is not None and need[3]) else None
+    st = capi.stream()
+    if not want_decoder_grad:
+        capi.call("nvsr_render_pass_backward_ex", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays), capi.ptr(z),
+                  capi.ptr(g_raw), gptrs, None, capi.ptr(view_ws), st)
+        return grads + [gnat]
+    step = min(N, RECORD_RAYS)
+    record = _f(capi.lib().nvsr_decoder_record_floats(step, S), like=rays)
+    for a in range(0, N, step):
+        n = min(step, N - a)
+        capi.call("nvsr_render_pass_backward_ex", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), n, S, capi.ptr(rays[a:]), capi.ptr(z[a:]),
+                  capi.ptr(g_raw[a:]), gptrs, capi.ptr(record), capi.ptr(view_ws), st)
+        # the recomputing kernel is the exact-f32 one; its record is contracted in the caller's arithmetic (both are held to 1e-5 of float64)
+        capi.call("nvsr_decoder_weight_grad_arith", n, S, capi.ptr(record), capi.ptr(gnat), arithmetic, st)
+    return grads + [gnat]
+
+
+@decode_rays_backward_recompute.register_fake
+def _(planes, consts, packed, packed_bwd, rays, z, g_raw, need, want_decoder_grad, arithmetic):
+    return [torch.empty_like(p) if need[d] else rays.new_empty((0,)) for d, p in enumerate(planes)] + \
+        [rays.new_empty((capi.DECODER_NATURAL_FLOATS if want_decoder_grad else 0,))]
+
+
+@custom_op("nvsr::decoder_weight_grad", mutates_args=(), device_types="cuda")
+def decoder_weight_grad(record: Tensor, N: int, S: int, arithmetic: int) -> Tensor:
+    """one contraction over all points of the record -> weight / bias gradients in state-dict order"""
+    gnat = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=record.device)
+    if N:
+        capi.call("nvsr_decoder_weight_grad_arith", N, S, capi.ptr(record), capi.ptr(gnat), arithmetic, capi.stream())
+    return gnat
+
+
+@decoder_weight_grad.register_fake
+def _(record, N, S, arithmetic):
+    return record.new_empty((capi.DECODER_NATURAL_FLOATS,))
+
+
+# =====================================================================================================================================
+# compositing (volume_rendering_utils.py:6-51)
+# =====================================================================================================================================
+@custom_op("nvsr::composite", mutates_args=(), device_types="cuda")
+def composite(raw: Tensor, z: Tensor, rd: Tensor, noise: Optional[Tensor], white: bool, mip: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """raw [N,S,4], z [N,S] (mip: the S+1 interval edges), rd [N,3] -> rgb [N,3], disp [N], acc [N], weights [N,S], depth [N]"""
+    raw, z, rd, noise = _c(raw), _c(z), _c(rd), _c(noise)
+    N = z.shape[0]
+    S = z.shape[1] - (1 if mip else 0)
+    rgb, disp, acc, depth, w = _f(N, 3, like=raw), _f(N, like=raw), _f(N, like=raw), _f(N, like=raw), _f(N, S, like=raw)
+    if N:
+        capi.call("nvsr_composite_mip" if mip else "nvsr_composite", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), int(white),
+                  capi.ptr(rgb), capi.ptr(disp), capi.ptr(acc), capi.ptr(w), capi.ptr(depth), capi.stream())
+    return rgb, disp, acc, w, depth
+
+
+@composite.register_fake
+def _(raw, z, rd, noise, white, mip):
+    N = z.shape[0]
+    S = z.shape[1] - (1 if mip else 0)
+    e = raw.new_empty
+    return e((N, 3)), e((N,)), e((N,)), e((N, S)), e((N,))
+
+
+@custom_op("nvsr::composite_rays", mutates_args=(), device_types="cuda")
+def composite_rays(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white: bool, want_weights: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """composite with the ray directions taken from packed rays [N,11] -> rgb, disp, acc, weights (empty unless want_weights)"""
+    raw, z, rays, noise = _c(raw), _c(z), _c(rays), _c(noise)
+    N, S = z.shape
+    rgb, disp, acc = _f(N, 3, like=raw), _f(N, like=raw), _f(N, like=raw)
+    w = _f(N, S, like=raw) if want_weights else _f(0, like=raw)
+    if N:
+        capi.call("nvsr_composite_rays", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rays), capi.ptr(noise), int(white), capi.ptr(rgb),
+                  capi.ptr(disp), capi.ptr(acc), capi.ptr(w) if want_weights else None, None, capi.stream())
+    return rgb, disp, acc, w
+
+
+@composite_rays.register_fake
+def _(raw, z, rays, noise, white, want_weights):
+    N, S = z.shape
+    e = raw.new_empty
+    return e((N, 3)), e((N,)), e((N,)), e((N, S) if want_weights else (0,))
+
+
+@custom_op("nvsr::composite_backward", mutates_args=(), device_types="cuda")
+def composite_backward(raw: Tensor, z: Tensor, rd: Tensor, noise: Optional[Tensor], white: bool, mip: bool, g_rgb: Tensor,
+                       g_acc: Optional[Tensor]) -> Tensor:
+    """gradient of rgb_map / acc_map with respect to the radiance field: -> g_raw [N,S,4]; S <= 512"""
+    raw, z, rd, noise, g_rgb, g_acc = _c(raw), _c(z), _c(rd), _c(noise), _c(g_rgb), _c(g_acc)
+    N = z.shape[0]
+    S = z.shape[1] - (1 if mip else 0)
+    g_raw = torch.zeros_like(raw)
+    if N:
+        if S > 512:
+            raise NotImplementedError("nvsr_composite_backward handles up to 512 samples per ray")
+        capi.call("nvsr_composite_backward_mip" if mip else "nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd),
+                  capi.ptr(noise), int(white), capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), capi.stream())
+    return g_raw
+
+
+@composite_backward.register_fake
+def _(raw, z, rd, noise, white, mip, g_rgb, g_acc):
+    return torch.empty_like(raw)
+
+
+def _composite_setup(ctx, inputs, output):
+    raw, z, rd, noise, white, mip = inputs
+    ctx.save_for_backward(raw, z, rd, noise)
+    ctx.white, ctx.mip = white, mip
+    ctx.mark_non_differentiable(output[1], output[3], output[4])
+
+
+def _composite_bwd(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+    # rgb_map and acc_map are differentiable; disp, weights and depth carry no gradient path (the reference's losses use rgb only,
+    # train_nerf.py:884-891)
+    raw, z, rd, noise = ctx.saved_tensors
+    g_rgb = torch.zeros((z.shape[0], 3), dtype=torch.float32, device=raw.device) if g_rgb is None else capi.f32c(g_rgb)
+    g_acc = None if g_acc is None else capi.f32c(g_acc)
+    return torch.ops.nvsr.composite_backward(raw, z, rd, noise, ctx.white, ctx.mip, g_rgb, g_acc), None, None, None, None, None
+
+
+composite.register_autograd(_composite_bwd, setup_context=_composite_setup)
+
+
+# =====================================================================================================================================
+# feature-plane super-resolution (models.py:769-822 EDSR, :884-926 PlanesSR).  geometry = [Cin, Cout, hidden, n_blocks, n_up]
+# =====================================================================================================================================
+def _edsr_out_size(H, W, nb, n_up):
+    h, w = H - 2 - 4 * nb - 2, W - 2 - 4 * nb - 2
+    for _ in range(n_up):
+        h, w = (h - 2) * 2, (w - 2) * 2
+    return h - 2, w - 2
+
+
+@custom_op("nvsr::pack_edsr", mutates_args=(), device_types="cuda")
+def pack_edsr(natural: Tensor, geometry: Sequence[int], dgrad: bool) -> Tensor:
+    """conv weights in state-dict order -> MFMA-fragment blob (dgrad: of the flipped, transposed kernels of the data gradient)"""
+    nat = capi.f32c(natural)
+    lib = capi.lib()
+    assert nat.numel() == lib.nvsr_edsr_natural_floats(*geometry)
+    n = (lib.nvsr_edsr_packed_dgrad_floats if dgrad else lib.nvsr_edsr_packed_floats)(*geometry)
+    assert n > 0
+    packed = _f(n, like=nat)
+    capi.call("nvsr_pack_edsr_dgrad" if dgrad else "nvsr_pack_edsr", capi.ptr(nat), *geometry, capi.ptr(packed), capi.stream())
+    return packed
+
+
+@pack_edsr.register_fake
+def _(natural, geometry, dgrad):
+    lib = capi.lib()
+    return natural.new_empty(((lib.nvsr_edsr_packed_dgrad_floats if dgrad else lib.nvsr_edsr_packed_floats)(*[int(g) for g in geometry]),))
+
+
+@custom_op("nvsr::edsr", mutates_args=(), device_types="cuda")
+def edsr(x: Tensor, packed: Tensor, geometry: Sequence[int], arithmetic: int) -> Tensor:
+    """EDSR.forward: x [B,Cin,H,W] -> [B,Cout,Ho,Wo] (un-padded 3x3 convolutions, fused ReLU / residual / PixelShuffle epilogues)"""
+    x = _c(x)
+    cin, cout, hid, nb, n_up = geometry
+    B, Cin, H, W = x.shape
+    assert Cin == cin
+    Ho, Wo = _edsr_out_size(H, W, nb, n_up)
+    if Ho < 1 or Wo < 1:
+        raise capi.NvsrError("EDSR: input smaller than the receptive field")
+    out = _f(B, cout, Ho, Wo, like=x)
+    ws = _f(B * capi.lib().nvsr_edsr_workspace_floats(hid, nb, n_up, H, W), like=x)
+    capi.call("nvsr_edsr_forward_batch_arith", capi.ptr(x), B, Cin, H, W, capi.ptr(packed), cout, hid, nb, n_up, capi.ptr(out), capi.ptr(ws),
+              arithmetic, capi.stream())
+    return out
+
+
+@edsr.register_fake
+def _(x, packed, geometry, arithmetic):
+    cin, cout, hid, nb, n_up = geometry
+    Ho, Wo = _edsr_out_size(x.shape[2], x.shape[3], nb, n_up)
+    return x.new_empty((x.shape[0], cout, Ho, Wo))
+
+
+@custom_op("nvsr::edsr_train", mutates_args=(), device_types="cuda")
+def edsr_train(x: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: Tensor, geometry: Sequence[int], arithmetic: int) -> Tuple[Tensor, Tensor]:
+    """EDSR.forward that keeps every layer's input (`acts`) for the backward; differentiable in x and `natural` (the conv weights in
+    state-dict order; `packed` / `packed_dgrad` are their fragment blobs).  x [1,Cin,H,W]"""
+    x = _c(x)
+    cin, cout, hid, nb, n_up = geometry
+    assert x.shape[0] == 1 and x.shape[1] == cin, "the training forward runs one plane at a time"
+    H, W = x.shape[2:]
+    Ho, Wo = _edsr_out_size(H, W, nb, n_up)
+    out = _f(1, cout, Ho, Wo, like=x)
+    acts = _f(capi.lib().nvsr_edsr_acts_floats(cin, cout, hid, nb, n_up, H, W), like=x)
+    capi.call("nvsr_edsr_forward_train_arith", capi.ptr(x), cin, H, W, capi.ptr(packed), cout, hid, nb, n_up, capi.ptr(out), capi.ptr(acts),
+              arithmetic, capi.stream())
+    return out, acts
+
+
+@edsr_train.register_fake
+def _(x, natural, packed, packed_dgrad, geometry, arithmetic):
+    cin, cout, hid, nb, n_up = geometry
+    Ho, Wo = _edsr_out_size(x.shape[2], x.shape[3], nb, n_up)
+    return x.new_empty((1, cout, Ho, Wo)), x.new_empty((capi.lib().nvsr_edsr_acts_floats(cin, cout, hid, nb, n_up, int(x.shape[2]), int(x.shape[3])),))
+
+
+@custom_op("nvsr::edsr_backward", mutates_args=(), device_types="cuda")
+def edsr_backward(x: Tensor, acts: Tensor, packed_dgrad: Tensor, geometry: Sequence[int], d_out: Tensor, need_dx: bool, arithmetic: int) -> Tuple[Tensor, Tensor]:
+    """-> (weight gradients in state-dict order, dx (empty unless need_dx)); deterministic"""
+    x, d_out = _c(x), _c(d_out)
+    cin, cout, hid, nb, n_up = geometry
+    H, W = x.shape[2:]
+    lib = capi.lib()
+    gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_dx else _f(0, like=x)
+    ws = _f(lib.nvsr_edsr_backward_workspace_floats(cin, cout, hid, nb, n_up, H, W), like=x)
+    capi.call("nvsr_edsr_backward_arith", capi.ptr(x), cin, H, W, capi.ptr(acts), capi.ptr(packed_dgrad), cout, hid, nb, n_up, capi.ptr(d_out),
+              capi.ptr(gnat), capi.ptr(dx) if need_dx else None, capi.ptr(ws), arithmetic, capi.stream())
+    return gnat, dx
+
+
+@edsr_backward.register_fake
+def _(x, acts, packed_dgrad, geometry, d_out, need_dx, arithmetic):
+    cin, cout, hid, nb, n_up = geometry
+    n = 9 * (hid * cin + (2 * nb + 1) * hid * hid + n_up * 4 * hid * hid + cout * hid)
+    return x.new_empty((n,)), (torch.empty_like(x) if need_dx else x.new_empty((0,)))
+
+
+def _edsr_train_setup(ctx, inputs, output):
+    x, natural, packed, packed_dgrad, geometry, arithmetic = inputs
+    ctx.save_for_backward(x, output[1], packed_dgrad)
+    ctx.geometry, ctx.arithmetic = list(geometry), arithmetic
+    ctx.mark_non_differentiable(output[1])
+
+
+def _edsr_train_bwd(ctx, d_out, d_acts):
+    x, acts, packed_dgrad = ctx.saved_tensors
+    gnat, dx = torch.ops.nvsr.edsr_backward(x, acts, packed_dgrad, ctx.geometry, capi.f32c(d_out), ctx.needs_input_grad[0], ctx.arithmetic)
+    return (dx if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+edsr_train.register_autograd(_edsr_train_bwd, setup_context=_edsr_train_setup)
+
+
+def _roi_c(roi):
+    return None if roi is None else (C.c_float * 4)(*[float(v) for v in roi])
+
+
+@custom_op("nvsr::planes_sr", mutates_args=(), device_types="cuda")
+def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad: int, over: int, roi: Optional[Sequence[float]],
+              mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int) -> List[Tensor]:
+    """PlanesSR.forward for B equally sized LR planes [C,R0,R1] in ONE batched pass: crop + replicate pad -> EDSR -> crop over-padding
+    -> + bilinear x sf of the LR plane, NaN outside the ROI.  roi: None (full plane) or [ymin, xmin, ymax, xmax] in [-1, 1].
+    -> B tensors [1,C,sf R0,sf R1]"""
+    lr = [_c(t) for t in lr]
+    cin, cout, hid, nb, n_up = geometry
+    B = len(lr)
+    Cc, R0, R1 = lr[0].shape[-3:]
+    assert Cc == cin == cout and all(tuple(t.shape[-3:]) == (Cc, R0, R1) for t in lr)
+    roi_c = _roi_c(roi)
+    nws = capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+    if nws < 0:
+        raise capi.NvsrError("PlanesSR: region of interest too small for the network")
+    sf = 1 << n_up
+    outs = [_f(1, Cc, R0 * sf, R1 * sf, like=lr[0]) for _ in lr]
+    ws = _f(B * nws, like=lr[0])
+    if B == 1:
+        capi.call("nvsr_planes_sr_arith", capi.ptr(lr[0]), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
+                  capi.ptr(std), capi.ptr(outs[0]), capi.ptr(ws), arithmetic, capi.stream())
+    else:
+        lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lr])
+        out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
+        capi.call("nvsr_planes_sr_batch_arith", lr_ptrs, B, Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
+                  capi.ptr(std), out_ptrs, capi.ptr(ws), arithmetic, capi.stream())
+    return outs
+
+
+@planes_sr.register_fake
+def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic):
+    sf = 1 << geometry[4]
+    Cc, R0, R1 = lr[0].shape[-3:]
+    return [t.new_empty((1, Cc, R0 * sf, R1 * sf)) for t in lr]
+
+
+@custom_op("nvsr::planes_sr_train", mutates_args=(), device_types="cuda")
+def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: Tensor, geometry: Sequence[int], pad: int, over: int,
+                    roi: Optional[Sequence[float]], mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int) -> Tuple[Tensor, Tensor]:
+    """planes_sr of one plane that keeps the prepared input + activation record (`keep`); differentiable in `lr` and `natural`"""
+    lr = _c(lr)
+    cin, cout, hid, nb, n_up = geometry
+    Cc, R0, R1 = lr.shape[-3:]
+    roi_c = _roi_c(roi)
+    lib = capi.lib()
+    nws = lib.nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+    nkeep = lib.nvsr_planes_sr_keep_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c)
+    if nws < 0 or nkeep < 0:
+        raise capi.NvsrError("PlanesSR: region of interest too small for the network")
+    sf = 1 << n_up
+    out, ws, keep = _f(1, Cc, R0 * sf, R1 * sf, like=lr), _f(nws, like=lr), _f(nkeep, like=lr)
+    capi.call("nvsr_planes_sr_train_arith", capi.ptr(lr), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
+              capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), arithmetic, capi.stream())
+    return out, keep
+
+
+@planes_sr_train.register_fake
+def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic):
+    cin, cout, hid, nb, n_up = geometry
+    sf = 1 << n_up
+    Cc, R0, R1 = lr.shape[-3:]
+    nkeep = capi.lib().nvsr_planes_sr_keep_floats(int(Cc), int(R0), int(R1), hid, nb, n_up, pad, _roi_c(roi))
+    return lr.new_empty((1, Cc, R0 * sf, R1 * sf)), lr.new_empty((nkeep,))
+
+
+@custom_op("nvsr::planes_sr_backward", mutates_args=(), device_types="cuda")
+def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence[int], geometry: Sequence[int], pad: int, over: int,
+                       roi: Optional[Sequence[float]], std: Optional[Tensor], d_out: Tensor, need_lr: bool, arithmetic: int) -> Tuple[Tensor, Tensor]:
+    """-> (EDSR weight gradients in state-dict order, d_lr [1,C,R0,R1] (empty unless need_lr))"""
+    d_out = _c(d_out)
+    cin, cout, hid, nb, n_up = geometry
+    Cc, R0, R1 = plane_shape
+    roi_c = _roi_c(roi)
+    lib = capi.lib()
+    gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
+    d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if need_lr else _f(0, like=keep)
+    ws = _f(lib.nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c), like=keep)
+    capi.call("nvsr_planes_sr_backward_arith", Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, roi_c, capi.ptr(std),
+              capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr) if need_lr else None, capi.ptr(ws), arithmetic, capi.stream())
+    return gnat, d_lr
+
+
+@planes_sr_backward.register_fake
+def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, need_lr, arithmetic):
+    cin, cout, hid, nb, n_up = geometry
+    n = 9 * (hid * cin + (2 * nb + 1) * hid * hid + n_up * 4 * hid * hid + cout * hid)
+    Cc, R0, R1 = plane_shape
+    return keep.new_empty((n,)), keep.new_empty((1, Cc, R0, R1) if need_lr else (0,))
+
+
+def _planes_sr_train_setup(ctx, inputs, output):
+    lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic = inputs
+    ctx.save_for_backward(output[1], packed_dgrad, std)
+    ctx.mark_non_differentiable(output[1])
+    ctx.args = (list(lr.shape[-3:]), list(geometry), pad, over, None if roi is None else list(roi), arithmetic, lr.shape)
+
+
+def _planes_sr_train_bwd(ctx, d_out, d_keep):
+    keep, packed_dgrad, std = ctx.saved_tensors
+    shape, geometry, pad, over, roi, arithmetic, lr_shape = ctx.args
+    gnat, d_lr = torch.ops.nvsr.planes_sr_backward(keep, packed_dgrad, shape, geometry, pad, over, roi, std, capi.f32c(d_out),
+                                                   ctx.needs_input_grad[0], arithmetic)
+    return ((d_lr.reshape(lr_shape) if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None)) + (None,) * 9
+
+
+planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr_train_setup)
+
+# operators whose forward is checked with torch.library.opcheck in the GPU tests
+FORWARD_OPS = ["plane_to_channel_last", "plane_from_channel_last", "pack_decoder", "coarse_z", "importance_resample", "triplane_decode",
+               "render_pass", "render_rays", "decode_rays", "composite", "composite_rays", "edsr", "planes_sr"]

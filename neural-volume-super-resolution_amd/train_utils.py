@@ -9,6 +9,7 @@ import torch
 
 from . import capi
 from . import models
+from . import ops
 
 
 def identity_encoding(x):
@@ -46,58 +47,58 @@ def _reference_chunks(n_rays, options, mode, model_coarse, model_fine):
     return [(i, min(i + chunk, n_rays)) for i in range(0, n_rays, chunk)]
 
 
-RECORD_RAYS = 8192   # rays per backward launch of the RECOMPUTING decoder-gradient path (bounds its record: 9.2 KB per point)
-RECORD_FORWARD_MAX_POINTS = 1 << 21   # up to this many points of a pass (19 GB of record) the forward itself records the layer
-                                      # inputs and the backward never recomputes; beyond, the chunked recomputing path runs
+from .ops import RECORD_RAYS, RECORD_FORWARD_MAX_POINTS  # noqa: E402,F401  (tests and tools tune them through this module)
+
+
+def _record_limits():
+    """(RECORD_RAYS, RECORD_FORWARD_MAX_POINTS) as currently set on THIS module (tests lower them to force the recomputing path)"""
+    import sys
+    me = sys.modules[__name__]
+    ops.RECORD_RAYS = me.RECORD_RAYS
+    return me.RECORD_RAYS, me.RECORD_FORWARD_MAX_POINTS
 
 
 class _RenderRaysFn(torch.autograd.Function):
-    """Differentiable predict_and_render_radiance.  Leaves: the four planes of the current scene and the decoder parameters of
-    the coarse / fine model, the latter as flat blobs in state-dict order (`TwoDimPlanesModel.natural_blob(differentiable=True)`;
-    torch's own cat/reshape backward hands the slices to the parameters).
+    """Differentiable predict_and_render_radiance, written against torch.ops.nvsr.*.  Leaves: the four planes of the current scene and
+    the decoder parameters of the coarse / fine model, the latter as flat blobs in state-dict order
+    (`TwoDimPlanesModel.natural_blob(differentiable=True)`; torch's own cat/reshape backward hands the slices to the parameters).
 
-    forward  = coarse z -> decode + composite (keeps raw + weights) -> importance resampling (no gradient, train_utils.py:153)
-               -> fine decode + composite (keeps raw);
-    backward = per pass: composite backward (wave per ray) -> decoder backward + plane scatter-add (MFMA + float atomics)
-               [+ record of layer inputs / deltas -> weight-gradient contraction]."""
+    forward  = coarse_z -> decode_rays + composite_rays (keeps raw + weights) -> importance_resample (no gradient, train_utils.py:153)
+               -> fine decode_rays + composite_rays (keeps raw);
+    backward = per pass: composite_backward (wave per ray) -> decode_rays_backward (MFMA + plane scatter)
+               [+ record of layer inputs / deltas -> decoder_weight_grad].
+    The arithmetic the forward ran in is stored with the context and handed to every backward operator."""
 
     @staticmethod
     def forward(ctx, cfg, p0, p1, p2, pv, nat_c, nat_f):
-        capi_ = capi
-        N, Nc, Nf, dev = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"].device
-        rays, st = cfg["rays"], capi.stream()
-        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        z_c, w_c, raw_c = f(N, Nc), f(N, Nc), f(N, Nc, 4)
-        rgb_c, disp_c, acc_c = f(N, 3), f(N), f(N)
-        capi_.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), cfg["lindisp"], capi.ptr(cfg["t_rand"]), capi.ptr(z_c), st)
-        # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip,
-        # the fused per-ray kernel would run 32 workgroups; raw is needed by the backward anyway
-        # the forward publishes its ReLU gates (128 B per point) so that the backward does not recompute it; when decoder gradients
-        # are wanted it also records every layer's input (9.2 KB per point) unless the pass is too large for that
-        def aux(S, dec_grad):
-            fwd_rec = dec_grad and N * S <= RECORD_FORWARD_MAX_POINTS
-            gates = torch.empty((N, S, 32), dtype=torch.int32, device=dev) if (fwd_rec or not dec_grad) else None
-            rec = torch.empty(capi.lib().nvsr_decoder_record_floats(N, S), dtype=torch.float32, device=dev) if fwd_rec else None
-            return gates, rec
+        N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
+        nv = torch.ops.nvsr
+        arith_c, arith_f = cfg["arith_c"], cfg["arith_f"]
+        _, fwd_max = _record_limits()
+        z_c = nv.coarse_z(rays, Nc, bool(cfg["lindisp"]), cfg["t_rand"])
+        # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip, the fused
+        # per-ray kernel would run 32 workgroups; raw is needed by the backward anyway.  The forward publishes its ReLU gates (128 B per
+        # point) so that the backward does not recompute it; when decoder gradients are wanted it also records every layer's input
+        # (9.2 KB per point) unless the pass is too large for that
+        def flags(S, dec_grad):
+            fwd_rec = dec_grad and N * S <= fwd_max
+            return (fwd_rec or not dec_grad), fwd_rec
 
-        gates_c, rec_c = aux(Nc, cfg["dec_c_grad"] and cfg["coarse_grad"])
-        capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_c"]), capi.ptr(cfg["packed_c"]), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(raw_c),
-                   capi.ptr(gates_c), capi.ptr(rec_c), st)
-        capi_.call("nvsr_composite_rays", N, Nc, capi.ptr(raw_c), capi.ptr(z_c), capi.ptr(rays), capi.ptr(cfg["noise_c"]), cfg["white"],
-                   capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None, st)
+        def none_if_empty(t):
+            return t if t.numel() else None
+
+        want_g, want_r = flags(Nc, cfg["dec_c_grad"] and cfg["coarse_grad"])
+        raw_c, gates_c, rec_c = nv.decode_rays(cfg["planes_c"], cfg["consts"], cfg["packed_c"], rays, z_c, want_g, want_r, arith_c)
+        rgb_c, disp_c, acc_c, w_c = nv.composite_rays(raw_c, z_c, rays, cfg["noise_c"], bool(cfg["white"]), True)
         outs = [rgb_c, disp_c, acc_c]
-        saved = dict(z_c=z_c, raw_c=raw_c, gates_c=gates_c, rec_c=rec_c)
+        saved = dict(z_c=z_c, raw_c=raw_c, gates_c=none_if_empty(gates_c), rec_c=none_if_empty(rec_c))
         if Nf > 0:
-            z_f, raw_f = f(N, Nc + Nf), f(N, Nc + Nf, 4)
-            rgb_f, disp_f, acc_f = f(N, 3), f(N), f(N)
-            capi_.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(cfg["u"]), capi.ptr(z_f), st)
-            gates_f, rec_f = aux(Nc + Nf, cfg["dec_f_grad"])
-            capi_.call("nvsr_decode_rays_ex", C.byref(cfg["scene_f"]), capi.ptr(cfg["packed_f"]), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f),
-                       capi.ptr(raw_f), capi.ptr(gates_f), capi.ptr(rec_f), st)
-            capi_.call("nvsr_composite_rays", N, Nc + Nf, capi.ptr(raw_f), capi.ptr(z_f), capi.ptr(rays), capi.ptr(cfg["noise_f"]), cfg["white"],
-                       capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None, st)
+            z_f = nv.importance_resample(z_c, w_c, Nf, cfg["u"])
+            want_g, want_r = flags(Nc + Nf, cfg["dec_f_grad"])
+            raw_f, gates_f, rec_f = nv.decode_rays(cfg["planes_f"], cfg["consts"], cfg["packed_f"], rays, z_f, want_g, want_r, arith_f)
+            rgb_f, disp_f, acc_f, _ = nv.composite_rays(raw_f, z_f, rays, cfg["noise_f"], bool(cfg["white"]), False)
             outs += [rgb_f, disp_f, acc_f]
-            saved.update(z_f=z_f, raw_f=raw_f, gates_f=gates_f, rec_f=rec_f)
+            saved.update(z_f=z_f, raw_f=raw_f, gates_f=none_if_empty(gates_f), rec_f=none_if_empty(rec_f))
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
         ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 == 1])    # disparity: no gradient path implemented
         return tuple(outs)
@@ -105,57 +106,54 @@ class _RenderRaysFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         cfg, sv = ctx.cfg, ctx.saved
-        N, Nc, Nf, rays, st = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"], capi.stream()
+        N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
+        nv = torch.ops.nvsr
         dev = rays.device
         rd = rays[:, 3:6].contiguous()
-        shapes = cfg["plane_shapes"]                                    # channel-last (H, W, C)
         need = ctx.needs_input_grad
-        gplanes = [torch.zeros(sh, dtype=torch.float32, device=dev) if need[1 + d] else None for d, sh in enumerate(shapes)]
-        gptrs = (C.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gplanes]) if any(need[1:5]) else None
-        gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if need[5] else None
-        gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev) if (need[6] and Nf > 0) else None
+        need_planes = [bool(n) for n in need[1:5]]
+        gplanes = [None, None, None, None]
 
-        def one_pass(S, z, raw, noise, scene, packed, packed_bwd, g_rgb, g_acc, gdec, gates, fwd_rec):
-            if (g_rgb is None and g_acc is None) or (gptrs is None and gdec is None):
-                return
+        def add_planes(gs):
+            for d, g in enumerate(gs):
+                if need_planes[d]:
+                    gplanes[d] = g if gplanes[d] is None else gplanes[d].add_(g)
+
+        def one_pass(S, z, raw, noise, planes, packed, packed_bwd, g_rgb, g_acc, want_dec, gates, fwd_rec, arith):
+            """-> decoder gradient of this pass (state-dict order) or None"""
+            if (g_rgb is None and g_acc is None) or (not any(need_planes) and not want_dec):
+                return None
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
             g_acc = None if g_acc is None else capi.f32c(g_acc)
-            g_raw = torch.empty((N, S, 4), dtype=torch.float32, device=dev)
-            capi.call("nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), cfg["white"],
-                      capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), st)
-            # per-point rows of the view-direction plane's gradient (summed per ray before they touch the plane)
-            view_ws = torch.empty(N * S * capi.PLANE_CHANNELS, dtype=torch.float32, device=dev) if (gptrs is not None and need[4]) else None
-            if gdec is not None and fwd_rec is not None:
-                # the forward recorded the layer inputs: gate-driven backward adds the gradient half, then the contraction
-                capi.call("nvsr_render_pass_backward_gates", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                          capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(fwd_rec), st)
-                capi.call("nvsr_decoder_weight_grad", N, S, capi.ptr(fwd_rec), capi.ptr(gdec), st)
-                return
-            if gdec is None:
-                if gates is not None:
-                    capi.call("nvsr_render_pass_backward_gates", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                              capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), None, st)
-                else:
-                    capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays),
-                              capi.ptr(z), capi.ptr(g_raw), gptrs, None, capi.ptr(view_ws), st)
-                return
-            step = min(N, RECORD_RAYS)
-            record = torch.empty(capi.lib().nvsr_decoder_record_floats(step, S), dtype=torch.float32, device=dev)
-            for a in range(0, N, step):
-                n = min(step, N - a)
-                capi.call("nvsr_render_pass_backward_ex", C.byref(scene), capi.ptr(packed), capi.ptr(packed_bwd), n, S, capi.ptr(rays[a:]),
-                          capi.ptr(z[a:]), capi.ptr(g_raw[a:]), gptrs, capi.ptr(record), capi.ptr(view_ws), st)
-                capi.call("nvsr_decoder_weight_grad", n, S, capi.ptr(record), capi.ptr(gdec), st)
+            g_raw = nv.composite_backward(raw, z, rd, noise, bool(cfg["white"]), False, g_rgb, g_acc)
+            if gates is not None and (not want_dec or fwd_rec is not None):
+                # gate-driven backward (no recomputation); with the forward's record it adds the gradient half, then ONE contraction
+                add_planes(nv.decode_rays_backward(planes, cfg["consts"], packed, packed_bwd, rays, z, g_raw, gates, fwd_rec if want_dec else None,
+                                                   need_planes, arith))
+                return nv.decoder_weight_grad(fwd_rec, N, S, arith) if want_dec else None
+            # no gates published (pass too large for a forward record): recompute the forward in the backward, RECORD_RAYS rays at a time
+            _record_limits()
+            out = nv.decode_rays_backward_recompute(planes, cfg["consts"], packed, packed_bwd, rays, z, g_raw, need_planes, want_dec, arith)
+            add_planes(out[:4])
+            return out[4] if want_dec else None
 
+        gdec_c = gdec_f = None
         if cfg["coarse_grad"]:
-            one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["scene_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2], gdec_c,
-                     sv["gates_c"], sv["rec_c"])
+            gdec_c = one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["planes_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2],
+                              bool(need[5]), sv["gates_c"], sv["rec_c"], cfg["arith_c"])
         if Nf > 0:
-            one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["scene_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
-                     gdec_f, sv["gates_f"], sv["rec_f"])
+            gdec_f = one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["planes_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
+                              bool(need[6]), sv["gates_f"], sv["rec_f"], cfg["arith_f"])
         out = [None]
-        for g, src in zip(gplanes, cfg["plane_leaves"]):
+        for d, src in enumerate(cfg["plane_leaves"]):
+            g = gplanes[d]
+            if need_planes[d] and g is None:
+                g = torch.zeros(cfg["plane_shapes"][d], dtype=torch.float32, device=dev)
             out.append(None if g is None else models.from_channel_last(g, like=src))    # back to the reference's [1,C,H,W]
+        if need[5] and gdec_c is None:
+            gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
+        if need[6] and gdec_f is None and Nf > 0:
+            gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
         return tuple(out) + (gdec_c, gdec_f)
 
 
@@ -211,13 +209,16 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         top.SR_model.inner_model.wants_grad(*top.SR_model.LR_planes.values())
     train_path = mode == "train" and N > 0 and (_planes_need_grad(top) or dec_c_grad or dec_f_grad or sr_grad)
     if not (train_path and sr_on):       # (the SR training path builds its scene from the ROI planes below)
-        sc_c, keep_c = model_coarse.native_scene()
+        planes_c, consts = model_coarse.scene_args()
         if Nf > 0:
             # both passes sample the same planes in the reference unless only the fine model super-resolves
-            sc_f, keep_f = model_fine.native_scene()
-            same = all(sc_c.planes[d] == sc_f.planes[d] for d in range(4))
+            planes_f, consts_f = model_fine.scene_args()
+            same = all(a.data_ptr() == b.data_ptr() for a, b in zip(planes_c, planes_f))
         else:
-            sc_f, keep_f, same = sc_c, keep_c, True
+            planes_f, same = planes_c, True
+    arith_c = capi.resolve_decoder_arithmetic(model_coarse.arithmetic)
+    arith_f = capi.resolve_decoder_arithmetic(model_fine.arithmetic) if Nf > 0 else arith_c
+    white, lindisp = bool(m.white_background), bool(m.lindisp)
 
     if train_path:
         # training path (mode == "train" only; evaluation never builds a graph): gradients flow to whatever requires grad among the
@@ -227,49 +228,51 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
             if Nf > 0 and not (hasattr(model_coarse, "SR_model") and not model_coarse.skip_SR_):
                 raise NotImplementedError("training with only one of the two models super-resolving")
             leaves = top.training_planes(rays)
-            keep_f = [models.to_channel_last(p.detach()) for p in leaves]
-            sc_f, keep_f = top.native_scene(planes=keep_f)
-            sc_c, keep_c = sc_f, keep_f
+            planes_f, consts = top.scene_args(planes=[models.to_channel_last(p.detach()) for p in leaves])
+            planes_c = planes_f
         else:
             names = [models.get_plane_name(scene_id, d) for d in range(4)]
             leaves = [top.planes_[n] for n in names]
         leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
-        cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=int(bool(m.lindisp)), white=int(bool(m.white_background)), t_rand=t_rand, u=u,
-                   noise_c=n_c, noise_f=n_f, scene_c=sc_c, scene_f=sc_f, keep=(keep_c, keep_f), packed_c=packed_c, packed_f=packed_f,
+        # a limb mode trains with 3 limbs (what feeds a gradient stays close to f32): the 2-limb mode is a rendering-only option
+        t3 = lambda a: capi.ARITHMETIC["bf16x3"] if a == capi.ARITHMETIC["bf16x2"] else a
+        cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=lindisp, white=white, t_rand=t_rand, u=u, noise_c=n_c, noise_f=n_f,
+                   planes_c=planes_c, planes_f=planes_f, consts=consts, packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
-                   plane_shapes=[tuple(k.shape) for k in keep_f], plane_leaves=leaves[:4], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
-                   dec_f_grad=dec_f_grad)
+                   plane_shapes=[tuple(k.shape) for k in planes_f], plane_leaves=leaves[:4], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
+                   dec_f_grad=dec_f_grad, arith_c=t3(arith_c), arith_f=t3(arith_f))
         outs = _RenderRaysFn.apply(cfg, *leaves)
         if Nf > 0:
             return outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], None, None, None
         return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
-    rgb_c = torch.empty((N, 3), dtype=torch.float32, device=dev)
-    disp_c, acc_c = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2))
-    rgb_f = disp_f = acc_f = None
-    if Nf > 0:
-        rgb_f = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        disp_f, acc_f = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2))
+    nv = torch.ops.nvsr
     if N == 0:
-        return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
-    ws = torch.empty(capi.lib().nvsr_render_workspace_floats(N, Nc, Nf), dtype=torch.float32, device=dev)
-    white = int(bool(m.white_background))
-    lindisp = int(bool(m.lindisp))
-    if same:
-        capi.call("nvsr_render_rays", C.byref(sc_c), capi.ptr(packed_c), capi.ptr(packed_f), N, Nc, Nf, capi.ptr(rays), lindisp,
-                  white, capi.ptr(t_rand), capi.ptr(u), capi.ptr(n_c), capi.ptr(n_f), capi.ptr(rgb_c), capi.ptr(disp_c),
-                  capi.ptr(acc_c), capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), capi.ptr(ws), capi.stream())
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        return (e(0, 3), e(0), e(0)) + ((e(0, 3), e(0), e(0)) if Nf > 0 else (None, None, None)) + (None, None, None)
+    if same and arith_c == arith_f:
+        rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f = nv.render_rays(planes_c, consts, packed_c, packed_f, rays, Nc, Nf, lindisp, white, t_rand, u,
+                                                                   n_c, n_f, arith_c)
+        if Nf <= 0:
+            rgb_f = disp_f = acc_f = None
     else:
-        z_c, w_c, z_f = ws[:N * Nc], ws[N * Nc:2 * N * Nc], ws[2 * N * Nc:]
-        st = capi.stream()
-        capi.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), lindisp, capi.ptr(t_rand), capi.ptr(z_c), st)
-        capi.call("nvsr_render_pass", C.byref(sc_c), capi.ptr(packed_c), N, Nc, capi.ptr(rays), capi.ptr(z_c), capi.ptr(n_c), white,
-                  capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c), capi.ptr(w_c), None, st)
-        capi.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_c), capi.ptr(w_c), capi.ptr(u), capi.ptr(z_f), st)
-        capi.call("nvsr_render_pass", C.byref(sc_f), capi.ptr(packed_f), N, Nc + Nf, capi.ptr(rays), capi.ptr(z_f), capi.ptr(n_f),
-                  white, capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), None, None, st)
+        # the two passes sample different planes (only the fine model super-resolves) or run in different arithmetic: pass by pass
+        fused = N >= 65536       # NVSR_FUSED_MIN_RAYS: below it the sample-parallel decoder + the wave-per-ray compositor fill the chip
+
+        def one_pass(planes, packed, z, noise, want_w, arith):
+            if fused:
+                return nv.render_pass(planes, consts, packed, rays, z, noise, white, want_w, arith)
+            raw, _, _ = nv.decode_rays(planes, consts, packed, rays, z, False, False, arith)
+            return nv.composite_rays(raw, z, rays, noise, white, want_w)
+
+        z_c = nv.coarse_z(rays, Nc, lindisp, t_rand)
+        rgb_c, disp_c, acc_c, w_c = one_pass(planes_c, packed_c, z_c, n_c, Nf > 0, arith_c)
+        rgb_f = disp_f = acc_f = None
+        if Nf > 0:
+            z_f = nv.importance_resample(z_c, w_c, Nf, u)
+            rgb_f, disp_f, acc_f, _ = one_pass(planes_f, packed_f, z_f, n_f, False, arith_f)
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
 
 

@@ -2,42 +2,7 @@
 import torch
 
 from . import capi
-
-
-class _CompositeFn(torch.autograd.Function):
-    """volume_render_radiance_field with a gradient for the radiance field (rgb_map and acc_map are differentiable; disp, weights and
-    depth are returned without a graph -- the reference's losses use rgb only, train_nerf.py:884-891)."""
-
-    @staticmethod
-    def forward(ctx, raw, z, rd, noise, white, mip=False):
-        lead, S = z.shape[:-1], z.shape[-1] - (1 if mip else 0)          # mip: z holds the S + 1 interval edges
-        N = z.numel() // z.shape[-1]
-        dev = raw.device
-        rgb = torch.empty(list(lead) + [3], dtype=torch.float32, device=dev)
-        disp, acc, depth = (torch.empty(list(lead), dtype=torch.float32, device=dev) for _ in range(3))
-        weights = torch.empty(list(lead) + [S], dtype=torch.float32, device=dev)
-        if N:
-            capi.call("nvsr_composite_mip" if mip else "nvsr_composite", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), white,
-                      capi.ptr(rgb), capi.ptr(disp), capi.ptr(acc), capi.ptr(weights), capi.ptr(depth), capi.stream())
-        ctx.save_for_backward(raw, z, rd)
-        ctx.noise, ctx.white, ctx.mip = noise, white, mip
-        ctx.mark_non_differentiable(disp, weights, depth)
-        return rgb, disp, acc, weights, depth
-
-    @staticmethod
-    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
-        raw, z, rd = ctx.saved_tensors
-        S = z.shape[-1] - (1 if ctx.mip else 0)
-        N = z.numel() // z.shape[-1]
-        g_raw = torch.zeros_like(raw)
-        if N and S <= 512:
-            g_rgb = torch.zeros(list(z.shape[:-1]) + [3], dtype=torch.float32, device=raw.device) if g_rgb is None else capi.f32c(g_rgb)
-            g_acc = None if g_acc is None else capi.f32c(g_acc)
-            capi.call("nvsr_composite_backward_mip" if ctx.mip else "nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(ctx.noise), ctx.white, capi.ptr(g_rgb),
-                      capi.ptr(g_acc), capi.ptr(g_raw), capi.stream())
-        elif N:
-            raise NotImplementedError("nvsr_composite_backward handles up to 512 samples per ray")
-        return g_raw, None, None, None, None, None
+from . import ops  # noqa: F401  (registers torch.ops.nvsr.*)
 
 
 def volume_render_radiance_field(radiance_field, depth_values, ray_directions, radiance_field_noise_std=0.0,
@@ -55,13 +20,9 @@ def volume_render_radiance_field(radiance_field, depth_values, ray_directions, r
         noise = (torch.randn(raw[..., 3].shape) * radiance_field_noise_std).to(raw)
     if noise is not None:
         noise = capi.f32c(noise)
-    if torch.is_grad_enabled() and radiance_field.requires_grad:
-        return _CompositeFn.apply(raw, z, rd, noise, int(bool(white_background)), mip)
-    dev = raw.device
-    rgb = torch.empty(list(lead) + [3], dtype=torch.float32, device=dev)
-    disp, acc, depth = (torch.empty(list(lead), dtype=torch.float32, device=dev) for _ in range(3))
-    weights = torch.empty(list(lead) + [S], dtype=torch.float32, device=dev)
-    if N:
-        capi.call("nvsr_composite_mip" if mip else "nvsr_composite", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise),
-                  int(bool(white_background)), capi.ptr(rgb), capi.ptr(disp), capi.ptr(acc), capi.ptr(weights), capi.ptr(depth), capi.stream())
-    return rgb, disp, acc, weights, depth
+    # torch.ops.nvsr.composite: differentiable in the radiance field (rgb_map and acc_map carry gradients; disp, weights and depth are
+    # returned without a gradient path -- the reference's losses use rgb only, train_nerf.py:884-891)
+    rgb, disp, acc, weights, depth = torch.ops.nvsr.composite(raw.reshape(N, S, 4), z.reshape(N, z.shape[-1]), rd.reshape(N, 3),
+                                                              None if noise is None else noise.reshape(N, S), bool(white_background), mip)
+    lead = list(lead)
+    return rgb.reshape(lead + [3]), disp.reshape(lead), acc.reshape(lead), weights.reshape(lead + [S]), depth.reshape(lead)

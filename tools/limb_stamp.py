@@ -1,5 +1,6 @@
 """Cycle stamps of render3.hip's step sections.  Run on the GPU box:
-   NVSR_EXTRA_HIPCC_FLAGS=-DR3_STAMP=1 python tools/limb_stamp.py   (rebuilds the library with the stamps compiled in)"""
+   NVSR_EXTRA_HIPCC_FLAGS=-DR3_STAMP=1 python tools/limb_stamp.py   (builds a VARIANT library with the stamps compiled in under
+   gpurun_out/variants/ and loads that one; the product library is never overwritten)"""
 import ctypes as C
 import os
 import sys
@@ -7,9 +8,16 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", "").split() and "NVSR_HIP_LIB" not in os.environ:
+    # experiment flags: compile to a separate file and bind THAT library (capi reads NVSR_HIP_LIB at import)
+    from importlib import util as _u
+    _spec = _u.spec_from_file_location("_nvsr_build", os.path.join(ROOT, "neural-volume-super-resolution_amd", "build.py"))
+    _b = _u.module_from_spec(_spec); _spec.loader.exec_module(_b)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "variants"), exist_ok=True)
+    os.environ["NVSR_HIP_LIB"] = _b.build_extension(out_path=os.path.join(ROOT, "gpurun_out", "variants", "stamp.so"))
 import nvsr_amd as hip
-hip.build_extension(force=True)
 from bench import make_synthetic_scene
 
 capi = hip.capi

@@ -1,6 +1,7 @@
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
+ROOT = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for tag in sys.argv[1:]:
-    for f in glob.glob('/root/repo/gpurun_out/pmc_%s/*/*counter_collection.csv'%tag):
+    for f in glob.glob(os.path.join(ROOT, 'gpurun_out/pmc_%s/*/*counter_collection.csv' % tag)):
         d=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if 'render_pass' not in r['Kernel_Name']: continue

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): bench lines + rocprofv3 kernel stats + the two HBM-counter passes.
 # usage: tools/profile_round.sh <round-tag>      outputs under gpurun_out/<round-tag>/
-R=$GRAFT_REPO_ROOT; T=${1:-r01}; O=$R/gpurun_out/$T
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; T=${1:-r01}; O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_render.json 2> $O/bench_render.err
