@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the rendering hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torch.distributed.run -- either launched that way
+                                                           by the driver, or, when WORLD_SIZE is not set, by this script itself: the
+                                                           parent spawns the N ranks BEFORE touching the GPU and relays their output)
 
-Default workload (BASELINE.json configs[1]): one "step" renders one 800x800 view (640 000 rays) of a synthetic Lego-like scene with
+Default workload (BASELINE.json configs[1]): one "step" renders 800x800 views (640 000 rays each) of a synthetic Lego-like scene with
 64 coarse + 128 fine samples per ray (256 decoder evaluations per ray) through the tri-plane decoder, planes 3 x 800^2 x 48 +
-32^2 x 48, everything resident in HBM before the timed region.  Weak scaling: every rank renders its own view of the same
-(replicated) scene; there is no data-path collective.  Prints ONE JSON line on rank 0.
+32^2 x 48, everything resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+Partition of the rays over N > 1 GPUs (--partition; SURVEY.md 8e: contiguous blocks of image rows per GPU, scene replicated, one
+all_gather of the finished pixels, no other data-path collective):
+  rows   (default for N > 1) a step renders N views, EVERY view sharded by row blocks over the N ranks (distributed.render_views_sharded):
+         a rank renders its rows of all N views in one launch = one frame's worth of rays per step whatever N is -> "scaling": "weak";
+  frame  a step renders ONE view, its rows sharded over the ranks (distributed.render_image_sharded) -> "scaling": "strong";
+  view   every rank renders its own whole view, no collective at all (round 1's mode) -> "weak".
 
 Other workloads of the same path (--workload; same JSON contract, their own metric):
   train   BASELINE configs[3] (Feature_Planes_Only.yml): one optimisation step = 4096 random rays of one view, 64+64 samples, planes
@@ -131,14 +138,38 @@ def time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine, reps=3):
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def pmc_traffic(workload, dtype):
-    """HBM bytes of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_latest.json,
-    FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes) -- counters cannot be read from inside this process.  None when the passes were
-    taken with another arithmetic."""
+def csrc_tree_hash():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/nvsr.h; names + contents): identifies the kernels a counter pass was
+    taken with.  (`git rev-parse HEAD:.../csrc` would do the same, but the GPU box receives a snapshot without .git.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neural-volume-super-resolution_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "include", "nvsr.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_record():
+    """profiles/pmc_latest.json if -- and only if -- its counters were taken with the kernels of THIS tree (csrc_sha256 recorded by
+    tools/profile_collect.py): a stale file must not put another kernel's traffic into the line.  Else None."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None
-    e = json.load(open(path)).get(workload)
+    rec = json.load(open(path))
+    return rec if rec.get("csrc_sha256") == csrc_tree_hash() else None
+
+
+def pmc_traffic(workload, dtype):
+    """HBM bytes of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_latest.json,
+    FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes) -- counters cannot be read from inside this process.  None when the passes were
+    taken with another arithmetic or with other kernel sources."""
+    rec = pmc_record()
+    if rec is None:
+        return None
+    e = rec.get(workload)
     return e["traffic_bytes"] if e and e.get("arithmetic") == dtype else None
 
 
@@ -198,9 +229,16 @@ def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
     t, _ = run(fast, n)
     n_chk = min(n, 2048)
     _, ref = run(chk, n_chk)
-    gpu = rgb_fine_gpu[torch.from_numpy(ids[:n_chk]).to(rgb_fine_gpu.device)].cpu().numpy()
-    mse = float(np.mean((gpu.astype(np.float64) - ref["rgb_fine"]) ** 2))
-    psnr = 200.0 if mse == 0 else -10.0 * np.log10(mse)
+    chk_ids = torch.from_numpy(ids[:n_chk]).to(rgb_fine_gpu.device)
+
+    def psnr_of(rgb_fine):
+        """PSNR of a rendered frame's checked rays against the double-precision oracle"""
+        gpu = rgb_fine.reshape(-1, 3)[chk_ids].cpu().numpy()
+        mse = float(np.mean((gpu.astype(np.float64) - ref["rgb_fine"]) ** 2))
+        return 200.0 if mse == 0 else -10.0 * np.log10(mse)
+
+    psnr = psnr_of(rgb_fine_gpu)
+    cpu_baseline.psnr_of = psnr_of
     cores = os.cpu_count() or 1
     return {"value": n / t, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d rays of the same 800x800 / 64+128 / planes 800^2 frame, %.1f s, C oracle fp32 -Ofast OpenMP (%d threads)" % (n, t, cores),
@@ -455,6 +493,8 @@ def main():
                     help="--workload train: keep the plane parameters in the reference's NCHW memory order (a re-layout kernel per plane and step) "
                          "instead of torch.channels_last, whose memory is the kernels' native [H][W][C] layout")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--partition", choices=["rows", "frame", "view"], default=None,
+                    help="--workload render, N > 1: how the rays are sharded (see the module docstring); default rows")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800, help="image side (default 800 = BASELINE config)")
@@ -463,7 +503,23 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no HIP call, no
+        # torch.cuda.is_available()); the ranks are CHILD processes (never an exec from a process that has initialised the GPU).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (or run without torch.distributed.run: --gpus N self-launches)"
+                 % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -495,14 +551,41 @@ def main():
 
     H = W = args.res
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
-    # same (replicated) scene on every rank, a different view per rank
-    mc, mf, sid, pose = make_synthetic_scene(dev, args.plane_res, 32, seed=0, theta=30.0 + 45.0 * rank)
+    partition = args.partition or ("rows" if world > 1 else "view")
+    if world == 1:
+        partition = "view"            # one rank: every partition is the same single-GPU frame
+    # same (replicated) scene on every rank; "view": a different view per rank, "frame": one view, "rows": one view per rank, all shared
+    mc, mf, sid, pose = make_synthetic_scene(dev, args.plane_res, 32, seed=0, theta=30.0 + (45.0 * rank if partition == "view" else 0.0))
     opts, scfg = render_options(64, 128)
     ro, rd = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    D = nvsr_amd.distributed
+    poses = [torch.from_numpy(pose_spherical(30.0 + 45.0 * v, -30.0, 4.0)).to(dev) for v in range(world)]
 
     def step():
-        r, d = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)   # ray generation is part of the path
-        return nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mf, r, d, opts, scene_id=sid, scene_config=scfg)
+        if partition == "view":
+            r, d = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)   # ray generation is part of the path
+            return nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mf, r, d, opts, scene_id=sid, scene_config=scfg)
+        if partition == "frame":
+            r, d = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+            return D.render_image_sharded(H, W, focal, mc, mf, r, d, opts, sid, scfg)
+        return D.render_views_sharded(H, W, focal, mc, mf, poses, opts, sid, scfg)
+
+    if rehearsal and world > 1 and partition != "view":
+        # correctness of the sharded partitions with the HIP renderer (asserted by tests/test_hip_round2.py through the exit code): every
+        # rank's assembled frames equal, bit for bit, the frames one rank renders alone
+        got = step()
+        if partition == "frame":
+            alone = nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+            same = torch.equal(got[0], alone[0]) and torch.equal(got[1], alone[3])
+        else:
+            same = True
+            for v, pv in enumerate(poses):
+                a = nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mf, *nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pv), opts, scene_id=sid,
+                                                   scene_config=scfg)
+                same = same and torch.equal(got[0][v], a[0]) and torch.equal(got[1][v], a[3])
+        print("SHARDED_RENDER_%s rank %d partition %s" % ("IDENTICAL" if same else "DIFFERS", rank, partition), file=sys.stderr, flush=True)
+        if not same:
+            sys.exit(3)
 
     for _ in range(args.warmup):
         out = step()
@@ -523,18 +606,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    rays_per_step = H * W
-    value = world * rays_per_step * args.steps / elapsed
+    rays_per_step = H * W                                            # per GPU and step ("frame": of the whole job)
+    frames_per_step = 1 if partition == "frame" else world
+    value = frames_per_step * rays_per_step * args.steps / elapsed
     mode = nvsr_amd.capi.get_decoder_arithmetic()
     arith = ARITHMETIC[mode]
     result = {
         "metric": "rendered rays/sec (64+128 samples) at 800x800 Lego-like view",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if (partition == "frame" and world > 1) else "weak",
+        "vs_baseline": None,
         "dtype": arith["dtype"], "data": "synthetic", "decoder_arithmetic": mode,
         "config": {"workload": "Blender-'lego'-like %dx%d view, 64 coarse + 128 fine samples, tri-plane decoder (3x%d^2x48 + 32^2x48 planes, "
-                               "4+4x128 MLP), 1 view per GPU per step" % (H, W, args.plane_res),
-                   "rays_per_step_per_gpu": rays_per_step, "decoder_evals_per_ray": 256, "parallelism": "rays sharded by view, no collective"},
+                               "4+4x128 MLP), %s" % (H, W, args.plane_res,
+                                                     {"view": "1 view per GPU per step", "frame": "1 view per step, its rows sharded over the GPUs",
+                                                      "rows": "%d views per step, every view's rows sharded over the GPUs" % world}[partition]),
+                   "rays_per_step_per_gpu": rays_per_step // (world if partition == "frame" else 1), "decoder_evals_per_ray": 256,
+                   "partition": partition,
+                   "parallelism": {"view": "rays sharded by view, no collective",
+                                   "frame": "rays of one frame sharded by row blocks, one all_gather of the pixels per frame",
+                                   "rows": "rays of every frame sharded by row blocks (a rank renders its rows of all views in one launch), "
+                                           "one all_gather of the pixels per step"}[partition]},
         "decoder_evals_per_s_per_gpu": value * 256 / world,
     }
     if rank == 0:
@@ -556,11 +648,9 @@ def main():
         # HBM-side traffic of that launch: PMC counters cannot be read from inside this process; the value comes from the
         # committed rocprofv3 --pmc passes of this same command (profiles/pmc_latest.json), corrected as the guide prescribes
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and H == 800 and args.plane_res == 800:
-            traffic = json.load(open(pmc)).get("traffic_bytes")
-        if traffic is not None and json.load(open(pmc)).get("decoder_arithmetic", "f32") != mode:
-            traffic = None                            # counters of another kernel
+        rec = pmc_record()                            # None unless the counter passes were taken with these kernel sources
+        if rec is not None and H == 800 and args.plane_res == 800 and rec.get("decoder_arithmetic", "f32") == mode:
+            traffic = rec.get("traffic_bytes")
         peak = arith["pipe_peak"] / arith["products"]
         result["roofline"] = {"kernel": "%s (fine pass, S=192)" % arith["kernel"], "bound": "mfma", "achieved": achieved,
                               "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -578,10 +668,11 @@ def main():
                 "algorithmic_gather_bytes": GATHER_BYTES_PER_EVAL * N * 192}
         if world == 1 and not args.no_modes:
             # the same frame in the other arithmetic modes (2 steps each), so that every number of this line can be re-based
-            modes = {}
+            modes, frames = {}, {}
             for m2 in ("f32", "bf16x3", "bf16x2"):
                 nvsr_amd.capi.set_decoder_arithmetic(m2)
-                step(); torch.cuda.synchronize()
+                frames[m2] = step()[3]
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(2):
                     step()
@@ -595,6 +686,10 @@ def main():
             cb, psnr = cpu_baseline(nvsr_amd, mc, mf, sid, rays, bufs[3])
             result["cpu_baseline"] = cb
             result["psnr_vs_oracle_db"] = psnr
+            if "arithmetic_modes" in result:          # the same frame in every arithmetic against the same oracle rays
+                for m2, fr in frames.items():
+                    result["arithmetic_modes"][m2]["psnr_vs_oracle_db"] = cpu_baseline.psnr_of(fr)
+                result["psnr_vs_oracle_db_by_arithmetic"] = {m2: v["psnr_vs_oracle_db"] for m2, v in result["arithmetic_modes"].items()}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -29,6 +29,12 @@ def shard_rays(batch_rays, rank=None, world=None, group=None):
     return batch_rays[:, lo:hi], (lo, hi)
 
 
+def _collective_device(t, group=None):
+    """the device a collective of this backend runs on: RCCL ("nccl") moves device buffers over xGMI; gloo (CPU rehearsals of the N > 1
+    path, also with the ranks' tensors on a GPU) implements all_gather for host buffers only -> stage through the host"""
+    return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def gather_row_blocks(local, counts, group=None):
     """all_gather of per-rank row blocks of unequal length (counts[r] rows on rank r) -> [sum(counts), ...] on every rank"""
     rank, world = world_info(group)
@@ -36,11 +42,12 @@ def gather_row_blocks(local, counts, group=None):
         return local
     assert local.shape[0] == counts[rank]
     n_max = max(counts)
-    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    cdev = _collective_device(local, group)
+    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([parts[r][: counts[r]] for r in range(world)], 0)
+    return torch.cat([parts[r][: counts[r]] for r in range(world)], 0).to(local.device)
 
 
 def gather_rows(local, n_total, group=None):
@@ -67,6 +74,36 @@ def render_image_sharded(height, width, focal, model_coarse, model_fine, ray_ori
     rgb_c = gather_rows(rgb_c, n, group).reshape(height, width, 3)
     rgb_f = None if rgb_f is None else gather_rows(rgb_f, n, group).reshape(height, width, 3)
     return rgb_c, rgb_f
+
+
+def render_views_sharded(height, width, focal, model_coarse, model_fine, poses, options, scene_id, scene_config, group=None, gather=True,
+                         render_fn=None, ray_fn=None):
+    """Several views of one scene, EVERY view sharded over the ranks by contiguous blocks of image rows -- rank r renders
+    rows shard_bounds(height, r, world) of each view, all of them in ONE launch of the fused passes (rays are independent units, so the
+    rank's blocks of the V views are simply concatenated: with V = world views per step a rank renders one frame's worth of rays per
+    step, whatever the world size).  One all_gather assembles the frames.  Returns (rgb_coarse, rgb_fine) as [V,H,W,3] on every rank
+    (gather=True) or this rank's [V, rows, W, 3] blocks and its (lo, hi)."""
+    if render_fn is None:
+        from .train_utils import run_one_iter_of_nerf as render_fn
+    if ray_fn is None:
+        from .nerf_helpers import get_ray_bundle as ray_fn
+    rank, world = world_info(group)
+    lo, hi = shard_bounds(height, rank, world)
+    V, rows = len(poses), hi - lo
+    blocks = []
+    for pose in poses:
+        ro, rd = ray_fn(height, width, focal, pose)
+        blocks.append(torch.stack([ro[lo:hi].reshape(-1, 3), rd[lo:hi].reshape(-1, 3)], 0))
+    out = render_fn(height, width, focal, model_coarse, model_fine, torch.cat(blocks, 1), options, scene_id, mode="validation",
+                    scene_config=scene_config)
+    local = [None if t is None else t.reshape(V, rows, width, 3) for t in (out[0], out[3])]
+    if not gather:
+        return local[0], local[1], (lo, hi)
+    counts = [shard_bounds(height, r, world)[1] - shard_bounds(height, r, world)[0] for r in range(world)]
+    full = []
+    for t in local:                    # rows first for gather_row_blocks, then back to [V,H,W,3]
+        full.append(None if t is None else gather_row_blocks(t.permute(1, 0, 2, 3).contiguous(), counts, group).permute(1, 0, 2, 3).contiguous())
+    return full[0], full[1]
 
 
 def band_roi(lo, hi, rows):
@@ -117,7 +154,13 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True
         if not bucket:
             return
         flat = torch.cat([t.reshape(-1) for t in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        cdev = _collective_device(flat, group)
+        if cdev != flat.device:           # (gloo rehearsal with device tensors)
+            host = flat.to(cdev)
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat /= world
         off = 0

@@ -160,3 +160,15 @@ def im_resize(image, scale_factor, degradation=None, fname=None):
         return image
     h, w = image.shape[0] // f, image.shape[1] // f
     return image.reshape(h, f, w, f, -1).mean(axis=(1, 3)).astype(image.dtype).reshape((h, w) + image.shape[2:])
+
+
+def safe_saving(file_name, content, suffix, best=False, run_time_signature=0):
+    """nerf_helpers.py:19-48 (implemented in plane_store.py)"""
+    from .plane_store import safe_saving as impl
+    return impl(file_name, content, suffix, best, run_time_signature)
+
+
+def safe_loading(file_name, suffix, best=False):
+    """nerf_helpers.py:50-67 (implemented in plane_store.py)"""
+    from .plane_store import safe_loading as impl
+    return impl(file_name, suffix, best)

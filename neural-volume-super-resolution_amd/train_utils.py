@@ -342,3 +342,9 @@ def eval_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins
     if rgb_fine is not None:
         rgb_fine = rgb_fine.reshape([height, width, -1])
     return rgb_coarse, None, None, rgb_fine, None, None, rgb_SR, None, None
+
+
+def find_latest_checkpoint(ckpt_path, sr, find_best=False):
+    """train_utils.py:333-345 (implemented with the rest of the store protocol in plane_store.py)"""
+    from .plane_store import find_latest_checkpoint as impl
+    return impl(ckpt_path, sr, find_best)

@@ -24,6 +24,8 @@ Fixture index:
   g14_sr_grads.npz    autograd through EDSR / PlanesSR (full plane and ROI): weights, network input and LR plane ('SR' in what)
   g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
   g16_composite_mip.npz volume_render_radiance_field(mip_nerf=True) + its autograd wrt the radiance field (volume_rendering_utils.py:19-26,41-42)
+  g17_store(.npz + g17_store/)  plane file, decoder checkpoint and SR checkpoint WRITTEN by the reference (PlanesOptimizer.save_params,
+                      safe_saving; models.py:640-670, nerf_helpers.py:19-48, train_nerf.py:996-1008) + what it renders from them
   g15_loaders.npz     load_blender_data / load_llff_data on two tiny synthetic scenes (load_blender.py:232-332, load_llff.py:70-360).
                       imageio and cv2 are absent here: the harness reads the PNGs with PIL and gives cv2.resize(INTER_AREA) its
                       definition for integer factors (block mean), so the resampling itself is pinned by definition only; the JSON /
@@ -52,6 +54,10 @@ def import_reference():
     scipy.signal.gaussian = scipy.signal.windows.gaussian
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
+    # the reference targets torch 1.12, whose torch.load unpickles arbitrary objects (its plane files hold an nn.ParameterDict);
+    # torch >= 2.6 defaults to weights_only=True
+    _load = torch.load
+    torch.load = lambda *a, **k: _load(*a, **{"weights_only": False, **k})
     sys.path.insert(0, REF)
     import nerf_helpers, volume_rendering_utils, models, train_utils  # noqa
     from cfgnode import CfgNode
@@ -878,9 +884,100 @@ def g16_composite_mip():
     save("g16_composite_mip.npz", **arrs)
 
 
+def g17_store():
+    """Files WRITTEN BY THE REFERENCE for the plane store / checkpoint formats:
+      g17_store/planes/coarse_<sid>.par      PlanesOptimizer.__init__(init_params) -> draw_scenes -> one Adam step -> save_params
+                                              (models.py:499-581,640-670,683-726) through safe_saving (nerf_helpers.py:19-48)
+      g17_store/checkpoint00007.ckpt         {model_coarse_state_dict, model_fine_state_dict, optimizer} with the key filtering of
+                                              train_nerf.py:996-1008, through safe_saving
+      g17_store/SR_checkpoint00007.ckpt      {SR_model, SR_optimizer} (train_nerf.py:996-999)
+    and, in g17_store.npz, what the reference renders / super-resolves from those files after reading them back itself
+    (PlanesOptimizer.load_scene, load_state_dict(strict=False), safe_loading)."""
+    import shutil
+    from collections import OrderedDict
+
+    out_dir = os.path.join(HERE, "g17_store")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    planes_dir = os.path.join(out_dir, "planes") + "/"
+    os.makedirs(planes_dir)
+    R, Rv = 12, 6
+    sid, mc, mf, _, box = build_models(R, Rv, 0.5, seed=17)
+    # -- the plane store, written by PlanesOptimizer itself ---------------------------------------------------------------
+    torch.manual_seed(170)
+    opt = models.PlanesOptimizer(optimizer_type="Adam", scene_id_plane_resolution={sid: (R, Rv)}, options=CfgNode({"steps_per_buffer": -1}),
+                                 save_location=[planes_dir], lr=5e-3, model_coarse=mc, model_fine=mf, use_coarse_planes=True, init_params=True,
+                                 optimize=True, training_scenes=[sid], coords_normalization={sid: box}, available_scenes=[sid],
+                                 STD_factor=2.0, run_time_signature=0)
+    opt.draw_scenes()                                     # reads the initial file, builds Adam
+    for m in (mc, mf):
+        m.set_cur_scene_id(sid)
+    opt.cur_id = sid
+    g = torch.Generator().manual_seed(171)
+    for p_ in mc.planes_.values():                        # one real Adam step so that the saved opt_states are populated
+        p_.grad = torch.randn(p_.shape, generator=g) * 1e-2
+    opt.step()
+    opt.save_params()                                     # safe_saving({'params','opt_states','coords_normalization'})
+    # -- decoder checkpoint with train_nerf.py's key filtering -------------------------------------------------------------
+    optimizer = torch.optim.Adam([p_ for k, p_ in mc.named_parameters() if "planes_" not in k and "NON_LEARNED" not in k], lr=1e-4)
+    tokens_2_exclude = ["planes_.", "SR_model"]
+    ck = {"model_coarse_state_dict": mc.state_dict(), "model_fine_state_dict": mf.state_dict()}
+    ck["model_fine_state_dict"] = OrderedDict([(k, v) for k, v in ck["model_fine_state_dict"].items() if all(t not in k for t in tokens_2_exclude + ["rot_mats"])])
+    ck["model_coarse_state_dict"] = OrderedDict([(k, v) for k, v in ck["model_coarse_state_dict"].items() if all(t not in k for t in tokens_2_exclude)])
+    ck["optimizer"] = optimizer.state_dict()
+    nh.safe_saving(os.path.join(out_dir, "checkpoint00007.ckpt"), content=ck, suffix="ckpt", best=False, run_time_signature=0)
+    # -- SR checkpoint -----------------------------------------------------------------------------------------------------
+    torch.manual_seed(172)
+    C, hidden, nblocks, sf = 48, 16, 2, 4
+    sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bilinear")
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    sr_opt = torch.optim.Adam(sr.parameters(), lr=1e-4)
+    nh.safe_saving(os.path.join(out_dir, "SR_checkpoint00007.ckpt"), content={"SR_model": sr.state_dict(), "SR_optimizer": sr_opt.state_dict()},
+                   suffix="ckpt", best=False, run_time_signature=0)
+    # -- read everything back WITH THE REFERENCE into fresh models and record what it computes ---------------------------------
+    sid2, mc2, mf2, _, _ = build_models(R, Rv, 0.5, seed=999)          # different weights / planes: everything must come from the files
+    assert sid2 == sid
+    opt2 = models.PlanesOptimizer(optimizer_type="Adam", scene_id_plane_resolution={sid: (R, Rv)}, options=CfgNode({"steps_per_buffer": -1}),
+                                  save_location=[planes_dir], lr=5e-3, model_coarse=mc2, model_fine=mf2, use_coarse_planes=True,
+                                  init_params=False, optimize=False, training_scenes=[sid], available_scenes=[sid], run_time_signature=0)
+    opt2.load_scene(sid)
+    ckpt_path = tu.find_latest_checkpoint(out_dir, sr=False)
+    sr_path = tu.find_latest_checkpoint(out_dir, sr=True)
+    assert ckpt_path.endswith("checkpoint00007.ckpt") and sr_path.endswith("SR_checkpoint00007.ckpt")
+    loaded = nh.safe_loading(ckpt_path, suffix="ckpt")
+    mc2.load_state_dict(loaded["model_coarse_state_dict"], strict=False)
+    mf2.load_state_dict(mf2.rot_mat_backward_support(loaded["model_fine_state_dict"]), strict=False)
+    sr2 = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bilinear")
+    sr2.load_state_dict(nh.safe_loading(sr_path, suffix="ckpt")["SR_model"])
+    for m in (mc2, mf2):
+        m.eval()
+        m.set_cur_scene_id(sid)
+    H = W = 12
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+    cfg = make_cfg(mode_cfg(32, 32), mode_cfg(32, 32))
+    with torch.no_grad():
+        rgb_c, _, _, rgb_f, *_ = tu.eval_nerf(H, W, focal, mc2, mf2, ro, rd, cfg, scene_id=sid, scene_config=cfg.dataset["synt"])
+        sr2.align_corners = True
+        sr2.eval()
+        name0 = models.get_plane_name(sid, 0)
+        sr2.set_LR_plane(mc2.planes_[name0].detach(), id=name0, save_interpolated=False)
+        sr_plane = sr2(name0)
+    par = nh.safe_loading(os.path.join(planes_dir, "coarse_%s.par" % sid), suffix="par")
+    save("g17_store.npz", sid=np.array(sid), cfg=np.array([H, W, 32, 32, R, Rv, C, hidden, nblocks, sf]), focal=np.float64(focal), pose=POSE,
+         rgb_coarse=npy(rgb_c), rgb_fine=npy(rgb_f), sr_plane0=npy(sr_plane), box=np.asarray(par["coords_normalization"], np.float64),
+         plane0=npy(par["params"][name0]), adam_step=np.float64(float(par["opt_states"][0]["step"])),
+         adam_exp_avg0=npy(par["opt_states"][0]["exp_avg"]), fc_alpha_w=npy(mc2.fc_alpha["0"].weight))
+    for f in sorted(os.listdir(out_dir)) + sorted(os.listdir(planes_dir)):
+        fp = os.path.join(out_dir, f) if os.path.exists(os.path.join(out_dir, f)) else os.path.join(planes_dir, f)
+        if os.path.isfile(fp):
+            print("wrote g17_store/%-28s %8.1f KB" % (os.path.relpath(fp, out_dir), os.path.getsize(fp) / 1024))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

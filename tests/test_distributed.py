@@ -31,6 +31,18 @@ def _worker(rank, world, port, tmp):
     assert torch.equal(c.reshape(-1, 3), full[0]) and torch.equal(f.reshape(-1, 3), full[3])
     lc, lf, (lo, hi) = D.render_image_sharded(H, W, 1.0, None, None, ro, rd, None, "s", None, render_fn=_fake_render, gather=False)
     assert (lo, hi) == D.shard_bounds(H * W, rank, world) and torch.equal(lc, full[0][lo:hi])
+    # several views, each sharded by ROW blocks, rendered in one launch per rank and assembled with one all_gather (the bench's default
+    # partition); H = 7 rows over 2 ranks is uneven
+    poses = [torch.randn(3, 3) for _ in range(3)]
+    ray_fn = lambda h, w, focal, pose: (ro @ pose, rd @ pose.T)
+    vc, vf = D.render_views_sharded(H, W, 1.0, None, None, poses, None, "s", None, render_fn=_fake_render, ray_fn=ray_fn)
+    assert vc.shape == (3, H, W, 3)
+    for v, pose in enumerate(poses):
+        o, d = ray_fn(H, W, 1.0, pose)
+        ref = _fake_render(H, W, 1.0, None, None, torch.stack([o.reshape(-1, 3), d.reshape(-1, 3)], 0), None, None)
+        assert torch.equal(vc[v].reshape(-1, 3), ref[0]) and torch.equal(vf[v].reshape(-1, 3), ref[3])
+    bc, bf, (rlo, rhi) = D.render_views_sharded(H, W, 1.0, None, None, poses, None, "s", None, render_fn=_fake_render, ray_fn=ray_fn, gather=False)
+    assert (rlo, rhi) == D.shard_bounds(H, rank, world) and torch.equal(bc, vc[:, rlo:rhi])
     # gradient all-reduce: rank r holds r+1 everywhere -> average 1.5
     grads = [torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(rank + 1)), torch.full((70000,), float(rank + 1))]
     D.allreduce_gradients(grads, bucket_bytes=1 << 16)

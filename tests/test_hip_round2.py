@@ -1,0 +1,470 @@
+"""GPU parity tests added in round 2 (-m gpu): every row-tile instantiation of the SR convolutions and the full-size 256 x 32 EDSR
+against the oracle, the stated error bound of the bf16x3 limb arithmetic on adversarial operands, per-call arithmetic on concurrent
+streams, and the torch.library operators (torch.ops.nvsr.*, opcheck)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_hip_parity import DEV, N_, T, build_model
+
+pytestmark = pytest.mark.gpu
+ARITH = {"f32": 0, "bf16x3": 3, "bf16x2": 2}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SR convolutions: every row-tile variant (models.py:769-822 -> csrc/sr.hip launch_conv)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
+    """The wide (multiple-of-256 output channels) conv kernels exist in 2-, 3- and 4-row tile instantiations, and at 200^2 -> 800^2 the
+    launcher's cost model picks the 3- and 4-row ones for most layers, while every small test shape gets 2 rows.  Force each
+    instantiation (rows_per_tile of nvsr_conv3x3_arith / nvsr_conv3x3_dgrad_arith) of both kernels (exact f32 / bf16x3 limbs), with
+    every fused epilogue, on shapes whose row count is ragged for 2, 3 and 4 rows, against the oracle.  Tolerance as in
+    test_conv3x3_shapes_vs_oracle: 3e-5 on O(1) outputs."""
+    rng = np.random.default_rng(41)
+    capi = hip.capi
+    #        Cin  Cout  H   W   epilogue (0 none, 1 ReLU, 2 residual, 3 PixelShuffle)
+    cases = [(48, 256, 15, 45, 0), (256, 256, 15, 70, 1), (256, 256, 13, 40, 2), (256, 1024, 9, 37, 3), (256, 512, 7, 33, 0)]
+    for Cin, Cout, H, W, epi in cases:
+        x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+        w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+        skip = rng.standard_normal((Cout, H + 2, W + 2), dtype=np.float32) if epi == 2 else None
+        xd, wd = T(x), T(w)
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cin, Cout), device=DEV)
+        capi.call("nvsr_pack_conv3x3", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+        ref = oracle.conv3x3(x, w, relu=(epi == 1))
+        if epi == 2:      # _Residual_Block: conv * 0.1 + centre-cropped identity (models.py:781-785)
+            ref = (ref.astype(np.float64) * np.float64(np.float32(0.1)) + skip[:, 2:-2, 2:-2]).astype(np.float32)
+        if epi == 3:
+            ref = ref.reshape(Cout // 4, 2, 2, H - 2, W - 2).transpose(0, 3, 1, 4, 2).reshape(Cout // 4, 2 * (H - 2), 2 * (W - 2))
+        skd = None if skip is None else T(skip)
+        results = {}
+        for mode in ("bf16x3", "f32"):
+            for rows in (2, 3, 4):
+                out = torch.full(ref.shape, -7.0, device=DEV)
+                capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, capi.ptr(skd), capi.ptr(out), ARITH[mode],
+                          rows, capi.stream())
+                np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi, mode, rows)))
+                results[(mode, rows)] = out
+            # the row tiling does not change the arithmetic of an output element: the three instantiations agree bit for bit
+            assert torch.equal(results[(mode, 2)], results[(mode, 3)]) and torch.equal(results[(mode, 2)], results[(mode, 4)])
+    # invalid rows_per_tile / arithmetic are refused, nothing is written
+    out = torch.full((256, 13, 43), -7.0, device=DEV)
+    x = T(rng.standard_normal((48, 15, 45), dtype=np.float32))
+    pk = torch.zeros(capi.lib().nvsr_conv3x3_packed_floats(48, 256), device=DEV)
+    for arith, rows in ((3, 5), (3, 1), (7, 0), (2, 0)):
+        st = capi.lib().nvsr_conv3x3_arith(capi.ptr(x), 48, 15, 45, capi.ptr(pk), 256, 0, None, capi.ptr(out), arith, rows, capi.stream())
+        assert st == 1 and float(out.min()) == -7.0
+    # data gradient (virtual zero border, flipped + transposed kernel): every row-tile variant, both kernels
+    for Cin, Cout, H, W in ((256, 256, 15, 38), (48, 256, 11, 70), (256, 1024, 8, 35)):
+        w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+        dy = rng.standard_normal((Cout, H - 2, W - 2), dtype=np.float32)
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cout, Cin), device=DEV)
+        capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(T(w)), Cin, Cout, capi.ptr(pk), capi.stream())
+        wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
+        ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
+        dyd = T(dy)
+        for mode in ("bf16x3", "f32"):
+            for rows in (0, 2, 3, 4):
+                dx = torch.full((Cin, H, W), -7.0, device=DEV)
+                capi.call("nvsr_conv3x3_dgrad_arith", capi.ptr(dyd), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), ARITH[mode], rows, capi.stream())
+                np.testing.assert_allclose(N_(dx), ref, rtol=0, atol=3e-5 * max(1.0, np.sqrt(Cout / Cin)),
+                                           err_msg="dgrad " + str((Cin, Cout, H, W, mode, rows)))
+
+
+def _full_size_sr(hip, seed=21):
+    torch.manual_seed(seed)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 256, "n_blocks": 32}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)          # PlanesSR initialises at 1/10 of He scale (models.py:843-848); x10 keeps 66 layers of activations O(1)
+    return sr
+
+
+def test_full_size_edsr_windows_vs_oracle(hip, oracle):
+    """BASELINE config 3 at its real size: PlanesSR(EDSR 256 channels x 32 blocks, x4) on the three 200^2 position planes of a scene in
+    one batched pass (the product path of a render: models.native_scene -> super_resolve_many) -- the shapes at which the launcher picks
+    the 3- and 4-row conv tiles.  Three 8x8-texel LR windows (32x32 HR) are compared with the oracle run on exactly the input that
+    determines them: the window plus the network's 68-texel receptive-field halo (models.py:836-842) cut out of the replicate-padded
+    plane, 144^2 -> 34^2 -> centre 32^2, plus the bilinear x4 residual of the full plane (models.py:918-919).  Windows: the top-left
+    corner (halo = replicate padding), an interior window at odd offsets (inside different row / column tiles of every layer), the
+    bottom-right corner.  Both arithmetic modes.  Then the ROI (training-mode) path at this size against the full-plane values."""
+    sr = _full_size_sr(hip)
+    sr.eval()
+    rng = np.random.default_rng(22)
+    R, sf, pad, over = 200, 4, 68, 1
+    assert sr.inner_model.required_padding == pad and sr.HR_overpadding == over
+    lrs = [(rng.standard_normal((48, R, R), dtype=np.float32) * 0.5) for _ in range(3)]
+    names = ["p0", "p1", "p2"]
+    sd = {k: N_(v) for k, v in sr.state_dict().items()}
+    blob, nblocks = oracle.edsr_blob(sd)
+    assert nblocks == 32
+    windows = [(0, 0, 0), (1, 96, 57), (2, R - 8, R - 8)]              # (plane, first LR row, first LR column)
+    refs = []
+    for pl, ay, ax in windows:
+        padded = np.pad(lrs[pl], ((0, 0), (pad, pad), (pad, pad)), mode="edge")
+        crop = np.ascontiguousarray(padded[:, ay: ay + 8 + 2 * pad, ax: ax + 8 + 2 * pad])          # [48,144,144]
+        diff = oracle.edsr_forward(crop, blob, 48, 256, 32, 2)
+        assert diff.shape == (48, 34, 34)
+        up = oracle.upsample_bilinear(lrs[pl], sf)
+        refs.append(diff[:, over:-over, over:-over] + up[:, sf * ay: sf * ay + 32, sf * ax: sf * ax + 32])
+    scale = max(float(np.abs(r).max()) for r in refs)
+    for mode, tol in (("bf16x3", 1e-4), ("f32", 1e-4)):
+        sr.inner_model.arithmetic = mode
+        sr.clear_SR_planes(all_planes=True)
+        for n, lr in zip(names, lrs):
+            sr.set_LR_plane(T(lr)[None], id=n, save_interpolated=False)
+        with torch.no_grad():
+            sr.super_resolve_many(names)
+        assert sorted(sr.SR_planes) == names
+        worst = 0.0
+        for (pl, ay, ax), ref in zip(windows, refs):
+            got = N_(sr.SR_planes[names[pl]][0, :, sf * ay: sf * ay + 32, sf * ax: sf * ax + 32])
+            err = float(np.abs(got - ref).max())
+            worst = max(worst, err)
+            # 66 chained convolutions with K = 2304 f32 products each, outputs O(1): stated tolerance 1e-4 of the output range
+            assert err <= tol * max(1.0, scale), (mode, pl, ay, ax, err, scale)
+        print("full-size EDSR windows, %s: max |err| %.2e (output range %.2f)" % (mode, worst, scale))
+    # ROI path at full size (what a band-sharded SR stage and an SR training step run): identical values inside the ROI, NaN outside
+    sr.inner_model.arithmetic = None
+    sr.clear_SR_planes()
+    with torch.no_grad():
+        full = sr("p1").clone()
+        sr.clear_SR_planes()
+        sr.train()
+        roi = torch.tensor([[-0.31, 0.12], [0.07, 0.55]])            # [[ymin, xmin], [ymax, xmax]] in [-1, 1]
+        part = sr(("p1", roi.to(DEV)))
+    valid = ~torch.isnan(part)
+    frac = float(valid.float().mean())
+    assert 0.03 < frac < 0.2 and torch.equal(part[valid], full[valid])
+    # ... and through the differentiable training forward (torch.ops.nvsr.planes_sr_train keeps the activations): same values
+    lr_p = torch.nn.Parameter(T(lrs[1])[None])
+    sr.clear_SR_planes(all_planes=True)
+    sr.set_LR_plane(lr_p, id="p1", save_interpolated=False)
+    small = torch.tensor([[-0.05, -0.02], [0.04, 0.06]])
+    out = sr(("p1", small.to(DEV)))
+    assert out.requires_grad
+    v2 = ~torch.isnan(out)
+    assert torch.equal(out.detach()[v2], full[v2]) and int(v2.sum()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The real bound of the bf16x3 limb arithmetic (include/nvsr.h, csrc/limb_core.h)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _adversarial(rng, shape, pattern, sign=None):
+    """f32 values with chosen mantissa bits: 'ones' = all 23 stored bits set (1.9999999 x 2^e); 'low16' = the 7 leading stored bits
+    clear and the 16 low bits set (1.0078124 x 2^e: the leading limb is 2^e exactly, the middle and low limbs take their largest
+    possible share, 2^-7 and 2^-15 of the value)"""
+    mant = {"ones": 0x7FFFFF, "low16": 0x00FFFF}[pattern]
+    e = rng.integers(124, 128, size=shape).astype(np.uint32)            # 2^-3 .. 2^0
+    s = rng.integers(0, 2, size=shape).astype(np.uint32) if sign is None else ((sign < 0).astype(np.uint32))
+    return ((s << 31) | (e << 23) | np.uint32(mant)).astype(np.uint32).view(np.float32)
+
+
+def test_limb_error_bound(hip):
+    """Measured worst case of the bf16x3 decoder arithmetic against its stated bound (include/nvsr.h).  One decoder layer with K = 192
+    -- rgb layer 0 (models.py:409-413) -- is isolated with the layer-input record of the training forward: the record holds the exact f32
+    layer input X [P,192] the kernel multiplied and the layer's post-ReLU output H [P,128]; the weights W are ours.  Operands are
+    adversarial: every mantissa is all ones or (the true worst case of truncation limbs) has its low 16 bits set, and the signs are
+    arranged so that all 192 products of a row are positive -- the dropped limb products Wm xl + Wl xm + Wl xl then all have the same sign
+    and add up instead of averaging out.  Reported: max over all outputs of |H - float64(W x)| / sum_k |W_k x_k| for exact f32 and for
+    bf16x3.  Asserted: bf16x3 <= 2^-21 + 2^-30 (the three dropped products at their largest: 2^-7 * 2^-15 twice, 2^-15 * 2^-15) plus
+    the f32 kernel's own error on the same data (accumulation roundings, common to both) -- and the same with mixed signs."""
+    capi = hip.capi
+    rng = np.random.default_rng(77)
+    g = torch.Generator().manual_seed(5)
+    BOUND = 2.0 ** -21 + 2.0 ** -30
+    report = {}
+    for pattern in ("ones", "low16"):
+        for signs in ("same", "mixed"):
+            # planes 3x3 texels: the points below sit exactly on texel centres, so a feature IS a texel value (blend weights 1, 0, 0, 0)
+            planes = [_adversarial(rng, (1, 48, 3, 3), pattern) for _ in range(4)]
+            m = hip.models.TwoDimPlanesModel(use_viewdirs=True, skip_connect_every=3, proj_combination="avg",
+                                             viewdir_proj_combination="concat_pos", align_corners=True)
+            state = {k: torch.randn(v.shape, generator=g) * 0.1 for k, v in m.state_dict().items() if "rot_mats" not in k}
+            box = np.array([[-1, -1, -1, -np.pi, -np.pi / 2], [1, 1, 1, np.pi, np.pi / 2]], np.float64)
+            state.update({k: v for k, v in m.state_dict().items() if "rot_mats" in k})
+            m, sid = build_model(hip, {k: N_(v) for k, v in state.items()}, planes, box, sid="adv_DS1_PlRes3_3")
+            # points on the 27 texel-centre combinations; view direction +x -> (az, el) = (0, 0) = the centre texel of the view plane
+            pts = np.array([[x, y, z] for x in (-1.0, 0.0, 1.0) for y in (-1.0, 0.0, 1.0) for z in (-1.0, 0.0, 1.0)], np.float32)
+            P = pts.shape[0]
+            rays = np.zeros((P, 11), np.float32)
+            rays[:, 0:3] = pts
+            rays[:, 8] = 1.0
+            raysd, z = T(rays), torch.zeros((P, 1), device=DEV)
+            sc, keep = m.native_scene()
+            nrec = capi.lib().nvsr_decoder_record_floats(P, 1)
+            Pp = (P + 7) // 8 * 8
+
+            def run(mode):
+                raw = torch.empty((P, 1, 4), device=DEV)
+                gates = torch.empty((P, 1, 32), dtype=torch.int32, device=DEV)
+                rec = torch.full((nrec,), float("nan"), device=DEV)
+                capi.call("nvsr_decode_rays_arith", C.byref(sc), capi.ptr(m.packed_decoder()), P, 1, capi.ptr(raysd), capi.ptr(z), capi.ptr(raw),
+                          capi.ptr(gates), capi.ptr(rec), ARITH[mode], capi.stream())
+                r = N_(rec)
+                off_xr = 64 * Pp + 2 * 4 * 128 * Pp
+                Xr = r[off_xr: off_xr + 192 * Pp].reshape(Pp, 192)[:P]
+                Hr0 = r[off_xr + 192 * Pp: off_xr + 192 * Pp + 128 * Pp].reshape(Pp, 128)[:P]
+                return Xr, Hr0
+
+            X, _ = run("f32")
+            assert np.isfinite(X).all() and (np.abs(X) >= 0.124).all()              # texel values, untouched by the blend
+            assert np.array_equal(X.view(np.uint32) & 0x7FFFFF, np.full(X.shape, {"ones": 0x7FFFFF, "low16": 0x00FFFF}[pattern], np.uint32))
+            # weights of rgb layer 0: adversarial mantissas; 'same': the sign of each weight follows its input of point 0 -> for the
+            # points that share point 0's signs every product is positive; judge every row by its own sum |w||x| anyway
+            sgn = np.sign(X[0])[None, :].repeat(128, 0) if signs == "same" else None
+            W = _adversarial(rng, (128, 192), pattern, sign=sgn) * np.float32(1.0 / 64)      # (a power of two: mantissas unchanged)
+            with torch.no_grad():
+                m.rgb_dec["0"][0].weight.copy_(T(W))
+                m.rgb_dec["0"][0].bias.zero_()
+            res = {}
+            for mode in ("f32", "bf16x3"):
+                Xm, H = run(mode)
+                assert np.array_equal(Xm, X)
+                pre = W.astype(np.float64) @ X.astype(np.float64).T                   # [128, P]
+                mag = np.abs(W.astype(np.float64)) @ np.abs(X.astype(np.float64)).T
+                ref = np.maximum(pre, 0.0).T                                          # [P, 128]
+                res[mode] = float((np.abs(H.astype(np.float64) - ref) / mag.T).max())
+            report[(pattern, signs)] = res
+            assert res["bf16x3"] <= BOUND + res["f32"] + 2.0 ** -24, (pattern, signs, res)
+    for k, v in report.items():
+        print("limb bound %-5s mantissas, %-5s signs: max |err| / sum|w||x|  f32 %.3e   bf16x3 %.3e   (2^-21 = %.3e)" % (k + (v["f32"], v["bf16x3"], 2.0 ** -21)))
+    # the one-sided worst case is real: with the worst-case mantissas and equal signs the limb error is well above the f32 kernel's
+    assert report[("low16", "same")]["bf16x3"] > 2.0 ** -23 > report[("low16", "same")]["f32"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# per-call arithmetic: nothing process-global, re-entrant across streams
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_two_streams_two_arithmetic_modes(hip):
+    """Two streams of one process run the same render pass and the same convolution concurrently, one in exact f32 and one in bf16x3
+    (the arithmetic is an argument of the call): each stream's result equals, bit for bit, that mode's result computed alone -- and
+    the process default (nvsr_set_decoder_arithmetic) is neither consulted nor changed."""
+    from bench import make_synthetic_scene
+
+    capi = hip.capi
+    nv = torch.ops.nvsr
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=128, view_res=16, seed=9)
+    H = W = 144                                           # 20 736 rays: the fused two-tile kernels (N >= 16 384)
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    N, S = rays.shape[0], 48
+    z = torch.sort(torch.rand((N, S), device=DEV) * 4 + 2, -1)[0].contiguous()
+    planes, consts = mf.scene_args()
+    packed = mf.packed_decoder()
+    x = torch.randn((1, 256, 40, 75), device=DEV)
+    net = hip.models.EDSR(256, 256, 256, 1, 2, 0).to(DEV)
+    geom, wts = list(net.geometry), net.packed_weights()
+    default_before = capi.get_decoder_arithmetic(), capi.get_conv_arithmetic()
+    alone = {}
+    for mode in ("f32", "bf16x3"):
+        alone[mode] = (nv.render_pass(planes, consts, packed, rays, z, None, False, True, ARITH[mode]), nv.edsr(x, wts, geom, ARITH[mode]))
+    torch.cuda.synchronize()
+    assert not torch.equal(alone["f32"][0][0], alone["bf16x3"][0][0]) and not torch.equal(alone["f32"][1], alone["bf16x3"][1])
+    streams = {"f32": torch.cuda.Stream(), "bf16x3": torch.cuda.Stream()}
+    got = {}
+    for rep in range(3):                                  # interleave the enqueues: both streams have work in flight at the same time
+        for mode in ("f32", "bf16x3"):
+            with torch.cuda.stream(streams[mode]):
+                got[mode] = (nv.render_pass(planes, consts, packed, rays, z, None, False, True, ARITH[mode]), nv.edsr(x, wts, geom, ARITH[mode]))
+    torch.cuda.synchronize()
+    for mode in ("f32", "bf16x3"):
+        for a, b in zip(got[mode][0], alone[mode][0]):
+            assert torch.equal(a, b), mode
+        assert torch.equal(got[mode][1], alone[mode][1]), mode
+    assert (capi.get_decoder_arithmetic(), capi.get_conv_arithmetic()) == default_before
+    # the host mirror carries the mode per model: two models, two modes, same process
+    mf.arithmetic, mc.arithmetic = "f32", "f32"
+    opts_scfg = __import__("bench").render_options(16, 16)
+    a = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)]), opts_scfg[0], sid,
+                                             mode="validation", scene_config=opts_scfg[1])[3]
+    mf.arithmetic, mc.arithmetic = "bf16x3", "bf16x3"
+    b = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)]), opts_scfg[0], sid,
+                                             mode="validation", scene_config=opts_scfg[1])[3]
+    assert not torch.equal(a, b) and float((a - b).abs().max()) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# torch.library registration
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_torch_library_ops_exist_and_opcheck(hip):
+    """torch.ops.nvsr.* are registered custom operators (schema, fake / meta implementation, autograd where differentiable):
+    torch.library.opcheck on the forward operators, FakeTensor tracing of a render, and gradients through the registered formulas."""
+    from bench import make_synthetic_scene
+
+    nv = torch.ops.nvsr
+    for name in hip.ops.FORWARD_OPS + ["decode_rays_backward", "decoder_weight_grad", "composite_backward", "edsr_train", "edsr_backward",
+                                       "planes_sr_train", "planes_sr_backward", "pack_edsr", "pack_decoder_bwd"]:
+        assert hasattr(nv, name), name
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=32, view_res=8, seed=4)
+    H = W = 12
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    N = rays.shape[0]
+    planes, consts = mf.scene_args()
+    packed = mf.packed_decoder()
+    z = nv.coarse_z(rays, 16, False, None)
+    raw, _, _ = nv.decode_rays(planes, consts, packed, rays, z, False, False, 3)
+    pts = torch.cat([rays[:, 0:3] + rays[:, 3:6] * z[:, :1], rays[:, 8:11]], -1).contiguous()
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    chk = lambda op, args: torch.library.opcheck(op, args, test_utils=tests)
+    chk(nv.plane_to_channel_last, (mf.planes_[hip.models.get_plane_name(sid, 0)].detach(),))
+    chk(nv.plane_from_channel_last, (planes[0],))
+    chk(nv.pack_decoder, (mf.natural_blob(),))
+    chk(nv.coarse_z, (rays, 16, False, None))
+    chk(nv.triplane_decode, (planes, consts, packed, pts))
+    chk(nv.render_pass, (planes, consts, packed, rays, z, None, False, True, 3))
+    chk(nv.render_rays, (planes, consts, mc.packed_decoder(), packed, rays, 16, 8, False, False, None, None, None, None, 0))
+    chk(nv.decode_rays, (planes, consts, packed, rays, z, True, True, 3))
+    w = nv.composite_rays(raw, z, rays, None, False, True)[3]
+    chk(nv.importance_resample, (z, w, 8, None))
+    chk(nv.composite_rays, (raw, z, rays, None, False, True))
+    rd3 = rays[:, 3:6].contiguous()
+    chk(nv.composite, (raw.clone().requires_grad_(True), z, rd3, None, True, False))
+    net = hip.models.EDSR(48, 48, 32, 1, 4, 0).to(DEV)
+    x = torch.randn((2, 48, 20, 23), device=DEV)
+    chk(nv.edsr, (x, net.packed_weights(), list(net.geometry), 3))
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 32, "n_blocks": 1}}, "bilinear").to(DEV)
+    lr = [torch.randn((48, 21, 19), device=DEV) for _ in range(2)]
+    pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+    chk(nv.planes_sr, (lr, sr.inner_model.packed_weights(), list(sr.inner_model.geometry), pad, over, None, None, None, 3))
+    chk(nv.planes_sr, (lr[:1], sr.inner_model.packed_weights(), list(sr.inner_model.geometry), pad, over, [-0.5, -0.4, 0.3, 0.6], None, None, 0))
+    # differentiable operators: torch.autograd.gradcheck is for float64; compare the registered backward with finite differences of the op
+    rawp = raw.clone().requires_grad_(True)
+    rgb, disp, acc, wts, depth = nv.composite(rawp, z, rd3, None, False, False)
+    assert rgb.requires_grad and acc.requires_grad and not disp.requires_grad and not wts.requires_grad and not depth.requires_grad
+    gout = torch.randn_like(rgb)
+    (rgb * gout).sum().backward()
+    d = torch.randn_like(raw) * 1e-3
+    with torch.no_grad():
+        fd = ((nv.composite(raw + d, z, rd3, None, False, False)[0] - nv.composite(raw - d, z, rd3, None, False, False)[0]) * gout).sum() / 2
+    assert abs(float((rawp.grad * d).sum()) - float(fd)) <= 5e-3 * max(abs(float(fd)), float(d.abs().mean()))
+    # the operators trace with FakeTensors (what torch.compile / export see): shapes and dtypes without touching the GPU
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode(allow_non_fake_inputs=False) as fm:
+        f = lambda t: fm.from_tensor(t)
+        out = nv.render_rays([f(p) for p in planes], consts, f(mc.packed_decoder()), f(packed), f(rays), 16, 8, False, False, None, None, None, None, -1)
+        assert [tuple(o.shape) for o in out] == [(N, 3), (N,), (N,), (N, 3), (N,), (N,)]
+        o2 = nv.planes_sr([f(t) for t in lr], f(sr.inner_model.packed_weights()), list(sr.inner_model.geometry), pad, over, None, None, None, -1)
+        assert [tuple(o.shape) for o in o2] == [(1, 48, 84, 76)] * 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# plane store / checkpoints written by the reference
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_render_from_reference_written_store(hip):
+    """The files under tests/golden/g17_store/ were written by the reference's own PlanesOptimizer.save_params / safe_saving and
+    checkpoint code (gen_golden.py::g17_store).  Read them with the mirror (plane_store.load_scene, find_latest_checkpoint,
+    load_decoder_checkpoint, load_sr_checkpoint), render with eval_nerf and super-resolve a plane: the pixels the reference rendered
+    from the same files (after reading them back itself) within the end-to-end tolerance, the SR plane within 1e-5."""
+    import os
+    from conftest import GOLDEN, load_golden
+
+    g = load_golden("g17_store.npz")
+    store = os.path.join(GOLDEN, "g17_store")
+    sid = str(g["sid"])
+    H, W, Nc, Nf, R, Rv, Cc, hidden, nblocks, sf = [int(v) for v in g["cfg"]]
+    M, ps = hip.models, hip.plane_store
+    kw = dict(use_viewdirs=True, skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos", align_corners=True)
+    torch.manual_seed(1234)                                   # fresh random modules: everything must come from the files
+    mc = M.TwoDimPlanesModel(**kw)
+    mf = M.TwoDimPlanesModel(num_planes_or_rot_mats=mc.rot_mats(), **kw)
+    ps.load_decoder_checkpoint(ps.find_latest_checkpoint(store, sr=False), mc, mf)
+    mc, mf = mc.to(DEV).eval(), mf.to(DEV).eval()
+    content = ps.load_scene([mc, mf], os.path.join(store, "planes"), sid, device=DEV)
+    assert mc.planes_ is mf.planes_ and all(p.is_cuda for p in mc.planes_.values())
+    from test_hip_parity import make_options, psnr
+    opts, scfg = make_options(Nc, Nf)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, float(g["focal"]), T(g["pose"]))
+    rgb_c, _, _, rgb_f, *_ = hip.train_utils.eval_nerf(H, W, float(g["focal"]), mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    np.testing.assert_allclose(N_(rgb_c), g["rgb_coarse"], rtol=0, atol=2e-5)
+    ef = np.abs(N_(rgb_f) - g["rgb_fine"]).max(-1)
+    assert (ef <= 2e-4).mean() >= 0.98 and psnr(N_(rgb_f), g["rgb_fine"]) >= 80.0
+    # a second load of the same scene replaces the parameters: the renderer must not serve stale channel-last copies
+    with torch.no_grad():
+        for p_ in mc.planes_.values():
+            p_.data.mul_(0.0)                                 # a write through .data: no version bump ...
+    mc.invalidate()                                           # ... so the caches are told; the fine model shares them
+    mf.invalidate()
+    z0 = hip.train_utils.eval_nerf(H, W, float(g["focal"]), mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
+    ps.load_scene([mc, mf], os.path.join(store, "planes"), sid, device=DEV)
+    again = hip.train_utils.eval_nerf(H, W, float(g["focal"]), mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
+    assert torch.equal(again, rgb_f) and not torch.equal(z0, rgb_f)
+    # SR checkpoint -> PlanesSR -> the plane the reference super-resolved
+    sr = M.PlanesSR(M.EDSR, sf, Cc, Cc, {"model": {"hidden_size": hidden, "n_blocks": nblocks}}, "bilinear")
+    ps.load_sr_checkpoint(ps.find_latest_checkpoint(store, sr=True), sr)
+    sr = sr.to(DEV).eval()
+    name0 = M.get_plane_name(sid, 0)
+    sr.set_LR_plane(mc.planes_[name0].detach(), id=name0, save_interpolated=False)
+    with torch.no_grad():
+        np.testing.assert_allclose(N_(sr(name0)), g["sr_plane0"], rtol=0, atol=1e-5)
+    # the mirror's writer produces a file the same reader accepts, with the reference's keys (round trip on the device tensors)
+    assert sorted(content) == ["coords_normalization", "opt_states", "params"]
+
+
+def test_render_rays_odd_sizes_keep_workspace_alignment(hip, oracle):
+    """N * Nc not a multiple of 4 (odd ray counts with odd sample counts): the sub-buffers of the caller's workspace are rounded up to
+    16 bytes each (the raw scratch used to land unaligned and the call failed with NVSR_ERR_ALIGN)."""
+    from bench import make_synthetic_scene
+    from oracle.oracle import decoder_blob
+
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=32, view_res=8, seed=6)
+    H, W = 3, 7
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    for nc, nf in ((5, 3), (7, 6), (9, 0)):
+        from test_hip_parity import make_options
+        opts, scfg = make_options(nc, nf)
+        rgb_c, _, _, rgb_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+        planes = [N_(mc.planes_[hip.models.get_plane_name(sid, d)]) for d in range(4)]
+        sc = oracle.scene(planes, mc.box_coords[sid].numpy())
+        sdn = lambda m: {k: N_(v) for k, v in m.state_dict().items()}
+        rays = oracle.pack_rays(N_(ro), N_(rd), 2.0, 6.0)
+        o = oracle.render_rays(sc, oracle.decoder(decoder_blob(sdn(mc))), oracle.decoder(decoder_blob(sdn(mf))), rays, nc, nf)
+        np.testing.assert_allclose(N_(rgb_c).reshape(-1, 3), o["rgb_coarse"], rtol=0, atol=2e-5)
+        if nf:
+            assert (np.abs(N_(rgb_f).reshape(-1, 3) - o["rgb_fine"]).max(-1) <= 2e-4).mean() >= 0.9
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# multi-GPU partitions with the HIP renderer, rehearsed with two ranks on this box's one GPU
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("partition,res,self_launch", [("frame", 384, False), ("rows", 160, True)])
+def test_sharded_render_is_bit_identical_to_one_rank(partition, res, self_launch):
+    """`bench.py --gpus 2` with the rays of a frame sharded by row blocks over two ranks (both on cuda:0, gloo: NVSR_BENCH_REHEARSAL=1):
+    inside the run every rank compares the frames assembled by distributed.render_image_sharded / render_views_sharded -- rendered by the
+    HIP kernels on its row block, gathered with one all_gather -- with the frames it renders alone: torch.equal, coarse and fine
+    (bench.py prints SHARDED_RENDER_IDENTICAL per rank and exits non-zero otherwise).  res 384: 73 728 rays per rank, the fused
+    two-tile passes on both sides (the identity holds while the per-rank ray count stays on the same side of NVSR_FUSED_MIN_RAYS = 65 536:
+    an 800^2 frame on up to 9 GPUs); res 160: the sample-parallel kernels.
+    'rows' is launched the way a user would -- plain `python bench.py --gpus 2`, which spawns its own ranks -- 'frame' the way the
+    driver does (torch.distributed.run)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NVSR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", str(res), "--plane-res", "128", "--no-cpu-baseline",
+            "--no-modes", "--partition", partition]
+    if self_launch:
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port)] + tail
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    for r in (0, 1):
+        assert "SHARDED_RENDER_IDENTICAL rank %d partition %s" % (r, partition) in p.stderr, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["partition"] == partition and r["scaling"] == ("strong" if partition == "frame" else "weak")
+    frames = 1 if partition == "frame" else 2
+    assert abs(r["value"] - frames * res * res * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]

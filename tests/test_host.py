@@ -34,6 +34,8 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.nvsr_version() >= 100
     assert lib.nvsr_render_workspace_floats(10, 64, 128) == 10 * (2 * 64 + 192) + 4 * 10 * 192      # small N: + raw [N,S,4]
     assert lib.nvsr_render_workspace_floats(640000, 64, 128) == 640000 * (2 * 64 + 192)           # fused path
+    # sub-buffers are rounded up to 4 floats each, so that all of them (the raw [N,S,4] scratch last) stay 16-byte aligned for odd N
+    assert lib.nvsr_render_workspace_floats(7, 5, 3) == 2 * 36 + 56 + 4 * 7 * 8
 
 
 def test_mirror_exposes_reference_surface(pkg):
@@ -238,3 +240,134 @@ def test_bench_pixel_sampler_is_a_permutation_prefix():
     assert sorted(full.tolist()) == list(range(100))
     big = sample_without_replacement(640000, 4096, "cpu", g)
     assert big.shape == (4096,) and len(set(big.tolist())) == 4096 and 0 <= int(big.min()) and int(big.max()) < 640000
+
+
+# ---- files written by the reference itself (tests/golden/g17_store/, generated by gen_golden.py::g17_store) --------------------------
+G17 = os.path.join(ROOT, "tests", "golden", "g17_store")
+
+
+def test_reference_written_plane_file_and_checkpoints_load(pkg):
+    """plane_store against a `.par` plane file, a decoder checkpoint and an SR checkpoint that the REFERENCE wrote
+    (PlanesOptimizer.save_params / safe_saving, models.py:640-670, nerf_helpers.py:19-48, train_nerf.py:996-1008): keys, shapes, values,
+    the Adam state, the key filtering of the checkpoint, and load_state_dict(strict=False) into the mirror's modules."""
+    ps, M = pkg.plane_store, pkg.models
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g17_store.npz")))
+    sid = str(g["sid"])
+    H, W, Nc, Nf, R, Rv, Cc, hidden, nblocks, sf = [int(v) for v in g["cfg"]]
+    path = ps.plane_file(os.path.join(G17, "planes"), sid)
+    assert os.path.isfile(path)
+    par = ps.load_plane_file(path)
+    assert sorted(par) == ["coords_normalization", "opt_states", "params"]
+    names = [M.get_plane_name(sid, d) for d in range(4)]
+    assert list(par["params"].keys()) == names
+    assert [tuple(par["params"][n].shape) for n in names] == [(1, 48, R, R)] * 3 + [(1, 48, Rv, Rv)]
+    np.testing.assert_array_equal(par["params"][names[0]].detach().numpy(), g["plane0"])
+    np.testing.assert_array_equal(np.asarray(par["coords_normalization"], np.float64), g["box"])
+    assert len(par["opt_states"]) == 4 and float(par["opt_states"][0]["step"]) == float(g["adam_step"]) == 1.0
+    np.testing.assert_array_equal(par["opt_states"][0]["exp_avg"].numpy(), g["adam_exp_avg0"])
+    # checkpoints: discovery + the reference's key filtering (no planes, no SR model; the fine model without the shared rot_mats)
+    ck_path, sr_path = ps.find_latest_checkpoint(G17, sr=False), ps.find_latest_checkpoint(G17, sr=True)
+    assert os.path.basename(ck_path) == "checkpoint00007.ckpt" and os.path.basename(sr_path) == "SR_checkpoint00007.ckpt"
+    assert pkg.train_utils.find_latest_checkpoint(G17, False) == ck_path
+    mc = M.TwoDimPlanesModel(use_viewdirs=True, skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos")
+    mf = M.TwoDimPlanesModel(use_viewdirs=True, skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos",
+                             num_planes_or_rot_mats=mc.rot_mats())
+    ck = ps.load_decoder_checkpoint(ck_path, mc, mf)
+    assert sorted(ck) == ["model_coarse_state_dict", "model_fine_state_dict", "optimizer"]
+    assert not any("planes_" in k or "SR_model" in k for d in (ck["model_coarse_state_dict"], ck["model_fine_state_dict"]) for k in d)
+    assert any("rot_mats" in k for k in ck["model_coarse_state_dict"]) and not any("rot_mats" in k for k in ck["model_fine_state_dict"])
+    own = {k for k in mc.state_dict() if "planes_" not in k}
+    assert set(ck["model_coarse_state_dict"]) == own                      # the mirror's state-dict keys ARE the reference's
+    np.testing.assert_array_equal(mc.fc_alpha["0"].weight.detach().numpy(), g["fc_alpha_w"])
+    sr = M.PlanesSR(M.EDSR, sf, Cc, Cc, {"model": {"hidden_size": hidden, "n_blocks": nblocks}}, "bilinear")
+    sck = ps.load_sr_checkpoint(sr_path, sr)
+    assert sorted(sck) == ["SR_model", "SR_optimizer"] and set(sck["SR_model"]) == set(sr.state_dict())
+    # wiring the scene into the model pair, as PlanesOptimizer.load_scene does
+    ps.load_scene([mc, mf], os.path.join(G17, "planes"), sid, device="cpu")
+    assert mc.planes_ is mf.planes_ and torch.equal(mf.box_coords[sid], torch.as_tensor(g["box"]))
+
+
+def test_find_latest_checkpoint_and_safe_saving_protocol(pkg, tmp_path):
+    """train_utils.py:333-345 and nerf_helpers.py:19-67: highest iteration wins (numerically, not lexically), SR and decoder files are
+    told apart, _best copies, not-a-folder -> None; safe_saving leaves exactly one file, safe_loading falls back to _temp / _bckp, and a
+    run with an older time signature is stopped."""
+    ps = pkg.plane_store
+    d = str(tmp_path)
+    for f in ("checkpoint00009.ckpt", "checkpoint00100.ckpt", "checkpoint100000.ckpt", "SR_checkpoint00050.ckpt", "checkpoint.ckpt_best",
+              "SR_checkpoint.ckpt_best", "checkpoint00100.ckpt_bckp", "xcheckpoint99999999.ckpt", "exp_info.pkl"):
+        open(os.path.join(d, f), "wb").close()
+    assert os.path.basename(ps.find_latest_checkpoint(d, sr=False)) == "checkpoint100000.ckpt"
+    assert os.path.basename(ps.find_latest_checkpoint(d, sr=True)) == "SR_checkpoint00050.ckpt"
+    assert os.path.basename(ps.find_latest_checkpoint(d, sr=False, find_best=True)) == "checkpoint.ckpt_best"
+    assert os.path.basename(ps.find_latest_checkpoint(d, sr=True, find_best=True)) == "SR_checkpoint.ckpt_best"
+    assert ps.find_latest_checkpoint(os.path.join(d, "nope"), sr=False) is None
+    run = os.path.join(d, "run")
+    os.makedirs(os.path.join(run, "planes"))
+    f = os.path.join(run, "checkpoint00001.ckpt")
+    ps.safe_saving(f, {"a": torch.arange(3)}, "ckpt", run_time_signature=10.0)
+    ps.safe_saving(f, {"a": torch.arange(4)}, "ckpt", run_time_signature=10.0)
+    assert sorted(os.listdir(run)) == ["checkpoint00001.ckpt", "planes", "time_sig.txt"]
+    assert ps.safe_loading(f, "ckpt")["a"].numel() == 4
+    ps.safe_saving(f, {"a": 1}, "ckpt", best=True)
+    assert os.path.isfile(f + "_best") and ps.safe_loading(f, "ckpt", best=True) == {"a": 1}
+    os.rename(f, f + "_temp")                                   # an interrupted save: only the temp copy is complete
+    assert ps.safe_loading(f, "ckpt")["a"].numel() == 4
+    with pytest.raises(Exception):
+        ps.safe_loading(os.path.join(run, "missing.ckpt"), "ckpt")
+    ps.safe_saving(os.path.join(run, "exp_info.pkl"), {"start_i": 5}, "pkl", run_time_signature=11.0)     # a newer run takes over ...
+    assert ps.safe_loading(os.path.join(run, "exp_info.pkl"), "pkl") == {"start_i": 5}
+    with pytest.raises(SystemExit):                              # ... and the older one stops at its next save (nerf_helpers.py:29-30)
+        ps.safe_saving(os.path.join(run, "planes", "coarse_x.par"), {}, "par", run_time_signature=10.0)
+
+
+def test_single_member_ensemble_draw_leaves_numpy_stream_alone():
+    """models.py:393 draws `np.random.randint(len(self.density_dec))` on every training-mode forward.  With ensemble_size == 1 (every
+    shipped config; the only size the kernels support) that is randint(1): a zero-width range, which returns 0 WITHOUT consuming NumPy's
+    global stream -- so the reference's own pixel selection (train_nerf.py:839, the same stream) does not depend on how many model
+    calls an iteration makes, and the fused path, which makes fewer, selects the same rays in a seeded run."""
+    np.random.seed(123)
+    a = np.random.choice(10 ** 6, size=16, replace=False)
+    np.random.seed(123)
+    for _ in range(7):
+        assert np.random.randint(1) == 0
+    b = np.random.choice(10 ** 6, size=16, replace=False)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_point_coords_noise_is_refused(pkg):
+    """models.py:291-293 jitters the coordinates in training; not implemented natively -> loud, not silently ignored"""
+    with pytest.raises(NotImplementedError):
+        pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", point_coords_noise=0.01)
+
+
+def test_plane_cache_evicts_dead_sources_and_sr_planes(pkg):
+    """the channel-last plane cache keeps only what is alive: an entry goes when its source tensor dies, when PlanesSR clears its
+    planes, and when the model moves to another scene (multi-scene runs must not grow device memory monotonically)."""
+    M = pkg.models
+    M.clear_plane_cache()
+    src = torch.nn.Parameter(torch.zeros(1, 48, 4, 4).contiguous(memory_format=torch.channels_last))      # native layout: cached as a view, no kernel
+    M._cache_plane("scA_DS1_PlRes4_4_D0", src)
+    M._cache_plane("scA_DS1_PlRes4_4_D0/SR", src)
+    M._cache_plane("scB_DS1_PlRes4_4_D0", src)
+    assert len(M._PLANE_CACHE) == 3
+    M.clear_plane_cache(keep_scene="B_DS1_PlRes4_4")
+    assert sorted(M._PLANE_CACHE) == ["scB_DS1_PlRes4_4_D0"]
+    M._cache_plane("scB_DS1_PlRes4_4_D1/SR", src)
+    sr = M.PlanesSR(M.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 1}}, "bilinear")
+    sr.SR_planes["scB_DS1_PlRes4_4_D1"] = torch.zeros(1)
+    sr.clear_SR_planes()
+    assert sorted(M._PLANE_CACHE) == ["scB_DS1_PlRes4_4_D0"]
+    del src
+    import gc
+    gc.collect()
+    assert len(M._PLANE_CACHE) == 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`bench.py --gpus N` under a launcher that started a different number of ranks exits non-zero before touching the GPU (round 1
+    silently ran one rank and reported n_gpus: 1)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr

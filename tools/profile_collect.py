@@ -56,7 +56,10 @@ def summed(match):
     return pick
 
 
-latest = {"round": tag, "correction": CORRECTION}
+sys.path.insert(0, root)
+from bench import csrc_tree_hash  # noqa: E402
+# the kernels these counters belong to: bench.py prints `traffic` only while the tree still hashes to this value
+latest = {"round": tag, "correction": CORRECTION, "csrc_sha256": csrc_tree_hash()}
 # render: the longest fused-pass launch = the fine pass (S = 192)
 pm = counters("pmc_", longest(lambda k: "render_pass" in k and "backward" not in k))
 if pm:
