@@ -63,13 +63,18 @@ int nvsr_version(void);
  * Inputs, outputs, accumulation and everything outside the GEMMs are f32 in every mode.
  *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation -- the reference's arithmetic
  *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs (8 + 8 + 8 significant bits, by truncation), the products
- *                     Wh(xh + xm + xl) + Wm(xh + xm) + Wl xh on v_mfma_f32_32x32x16_bf16, 2.7x the f32 matrix rate.  The three dropped
- *                     products are bounded by |Wm xl| + |Wl xm| + |Wl xl| < (2^-23 + 2^-23 + 2^-30) |W||x|  (truncation limbs:
- *                     |m| < 2^-8 |v|, |l| < 2^-16 |v| relative to the leading limb's binade, i.e. < 2^-7, 2^-15 of |v| at worst):
- *                     about TWO f32 roundings per product in the worst case, and because truncated limbs carry the operand's sign the
- *                     error is a one-sided bias of the sign of W x, which adds up over K instead of averaging out.  Measured worst case
- *                     on adversarial operands (all mantissa bits set, K = 192): tests/test_hip_parity.py::test_limb_error_bound.
- *                     NOT bit-grade f32; it is the default because every parity tolerance of the path (2e-5 on decoder outputs) holds.
+ *                     Wh(xh + xm + xl) + Wm(xh + xm) + Wl xh on v_mfma_f32_32x32x16_bf16, 2.7x the f32 matrix rate.  Error of a dot
+ *                     product of K terms, relative to sum |W_k||x_k|:
+ *                       - the three dropped products: |Wm xl| + |Wl xm| + |Wl xl| < (2^-22 + 2^-22 + 2^-30) |W||x| = 2^-21 + 2^-30
+ *                         (truncation limbs: |m| < 2^-7 |v|, |l| < 2^-15 |v|) -- about FOUR f32 roundings per product at worst, and
+ *                         one-sided: truncated limbs carry the operand's sign, so the dropped part has the sign of W x and adds up
+ *                         over K instead of averaging out;
+ *                       - plus one f32 rounding of the running sum per MFMA that adds into it: 6 K / 16 of them (K / 2 for the f32
+ *                         MFMA), <= 2^-24 each -- the products are exact, the sums are ordinary f32 sums.
+ *                     Measured on adversarial operands (every mantissa 0x7FFFFF or 0x00FFFF, equal signs, K = 192; tests/
+ *                     test_hip_round2.py::test_limb_error_bound): max error 9.8e-7 (2^-20), mean -1.8e-7, against 5.6e-7 / +1.8e-8 for
+ *                     the exact-f32 kernel.  NOT bit-grade f32; it is the default because every parity tolerance of the path holds in
+ *                     it (2e-5 on decoder outputs; PSNR of the 800^2 frame vs the double-precision oracle 89.2 dB against 90.8 dB).
  *   NVSR_ARITH_BF16X2 2 limbs (16 significant bits per operand), 3 products, 5.3x; error <= 2^-15 |W||x| per product (opt-in)
  * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
  * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | bf16x2

@@ -3,9 +3,12 @@
 // v_mfma_f32_32x32x2_f32 retires 32 MAC / cycle / SIMD, v_mfma_f32_32x32x16_bf16 512.  An f32 value is EXACTLY the sum of three bf16
 // values taken by truncation (8 + 8 + 8 significant bits):  x = xh + xm + xl, and a product of two bf16 values is exact in f32.  So
 //     W x  =  Wh(xh + xm + xl) + Wm(xh + xm) + Wl xh   +  [Wm xl + Wl xm + Wl xl]
-// where the bracket is <= 2^-24 |W||x| per product, the size of one f32 rounding: six bf16 MFMAs with f32 accumulation give an f32-grade
-// product at 16/6 = 2.7x the rate of the f32 MFMA (LIMBS = 3).  LIMBS = 2 keeps 16 bits per operand (second limb rounded to nearest,
-// 3 products, error <= 2^-15 |W||x| per product) at 5.3x.
+// With truncation limbs |m| < 2^-7 |v| and |l| < 2^-15 |v|, so the dropped bracket is < (2^-22 + 2^-22 + 2^-30) |W||x| = 2^-21 + 2^-30 per
+// product -- up to four f32 roundings, and ONE-SIDED (the limbs carry the operand's sign: the bracket has the sign of W x and adds up
+// over K).  Six bf16 MFMAs with f32 accumulation give the product at 16/6 = 2.7x the rate of the f32 MFMA (LIMBS = 3); the running sum
+// takes one f32 rounding per MFMA (6 K / 16 of them).  Measured worst case at K = 192 on adversarial mantissas: 9.8e-7 of sum |W||x|
+// (exact-f32 kernel: 5.6e-7), tests/test_hip_round2.py::test_limb_error_bound -- close to, not bit-grade, f32.  LIMBS = 2 keeps 16 bits
+// per operand (second limb rounded to nearest, 3 products, error <= 2^-15 |W||x| per product) at 5.3x.
 //
 // Fragment layout: A = weights [32 out x 16 in], B = activations [16 in x 32 points].  Lane l = (m | n = l & 31, h = l >> 5) holds the
 // 8 k-values 8h .. 8h+7 of its row / column as 4 words {bf16 k even (low half), bf16 k odd (high half)}.  The C/D layout of a 32x32

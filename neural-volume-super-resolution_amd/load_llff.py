@@ -141,37 +141,61 @@ def spherify_poses(poses, bds):
     return reset, ring, bds
 
 
+def _views_first(poses_35n, bds_2n, imgs):
+    """LLFF stores poses [3,5,n] with rotation columns [down, right, back]; the renderer wants [right, up, back] and the view index first
+    (load_llff.py:291-297).  -> poses [n,3,5], bds [n,2], imgs [n,H,W,3] (or the untouched file list), all float32."""
+    rot_fixed = np.concatenate([poses_35n[:, 1:2, :], -poses_35n[:, 0:1, :], poses_35n[:, 2:, :]], 1)
+    front = lambda a: np.moveaxis(a, -1, 0).astype(np.float32)
+    return front(rot_fixed), front(bds_2n), (front(imgs) if isinstance(imgs, np.ndarray) else imgs)
+
+
+def _normalise_depth_scale(poses, bds, bd_factor):
+    """scale the scene so that the nearest depth bound sits at 1 / bd_factor (load_llff.py:299-302); in place"""
+    if bd_factor is not None:
+        s = 1.0 / (bds.min() * bd_factor)
+        poses[:, :3, 3] *= s
+        bds *= s
+    return poses, bds
+
+
+def _forward_facing_path(poses, bds, flat):
+    """the spiral fly-through of a forward-facing capture (load_llff.py:310-341): around the mean camera, radii = 90th percentile of the
+    camera offsets, looking at a depth between the bounds (harmonic mix, 3/4 towards the far bound); `flat` (path_zflat): half as many
+    views on one planar turn, pushed slightly towards the scene"""
+    centre = poses_avg(poses)
+    up = normalize(poses[:, :3, 1].sum(0))
+    near, far = bds.min() * 0.9, bds.max() * 5.0
+    w_far = 0.75
+    focus_depth = 1.0 / ((1.0 - w_far) / near + w_far / far)
+    radii = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+    views, turns = 120, 2
+    if flat:
+        centre[:3, 3] = centre[:3, 3] + (-near * 0.1) * centre[:3, 2]
+        radii[2] = 0.0
+        views, turns = views // 2, 1
+    return render_path_spiral(centre, up, radii, focus_depth, near * 0.2, zrate=0.5, rots=turns, N=views)
+
+
+def _most_central_view(poses):
+    """index of the camera closest to the mean camera position: the reference's hold-out view (load_llff.py:349-352)"""
+    offsets = poses_avg(poses)[:3, 3] - poses[:, :3, 3]
+    return np.argmin((offsets * offsets).sum(-1))
+
+
 def load_llff_data(basedir, factor=8, base_factor=1, max_factor=1, recenter=True, bd_factor=0.75, spherify=False, path_zflat=False,
                    load_imgs=True, min_eval_frames=None):
-    """-> (images [n,H,W,3] float32 tensor | file list, poses [n,3,5] tensor, bds [n,2], render_poses [m,3,5], i_test, (base_factor, margins))"""
-    poses, bds, imgs, load_params = _load_data(basedir, factor=factor, base_factor=base_factor, max_factor=max_factor, load_imgs=load_imgs,
-                                               min_eval_frames=min_eval_frames)
-    # LLFF stores [down, right, back]; the renderer wants [right, up, back].  Images / poses / bounds: view index first.
-    poses = np.moveaxis(np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1), -1, 0).astype(np.float32)
-    if load_imgs:
-        imgs = np.moveaxis(imgs, -1, 0).astype(np.float32)
-    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    sc = 1.0 if bd_factor is None else 1.0 / (bds.min() * bd_factor)       # nearest depth bound -> 1 / bd_factor
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    """load_llff.py:282-359 -> (images [n,H,W,3] float32 tensor | file list, poses [n,3,5] tensor, bds [n,2], render_poses [m,3,5], i_test,
+    (base_factor, margins))"""
+    raw_poses, raw_bds, raw_imgs, load_params = _load_data(basedir, factor=factor, base_factor=base_factor, max_factor=max_factor,
+                                                           load_imgs=load_imgs, min_eval_frames=min_eval_frames)
+    poses, bds, imgs = _views_first(raw_poses, raw_bds, raw_imgs if load_imgs else None)
+    poses, bds = _normalise_depth_scale(poses, bds, bd_factor)
     if recenter:
         poses = recenter_poses(poses)
     if spherify:
-        poses, render_poses, bds = spherify_poses(poses, bds)
+        poses, path, bds = spherify_poses(poses, bds)
     else:
-        c2w = poses_avg(poses)
-        up = normalize(poses[:, :3, 1].sum(0))
-        close_depth, inf_depth = bds.min() * 0.9, bds.max() * 5.0
-        dt = 0.75
-        focus = 1.0 / ((1.0 - dt) / close_depth + dt / inf_depth)          # the spiral looks at a depth between the bounds
-        rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
-        n_views, n_rots = 120, 2
-        if path_zflat:
-            c2w[:3, 3] = c2w[:3, 3] + (-close_depth * 0.1) * c2w[:3, 2]
-            rads[2] = 0.0
-            n_rots, n_views = 1, n_views // 2
-        render_poses = render_path_spiral(c2w, up, rads, focus, close_depth * 0.2, zrate=0.5, rots=n_rots, N=n_views)
-    render_poses = np.array(render_poses).astype(np.float32)
-    i_test = np.argmin(np.sum(np.square(poses_avg(poses)[:3, 3] - poses[:, :3, 3]), -1))       # hold out the most central view
-    poses = poses.astype(np.float32)
-    return (torch.from_numpy(imgs) if load_imgs else imgs), torch.from_numpy(poses), bds, render_poses, i_test, load_params
+        path = _forward_facing_path(poses, bds, flat=path_zflat)
+    held_out = _most_central_view(poses)
+    images = torch.from_numpy(imgs) if load_imgs else raw_imgs
+    return images, torch.from_numpy(poses.astype(np.float32)), bds, np.array(path).astype(np.float32), held_out, load_params
