@@ -395,7 +395,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
             result["cpu_baseline"] = {"value": n / t, "unit": "rays/s", "cores": 1, "kind": "port",
                                       "sample": "%d rays of the same step (forward + analytic backward: %s), %.1f s, C "
                                                 "oracle, double accumulation, single thread" % (n, label, t)}
-        print(json.dumps(result), flush=True)
+        return result
 
 
 def bench_sr(args, nvsr_amd, dist, dev, rank, world):
@@ -481,7 +481,7 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
             result["cpu_baseline"] = {"value": (reps * fl / t) / (flop_scene / 3), "unit": "planes/s", "cores": cores, "kind": "port",
                                       "sample": "%d x one 256->256 3x3 conv on a 66x66 tile (%.2f GFLOP each, %.1f s in total, C oracle fp32 OpenMP "
                                                 "%d threads), scaled by FLOPs to a whole plane" % (reps, fl / 1e9, t, cores)}
-        print(json.dumps(result), flush=True)
+        return result
 
 
 def main():
@@ -501,6 +501,8 @@ def main():
     ap.add_argument("--plane-res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="--workload render, N = 1: do not append the short train / sr runs (`other_workloads` of the line)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -543,7 +545,9 @@ def main():
     nvsr_amd.capi.lib()  # fail loudly if the HIP library is not built
 
     if args.workload != "render":
-        (bench_train if args.workload == "train" else bench_sr)(args, nvsr_amd, dist, dev, rank, world)
+        res = (bench_train if args.workload == "train" else bench_sr)(args, nvsr_amd, dist, dev, rank, world)
+        if res is not None:          # rank 0
+            print(json.dumps(res), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -690,6 +694,26 @@ def main():
                 for m2, fr in frames.items():
                     result["arithmetic_modes"][m2]["psnr_vs_oracle_db"] = cpu_baseline.psnr_of(fr)
                 result["psnr_vs_oracle_db_by_arithmetic"] = {m2: v["psnr_vs_oracle_db"] for m2, v in result["arithmetic_modes"].items()}
+        if world == 1 and not args.no_modes and not args.no_other_workloads and H == 800 and args.plane_res == 800:
+            # The other BASELINE configurations of the same path, measured in this same driver-timed process (short runs; each is also its
+            # own `--workload`): configs[3] = the 4 096-ray Feature_Planes_Only optimisation step, configs[2]'s SR stage = EDSR 256 x 32 on
+            # the three 200^2 planes of a scene (+ its training forward / backward per plane).  Same JSON contract per entry.
+            del out
+            sub = argparse.Namespace(**vars(args))
+            sub.no_cpu_baseline, sub.no_modes = True, False
+            other = {}
+            for wl, fn, steps, warm, extra in (("train", bench_train, 30, 5, {"train_what": "planes"}),
+                                               ("train_decoder", bench_train, 20, 3, {"train_what": "planes+decoder"}),
+                                               ("sr", bench_sr, 3, 1, {})):
+                sub.steps, sub.warmup = steps, warm
+                for k, v in extra.items():
+                    setattr(sub, k, v)
+                try:
+                    other[wl] = fn(sub, nvsr_amd, None, dev, 0, 1)
+                except Exception as e:          # the headline line must not depend on the side runs
+                    other[wl] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+            result["other_workloads"] = other
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -496,3 +496,75 @@ def test_sharded_render_is_bit_identical_to_one_rank(partition, res, self_launch
     assert r["n_gpus"] == 2 and r["config"]["partition"] == partition and r["scaling"] == ("strong" if partition == "frame" else "weak")
     frames = 1 if partition == "frame" else 2
     assert abs(r["value"] - frames * res * res * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at its real size: LLFF 'fern'-like forward-facing view, NDC rays, 64 + 128 samples, planes super-resolved by the
+# full EDSR(256 x 32) -- rendering and one SR-refinement optimisation step
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_config5_llff_ndc_real_size_render_and_sr_refinement_step(hip, oracle):
+    """378 x 504 view (LLFF at 1/8), scene_config.no_ndc = False (train_utils.py:215-218), LR planes 200^2 super-resolved to
+    800^2 by PlanesSR(EDSR 256 x 32) on first use (models.py:270-284), 64 + 128 samples: 190 512 rays through the fused passes.
+    2 048 randomly chosen rays are checked against the oracle rendering the SAME super-resolved planes (their values are pinned by
+    test_full_size_edsr_windows_vs_oracle); then one `what: ['SR']` refinement step at this size (4 096 rays, ROI super-resolution of
+    the three planes in training mode, gradients through the renderer into all 43 M SR weights) must run, give finite gradients for
+    every conv, and a second evaluation must serve freshly super-resolved planes."""
+    from oracle.oracle import decoder_blob
+    from test_hip_parity import Opt, make_options
+    from bench import make_synthetic_scene
+
+    mc, mf, sid, _ = make_synthetic_scene(DEV, plane_res=200, view_res=32, seed=11)
+    sr = _full_size_sr(hip, seed=31)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(0.3)                     # keep the super-resolved planes in the range of the LR ones
+    sr.eval()
+    for m in (mc, mf):
+        m.assign_SR_model(sr, SR_viewdir=False)
+        # forward-facing NDC scene: the box spans the NDC cube
+        m.box_coords = {sid: torch.tensor([[-1.5, -1.5, -1.5, -np.pi, -np.pi / 2], [1.5, 1.5, 1.5, np.pi, np.pi / 2]], dtype=torch.float64)}
+        m.invalidate()
+    mf.assign_LR_planes()
+    H, W, focal = 378, 504, 407.6
+    pose = torch.tensor([[1.0, 0.0, 0.0, 0.03], [0.0, 1.0, 0.0, -0.02], [0.0, 0.0, 1.0, 0.1], [0.0, 0.0, 0.0, 1.0]], device=DEV)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    opts, _ = make_options(64, 128)
+    scfg = Opt(near=0, far=1, no_ndc=False)
+    with torch.no_grad():
+        rgb_c, _, _, rgb_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    assert rgb_f.shape == (H, W, 3) and torch.isfinite(rgb_f).all()
+    names = [hip.models.get_plane_name(sid, d) for d in range(4)]
+    assert sorted(sr.SR_planes) == sorted(names[:3]) and all(sr.SR_planes[n].shape[-1] == 800 for n in names[:3])
+    # oracle on a sample of the rays, from the same HR planes
+    rng = np.random.default_rng(5)
+    ids = np.sort(rng.choice(H * W, 2048, replace=False))
+    planes = [N_(sr.SR_planes[n]) for n in names[:3]] + [N_(mc.planes_[names[3]])]
+    osc = oracle.scene(planes, mc.box_coords[sid].numpy())
+    sdn = lambda m: {k: N_(v) for k, v in m.state_dict().items() if "SR_model" not in k}
+    ro_n, rd_n = hip.nerf_helpers.ndc_rays(H, W, focal, 1.0, ro.reshape(-1, 3), rd.reshape(-1, 3))
+    rays = oracle.pack_rays(N_(ro_n)[ids], N_(rd_n)[ids], 0.0, 1.0, dirs_for_view=N_(rd.reshape(-1, 3))[ids])
+    o = oracle.render_rays(osc, oracle.decoder(decoder_blob(sdn(mc))), oracle.decoder(decoder_blob(sdn(mf))), rays, 64, 128)
+    np.testing.assert_allclose(N_(rgb_c).reshape(-1, 3)[ids], o["rgb_coarse"], rtol=0, atol=3e-5)
+    err = np.abs(N_(rgb_f).reshape(-1, 3)[ids] - o["rgb_fine"]).max(-1)
+    assert (err <= 2e-4).mean() >= 0.97, ((err <= 2e-4).mean(), err.max())
+    # SR refinement step at this size
+    for m in (mc, mf):
+        for n_, p_ in m.named_parameters():           # (the SR model is a registered sub-module of both: leave its weights trainable)
+            if "SR_model" not in n_:
+                p_.requires_grad_(False)
+    for p_ in mc.planes_.values():
+        p_.requires_grad_(False)
+    sr_opt = torch.optim.Adam(sr.parameters(), lr=1e-4)
+    step = hip.training.TrainStep(mc, mf, opts, {"SR"}, SR_optimizer=sr_opt, SR_model=sr, sr_loss="fine")
+    np.random.seed(3)
+    before = [w_.detach().clone() for w_ in sr.inner_model.conv_weights()[:2]]
+    r = step(0, rgb_f.detach() * 0.9, pose, H, W, focal, 1, sid, scfg, 4096, sr_iter=True)
+    assert np.isfinite(r["loss"]) and r["coarse_loss"] is None
+    grads = [w_.grad for w_ in sr.inner_model.conv_weights()]
+    assert all(g_ is not None and torch.isfinite(g_).all() for g_ in grads) and float(grads[0].abs().max()) > 0 and float(grads[-1].abs().max()) > 0
+    assert not torch.equal(before[0], sr.inner_model.conv_weights()[0]) and not torch.equal(before[1], sr.inner_model.conv_weights()[1])
+    sr.eval()
+    sr.clear_SR_planes()
+    with torch.no_grad():
+        again = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
+    assert torch.isfinite(again).all() and not torch.equal(again, rgb_f)          # the refined network was used
