@@ -1,5 +1,5 @@
 // Fused render pass, third generation: the decoder GEMMs on the bf16 matrix pipe with every f32 operand split into bf16 limbs
-// (limb_core.h) -- f32-grade products at 2.7x (3 limbs) or 16-bit operands at 5.3x (2 limbs) the rate of v_mfma_f32_32x32x2_f32.
+// (limb_core.h; error bound there) -- products at 2.7x (3 limbs) or 16-bit operands at 5.3x (2 limbs) the rate of v_mfma_f32_32x32x2_f32.
 //
 // Same skeleton as render2.hip: one wave per SIMD owns two 32-point tiles X and Y; while the matrix pipe multiplies one tile, the other
 // tile's gathers / bias + ReLU / heads are issued in the gaps.  What changes with a 32-cycle MFMA: a gap hides ~5 single-issue

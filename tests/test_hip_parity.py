@@ -456,7 +456,7 @@ def test_edsr_and_planes_sr_golden(hip):
 
 def test_conv3x3_shapes_vs_oracle(hip, oracle):
     """channel counts that exercise both workgroup shapes and the padding of Cin/Cout (48->256, 256->256, 256->48, 16->64 shuffle,
-    256->1024 shuffle), in both arithmetic modes (the wide layers run on the bf16-limb kernel by default: f32-grade products, the same
+    256->1024 shuffle), in both arithmetic modes (the wide layers run on the bf16-limb kernel by default: near-f32 products (bound in include/nvsr.h), the same
     tolerance; the others always on the f32 kernel)"""
     rng = np.random.default_rng(3)
     capi = hip.capi
@@ -1351,7 +1351,7 @@ def test_limb_fragments_reproduce_the_weights(hip):
 
 
 def test_render_pass_limb_arithmetic(hip, oracle):
-    """nvsr_render_pass with the decoder GEMMs on the bf16 matrix pipe (render3.hip): 3 limbs per operand = f32-grade products
+    """nvsr_render_pass with the decoder GEMMs on the bf16 matrix pipe (render3.hip): 3 limbs per operand = near-f32 products (bound in include/nvsr.h)
     (tolerances of the f32 kernels), 2 limbs = 16-bit operands (stated looser tolerance); against the f32-MFMA kernel and the oracle.
     20 011 rays (partial last workgroup, a wave whose second tile is empty), 37 samples, density noise, white background."""
     import ctypes as C

@@ -175,7 +175,7 @@ def test_limb_error_bound(hip):
                               + n_acc * 2^-24                    one f32 rounding of the running sum per MFMA that adds into it:
                                                                  n_acc = 6 K / 16 = 72 for bf16x3, K / 2 = 96 for v_mfma_f32_32x32x2_f32
     The second term is the worst case of round-to-nearest accumulation and is what dominates the MEASURED limb error (printed below,
-    recorded in DESIGN.md 4): the products are f32-grade, the sums are ordinary f32 sums of 6x as many, partly much smaller, terms."""
+    recorded in DESIGN.md 4): the products are exact up to the dropped terms, the sums are ordinary f32 sums of 6x as many, partly much smaller, terms."""
     capi = hip.capi
     rng = np.random.default_rng(77)
     g = torch.Generator().manual_seed(5)
