@@ -302,6 +302,33 @@ int nvsr_planes_sr_backward(int C, int R0, int R1, const float* keep, const floa
                             int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural, float* d_lr,
                             float* workspace, nvsr_stream_t stream);
 
+/* ---- decoder geometries other than the shipped one (inference) --------------------------------------------------------------------
+ * TwoDimPlanesModel (models.py:118-434) is configurable: dec_channels, layer counts, skip_connect_every, num_plane_channels,
+ * proj_combination, viewdir_proj_combination (config/TrainModels.yml:78,82,92 list alternatives).  The MFMA kernels above are compiled for
+ * the shipped configuration; every other one the reference's own layer sizes admit runs through this generic path (plain kernels,
+ * activations through HBM, exact-f32 MFMA layers): forward only. */
+typedef struct nvsr_decoder_geometry {
+    int32_t plane_channels;        /* num_plane_channels */
+    int32_t viewdir_channels;      /* num_viewdir_plane_channels */
+    int32_t hidden;                /* dec_channels */
+    int32_t density_layers;        /* dec_density_layers */
+    int32_t rgb_layers;            /* dec_rgb_layers */
+    int32_t skip_connect_every;    /* 0 = None (models.py:203-207) */
+    int32_t proj_combination;      /* 0 'sum' | 1 'avg' | 2 'concat'                              (models.py:355-361) */
+    int32_t viewdir_combination;   /* 0 'sum' | 1 'avg' | 2 'mult' | 3 'concat' | 4 'concat_pos'  (models.py:363-379) */
+} nvsr_decoder_geometry;
+/* parameters in state-dict order: density_dec.0.{l}.{weight[out,in],bias}, fc_alpha.0.{weight,bias}, rgb_dec.0.{l}.{weight,bias},
+ * fc_rgb.0.{weight,bias}; -1 for a geometry whose layer sizes are inconsistent in the reference itself (e.g. 'concat' view features on
+ * summed position features) */
+int64_t nvsr_generic_decoder_natural_floats(const nvsr_decoder_geometry* geometry);
+int64_t nvsr_generic_decode_workspace_floats(const nvsr_decoder_geometry* geometry, int64_t P);
+/* TwoDimPlanesModel.forward: x [P,6] = [xyz, viewdir] -> out [P,4].  scene: planes channel-last [H][W][plane_channels] (the view plane:
+ * [H][W][viewdir_channels]); natural: the blob above (device). */
+int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P, const float* x,
+                        float* out, float* workspace, nvsr_stream_t stream);
+/* run_network's model input for a pass (train_utils.py:15-64,111): x [N*S,6] = [ro + rd * z, viewdir] from packed rays [N,11], z [N,S] */
+int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* x, nvsr_stream_t stream);
+
 /* ---- per-call arithmetic -----------------------------------------------------------------------------------------------------
  * Twins of the entry points above that run decoder GEMMs or SR convolutions, with the arithmetic as an explicit argument
  * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_BF16X2 (decoder forward only) | NVSR_ARITH_INHERIT).  Same arguments, same

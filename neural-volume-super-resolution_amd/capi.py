@@ -34,6 +34,12 @@ class Scene(C.Structure):
                 ("range", C.c_float * 5), ("proj", (C.c_float * 6) * 3)]
 
 
+class DecoderGeometry(C.Structure):
+    """struct nvsr_decoder_geometry"""
+    _fields_ = [(n, C.c_int32) for n in ("plane_channels", "viewdir_channels", "hidden", "density_layers", "rgb_layers", "skip_connect_every",
+                                         "proj_combination", "viewdir_combination")]
+
+
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _PROTOS = {
     "nvsr_version": ([], C.c_int),
@@ -105,6 +111,11 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_planes_sr_train": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_planes_sr_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr_backward": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    # decoder geometries other than the shipped one (csrc/generic.hip)
+    "nvsr_generic_decoder_natural_floats": ([C.POINTER(DecoderGeometry)], _i64),
+    "nvsr_generic_decode_workspace_floats": ([C.POINTER(DecoderGeometry), _i64], _i64),
+    "nvsr_generic_decode": ([C.POINTER(Scene), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "nvsr_ray_points": ([_i64, _i, _vp, _vp, _vp, _vp], _i),
     # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")
     "nvsr_render_pass_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "nvsr_decode_rays_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),

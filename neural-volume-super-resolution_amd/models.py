@@ -263,22 +263,42 @@ class TwoDimPlanesModel(nn.Module):
             self.SR_model.set_LR_plane(plane.detach() if self.detach_LR_planes else plane, id=k, save_interpolated=False)
 
     # ---- native path ---------------------------------------------------------------------------------------------------
+    def is_native_geometry(self):
+        """the configuration the fused MFMA kernels are compiled for: 3 + 1 planes x 48 channels, 'avg' / 'concat_pos', 4 + 4 layers x 128,
+        no skip layer (every shipped YAML).  Any other geometry the reference's layer sizes admit renders through the generic kernels
+        (csrc/generic.hip: forward only, activations through HBM)."""
+        return (self.use_viewdirs and self.num_density_planes == 3 and self.num_plane_channels == capi.PLANE_CHANNELS
+                and self.num_viewdir_plane_channels == capi.PLANE_CHANNELS and self.dec_channels == capi.DEC_CHANNELS
+                and self.dec_density_layers == 4 and self.dec_rgb_layers == 4 and self.ensemble_size == 1
+                and self.proj_combination == "avg" and self.viewdir_proj_combination == "concat_pos"
+                and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear" and self.align_corners
+                and not any(self.is_skip_layer(l) for l in range(3)))
+
     def _check_native_geometry(self):
-        ok = (self.use_viewdirs and self.num_density_planes == 3 and self.num_plane_channels == capi.PLANE_CHANNELS
-              and self.num_viewdir_plane_channels == capi.PLANE_CHANNELS and self.dec_channels == capi.DEC_CHANNELS
-              and self.dec_density_layers == 4 and self.dec_rgb_layers == 4 and self.ensemble_size == 1
-              and self.proj_combination == "avg" and self.viewdir_proj_combination == "concat_pos"
-              and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear" and self.align_corners
-              and not any(self.is_skip_layer(l) for l in range(3)))
-        if not ok:
+        if not self.is_native_geometry():
             raise NotImplementedError(
-                "the gfx950 decoder kernel is compiled for the shipped configuration (3+1 planes x 48 channels, 'avg' / "
-                "'concat_pos', 4+4 layers x 128, no skip layer); got a different TwoDimPlanesModel geometry")
+                "this entry point (training / fused passes) runs on the kernels compiled for the shipped configuration (3+1 planes x 48 "
+                "channels, 'avg' / 'concat_pos', 4+4 layers x 128, no skip layer); other TwoDimPlanesModel geometries are rendered by the "
+                "generic forward kernels only")
+
+    def generic_geometry(self):
+        """[plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every, proj, view] for
+        torch.ops.nvsr.triplane_decode_generic (struct nvsr_decoder_geometry)"""
+        if not (self.use_viewdirs and self.num_density_planes == 3 and self.ensemble_size == 1 and self.rgb_dec_input == "projections"
+                and self.plane_interp == "bilinear" and self.align_corners):
+            raise NotImplementedError("the generic decoder kernels cover use_viewdirs=True, 3 axis-aligned position planes, ensemble_size 1, "
+                                      "rgb_dec_input='projections', bilinear planes with align_corners=True")
+        return [self.num_plane_channels, self.num_viewdir_plane_channels, self.dec_channels, self.dec_density_layers, self.dec_rgb_layers,
+                int(self.skip_connect_every or 0), {"sum": 0, "avg": 1, "concat": 2}[self.proj_combination],
+                {"sum": 0, "avg": 1, "mult": 2, "concat": 3, "concat_pos": 4}[self.viewdir_proj_combination]]
 
     def decoder_parameters(self):
         """the decoder's weights and biases in state-dict order (planes and the fixed projection matrices excluded)"""
         sd = dict(self.named_parameters())
-        return [sd[k] for pair in DECODER_KEYS for k in pair]
+        keys = [("density_dec.0.%d.weight" % i, "density_dec.0.%d.bias" % i) for i in range(self.dec_density_layers)] + \
+               [("fc_alpha.0.weight", "fc_alpha.0.bias")] + \
+               [("rgb_dec.0.%d.weight" % i, "rgb_dec.0.%d.bias" % i) for i in range(self.dec_rgb_layers)] + [("fc_rgb.0.weight", "fc_rgb.0.bias")]
+        return [sd[k] for pair in keys for k in pair]
 
     def natural_blob(self, differentiable=False):
         """Decoder parameters flattened in state-dict order (the layout nvsr_pack_decoder consumes).  differentiable=True keeps
@@ -362,11 +382,30 @@ class TwoDimPlanesModel(nn.Module):
             out.append(self.SR_model((saved, roi)))
         return out
 
-    def scene_args(self, planes=None):
+    def _generic_forward(self, x):
+        """forward through the generic kernels (any geometry): inference only"""
+        if torch.is_grad_enabled() and self.training and (any(p.requires_grad for p in self.decoder_parameters()) or
+                                                          any(p.requires_grad for p in self.planes_.values())):
+            raise NotImplementedError("training is implemented for the shipped decoder geometry only; this geometry renders (inference) "
+                                      "through the generic kernels")
+        if hasattr(self, "SR_model") and not self.skip_SR_:
+            names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]
+            names = [n for n in names if self._should_SR(n)]
+            if self.scene_coupler is not None:
+                names = [self.scene_coupler.scene_with_saved_plane(n, plane_not_scene=True) for n in names]
+            self.SR_model.super_resolve_many(names)
+        planes = [self.channel_last_plane(d) for d in range(self.num_density_planes + 1)]
+        planes, consts = self.scene_args(planes=planes, check_native=False)
+        nat = self.natural_blob()
+        capi.require_cuda(nat)
+        return torch.ops.nvsr.triplane_decode_generic(planes, consts, nat, self.generic_geometry(), x)
+
+    def scene_args(self, planes=None, check_native=True):
         """(planes, consts) of the current scene id as the torch.ops.nvsr operators take them: 4 channel-last planes + the 28 host floats
         of struct nvsr_scene.  planes: optional explicit channel-last planes (the training path samples tensors that are part of the
         autograd graph)."""
-        self._check_native_geometry()
+        if check_native:
+            self._check_native_geometry()
         if planes is None:
             if hasattr(self, "SR_model") and not self.skip_SR_ and not (self.SR_model.training and torch.is_grad_enabled()):
                 # evaluation: super-resolve every plane that needs it in one batched pass; _plane_source then hits the cache
@@ -411,6 +450,8 @@ class TwoDimPlanesModel(nn.Module):
         P = x.numel() // 6
         if P == 0:
             return torch.empty(list(x.shape[:-1]) + [4], dtype=torch.float32, device=x.device)
+        if not self.is_native_geometry():
+            return self._generic_forward(x.reshape(P, 6)).reshape(list(x.shape[:-1]) + [4])
         if self.training and torch.is_grad_enabled() and not (hasattr(self, "SR_model") and not self.skip_SR_):
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
             planes = [self.planes_[n] for n in names]

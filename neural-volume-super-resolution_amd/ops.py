@@ -44,13 +44,14 @@ def _none_if_empty(t):
     return None if (t is None or t.numel() == 0) else t
 
 
-def _scene(planes, consts):
-    """struct nvsr_scene from 4 channel-last planes + the 28 host constants"""
+def _scene(planes, consts, channels=None):
+    """struct nvsr_scene from 4 channel-last planes + the 28 host constants (channels: (C, Cv) of a non-default decoder geometry)"""
     assert len(planes) == 4 and len(consts) == 28
     sc = capi.Scene()
     for d, p in enumerate(planes):
         capi.require_cuda(p)
-        assert p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] == PC and p.is_contiguous(), "planes must be channel-last [H,W,48] f32"
+        cc = PC if channels is None else channels[0 if d < 3 else 1]
+        assert p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] == cc and p.is_contiguous(), "planes must be channel-last [H,W,%d] f32" % cc
         sc.planes[d] = p.data_ptr()
         sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
     for i in range(5):
@@ -189,6 +190,48 @@ def triplane_decode(planes: Sequence[Tensor], consts: Sequence[float], packed: T
 @triplane_decode.register_fake
 def _(planes, consts, packed, x):
     return x.new_empty((x.shape[0], 4))
+
+
+@custom_op("nvsr::triplane_decode_generic", mutates_args=(), device_types="cuda")
+def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor) -> Tensor:
+    """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (inference; csrc/generic.hip).
+    geometry = [plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every (0 = None), proj_combination
+    (0 sum, 1 avg, 2 concat), viewdir_combination (0 sum, 1 avg, 2 mult, 3 concat, 4 concat_pos)]; natural = the parameters in
+    state-dict order; planes channel-last [H,W,plane_channels] x 3 + [H,W,viewdir_channels]."""
+    x, natural = _c(x), _c(natural)
+    geo = capi.DecoderGeometry(*[int(v) for v in geometry])
+    n = capi.lib().nvsr_generic_decoder_natural_floats(C.byref(geo))
+    if n < 0:
+        raise capi.NvsrError("this decoder geometry is inconsistent (the reference's own layer sizes do not admit it)")
+    assert natural.numel() == n, "natural blob: %d floats, the geometry needs %d" % (natural.numel(), n)
+    sc = _scene(planes, consts, channels=(geo.plane_channels, geo.viewdir_channels))
+    P = x.shape[0]
+    out = _f(P, 4, like=x)
+    if P:
+        ws = _f(capi.lib().nvsr_generic_decode_workspace_floats(C.byref(geo), P), like=x)
+        capi.call("nvsr_generic_decode", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x), capi.ptr(out), capi.ptr(ws), capi.stream())
+    return out
+
+
+@triplane_decode_generic.register_fake
+def _(planes, consts, natural, geometry, x):
+    return x.new_empty((x.shape[0], 4))
+
+
+@custom_op("nvsr::ray_points", mutates_args=(), device_types="cuda")
+def ray_points(rays: Tensor, z: Tensor) -> Tensor:
+    """run_network's model input (train_utils.py:15-64,111): [N*S,6] = [ro + rd * z, viewdir] from packed rays [N,11] and depths [N,S]"""
+    rays, z = _c(rays), _c(z)
+    N, S = z.shape
+    x = _f(N * S, 6, like=rays)
+    if N:
+        capi.call("nvsr_ray_points", N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(x), capi.stream())
+    return x
+
+
+@ray_points.register_fake
+def _(rays, z):
+    return rays.new_empty((z.shape[0] * z.shape[1], 6))
 
 
 @custom_op("nvsr::render_pass", mutates_args=(), device_types="cuda")
@@ -656,4 +699,5 @@ planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr
 
 # operators whose forward is checked with torch.library.opcheck in the GPU tests
 FORWARD_OPS = ["plane_to_channel_last", "plane_from_channel_last", "pack_decoder", "coarse_z", "importance_resample", "triplane_decode",
+               "triplane_decode_generic", "ray_points",
                "render_pass", "render_rays", "decode_rays", "composite", "composite_rays", "edsr", "planes_sr"]

@@ -24,6 +24,7 @@ def _cfg(node, name, default=None):
 
 
 MAX_RAYS_PER_LAUNCH = 1 << 22   # bounds the [N, 3*Nc+Nf] depth/weight workspace (5.4 GB at 64+128 samples)
+MAX_RAYS_PER_LAUNCH_GENERIC = 1 << 17   # generic geometries materialise [N*S,6] points and [N*S,4] outputs per pass (0.25 GB at 192 samples)
 
 
 def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn, scene_id=None, **kw):
@@ -199,6 +200,8 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
 
     for mdl in (model_coarse, model_fine):
         mdl.set_cur_scene_id(scene_id)
+    if not (model_coarse.is_native_geometry() and (Nf <= 0 or model_fine.is_native_geometry())):
+        return _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f)
     packed_c = model_coarse.packed_decoder()
     packed_f = model_fine.packed_decoder() if Nf > 0 else None
     top = model_fine if Nf > 0 else model_coarse
@@ -276,6 +279,27 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
 
 
+def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f):
+    """predict_and_render_radiance for decoder geometries other than the shipped one, pass by pass like the reference (train_utils.py:95-180):
+    depths -> run_network (the model's generic forward kernels on the [N*S,6] point list) -> compositing -> importance resampling -> again.
+    Inference only (the models raise when gradients are asked for)."""
+    nv = torch.ops.nvsr
+    N = rays.shape[0]
+    white, lindisp = bool(m.white_background), bool(m.lindisp)
+    if N == 0:
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=rays.device)
+        return (e(0, 3), e(0), e(0)) + ((e(0, 3), e(0), e(0)) if Nf > 0 else (None, None, None)) + (None, None, None)
+    z_c = nv.coarse_z(rays, Nc, lindisp, t_rand)
+    raw = model_coarse(nv.ray_points(rays, z_c)).reshape(N, Nc, 4)
+    rgb_c, disp_c, acc_c, w_c = nv.composite_rays(raw, z_c, rays, n_c, white, Nf > 0)
+    rgb_f = disp_f = acc_f = None
+    if Nf > 0:
+        z_f = nv.importance_resample(z_c, w_c, Nf, u)
+        raw_f = model_fine(nv.ray_points(rays, z_f)).reshape(N, Nc + Nf, 4)
+        rgb_f, disp_f, acc_f, _ = nv.composite_rays(raw_f, z_f, rays, n_f, white, False)
+    return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
+
+
 def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None, no_ndc=True):
     """run_one_iter_of_nerf's ray packing (train_utils.py:207-226): rays [N,11] = [ro, rd, near, far, viewdir]."""
     ro, rd = capi.f32c(ray_origins).reshape(-1, 3), capi.f32c(ray_directions).reshape(-1, 3)
@@ -320,8 +344,9 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
             parts.append(p)
         randoms = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]} if parts else {}
     outs = []
-    for a in range(0, max(N, 1), MAX_RAYS_PER_LAUNCH):
-        b = min(a + MAX_RAYS_PER_LAUNCH, N)
+    step = MAX_RAYS_PER_LAUNCH if (model_coarse.is_native_geometry() and model_fine.is_native_geometry()) else MAX_RAYS_PER_LAUNCH_GENERIC
+    for a in range(0, max(N, 1), step):
+        b = min(a + step, N)
         sub = None if randoms is None else {k: v[a:b] for k, v in randoms.items()}
         outs.append(predict_and_render_radiance(rays[a:b], model_coarse, model_fine, options, scene_id, mode=mode, randoms=sub if sub is not None else {}))
     if len(outs) == 1:

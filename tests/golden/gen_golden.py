@@ -24,6 +24,7 @@ Fixture index:
   g14_sr_grads.npz    autograd through EDSR / PlanesSR (full plane and ROI): weights, network input and LR plane ('SR' in what)
   g13_decoder_grads.npz autograd of one train step wrt the decoder parameters of both models (what: ['decoder'], train_nerf.py:75-77)
   g16_composite_mip.npz volume_render_radiance_field(mip_nerf=True) + its autograd wrt the radiance field (volume_rendering_utils.py:19-26,41-42)
+  g18_decoder_variants.npz  TwoDimPlanesModel.forward for other decoder geometries (widths, channel counts, combinations, skip layers)
   g17_store(.npz + g17_store/)  plane file, decoder checkpoint and SR checkpoint WRITTEN by the reference (PlanesOptimizer.save_params,
                       safe_saving; models.py:640-670, nerf_helpers.py:19-48, train_nerf.py:996-1008) + what it renders from them
   g15_loaders.npz     load_blender_data / load_llff_data on two tiny synthetic scenes (load_blender.py:232-332, load_llff.py:70-360).
@@ -975,9 +976,84 @@ def g17_store():
             print("wrote g17_store/%-28s %8.1f KB" % (os.path.relpath(fp, out_dir), os.path.getsize(fp) / 1024))
 
 
+# geometry variants of TwoDimPlanesModel that the shipped YAMLs list as alternatives (config/TrainModels.yml:78,82,92): constructor kwargs
+G18_VARIANTS = {
+    "wide256": dict(dec_channels=256, proj_combination="avg", viewdir_proj_combination="concat_pos", num_plane_channels=48),
+    "sum_sum": dict(dec_channels=128, proj_combination="sum", viewdir_proj_combination=None, num_plane_channels=48),
+    "avg_mult": dict(dec_channels=64, proj_combination="avg", viewdir_proj_combination="mult", num_plane_channels=48),
+    "concat24": dict(dec_channels=128, proj_combination="concat", viewdir_proj_combination="concat", num_plane_channels=24),
+    "skip2": dict(dec_channels=128, proj_combination="avg", viewdir_proj_combination="concat_pos", num_plane_channels=48, skip_connect_every=2),
+    "deep5_c24": dict(dec_channels=96, proj_combination="sum", viewdir_proj_combination="concat_pos", num_plane_channels=24, dec_density_layers=5,
+                      dec_rgb_layers=3, skip_connect_every=2),
+}
+
+
+def g18_decoder_variants():
+    """TwoDimPlanesModel.forward (models.py:381-421) for decoder geometries other than the shipped one: other widths, plane channel counts,
+    proj_combination sum / concat, viewdir_proj_combination sum / mult / concat, skip layers, unequal layer counts.  Per variant: the
+    points, planes, box, state dict and the reference's output; for one variant also an eval_nerf render (8 x 8 rays, 16 + 16 samples)."""
+    arrs = {}
+    R, Rv, P = 10, 6, 203
+    for vi, (name, kw) in enumerate(G18_VARIANTS.items()):
+        torch.manual_seed(180 + vi)
+        np.random.seed(180 + vi)
+        sid = models.get_scene_id("lego", 8, (R, Rv))
+        sc = models.SceneCoupler([sid], planes_res="LR", num_pos_planes=3, training_scenes=[sid])
+        kwargs = dict(use_viewdirs=True, skip_connect_every=3, align_corners=True, scene_coupler=sc)
+        kwargs.update(kw)
+        m = models.TwoDimPlanesModel(**kwargs)
+        m.optional_no_grad = nh.null_with
+        Cc = kwargs["num_plane_channels"]
+        planes = nn.ParameterDict([(models.get_plane_name(sid, d), models.create_plane(R if d < 3 else Rv, Cc, 0.5)) for d in range(4)])
+        box = torch.tensor(BOX, dtype=torch.float64)
+        m.planes_, m.plane_rank, m.generated_planes, m.downsampled_planes, m.coverages = planes, None, {}, {}, {}
+        m.box_coords = {sid: box}
+        m.set_cur_scene_id(sid)
+        m.eval()
+        pts = torch.rand(P, 3) * 8.4 - 4.2
+        d = torch.randn(P, 3)
+        x = torch.cat([pts, d / d.norm(dim=-1, keepdim=True)], -1)
+        mf = None
+        if name == "concat24":             # this variant is also rendered: a fine model, densities spread so that compositing is exercised
+            mf = models.TwoDimPlanesModel(num_planes_or_rot_mats=m.rot_mats(), **{k: v for k, v in kwargs.items()})
+            mf.optional_no_grad = nh.null_with
+            mf.planes_, mf.plane_rank, mf.generated_planes, mf.downsampled_planes, mf.coverages = planes, None, {}, {}, {}
+            mf.box_coords = {sid: box}
+            mf.set_cur_scene_id(sid)
+            mf.eval()
+            with torch.no_grad():
+                for mm in (m, mf):
+                    raw = mm(x)[:, 3]
+                    s_ = 1.0 / float(raw.std())
+                    mm.fc_alpha["0"].weight.mul_(s_)
+                    mm.fc_alpha["0"].bias.mul_(s_)
+                    mm.fc_alpha["0"].bias.add_(-float(mm(x)[:, 3].mean()) - 0.5)
+        with torch.no_grad():
+            out = m(x)
+        pre = "%s." % name
+        arrs[pre + "x"], arrs[pre + "out"] = npy(x), npy(out)
+        for dnum in range(4):
+            arrs[pre + "plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
+        arrs.update(state_arrays(pre + "sd.", m))
+        if name == "concat24":
+            arrs.update(state_arrays(pre + "render.coarse.", m))
+            arrs.update(state_arrays(pre + "render.fine.", mf))
+            H = W = 8
+            focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+            ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+            cfg = make_cfg(mode_cfg(16, 16), mode_cfg(16, 16))
+            with torch.no_grad():
+                rgb_c, _, _, rgb_f, *_ = tu.eval_nerf(H, W, focal, m, mf, ro, rd, cfg, scene_id=sid, scene_config=cfg.dataset["synt"])
+            arrs[pre + "render.rgb_coarse"], arrs[pre + "render.rgb_fine"] = npy(rgb_c), npy(rgb_f)
+            arrs[pre + "render.hwf"] = np.array([H, W, focal])
+    arrs["box"] = np.array(BOX, np.float64)
+    arrs["pose"] = POSE
+    save("g18_decoder_variants.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

@@ -336,6 +336,8 @@ def test_torch_library_ops_exist_and_opcheck(hip):
     chk(nv.coarse_z, (rays, 16, False, None))
     chk(nv.triplane_decode, (planes, consts, packed, pts))
     chk(nv.render_pass, (planes, consts, packed, rays, z, None, False, True, 3))
+    chk(nv.ray_points, (rays, z))
+    chk(nv.triplane_decode_generic, (planes, consts, mf.natural_blob(), mf.generic_geometry(), pts))     # (the shipped geometry is one of the geometries)
     chk(nv.render_rays, (planes, consts, mc.packed_decoder(), packed, rays, 16, 8, False, False, None, None, None, None, 0))
     chk(nv.decode_rays, (planes, consts, packed, rays, z, True, True, 3))
     w = nv.composite_rays(raw, z, rays, None, False, True)[3]
@@ -568,3 +570,72 @@ def test_config5_llff_ndc_real_size_render_and_sr_refinement_step(hip, oracle):
     with torch.no_grad():
         again = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]
     assert torch.isfinite(again).all() and not torch.equal(again, rgb_f)          # the refined network was used
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# decoder geometries other than the shipped one (csrc/generic.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _variant_model(hip, g, name, state_prefix=None):
+    from test_oracle import G18_VARIANTS, g18_variant
+    kw, sd_, planes = g18_variant(g, name)
+    if state_prefix is not None:
+        sd_ = {k[len(state_prefix):]: v for k, v in g.items() if k.startswith(state_prefix)}
+    m = hip.models.TwoDimPlanesModel(use_viewdirs=True, align_corners=True, **kw)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd_.items()}, strict=True)
+    m = m.to(DEV).eval()
+    sid = "lego_DS8_PlRes10_6"
+    m.planes_ = torch.nn.ParameterDict({hip.models.get_plane_name(sid, d): torch.nn.Parameter(T(planes[d])) for d in range(4)})
+    m.box_coords = {sid: torch.as_tensor(g["box"], dtype=torch.float64)}
+    m.set_cur_scene_id(sid)
+    return m, sid, kw, sd_, planes
+
+
+def test_generic_decoder_geometries_vs_reference_and_oracle(hip):
+    """TwoDimPlanesModel for geometries the MFMA kernels are not compiled for -- dec_channels 256 / 64 / 96, 24-channel planes,
+    proj_combination sum / concat, viewdir_proj_combination sum / mult / concat, skip layers, 5 + 3 layers (config/TrainModels.yml lists such
+    alternatives) -- through torch.ops.nvsr.triplane_decode_generic: the reference's own outputs (g18) within 2e-5 of the output range,
+    the numpy restatement on a large ragged point list that crosses the kernel's chunk boundary, a render through eval_nerf against the
+    reference's pixels; training on such a geometry and geometries the reference's own layer sizes do not admit are refused loudly."""
+    from conftest import load_golden
+    from oracle.generic_decoder import decode
+    from test_oracle import G18_VARIANTS
+    from test_hip_parity import make_options, psnr
+    g = load_golden("g18_decoder_variants.npz")
+    for name in G18_VARIANTS:
+        m, sid, kw, sd_, planes = _variant_model(hip, g, name)
+        assert not m.is_native_geometry()
+        with torch.no_grad():
+            out = N_(m(T(g[name + ".x"])))
+        ref = g[name + ".out"]
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=name)
+    # a point list that is not a multiple of anything and crosses the 2^20-point chunk of the layer stack
+    m, sid, kw, sd_, planes = _variant_model(hip, g, "avg_mult")
+    rng = np.random.default_rng(3)
+    P = (1 << 20) + 77
+    x = np.concatenate([rng.uniform(-4.3, 4.3, (P, 3)), rng.standard_normal((P, 3))], 1).astype(np.float32)
+    with torch.no_grad():
+        out = N_(m(T(x)))
+    sel = np.concatenate([np.arange(0, 5000), np.arange((1 << 20) - 2500, P)])
+    ref = decode(sd_, planes, g["box"], x[sel], **kw)
+    np.testing.assert_allclose(out[sel], ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    with torch.no_grad():
+        assert N_(m(T(x[:1]))).shape == (1, 4) and m(T(x[:0])).shape == (0, 4)
+    # render (8 x 8 rays, 16 + 16 samples) with a coarse / fine pair of the 'concat24' geometry
+    mc, sid, *_ = _variant_model(hip, g, "concat24", state_prefix="concat24.render.coarse.")
+    mf, *_ = _variant_model(hip, g, "concat24", state_prefix="concat24.render.fine.")
+    mf.planes_ = mc.planes_
+    H, W, focal = int(g["concat24.render.hwf"][0]), int(g["concat24.render.hwf"][1]), float(g["concat24.render.hwf"][2])
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    opts, scfg = make_options(16, 16)
+    rgb_c, _, _, rgb_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    np.testing.assert_allclose(N_(rgb_c), g["concat24.render.rgb_coarse"], rtol=0, atol=3e-5)
+    ef = np.abs(N_(rgb_f) - g["concat24.render.rgb_fine"]).max(-1)
+    assert (ef <= 2e-4).mean() >= 0.95 and psnr(N_(rgb_f), g["concat24.render.rgb_fine"]) >= 70.0, ((ef <= 2e-4).mean(), ef.max())
+    # loud refusals
+    mc.train()
+    for p_ in mc.parameters():
+        p_.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        mc(T(g["concat24.x"]))
+    bad = hip.capi.DecoderGeometry(48, 48, 128, 4, 4, 0, 0, 3)          # 'concat' view features on summed position features (models.py:186-190)
+    assert hip.capi.lib().nvsr_generic_decoder_natural_floats(C.byref(bad)) == -1

@@ -322,3 +322,35 @@ def test_composite_mip_golden(oracle):
         np.testing.assert_allclose(depth, g[tag + "_depth"], rtol=0, atol=1e-5)
         np.testing.assert_allclose(disp, g[tag + "_disp"], rtol=1e-5, atol=0, equal_nan=True)
         assert np.isnan(g[tag + "_disp"]).any() or tag == "b"
+
+
+G18_VARIANTS = {      # constructor kwargs of tests/golden/gen_golden.py::G18_VARIANTS (skip_connect_every defaults to 3 there)
+    "wide256": dict(dec_channels=256, proj_combination="avg", viewdir_proj_combination="concat_pos", num_plane_channels=48),
+    "sum_sum": dict(dec_channels=128, proj_combination="sum", viewdir_proj_combination=None, num_plane_channels=48),
+    "avg_mult": dict(dec_channels=64, proj_combination="avg", viewdir_proj_combination="mult", num_plane_channels=48),
+    "concat24": dict(dec_channels=128, proj_combination="concat", viewdir_proj_combination="concat", num_plane_channels=24),
+    "skip2": dict(dec_channels=128, proj_combination="avg", viewdir_proj_combination="concat_pos", num_plane_channels=48, skip_connect_every=2),
+    "deep5_c24": dict(dec_channels=96, proj_combination="sum", viewdir_proj_combination="concat_pos", num_plane_channels=24, dec_density_layers=5,
+                      dec_rgb_layers=3, skip_connect_every=2),
+}
+
+
+def g18_variant(g, name):
+    kw = dict(skip_connect_every=3)
+    kw.update(G18_VARIANTS[name])
+    sd = {k[len(name) + 4:]: v for k, v in g.items() if k.startswith(name + ".sd.")}
+    planes = [g["%s.plane%d" % (name, d)] for d in range(4)]
+    return kw, sd, planes
+
+
+def test_generic_decoder_restatement_vs_reference():
+    """oracle/generic_decoder.py (numpy, float64: TwoDimPlanesModel.forward for any geometry) against the reference's outputs for six
+    decoder geometries (g18): widths, 24-channel planes, sum / concat / mult combinations, skip layers, unequal layer counts"""
+    from oracle.generic_decoder import decode
+    g = load_golden("g18_decoder_variants.npz")
+    for name in G18_VARIANTS:
+        kw, sd, planes = g18_variant(g, name)
+        out = decode(sd, planes, g["box"], g[name + ".x"], **kw)
+        ref = g[name + ".out"]
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, rtol=0, atol=5e-6 * max(1.0, float(np.abs(ref).max())), err_msg=name)
