@@ -128,6 +128,8 @@ int nvsr_coarse_z(int64_t N, int Nc, const float* rays, int lindisp, const float
  * -> samples [N,ns].  nb <= 256. */
 int nvsr_sample_pdf(int64_t N, int nb, int ns, const float* bins, const float* weights, const float* u, float* samples,
                     nvsr_stream_t stream);
+/* cumprod_exclusive (nerf_helpers.py:409-430): [N,n] rows -> out[:,0] = 1, out[:,i] = in[:,0] * ... * in[:,i-1]; in and out must not alias */
+int nvsr_cumprod_exclusive(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream);
 /* torch.sort(x, dim=-1) values of [N,n] rows, n <= 512 (train_utils.py:155); in and out may alias */
 int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream);
 /* fused train_utils.py:144-155: z_mid, sample_pdf(z_mid, w[1:-1], Nf, det = (u == NULL)), sort(cat(z, samples)) -> [N,Nc+Nf] */

@@ -249,6 +249,22 @@ __device__ __forceinline__ void merge_sort_wave(const float* all /*LDS[na+nb]*/,
     }
 }
 
+// cumprod_exclusive (nerf_helpers.py:409-430): out[.., 0] = 1, out[.., i] = prod_{k < i} in[.., k], multiplied left to right like torch.cumprod's
+// sequential CPU scan (the fused passes carry this product in a register; this is the stand-alone helper of the reference's surface)
+__global__ void cumprod_exclusive_kernel(long N, int n, const float* __restrict__ in, float* __restrict__ out) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const float* a = in + row * n;
+    float* o = out + row * n;
+    float p = 1.0f, run = 1.0f;
+    for (int i = 0; i < n; ++i) {
+        const float v = a[i];
+        o[i] = (i == 0) ? 1.0f : p;
+        run = (i == 0) ? v : __fmul_rn(run, v);     // inclusive cumprod up to i
+        p = run;
+    }
+}
+
 __global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, const float* __restrict__ in, float* __restrict__ out) {
     __shared__ float vals[WPB][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -430,6 +446,14 @@ int nvsr_sample_pdf(int64_t N, int nb, int ns, const float* bins, const float* w
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, nb, ns, bins,
                        weights, u, samples);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_cumprod_exclusive(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream) {
+    if (!in || !out) return NVSR_ERR_NULL;
+    if (N < 0 || n < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(cumprod_exclusive_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)N, n, in, out);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -79,11 +79,13 @@ def positional_encoding(tensor, num_encoding_functions=6, include_input=True) ->
 
 
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
-    """nerf_helpers.py:409-430 (plumbing for callers outside the fused path; the kernels carry the running product in a register)"""
-    cumprod = torch.cumprod(tensor, -1)
-    cumprod = torch.roll(cumprod, 1, -1)
-    cumprod[..., 0] = 1.0
-    return cumprod
+    """nerf_helpers.py:409-430: exclusive cumulative product along the last dim (for callers outside the fused path; the render kernels carry
+    the running product in a register)"""
+    t = capi.f32c(tensor)
+    out = torch.empty_like(t)
+    if t.numel():
+        capi.call("nvsr_cumprod_exclusive", t.numel() // t.shape[-1], t.shape[-1], capi.ptr(t), capi.ptr(out), capi.stream())
+    return out
 
 
 def get_minibatches(inputs: torch.Tensor, chunksize: Optional[int] = 1024 * 8):

@@ -639,3 +639,16 @@ def test_generic_decoder_geometries_vs_reference_and_oracle(hip):
         mc(T(g["concat24.x"]))
     bad = hip.capi.DecoderGeometry(48, 48, 128, 4, 4, 0, 0, 3)          # 'concat' view features on summed position features (models.py:186-190)
     assert hip.capi.lib().nvsr_generic_decoder_natural_floats(C.byref(bad)) == -1
+
+
+def test_cumprod_exclusive_kernel(hip, oracle):
+    """nerf_helpers.cumprod_exclusive (nerf_helpers.py:409-430) runs a HIP kernel too (round 1 used torch.cumprod): the reference's golden
+    values (g05) and the oracle's left-to-right products, bit for bit"""
+    from conftest import load_golden
+    g = load_golden("g05_composite.npz")
+    got = N_(hip.nerf_helpers.cumprod_exclusive(T(g["cumprod_in"])))
+    np.testing.assert_allclose(got, g["cumprod_out"], rtol=1e-6, atol=1e-7)
+    rng = np.random.default_rng(9)
+    a = rng.uniform(0.2, 1.3, (1001, 193)).astype(np.float32)
+    np.testing.assert_array_equal(N_(hip.nerf_helpers.cumprod_exclusive(T(a))), oracle.cumprod_exclusive(a))
+    assert hip.nerf_helpers.cumprod_exclusive(T(a[:, :1])).eq(1.0).all() and hip.nerf_helpers.cumprod_exclusive(T(a[:0])).shape == (0, 193)
