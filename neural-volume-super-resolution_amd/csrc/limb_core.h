@@ -148,7 +148,11 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
                     acc[ob] = mfma_bf16(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], acc[ob]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if defined(R3_ABLATE) && (R3_ABLATE & 128)       // timing experiment (render3.hip): no A-fragment reads after the block's first
+                if (p < LIMBS) { fn.v[p] = fa.v[p]; fn.v[p][0] ^= (unsigned)(q + 1); }     // (distinct per output block: no CSE of the MFMAs)
+#else
                 if (p < LIMBS) fn.v[p] = wv[(((q + 1) % NQ) * LIMBS + p) * 64];
+#endif
                 if (kb + 1 < NKB) split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
                 else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);
                 side(q * NP + p);

@@ -12,6 +12,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef R3_ABLATE
+#define R3_ABLATE 0   // timing experiments (wrong results): 1 no gather loads, 2 / 4 see gather_roll, 32 no weight copies, 64 no ring barriers, 128 no A-fragment reads
+#endif
 #include "limb_core.h"
 #include "side_work.h"
 
@@ -68,9 +71,6 @@ struct Tile3 {
 // first slots of a block and blended in its last quarter
 struct RawTaps4 { f32x4 r[4][HALF_C / 4]; };
 constexpr int GATHER_STEPS = 12 + HALF_C;
-#ifndef R3_ABLATE
-#define R3_ABLATE 0   // timing experiments: 1 no gather loads
-#endif
 __device__ __forceinline__ void gather4_load(int k, const GatherJob& job, int h, RawTaps4& rt) {           // k 0..11: tap k/3, 2 loads
     const int tap = k / 3, i0 = 2 * (k % 3);
 #if R3_ABLATE & 1
@@ -126,12 +126,15 @@ __device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float
 // ring wait with N younger vector-memory operations allowed in flight (vmcnt counts in issue order: the chunk issued before them has landed)
 template <int N>
 __device__ __forceinline__ void ring3_sync() {
-#if R3_ABLATE & 9
+#if R3_ABLATE & 256       // timing experiment: the ring waits do not wait for the copies
+#elif R3_ABLATE & 9
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
+#if !(R3_ABLATE & 64)      // timing experiment: no workgroup barrier at the ring waits
     __syncthreads();
+#endif
 }
 
 // act = max(acc + bias, 0): 64 elements in 68 steps (a bias quad is read 4 steps before its first use)
@@ -181,10 +184,18 @@ __device__ __forceinline__ unsigned* ring3_take(Ring3<LIMBS>& rs) {
 template <int LIMBS, int NKB>
 __device__ __forceinline__ void dma_side(int slot, const Ring3<LIMBS>& rs, unsigned* dst, int kb0) {
     constexpr int PIECES = NKB * LIMBS;                     // per wave
+#if R3_ABLATE & 32         // timing experiment: no weight copies (stale LDS contents)
+    return;
+#endif
     if (slot % 3 == 2 && slot / 3 < PIECES) {
         const int i = slot / 3;
+#if R3_ABLATE & 512        // timing experiment: the same number of copy instructions, a quarter of the bytes (dword instead of dwordx4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 4,
+                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+#else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
                                                  (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+#endif
     }
 }
 // the last piece of a chunk is issued in slot 3 * PIECES - 1 <= 35 of a block that also issues a gather: at least 12 of that gather's loads
@@ -400,7 +411,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
         R3_MARKH(3)                                                                                                                 \
         cw = nw;                                                                                                                    \
-        ring2_sync();                                                                                                               \
+        ring3_sync<0>();                                                                                                               \
         nw = ring3_take(rs);                                                                                                        \
         R3_MARKH(4)                                                                                                                 \
         limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4),                                                  \
@@ -410,7 +421,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         R3_MARKH(6)                                                                                                                 \
         cw = nw;
 
-#define NVSR_HIDDEN_LAYER(VPREV, ...) NVSR_HIDDEN_LAYER_(ring2_sync(), relu_side(Y, VPREV), VPREV, __VA_ARGS__)
+#define NVSR_HIDDEN_LAYER(VPREV, ...) NVSR_HIDDEN_LAYER_(ring3_sync<0>(), relu_side(Y, VPREV), VPREV, __VA_ARGS__)
         // rgb layers 1, 2: Y b | X relu, tail X kb 0
 #define NVSR_YB_PLAIN(VTHIS) (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4), relu_side(X, VTHIS), tail_of(X.act, 0)))
         NVSR_HIDDEN_LAYER(4, 5, KB_RGB1 + 4, 4, KB_RGB1 + 8, 4, NVSR_YB_PLAIN(5))
@@ -421,7 +432,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
 
         R3_MARK(3)      // rgb layers 1..3
         // ---- density layer 0 (from D) -------------------------------------------------------------------------------------------
-        ring2_sync();
+        ring3_sync<0>();
         nw = ring3_take(rs);
         // X density 0 | Y: act of rgb layer 3; X: rgb heads
         float hx[3] = {0.0f, 0.0f, 0.0f};
