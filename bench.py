@@ -192,7 +192,9 @@ def hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws, reps=5):
     stages = {
         "get_ray_bundle (ray_bundle_kernel)": (24 * N, lambda: nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)),
         "pack_rays (pack_rays_kernel)": ((24 + 44) * N, lambda: nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)),
-        "coarse depths (coarse_z_kernel)": ((8 + 4 * 64) * N, lambda: capi.call("nvsr_coarse_z", N, 64, capi.ptr(rays), 0, None, capi.ptr(z_c), capi.stream())),
+        # (not part of this frame any more: without stratified jitter the limb passes compute the coarse depths in registers; the kernel remains
+        #  for training batches and the exact-f32 arithmetic)
+        "coarse depths (coarse_z_kernel; NOT launched by an inference frame)": ((8 + 4 * 64) * N, lambda: capi.call("nvsr_coarse_z", N, 64, capi.ptr(rays), 0, None, capi.ptr(z_c), capi.stream())),
         "sample_pdf + sort (importance_resample_kernel)": (4 * (64 + 64 + 192) * N, lambda: capi.call(
             "nvsr_importance_resample", N, 64, 128, capi.ptr(z_c), capi.ptr(w_c), None, capi.ptr(z_f), capi.stream())),
     }

@@ -136,6 +136,11 @@ int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t 
 int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, const float* weights, const float* u,
                              float* z_fine, nvsr_stream_t stream);
 
+/* the same with the un-jittered coarse depths of train_utils.py:95-100 recomputed from the rays' near / far (packed rays columns 6, 7)
+ * instead of read: z_coarse of nvsr_coarse_z(..., t_rand = NULL) never has to exist (nvsr_render_rays does this for inference frames) */
+int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, int lindisp, const float* weights, const float* u,
+                                  float* z_fine, nvsr_stream_t stream);
+
 /* ---- tri-plane decoder -------------------------------------------------------------------------------------------- */
 /* TwoDimPlanesModel.forward (models.py:381-421): x [P,6] = [xyz, viewdir] -> out [P,4] = [rgb_raw, sigma_raw] */
 int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out,

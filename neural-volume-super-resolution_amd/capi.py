@@ -59,6 +59,7 @@ _PROTOS = {
     "nvsr_sort_rows": ([_i64, _i, _vp, _vp, _vp], _i),
     "nvsr_cumprod_exclusive": ([_i64, _i, _vp, _vp, _vp], _i),
     "nvsr_importance_resample": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_importance_resample_rays": ([_i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
     "nvsr_composite": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_rays": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),

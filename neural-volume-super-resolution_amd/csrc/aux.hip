@@ -4,6 +4,7 @@
 // Reference functions replaced (upstream paths): get_ray_bundle nerf_helpers.py:507-549, ndc_rays :578-605,
 // sample_pdf_2 :668-702, cumprod_exclusive :409-430, predict_and_render_radiance train_utils.py:95-109,144-155,
 // run_one_iter_of_nerf train_utils.py:213-226, volume_render_radiance_field volume_rendering_utils.py:6-51.
+#include <cstdlib>
 #include "nvsr_common.h"
 
 namespace nvsr {
@@ -128,11 +129,6 @@ __global__ void pack_rays_kernel(long N, const float* __restrict__ ro, const flo
     r[8] = __fdiv_rn(v0, nrm); r[9] = __fdiv_rn(v1, nrm); r[10] = __fdiv_rn(v2, nrm);
 }
 
-__device__ __forceinline__ float coarse_depth(float nr, float fr, int s, int Nc, int lindisp) {
-    const float t = linspace01(s, Nc);
-    if (!lindisp) return __fadd_rn(__fmul_rn(nr, __fsub_rn(1.0f, t)), __fmul_rn(fr, t));
-    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, nr), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, fr), t)));
-}
 
 __global__ void coarse_z_kernel(long N, int Nc, const float* __restrict__ rays, int lindisp, const float* __restrict__ t_rand,
                                 float* __restrict__ z) {
@@ -277,7 +273,10 @@ __global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, cons
 }
 
 // train_utils.py:144-155 fused: z_mid -> sample_pdf(z_mid, w[1:-1]) -> sort(cat(z, samples))
+// zc == NULL: the coarse depths are the un-jittered ones of train_utils.py:95-100 and are recomputed from the ray's near / far (packed rays
+// columns 6, 7) -- bit for bit what nvsr_coarse_z writes -- so that an inference frame never stores them
 __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, int Nc, int Nf, const float* __restrict__ zc,
+                                                                      const float* __restrict__ rays, int lindisp,
                                                                       const float* __restrict__ weights,
                                                                       const float* __restrict__ u, float* __restrict__ zf) {
     __shared__ float cdf_s[WPB][256];
@@ -286,11 +285,16 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * WPB + wave;
     if (ray >= N) return;
-    const float* z = zc + ray * Nc;
     const float* w = weights + ray * Nc;
     float* all = all_s[wave];
     float* zm = zmid_s[wave];
-    for (int i = lane; i < Nc; i += 64) all[i] = z[i];
+    if (zc) {
+        const float* z = zc + ray * Nc;
+        for (int i = lane; i < Nc; i += 64) all[i] = z[i];
+    } else {
+        const float nr = rays[ray * 11 + 6], fr = rays[ray * 11 + 7];
+        for (int i = lane; i < Nc; i += 64) all[i] = coarse_depth(nr, fr, i, Nc, lindisp);
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int i = lane; i < Nc - 1; i += 64) zm[i] = __fmul_rn(0.5f, __fadd_rn(all[i + 1], all[i]));
@@ -471,7 +475,17 @@ int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, c
     if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
-                       z_coarse, weights, u, z_fine);
+                       z_coarse, (const float*)nullptr, 0, weights, u, z_fine);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, int lindisp, const float* weights, const float* u,
+                                  float* z_fine, nvsr_stream_t stream) {
+    if (!rays || !weights || !z_fine) return NVSR_ERR_NULL;
+    if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
+                       (const float*)nullptr, rays, lindisp, weights, u, z_fine);
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -516,6 +530,11 @@ int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf) {
     return base + (N < NVSR_FUSED_MIN_RAYS ? 4 * N * (int64_t)(Nc + (Nf > 0 ? Nf : 0)) : 0);   // + raw [N,S,4] for the un-fused path
 }
 
+extern "C" int nvsr_internal_resolve_decoder_arith(int arithmetic);      // render.hip
+extern "C" int nvsr_render_pass3_coarse_z_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                                 int lindisp, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
+                                                 float* weights, float* depth, nvsr_stream_t stream);
+
 static int render_one_pass(const nvsr_scene* scene, const float* packed, int64_t N, int S, const float* rays, const float* z,
                            const float* noise, int white, float* rgb, float* disp, float* acc, float* weights, float* raw_ws,
                            int arithmetic, nvsr_stream_t stream) {
@@ -549,7 +568,27 @@ int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, 
     float* w_c = z_c + round4(N * (int64_t)Nc);
     float* z_f = w_c + round4(N * (int64_t)Nc);
     float* raw_ws = z_f + (Nf > 0 ? round4(N * (int64_t)(Nc + Nf)) : 0);
-    int e = nvsr_coarse_z(N, Nc, rays, lindisp, t_rand, z_c, stream);
+    int e;
+    // Inference frames (no stratified jitter) on the fused limb passes: the coarse depths are a function of (near, far, s) -- the coarse
+    // pass and the resampler compute them in registers, the [N,Nc] depth tensor (164 MB at 800 x 800 x 64) is never written or read
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    const bool in_kernel_z = !t_rand && Nf > 0 && N >= NVSR_FUSED_MIN_RAYS && arith > 0 && !getenv("NVSR_RENDER_V1") && !getenv("NVSR_STORE_COARSE_Z");
+    if (in_kernel_z) {
+        if (!scene || !packed_coarse || !rays || !rgb_c || !disp_c || !acc_c) return NVSR_ERR_NULL;
+        for (int d = 0; d < 4; ++d) {
+            if (!scene->planes[d]) return NVSR_ERR_NULL;
+            if (!aligned16(scene->planes[d])) return NVSR_ERR_ALIGN;
+            if (scene->ph[d] < 1 || scene->pw[d] < 1 || (int64_t)scene->ph[d] * scene->pw[d] * NVSR_PLANE_CHANNELS >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
+        }
+        if (!aligned16(packed_coarse)) return NVSR_ERR_ALIGN;
+        e = nvsr_render_pass3_coarse_z_launch(arith, scene, packed_coarse, N, Nc, rays, lindisp, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, w_c,
+                                              nullptr, stream);
+        if (e) return e;
+        e = nvsr_importance_resample_rays(N, Nc, Nf, rays, lindisp, w_c, u, z_f, stream);
+        if (e) return e;
+        return render_one_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, raw_ws, arithmetic, stream);
+    }
+    e = nvsr_coarse_z(N, Nc, rays, lindisp, t_rand, z_c, stream);
     if (e) return e;
     e = render_one_pass(scene, packed_coarse, N, Nc, rays, z_c, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, Nf > 0 ? w_c : nullptr,
                         raw_ws, arithmetic, stream);

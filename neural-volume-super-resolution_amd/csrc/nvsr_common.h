@@ -121,4 +121,11 @@ __host__ __device__ inline float linspace01(int i, int n) {
     return (i < n / 2) ? (step * (float)i) : (1.0f - step * (float)(n - 1 - i));
 }
 
+// un-jittered coarse depth s of Nc between near and far (predict_and_render_radiance, train_utils.py:95-100)
+__device__ __forceinline__ float coarse_depth(float nr, float fr, int s, int Nc, int lindisp) {
+    const float t = linspace01(s, Nc);
+    if (!lindisp) return __fadd_rn(__fmul_rn(nr, __fsub_rn(1.0f, t)), __fmul_rn(fr, t));
+    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, nr), __fsub_rn(1.0f, t)), __fmul_rn(__fdiv_rn(1.0f, fr), t)));
+}
+
 }  // namespace nvsr

@@ -48,7 +48,7 @@
 #endif
 namespace nvsr {
 
-constexpr int RAY3_FLOATS = 16;
+constexpr int RAY3_FLOATS = 20;      // ro, rd, |rd|, near | view-plane taps | far (+ 3 spare): the per-ray constants of a tile
 template <int LIMBS>
 struct Lds3 {
     static constexpr int SLOT = 4 * kb_words(LIMBS);                 // words: 48 KB (3 limbs) / 32 KB
@@ -205,13 +205,18 @@ constexpr int YOUNGER_THAN_CHUNK = 32;
 // =====================================================================================================================
 // The body of both kernels below (one instantiation per LIMBS; the kernels are thin shells so that the coarse and the fine pass are two
 // symbols in a rocprofv3 kernel trace -- a second template parameter on one kernel trips hipcc's host pass over the LDS-DMA builtins).
-template <int LIMBS>
+// ZCOMP: the depths are the un-jittered coarse ones (train_utils.py:95-100) and are computed from the ray's near / far in registers
+// (coarse_depth, bit for bit what nvsr_coarse_z writes) instead of being read: `z` is NULL and `lindisp` selects the spacing
+// (ONE template parameter, LZ = LIMBS + 8 * ZCOMP: with a second one hipcc's host pass fails to resolve the LDS-DMA helpers inside the body)
+template <int LZ>
 __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const float* __restrict__ packed, long N, int S,
-                                                  const float* __restrict__ rays, const float* __restrict__ z,
+                                                  const float* __restrict__ rays, const float* __restrict__ z, int lindisp,
                                                   const float* __restrict__ noise, int white,
                                                   float* __restrict__ rgb, float* __restrict__ disp,
                                                   float* __restrict__ acc, float* __restrict__ weights,
                                                   float* __restrict__ depth, float* __restrict__ raw_out) {
+    constexpr int LIMBS = LZ & 7;
+    constexpr bool ZCOMP = (LZ & 8) != 0;
     using L = Lds3<LIMBS>;
     constexpr int NP = limb_products(LIMBS);
     constexpr int NSF = 3 * 4 * NP, NSH = 4 * 4 * NP;          // slots of a feature block / of half a hidden layer
@@ -243,19 +248,25 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
         if (lane0 < 32) {
             reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], dx};
-            reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, 0.0f};
+            reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, r[6]};
+            rc[16] = r[7];
             reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
             reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
         }
     }
-    const float* zX = z + rayX * S;
-    const float* zY = z + rayY * S;
+    const float* zX = ZCOMP ? nullptr : z + rayX * S;
+    const float* zY = ZCOMP ? nullptr : z + rayY * S;
+    auto depth_of = [&](const float* zp, const float* rc, int k) {
+        if constexpr (ZCOMP) return coarse_depth(rc[7], rc[16], k, S, lindisp);
+        else return zp[k];
+    };
 
     Tile3 X, Y;
     X.T = Y.T = 1.0f;
     X.cr = X.cg = X.cb = X.dep = X.ac = 0.0f;
     Y.cr = Y.cg = Y.cb = Y.dep = Y.ac = 0.0f;
-    X.zc = zX[0]; Y.zc = zY[0];
+    if constexpr (ZCOMP) __syncthreads();   // (the ray cache is written by lanes 0..31 and read by all 64, see below)
+    X.zc = depth_of(zX, rcX, 0); Y.zc = depth_of(zY, rcY, 0);
     RawTaps4 rt;
 
     auto point_norm = [&](const float* rc, float zc, float& n0, float& n1, float& n2) {
@@ -296,8 +307,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
         const bool last = (s + 1 == S);
-        X.zn = zX[last ? s : s + 1];                           // (unconditional loads: ring3_sync<2> below counts them)
-        Y.zn = zY[last ? s : s + 1];
+        X.zn = depth_of(zX, rcX, last ? s : s + 1);            // (unconditional loads unless ZCOMP: ring3_sync<2> below counts them)
+        Y.zn = depth_of(zY, rcY, last ? s : s + 1);
         const float nzX = noise ? noise[rayX * S + s] : 0.0f;
         const float nzY = noise ? noise[rayY * S + s] : 0.0f;
         float xn0, xn1, xn2, yn0, yn1, yn2;
@@ -322,7 +333,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // multiplies plane p - 1 of a tile loads plane p of the same tile, the next block blends it.
         GatherJob ja, jb;
         R3_MARK(0)      // loop top
-        ring3_sync<2>();                                         // chunk 0 (issued during the previous sample) -- younger: the two z loads above
+        ring3_sync<ZCOMP ? 0 : 2>();                             // chunk 0 (issued during the previous sample) -- younger: the two z loads above
         unsigned* nw = ring3_take(rs);
         R3_MARK(1)      // first ring wait
         R3_RESET
@@ -534,7 +545,19 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_coarse_kernel(SceneDev s
                                                                      float* __restrict__ rgb, float* __restrict__ disp,
                                                                      float* __restrict__ acc, float* __restrict__ weights,
                                                                      float* __restrict__ depth, float* __restrict__ raw_out) {
-    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, noise, white, rgb, disp, acc, weights, depth, raw_out);
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, weights, depth, raw_out);
+}
+// coarse pass of an inference frame: un-jittered depths computed in registers (no [N,S] depth tensor is written or read)
+template <int LIMBS>
+__global__ __launch_bounds__(TPB2, 1) void render_pass3_coarse_z_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+                                                                       const float* __restrict__ rays, int lindisp,
+                                                                       const float* __restrict__ noise, int white,
+                                                                       float* __restrict__ rgb, float* __restrict__ disp,
+                                                                       float* __restrict__ acc, float* __restrict__ weights,
+                                                                       float* __restrict__ depth, float* __restrict__ raw_out) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (hipcc's host pass cannot resolve the LDS-DMA helpers inside this instantiation; it only needs the stub)
+    render_pass3_body<LIMBS + 8>(sc, packed, N, S, rays, nullptr, lindisp, noise, white, rgb, disp, acc, weights, depth, raw_out);
+#endif
 }
 // fine pass (or any pass whose weights are not wanted)
 template <int LIMBS>
@@ -544,7 +567,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
                                                               float* __restrict__ rgb, float* __restrict__ disp,
                                                               float* __restrict__ acc, float* __restrict__ depth,
                                                               float* __restrict__ raw_out) {
-    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, noise, white, rgb, disp, acc, nullptr, depth, raw_out);
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, nullptr, depth, raw_out);
 }
 
 // ---- natural blob -> bf16 limb fragments (the tail of the packed blob) -----------------------------------------------------------
@@ -613,5 +636,20 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
                            packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, depth, raw_out)
     if (limbs == 3) { NVSR_LAUNCH3(3); } else { NVSR_LAUNCH3(2); }
 #undef NVSR_LAUNCH3
+    return NVSR_CHECK_LAUNCH();
+}
+
+// the coarse pass with its depths computed in the kernel (z = coarse_depth(near, far, s, S, lindisp)); weights are always written
+extern "C" int nvsr_render_pass3_coarse_z_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+                                                 int lindisp, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
+                                                 float* weights, float* depth, nvsr_stream_t stream) {
+    const int64_t grid = (N + RAYS2 - 1) / RAYS2;
+    if (grid > 0x7fffffff || (limbs != 2 && limbs != 3) || !weights) return NVSR_ERR_SHAPE;
+    if (limbs == 3)
+        hipLaunchKernelGGL(render_pass3_coarse_z_kernel<3>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(render_pass3_coarse_z_kernel<2>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr);
     return NVSR_CHECK_LAUNCH();
 }

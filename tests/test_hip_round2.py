@@ -652,3 +652,40 @@ def test_cumprod_exclusive_kernel(hip, oracle):
     a = rng.uniform(0.2, 1.3, (1001, 193)).astype(np.float32)
     np.testing.assert_array_equal(N_(hip.nerf_helpers.cumprod_exclusive(T(a))), oracle.cumprod_exclusive(a))
     assert hip.nerf_helpers.cumprod_exclusive(T(a[:, :1])).eq(1.0).all() and hip.nerf_helpers.cumprod_exclusive(T(a[:0])).shape == (0, 193)
+
+
+def test_inference_frame_computes_coarse_depths_in_kernel(hip):
+    """An inference frame (no stratified jitter) on the fused passes never stores its coarse depths: the coarse pass
+    (render_pass3_coarse_z_kernel) and the resampler (nvsr_importance_resample_rays) recompute z = near (1 - t) + far t (or the lindisp
+    form, train_utils.py:95-100) from the ray in registers.  The frame must equal, bit for bit, the explicit sequence coarse_z ->
+    render pass -> importance_resample -> render pass on stored depths, for both spacings; NVSR_STORE_COARSE_Z=1 selects the stored form."""
+    import os
+    from bench import make_synthetic_scene, render_options
+    nv = torch.ops.nvsr
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=96, view_res=16, seed=13)
+    H = W = 272                                       # 73 984 rays >= NVSR_FUSED_MIN_RAYS
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    planes, consts = mc.scene_args()
+    bits = lambda t: t.contiguous().view(torch.int32)
+    for lindisp in (False, True):
+        opts, scfg = render_options(64, 128)
+        opts.nerf.validation.lindisp = lindisp
+        got = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+        z_c = nv.coarse_z(rays, 64, lindisp, None)
+        rgb_c, disp_c, acc_c, w_c = nv.render_pass(planes, consts, mc.packed_decoder(), rays, z_c, None, False, True, 3)
+        z_f = nv.importance_resample(z_c, w_c, 128, None)
+        rgb_f, *_ = nv.render_pass(planes, consts, mf.packed_decoder(), rays, z_f, None, False, False, 3)
+        assert torch.equal(bits(got[0].reshape(-1, 3)), bits(rgb_c)) and torch.equal(bits(got[3].reshape(-1, 3)), bits(rgb_f)), lindisp
+        # the resampler alone: depths recomputed from the rays == depths read
+        z_f2 = torch.empty_like(z_f)
+        hip.capi.call("nvsr_importance_resample_rays", rays.shape[0], 64, 128, hip.capi.ptr(rays), int(lindisp), hip.capi.ptr(w_c), None,
+                      hip.capi.ptr(z_f2), hip.capi.stream())
+        assert torch.equal(z_f, z_f2)
+    os.environ["NVSR_STORE_COARSE_Z"] = "1"
+    try:
+        stored = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    finally:
+        del os.environ["NVSR_STORE_COARSE_Z"]
+    assert torch.equal(bits(stored[3]), bits(got[3]))
