@@ -12,6 +12,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef R3_DMA_AUX
+#define R3_DMA_AUX 0      // cache-policy bits of the weight copies (experiment: 2 = nt, 1 = sc0, 16 = sc1)
+#endif
 #ifndef R3_ABLATE
 #define R3_ABLATE 0   // timing experiments (wrong results): 1 no gather loads, 2 / 4 see gather_roll, 32 no weight copies, 64 no ring barriers, 128 no A-fragment reads
 #endif
@@ -167,7 +170,7 @@ __device__ __forceinline__ const unsigned* ring3_issue(Ring3<LIMBS>& rs, int kb0
 #pragma unroll
     for (int i = 0; i < BLOCKS / NW2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
-                                             (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+                                             (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, R3_DMA_AUX);
     rs.slot ^= 1;
     return dst;
 }
@@ -191,10 +194,10 @@ __device__ __forceinline__ void dma_side(int slot, const Ring3<LIMBS>& rs, unsig
         const int i = slot / 3;
 #if R3_ABLATE & 512        // timing experiment: the same number of copy instructions, a quarter of the bytes (dword instead of dwordx4)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 4,
-                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, R3_DMA_AUX);
 #else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
-                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, 0);
+                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, R3_DMA_AUX);
 #endif
     }
 }
