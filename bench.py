@@ -658,6 +658,12 @@ def main():
         if rec is not None and H == 800 and args.plane_res == 800 and rec.get("decoder_arithmetic", "f32") == mode:
             traffic = rec.get("traffic_bytes")
         peak = arith["pipe_peak"] / arith["products"]
+        # matrix-pipe busy fraction / clock of this launch as the counters saw them (same guard as `traffic`)
+        mfma_pmc = rec.get("mfma") if (rec is not None and traffic is not None) else None
+        result["roofline_counters"] = None if mfma_pmc is None else {
+            "mfma_busy_frac": mfma_pmc["mfma_busy_frac"], "clock_ghz": mfma_pmc["clock_ghz"], "SQ_VALU_MFMA_BUSY_CYCLES": mfma_pmc["SQ_VALU_MFMA_BUSY_CYCLES"],
+            "GRBM_GUI_ACTIVE": mfma_pmc["GRBM_GUI_ACTIVE"], "note": "busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the dense peak "
+            "assumes 2.4 GHz: frac ~= busy x clock / 2.4"}
         result["roofline"] = {"kernel": "%s (fine pass, S=192)" % arith["kernel"], "bound": "mfma", "achieved": achieved,
                               "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                               "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,

@@ -689,3 +689,43 @@ def test_inference_frame_computes_coarse_depths_in_kernel(hip):
     finally:
         del os.environ["NVSR_STORE_COARSE_Z"]
     assert torch.equal(bits(stored[3]), bits(got[3]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# property tests ("property tests with hypothesis for sample_pdf monotonicity / range and compositing weight sum <= 1")
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_properties_of_sampling_and_compositing(hip):
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.integers(1, 300), st.integers(3, 96), st.integers(1, 160), st.integers(0, 2 ** 31 - 1), st.booleans())
+    def sample_pdf_props(N, nb, ns, seed, det):
+        """sample_pdf_2 (nerf_helpers.py:668-702): every sample lies inside [bins[0], bins[-1]]; with sorted u (det) the samples are
+        non-decreasing; a row of zero weights still gives finite samples"""
+        g = torch.Generator().manual_seed(seed)
+        bins = torch.sort(torch.rand(N, nb, generator=g) * 4 + 2, -1)[0].to(DEV)
+        w = torch.rand(N, nb - 1, generator=g).pow(4).to(DEV)
+        w[0] = 0.0
+        u = None if det else torch.rand(N, ns, generator=g).to(DEV)
+        out = hip.nerf_helpers.sample_pdf_2(bins, w, ns, det=det, u=u)
+        assert out.shape == (N, ns) and torch.isfinite(out).all()
+        assert (out >= bins[:, :1] - 1e-6).all() and (out <= bins[:, -1:] + 1e-6).all()
+        if det:
+            assert (out[:, 1:] >= out[:, :-1] - 1e-6).all()
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.integers(1, 200), st.integers(1, 300), st.integers(0, 2 ** 31 - 1), st.booleans())
+    def composite_props(N, S, seed, white):
+        """volume_render_radiance_field (volume_rendering_utils.py:6-51): weights >= 0, acc = sum(weights) <= 1 (+ rounding), rgb inside
+        [0, 1] without a background and <= 1 + rounding with one"""
+        g = torch.Generator().manual_seed(seed)
+        raw = (torch.randn(N, S, 4, generator=g) * 3).to(DEV)
+        z = torch.sort(torch.rand(N, S, generator=g) * 4 + 2, -1)[0].to(DEV)
+        rd = torch.randn(N, 3, generator=g).to(DEV)
+        rgb, disp, acc, w, depth = hip.volume_rendering_utils.volume_render_radiance_field(raw, z, rd, white_background=white)
+        assert (w >= 0).all() and torch.allclose(acc, w.sum(-1), atol=1e-5)
+        assert (acc <= 1 + 1e-4).all() and (rgb >= -1e-6).all() and (rgb <= 1 + 1e-4).all()
+        assert (depth >= -1e-6).all() and (depth <= 6 * (1 + 1e-4)).all()
+
+    sample_pdf_props()
+    composite_props()

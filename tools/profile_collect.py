@@ -70,6 +70,24 @@ if pm:
                    "fetch_size_kb": pm["FETCH_SIZE"][0], "write_size_kb": pm["WRITE_SIZE"][0],
                    "kernel_ms_under_pmc": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]], "traffic_bytes": traffic})
     print("render: traffic per fine launch %.1f GB" % (traffic / 1e9))
+# matrix-pipe busy fraction and clock of the same launch: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock =
+# GRBM_GUI_ACTIVE / 8 / kernel time (MI355X_MICROARCH.md)
+mf = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
+    rows = [r for r in csv.DictReader(open(f)) if "render_pass" in r["Kernel_Name"] and "backward" not in r["Kernel_Name"]]
+    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"):
+        rc = [r for r in rows if r["Counter_Name"] == c]
+        if rc:
+            r = max(rc, key=dur_ms)
+            mf[c] = (float(r["Counter_Value"]), dur_ms(r))
+if len(mf) == 3 and "traffic_bytes" in latest:
+    cyc = mf["GRBM_GUI_ACTIVE"][0] / 8.0
+    latest["mfma"] = {"SQ_VALU_MFMA_BUSY_CYCLES": mf["SQ_VALU_MFMA_BUSY_CYCLES"][0], "GRBM_GUI_ACTIVE": mf["GRBM_GUI_ACTIVE"][0],
+                      "SQ_INSTS_MFMA": mf["SQ_INSTS_MFMA"][0], "kernel_ms_under_pmc": mf["GRBM_GUI_ACTIVE"][1],
+                      "mfma_busy_frac": mf["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (1024.0 * cyc), "clock_ghz": cyc / (mf["GRBM_GUI_ACTIVE"][1] * 1e6),
+                      "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --kernel-trace -- python3 bench.py --steps 1 --warmup 0 "
+                                 "--no-cpu-baseline --no-modes"}
+    print("render: matrix pipe %.1f %% busy at %.2f GHz" % (100 * latest["mfma"]["mfma_busy_frac"], latest["mfma"]["clock_ghz"]))
 # train: the longest gate-driven backward launch = the fine pass (S = 128); sr: every convolution of one step
 for w, prefix, pick, what in (("train", "pmc_train_", longest(lambda k: "backward_gates" in k), "longest render_pass_backward_gates launch (fine pass)"),
                               ("train_dec", "pmc_train_dec_", longest(lambda k: "backward_gates" in k), "longest render_pass_backward_gates launch (fine pass)"),

@@ -18,6 +18,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_train_dec_$c -- python3 $R/bench.py --workload train --train-what planes+decoder --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_sr_$c -- python3 $R/bench.py --workload sr --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
 done
+# matrix-pipe utilisation and clock of the fine pass (one more counter pass of the same command)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
 # keep the merged-back payload small: drop the per-dispatch traces of the stats runs (the *_kernel_stats.csv summaries stay)
 find $O/stats_* -name "*kernel_trace.csv" -delete
 tail -c 400 $O/bench_render.json
