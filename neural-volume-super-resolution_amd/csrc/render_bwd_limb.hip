@@ -24,11 +24,15 @@
 
 namespace nvsr {
 
-constexpr int BL_TPB = 256, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
+#ifndef BL_WAVES_N
+#define BL_WAVES_N 4    // waves per workgroup: 4 = two independent workgroups per CU; 8 (experiment) = one workgroup, twice the points per weight chunk
+#endif
+constexpr int BL_TPB = 64 * BL_WAVES_N, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
+constexpr int BL_WG_PER_CU = BL_WAVES_N == 4 ? 2 : 1;
 constexpr int BL_SMALL = 2 * BL_CHUNK_WORDS;
 constexpr int BL_TILES = BL_SMALL + SMALL_FLOATS;
 constexpr int BL_LDS = BL_TILES + BL_WAVES * TILE_FLOATS;
-static_assert(2 * BL_LDS * 4 <= 160 * 1024, "two workgroups per CU");
+static_assert(BL_WG_PER_CU * BL_LDS * 4 <= 160 * 1024, "workgroups per CU");
 
 // natural blob -> limb fragments of the transposed layers
 __global__ void pack_decoder_bwd_limbs_kernel(const float* __restrict__ nat, unsigned* __restrict__ out) {
@@ -135,7 +139,7 @@ __device__ __forceinline__ void limb_mm2(const unsigned* wl, int lane, f32x16 (&
 }
 
 template <bool RECORD>
-__global__ __launch_bounds__(BL_TPB, 2) void render_pass_backward_gates_limb_kernel(SceneDev sc, const float* __restrict__ packed,
+__global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gates_limb_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                                    const float* __restrict__ packed_bwd, long N, int S,
                                                                                    const float* __restrict__ rays, const float* __restrict__ z,
                                                                                    const float* __restrict__ g_raw,
