@@ -373,7 +373,7 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 
 extern "C" {
 
-int nvsr_version(void) { return 100; }
+int nvsr_version(void) { return 200; }   // 200: round 2 (per-call arithmetic twins, generic decoder geometries, in-kernel coarse depths)
 
 int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int Cc, int H, int W, nvsr_stream_t stream) {
     if (!nchw || !nhwc) return NVSR_ERR_NULL;
