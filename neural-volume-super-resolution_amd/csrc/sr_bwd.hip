@@ -129,17 +129,35 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p)
 // Both operands are activations here, so both are split when they are staged: dy as [limb][co][40 px] and X as [limb][ci][3 rows][40 px]
 // bf16 (20-word rows: conflict-free ds_read_b128 for 16 consecutive channels), 8 consecutive pixels = one operand fragment.  A K-block is
 // 16 pixels of the row; the three kx taps of an X row come from ONE 5-word read: words 0..3, words 1..4, and their 16-bit funnel shift.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte global load from a 4-byte aligned address
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const float (&e)[4], u32x2 (&out)[3]) {   // 3-limb split of 4 values -> 2 words per limb
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float r0 = e[2 * j], r1 = e[2 * j + 1];
+        out[0][j] = trunc_pair(r1, r0);
+        r0 = limb_rest(r0); r1 = limb_rest(r1);
+        out[1][j] = trunc_pair(r1, r0);
+        r0 = limb_rest(r0); r1 = limb_rest(r1);
+        out[2][j] = trunc_pair(r1, r0);
+    }
+}
 constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels
 constexpr int WL_DY_WORDS = WG_CO * WL_ROW;               // one limb of dy
 constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
+#ifndef WG_ABLATE
+#define WG_ABLATE 0     // variant builds of tools/wgrad_ablate.sh: 1 no global fetches, 2 no split + LDS writes, 4 no MFMAs, 8 no fragment reads
+#endif
 
-__global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
+// TAIL: this workgroup's last quads may reach past the end of dy or X (the last channel's last rows): only then are the 16-byte loads
+// guarded -- a guard is a divergent branch, and hipcc answers each with s_waitcnt vmcnt(0), which serialises a step's loads
+template <bool TAIL>
+__device__ __forceinline__ void wgrad_limb_body(const WgradParams& p, unsigned* lds) {
     unsigned* dyl = lds;                                  // [limb][co][WL_ROW]
     unsigned* xl = lds + 3 * WL_DY_WORDS;                 // [limb][ci][row][WL_ROW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
-    const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = blockIdx.z;
+    const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = (int)gridDim.z - 1 - (int)blockIdx.z;   // (guarded workgroups first)
     const int W = p.Wo + 2;
     const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
     const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
@@ -154,73 +172,91 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 
     // A workgroup walks DOWN one 32-pixel column chunk (slab = (chunk, row range)): consecutive steps share two of their three X rows,
     // which stay in LDS (ring of 3 row slots, row ya + k in slot k % 3) -- a step stages dy and ONE new X row.
-    // staging: thread -> (dy row tid >> 2, pixel octet tid & 3); X octets e = tid + 256 k, k < 2 -> (ci, octet) = (e / 5, e % 5) of one row
+    // Staging unit = a QUAD of 4 consecutive pixels, quads numbered along the row and then down the channels, thread -> quads tid + 256 k:
+    // a wave's load instruction covers whole contiguous rows (8 rows of dy, 7 of X) with one 16-byte request per lane (4-byte aligned:
+    // rows start anywhere), a quad becomes 2 words of every limb.  dy: 64 co x 8 quads; X: 64 ci x 9 quads (32 + 2 halo pixels, padded).
     const int rows = yb - ya;
-    float rdy[8], rx[2][8];
-    const int dco = tid >> 2, doct = tid & 3;
-    int xci1[2], xo1[2];
+    constexpr int XQ_ROW = 9, XQ_N = WG_CI * XQ_ROW;         // 576 quads of an X row
+    float rdy[2][4], rx[3][4];
+    long dy_off[2], x_off[3];                                 // element offsets of the thread's quads in row 0 of dy / X
+    int dy_valid[2], dy_lds[2], x_lds[3];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int e = min(tid + WG_TPB * k, WG_CI * 5 - 1);
-        xci1[k] = e / 5; xo1[k] = e % 5;
+        const int e = tid + WG_TPB * k, co = e >> 3, q = e & 7;
+        dy_off[k] = (long)min(co0 + co, p.Cout - 1) * HoWo + x0 + 4 * q;
+        dy_valid[k] = min(max(p.Wo - (x0 + 4 * q), 0), 4);   // pixels past the row's end contribute nothing: they are zeroed
+        dy_lds[k] = co * WL_ROW + 2 * q;
     }
-    auto fetch_row = [&](int row) {                           // X row `row` of this chunk -> rx
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool ci_ok = ci0 + xci1[q] < p.Cin;
-            const float* xp = p.x + (long)min(ci0 + xci1[q], p.Cin - 1) * HW + (long)row * W;
+    for (int k = 0; k < 3; ++k) {
+        const int e = min(tid + WG_TPB * k, XQ_N - 1), ci = e / XQ_ROW, q = e % XQ_ROW;
+        x_off[k] = (long)min(ci0 + ci, p.Cin - 1) * HW + x0 + 4 * q;
+        x_lds[k] = ci * 3 * WL_ROW + 2 * q;
+    }
+    const long dy_total = (long)p.Cout * HoWo, x_total = (long)p.Cin * HW;
+    // 4 consecutive floats at base[idx .. idx + 3]; what lies past a row's end is the next row (finite; it only ever meets dy == 0),
+    // what would lie past the tensor's end is not touched
+    auto load4 = [&](const float* base, long idx, long total, float (&o)[4]) {
+        if (!TAIL || idx + 4 <= total) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + idx);
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = xp[min(x0 + 8 * xo1[q] + k, W - 1)];   // columns past the edge only ever meet dy == 0: any finite value will do
-                rx[q][k] = ci_ok ? v : 0.0f;
-            }
+            for (int j = 0; j < 4; ++j) o[j] = base[min(idx + j, total - 1)];
         }
     };
-    auto stage_row = [&](int slot) {                          // rx -> row slot `slot`
-        Limbs<3> L;
+    auto fetch_row = [&](int row, float (&dst)[3][4]) {        // X row `row` of this chunk
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            split8(rx[q], L);
-            if (tid + WG_TPB * q < WG_CI * 5) {
+        for (int k = 0; k < 3; ++k)
+            if (k < 2 || tid < XQ_N - 2 * WG_TPB) load4(p.x, x_off[k] + (long)row * W, x_total, dst[k]);
+    };
+    auto stage_row = [&](int slot, const float (&src)[3][4]) { // -> row slot `slot`
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    *reinterpret_cast<u32x4*>(xl + t * WL_X_WORDS + (xci1[q] * 3 + slot) * WL_ROW + xo1[q] * 4) = L.v[t];
+        for (int k = 0; k < 3; ++k) {
+            u32x2 L[3];
+            split4(src[k], L);
+            if (k < 2 || tid < XQ_N - 2 * WG_TPB) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(xl + t * WL_X_WORDS + x_lds[k] + slot * WL_ROW) = L[t];
             }
         }
     };
     auto fetch = [&](int yr) {                                // what step yr adds: dy row ya + yr, X row ya + yr + 2
-        const float* dp = p.dy + (long)min(co0 + dco, p.Cout - 1) * HoWo + (long)(ya + yr) * p.Wo;
-        const bool co_ok = co0 + dco < p.Cout;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int px = x0 + 8 * doct + k;
-            const float v = dp[min(px, p.Wo - 1)];
-            rdy[k] = (co_ok && px < p.Wo) ? v : 0.0f;       // pixels past the row's end and padded channels contribute nothing
+        for (int k = 0; k < 2; ++k) load4(p.dy, dy_off[k] + (long)(ya + yr) * p.Wo, dy_total, rdy[k]);
+        fetch_row(ya + yr + 2, rx);
+    };
+    auto stage_dy = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rdy[k][j] = j < dy_valid[k] ? rdy[k][j] : 0.0f;
+            u32x2 L[3];
+            split4(rdy[k], L);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dyl + t * WL_DY_WORDS + dy_lds[k]) = L[t];
         }
-        fetch_row(ya + yr + 2);
     };
 
     const unsigned* Ap = dyl + (cw * 32 + i) * WL_ROW + kh * 4;
     const unsigned* Bp = xl + ((iw * 32 + i) * 3) * WL_ROW + kh * 4;
     if (rows > 0) {
-        // prologue (exposed, once per workgroup): X rows ya, ya + 1
-        fetch_row(ya);
-        stage_row(0);
-        fetch_row(ya + 1);
-        stage_row(1);
+        // prologue (exposed, once per workgroup): X rows ya, ya + 1; all loads first
+        float r0[3][4], r1[3][4];
+        fetch_row(ya, r0);
+        fetch_row(ya + 1, r1);
         fetch(0);
+        stage_row(0, r0);
+        stage_row(1, r1);
     }
     for (int yr = 0; yr < rows; ++yr) {
         __syncthreads();                       // everyone is done reading the previous tile
-        {
-            Limbs<3> L;
-            split8(rdy, L);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(dyl + t * WL_DY_WORDS + dco * WL_ROW + doct * 4) = L.v[t];
+        if (!(WG_ABLATE & 2)) {
+            stage_dy();
+            stage_row((yr + 2) % 3, rx);
         }
-        stage_row((yr + 2) % 3);
         __syncthreads();
-        if (yr + 1 < rows) fetch(yr + 1);      // global loads fly under the MFMAs below
+        if (!(WG_ABLATE & 1) && yr + 1 < rows) fetch(yr + 1);      // global loads fly under the MFMAs below
         int rowoff[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((yr + ky) % 3) * WL_ROW;
@@ -236,19 +272,33 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const unsigned* bp = Bp + t * WL_X_WORDS + rowoff[ky] + kb * 8;
-                    const u32x4 w = *reinterpret_cast<const u32x4*>(bp);
-                    const unsigned w4 = bp[4];
+#if WG_ABLATE & 8
+                    const u32x4 w = u32x4{(unsigned)lane, (unsigned)yr, (unsigned)(lane ^ ky), (unsigned)t};
+                    const unsigned w4 = kb;
+#else
+                    u32x4 w = *reinterpret_cast<const u32x4*>(bp);
+                    unsigned w4 = bp[4];
+                    // one conflict-free ds_read_b128 + one ds_read_b32, the shifted fragments from REGISTERS: left alone, hipcc fetches words
+                    // 1..4 again as two ds_read2_b32 (no v_mov needed then) -- 4-way bank conflicts each, 32 LDS cycles instead of 4, and
+                    // the LDS becomes the busiest unit of the kernel (SQ_LDS_BANK_CONFLICT 64 % of SQ_LDS_IDX_ACTIVE, round 2)
+                    asm volatile("" : "+v"(w), "+v"(w4));
+#endif
                     B0[t] = w;
                     B2[t] = u32x4{w[1], w[2], w[3], w4};
                     B1[t] = u32x4{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
                                   __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
                 }
+#if WG_ABLATE & 4
+#pragma unroll
+                for (int t = 0; t < 3; ++t) asm volatile("" :: "v"(A[t]), "v"(B0[t]), "v"(B1[t]), "v"(B2[t]));
+#else
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     acc[ky * 3 + 0] = mfma_bf16(A[limb_w(3, q)], B0[limb_x(3, q)], acc[ky * 3 + 0]);
                     acc[ky * 3 + 1] = mfma_bf16(A[limb_w(3, q)], B1[limb_x(3, q)], acc[ky * 3 + 1]);
                     acc[ky * 3 + 2] = mfma_bf16(A[limb_w(3, q)], B2[limb_x(3, q)], acc[ky * 3 + 2]);
                 }
+#endif
             }
         }
     }
@@ -263,6 +313,19 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
                 if (co < p.Cout) p.partial[(((long)slab * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][r];
             }
     }
+}
+
+__global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
+    // the furthest element a quad of this workgroup can start at: last channel of the block, last row of the range, quad 8 of the chunk
+    const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
+    const int slab = (int)gridDim.z - 1 - (int)blockIdx.z;
+    const int x0 = (slab % nxc) * WG_PX, yb = min((slab / nxc + 1) * p.rows_per_slab_limb, p.Ho);
+    const long W = p.Wo + 2, HW = (long)(p.Ho + 2) * W, HoWo = (long)p.Ho * p.Wo;
+    const bool x_tail = (long)min((int)blockIdx.y * WG_CI + WG_CI - 1, p.Cin - 1) * HW + (long)(yb + 1) * W + x0 + 36 > (long)p.Cin * HW;
+    const bool dy_tail = (long)min((int)blockIdx.x * WG_CO + WG_CO - 1, p.Cout - 1) * HoWo + (long)(yb - 1) * p.Wo + x0 + 32 > (long)p.Cout * HoWo;
+    if (x_tail || dy_tail) wgrad_limb_body<true>(p, lds);
+    else wgrad_limb_body<false>(p, lds);
 }
 
 // dw[co][ci][tap] += scale * sum_slab partial[slab][tap][co][ci]
@@ -355,8 +418,14 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     arith = conv_resolve_arith(arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
     const bool limb = arith != NVSR_ARITH_F32;
-    const int nrr = wgrad_row_ranges_limb(Cin, Cout, Ho, Wo);
-    const int ns = limb ? wgrad_slabs_limb(Cin, Cout, Ho, Wo) : wgrad_slabs(Cin, Cout, Ho);
+    int nrr = wgrad_row_ranges_limb(Cin, Cout, Ho, Wo);
+    int ns = limb ? wgrad_slabs_limb(Cin, Cout, Ho, Wo) : wgrad_slabs(Cin, Cout, Ho);
+#ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py)
+    if (limb && getenv("NVSR_WGRAD_ROW_RANGES")) {
+        const int v = atoi(getenv("NVSR_WGRAD_ROW_RANGES"));
+        if (v >= 1 && v <= Ho) { nrr = v; ns = nrr * ((Wo + WG_PX - 1) / WG_PX); }   // (the tool sizes the workspace itself)
+    }
+#endif
     WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, (Ho + nrr - 1) / nrr};
     dim3 grid((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns);
     if (limb) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, grid, dim3(WG_TPB), 0, stream, p);
