@@ -31,7 +31,8 @@ struct WgradParams {
     float* partial;      // [nslab][9][Cout][Cin]
     int Cin, Cout, Ho, Wo;
     int rows_per_slab;
-    int rows_per_slab_limb;   // conv3x3_wgrad_limb_kernel: slab = (32-pixel column chunk, range of this many rows)
+    int n_wg;            // conv3x3_wgrad_limb_kernel: workgroups = pieces of the linear range of `total` row steps
+    long total;
 };
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
@@ -145,103 +146,149 @@ __device__ __forceinline__ void split4(const float (&e)[4], u32x2 (&out)[3]) {  
 constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels
 constexpr int WL_DY_WORDS = WG_CO * WL_ROW;               // one limb of dy
 constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
+#ifndef WG_STAMP
+#define WG_STAMP 0      // debug builds: cycles per step in 6 sections, wave 0 of every workgroup -> 8 floats behind the partial slots (tools/conv_wgrad_time.py)
+#endif
+#if WG_STAMP
+#define WG_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (float)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WG_MARK(i)
+#endif
 #ifndef WG_ABLATE
-#define WG_ABLATE 0     // variant builds of tools/wgrad_ablate.sh: 1 no global fetches, 2 no split + LDS writes, 4 no MFMAs, 8 no fragment reads
+#define WG_ABLATE 0     // variant builds of tools/conv_wgrad_ablate.sh: 1 no global fetches, 2 no split + LDS writes, 4 no MFMAs
 #endif
 
-// TAIL: this workgroup's last quads may reach past the end of dy or X (the last channel's last rows): only then are the 16-byte loads
-// guarded -- a guard is a divergent branch, and hipcc answers each with s_waitcnt vmcnt(0), which serialises a step's loads
-template <bool TAIL>
-__device__ __forceinline__ void wgrad_limb_body(const WgradParams& p, unsigned* lds) {
+// Work split: the row steps of a layer -- (tile of 64 co x 64 ci, 32-pixel column chunk, output row), in that order -- form ONE linear
+// range that is cut into n_wg equal pieces, one per workgroup (n_wg = the 512 workgroup slots of the chip when the layer is large enough):
+// every workgroup does the same number of steps and all of them are resident from the start, so there is no partly filled last round
+// (the former (chunk, row range) slabs gave 720 workgroups for a trunk layer: 1.4 rounds).  A piece that crosses a chunk boundary restarts
+// its X-row ring; one that crosses a TILE boundary (at most once: pieces are no longer than a tile) writes its accumulators and starts
+// over -- a workgroup owns two partial slots [9][64][64], and wgrad_reduce_pieces_kernel adds, for every tile, the slots of the pieces
+// that overlap it in piece order (deterministic).
+__device__ __forceinline__ long wgrad_piece_start(long w, long total, int n_wg) { return w * total / n_wg; }
+
+// rows [ya, yb) of column chunk x0 of tile (co0, ci0), accumulated into acc.
+__device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* lds, f32x16 (&acc)[9], int co0, int ci0, int x0, int ya, int yb
+#if WG_STAMP
+                                                , float (&stamp)[8]
+#endif
+                                                ) {
     unsigned* dyl = lds;                                  // [limb][co][WL_ROW]
     unsigned* xl = lds + 3 * WL_DY_WORDS;                 // [limb][ci][row][WL_ROW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
-    const int co0 = blockIdx.x * WG_CO, ci0 = blockIdx.y * WG_CI, slab = (int)gridDim.z - 1 - (int)blockIdx.z;   // (guarded workgroups first)
     const int W = p.Wo + 2;
     const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
-    const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
-    const int x0 = (slab % nxc) * WG_PX;
-    const int ya = (slab / nxc) * p.rows_per_slab_limb, yb = min(ya + p.rows_per_slab_limb, p.Ho);
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    // A workgroup walks DOWN one 32-pixel column chunk (slab = (chunk, row range)): consecutive steps share two of their three X rows,
-    // which stay in LDS (ring of 3 row slots, row ya + k in slot k % 3) -- a step stages dy and ONE new X row.
+    // A workgroup walks DOWN a 32-pixel column chunk: consecutive steps share two of their three X rows, which stay in LDS (ring of 3 row
+    // slots, row ya + k in slot k % 3) -- a step stages dy and ONE new X row.
     // Staging unit = a QUAD of 4 consecutive pixels, quads numbered along the row and then down the channels, thread -> quads tid + 256 k:
     // a wave's load instruction covers whole contiguous rows (8 rows of dy, 7 of X) with one 16-byte request per lane (4-byte aligned:
     // rows start anywhere), a quad becomes 2 words of every limb.  dy: 64 co x 8 quads; X: 64 ci x 9 quads (32 + 2 halo pixels, padded).
     const int rows = yb - ya;
-    constexpr int XQ_ROW = 9, XQ_N = WG_CI * XQ_ROW;         // 576 quads of an X row
+    // Thread -> quads.  dy (64 co x 8 quads): quad tid & 7 of rows (tid >> 3) + 32 k, k < 2.  X (64 ci x 9 quads: 32 + 2 halo pixels,
+    // padded): lane l < 63 of wave w takes quad l % 9 of rows 7 w + l / 9 + 28 k, k < 3 (rows >= 64 do not exist).  The rows of one
+    // thread differ by a constant, so ONE 32-bit byte offset per operand serves all of them (scalar base per k: the saddr form of
+    // global_load, no 64-bit address registers), and so does one LDS address.  Channels past Cout / Cin are not loaded: whatever is
+    // staged for them only reaches accumulator rows / columns the reduction never reads.
     float rdy[2][4], rx[3][4];
-    long dy_off[2], x_off[3];                                 // element offsets of the thread's quads in row 0 of dy / X
-    int dy_valid[2], dy_lds[2], x_lds[3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int e = tid + WG_TPB * k, co = e >> 3, q = e & 7;
-        dy_off[k] = (long)min(co0 + co, p.Cout - 1) * HoWo + x0 + 4 * q;
-        dy_valid[k] = min(max(p.Wo - (x0 + 4 * q), 0), 4);   // pixels past the row's end contribute nothing: they are zeroed
-        dy_lds[k] = co * WL_ROW + 2 * q;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int e = min(tid + WG_TPB * k, XQ_N - 1), ci = e / XQ_ROW, q = e % XQ_ROW;
-        x_off[k] = (long)min(ci0 + ci, p.Cin - 1) * HW + x0 + 4 * q;
-        x_lds[k] = ci * 3 * WL_ROW + 2 * q;
-    }
-    const long dy_total = (long)p.Cout * HoWo, x_total = (long)p.Cin * HW;
-    // 4 consecutive floats at base[idx .. idx + 3]; what lies past a row's end is the next row (finite; it only ever meets dy == 0),
-    // what would lie past the tensor's end is not touched
-    auto load4 = [&](const float* base, long idx, long total, float (&o)[4]) {
-        if (!TAIL || idx + 4 <= total) {
-            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + idx);
+    const int dco = tid >> 3, xr = 7 * wave + lane / 9, xq = lane % 9;
+    const unsigned dy_voff = ((unsigned)dco * (unsigned)HoWo + 4 * (tid & 7)) * 4u;      // (the launcher checks that 64 channels fit 2^31 bytes)
+    const unsigned x_voff = ((unsigned)xr * (unsigned)HW + 4 * xq) * 4u;
+    const int dy_valid = min(max(p.Wo - (x0 + 4 * (tid & 7)), 0), 4);   // pixels past the row's end contribute nothing: they are zeroed
+    unsigned* const dy_st = dyl + dco * WL_ROW + 2 * (tid & 7);
+    unsigned* const x_st = xl + xr * 3 * WL_ROW + 2 * xq;
+    const int n_co = min(WG_CO, p.Cout - co0), n_ci = min(WG_CI, p.Cin - ci0);
+    const bool x_lane = lane < 63;
+    const long dy_rest = (long)(p.Cout - co0) * HoWo - x0, x_rest = (long)(p.Cin - ci0) * HW - x0;   // elements from the bases below to the end
+    const float* const dy_base = p.dy + (long)co0 * HoWo + x0;
+    const float* const x_base = p.x + (long)ci0 * HW + x0;
+    // 4 consecutive floats; what lies past a row's end is the next row (finite; it only ever meets dy == 0), what would lie past the
+    // tensor's end is not touched: a quad of the LAST row of the LAST channel may reach there, and rows that can (a scalar test per row)
+    // take the guarded loads -- a guard is a divergent branch, and hipcc answers each with s_waitcnt vmcnt(0), which serialises the row's
+    // loads; all other rows take the bare 16-byte loads
+    auto load4 = [&](const float* base, unsigned voff, long rest, float (&o)[4], bool guard) {   // `rest` elements are left from base
+        if (!guard || (long)(voff >> 2) + 4 <= rest) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(base) + voff);
             o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = base[min(idx + j, total - 1)];
+            for (int j = 0; j < 4; ++j) o[j] = base[min((long)(voff >> 2) + j, rest - 1)];
         }
     };
+    const long x_last = (long)(n_ci - 1) * HW + 36, dy_last = (long)(n_co - 1) * HoWo + 32;
     auto fetch_row = [&](int row, float (&dst)[3][4]) {        // X row `row` of this chunk
+        const float* b = x_base + (long)row * W;
+        const long rest = x_rest - (long)row * W;
+        const bool guard = x_last > rest;                      // (uniform)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < 2 || tid < XQ_N - 2 * WG_TPB) load4(p.x, x_off[k] + (long)row * W, x_total, dst[k]);
+        for (int k = 0; k < 3; ++k) {
+            if (x_lane && xr + 28 * k < n_ci) {
+                if (guard) load4(b + 28L * k * HW, x_voff, rest - 28L * k * HW, dst[k], true);
+                else load4(b + 28L * k * HW, x_voff, 0, dst[k], false);
+            }
+        }
     };
     auto stage_row = [&](int slot, const float (&src)[3][4]) { // -> row slot `slot`
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             u32x2 L[3];
             split4(src[k], L);
-            if (k < 2 || tid < XQ_N - 2 * WG_TPB) {
+            if (x_lane && xr + 28 * k < WG_CI) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(xl + t * WL_X_WORDS + x_lds[k] + slot * WL_ROW) = L[t];
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(x_st + t * WL_X_WORDS + (28 * k * 3 + slot) * WL_ROW) = L[t];
             }
         }
     };
     auto fetch = [&](int yr) {                                // what step yr adds: dy row ya + yr, X row ya + yr + 2
+        const float* b = dy_base + (long)(ya + yr) * p.Wo;
+        const long rest = dy_rest - (long)(ya + yr) * p.Wo;
+        const bool guard = dy_last > rest;                     // (uniform)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) load4(p.dy, dy_off[k] + (long)(ya + yr) * p.Wo, dy_total, rdy[k]);
+        for (int k = 0; k < 2; ++k) {
+            if (dco + 32 * k < n_co) {
+                if (guard) load4(b + 32L * k * HoWo, dy_voff, rest - 32L * k * HoWo, rdy[k], true);
+                else load4(b + 32L * k * HoWo, dy_voff, 0, rdy[k], false);
+            }
+        }
         fetch_row(ya + yr + 2, rx);
     };
     auto stage_dy = [&]() {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rdy[k][j] = j < dy_valid[k] ? rdy[k][j] : 0.0f;
+            for (int j = 0; j < 4; ++j) rdy[k][j] = j < dy_valid ? rdy[k][j] : 0.0f;
             u32x2 L[3];
             split4(rdy[k], L);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dyl + t * WL_DY_WORDS + dy_lds[k]) = L[t];
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dy_st + t * WL_DY_WORDS + 32 * k * WL_ROW) = L[t];
         }
     };
 
     const unsigned* Ap = dyl + (cw * 32 + i) * WL_ROW + kh * 4;
     const unsigned* Bp = xl + ((iw * 32 + i) * 3) * WL_ROW + kh * 4;
+    // one X fragment read = a conflict-free ds_read_b128 (words 0..3) + a ds_read_b32 (word 4); the three kx taps are built from these
+    // five REGISTERS: left alone, hipcc fetches words 1..4 again as two ds_read2_b32 (no v_mov needed then) -- 4-way bank conflicts each,
+    // 32 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT was 64 % of SQ_LDS_IDX_ACTIVE, the LDS 57 % busy)
+    struct Raw { u32x4 w; unsigned w4; };
+    auto read_x = [&](int t, int off) {
+        const unsigned* bp = Bp + t * WL_X_WORDS + off;
+        Raw r;
+        r.w = *reinterpret_cast<const u32x4*>(bp);
+        r.w4 = bp[4];
+        return r;
+    };
+    auto taps = [&](Raw& r, u32x4 (&b)[3]) {
+        asm volatile("" : "+v"(r.w), "+v"(r.w4));
+        b[0] = r.w;
+        b[2] = u32x4{r.w[1], r.w[2], r.w[3], r.w4};
+        b[1] = u32x4{__builtin_amdgcn_alignbit(r.w[1], r.w[0], 16), __builtin_amdgcn_alignbit(r.w[2], r.w[1], 16),
+                     __builtin_amdgcn_alignbit(r.w[3], r.w[2], 16), __builtin_amdgcn_alignbit(r.w4, r.w[3], 16)};
+    };
+
+    __syncthreads();                           // the previous rows' (piece's) fragment reads are done: the ring may be overwritten
     if (rows > 0) {
-        // prologue (exposed, once per workgroup): X rows ya, ya + 1; all loads first
+        // prologue (exposed, once per call): X rows ya, ya + 1; all loads first
         float r0[3][4], r1[3][4];
         fetch_row(ya, r0);
         fetch_row(ya + 1, r1);
@@ -249,83 +296,148 @@ __device__ __forceinline__ void wgrad_limb_body(const WgradParams& p, unsigned* 
         stage_row(0, r0);
         stage_row(1, r1);
     }
+#if WG_STAMP
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (int yr = 0; yr < rows; ++yr) {
+        WG_MARK(5)
         __syncthreads();                       // everyone is done reading the previous tile
+        WG_MARK(0)
         if (!(WG_ABLATE & 2)) {
             stage_dy();
             stage_row((yr + 2) % 3, rx);
         }
+        WG_MARK(1)
         __syncthreads();
+        WG_MARK(2)
         if (!(WG_ABLATE & 1) && yr + 1 < rows) fetch(yr + 1);      // global loads fly under the MFMAs below
+        WG_MARK(3)
         int rowoff[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((yr + ky) % 3) * WL_ROW;
+        // 6 groups g = (K-block kb of 16 pixels, ky): 18 MFMAs each, products in the order of limb_w / limb_x (small terms first), which
+        // starts with X limb 2: that limb's words of group g + 1 are requested before the MFMAs of group g, limbs 1 and 0 at the start of
+        // their own group, under its first MFMAs
+        Raw nxt = read_x(2, rowoff[0]);
+        u32x4 A[3];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            u32x4 A[3];
+        for (int g = 0; g < 6; ++g) {
+            const int kb = g / 3, ky = g % 3, off = rowoff[ky] + kb * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ky == 0) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) A[t] = *reinterpret_cast<const u32x4*>(Ap + t * WL_DY_WORDS + kb * 8);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                __builtin_amdgcn_sched_barrier(0);          // keep later rows' fragment reads out of this one (register pressure)
-                u32x4 B0[3], B1[3], B2[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const unsigned* bp = Bp + t * WL_X_WORDS + rowoff[ky] + kb * 8;
-#if WG_ABLATE & 8
-                    const u32x4 w = u32x4{(unsigned)lane, (unsigned)yr, (unsigned)(lane ^ ky), (unsigned)t};
-                    const unsigned w4 = kb;
-#else
-                    u32x4 w = *reinterpret_cast<const u32x4*>(bp);
-                    unsigned w4 = bp[4];
-                    // one conflict-free ds_read_b128 + one ds_read_b32, the shifted fragments from REGISTERS: left alone, hipcc fetches words
-                    // 1..4 again as two ds_read2_b32 (no v_mov needed then) -- 4-way bank conflicts each, 32 LDS cycles instead of 4, and
-                    // the LDS becomes the busiest unit of the kernel (SQ_LDS_BANK_CONFLICT 64 % of SQ_LDS_IDX_ACTIVE, round 2)
-                    asm volatile("" : "+v"(w), "+v"(w4));
-#endif
-                    B0[t] = w;
-                    B2[t] = u32x4{w[1], w[2], w[3], w4};
-                    B1[t] = u32x4{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
-                                  __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
-                }
-#if WG_ABLATE & 4
-#pragma unroll
-                for (int t = 0; t < 3; ++t) asm volatile("" :: "v"(A[t]), "v"(B0[t]), "v"(B1[t]), "v"(B2[t]));
-#else
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    acc[ky * 3 + 0] = mfma_bf16(A[limb_w(3, q)], B0[limb_x(3, q)], acc[ky * 3 + 0]);
-                    acc[ky * 3 + 1] = mfma_bf16(A[limb_w(3, q)], B1[limb_x(3, q)], acc[ky * 3 + 1]);
-                    acc[ky * 3 + 2] = mfma_bf16(A[limb_w(3, q)], B2[limb_x(3, q)], acc[ky * 3 + 2]);
-                }
-#endif
+                for (int t = 0; t < 3; ++t) A[t] = *reinterpret_cast<const u32x4*>(Ap + t * WL_DY_WORDS + kb * 8);
             }
+            Raw r1 = read_x(1, off), r0 = read_x(0, off);
+            u32x4 B2[3], B1[3], B0[3];
+            taps(nxt, B2);
+            __builtin_amdgcn_sched_barrier(0);
+#if !(WG_ABLATE & 4)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_bf16(A[limb_w(3, 0)], B2[kx], acc[ky * 3 + kx]);
+#endif
+            if (g < 5) nxt = read_x(2, rowoff[(g + 1) % 3] + ((g + 1) / 3) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            taps(r1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+#if !(WG_ABLATE & 4)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_bf16(A[limb_w(3, 1)], B1[kx], acc[ky * 3 + kx]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            taps(r0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+#if !(WG_ABLATE & 4)
+#pragma unroll
+            for (int q = 2; q < 6; ++q) {
+                static_assert(limb_x(3, 0) == 2 && limb_x(3, 1) == 1 && limb_x(3, 2) == 0 && limb_x(3, 3) == 1 && limb_x(3, 4) == 0 && limb_x(3, 5) == 0, "");
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = mfma_bf16(A[limb_w(3, q)], limb_x(3, q) == 1 ? B1[kx] : B0[kx], acc[ky * 3 + kx]);
+            }
+#else
+#pragma unroll
+            for (int t = 0; t < 3; ++t) asm volatile("" :: "v"(A[t]), "v"(B0[t]), "v"(B1[t]), "v"(B2[t]));
+#endif
         }
-    }
-    // D[row = co][col = ci]: lanes run along ci -> 128-byte rows of the [tap][co][ci] partial
-    const int ci = ci0 + iw * 32 + i;
-    if (ci < p.Cin) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (co < p.Cout) p.partial[(((long)slab * 9 + t) * p.Cout + co) * p.Cin + ci] = acc[t][r];
-            }
+        WG_MARK(4)
+#if WG_STAMP
+        stamp[6] += 1.0f;
+#endif
     }
 }
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
-    // the furthest element a quad of this workgroup can start at: last channel of the block, last row of the range, quad 8 of the chunk
-    const int nxc = (p.Wo + WG_PX - 1) / WG_PX;
-    const int slab = (int)gridDim.z - 1 - (int)blockIdx.z;
-    const int x0 = (slab % nxc) * WG_PX, yb = min((slab / nxc + 1) * p.rows_per_slab_limb, p.Ho);
-    const long W = p.Wo + 2, HW = (long)(p.Ho + 2) * W, HoWo = (long)p.Ho * p.Wo;
-    const bool x_tail = (long)min((int)blockIdx.y * WG_CI + WG_CI - 1, p.Cin - 1) * HW + (long)(yb + 1) * W + x0 + 36 > (long)p.Cin * HW;
-    const bool dy_tail = (long)min((int)blockIdx.x * WG_CO + WG_CO - 1, p.Cout - 1) * HoWo + (long)(yb - 1) * p.Wo + x0 + 32 > (long)p.Cout * HoWo;
-    if (x_tail || dy_tail) wgrad_limb_body<true>(p, lds);
-    else wgrad_limb_body<false>(p, lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
+    const int cw = wave & 1, iw = wave >> 1;
+    const int nxc = (p.Wo + WG_PX - 1) / WG_PX, n_ci = (p.Cin + WG_CI - 1) / WG_CI;
+    const int TS = nxc * p.Ho;                             // steps of a tile (the launcher checks that `total` fits an int)
+    const int wg = blockIdx.x;
+    // (integer division runs on the vector ALU: without readfirstlane everything derived from the quotients counts as divergent, the
+    //  TAIL branch below becomes a divergent one and the accumulators are spilled around it)
+    int s = __builtin_amdgcn_readfirstlane((int)wgrad_piece_start(wg, p.total, p.n_wg));
+    const int s1 = __builtin_amdgcn_readfirstlane((int)wgrad_piece_start(wg + 1, p.total, p.n_wg));
+    int slot = 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+#if WG_STAMP
+    float stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    while (s < s1) {
+        const int tile = __builtin_amdgcn_readfirstlane(s / TS), rem = s - tile * TS;
+        const int chunk = __builtin_amdgcn_readfirstlane(rem / p.Ho), ya = rem - chunk * p.Ho;
+        const int seg_end = min(s1, tile * TS + (chunk + 1) * p.Ho);
+        const int yb = ya + (seg_end - s);
+        const int cob = __builtin_amdgcn_readfirstlane(tile / n_ci);
+        const int co0 = cob * WG_CO, ci0 = (tile - cob * n_ci) * WG_CI, x0 = chunk * WG_PX;
+#if WG_STAMP
+        wgrad_limb_rows(p, lds, acc, co0, ci0, x0, ya, yb, stamp);
+#else
+        wgrad_limb_rows(p, lds, acc, co0, ci0, x0, ya, yb);
+#endif
+        s = seg_end;
+        if (s == s1 || s == (tile + 1) * TS) {
+            // D[row = co][col = ci]: lanes run along ci -> 128-byte rows of the slot's [tap][co][ci]
+            float* dst = p.partial + ((long)wg * 2 + slot) * (9 * WG_CO * WG_CI) + iw * 32 + i;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dst[(t * WG_CO + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * WG_CI] = acc[t][r];
+                    acc[t][r] = 0.0f;
+                }
+            ++slot;
+        }
+    }
+#if WG_STAMP
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) p.partial[(long)p.n_wg * 2 * (9 * WG_CO * WG_CI) + wg * 8 + k] = stamp[k];
+#endif
+}
+
+// dw[co][ci][tap] += scale * (sum over the pieces that overlap the element's tile, in piece order, of their slot for that tile)
+__global__ void wgrad_reduce_pieces_kernel(const float* __restrict__ partial, int n_wg, long total, long TS, int Cout, int Cin, float scale,
+                                           float* __restrict__ dw) {
+    const int n_ci = (Cin + WG_CI - 1) / WG_CI;
+    const int ci = blockIdx.x * 64 + (threadIdx.x & 63), co = blockIdx.y * 4 + (threadIdx.x >> 6), t = blockIdx.z;
+    if (ci >= Cin || co >= Cout) return;
+    const long tile = (long)(co / WG_CO) * n_ci + ci / WG_CI, lo = tile * TS, hi = lo + TS;
+    long w = lo * n_wg / total;
+    while (w + 1 < n_wg && wgrad_piece_start(w + 1, total, n_wg) <= lo) ++w;
+    while (w > 0 && wgrad_piece_start(w, total, n_wg) > lo) --w;
+    const long e = ((long)t * WG_CO + (co % WG_CO)) * WG_CI + (ci % WG_CI);
+    float sum = 0.0f;
+    for (; w < n_wg && wgrad_piece_start(w, total, n_wg) < hi; ++w) {
+        const int slot = wgrad_piece_start(w, total, n_wg) >= lo ? 0 : 1;       // the piece's first tile, or the one it crossed into
+        sum += partial[(w * 2 + slot) * (9L * WG_CO * WG_CI) + e];
+    }
+    dw[((long)co * Cin + ci) * 9 + t] += scale * sum;
 }
 
 // dw[co][ci][tap] += scale * sum_slab partial[slab][tap][co][ci]
@@ -397,17 +509,20 @@ static int wgrad_slabs(int Cin, int Cout, int Ho) {
     if (ns > Ho) ns = Ho;
     return ns < 1 ? 1 : ns;
 }
-// limb kernel: slabs = column chunks x row ranges, about as many as above
-static int wgrad_row_ranges_limb(int Cin, int Cout, int Ho, int Wo) {
-    const int nxc = (Wo + WG_PX - 1) / WG_PX;
-    int nrr = (wgrad_slabs(Cin, Cout, Ho) + nxc - 1) / nxc;
-    if (nrr > Ho) nrr = Ho;
-    return nrr < 1 ? 1 : nrr;
+// limb kernel: equal pieces of the linear range of row steps (see conv3x3_wgrad_limb_kernel)
+static long wgrad_total_steps(int Cin, int Cout, int Ho, int Wo) {
+    return (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI) * ((Wo + WG_PX - 1) / WG_PX) * Ho;
 }
-static int wgrad_slabs_limb(int Cin, int Cout, int Ho, int Wo) { return wgrad_row_ranges_limb(Cin, Cout, Ho, Wo) * ((Wo + WG_PX - 1) / WG_PX); }
+static int wgrad_pieces(int Cin, int Cout, int Ho, int Wo) {
+    const long tiles = (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI), total = wgrad_total_steps(Cin, Cout, Ho, Wo);
+    long n = total / 8;                      // at least ~8 steps per piece (prologue: 2 rows), ...
+    if (n > 512) n = 512;                    // ... the chip's 512 workgroup slots (2 per CU) when the layer is large enough, ...
+    if (n < tiles) n = tiles;                // ... and never longer than a tile: a piece crosses at most one tile boundary
+    return (int)n;
+}
 static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho, int Wo) {
-    const int a = wgrad_slabs(Cin, Cout, Ho), b = wgrad_slabs_limb(Cin, Cout, Ho, Wo);
-    return (int64_t)(a > b ? a : b) * 9 * Cout * Cin;      // either kernel may run (nvsr_set_conv_arithmetic)
+    const int64_t a = (int64_t)wgrad_slabs(Cin, Cout, Ho) * 9 * Cout * Cin, b = (int64_t)wgrad_pieces(Cin, Cout, Ho, Wo) * 2 * 9 * WG_CO * WG_CI;
+    return a > b ? a : b;                                  // either kernel may run (nvsr_set_conv_arithmetic)
 }
 
 // dw += scale * dW(dy, x);  H, W = size of x
@@ -418,20 +533,24 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     arith = conv_resolve_arith(arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
     const bool limb = arith != NVSR_ARITH_F32;
-    int nrr = wgrad_row_ranges_limb(Cin, Cout, Ho, Wo);
-    int ns = limb ? wgrad_slabs_limb(Cin, Cout, Ho, Wo) : wgrad_slabs(Cin, Cout, Ho);
-#ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py)
-    if (limb && getenv("NVSR_WGRAD_ROW_RANGES")) {
-        const int v = atoi(getenv("NVSR_WGRAD_ROW_RANGES"));
-        if (v >= 1 && v <= Ho) { nrr = v; ns = nrr * ((Wo + WG_PX - 1) / WG_PX); }   // (the tool sizes the workspace itself)
-    }
-#endif
-    WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, (Ho + nrr - 1) / nrr};
-    dim3 grid((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns);
-    if (limb) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, grid, dim3(WG_TPB), 0, stream, p);
-    else hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(WG_TPB), 0, stream, p);
     const long n = 9L * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
+    if (limb) {
+        int n_wg = wgrad_pieces(Cin, Cout, Ho, Wo);
+        const long total = wgrad_total_steps(Cin, Cout, Ho, Wo), TS = (long)((Wo + WG_PX - 1) / WG_PX) * Ho;
+        if (total >= (1L << 31) - TS || 64L * H * W >= (1L << 29)) return NVSR_ERR_SHAPE;   // (the kernel's int step and offset arithmetic)
+#ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py; the tool sizes the workspace itself)
+        if (getenv("NVSR_WGRAD_PIECES")) n_wg = atoi(getenv("NVSR_WGRAD_PIECES"));
+#endif
+        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, 0, n_wg, total};
+        hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
+        hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, stream, partial, n_wg, total, TS, Cout,
+                           Cin, scale, dw);
+    } else {
+        const int ns = wgrad_slabs(Cin, Cout, Ho);
+        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, 0, 0};
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns), dim3(WG_TPB), 0, stream, p);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
+    }
     return NVSR_CHECK_LAUNCH();
 }
 
