@@ -197,6 +197,9 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV_ABLATE
+#define CV_ABLATE 0     // variant builds of tools/conv_ablate.sh: 1 weight fragments of tap 0 only, 2 no patch loads, 4 no split + LDS writes
+#endif
 template <int PB, int CO_WAVES = 4>
 __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     constexpr int PX_WAVES = 4 / CO_WAVES, ROWS = PX_WAVES * PB;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunks) gload(chunk + 1);          // in flight during this chunk's MFMAs
+        if (chunk + 1 < nchunks && !(CV_ABLATE & 2)) gload(chunk + 1);          // in flight during this chunk's MFMAs
         const u32x4* wa = wbase + chunk * wchunk;
         const unsigned* pl = lds + buf * BUF + (j * 2 + h) * 4;
         // A fragments one tap ahead (the sched_barriers keep hipcc from hoisting every load of the chunk to its top: 95+ spills)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < 9) {
+            if (tap + 1 < 9 && !(CV_ABLATE & 1)) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -304,14 +307,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
                     for (int q = 0; q < 6; ++q) acc[cb][pb] = mfma_bf16(A[cb][limb_w(3, q)], B[limb_x(3, q)], acc[cb][pb]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < 9) {
+            if (tap + 1 < 9 && !(CV_ABLATE & 1)) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) A[cb][t] = An[cb][t];
             }
         }
-        if (chunk + 1 < nchunks) sstore(buf ^ 1);
+        if (chunk + 1 < nchunks && !(CV_ABLATE & 4)) sstore(buf ^ 1);
         __syncthreads();
     }
     conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);

@@ -551,10 +551,11 @@ def test_planes_sr_row_bands_equal_the_full_plane(hip):
 
 def test_conv3x3_backward_vs_oracle(hip, oracle):
     """data and weight gradients of the valid 3x3 conv through the C ABI; sizes that exercise partial tiles in every dimension
-    (channels not multiples of 64, width not a multiple of 32, fewer rows than row slabs)"""
+    (channels not multiples of 64, width not a multiple of 32, fewer rows than row slabs; the last shape gives the weight-gradient kernel
+    408 equal pieces of 8 row steps over 16 tiles, i.e. pieces that cross column chunks and tiles)"""
     rng = np.random.default_rng(33)
     capi = hip.capi
-    for Cin, Cout, H, W in [(48, 256, 21, 45), (256, 256, 14, 40), (256, 48, 37, 35), (70, 130, 9, 70), (5, 7, 3, 3), (64, 1024, 10, 12)]:
+    for Cin, Cout, H, W in [(48, 256, 21, 45), (256, 256, 14, 40), (256, 48, 37, 35), (70, 130, 9, 70), (5, 7, 3, 3), (64, 1024, 10, 12), (256, 256, 70, 70)]:
         x = rng.standard_normal((Cin, H, W), dtype=np.float32)
         w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
         dy = rng.standard_normal((Cout, H - 2, W - 2), dtype=np.float32)
