@@ -313,7 +313,7 @@ int nvsr_planes_sr_backward(int C, int R0, int R1, const float* keep, const floa
  * TwoDimPlanesModel (models.py:118-434) is configurable: dec_channels, layer counts, skip_connect_every, num_plane_channels,
  * proj_combination, viewdir_proj_combination (config/TrainModels.yml:78,82,92 list alternatives).  The MFMA kernels above are compiled for
  * the shipped configuration; every other one the reference's own layer sizes admit runs through this generic path (plain kernels,
- * activations through HBM, exact-f32 MFMA layers): forward only. */
+ * activations through HBM, exact-f32 MFMA layers): forward and backward. */
 typedef struct nvsr_decoder_geometry {
     int32_t plane_channels;        /* num_plane_channels */
     int32_t viewdir_channels;      /* num_viewdir_plane_channels */
@@ -333,6 +333,14 @@ int64_t nvsr_generic_decode_workspace_floats(const nvsr_decoder_geometry* geomet
  * [H][W][viewdir_channels]); natural: the blob above (device). */
 int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P, const float* x,
                         float* out, float* workspace, nvsr_stream_t stream);
+/* Backward of nvsr_generic_decode (the reference: torch.autograd through models.py:381-421): d_out [P,4] -> the gradients of the
+ * parameters (d_natural, the blob's layout; NULL = not wanted) and of the four planes (d_plane0..3, channel-last like the planes; NULL =
+ * not wanted), all ACCUMULATED into what is there (float atomics: last-bit run-to-run differences, like grid_sampler_2d_backward).
+ * The forward is recomputed chunk by chunk with every layer's output kept in the workspace. */
+int64_t nvsr_generic_decode_backward_workspace_floats(const nvsr_decoder_geometry* geometry, int64_t P);
+int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P, const float* x,
+                                 const float* d_out, float* d_natural, float* d_plane0, float* d_plane1, float* d_plane2, float* d_plane3,
+                                 float* workspace, nvsr_stream_t stream);
 /* run_network's model input for a pass (train_utils.py:15-64,111): x [N*S,6] = [ro + rd * z, viewdir] from packed rays [N,11], z [N,S] */
 int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* x, nvsr_stream_t stream);
 

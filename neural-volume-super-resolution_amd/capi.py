@@ -117,6 +117,8 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_generic_decoder_natural_floats": ([C.POINTER(DecoderGeometry)], _i64),
     "nvsr_generic_decode_workspace_floats": ([C.POINTER(DecoderGeometry), _i64], _i64),
     "nvsr_generic_decode": ([C.POINTER(Scene), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "nvsr_generic_decode_backward_workspace_floats": ([C.POINTER(DecoderGeometry), _i64], _i64),
+    "nvsr_generic_decode_backward": ([C.POINTER(Scene), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_ray_points": ([_i64, _i, _vp, _vp, _vp, _vp], _i),
     # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")
     "nvsr_render_pass_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),

@@ -5,12 +5,19 @@
 // combine_all_planes :363-379; the shipped YAMLs list dec_channels 256, proj_combination sum / concat, 24-channel planes and skip layers as
 // alternatives (config/TrainModels.yml:78,82,92).
 //
-// Three plain kernels, activations through HBM (this is the compatibility path, not the hot one):
+// Forward: three plain kernels, activations through HBM (this is the compatibility path, not the hot one):
 //   generic_inputs_kernel   one thread per (point, input column): normalise, project, 4 bilinear taps per plane, combine -> the density
 //                           decoder's input Xd [P][Kd] and the colour decoder's input Xr [P][Kr]
 //   generic_linear_kernel   Y[P][M] = act(b + W[M][K1 + K2] . [X1[P][K1] | X2[P][K2]])  (X2 = the skip connection's second operand) on
 //                           v_mfma_f32_32x32x2_f32 (exact f32 products, k in order), one 32 x 32 tile per wave, operands staged through LDS
 //   ray_points_kernel       x[N*S][6] = [ro + rd * z, viewdir]  (run_network's input, train_utils.py:15-64,111)
+// Backward (the reference differentiates the same forward with torch.autograd): the forward of a chunk is recomputed with every layer's
+// output kept, then per layer, top down,
+//   generic_wgrad_kernel    dW[M][K] += dZ^T . [X1 | X2],  db += column sums of dZ   (dZ = dY where the layer's output is > 0; the points
+//                           are the contraction index: MFMA operands straight from memory, partial tiles added with float atomics)
+//   generic_dgrad_kernel    dX[P][columns of W] (+)= dZ . W   (the forward's tiling with W read transposed)
+// and generic_inputs_backward_kernel scatters the gradients of the two decoder inputs through the combination rule and the four
+// bilinear taps into the channel-last gradient planes (float atomics, like grid_sampler_2d_backward).
 #include "decode_core.h"
 
 namespace nvsr {
@@ -159,7 +166,149 @@ __global__ void ray_points_kernel(long N, int S, const float* __restrict__ rays,
     o[3] = r[8]; o[4] = r[9]; o[5] = r[10];
 }
 
+// dX[p][xoff + k] (row stride ldx; ACCUM: +=) = sum_m dZ[p][m] W[m][koff + k], k < Kn;  dZ[p][m] = dY[p * ldd + doff + m], zeroed where
+// Hmask[p][m] <= 0 (Hmask = the layer's post-ReLU output, NULL for the linear heads);  W row-major [M][K]
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void generic_dgrad_kernel(long P, int M, int K, int koff, int Kn, const float* __restrict__ dY, int ldd, int doff,
+                                                           const float* __restrict__ Hmask, const float* __restrict__ Wt, float* __restrict__ dX,
+                                                           int ldx, int xoff) {
+    __shared__ float xs[GL_PTS * GL_LD], ws[GL_OUT * GL_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const long p0 = (long)blockIdx.x * GL_PTS;
+    const int o0 = blockIdx.y * GL_OUT;                    // first output column (k) of this tile
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int m0 = 0; m0 < M; m0 += GL_K) {
+        __syncthreads();
+        for (int e = tid; e < GL_PTS * GL_K; e += 256) {
+            const int pt = e / GL_K, mm = m0 + e % GL_K;
+            const long p = p0 + pt;
+            float v = 0.0f;
+            if (p < P && mm < M) {
+                v = dY[p * ldd + doff + mm];
+                if (Hmask && !(Hmask[p * M + mm] > 0.0f)) v = 0.0f;
+            }
+            xs[pt * GL_LD + e % GL_K] = v;
+        }
+        for (int e = tid; e < GL_OUT * GL_K; e += 256) {
+            const int o = e % GL_OUT, mm = m0 + e / GL_OUT;      // consecutive threads -> consecutive k of one row of W
+            ws[o * GL_LD + e / GL_OUT] = (o0 + o < Kn && mm < M) ? Wt[(long)mm * K + koff + o0 + o] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GL_K / 2; ++s)      // A: lane (k, h) = W[m0 + 2s + h][k];  B: lane (n, h) = dZ[point n of this wave][m0 + 2s + h]
+            acc = mfma32(ws[n * GL_LD + 2 * s + h], xs[(wave * 32 + n) * GL_LD + 2 * s + h], acc);
+    }
+    const long p = p0 + wave * 32 + n;
+    if (p >= P) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < Kn) {
+            float* q = dX + p * ldx + xoff + k;
+            *q = ACCUM ? __fadd_rn(*q, acc[r]) : acc[r];
+        }
+    }
+}
+
+// dW[m][k] += sum_p dZ[p][m] Xc[p][k] for k < K = K1 + K2 (Xc = [X1 | X2]),  db[m] += sum_p dZ[p][m] (the column k == K of the tile grid,
+// whose operand is 1).  Workgroup = one 32 x 32 tile of (m, k) x a slab of GW_PTS points, a quarter of the slab per wave.
+constexpr int GW_PTS = 2048;
+__global__ __launch_bounds__(256) void generic_wgrad_kernel(long P, int M, int K1, int K2, const float* __restrict__ dY, int ldd, int doff,
+                                                           const float* __restrict__ Hmask, const float* __restrict__ X1, const float* __restrict__ X2,
+                                                           float* __restrict__ dW, float* __restrict__ db) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32, K = K1 + K2;
+    const long pa = (long)blockIdx.z * GW_PTS + wave * (GW_PTS / 4), pb = min(pa + GW_PTS / 4, P);
+    const int m = m0 + n, k = k0 + n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (long ps = pa; ps < pb; ps += 2) {                   // (uniform trip count: every lane takes part in every MFMA)
+        const long p = ps + h;
+        float a = 0.0f, b = 0.0f;
+        if (p < pb) {
+            if (m < M) {
+                a = dY[p * ldd + doff + m];
+                if (Hmask && !(Hmask[p * M + m] > 0.0f)) a = 0.0f;
+            }
+            if (k < K1) b = X1[p * K1 + k];
+            else if (k < K) b = X2[p * K2 + (k - K1)];
+            else if (k == K) b = 1.0f;
+        }
+        acc = mfma32(a, b, acc);                              // A: lane (m, h) = dZ[p][m];  B: lane (k, h) = Xc[p][k]
+    }
+    if (k > K) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mr = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (mr < M) unsafeAtomicAdd(k < K ? dW + (long)mr * K + k : db + mr, acc[r]);
+    }
+}
+
+// gradients of the decoder inputs -> gradient planes: the transpose of generic_inputs_kernel, one thread per (point, input column)
+__global__ void generic_inputs_backward_kernel(SceneDev sc, GenGeom g, long P, const float* __restrict__ x, const float* __restrict__ dXd,
+                                               const float* __restrict__ dXr, float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2,
+                                               float* __restrict__ g3) {
+    const int K = g.Kd + g.Kr;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * K) return;
+    const long p = idx / K;
+    const int j = (int)(idx - p * K);
+    const float* q = x + p * 6;
+    const float n0 = norm_coord(q[0], sc.lo[0], sc.range[0]), n1 = norm_coord(q[1], sc.lo[1], sc.range[1]), n2 = norm_coord(q[2], sc.lo[2], sc.range[2]);
+    float* gp[4] = {g0, g1, g2, g3};
+    auto pos_taps = [&](int d) {
+        const float* M = sc.proj + 6 * d;
+        return gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+    };
+    auto view_taps = [&]() {
+        const float az = atan2f(q[4], q[3]);
+        const float el = atan2f(q[5], sqrtf(__fadd_rn(__fmul_rn(q[3], q[3]), __fmul_rn(q[4], q[4]))));
+        return gen_taps(sc.ph[3], sc.pw[3], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]));
+    };
+    auto scatter = [&](int d, const GenTaps& t, int c, float v) {
+        if (!gp[d] || v == 0.0f) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t.w[i] != 0.0f) unsafeAtomicAdd(gp[d] + t.o[i] + c, v * t.w[i]);
+    };
+    auto scatter_pos = [&](int c, float v) {                 // combine_pos_planes transposed, column c of its result
+        if (g.proj == 2) { scatter(c / g.C, pos_taps(c / g.C), c % g.C, v); return; }
+        const float f = g.proj == 1 ? v / 3.0f : v;
+        for (int d = 0; d < 3; ++d) scatter(d, pos_taps(d), c, f);
+    };
+    auto combined_pos = [&](int c) {
+        if (g.proj == 2) return gen_blend(sc.plane[c / g.C], pos_taps(c / g.C), c % g.C);
+        const float s = __fadd_rn(__fadd_rn(gen_blend(sc.plane[0], pos_taps(0), c), gen_blend(sc.plane[1], pos_taps(1), c)), gen_blend(sc.plane[2], pos_taps(2), c));
+        return g.proj == 1 ? __fdiv_rn(s, 3.0f) : s;
+    };
+    if (j < g.Kd) { scatter_pos(j, dXd[p * g.Kd + j]); return; }
+    const int c = j - g.Kd;
+    const float v = dXr[p * g.Kr + c];
+    if (g.view == 4) {
+        if (c < 3 * g.C) scatter(c / g.C, pos_taps(c / g.C), c % g.C, v);
+        else scatter(3, view_taps(), c - 3 * g.C, v);
+    } else if (g.view == 3) {
+        if (c < g.Kd) scatter_pos(c, v);
+        else scatter(3, view_taps(), c - g.Kd, v);
+    } else if (g.view == 0) {
+        scatter_pos(c, v);
+        scatter(3, view_taps(), c, v);
+    } else if (g.view == 1) {
+        scatter_pos(c, v * 0.5f);
+        scatter(3, view_taps(), c, v * 0.5f);
+    } else {                                                 // mult: pp * (1 + vv)
+        const GenTaps tv = view_taps();
+        const float pp = combined_pos(c), vv = gen_blend(sc.plane[3], tv, c);
+        scatter_pos(c, v * __fadd_rn(1.0f, vv));
+        scatter(3, tv, c, v * pp);
+    }
+}
+
 constexpr long GEN_CHUNK = 1L << 20;       // points per pass of the layer stack (bounds the activation workspace)
+constexpr long GEN_BWD_CHUNK = 1L << 17;   // the backward keeps every layer's output of a chunk
 
 }  // namespace nvsr
 
@@ -229,6 +378,120 @@ int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* ge
                                out + a * 4, 4, rgb ? 0 : 3);
             if (int e = NVSR_CHECK_LAUNCH()) return e;
             w += (long)M * g.hidden + M;
+        }
+    }
+    return NVSR_OK;
+}
+
+static int64_t gen_bwd_floats_per_point(const GenGeom& g) { return 2 * (int64_t)(g.Kd + g.Kr) + (int64_t)(g.nd + g.nr + 2) * g.hidden; }
+
+int64_t nvsr_generic_decode_backward_workspace_floats(const nvsr_decoder_geometry* geom, int64_t P) {
+    GenGeom g;
+    if (gen_resolve(geom, &g) || P < 0) return -1;
+    return (P < GEN_BWD_CHUNK ? P : GEN_BWD_CHUNK) * gen_bwd_floats_per_point(g);
+}
+
+int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x,
+                                 const float* d_out, float* d_natural, float* d_plane0, float* d_plane1, float* d_plane2, float* d_plane3,
+                                 float* workspace, nvsr_stream_t stream_) {
+    GenGeom g;
+    if (int e = gen_resolve(geom, &g)) return e;
+    if (!scene || !natural || !x || !d_out || !workspace) return NVSR_ERR_NULL;
+    for (int d = 0; d < 4; ++d) {
+        if (!scene->planes[d]) return NVSR_ERR_NULL;
+        const int64_t cc = d < 3 ? g.C : g.Cv;
+        if (scene->ph[d] < 1 || scene->pw[d] < 1 || (int64_t)scene->ph[d] * scene->pw[d] * cc >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
+    }
+    if (P < 0 || g.nd + g.nr > 128) return NVSR_ERR_SHAPE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const SceneDev sc = to_dev(scene);
+    const bool want_planes = d_plane0 || d_plane1 || d_plane2 || d_plane3;
+    // offsets of the layers in the natural blob (state-dict order: density layers, fc_alpha, rgb layers, fc_rgb; weight then bias)
+    long woff[2][65];
+    {
+        long o = 0;
+        for (int dec = 0; dec < 2; ++dec) {
+            const int nl = dec ? g.nr : g.nd;
+            for (int l = 0; l < nl; ++l) { woff[dec][l] = o; o += (long)g.hidden * gen_layer_in(g, dec, l) + g.hidden; }
+            woff[dec][nl] = o;
+            o += (long)(dec ? 3 : 1) * g.hidden + (dec ? 3 : 1);
+        }
+    }
+    for (int64_t a = 0; a < P; a += GEN_BWD_CHUNK) {
+        const long n = (long)((P - a) < GEN_BWD_CHUNK ? (P - a) : GEN_BWD_CHUNK);
+        float* Xin[2] = {workspace, workspace + n * g.Kd};
+        float* Hs[2] = {Xin[1] + n * g.Kr, Xin[1] + n * g.Kr + (long)g.nd * n * g.hidden};          // [layer][n][hidden] per decoder
+        float* dXin[2] = {Hs[1] + (long)g.nr * n * g.hidden, Hs[1] + (long)g.nr * n * g.hidden + n * g.Kd};
+        float* dH[2] = {dXin[1] + n * g.Kr, dXin[1] + n * g.Kr + n * g.hidden};
+        const float* xa = x + a * 6;
+        const float* da = d_out + a * 4;
+        const long threads = n * (g.Kd + g.Kr);
+        hipLaunchKernelGGL(generic_inputs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, Xin[0], Xin[1]);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+        const dim3 pts((unsigned)((n + GL_PTS - 1) / GL_PTS));
+        const unsigned slabs = (unsigned)((n + GW_PTS - 1) / GW_PTS);
+        if (hipMemsetAsync(dXin[0], 0, sizeof(float) * n * (g.Kd + g.Kr), stream) != hipSuccess) return NVSR_ERR_LAUNCH;
+        for (int dec = 0; dec < 2; ++dec) {
+            const float* in0 = Xin[dec];
+            const int k0 = dec ? g.Kr : g.Kd, nl = dec ? g.nr : g.nd, Mh = dec ? 3 : 1, hoff = dec ? 0 : 3;
+            // forward with every layer's output kept
+            const float* cur = in0;
+            int cur_k = k0;
+            for (int l = 0; l < nl; ++l) {
+                const bool skip = l > 0 && gen_skip_layer(l - 1, g.skip);
+                const int K1 = cur_k, K2 = skip ? k0 : 0;
+                const float* w = natural + woff[dec][l];
+                float* y = Hs[dec] + (long)l * n * g.hidden;
+                hipLaunchKernelGGL(generic_linear_kernel<true>, dim3(pts.x, (g.hidden + GL_OUT - 1) / GL_OUT), dim3(256), 0, stream, n, g.hidden, K1, K2,
+                                   cur, in0, w, w + (long)g.hidden * (K1 + K2), y, g.hidden, 0);
+                if (int e = NVSR_CHECK_LAUNCH()) return e;
+                cur = y; cur_k = g.hidden;
+            }
+            // head: d_out[:, hoff : hoff + Mh] -> dH[0]; its weight gradient from the last layer's output
+            const float* wh = natural + woff[dec][nl];
+            if (d_natural) {
+                float* gw = d_natural + woff[dec][nl];
+                hipLaunchKernelGGL(generic_wgrad_kernel, dim3(1, (g.hidden + 1 + 31) / 32, slabs), dim3(256), 0, stream, n, Mh, g.hidden, 0, da, 4, hoff,
+                                   (const float*)nullptr, cur, cur, gw, gw + (long)Mh * g.hidden);
+                if (int e = NVSR_CHECK_LAUNCH()) return e;
+            }
+            hipLaunchKernelGGL(generic_dgrad_kernel<false>, dim3(pts.x, (g.hidden + GL_OUT - 1) / GL_OUT), dim3(256), 0, stream, n, Mh, g.hidden, 0, g.hidden,
+                               da, 4, hoff, (const float*)nullptr, wh, dH[0], g.hidden, 0);
+            if (int e = NVSR_CHECK_LAUNCH()) return e;
+            int cb = 0;
+            for (int l = nl - 1; l >= 0; --l) {
+                const bool skip = l > 0 && gen_skip_layer(l - 1, g.skip);
+                const int K1 = l == 0 ? k0 : g.hidden, K2 = skip ? k0 : 0, K = K1 + K2;
+                const float* X1 = l == 0 ? in0 : Hs[dec] + (long)(l - 1) * n * g.hidden;
+                const float* Hl = Hs[dec] + (long)l * n * g.hidden;
+                const float* w = natural + woff[dec][l];
+                if (d_natural) {
+                    float* gw = d_natural + woff[dec][l];
+                    hipLaunchKernelGGL(generic_wgrad_kernel, dim3((g.hidden + 31) / 32, (K + 1 + 31) / 32, slabs), dim3(256), 0, stream, n, g.hidden, K1, K2,
+                                       dH[cb], g.hidden, 0, Hl, X1, in0, gw, gw + (long)g.hidden * K);
+                    if (int e = NVSR_CHECK_LAUNCH()) return e;
+                }
+                if (l > 0) {
+                    hipLaunchKernelGGL(generic_dgrad_kernel<false>, dim3(pts.x, (K1 + GL_OUT - 1) / GL_OUT), dim3(256), 0, stream, n, g.hidden, K, 0, K1,
+                                       dH[cb], g.hidden, 0, Hl, w, dH[cb ^ 1], g.hidden, 0);
+                    if (int e = NVSR_CHECK_LAUNCH()) return e;
+                    if (skip && want_planes) {
+                        hipLaunchKernelGGL(generic_dgrad_kernel<true>, dim3(pts.x, (K2 + GL_OUT - 1) / GL_OUT), dim3(256), 0, stream, n, g.hidden, K, K1, K2,
+                                           dH[cb], g.hidden, 0, Hl, w, dXin[dec], k0, 0);
+                        if (int e = NVSR_CHECK_LAUNCH()) return e;
+                    }
+                } else if (want_planes) {
+                    hipLaunchKernelGGL(generic_dgrad_kernel<true>, dim3(pts.x, (K1 + GL_OUT - 1) / GL_OUT), dim3(256), 0, stream, n, g.hidden, K, 0, K1,
+                                       dH[cb], g.hidden, 0, Hl, w, dXin[dec], k0, 0);
+                    if (int e = NVSR_CHECK_LAUNCH()) return e;
+                }
+                cb ^= 1;
+            }
+        }
+        if (want_planes) {
+            hipLaunchKernelGGL(generic_inputs_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, dXin[0], dXin[1],
+                               d_plane0, d_plane1, d_plane2, d_plane3);
+            if (int e = NVSR_CHECK_LAUNCH()) return e;
         }
     }
     return NVSR_OK;

@@ -266,7 +266,7 @@ class TwoDimPlanesModel(nn.Module):
     def is_native_geometry(self):
         """the configuration the fused MFMA kernels are compiled for: 3 + 1 planes x 48 channels, 'avg' / 'concat_pos', 4 + 4 layers x 128,
         no skip layer (every shipped YAML).  Any other geometry the reference's layer sizes admit renders through the generic kernels
-        (csrc/generic.hip: forward only, activations through HBM)."""
+        and trains through the generic kernels (csrc/generic.hip: plain layer-by-layer kernels, activations through HBM)."""
         return (self.use_viewdirs and self.num_density_planes == 3 and self.num_plane_channels == capi.PLANE_CHANNELS
                 and self.num_viewdir_plane_channels == capi.PLANE_CHANNELS and self.dec_channels == capi.DEC_CHANNELS
                 and self.dec_density_layers == 4 and self.dec_rgb_layers == 4 and self.ensemble_size == 1
@@ -278,8 +278,8 @@ class TwoDimPlanesModel(nn.Module):
         if not self.is_native_geometry():
             raise NotImplementedError(
                 "this entry point (training / fused passes) runs on the kernels compiled for the shipped configuration (3+1 planes x 48 "
-                "channels, 'avg' / 'concat_pos', 4+4 layers x 128, no skip layer); other TwoDimPlanesModel geometries are rendered by the "
-                "generic forward kernels only")
+                "channels, 'avg' / 'concat_pos', 4+4 layers x 128, no skip layer); other TwoDimPlanesModel geometries go through the "
+                "generic kernels (model.forward / run_one_iter_of_nerf pass by pass)")
 
     def generic_geometry(self):
         """[plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every, proj, view] for
@@ -383,11 +383,17 @@ class TwoDimPlanesModel(nn.Module):
         return out
 
     def _generic_forward(self, x):
-        """forward through the generic kernels (any geometry): inference only"""
-        if torch.is_grad_enabled() and self.training and (any(p.requires_grad for p in self.decoder_parameters()) or
-                                                          any(p.requires_grad for p in self.planes_.values())):
-            raise NotImplementedError("training is implemented for the shipped decoder geometry only; this geometry renders (inference) "
-                                      "through the generic kernels")
+        """forward through the generic kernels (any geometry); in training mode with gradients for the planes and the decoder"""
+        if torch.is_grad_enabled():                                    # (like any torch module: a graph whenever gradients are on)
+            names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
+            dec = any(p.requires_grad for p in self.decoder_parameters())
+            if dec or any(self.planes_[n].requires_grad for n in names):
+                if hasattr(self, "SR_model") and not self.skip_SR_:
+                    raise NotImplementedError("training THROUGH super-resolved planes is implemented for the shipped decoder geometry only")
+                if self.training:
+                    np.random.randint(self.ensemble_size)             # models.py:393 (see forward())
+                planes = [self.planes_[n] for n in names]
+                return _GenericDecodeFn.apply(self, x, *planes, self.natural_blob(differentiable=True) if dec else None)
         if hasattr(self, "SR_model") and not self.skip_SR_:
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]
             names = [n for n in names if self._should_SR(n)]
@@ -504,6 +510,33 @@ class _DecodePointsFn(torch.autograd.Function):
                                                       rec, need_planes, arith)
         gnat = torch.ops.nvsr.decoder_weight_grad(rec, P, 1, arith) if (rec is not None and need[6]) else None
         return (None, None) + tuple(from_channel_last(g, like=p_) if n else None for g, p_, n in zip(gplanes, ctx.plane_srcs, need_planes)) + (gnat,)
+
+
+class _GenericDecodeFn(torch.autograd.Function):
+    """TwoDimPlanesModel.forward for a decoder geometry other than the shipped one, with gradients for the planes and the decoder
+    (torch.ops.nvsr.triplane_decode_generic / _backward: csrc/generic.hip recomputes the forward in the backward)."""
+
+    @staticmethod
+    def forward(ctx, model, x, p0, p1, p2, pv, nat):
+        planes_cl = [to_channel_last(p.detach()) for p in (p0, p1, p2, pv)]
+        planes_cl, consts = model.scene_args(planes=planes_cl, check_native=False)
+        natural = model.natural_blob() if nat is None else nat.detach()
+        capi.require_cuda(natural)
+        geometry = model.generic_geometry()
+        ctx.plane_srcs = (p0, p1, p2, pv)
+        ctx.state = (planes_cl, consts, natural, geometry, x)
+        return torch.ops.nvsr.triplane_decode_generic(planes_cl, consts, natural, geometry, x)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        planes_cl, consts, natural, geometry, x = ctx.state
+        need = ctx.needs_input_grad
+        need_planes = [bool(n) for n in need[2:6]]
+        if not any(need_planes) and not need[6]:
+            return (None,) * 7
+        g = torch.ops.nvsr.triplane_decode_generic_backward(planes_cl, consts, natural, geometry, x, capi.f32c(g_out), bool(need[6]), need_planes)
+        return (None, None) + tuple(from_channel_last(gp, like=p_) if n else None for gp, p_, n in zip(g[1:], ctx.plane_srcs, need_planes)) + \
+               (g[0] if need[6] else None,)
 
 
 # =======================================================================================================================

@@ -194,7 +194,7 @@ def _(planes, consts, packed, x):
 
 @custom_op("nvsr::triplane_decode_generic", mutates_args=(), device_types="cuda")
 def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor) -> Tensor:
-    """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (inference; csrc/generic.hip).
+    """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (csrc/generic.hip).
     geometry = [plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every (0 = None), proj_combination
     (0 sum, 1 avg, 2 concat), viewdir_combination (0 sum, 1 avg, 2 mult, 3 concat, 4 concat_pos)]; natural = the parameters in
     state-dict order; planes channel-last [H,W,plane_channels] x 3 + [H,W,viewdir_channels]."""
@@ -216,6 +216,36 @@ def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], n
 @triplane_decode_generic.register_fake
 def _(planes, consts, natural, geometry, x):
     return x.new_empty((x.shape[0], 4))
+
+
+@custom_op("nvsr::triplane_decode_generic_backward", mutates_args=(), device_types="cuda")
+def triplane_decode_generic_backward(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor,
+                                     g_out: Tensor, want_natural: bool, want_planes: Sequence[bool]) -> List[Tensor]:
+    """Backward of triplane_decode_generic (csrc/generic.hip; the reference: torch.autograd through models.py:381-421): g_out [P,4] ->
+    [d_natural, d_plane0 .. d_plane3] (channel-last like the planes; a gradient that is not wanted comes back as an empty tensor)."""
+    x, natural, g_out = _c(x), _c(natural), _c(g_out)
+    geo = capi.DecoderGeometry(*[int(v) for v in geometry])
+    n = capi.lib().nvsr_generic_decoder_natural_floats(C.byref(geo))
+    if n < 0:
+        raise capi.NvsrError("this decoder geometry is inconsistent (the reference's own layer sizes do not admit it)")
+    assert natural.numel() == n, "natural blob: %d floats, the geometry needs %d" % (natural.numel(), n)
+    sc = _scene(planes, consts, channels=(geo.plane_channels, geo.viewdir_channels))
+    P = x.shape[0]
+    assert tuple(g_out.shape) == (P, 4)
+    want_planes = [bool(w) for w in want_planes]
+    g_nat = torch.zeros(n if want_natural else 0, dtype=torch.float32, device=x.device)
+    g_pl = [torch.zeros_like(pl) if w else _f(0, like=x) for pl, w in zip(planes, want_planes)]
+    if P and (want_natural or any(want_planes)):
+        ws = _f(capi.lib().nvsr_generic_decode_backward_workspace_floats(C.byref(geo), P), like=x)
+        capi.call("nvsr_generic_decode_backward", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x), capi.ptr(g_out),
+                  capi.ptr(g_nat) if want_natural else None, *[capi.ptr(g) if w else None for g, w in zip(g_pl, want_planes)], capi.ptr(ws),
+                  capi.stream())
+    return [g_nat] + g_pl
+
+
+@triplane_decode_generic_backward.register_fake
+def _(planes, consts, natural, geometry, x, g_out, want_natural, want_planes):
+    return [natural.new_empty(natural.numel() if want_natural else 0)] + [pl.new_empty(pl.shape if w else (0,)) for pl, w in zip(planes, want_planes)]
 
 
 @custom_op("nvsr::ray_points", mutates_args=(), device_types="cuda")

@@ -281,22 +281,29 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
 
 def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f):
     """predict_and_render_radiance for decoder geometries other than the shipped one, pass by pass like the reference (train_utils.py:95-180):
-    depths -> run_network (the model's generic forward kernels on the [N*S,6] point list) -> compositing -> importance resampling -> again.
-    Inference only (the models raise when gradients are asked for)."""
+    depths -> run_network (the model's generic kernels on the [N*S,6] point list) -> compositing -> importance resampling -> again.
+    With gradients enabled the model call and the compositing are the differentiable operators (the importance samples are detached,
+    train_utils.py:153)."""
     nv = torch.ops.nvsr
     N = rays.shape[0]
     white, lindisp = bool(m.white_background), bool(m.lindisp)
     if N == 0:
         e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=rays.device)
         return (e(0, 3), e(0), e(0)) + ((e(0, 3), e(0), e(0)) if Nf > 0 else (None, None, None)) + (None, None, None)
+    def composite(raw, z, noise, want_weights):
+        if raw.requires_grad:
+            rgb, disp, acc, w, _ = nv.composite(raw, z, rays[:, 3:6].contiguous(), noise, white, False)
+            return rgb, disp, acc, w.detach()
+        return nv.composite_rays(raw, z, rays, noise, white, want_weights)
+
     z_c = nv.coarse_z(rays, Nc, lindisp, t_rand)
     raw = model_coarse(nv.ray_points(rays, z_c)).reshape(N, Nc, 4)
-    rgb_c, disp_c, acc_c, w_c = nv.composite_rays(raw, z_c, rays, n_c, white, Nf > 0)
+    rgb_c, disp_c, acc_c, w_c = composite(raw, z_c, n_c, Nf > 0)
     rgb_f = disp_f = acc_f = None
     if Nf > 0:
         z_f = nv.importance_resample(z_c, w_c, Nf, u)
         raw_f = model_fine(nv.ray_points(rays, z_f)).reshape(N, Nc + Nf, 4)
-        rgb_f, disp_f, acc_f, _ = nv.composite_rays(raw_f, z_f, rays, n_f, white, False)
+        rgb_f, disp_f, acc_f, _ = composite(raw_f, z_f, n_f, False)
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
 
 

@@ -991,8 +991,9 @@ G18_VARIANTS = {
 def g18_decoder_variants():
     """TwoDimPlanesModel.forward (models.py:381-421) for decoder geometries other than the shipped one: other widths, plane channel counts,
     proj_combination sum / concat, viewdir_proj_combination sum / mult / concat, skip layers, unequal layer counts.  Per variant: the
-    points, planes, box, state dict and the reference's output; for one variant also an eval_nerf render (8 x 8 rays, 16 + 16 samples)."""
-    arrs = {}
+    points, planes, box, state dict and the reference's output; for one variant also an eval_nerf render (8 x 8 rays, 16 + 16 samples).
+    Also writes g19_decoder_variant_grads.npz: the reference's autograd gradients of planes and decoder parameters for five of the variants."""
+    arrs, grads = {}, {}
     R, Rv, P = 10, 6, 203
     for vi, (name, kw) in enumerate(G18_VARIANTS.items()):
         torch.manual_seed(180 + vi)
@@ -1035,6 +1036,23 @@ def g18_decoder_variants():
         for dnum in range(4):
             arrs[pre + "plane%d" % dnum] = npy(planes[models.get_plane_name(sid, dnum)])
         arrs.update(state_arrays(pre + "sd.", m))
+        if name != "wide256":
+            # g19: torch.autograd through the same forward -- gradients of the four planes and of the decoder parameters (state-dict order:
+            # density_dec.0.{l}.{weight,bias}, fc_alpha.0, rgb_dec.0.{l}, fc_rgb.0) for a fixed cotangent (its own generator: g18 is unchanged)
+            gout = torch.randn(P, 4, generator=torch.Generator().manual_seed(1900 + vi))
+            sdp = dict(m.named_parameters())
+            keys = ["density_dec.0.%d" % i for i in range(kwargs.get("dec_density_layers", 4))] + ["fc_alpha.0"] + \
+                   ["rgb_dec.0.%d" % i for i in range(kwargs.get("dec_rgb_layers", 4))] + ["fc_rgb.0"]
+            params = [sdp[k + sfx] for k in keys for sfx in (".weight", ".bias")]
+            plist = [planes[models.get_plane_name(sid, dnum)] for dnum in range(4)]
+            for t_ in params + plist:
+                t_.requires_grad_(True)
+                t_.grad = None
+            (m(x) * gout).sum().backward()
+            grads[pre + "gout"] = npy(gout)
+            grads[pre + "gnat"] = np.concatenate([npy(t_.grad).reshape(-1) for t_ in params])
+            for dnum in range(4):
+                grads[pre + "gplane%d" % dnum] = npy(plist[dnum].grad)
         if name == "concat24":
             arrs.update(state_arrays(pre + "render.coarse.", m))
             arrs.update(state_arrays(pre + "render.fine.", mf))
@@ -1049,6 +1067,7 @@ def g18_decoder_variants():
     arrs["box"] = np.array(BOX, np.float64)
     arrs["pose"] = POSE
     save("g18_decoder_variants.npz", **arrs)
+    save("g19_decoder_variant_grads.npz", **grads)
 
 
 if __name__ == "__main__":

@@ -595,7 +595,7 @@ def test_generic_decoder_geometries_vs_reference_and_oracle(hip):
     proj_combination sum / concat, viewdir_proj_combination sum / mult / concat, skip layers, 5 + 3 layers (config/TrainModels.yml lists such
     alternatives) -- through torch.ops.nvsr.triplane_decode_generic: the reference's own outputs (g18) within 2e-5 of the output range,
     the numpy restatement on a large ragged point list that crosses the kernel's chunk boundary, a render through eval_nerf against the
-    reference's pixels; training on such a geometry and geometries the reference's own layer sizes do not admit are refused loudly."""
+    reference's pixels; geometries the reference's own layer sizes do not admit are refused loudly."""
     from conftest import load_golden
     from oracle.generic_decoder import decode
     from test_oracle import G18_VARIANTS
@@ -631,14 +631,78 @@ def test_generic_decoder_geometries_vs_reference_and_oracle(hip):
     np.testing.assert_allclose(N_(rgb_c), g["concat24.render.rgb_coarse"], rtol=0, atol=3e-5)
     ef = np.abs(N_(rgb_f) - g["concat24.render.rgb_fine"]).max(-1)
     assert (ef <= 2e-4).mean() >= 0.95 and psnr(N_(rgb_f), g["concat24.render.rgb_fine"]) >= 70.0, ((ef <= 2e-4).mean(), ef.max())
-    # loud refusals
-    mc.train()
-    for p_ in mc.parameters():
-        p_.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        mc(T(g["concat24.x"]))
+    # loud refusal
     bad = hip.capi.DecoderGeometry(48, 48, 128, 4, 4, 0, 0, 3)          # 'concat' view features on summed position features (models.py:186-190)
     assert hip.capi.lib().nvsr_generic_decoder_natural_floats(C.byref(bad)) == -1
+
+
+def test_generic_decoder_gradients_vs_reference(hip):
+    """Training on decoder geometries other than the shipped one (csrc/generic.hip backward: forward recomputed with every layer's output
+    kept, weight / data gradient kernels, scatter through combination rule and bilinear taps): the reference's own torch.autograd
+    gradients of the four planes and of every decoder parameter (g19) for a fixed cotangent -- 'avg' + 'mult', 'sum' + 'sum', 'concat' +
+    'concat' on 24-channel planes, skip layers, 5 + 3 layers; then a few Adam steps through run_one_iter_of_nerf (pass by pass:
+    differentiable model call + differentiable compositing) must lower the loss."""
+    from conftest import load_golden
+    from test_oracle import G18_VARIANTS
+    from test_hip_parity import make_options
+    g, gg = load_golden("g18_decoder_variants.npz"), load_golden("g19_decoder_variant_grads.npz")
+    names = [n for n in G18_VARIANTS if n + ".gout" in gg]
+    assert len(names) == 5
+    for name in names:
+        m, sid, kw, sd_, planes = _variant_model(hip, g, name)
+        m.train()
+        params = m.decoder_parameters()
+        plist = [m.planes_[hip.models.get_plane_name(sid, d)] for d in range(4)]
+        for t_ in list(params) + plist:
+            t_.requires_grad_(True)
+        out = m(T(g[name + ".x"]))
+        np.testing.assert_allclose(N_(out), g[name + ".out"], rtol=0, atol=2e-5 * max(1.0, float(np.abs(g[name + ".out"]).max())), err_msg=name)
+        (out * T(gg[name + ".gout"])).sum().backward()
+        gnat = np.concatenate([N_(t_.grad).reshape(-1) for t_ in params])
+        ref = gg[name + ".gnat"]
+        assert gnat.shape == ref.shape
+        assert np.linalg.norm(gnat - ref) / np.linalg.norm(ref) < 2e-5, (name, np.linalg.norm(gnat - ref) / np.linalg.norm(ref))
+        np.testing.assert_allclose(gnat, ref, rtol=0, atol=3e-5 * float(np.abs(ref).max()), err_msg=name + " decoder")
+        for d in range(4):
+            got, refp = N_(plist[d].grad), gg[name + ".gplane%d" % d]
+            assert got.shape == refp.shape
+            assert np.linalg.norm(got - refp) / np.linalg.norm(refp) < 2e-5, (name, d)
+            np.testing.assert_allclose(got, refp, rtol=0, atol=3e-5 * float(np.abs(refp).max()), err_msg="%s plane %d" % (name, d))
+        # only what asks for a gradient gets one
+        for t_ in list(params) + plist:
+            t_.grad = None
+            t_.requires_grad_(False)
+        plist[1].requires_grad_(True)
+        (m(T(g[name + ".x"])) * T(gg[name + ".gout"])).sum().backward()
+        np.testing.assert_allclose(N_(plist[1].grad), gg[name + ".gplane1"], rtol=0, atol=3e-5 * float(np.abs(gg[name + ".gplane1"]).max()))
+        assert all(t_.grad is None for t_ in params) and plist[0].grad is None
+    # training through run_one_iter_of_nerf: 64 rays, 16 + 16 samples, planes + both decoders of the 'skip2' geometry
+    mc, sid, *_ = _variant_model(hip, g, "skip2")
+    mf, *_ = _variant_model(hip, g, "skip2")
+    mf.planes_ = mc.planes_
+    opts, scfg = make_options(16, 16)
+    for mm in (mc, mf):
+        mm.train()
+        for t_ in mm.decoder_parameters():
+            t_.requires_grad_(True)
+    for t_ in mc.planes_.values():
+        t_.requires_grad_(True)
+    opt = torch.optim.Adam(list(mc.decoder_parameters()) + list(mf.decoder_parameters()) + list(mc.planes_.values()), lr=2e-3)
+    H = W = 8
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+    batch = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    target = torch.rand((H * W, 3), generator=torch.Generator().manual_seed(4)).to(DEV) * 0.5 + 0.25
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        rgb_c, _, _, rgb_f, *_ = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="validation", scene_config=scfg)
+        loss = ((rgb_c - target) ** 2).mean() + ((rgb_f - target) ** 2).mean()
+        loss.backward()
+        assert all(t_.grad is not None and torch.isfinite(t_.grad).all() for t_ in opt.param_groups[0]["params"])
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0], losses
 
 
 def test_cumprod_exclusive_kernel(hip, oracle):
