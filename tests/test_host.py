@@ -38,6 +38,32 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.nvsr_render_workspace_floats(7, 5, 3) == 2 * 36 + 56 + 4 * 7 * 8
 
 
+def test_generic_geometry_fixtures_match_the_blob_layout(pkg):
+    """g19 (the reference's autograd gradients for decoder geometries other than the shipped one): the gradient blob of every variant has
+    exactly the length nvsr_generic_decoder_natural_floats gives for its geometry (state-dict order: density layers, fc_alpha, rgb layers,
+    fc_rgb), the plane gradients have the planes' shapes, and the backward's workspace sizing is positive and grows with the chunk"""
+    import ctypes as C
+    from conftest import load_golden
+    from test_oracle import G18_VARIANTS, g18_variant
+    g, gg = load_golden("g18_decoder_variants.npz"), load_golden("g19_decoder_variant_grads.npz")
+    lib = pkg.capi.lib()
+    seen = 0
+    for name in G18_VARIANTS:
+        if name + ".gout" not in gg:
+            continue
+        seen += 1
+        kw, sd, planes = g18_variant(g, name)
+        m = pkg.models.TwoDimPlanesModel(use_viewdirs=True, align_corners=True, **kw)
+        geo = pkg.capi.DecoderGeometry(*m.generic_geometry())
+        assert gg[name + ".gnat"].size == lib.nvsr_generic_decoder_natural_floats(C.byref(geo)) == sum(p.numel() for p in m.decoder_parameters())
+        for d in range(4):
+            assert gg[name + ".gplane%d" % d].shape == planes[d].shape
+        assert gg[name + ".gout"].shape == (g[name + ".x"].shape[0], 4)
+        w1, w2 = (lib.nvsr_generic_decode_backward_workspace_floats(C.byref(geo), P) for P in (1000, 1 << 20))
+        assert 0 < w1 < w2 and w2 == (1 << 17) * (w1 // 1000)
+    assert seen == 5
+
+
 def test_mirror_exposes_reference_surface(pkg):
     for mod, names in {
         "nerf_helpers": ["get_ray_bundle", "ndc_rays", "sample_pdf_2", "cumprod_exclusive", "get_minibatches", "meshgrid_xy", "imread", "im_resize",
