@@ -21,6 +21,9 @@
 #include "limb_core.h"
 #include "side_work.h"
 
+#ifndef R3_GATHER_NT
+#define R3_GATHER_NT 0
+#endif
 #ifndef R3_STAMP
 #define R3_STAMP 0    // debug builds: raw_out[ray, s = 0..1, :] of tile X = cycles per sample spent in 7 sections of the step (tools/limb_stamp.py)
 #endif
@@ -114,7 +117,11 @@ __device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float
             off = off & 0xffff;                                  // all gathers inside the first 256 KB of the plane (timing experiment)
             off -= off % 48;
 #endif
+#if R3_GATHER_NT            // timing experiment: non-temporal plane gathers (do they leave more of the L2 to the weight stream?)
+            rt.r[tap][piece] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(jl.plane + off + HALF_C * h) + piece);
+#else
             rt.r[tap][piece] = reinterpret_cast<const f32x4*>(jl.plane + off + HALF_C * h)[piece];
+#endif
 #endif
         }
         const int w = v / 18, u = v % 18;
