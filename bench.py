@@ -629,6 +629,8 @@ def main():
                                                       "rows": "%d views per step, every view's rows sharded over the GPUs" % world}[partition]),
                    "rays_per_step_per_gpu": rays_per_step // (world if partition == "frame" else 1), "decoder_evals_per_ray": 256,
                    "partition": partition,
+                   "ray_order": "row-major (NVSR_ROW_ORDER)" if os.environ.get("NVSR_ROW_ORDER") else
+                                "8x4 pixel patches (train_utils.patch_order; same pixels bit for bit, returned in row-major order)",
                    "parallelism": {"view": "rays sharded by view, no collective",
                                    "frame": "rays of one frame sharded by row blocks, one all_gather of the pixels per frame",
                                    "rows": "rays of every frame sharded by row blocks (a rank renders its rows of all views in one launch), "
@@ -639,6 +641,8 @@ def main():
         # dominant kernel: fused fine render pass (192 of the 256 evaluations per ray), render2.hip
         rays = nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)
         N = rays.shape[0]
+        if not os.environ.get("NVSR_ROW_ORDER") and N >= nvsr_amd.train_utils.PATCH_ORDER_MIN_RAYS:
+            rays = rays.index_select(0, nvsr_amd.train_utils.patch_order(N, W, dev)[0])     # the order eval_nerf renders a frame in
         import ctypes as C
         capi = nvsr_amd.capi
         ws = torch.empty(capi.lib().nvsr_render_workspace_floats(N, 64, 128), device=dev)

@@ -61,12 +61,14 @@ def render_image_sharded(height, width, focal, model_coarse, model_fine, ray_ori
                          group=None, gather=True, render_fn=None):
     """eval_nerf with the rays of one view sharded over the ranks (contiguous row blocks).  Returns (rgb_coarse, rgb_fine) as
     [H,W,3] on every rank when gather=True, else this rank's [n_local,3] blocks and its (lo, hi)."""
+    grid = {}
     if render_fn is None:
         from .train_utils import run_one_iter_of_nerf as render_fn
+        grid = dict(ray_grid_width=width)      # (used when the rank's block is whole rows: the renderer then works in 8 x 4 pixel patches)
     rank, world = world_info(group)
     batch = torch.stack([ray_origins.reshape(-1, 3), ray_directions.reshape(-1, 3)], 0)
     local, (lo, hi) = shard_rays(batch, rank, world)
-    out = render_fn(height, width, focal, model_coarse, model_fine, local, options, scene_id, mode="validation", scene_config=scene_config)
+    out = render_fn(height, width, focal, model_coarse, model_fine, local, options, scene_id, mode="validation", scene_config=scene_config, **grid)
     rgb_c, rgb_f = out[0], out[3]
     if not gather:
         return rgb_c, rgb_f, (lo, hi)
@@ -83,8 +85,10 @@ def render_views_sharded(height, width, focal, model_coarse, model_fine, poses, 
     rank's blocks of the V views are simply concatenated: with V = world views per step a rank renders one frame's worth of rays per
     step, whatever the world size).  One all_gather assembles the frames.  Returns (rgb_coarse, rgb_fine) as [V,H,W,3] on every rank
     (gather=True) or this rank's [V, rows, W, 3] blocks and its (lo, hi)."""
+    grid = {}
     if render_fn is None:
         from .train_utils import run_one_iter_of_nerf as render_fn
+        grid = dict(ray_grid_width=width)
     if ray_fn is None:
         from .nerf_helpers import get_ray_bundle as ray_fn
     rank, world = world_info(group)
@@ -95,7 +99,7 @@ def render_views_sharded(height, width, focal, model_coarse, model_fine, poses, 
         ro, rd = ray_fn(height, width, focal, pose)
         blocks.append(torch.stack([ro[lo:hi].reshape(-1, 3), rd[lo:hi].reshape(-1, 3)], 0))
     out = render_fn(height, width, focal, model_coarse, model_fine, torch.cat(blocks, 1), options, scene_id, mode="validation",
-                    scene_config=scene_config)
+                    scene_config=scene_config, **grid)
     local = [None if t is None else t.reshape(V, rows, width, 3) for t in (out[0], out[3])]
     if not gather:
         return local[0], local[1], (lo, hi)

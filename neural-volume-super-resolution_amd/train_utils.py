@@ -4,6 +4,7 @@ Same call surface as the reference (`run_one_iter_of_nerf` returns the 9-tuple, 
 ray-chunk and point-chunk Python loops of the reference collapse into one `nvsr_render_rays` call per ray block: coarse
 depths -> fused coarse pass -> inverse-CDF resampling + sort -> fused fine pass, all on the current stream."""
 import ctypes as C
+import os
 
 import torch
 
@@ -322,9 +323,38 @@ def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None
     return rays
 
 
+_PATCH_ORDER = {}
+PATCH_W, PATCH_H = 8, 4                  # 32 rays = one wave tile of the fused pass
+PATCH_ORDER_MIN_RAYS = 65536             # (the fused passes; below it the sample-parallel kernels do not tile by ray)
+
+
+def patch_order(n_rays, grid_width, device):
+    """(perm, inv) that reorder the rays of a row-major pixel grid [n_rays / grid_width, grid_width] into 8 x 4 pixel patches (row-major
+    inside a patch, patches row-major).  A wave tile of the fused render pass is 32 consecutive rays: as a patch they are at most 8
+    pixels apart instead of 32, their samples share more texels (fewer distinct cache lines per gather instruction, more L1 / L2 hits)
+    and the frame renders 1.8 % faster -- the pixels are the same bits, every ray is independent of its neighbours
+    (tools/ray_order_time.py).  Ragged edges are fine: any permutation is valid."""
+    key = (int(n_rays), int(grid_width), str(device))
+    hit = _PATCH_ORDER.get(key)
+    if hit is None:
+        rows = n_rays // grid_width
+        ys = torch.arange(rows, device=device)[:, None]
+        xs = torch.arange(grid_width, device=device)[None, :]
+        k = ((ys // PATCH_H) * ((grid_width + PATCH_W - 1) // PATCH_W) + xs // PATCH_W) * (PATCH_W * PATCH_H) + (ys % PATCH_H) * PATCH_W + xs % PATCH_W
+        perm = torch.argsort(k.reshape(-1))
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=device)
+        if len(_PATCH_ORDER) > 16:
+            _PATCH_ORDER.clear()
+        hit = _PATCH_ORDER[key] = (perm, inv)
+    return hit
+
+
 def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, options, scene_id, mode="train",
-                         encode_position_fn=None, encode_direction_fn=None, scene_config={}, randoms=None):
-    """train_utils.py:185-282 -> (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, None, None, None)"""
+                         encode_position_fn=None, encode_direction_fn=None, scene_config={}, randoms=None, ray_grid_width=None):
+    """train_utils.py:185-282 -> (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, None, None, None)
+    ray_grid_width (not in the reference): the rays are whole rows of a row-major pixel grid of this width (eval_nerf, the row-sharded
+    renders) -- an evaluation pass then renders them in patch order (patch_order) and returns the results in the caller's order."""
     if not isinstance(model_coarse, models.TwoDimPlanesModel):
         raise NotImplementedError("only the tri-plane model is on the accelerated path")
     if not options.nerf.use_viewdirs:
@@ -351,14 +381,23 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
             parts.append(p)
         randoms = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]} if parts else {}
     outs = []
-    step = MAX_RAYS_PER_LAUNCH if (model_coarse.is_native_geometry() and model_fine.is_native_geometry()) else MAX_RAYS_PER_LAUNCH_GENERIC
+    native = model_coarse.is_native_geometry() and model_fine.is_native_geometry()
+    inv = None
+    if (ray_grid_width and native and mode != "train" and not randoms and N >= PATCH_ORDER_MIN_RAYS
+            and N % int(ray_grid_width) == 0 and not os.environ.get("NVSR_ROW_ORDER")):
+        perm, inv = patch_order(N, ray_grid_width, rays.device)
+        rays = rays.index_select(0, perm)
+    step = MAX_RAYS_PER_LAUNCH if native else MAX_RAYS_PER_LAUNCH_GENERIC
+    if inv is not None:
+        step -= step % (PATCH_H * int(ray_grid_width))       # launches split between patch rows
     for a in range(0, max(N, 1), step):
         b = min(a + step, N)
         sub = None if randoms is None else {k: v[a:b] for k, v in randoms.items()}
         outs.append(predict_and_render_radiance(rays[a:b], model_coarse, model_fine, options, scene_id, mode=mode, randoms=sub if sub is not None else {}))
-    if len(outs) == 1:
-        return outs[0]
-    return tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs], 0) for i in range(9))
+    out = outs[0] if len(outs) == 1 else tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs], 0) for i in range(9))
+    if inv is not None:
+        out = tuple(None if t is None else t.index_select(0, inv) for t in out)
+    return out
 
 
 def eval_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins, ray_directions, options, scene_id,
@@ -369,7 +408,8 @@ def eval_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins
     batch_rays = torch.cat((ray_origins, ray_directions), dim=0)
     rgb_coarse, _, _, rgb_fine, _, _, rgb_SR, _, _ = run_one_iter_of_nerf(
         height, width, focal_length, model_coarse, model_fine, batch_rays, options, mode="validation",
-        encode_position_fn=encode_position_fn, encode_direction_fn=encode_direction_fn, scene_id=scene_id, scene_config=scene_config)
+        encode_position_fn=encode_position_fn, encode_direction_fn=encode_direction_fn, scene_id=scene_id, scene_config=scene_config,
+        ray_grid_width=width)
     rgb_coarse = rgb_coarse.reshape([height, width, -1])
     if rgb_fine is not None:
         rgb_fine = rgb_fine.reshape([height, width, -1])
