@@ -641,8 +641,10 @@ def main():
         # dominant kernel: fused fine render pass (192 of the 256 evaluations per ray), render2.hip
         rays = nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)
         N = rays.shape[0]
+        rays_row, inv = rays, None                        # (row-major: what the CPU baseline / PSNR check pairs with row-major images)
         if not os.environ.get("NVSR_ROW_ORDER") and N >= nvsr_amd.train_utils.PATCH_ORDER_MIN_RAYS:
-            rays = rays.index_select(0, nvsr_amd.train_utils.patch_order(N, W, dev)[0])     # the order eval_nerf renders a frame in
+            perm, inv = nvsr_amd.train_utils.patch_order(N, W, dev)
+            rays = rays.index_select(0, perm)             # the order eval_nerf renders a frame in: the kernel is timed on what the steps launch
         import ctypes as C
         capi = nvsr_amd.capi
         ws = torch.empty(capi.lib().nvsr_render_workspace_floats(N, 64, 128), device=dev)
@@ -699,7 +701,7 @@ def main():
             nvsr_amd.capi.set_decoder_arithmetic(mode)
             result["arithmetic_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
-            cb, psnr = cpu_baseline(nvsr_amd, mc, mf, sid, rays, bufs[3])
+            cb, psnr = cpu_baseline(nvsr_amd, mc, mf, sid, rays_row, bufs[3] if inv is None else bufs[3].index_select(0, inv))
             result["cpu_baseline"] = cb
             result["psnr_vs_oracle_db"] = psnr
             if "arithmetic_modes" in result:          # the same frame in every arithmetic against the same oracle rays
