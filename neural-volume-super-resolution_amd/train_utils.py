@@ -384,7 +384,7 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
     native = model_coarse.is_native_geometry() and model_fine.is_native_geometry()
     inv = None
     if (ray_grid_width and native and mode != "train" and not randoms and N >= PATCH_ORDER_MIN_RAYS
-            and N % int(ray_grid_width) == 0 and not os.environ.get("NVSR_ROW_ORDER")):
+            and N % int(ray_grid_width) == 0 and PATCH_H * int(ray_grid_width) <= MAX_RAYS_PER_LAUNCH and not os.environ.get("NVSR_ROW_ORDER")):
         perm, inv = patch_order(N, ray_grid_width, rays.device)
         rays = rays.index_select(0, perm)
     step = MAX_RAYS_PER_LAUNCH if native else MAX_RAYS_PER_LAUNCH_GENERIC
