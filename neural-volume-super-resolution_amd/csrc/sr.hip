@@ -218,6 +218,9 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV_COST_MODEL
+#define CV_COST_MODEL 2     // rows per tile of the limb convolution: 0 round 1's model, 1 always 4 rows, 2 measured round / row costs (SR stage 31.5 / 32.1 / 32.3 planes/s)
+#endif
 #ifndef CV_ABLATE
 #define CV_ABLATE 0     // variant builds of tools/conv_ablate.sh: 1 weight fragments of tap 0 only, 2 no patch loads, 4 no split + LDS writes
 #endif
@@ -469,7 +472,17 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         double best_cost = 1e300;
         for (int pb = 4; pb >= 2; --pb) {
             const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+#if CV_COST_MODEL == 0
             const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
+#elif CV_COST_MODEL == 1
+            const double cost = pb == 4 ? 0.0 : 1.0;
+#else
+            // rounds of the 512 workgroup slots; a last round of at most 256 tiles has every CU to itself (~0.62 of a full round's time);
+            // per row of a tile, 3-row tiles cost 1.13 x and 2-row tiles 1.39 x a 4-row tile's (their weight stream per MFMA is 4/3, 2 x)
+            const long full = tiles / 512, rest = tiles % 512;
+            const double rounds = (double)full + (rest == 0 ? 0.0 : rest <= 256 ? 0.62 : 1.0);
+            const double cost = rounds * pb * (pb == 4 ? 1.0 : pb == 3 ? 1.13 : 1.39);
+#endif
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
         if (cx.rows) best_pb = cx.rows;
