@@ -630,7 +630,7 @@ def main():
                    "rays_per_step_per_gpu": rays_per_step // (world if partition == "frame" else 1), "decoder_evals_per_ray": 256,
                    "partition": partition,
                    "ray_order": "row-major (NVSR_ROW_ORDER)" if os.environ.get("NVSR_ROW_ORDER") else
-                                "8x4 pixel patches (train_utils.patch_order; same pixels bit for bit, returned in row-major order)",
+                                "16x2 pixel patches in 128x32 pixel blocks (train_utils.patch_order; same pixels bit for bit, returned in row-major order)",
                    "parallelism": {"view": "rays sharded by view, no collective",
                                    "frame": "rays of one frame sharded by row blocks, one all_gather of the pixels per frame",
                                    "rows": "rays of every frame sharded by row blocks (a rank renders its rows of all views in one launch), "

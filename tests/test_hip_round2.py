@@ -706,18 +706,24 @@ def test_generic_decoder_gradients_vs_reference(hip):
 
 
 def test_patch_ordered_render_is_bit_identical_to_row_order(hip, monkeypatch):
-    """eval_nerf renders a frame's rays in 8 x 4 pixel patches (train_utils.patch_order: a wave tile of the fused passes is then a compact
-    patch instead of 32 pixels of a row -- 1.8 % faster on the 800 x 800 frame): every ray is independent, so the image must be the same
+    """eval_nerf renders a frame's rays in 16 x 2 pixel patches inside 128 x 32 pixel blocks (train_utils.patch_order: a wave tile of the
+    fused passes is then a compact patch instead of 32 pixels of a row -- 3 % faster on the 800 x 800 frame): every ray is independent, so the image must be the same
     bits as in row order (NVSR_ROW_ORDER=1), also for sizes that leave ragged patches at the right and bottom edges; and the order itself
     is a permutation that visits the grid patch by patch"""
     from test_hip_parity import make_options
     tu = hip.train_utils
     perm, inv = tu.patch_order(12 * 19, 19, DEV)
     assert sorted(N_(perm).tolist()) == list(range(12 * 19)) and torch.equal(perm[inv], torch.arange(12 * 19, device=DEV))
-    first = N_(perm[:32])
-    assert sorted(first.tolist()) == sorted(y * 19 + x for y in range(4) for x in range(8))           # the first patch: 8 x 4 pixels
-    last_cols = N_(perm[64:64 + 12])
-    assert sorted(last_cols.tolist()) == sorted(y * 19 + x for y in range(4) for x in range(16, 19))   # the ragged third patch: 3 x 4
+    pw, ph = tu.PATCH_W, tu.PATCH_H
+    assert pw * ph == 32 and (pw, ph) == (16, 2)
+    assert N_(perm[:32]).tolist() == [y * 19 + x for y in range(ph) for x in range(pw)]               # the first patch: 16 x 2 pixels, row-major
+    assert N_(perm[32:38]).tolist() == [y * 19 + x for y in range(ph) for x in range(16, 19)]         # the ragged second patch: 3 x 2
+    assert N_(perm[38:70]).tolist() == [y * 19 + x for y in range(2, 4) for x in range(pw)]           # then the next patch row of the block
+    # a grid wider and taller than a super-block: the first block (128 x 32 pixels) is visited completely before the second
+    Wb, Hb = tu.PATCH_W * tu.SUPER_W, tu.PATCH_H * tu.SUPER_H
+    perm2, _ = tu.patch_order((Hb + 2) * (Wb + 16), Wb + 16, DEV)
+    head = N_(perm2[:Wb * Hb])
+    assert sorted(head.tolist()) == sorted(y * (Wb + 16) + x for y in range(Hb) for x in range(Wb))
     bench = __import__("bench")
     mc, mf, sid, pose = bench.make_synthetic_scene(DEV, 96, 16, seed=2)
     opts, scfg = make_options(16, 16)

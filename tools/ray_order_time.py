@@ -17,12 +17,17 @@ pc, pf = mc.packed_decoder(), mf.packed_decoder()
 def perm_for(pw, ph, sw=1, sh=1):
     """pixel order: patches of pw x ph pixels, row-major inside a patch; patches grouped into super-patches of sw x sh patches, row-major"""
     ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    key = (((ys // (ph * sh)) * (W // (pw * sw)) + xs // (pw * sw)) * (sw * sh) + ((ys // ph) % sh) * sw + (xs // pw) % sw) * (pw * ph) + (ys % ph) * pw + xs % pw
+    key = (((ys // (ph * sh)) * (-(-W // (pw * sw))) + xs // (pw * sw)) * (sw * sh) + ((ys // ph) % sh) * sw + (xs // pw) % sw) * (pw * ph) + (ys % ph) * pw + xs % pw
     return torch.as_tensor(np.argsort(key.reshape(-1), kind="stable"), device=dev)
 
 ref = None
-for name, args in [("32x1 (row order)", (32, 1)), ("8x4", (8, 4)), ("4x8", (4, 8)), ("16x2", (16, 2)), ("8x4 in 2x1 super (X/Y tiles side by side)", (8, 4, 2, 1)),
-                   ("8x4 in 1x2 super", (8, 4, 1, 2)), ("8x4 in 4x2 super (256 rays = 32x8)", (8, 4, 4, 2)), ("8x4 in 2x4 super (16x16)", (8, 4, 2, 4))]:
+ONLY = [a for a in sys.argv[1:]]
+for name, args in [c for c in [("32x1 (row order)", (32, 1)), ("8x4", (8, 4)), ("4x8", (4, 8)), ("16x2", (16, 2)), ("8x4 in 2x1 super (X/Y tiles side by side)", (8, 4, 2, 1)),
+                   ("8x4 in 1x2 super", (8, 4, 1, 2)), ("8x4 in 4x2 super (256 rays = 32x8)", (8, 4, 4, 2)), ("8x4 in 2x4 super (16x16)", (8, 4, 2, 4)),
+                   ("8x4 in 16x8 super (128x32 px)", (8, 4, 16, 8)), ("8x4 in 16x32 super (128x128 px)", (8, 4, 16, 32)), ("8x4 in 32x16 super (256x64 px)", (8, 4, 32, 16)),
+                   ("8x4 in 25x25 super (200x100 px)", (8, 4, 25, 25)), ("8x4 in 50x25 super (400x100 px)", (8, 4, 50, 25)),
+                   ("16x2 in 8x16 super (128x32 px)", (16, 2, 8, 16)), ("8x4 in 16x8 super, again", (8, 4, 16, 8)), ("8x4, again", (8, 4))]
+                   if not ONLY or any(o in c[0] for o in ONLY)]:
     perm = perm_for(*args)
     rays = rays0[perm].contiguous()
     bufs = [torch.empty((N, 3), device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty((N, 3), device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
