@@ -130,6 +130,10 @@ int nvsr_sample_pdf(int64_t N, int nb, int ns, const float* bins, const float* w
                     nvsr_stream_t stream);
 /* cumprod_exclusive (nerf_helpers.py:409-430): [N,n] rows -> out[:,0] = 1, out[:,i] = in[:,0] * ... * in[:,i-1]; in and out must not alias */
 int nvsr_cumprod_exclusive(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream);
+/* autograd of cumprod_exclusive (the reference's helper is differentiable torch code, nerf_helpers.py:409-430): in, out = the forward's input
+ * and output [N,n], g_out = dL/dout -> g_in = dL/din; exact for zeros in `in` (no division) */
+int nvsr_cumprod_exclusive_backward(int64_t N, int n, const float* in, const float* out, const float* g_out, float* g_in,
+                                    nvsr_stream_t stream);
 /* torch.sort(x, dim=-1) values of [N,n] rows, n <= 512 (train_utils.py:155); in and out may alias */
 int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t stream);
 /* fused train_utils.py:144-155: z_mid, sample_pdf(z_mid, w[1:-1], Nf, det = (u == NULL)), sort(cat(z, samples)) -> [N,Nc+Nf] */
@@ -178,6 +182,8 @@ int nvsr_decode_rays(const nvsr_scene* scene, const float* packed_decoder, int64
  * fine pass.  workspace: nvsr_render_workspace_floats(N, Nc, Nf) floats.  Nf == 0: coarse only (fine outputs untouched).
  * Up to NVSR_FUSED_MIN_RAYS rays the passes run un-fused (nvsr_decode_rays + nvsr_composite), above it fused (nvsr_render_pass). */
 #define NVSR_FUSED_MIN_RAYS 65536
+/* the same threshold as the library was BUILT with (host mirrors that pick kernels per launch must use this, not a copy of the constant) */
+int64_t nvsr_fused_min_rays(void);
 int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf);
 int nvsr_render_rays(const nvsr_scene* scene, const float* packed_coarse, const float* packed_fine, int64_t N, int Nc, int Nf,
                      const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u,

@@ -43,6 +43,7 @@ class DecoderGeometry(C.Structure):
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _PROTOS = {
     "nvsr_version": ([], C.c_int),
+    "nvsr_fused_min_rays": ([], C.c_int64),
     "nvsr_get_decoder_arithmetic": ([], C.c_int),
     "nvsr_set_decoder_arithmetic": ([_i], _i),
     "nvsr_get_conv_arithmetic": ([], C.c_int),
@@ -58,6 +59,7 @@ _PROTOS = {
     "nvsr_sample_pdf": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_sort_rows": ([_i64, _i, _vp, _vp, _vp], _i),
     "nvsr_cumprod_exclusive": ([_i64, _i, _vp, _vp, _vp], _i),
+    "nvsr_cumprod_exclusive_backward": ([_i64, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_importance_resample": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_importance_resample_rays": ([_i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
@@ -204,6 +206,18 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, res
     return _lib
+
+
+_fused_min_rays = None
+
+
+def fused_min_rays():
+    """NVSR_FUSED_MIN_RAYS as the loaded library was built with (nvsr_fused_min_rays): from this many rays on a render pass runs fused, per
+    ray; below it sample-parallel.  Host code that picks a kernel or a ray order per launch reads it here, never from a Python copy."""
+    global _fused_min_rays
+    if _fused_min_rays is None:
+        _fused_min_rays = int(lib().nvsr_fused_min_rays())
+    return _fused_min_rays
 
 
 def call(name, *args):

@@ -261,6 +261,23 @@ __global__ void cumprod_exclusive_kernel(long N, int n, const float* __restrict_
     }
 }
 
+// backward of cumprod_exclusive: out_i = prod_{k<i} x_k  =>  dL/dx_j = out_j * R_j,  R_j = sum_{i>j} g_i prod_{j<k<i} x_k, i.e.
+// R_{n-1} = 0, R_j = g_{j+1} + x_{j+1} R_{j+1} -- no division, so zeros in x are exact (torch.cumprod's backward special-cases them)
+__global__ void cumprod_exclusive_backward_kernel(long N, int n, const float* __restrict__ in, const float* __restrict__ out,
+                                                  const float* __restrict__ g_out, float* __restrict__ g_in) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const float* x = in + row * n;
+    const float* o = out + row * n;
+    const float* g = g_out + row * n;
+    float* gi = g_in + row * n;
+    float R = 0.0f;
+    for (int j = n - 1; j >= 0; --j) {
+        gi[j] = __fmul_rn(o[j], R);
+        R = fmaf(x[j], R, g[j]);
+    }
+}
+
 __global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, const float* __restrict__ in, float* __restrict__ out) {
     __shared__ float vals[WPB][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -373,7 +390,8 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 
 extern "C" {
 
-int nvsr_version(void) { return 200; }   // 200: round 2 (per-call arithmetic twins, generic decoder geometries, in-kernel coarse depths)
+int nvsr_version(void) { return 300; }   // 300: round 3 (texel-deduplicating plane scatter, cumprod backward, exported fused-path threshold)
+int64_t nvsr_fused_min_rays(void) { return NVSR_FUSED_MIN_RAYS; }
 
 int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int Cc, int H, int W, nvsr_stream_t stream) {
     if (!nchw || !nhwc) return NVSR_ERR_NULL;
@@ -458,6 +476,15 @@ int nvsr_cumprod_exclusive(int64_t N, int n, const float* in, float* out, nvsr_s
     if (N < 0 || n < 1) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(cumprod_exclusive_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)N, n, in, out);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_cumprod_exclusive_backward(int64_t N, int n, const float* in, const float* out, const float* g_out, float* g_in, nvsr_stream_t stream) {
+    if (!in || !out || !g_out || !g_in) return NVSR_ERR_NULL;
+    if (N < 0 || n < 1) return NVSR_ERR_SHAPE;
+    if (N == 0) return NVSR_OK;
+    hipLaunchKernelGGL(cumprod_exclusive_backward_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)N, n, in, out,
+                       g_out, g_in);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -131,6 +131,82 @@ __device__ __forceinline__ void scatter_plane_runs(const f32x16 (&acc2)[2], floa
     __builtin_amdgcn_wave_barrier();
 }
 
+#if defined(BL_ABLATE) && (BL_ABLATE & 16)      // timing experiment: the scatter loop without its atomics (the sums stay live through an empty asm)
+#define NVSR_BWD_ATOMIC(P, V) asm volatile("" : : "v"(P), "v"(V))
+#else
+#define NVSR_BWD_ATOMIC(P, V) unsafeAtomicAdd(P, V)
+#endif
+// The same tile with EVERY texel written once (round 3).  Along a ray the cell index is monotone in x and in y, so a texel that the path
+// has left never comes back: a four-entry cache keyed by the texel's (x & 1, y & 1) holds exactly the texels that the current cell and the
+// next one can share -- tap k = (dx, dy) of a cell with parity par lands in slot k ^ par, the four taps of a cell in four different slots.
+// The slot -> (texel, weight) assignment of a point is a permutation of wave-uniform values and is done on the scalar unit (two rounds of
+// conditional swaps); the vector side is the same 4 fused multiply-adds per point as in scatter_plane_runs, the accumulators are 4 registers.
+// A slot is flushed (one 192-byte atomic) when its texel changes.  Atomic payload of a training step's fine pass: 0.35 of the
+// one-set-per-point scatter (scatter_plane_runs: 0.54), of its coarse pass 0.62 (0.82) -- the tile's distinct texels, i.e. the minimum
+// without merging across waves.  `t.o00` carries the parity of the cell in its two low bits (texel offsets are multiples of 48).
+// (Leaving the atomics in flight behind a counted s_waitcnt at the next chunk boundary -- they are younger than the copy it waits for --
+//  measured no gain: 0.807 vs 0.800 ms.)
+__device__ __forceinline__ void scatter_plane_cached(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
+                                                    bool valid) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    int k0 = -1, k1 = -1, k2 = -1, k3 = -1;                        // texel held by slot j
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;              // this lane's channel of slot j
+    float* const gl = gplane + lane;
+#define NVSR_SLOT(K, S, NK, A)                                                                          \
+        if (NK != K) {                                             /* (wave-uniform) */                 \
+            if (K >= 0 && lane < C) NVSR_BWD_ATOMIC(gl + K, S);                                         \
+            K = NK;                                                                                     \
+            S = 0.0f;                                                                                   \
+        }                                                                                               \
+        S = fmaf(v, A, S);
+    // (lanes 48..63 run along on the next point's first channels -- their sums are never written; the last point's read is clamped into the tile)
+    const int li = lane < C ? lane : lane - 16;
+#pragma unroll 2
+    for (int p0 = 0; p0 < 32; p0 += 4) {
+        float vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + li];                  // 4 points' rows in flight
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            int o0 = __builtin_amdgcn_readlane(t.o00, p), o1 = __builtin_amdgcn_readlane(t.o01, p);
+            int o2 = __builtin_amdgcn_readlane(t.o10, p), o3 = __builtin_amdgcn_readlane(t.o11, p);
+            float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), p));
+            float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), p));
+            float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w2), p));
+            float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), p));
+            const int par = o0 & 3;
+            o0 &= ~3;
+            if (par & 1) { int x = o0; o0 = o1; o1 = x; x = o2; o2 = o3; o3 = x; float y = a0; a0 = a1; a1 = y; y = a2; a2 = a3; a3 = y; }
+            if (par & 2) { int x = o0; o0 = o2; o2 = x; x = o1; o1 = o3; o3 = x; float y = a0; a0 = a2; a2 = y; y = a1; a1 = a3; a3 = y; }
+            const float v = vv[j];
+            NVSR_SLOT(k0, s0, o0, a0)
+            NVSR_SLOT(k1, s1, o1, a1)
+            NVSR_SLOT(k2, s2, o2, a2)
+            NVSR_SLOT(k3, s3, o3, a3)
+        }
+    }
+#undef NVSR_SLOT
+    if (lane < C) {
+        if (k0 >= 0) NVSR_BWD_ATOMIC(gl + k0, s0);
+        if (k1 >= 0) NVSR_BWD_ATOMIC(gl + k1, s1);
+        if (k2 >= 0) NVSR_BWD_ATOMIC(gl + k2, s2);
+        if (k3 >= 0) NVSR_BWD_ATOMIC(gl + k3, s3);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
 // address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
 // gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.

@@ -44,7 +44,8 @@ struct Taps {
     float nw, ne, sw, se;
 };
 
-__device__ __forceinline__ Taps make_taps(const SceneDev& sc, int d, float gx, float gy) {
+// ix, iy: the cell (north-west texel) the point falls into
+__device__ __forceinline__ Taps make_taps_cell(const SceneDev& sc, int d, float gx, float gy, int& ix, int& iy) {
     const int H = sc.ph[d], W = sc.pw[d];
     const float mx = sc.mx[d], my = sc.my[d];
     float x = (gx + 1.0f) * sc.hx[d];
@@ -55,11 +56,15 @@ __device__ __forceinline__ Taps make_taps(const SceneDev& sc, int d, float gx, f
     const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
     Taps t;
     t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
-    const int ix = (int)xw, iy = (int)yn;
+    ix = (int)xw; iy = (int)yn;
     const int ix1 = min(ix + 1, W - 1), iy1 = min(iy + 1, H - 1);   // a clamped neighbour always carries weight 0
     t.o00 = (iy * W + ix) * C;  t.o01 = (iy * W + ix1) * C;
     t.o10 = (iy1 * W + ix) * C; t.o11 = (iy1 * W + ix1) * C;
     return t;
+}
+__device__ __forceinline__ Taps make_taps(const SceneDev& sc, int d, float gx, float gy) {
+    int ix, iy;
+    return make_taps_cell(sc, d, gx, gy, ix, iy);
 }
 
 // 24 channels (half h of the texel) of the bilinear blend -> f[0..23].  Two taps are in flight at a time (48 registers).

@@ -17,7 +17,12 @@
 
 #ifndef BL_ABLATE
 #define BL_ABLATE 0   // timing experiments only (wrong results): 1 no wait for the weight copies, 2 no gate masks, 4 no plane scatter / view rows,
-#endif                // 8 no splits outside the MFMA gaps (first K-block of a chunk)      (tools/bwd_limb_ablate.sh)
+#endif                // 8 no splits outside the MFMA gaps (first K-block of a chunk), 16 scatter loop without its atomics, 64 no workgroup barriers
+                      // (tools/bwd_limb_ablate.sh, tools/bwd_limb_kernel_ablate.sh)
+
+#ifndef BL_SCATTER
+#define BL_SCATTER 2  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once
+#endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
 #include "limb_core.h"
 #include "bwd_core.h"
@@ -87,10 +92,12 @@ __device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
     int base = chunk * (BL_CHUNK_WORDS * 4), slot = rs.slot;
     asm volatile("" : "+s"(base), "+s"(slot));
     unsigned* dst = rs.lds + slot * BL_CHUNK_WORDS;
+#if !(BL_ABLATE & 32)         // (32: no weight copies at all -- the matrix work runs on whatever the slots hold)
 #pragma unroll
     for (int i = 0; i < 24 / BL_WAVES; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * BL_WAVES + rs.wave) * 256), 16,
                                                  (int)rs.voff, base + i * (BL_WAVES * 1024), 0, 0);
+#endif
     rs.slot = slot ^ 1;
     return dst;
 }
@@ -98,7 +105,9 @@ __device__ __forceinline__ void ringb_sync() {
 #if !(BL_ABLATE & 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+#if !(BL_ABLATE & 64)
     __syncthreads();
+#endif
 }
 
 // acc2[ob] += W0^T fragments [K-block 4][channel block 2][limb 3] x limbs of src(kb, 0..7): 4 x 2 x 6 MFMAs
@@ -191,7 +200,12 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             const float n1 = norm_coord(__fadd_rn(r[1], __fmul_rn(r[4], zc)), sc.lo[1], sc.range[1]);
             const float n2 = norm_coord(__fadd_rn(r[2], __fmul_rn(r[5], zc)), sc.lo[2], sc.range[2]);
             const float* M = sc.proj + 6 * d;
-            return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+            int ix, iy;
+            Taps t = make_taps_cell(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], ix, iy);
+#if BL_SCATTER == 2
+            t.o00 |= (ix & 1) | ((iy & 1) << 1);             // the cell's parity rides in the low bits (scatter_plane_cached)
+#endif
+            return t;
         };
         f32x16 accA[4], accB[4];
         Limbs<3> cur, fa;
@@ -221,14 +235,14 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         BL_HBLOCK(false, true, G, 2, GN, (C0) + 2, NoTail{})                                            \
         BL_HBLOCK(false, true, G, 4, GN, (C0) + 3, NoTail{})                                            \
         BL_HBLOCK(false, true, G, 6, GN, (C0) + 4, NoTail{})                                            \
-        if (!(BL_ABLATE & 2)) apply_mask(gate(MK), GN);
+        if (!(BL_ABLATE & 2)) { apply_mask(gate(MK), GN); BL_FENCE(GN) }
 #else
 #define BL_HIDDEN_T(G, MK, GN, C0)                                                                      \
         BL_HBLOCK(true, true, G, 0, GN, (C0) + 1, tail_of(G, 2))                                        \
         BL_HBLOCK(false, false, G, 2, GN, (C0) + 2, tail_of(G, 4))                                      \
         BL_HBLOCK(false, false, G, 4, GN, (C0) + 3, tail_of(G, 6))                                      \
         BL_HBLOCK(false, false, G, 6, GN, (C0) + 4, NoTail{})                                           \
-        if (!(BL_ABLATE & 2)) apply_mask(gate(MK), GN);
+        if (!(BL_ABLATE & 2)) { apply_mask(gate(MK), GN); BL_FENCE(GN) }
 #endif
         // acc2 += W0^T g: chunks C0, C0 + 1; LAST: no chunk follows in this step
 #define BL_LAYER0_T(G, ACC2, C0, LAST)                                                                  \
@@ -256,6 +270,8 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                 for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = wv[j] * graw[3];
             }
         apply_mask(gate(3), accA);
+        BL_FENCE(accA)      // the masked gradient is a value of its own: without the fence hipcc keeps mask AND unmasked value alive to fold
+                            // `(g & keep) & 0xffff0000` of the limb split into one v_bitop3 -- 128 more live registers, 165 spills
         if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 2, accB, 0)
         if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                 for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
             }
         apply_mask(gate(7), accA);
+        BL_FENCE(accA)
         if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 6, accB, 14)
         if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
@@ -330,7 +347,14 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     const Taps t = (d < 3) ? pos_taps(d) : view_taps(sc, r[8], r[9], r[10]);
+#if BL_SCATTER == 2
+                    if (d < 3) scatter_plane_cached(gF, tile, t, gp.p[d], lane, valid);
+                    else scatter_plane_runs(gF, tile, t, gp.p[d], lane, valid);          // (view plane without a row workspace: one cell per ray)
+#elif BL_SCATTER == 1
                     scatter_plane_runs(gF, tile, t, gp.p[d], lane, valid);
+#else
+                    scatter_plane(gF, tile, t, gp.p[d], lane, valid);
+#endif
                 }
             }
         }

@@ -80,12 +80,11 @@ def positional_encoding(tensor, num_encoding_functions=6, include_input=True) ->
 
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     """nerf_helpers.py:409-430: exclusive cumulative product along the last dim (for callers outside the fused path; the render kernels carry
-    the running product in a register)"""
-    t = capi.f32c(tensor)
-    out = torch.empty_like(t)
-    if t.numel():
-        capi.call("nvsr_cumprod_exclusive", t.numel() // t.shape[-1], t.shape[-1], capi.ptr(t), capi.ptr(out), capi.stream())
-    return out
+    the running product in a register).  A registered operator (torch.ops.nvsr.cumprod_exclusive) with autograd, like the reference's
+    differentiable torch helper: the gradient comes from nvsr_cumprod_exclusive_backward."""
+    from . import ops  # noqa: F401  (registers torch.ops.nvsr.*)
+
+    return torch.ops.nvsr.cumprod_exclusive(capi.f32c(tensor))
 
 
 def get_minibatches(inputs: torch.Tensor, chunksize: Optional[int] = 1024 * 8):

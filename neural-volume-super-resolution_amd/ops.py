@@ -342,29 +342,52 @@ def _(planes, consts, packed, rays, z, want_gates, want_record, arithmetic):
             rays.new_empty((nrec,)))
 
 
+def _decode_rays_backward_launch(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic, grads):
+    """the gate-driven backward scattering into `grads` (channel-last gradient planes, ADDED to; entries of planes that need no gradient ignored)"""
+    rays, z, g_raw = _c(rays), _c(z), _c(g_raw)
+    sc = _scene(planes, consts)
+    N, S = z.shape
+    if N == 0 or (not any(need) and record is None):
+        return
+    gptrs = (C.c_void_p * 4)(*[g.data_ptr() if need[d] else None for d, g in enumerate(grads)]) if any(need) else None
+    # per-tile rows of the view-direction plane's gradient (summed per ray before they touch the plane)
+    view_ws = _f(N * S * PC, like=rays) if (gptrs is not None and need[3]) else None
+    capi.call("nvsr_render_pass_backward_gates_arith", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays), capi.ptr(z),
+              capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(record), arithmetic, capi.stream())
+
+
 @custom_op("nvsr::decode_rays_backward", mutates_args=("record",), device_types="cuda")
 def decode_rays_backward(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, packed_bwd: Tensor, rays: Tensor, z: Tensor,
                          g_raw: Tensor, gates: Tensor, record: Optional[Tensor], need: Sequence[bool], arithmetic: int) -> List[Tensor]:
     """gate-driven backward of decode_rays: g_raw [N,S,4] -> gradient planes (channel-last, zeros where need[d] is False -> empty tensor);
     with `record` (the forward's) the pre-activation gradients are added to it for decoder_weight_grad.  `arithmetic` must be the
     forward's."""
-    rays, z, g_raw = _c(rays), _c(z), _c(g_raw)
-    sc = _scene(planes, consts)
-    N, S = z.shape
     grads = [torch.zeros_like(p) if need[d] else _f(0, like=rays) for d, p in enumerate(planes)]
-    if N == 0 or (not any(need) and record is None):
-        return grads
-    gptrs = (C.c_void_p * 4)(*[g.data_ptr() if need[d] else None for d, g in enumerate(grads)]) if any(need) else None
-    # per-point rows of the view-direction plane's gradient (summed per ray before they touch the plane)
-    view_ws = _f(N * S * PC, like=rays) if (gptrs is not None and need[3]) else None
-    capi.call("nvsr_render_pass_backward_gates_arith", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays), capi.ptr(z),
-              capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(record), arithmetic, capi.stream())
+    _decode_rays_backward_launch(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic, grads)
     return grads
 
 
 @decode_rays_backward.register_fake
 def _(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic):
     return [torch.empty_like(p) if need[d] else rays.new_empty((0,)) for d, p in enumerate(planes)]
+
+
+@custom_op("nvsr::decode_rays_backward_", mutates_args=("record", "grads"), device_types="cuda")
+def decode_rays_backward_(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, packed_bwd: Tensor, rays: Tensor, z: Tensor,
+                          g_raw: Tensor, gates: Tensor, record: Optional[Tensor], need: Sequence[bool], arithmetic: int,
+                          grads: Sequence[Tensor]) -> None:
+    """decode_rays_backward ACCUMULATING into existing gradient planes (`grads`: what the functional form returned for an earlier pass over
+    the same planes): the fine pass of a training step scatters into the coarse pass's buffers instead of zero-filling a second set of
+    full-size planes and adding the two (the reference's autograd accumulates into one .grad the same way)."""
+    for d, (g, p) in enumerate(zip(grads, planes)):
+        if need[d] and (g.shape != p.shape or g.stride() != p.stride() or g.dtype != torch.float32 or not g.is_cuda):
+            raise ValueError("decode_rays_backward_: grads[%d] must be a float32 CUDA tensor laid out like planes[%d]" % (d, d))
+    _decode_rays_backward_launch(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic, grads)
+
+
+@decode_rays_backward_.register_fake
+def _(planes, consts, packed, packed_bwd, rays, z, g_raw, gates, record, need, arithmetic, grads):
+    return None
 
 
 @custom_op("nvsr::decode_rays_backward_recompute", mutates_args=(), device_types="cuda")
@@ -728,6 +751,51 @@ def _planes_sr_train_bwd(ctx, d_out, d_keep):
 planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr_train_setup)
 
 # operators whose forward is checked with torch.library.opcheck in the GPU tests
+# =====================================================================================================================================
+# cumprod_exclusive (nerf_helpers.py:409-430) -- differentiable like the reference's torch helper
+# =====================================================================================================================================
+@custom_op("nvsr::cumprod_exclusive", mutates_args=(), device_types="cuda")
+def cumprod_exclusive(x: Tensor) -> Tensor:
+    """out[..., 0] = 1, out[..., i] = x[..., 0] * ... * x[..., i-1]"""
+    x = _c(x)
+    out = torch.empty_like(x)
+    if x.numel():
+        capi.call("nvsr_cumprod_exclusive", x.numel() // x.shape[-1], x.shape[-1], capi.ptr(x), capi.ptr(out), capi.stream())
+    return out
+
+
+@cumprod_exclusive.register_fake
+def _(x):
+    return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+@custom_op("nvsr::cumprod_exclusive_backward", mutates_args=(), device_types="cuda")
+def cumprod_exclusive_backward(x: Tensor, out: Tensor, g_out: Tensor) -> Tensor:
+    x, out, g_out = _c(x), _c(out), _c(g_out)
+    g = torch.empty_like(x)
+    if x.numel():
+        capi.call("nvsr_cumprod_exclusive_backward", x.numel() // x.shape[-1], x.shape[-1], capi.ptr(x), capi.ptr(out), capi.ptr(g_out), capi.ptr(g),
+                  capi.stream())
+    return g
+
+
+@cumprod_exclusive_backward.register_fake
+def _(x, out, g_out):
+    return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+def _cumprod_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], output)
+
+
+def _cumprod_bwd(ctx, g):
+    x, out = ctx.saved_tensors
+    return torch.ops.nvsr.cumprod_exclusive_backward(x, out, capi.f32c(g))
+
+
+cumprod_exclusive.register_autograd(_cumprod_bwd, setup_context=_cumprod_setup)
+
+
 FORWARD_OPS = ["plane_to_channel_last", "plane_from_channel_last", "pack_decoder", "coarse_z", "importance_resample", "triplane_decode",
                "triplane_decode_generic", "ray_points",
-               "render_pass", "render_rays", "decode_rays", "composite", "composite_rays", "edsr", "planes_sr"]
+               "render_pass", "render_rays", "decode_rays", "composite", "composite_rays", "edsr", "planes_sr", "cumprod_exclusive"]

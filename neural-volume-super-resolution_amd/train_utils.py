@@ -130,8 +130,15 @@ class _RenderRaysFn(torch.autograd.Function):
             g_raw = nv.composite_backward(raw, z, rd, noise, bool(cfg["white"]), False, g_rgb, g_acc)
             if gates is not None and (not want_dec or fwd_rec is not None):
                 # gate-driven backward (no recomputation); with the forward's record it adds the gradient half, then ONE contraction
-                add_planes(nv.decode_rays_backward(planes, cfg["consts"], packed, packed_bwd, rays, z, g_raw, gates, fwd_rec if want_dec else None,
-                                                   need_planes, arith))
+                rec = fwd_rec if want_dec else None
+                have = [gplanes[d] is not None for d in range(4) if need_planes[d]]
+                if have and all(have) and all(gplanes[d].shape == planes[d].shape and gplanes[d].stride() == planes[d].stride()
+                                              for d in range(4) if need_planes[d]):
+                    # a second pass over the same planes scatters into the first pass's gradient planes (no second zero-fill, no add)
+                    nv.decode_rays_backward_(planes, cfg["consts"], packed, packed_bwd, rays, z, g_raw, gates, rec, need_planes, arith,
+                                             [g if g is not None else rays.new_empty((0,)) for g in gplanes])
+                else:
+                    add_planes(nv.decode_rays_backward(planes, cfg["consts"], packed, packed_bwd, rays, z, g_raw, gates, rec, need_planes, arith))
                 return nv.decoder_weight_grad(fwd_rec, N, S, arith) if want_dec else None
             # no gates published (pass too large for a forward record): recompute the forward in the backward, RECORD_RAYS rays at a time
             _record_limits()
@@ -263,7 +270,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
             rgb_f = disp_f = acc_f = None
     else:
         # the two passes sample different planes (only the fine model super-resolves) or run in different arithmetic: pass by pass
-        fused = N >= 65536       # NVSR_FUSED_MIN_RAYS: below it the sample-parallel decoder + the wave-per-ray compositor fill the chip
+        fused = N >= capi.fused_min_rays()     # below it the sample-parallel decoder + the wave-per-ray compositor fill the chip
 
         def one_pass(planes, packed, z, noise, want_w, arith):
             if fused:
@@ -326,7 +333,15 @@ def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None
 _PATCH_ORDER = {}
 PATCH_W, PATCH_H = 16, 2                 # 32 rays = one wave tile of the fused pass
 SUPER_W, SUPER_H = 8, 16                 # patches per super-block: 128 x 32 pixels, visited block by block
-PATCH_ORDER_MIN_RAYS = 65536             # (the fused passes; below it the sample-parallel kernels do not tile by ray)
+
+
+def __getattr__(name):
+    # PATCH_ORDER_MIN_RAYS = the library's fused-path threshold (the fused passes tile by ray; below it the sample-parallel kernels do not),
+    # read from the library when first used so that the two can never disagree
+    if name == "PATCH_ORDER_MIN_RAYS":
+        return capi.fused_min_rays()
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+
 
 
 def patch_order(n_rays, grid_width, device):
@@ -388,7 +403,7 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
     outs = []
     native = model_coarse.is_native_geometry() and model_fine.is_native_geometry()
     inv = None
-    if (ray_grid_width and native and mode != "train" and not randoms and N >= PATCH_ORDER_MIN_RAYS
+    if (ray_grid_width and native and mode != "train" and not randoms and N >= capi.fused_min_rays()
             and N % int(ray_grid_width) == 0 and PATCH_H * SUPER_H * int(ray_grid_width) <= MAX_RAYS_PER_LAUNCH and not os.environ.get("NVSR_ROW_ORDER")):
         perm, inv = patch_order(N, ray_grid_width, rays.device)
         rays = rays.index_select(0, perm)

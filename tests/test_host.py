@@ -397,3 +397,24 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_no_spills_on_benchmarked_kernels(pkg):
+    """The spill gate (VERDICT r2 #1a): every kernel on a path bench.py times must fit its register budget -- a spilled accumulator turns
+    into scratch traffic inside the MFMA stream (round 2 shipped render_pass_backward_gates_limb_kernel<false> with 165 spilled VGPRs).
+    Reads the metadata of the gfx950 code objects in the in-tree library (tools/kernel_resources.py; temp dir, nothing is executed)."""
+    import importlib.util
+    import shutil
+
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("llvm-objdump")):
+        pytest.skip("no llvm-objdump on this machine")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    table = kr.kernel_table(pkg.capi.LIB_PATH)
+    names = " ".join(k["name"] for k in table)
+    for must in ("render_pass3_kernel", "render_pass_backward_gates_limb_kernel", "decode_rays_limb_kernel", "conv3x3_limb_kernel"):
+        assert must in names, "kernel table is missing %s" % must
+    bad = kr.violations(table)
+    assert not bad, "spilling kernels on benchmarked paths: " + "; ".join(
+        "%s: %d VGPRs, %d B scratch" % (k["name"][:90], k["vgpr_spill"], k["scratch"]) for k in bad)

@@ -1,5 +1,6 @@
+#!/bin/bash
 export PMC_SCRIPT=conv_wgrad_time.py PMC_ARGS=""
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 bash $R/tools/pmc.sh w1 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA && \
 bash $R/tools/pmc.sh w2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS && \
 bash $R/tools/pmc.sh w3 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS && \
