@@ -21,7 +21,10 @@ Other workloads of the same path (--workload; same JSON contract, their own metr
           N > 1: every rank draws its own rays, gradients are averaged with one bucketed RCCL all-reduce (planes 23 MB [+ decoders
           1 MB]) before the optimizer steps.
   sr      BASELINE configs[2]'s SR stage: the 3 position planes of a scene 200^2 -> 800^2 through EDSR (hidden 256, 32 blocks, x4)
-          in one batched pass (20.2 TFLOP); N > 1: independent replicas (a scene's planes are SR'd once and cached).
+          in one batched pass (20.2 TFLOP); N > 1: independent replicas (a scene's planes are SR'd once and cached), or with
+          --partition bands the stated SR partition of SURVEY 8e: every plane cut into N horizontal bands (68-pixel LR halo), one
+          all_gather per plane ("scaling": "strong").
+  train --rays-global 4096: the stated training partition of SURVEY 8e (4096 rays -> 4096 / N per GPU, same pixels on all ranks), "strong".
 """
 import argparse
 import json
@@ -292,11 +295,59 @@ def sample_without_replacement(total, n, dev, gen, margin=512):
     return buf[:n]
 
 
+def train_partition_check(nvsr_amd, dist, dev, rank, world, mc, mf, sid, scfg, opts, pose, H, W, focal, N, Nc, Nf, planes, dec, what):
+    """Rehearsal only (NVSR_BENCH_REHEARSAL=1, tests/test_hip_round3.py): the 8e training partition is exact -- the gradients of a step on
+    this rank's N rays, averaged over the ranks by distributed.allreduce_gradients, equal the one-rank gradients of the step on all
+    world x N rays (every rank computes that reference itself).  Tolerance: the order of the float atomics of the plane scatter
+    (test_plane_gradients_vs_oracle_larger: relative L2 2e-3; here the same kernels on both sides: 1e-5) -- decoders: 1e-4."""
+    G = N * world
+    g = torch.Generator(device=dev).manual_seed(4242)
+    sel = torch.randint(0, H, (G, 2), device=dev, generator=g)
+    target = torch.rand(G, 3, device=dev, generator=g)
+    rnd = dict(t_rand=torch.rand(G, Nc, device=dev, generator=g), u=torch.rand(G, Nf, device=dev, generator=g),
+               noise_coarse=0.2 * torch.randn(G, Nc, device=dev, generator=g), noise_fine=0.2 * torch.randn(G, Nc + Nf, device=dev, generator=g))
+    params = planes + (dec if "decoder" in what else [])
+
+    def grads_of(lo, hi):
+        for p in params:
+            p.grad = None
+        ro, rd = nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, sel[lo:hi])
+        out = nvsr_amd.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, torch.stack([ro, rd], 0), opts, sid, mode="train", scene_config=scfg,
+                                                        randoms={k: v[lo:hi].contiguous() for k, v in rnd.items()})
+        loss = torch.nn.functional.mse_loss(out[0], target[lo:hi]) + torch.nn.functional.mse_loss(out[3], target[lo:hi])
+        loss.backward()
+        return [p.grad for p in params]
+
+    ref = [t.clone() for t in grads_of(0, G)]
+    mine = grads_of(rank * N, (rank + 1) * N)
+    nvsr_amd.distributed.allreduce_gradients(mine)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        worst = max(worst, rel)
+        tol = 1e-5 if i < len(planes) else 1e-4
+        if not rel <= tol:
+            print("TRAIN_GRADIENTS_DIFFER rank %d tensor %d rel %.3e" % (rank, i, rel), file=sys.stderr, flush=True)
+            sys.exit(3)
+    for p in params:
+        p.grad = None
+    print("TRAIN_GRADIENTS_MATCH rank %d of %d: %d tensors, worst relative L2 difference %.2e" % (rank, world, len(params), worst), file=sys.stderr, flush=True)
+
+
 def bench_train(args, nvsr_amd, dist, dev, rank, world):
     """4096 rays / 64+64 / planes 200^2: forward + backward (planes + both decoders) + Adam"""
     import ctypes as C
     capi = nvsr_amd.capi
     R, N, Nc, Nf = 200, 4096, 64, 64
+    # --rays-global G (SURVEY.md 8e "Training partition": 4096 rays -> 4096 / N per GPU, same scene and same pixels on all ranks): every
+    # rank draws the SAME G pixels and random numbers (a generator seeded alike) and keeps its contiguous G / world share -> strong scaling.
+    # Default: every rank draws its own 4096 rays (global batch world x 4096) -> weak scaling.
+    strong = args.rays_global is not None
+    if strong:
+        G = int(args.rays_global)
+        if G % world:
+            sys.exit("bench.py: --rays-global %d is not divisible by %d ranks (the loss is a mean over the local rays)" % (G, world))
+        N = G // world
     what = {"planes": {"LR_planes"}, "planes+decoder": {"LR_planes", "decoder"}}[args.train_what]
     mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0, channels_last=not args.nchw_planes)
     for m in (mc, mf):
@@ -306,8 +357,10 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
     opts, scfg = render_options(Nc, Nf, perturb=True, noise=0.2)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    g = torch.Generator(device=dev).manual_seed(100 + (0 if strong else rank))
     target = torch.rand(H, W, 3, device=dev, generator=g)
+    lo = rank * N if strong else 0                    # this rank's share of a global draw of n_draw rays
+    n_draw = N * world if strong else N
     dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
     planes = list(mc.planes_.values())
     # (fused=True: one kernel per parameter group instead of five multi-tensor passes over the 23 MB of planes)
@@ -316,7 +369,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     def device_sampler(img, n_rays, consistency_ds=None):
         # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the
         # device: the host permutation of 640 000 indices costs more than the whole GPU step
-        flat = sample_without_replacement(img.shape[0] * img.shape[1], n_rays, dev, g)
+        flat = sample_without_replacement(img.shape[0] * img.shape[1], n_draw, dev, g)[lo: lo + n_rays]
         sel = torch.stack([flat % img.shape[0], flat // img.shape[0]], -1)
         return sel, img[sel[:, 0], sel[:, 1], :]
 
@@ -327,22 +380,30 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     def one():
         # the random draws of the train mode come from the device generator here: the reference draws them on the host, which on
         # this box costs more than the whole GPU step
-        rnd = dict(t_rand=torch.rand(N, Nc, device=dev, generator=g), u=torch.rand(N, Nf, device=dev, generator=g),
-                   noise_coarse=0.2 * torch.randn(N, Nc, device=dev, generator=g), noise_fine=0.2 * torch.randn(N, Nc + Nf, device=dev, generator=g))
+        rnd = dict(t_rand=torch.rand(n_draw, Nc, device=dev, generator=g), u=torch.rand(n_draw, Nf, device=dev, generator=g),
+                   noise_coarse=0.2 * torch.randn(n_draw, Nc, device=dev, generator=g), noise_fine=0.2 * torch.randn(n_draw, Nc + Nf, device=dev, generator=g))
+        if strong:
+            rnd = {k: v[lo: lo + N].contiguous() for k, v in rnd.items()}
         step(it[0], target, pose, H, W, focal, 1, sid, scfg, N, randoms=rnd)
         it[0] += 1
+
+    if strong and world > 1 and os.environ.get("NVSR_BENCH_REHEARSAL", "0") == "1":
+        train_partition_check(nvsr_amd, dist, dev, rank, world, mc, mf, sid, scfg, opts, pose, H, W, focal, N, Nc, Nf, planes, dec, what)
 
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
     value = world * N * args.steps / elapsed
     label = "planes + decoder gradients" if "decoder" in what else "plane gradients (Feature_Planes_Only.yml: what = ['LR_planes'])"
+    par = ("%d rays per iteration split %d per rank (same pixels and random numbers on every rank: the step equals the one-rank step on the "
+           "whole batch)" % (N * world, N)) if strong else "every rank draws its own %d rays (global batch %d)" % (N, N * world)
     result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, %s, Adam)" % label, "value": value,
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
               "dtype": ARITHMETIC["bf16x3" if capi.get_decoder_arithmetic() != "f32" else "f32"]["dtype"], "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
                          "plane_memory_format": "NCHW" if args.nchw_planes else "channels_last (same [1,48,R,R] parameters, native [H][W][C] memory)",
-                         "parallelism": "rays sharded by rank; one bucketed all-reduce of the %s per step"
+                         "partition": par,
+                         "parallelism": "rays sharded by rank; one coalesced in-place all-reduce of the %s per step"
                                         % ("plane + decoder gradients" if "decoder" in what else "plane gradients (23 MB)")}}
     if rank == 0:
         # dominant kernel: gate-driven backward of the fine pass (transposed layers + plane scatter + gradient half of the record), S = 128
@@ -411,20 +472,39 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
         sr.set_LR_plane(torch.randn(1, 48, 200, 200, device=dev) * 0.5, id=n, save_interpolated=False)
     flop_scene = 3 * 6.74e12
 
+    bands = world > 1 and args.partition == "bands"
+
     def one():
         sr.clear_SR_planes()
         with torch.no_grad():
-            sr.super_resolve_many(names)
+            if bands:          # every rank one horizontal band of every plane (+ the 68-pixel LR halo), one all_gather per plane
+                nvsr_amd.distributed.super_resolve_planes_sharded(sr, names)
+            else:
+                sr.super_resolve_many(names)
 
+    if bands and os.environ.get("NVSR_BENCH_REHEARSAL", "0") == "1":
+        # rehearsal (tests/test_hip_round3.py): the planes assembled from the ranks' bands are the single-rank planes, bit for bit
+        one()
+        got = [sr.SR_planes[n].clone() for n in names]
+        sr.clear_SR_planes()
+        with torch.no_grad():
+            sr.super_resolve_many(names)
+        same = all(torch.equal(a, sr.SR_planes[n]) for a, n in zip(got, names))
+        print("SR_BANDS_%s rank %d of %d" % ("IDENTICAL" if same else "DIFFER", rank, world), file=sys.stderr, flush=True)
+        if not same:
+            sys.exit(3)
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
-    value = world * 3 * args.steps / elapsed
+    value = (1 if bands else world) * 3 * args.steps / elapsed
     mode = nvsr_amd.capi.get_conv_arithmetic()
     arith = ARITHMETIC[mode]
     result = {"metric": "super-resolved feature planes/sec (48ch 200^2 -> 800^2, EDSR hidden 256 x 32 blocks)", "value": value, "unit": "planes/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-              "scaling": "weak", "vs_baseline": None, "dtype": arith["dtype"], "data": "synthetic", "conv_arithmetic": mode,
+              "scaling": "strong" if bands else "weak", "vs_baseline": None, "dtype": arith["dtype"], "data": "synthetic", "conv_arithmetic": mode,
               "config": {"workload": "PlanesSR full-plane pass over the 3 position planes of one scene (batched), LR 200^2 + 68 px replicate "
-                                     "padding -> HR 800^2", "planes_per_step_per_gpu": 3, "parallelism": "replicas only"}}
+                                     "padding -> HR 800^2", "planes_per_step_per_gpu": 3.0 / world if bands else 3,
+                         "partition": "bands" if bands else "replicas",
+                         "parallelism": ("every plane split into %d horizontal bands (one per rank, 68-pixel LR halo from real rows), one all_gather per "
+                                         "plane (123 MB)" % world) if bands else "replicas only"}}
     if rank == 0:
         ach = flop_scene / (elapsed / args.steps) / 1e12
         peak = arith["pipe_peak"] / arith["products"]
@@ -494,9 +574,13 @@ def main():
     ap.add_argument("--nchw-planes", action="store_true",
                     help="--workload train: keep the plane parameters in the reference's NCHW memory order (a re-layout kernel per plane and step) "
                          "instead of torch.channels_last, whose memory is the kernels' native [H][W][C] layout")
+    ap.add_argument("--rays-global", type=int, default=None,
+                    help="--workload train: total rays per iteration over ALL ranks, rank r takes its 1/N share of the same draw (SURVEY 8e: 4096 -> "
+                         "4096 / N per GPU) -> \"scaling\": \"strong\"; default: 4096 rays per rank, drawn per rank (weak)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--partition", choices=["rows", "frame", "view"], default=None,
-                    help="--workload render, N > 1: how the rays are sharded (see the module docstring); default rows")
+    ap.add_argument("--partition", choices=["rows", "frame", "view", "bands"], default=None,
+                    help="--workload render, N > 1: how the rays are sharded (see the module docstring); default rows.  --workload sr, N > 1: "
+                         "bands = every plane split into one horizontal band per rank + one all_gather (strong scaling); default replicas")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800, help="image side (default 800 = BASELINE config)")
@@ -558,6 +642,8 @@ def main():
     H = W = args.res
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
     partition = args.partition or ("rows" if world > 1 else "view")
+    if partition == "bands":
+        sys.exit("bench.py: --partition bands belongs to --workload sr")
     if world == 1:
         partition = "view"            # one rank: every partition is the same single-GPU frame
     # same (replicated) scene on every rank; "view": a different view per rank, "frame": one view, "rows": one view per rank, all shared

@@ -49,33 +49,82 @@ __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the v
 //  indexed dynamically, i.e. go through scratch)
 template <int PB>
 __device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16 (&acc)[2][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
-    auto write_out = [&](auto kind) {
+    // Round 3: per (co-block, row) the 16 channel rows of a lane are handled as a GROUP -- all 16 skip values are loaded first (independent
+    // loads, one wait), then 16 stores -- through restrict-qualified local pointers with 32-bit element offsets (a plane is < 2^31 floats;
+    // the batch offset is already in the pointers).  Before, every element was its own load -> s_waitcnt vmcnt(0) -> store behind 64-bit
+    // multiply-adds (hipcc could not prove that out and skip do not alias): 128 serial memory round trips per lane in the residual blocks.
+    float* __restrict__ const out = p.out;
+    const float* __restrict__ const skip = p.skip;
+    const int Cout = p.Cout;
+    auto write_out_a = [&](auto kind, auto aligned) {
         constexpr int EPI = decltype(kind)::value;
+        constexpr int ALIGN = decltype(aligned)::value;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 const int y = y0 + pb;
-                const bool inside = y < Ho && x < Wo;
+                if (!(y < Ho && x < Wo)) continue;
+                const int cbase = co0 + cb * 32 + 4 * h;                    // channel of register r: cbase + (r & 3) + 8 (r >> 2)
+                // channel in range?  Cout a multiple of 32 (every layer of EDSR but the last): the whole co-block is or is not, no
+                // per-element test; a multiple of 8 (the 48-channel output layer): the same answer for the 8 channels
+                // 8 (r >> 2) + {0..3} + 4h of a register quad in both lane halves, a wave-uniform test; otherwise per lane
+                if (ALIGN == 32 && __builtin_amdgcn_readfirstlane(co0) + cb * 32 >= Cout) continue;
+                auto chan_ok = [&](int r) {
+                    if (ALIGN == 32) return true;
+                    if (ALIGN == 8) return __builtin_amdgcn_readfirstlane(co0) + cb * 32 + 8 * (r >> 2) < Cout;
+                    return cbase + (r & 3) + 8 * (r >> 2) < Cout;
+                };
+                float v[16];
+                float sk[16];
+                if (EPI == EPI_RESIDUAL || EPI == EPI_MASK_SCALE || EPI == EPI_ADD_CENTER) {
+                    // skip layouts: RESIDUAL [Cout][Ho+4][Wo+4] at (y+2, x+2); MASK_SCALE [Cout][Ho][Wo]; ADD_CENTER [Cout][Ho-4][Wo-4] at (y-2, x-2)
+                    const int sH = EPI == EPI_RESIDUAL ? Ho + 4 : EPI == EPI_MASK_SCALE ? Ho : Ho - 4;
+                    const int sW = EPI == EPI_RESIDUAL ? Wo + 4 : EPI == EPI_MASK_SCALE ? Wo : Wo - 4;
+                    const int sy = EPI == EPI_RESIDUAL ? y + 2 : EPI == EPI_MASK_SCALE ? y : y - 2;
+                    const int sx = EPI == EPI_RESIDUAL ? x + 2 : EPI == EPI_MASK_SCALE ? x : x - 2;
+                    const bool sin = sy >= 0 && sy < sH && sx >= 0 && sx < sW;     // (only ADD_CENTER can be outside)
+                    const int splane = sH * sW, s0 = cbase * splane + sy * sW + sx;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dc = (r & 3) + 8 * (r >> 2);
+                        // (unconditional load from a clamped address + select: no branch per element)
+                        const bool ok = sin && chan_ok(r);
+                        const float ld = skip[ok ? s0 + dc * splane : 0];
+                        sk[r] = ok ? ld : 0.0f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (inside && co < p.Cout) {
-                        float v = acc[cb][pb][r];
-                        if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
-                        if (EPI == EPI_RESIDUAL)   // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
-                            v = v * 0.1f + p.skip[((long)co * (Ho + 4) + (y + 2)) * (Wo + 4) + (x + 2)];
-                        if (EPI == EPI_MASK_SCALE)  // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
-                            v = (p.skip[((long)co * Ho + y) * Wo + x] > 0.0f) ? v * 0.1f : 0.0f;
-                        if (EPI == EPI_ADD_CENTER)  // backward of the cropped identity: the block's output gradient lands in the centre
-                            if (y >= 2 && y < Ho - 2 && x >= 2 && x < Wo - 2) v += p.skip[((long)co * (Ho - 4) + (y - 2)) * (Wo - 4) + (x - 2)];
-                        if (EPI == EPI_PIXEL_SHUFFLE)
-                            p.out[((long)(co >> 2) * (2 * Ho) + 2 * y + ((co >> 1) & 1)) * (2 * Wo) + 2 * x + (co & 1)] = v;
-                        else
-                            p.out[((long)co * Ho + y) * Wo + x] = v;
+                    float t = acc[cb][pb][r];
+                    if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
+                    if (EPI == EPI_RESIDUAL) t = t * 0.1f + sk[r];     // output *= 0.1; output = output + identity[..., 2:-2, 2:-2]  (models.py:781-785)
+                    if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;   // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
+                    if (EPI == EPI_ADD_CENTER) t += sk[r];             // backward of the cropped identity: the block's output gradient lands in the centre
+                    v[r] = t;
+                }
+                if (EPI == EPI_PIXEL_SHUFFLE) {
+                    // co -> (co >> 2, 2y + ((co >> 1) & 1), 2x + (co & 1)); cbase is a multiple of 4: r & 3 = co & 3
+                    const int oplane = 4 * Ho * Wo, o0 = (cbase >> 2) * oplane + (2 * y) * (2 * Wo) + 2 * x;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dc = (r & 3) + 8 * (r >> 2);
+                        if (chan_ok(r)) out[o0 + (dc >> 2) * oplane + ((r >> 1) & 1) * (2 * Wo) + (r & 1)] = v[r];
+                    }
+                } else {
+                    const int oplane = Ho * Wo, o0 = cbase * oplane + y * Wo + x;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dc = (r & 3) + 8 * (r >> 2);
+                        if (chan_ok(r)) out[o0 + dc * oplane] = v[r];
                     }
                 }
             }
+    };
+    auto write_out = [&](auto kind) {
+        if ((Cout & 31) == 0) write_out_a(kind, std::integral_constant<int, 32>{});
+        else if ((Cout & 7) == 0) write_out_a(kind, std::integral_constant<int, 8>{});
+        else write_out_a(kind, std::integral_constant<int, 1>{});       // (no layer of EDSR: the per-lane channel test)
     };
     switch (p.epilogue) {
         case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
@@ -312,6 +361,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int t = 0; t < 3; ++t) A[cb][t] = wa[((cb * 9 + 0) * 3 + t) * 64 + lane];
+        // B fragments of a tap's FIRST row come from the previous tap (round 3): the sched_barriers at the tap boundaries keep hipcc from
+        // hoisting them, and every tap used to open with an exposed LDS round trip (9 per chunk)
+        u32x4 B0[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB) * PC) * 8);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -322,11 +376,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * 3 + t) * 64 + lane];
             }
+            // (pinned at the top of the tap: hipcc otherwise sinks these six loads to the tap's END, and the next tap's first MFMA waits
+            //  out their L2 latency -- 9 times per chunk)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 u32x4 B[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + pb + ky) * PC + kx) * 8);
+                for (int t = 0; t < 3; ++t)
+                    B[t] = pb == 0 ? B0[t] : *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + pb + ky) * PC + kx) * 8);
+                if (pb == PB - 1 && tap + 1 < 9) {
+                    const int ky1 = (tap + 1) / 3, kx1 = (tap + 1) % 3;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + ky1) * PC + kx1) * 8);
+                }
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll

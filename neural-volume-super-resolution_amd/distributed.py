@@ -35,19 +35,35 @@ def _collective_device(t, group=None):
     return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
-def gather_row_blocks(local, counts, group=None):
-    """all_gather of per-rank row blocks of unequal length (counts[r] rows on rank r) -> [sum(counts), ...] on every rank"""
+def gather_row_blocks(local, counts, group=None, out=None):
+    """all_gather of per-rank row blocks (counts[r] rows on rank r) -> [sum(counts), ...] on every rank.
+    Even split: ONE all_gather_into_tensor straight into the assembled frame (`out`, preallocated by the caller or here) -- no padding, no
+    list of parts, no cat.  Ragged split: blocks padded to the longest one, gathered the same way, the padding rows dropped by one
+    index_select.  A backend that only moves host buffers (gloo rehearsals) stages through the host."""
     rank, world = world_info(group)
     if world == 1:
         return local
     assert local.shape[0] == counts[rank]
-    n_max = max(counts)
     cdev = _collective_device(local, group)
-    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
-    pad[: local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([parts[r][: counts[r]] for r in range(world)], 0).to(local.device)
+    tail = tuple(local.shape[1:])
+    even = all(c == counts[0] for c in counts)
+    n_max = max(counts)
+    src = local.contiguous()
+    if not even:
+        src = torch.zeros((n_max,) + tail, dtype=local.dtype, device=local.device)
+        src[: local.shape[0]] = local
+    if even and out is not None and out.device == cdev and out.is_contiguous():
+        buf = out
+    else:
+        buf = torch.empty((world * n_max,) + tail, dtype=local.dtype, device=cdev)
+    dist.all_gather_into_tensor(buf, src.to(cdev), group=group)
+    if not even:
+        keep = torch.cat([torch.arange(r * n_max, r * n_max + counts[r]) for r in range(world)]).to(buf.device)
+        buf = buf.index_select(0, keep)
+    if out is not None and buf is not out:
+        out.copy_(buf)
+        return out
+    return buf.to(local.device)
 
 
 def gather_rows(local, n_total, group=None):
@@ -146,11 +162,30 @@ def super_resolve_planes_sharded(sr_model, plane_names, group=None, sr_fn=None):
 
 
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):
-    """Sum (or average) a list of gradient tensors over the ranks in flat buckets of ~bucket_bytes.  The loss is a mean over rays
-    (train_nerf.py:884-891), so with rays sharded evenly the data-parallel gradient is the average of the per-rank gradients."""
+    """Sum (or average) a list of gradient tensors over the ranks.  The loss is a mean over rays (train_nerf.py:884-891), so with rays
+    sharded evenly the data-parallel gradient is the average of the per-rank gradients.
+    RCCL: every dense tensor (row-major or channels_last -- the plane gradients are channels_last views) is reduced IN PLACE, all of them
+    inside one coalesced group (one ncclGroup launch): no flattening copy in, none out (round 2 concatenated the 23 MB of plane gradients
+    into a bucket and copied them back every step).  Other backends (gloo rehearsals) and non-dense tensors go through flat buckets of
+    ~bucket_bytes, staged through the host when the backend needs it."""
     rank, world = world_info(group)
     if world == 1:
         return
+    tensors = [t for t in tensors if t is not None]
+    scale = 1.0 / world if average else None
+
+    def dense(t):
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+    direct = [t for t in tensors if t.is_cuda and dense(t)] if dist.get_backend(group) == "nccl" else []
+    if direct:
+        with dist._coalescing_manager(group=group, device=direct[0].device, async_ops=True) as cm:
+            for t in direct:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        cm.wait()
+        if scale is not None:
+            torch._foreach_mul_(direct, scale)
+    ids = {id(t) for t in direct}
     bucket, size = [], 0
 
     def flush():
@@ -165,15 +200,17 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True
             flat.copy_(host)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= world
+        if scale is not None:
+            flat *= scale
         off = 0
         for t in bucket:
-            t.copy_(flat[off: off + t.numel()].view_as(t))
+            t.copy_(flat[off: off + t.numel()].view(t.shape))          # (logical order both ways: any strides of t)
             off += t.numel()
         bucket, size = [], 0
 
     for t in tensors:
+        if id(t) in ids:
+            continue
         bucket.append(t)
         size += t.numel() * t.element_size()
         if size >= bucket_bytes:

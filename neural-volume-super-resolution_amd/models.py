@@ -737,19 +737,49 @@ class PlanesSR(nn.Module):
         for n, o in zip(todo, outs):
             self.SR_planes[n] = o
 
+    def _apply_training_noise(self, out, noise_in, lr_clean):
+        """The training-mode noises of models.py:896-897,920-921 on the operator's output `out` = EDSR(prep(LR + n_in)) + up(LR + n_in) (NaN
+        outside the region of interest): remove up(n_in) -- the reference's residual is up(LR) -- then add
+        N(0, (sr_output_noise * difference.std())^2) over the region, difference = the network's (cropped) output.  Training only, not a
+        hot path: plain torch on the device, draws from the CPU generator in the reference's order (input noise first)."""
+        if noise_in is not None:
+            out = out - torch.nn.functional.interpolate(noise_in, scale_factor=self.scale_factor, mode=self.plane_interp, align_corners=self.align_corners)
+        if self.output_noise > 0:
+            inside = ~torch.isnan(out.detach()[0, 0])
+            rows, cols = inside.any(1).nonzero().flatten(), inside.any(0).nonzero().flatten()
+            r0, r1, c0, c1 = int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1
+            # difference = out - up(LR) on the region (the noisy LR plane's residual was removed above)
+            resid = torch.nn.functional.interpolate(lr_clean.detach().float(), scale_factor=self.scale_factor, mode=self.plane_interp,
+                                                    align_corners=self.align_corners)[..., r0:r1, c0:c1]
+            diff = out.detach()[..., r0:r1, c0:c1] - resid
+            sd_out = float(self.output_noise * diff.std())
+            n_out = torch.normal(mean=0.0, std=sd_out, size=tuple(diff.shape)).to(device=out.device, dtype=torch.float32)
+            pad_n = torch.zeros_like(out.detach())
+            pad_n[..., r0:r1, c0:c1] = n_out
+            out = out + pad_n
+        return out
+
     def forward(self, plane_name):
         if isinstance(plane_name, tuple):
             full_plane, plane_roi, plane_name = False, plane_name[1], plane_name[0]
         else:
             full_plane, plane_roi = True, None
-        lr_src = self.LR_planes[plane_name]
+        lr_src = lr_clean = self.LR_planes[plane_name]
         differentiable = self.training and self.inner_model.wants_grad(lr_src)
         if plane_name in self.SR_planes and not differentiable:      # (a cached plane carries no graph: never serve it to a training step)
             return self.SR_planes[plane_name]
         if not self.align_corners:
             raise NotImplementedError("align_corners=False is not used by the planes model")
-        if self.training and (self.input_noise > 0 or self.output_noise > 0):
-            raise NotImplementedError("sr_input_noise / sr_output_noise are 0 in every shipped config")
+        noisy = self.training and (self.input_noise > 0 or self.output_noise > 0)
+        noise_in = None
+        if noisy and self.input_noise > 0:
+            # models.py:896-897: LR_plane + N(0, (sr_input_noise * LR_plane.std())^2), drawn by torch.normal from the CPU generator (the
+            # reference's call has no device: a seeded run draws the same numbers here).  Only the NETWORK sees the noisy plane -- the
+            # bilinear residual is taken from self.LR_planes (models.py:858-868) -- so the fused operator runs on LR + n and the
+            # up-sampled noise is taken out of its (linear) residual term below.
+            sd_in = float(self.input_noise * lr_src.detach().float().std())
+            noise_in = torch.normal(mean=0.0, std=sd_in, size=tuple(lr_src.shape)).to(device=lr_src.device, dtype=torch.float32)
+            lr_src = lr_src + noise_in
         lr = capi.f32c(lr_src.detach())
         Cc, R0, R1 = lr.shape[-3:]
         cin, cout, hid, nb, n_up = self.inner_model.geometry
@@ -768,9 +798,11 @@ class PlanesSR(nn.Module):
             out, _ = torch.ops.nvsr.planes_sr_train(lr_src if lr_src.dtype == torch.float32 else lr_src.float(), net.natural_blob(differentiable=True),
                                                     net.packed_weights(), net.packed_dgrad_weights(), geometry, pad, over, roi, mean, std,
                                                     capi.resolve_conv_arithmetic(net.arithmetic))
-            return out
+            return self._apply_training_noise(out, noise_in, lr_clean) if noisy else out
         out = torch.ops.nvsr.planes_sr([lr.reshape(Cc, R0, R1)], self.inner_model.packed_weights(), geometry, pad, over, roi, mean, std,
                                        self.inner_model.arith())[0]
+        if noisy:
+            return self._apply_training_noise(out, noise_in, lr_clean)          # (like the reference, a noisy plane is never cached: training only)
         if full_plane:
             self.SR_planes[plane_name] = out      # kept on the GPU (the reference parks it on the CPU and re-uploads per call, :893,:925)
         return out

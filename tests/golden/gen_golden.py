@@ -27,6 +27,9 @@ Fixture index:
   g18_decoder_variants.npz  TwoDimPlanesModel.forward for other decoder geometries (widths, channel counts, combinations, skip layers)
   g17_store(.npz + g17_store/)  plane file, decoder checkpoint and SR checkpoint WRITTEN by the reference (PlanesOptimizer.save_params,
                       safe_saving; models.py:640-670, nerf_helpers.py:19-48, train_nerf.py:996-1008) + what it renders from them
+  g20_sr_options.npz  PlanesSR with input_normalization (models.py:855-857,899-901) and the training noises sr_input_noise / sr_output_noise
+                      (models.py:896-897,920-921; drawn from the seeded CPU generator)
+  g21_run_network.npz run_network (train_utils.py:15-64) on g08's fine model: points + view directions -> raw [N,S,4], chunked
   g15_loaders.npz     load_blender_data / load_llff_data on two tiny synthetic scenes (load_blender.py:232-332, load_llff.py:70-360).
                       imageio and cv2 are absent here: the harness reads the PNGs with PIL and gives cv2.resize(INTER_AREA) its
                       definition for integer factors (block mean), so the resampling itself is pinned by definition only; the JSON /
@@ -1070,9 +1073,74 @@ def g18_decoder_variants():
     save("g19_decoder_variant_grads.npz", **grads)
 
 
+def g20_sr_options():
+    """PlanesSR with the options g09 leaves at their defaults: `input_normalization` (models.py:855-857,899-901: the network
+    sees (LR - mean) / std per channel, the bilinear residual the raw plane) -- full plane in eval mode and an ROI in training mode -- and the
+    training noises `sr_input_noise` / `sr_output_noise` (models.py:896-897,920-921), drawn by torch.normal from the CPU generator seeded
+    here: the build draws the same numbers in the same order."""
+    torch.manual_seed(20)
+    C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+    cfg = CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}, "input_normalization": True})
+    sr = models.PlanesSR(models.EDSR, sf, C, C, cfg, "bilinear")
+    sr.align_corners = True
+    sr.eval()
+    with torch.no_grad():
+        for p_ in sr.inner_model.parameters():
+            p_.mul_(10.0)
+    lr = torch.randn(1, C, R, R) * 0.5 + torch.linspace(-1.0, 1.0, C).reshape(1, C, 1, 1)
+    mean, std = lr.mean(dim=(0, 2, 3)), lr.std(dim=(0, 2, 3)) * 1.7
+    sr.normalization_params({"mean": mean.clone(), "std": std.clone()})
+    sr.set_LR_plane(lr, id="p", save_interpolated=False)
+    arrs = dict(cfg=np.array([C, hidden, nblocks, sf, R, sr.inner_model.required_padding, sr.HR_overpadding]), lr=npy(lr), mean=npy(mean),
+                std=npy(std))
+    arrs.update({"sd." + k: npy(v) for k, v in sr.state_dict().items()})
+    roi = torch.tensor([[-0.5, -0.2], [0.3, 0.65]])
+    arrs["roi"] = npy(roi)
+    with torch.no_grad():
+        arrs["sr_full"] = npy(sr("p"))
+        sr.clear_SR_planes()
+        sr.train()
+        arrs["sr_roi"] = npy(sr(("p", roi)))
+        # training noises: input only, output only, both; each call after torch.manual_seed(seed)
+        for tag, (ni, no), seed in (("in", (0.3, 0.0), 101), ("out", (0.0, 0.25), 102), ("both", (0.2, 0.15), 103)):
+            sr.input_noise, sr.output_noise = ni, no
+            torch.manual_seed(seed)
+            arrs["sr_noise_" + tag] = npy(sr(("p", roi)))
+        arrs["noise_levels"] = np.array([[0.3, 0.0], [0.0, 0.25], [0.2, 0.15]])
+        arrs["noise_seeds"] = np.array([101, 102, 103])
+        sr.input_noise = sr.output_noise = 0
+        sr.eval()
+    save("g20_sr_options.npz", **arrs)
+
+
+def g21_run_network():
+    """run_network (train_utils.py:15-64) alone: g08's fine model (same seed -> same weights and planes; checked against g08's arrays) on 40
+    rays x 32 coarse depths, chunked (chunksize 100 of 1280 points, so the loop and the final cat run), identity encodings for points
+    and directions like the planes model -> raw radiance field [40, 32, 4]."""
+    R, Rv = 32, 8
+    sid, mc, mf, planes, box = build_models(R, Rv, 0.5, seed=8)
+    g8 = np.load(os.path.join(HERE, "g08_render.npz"))
+    assert np.array_equal(g8["plane0"], npy(planes[models.get_plane_name(sid, 0)])), "g21 must rebuild the g08 scene"
+    assert np.array_equal(g8["fine.fc_rgb.0.weight"], npy(mf.fc_rgb["0"].weight))
+    H = W = 16
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = nh.get_ray_bundle(H, W, focal, torch.from_numpy(POSE))
+    sel = torch.arange(3, 3 + 40 * 5, 5)
+    ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+    vd = rd / rd.norm(p=2, dim=-1, keepdim=True)
+    near, far = 2.0 * torch.ones_like(ro[..., :1]), 6.0 * torch.ones_like(ro[..., :1])
+    ray_batch = torch.cat((ro, rd, near, far, vd), -1)
+    z = near * (1.0 - torch.linspace(0.0, 1.0, 32)) + far * torch.linspace(0.0, 1.0, 32)
+    pts = ro[..., None, :] + rd[..., None, :] * z[..., :, None]
+    mf.eval()
+    with torch.no_grad():
+        raw = tu.run_network(mf, pts, ray_batch, 100, tu.identity_encoding, tu.identity_encoding, sid)
+    save("g21_run_network.npz", pts=npy(pts), ray_batch=npy(ray_batch), raw=npy(raw), chunksize=np.array(100))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g01", "g02", "g03", "g04", "g05", "g06", "g07", "g08", "g09", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g20", "g21"]
     for name, fn in list(globals().items()):
         if callable(fn) and name[:3] in which and name.startswith("g"):
             fn()

@@ -124,3 +124,135 @@ def test_backward_accumulates_into_existing_gradient_planes(hip):
         assert float((acc[d] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     with pytest.raises(ValueError):
         nv.decode_rays_backward_(planes, consts, packed, packed_bwd, rays, z2, g2, gates2, None, need, 3, [t[..., :1].contiguous() for t in acc])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the stated multi-GPU partitions of SURVEY.md 8e with the HIP kernels, rehearsed with two ranks on this box's one GPU (gloo)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _bench_rehearsal(args, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NVSR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-modes"] + args      # (bench.py spawns its ranks)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0]), p.stderr
+
+
+@pytest.mark.parametrize("what", ["planes", "planes+decoder"])
+def test_training_partition_two_ranks_equal_one_rank(what):
+    """SURVEY 8e "Training partition": 4096 rays -> 4096 / N per GPU, same scene and pixels on all ranks, all-reduced gradients.
+    `bench.py --workload train --rays-global 512 --gpus 2` (two ranks on cuda:0, gloo): inside the run every rank takes a step on its half
+    of a ray set, all-reduces (distributed.allreduce_gradients) and compares with the gradients of the one-rank step on the whole set
+    (the same HIP kernels): planes within 1e-5 relative L2 (order of the float atomics), decoders within 1e-4
+    (bench.train_partition_check prints TRAIN_GRADIENTS_MATCH per rank and exits non-zero otherwise).  Reference hook: train_nerf.py:839-860."""
+    r, err = _bench_rehearsal(["--workload", "train", "--rays-global", "512", "--train-what", what, "--steps", "2", "--warmup", "1"])
+    for rank in (0, 1):
+        assert "TRAIN_GRADIENTS_MATCH rank %d of 2" % rank in err, err[-3000:]
+    assert r["scaling"] == "strong" and r["n_gpus"] == 2 and r["config"]["rays_per_step_per_gpu"] == 256
+    assert abs(r["value"] - 512 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+
+
+def test_band_sharded_sr_stage_is_bit_identical_to_one_rank():
+    """SURVEY 8e "SR stage": `bench.py --workload sr --partition bands --gpus 2` drives the REAL PlanesSR(EDSR 256 x 32) through
+    distributed.super_resolve_planes_sharded -- each rank one horizontal band of every 200^2 plane with its 68-pixel LR halo, one
+    all_gather per plane -- and asserts inside the run that the assembled 800^2 planes torch.equal the single-rank planes
+    (SR_BANDS_IDENTICAL per rank).  Reference: models.py:884-926."""
+    r, err = _bench_rehearsal(["--workload", "sr", "--partition", "bands", "--steps", "1", "--warmup", "0"])
+    for rank in (0, 1):
+        assert "SR_BANDS_IDENTICAL rank %d of 2" % rank in err, err[-3000:]
+    assert r["scaling"] == "strong" and r["config"]["partition"] == "bands"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# small parity holes of VERDICT r2 #5
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _sr_model_g20(hip, g):
+    Cc, hid, nblocks, sf, R, pad, over = [int(v) for v in g["cfg"]]
+    sr = hip.models.PlanesSR(hip.models.EDSR, sf, Cc, Cc, {"model": {"hidden_size": hid, "n_blocks": nblocks}, "input_normalization": True}, "bilinear")
+    sr.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    sr = sr.to(DEV)
+    assert sr.inner_model.required_padding == pad and sr.HR_overpadding == over
+    return sr, (Cc, hid, nblocks, sf, R)
+
+
+def test_planes_sr_input_normalization_golden(hip):
+    """PlanesSR's input normalisation (models.py:855-857,899-901 -> sr_prepare_kernel): g09 never sets planes_mean/std_NON_LEARNED, g20 does.
+    Full plane (eval), ROI (training mode), the batched full-plane pass and the differentiable training forward against the reference."""
+    from conftest import load_golden
+    g = load_golden("g20_sr_options.npz")
+    sr, (Cc, hid, nblocks, sf, R) = _sr_model_g20(hip, g)
+    sr.eval()
+    sr.set_LR_plane(T(g["lr"]), id="p", save_interpolated=False)
+    sr.set_LR_plane(T(g["lr"]), id="q", save_interpolated=False)
+    full = sr("p")
+    np.testing.assert_allclose(N_(full), g["sr_full"], rtol=0, atol=1e-5)
+    sr.clear_SR_planes()
+    sr.super_resolve_many(["p", "q"])                       # batched pass takes the same mean / std
+    assert torch.equal(sr.SR_planes["p"], full) and torch.equal(sr.SR_planes["q"], full)
+    sr.clear_SR_planes()
+    sr.train()
+    ref = g["sr_roi"]
+    m = ~np.isnan(ref)
+    roi = N_(sr(("p", T(g["roi"]))))
+    assert np.array_equal(np.isnan(roi), np.isnan(ref)) and np.isnan(ref).any()
+    np.testing.assert_allclose(roi[m], ref[m], rtol=0, atol=1e-5)
+    for p_ in sr.inner_model.parameters():                  # differentiable forward: same values
+        p_.requires_grad_(True)
+    roi_t = sr(("p", T(g["roi"])))
+    assert roi_t.requires_grad
+    np.testing.assert_allclose(N_(roi_t.detach())[m], ref[m], rtol=0, atol=1e-5)
+
+
+def test_planes_sr_training_noise_matches_seeded_reference(hip):
+    """sr_input_noise / sr_output_noise (models.py:896-897,920-921): training-mode Gaussian noise on the network input (std = level x
+    LR.std()) and on the super-resolved region (std = level x difference.std()), drawn with torch.normal from the CPU generator.  Seeded
+    like the fixture generator, the build draws the same numbers in the same order: outputs equal the reference's within 2e-5 (noise
+    amplitudes are ~0.1, so a different draw, a missing noise or noise on the wrong tensor is off by 1e-1)."""
+    from conftest import load_golden
+    g = load_golden("g20_sr_options.npz")
+    sr, _ = _sr_model_g20(hip, g)
+    sr.set_LR_plane(T(g["lr"]), id="p", save_interpolated=False)
+    sr.train()
+    clean = g["sr_roi"]
+    m = ~np.isnan(clean)
+    for tag, (ni, no), seed in zip(("in", "out", "both"), g["noise_levels"], g["noise_seeds"]):
+        sr.input_noise, sr.output_noise = float(ni), float(no)
+        torch.manual_seed(int(seed))
+        got = N_(sr(("p", T(g["roi"]))))
+        ref = g["sr_noise_" + tag]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.abs(ref[m] - clean[m]).max() > 2e-2, tag         # the fixture's noise is visible
+        np.testing.assert_allclose(got[m], ref[m], rtol=0, atol=2e-5, err_msg=tag)
+    # differentiable path: gradients flow through the noisy forward (noise is an additive constant)
+    sr.input_noise, sr.output_noise = 0.2, 0.15
+    for p_ in sr.inner_model.parameters():
+        p_.requires_grad_(True)
+    torch.manual_seed(103)
+    out = sr(("p", T(g["roi"])))
+    np.testing.assert_allclose(N_(out.detach())[m], g["sr_noise_both"][m], rtol=0, atol=2e-5)
+    out[~torch.isnan(out.detach())].sum().backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in sr.inner_model.parameters())
+    sr.eval()
+    sr.input_noise = sr.output_noise = 0
+
+
+def test_run_network_mirror_matches_golden_raw_field(hip):
+    """The stand-alone run_network mirror (train_utils.py:15-64: flatten the points, expand the batch's view directions to every sample,
+    call the model, reshape to [N,S,4]) against the reference's raw radiance field on g08's fine model (fixture g21: 40 rays x 32 depths,
+    chunked in the reference) -- the fused passes never call the mirror, so it had no numeric test (VERDICT r2 weak #1a).  Tolerance = the
+    decoder's: 2e-5."""
+    from conftest import load_golden
+    g8, g = load_golden("g08_render.npz"), load_golden("g21_run_network.npz")
+    mf, sid = build_model(hip, {k[5:]: v for k, v in g8.items() if k.startswith("fine.")}, [g8["plane%d" % d] for d in range(4)], g8["box"])
+    ident = hip.train_utils.identity_encoding
+    raw = hip.train_utils.run_network(mf, T(g["pts"]), T(g["ray_batch"]), int(g["chunksize"]), ident, ident, sid)
+    assert tuple(raw.shape) == g["raw"].shape == (40, 32, 4)
+    np.testing.assert_allclose(N_(raw), g["raw"], rtol=0, atol=2e-5)
+    # and it agrees with what the fused coarse pass composites from: the same points through the decode operator
+    flat = torch.cat([T(g["pts"]).reshape(-1, 3), T(g["ray_batch"])[:, None, -3:].expand(40, 32, 3).reshape(-1, 3)], -1)
+    assert torch.equal(mf(flat).reshape(40, 32, 4), raw)

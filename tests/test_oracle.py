@@ -195,6 +195,23 @@ def test_edsr_and_planes_sr(oracle):
     np.testing.assert_allclose(roi[m], ref[m], rtol=0, atol=1e-5)
 
 
+def test_planes_sr_input_normalization(oracle):
+    """g20: PlanesSR with input_normalization (models.py:855-857,899-901) -- the network sees (LR - mean) / std, the residual the raw plane"""
+    g = load_golden("g20_sr_options.npz")
+    Cc, hid, nblocks, sf, R, pad, over = [int(v) for v in g["cfg"]]
+    blob, nb = Oracle.edsr_blob(sd(g, "sd."), n_up=2)
+    assert np.array_equal(g["sd.planes_mean_NON_LEARNED"].reshape(-1), g["mean"]) and np.array_equal(g["sd.planes_std_NON_LEARNED"].reshape(-1), g["std"])
+    full = oracle.planes_sr(g["lr"][0], blob, hid, nblocks, 2, pad, over, mean=g["mean"], std=g["std"])
+    np.testing.assert_allclose(full, g["sr_full"][0], rtol=0, atol=1e-5)
+    plain = oracle.planes_sr(g["lr"][0], blob, hid, nblocks, 2, pad, over)
+    assert np.abs(plain - g["sr_full"][0]).max() > 1e-3              # the normalisation matters on this fixture
+    roi = oracle.planes_sr(g["lr"][0], blob, hid, nblocks, 2, pad, over, roi=g["roi"], mean=g["mean"], std=g["std"])
+    ref = g["sr_roi"][0]
+    assert np.array_equal(np.isnan(roi), np.isnan(ref)) and np.isnan(ref).any() and (~np.isnan(ref)).any()
+    m = ~np.isnan(ref)
+    np.testing.assert_allclose(roi[m], ref[m], rtol=0, atol=1e-5)
+
+
 def _rel(a, b):
     return np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
 
