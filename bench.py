@@ -165,6 +165,15 @@ def pmc_record():
     return rec if rec.get("csrc_sha256") == csrc_tree_hash() else None
 
 
+def pmc_source():
+    """what a reader must know about every number of the line that comes from profiles/pmc_latest.json: NOT measured by this process"""
+    rec = pmc_record()
+    if rec is None:
+        return None
+    return ("profiles/pmc_latest.json (round %s): builder-run rocprofv3 --pmc passes of this same command on another MI355X box, not measured by "
+            "this process; valid for this tree only -- csrc_sha256 %s... matches the kernel sources that ran" % (rec.get("round", "?"), rec.get("csrc_sha256", "")[:16]))
+
+
 def pmc_traffic(workload, dtype):
     """HBM bytes of the workload's dominant kernel from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_latest.json,
     FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes) -- counters cannot be read from inside this process.  None when the passes were
@@ -247,7 +256,11 @@ def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
     cores = os.cpu_count() or 1
     return {"value": n / t, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d rays of the same 800x800 / 64+128 / planes 800^2 frame, %.1f s, C oracle fp32 -Ofast OpenMP (%d threads)" % (n, t, cores),
-            "evals_per_s": n * 256 / t}, psnr
+            "evals_per_s": n * 256 / t,
+            # the reference ITSELF never travels to the GPU box; its only CPU figure is the survey's
+            "reference_on_cpu": {"value": 10000 / 9.79, "unit": "rays/s", "cores": 8, "kind": "reference",
+                                 "sample": "the reference's own PyTorch path, 100x100 rays of this configuration (64+128 samples, planes 800^2) in 9.79 s on the "
+                                           "8 Xeon cores of the build container (BASELINE.md section 2 / SURVEY.md 8d) -- quoted, not measured by this process"}}, psnr
 
 
 def _sync_time(dist, dev, fn, warmup, steps):
@@ -438,6 +451,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
                               "peak_note": ("algorithmic f32 FLOP; peak = %.1f TFLOP/s dense bf16 / 6 MFMA products per f32 product" % PEAK_BF16_MFMA_TFLOPS)
                                            if limb else "v_mfma_f32_32x32x2_f32 dense peak",
                               "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
+        result["roofline"]["traffic_source"] = None if result["roofline"]["traffic"] is None else pmc_source()
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle, decoder_blob
             o = Oracle(f32=False)
@@ -515,6 +529,7 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
                               "peak_note": "algorithmic f32 FLOP over the whole step; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
                                            % (arith["pipe_peak"], arith["products"]),
                               "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
+        result["roofline"]["traffic_source"] = None if result["roofline"]["traffic"] is None else pmc_source()
         if world == 1 and not args.no_modes:
             modes = {}
             for m2 in ("f32", "bf16x3"):
@@ -755,10 +770,12 @@ def main():
         result["roofline_counters"] = None if mfma_pmc is None else {
             "mfma_busy_frac": mfma_pmc["mfma_busy_frac"], "clock_ghz": mfma_pmc["clock_ghz"], "SQ_VALU_MFMA_BUSY_CYCLES": mfma_pmc["SQ_VALU_MFMA_BUSY_CYCLES"],
             "GRBM_GUI_ACTIVE": mfma_pmc["GRBM_GUI_ACTIVE"], "note": "busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the dense peak "
-            "assumes 2.4 GHz: frac ~= busy x clock / 2.4"}
+            "assumes 2.4 GHz: frac ~= busy x clock / 2.4", "source": pmc_source()}
         result["roofline"] = {"kernel": "%s (fine pass, S=192)" % arith["kernel"], "bound": "mfma", "achieved": achieved,
                               "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                              "kernel_ms": dt * 1e3, "algorithmic_flop_per_launch": flops,
+                              "traffic_source": None if traffic is None else pmc_source(),
+                              "kernel_ms": dt * 1e3, "kernel_ms_source": "HIP events on the launch stream, this process",
+                              "algorithmic_flop_per_launch": flops,
                               "algorithmic_gather_bytes_per_launch": GATHER_BYTES_PER_EVAL * N * 192,
                               "peak_note": "algorithmic f32 FLOP; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
                                            % (arith["pipe_peak"], arith["products"]),
