@@ -47,8 +47,8 @@ __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the v
 // Epilogue shared by the conv kernels: acc[cb][pb] = 32 output channels (co0 + 32 cb + C/D row) x the 32 pixels of output row y0 + pb.
 // (one fully unrolled copy per epilogue kind: with the kind tested inside, the unroller gives up and the accumulators are
 //  indexed dynamically, i.e. go through scratch)
-template <int PB>
-__device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16 (&acc)[2][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
+template <int PB, int NCB = 2>
+__device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16 (&acc)[NCB][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
     // Round 3: per (co-block, row) the 16 channel rows of a lane are handled as a GROUP -- all 16 skip values are loaded first (independent
     // loads, one wait), then 16 stores -- through restrict-qualified local pointers with 32-bit element offsets (a plane is < 2^31 floats;
     // the batch offset is already in the pointers).  Before, every element was its own load -> s_waitcnt vmcnt(0) -> store behind 64-bit
@@ -60,7 +60,7 @@ __device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16
         constexpr int EPI = decltype(kind)::value;
         constexpr int ALIGN = decltype(aligned)::value;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 const int y = y0 + pb;
@@ -144,6 +144,16 @@ __device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16
 #ifndef CV_XCD_ORDER
 #define CV_XCD_ORDER 1
 #endif
+// the same mapping as a linear index into the tile list (the limb kernel decodes it itself: co-group fastest)
+__device__ __forceinline__ unsigned conv_tile_index() {
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z, b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#if CV_XCD_ORDER
+    const unsigned xcd = b & 7u, per = nb >> 3, rem = nb & 7u;
+    return xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+#else
+    return b;
+#endif
+}
 __device__ __forceinline__ void conv_tile_of_block(unsigned& bx, unsigned& by, unsigned& bz) {
 #if CV_XCD_ORDER
     const unsigned nb = gridDim.x * gridDim.y * gridDim.z, b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -263,17 +273,38 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // ---- the same conv on the bf16 matrix pipe: f32 operands as 3 exact bf16 limbs (limb_core.h), 6 MFMAs per product block -------------
 // Workgroup = 4 waves = 256 output channels (2 co-blocks per wave) x PB output rows x 32 pixels; input channels stream 16 at a time
 // (one K-block per tap).  The input patch is split into limbs ONCE when it is staged -- every staged value feeds 9 taps x 8 co-blocks --
-// and kept in LDS as [limb][row][col][octet][8 bf16], so a B operand (8 channels of one pixel) is one conflict-free ds_read_b128.
+// and kept in LDS as [limb][row][octet][col][8 bf16], so a B operand (8 channels of one pixel) is one ds_read_b128 and the 32 lanes of a
+// half wave (32 neighbouring pixels, one octet) read 512 contiguous bytes: conflict-free.  (Rounds 1-2 kept [row][col][octet]: the lanes
+// of a half wave then stride by 32 bytes and every 16-lane group of the read hits each bank twice -- SQ_LDS_BANK_CONFLICT was 50 % of the
+// LDS-active cycles, profiles/r03_conv_issue_counters.txt.)
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV_WIDE_ROWS8
+#define CV_WIDE_ROWS8 0     // wide layers: 1 = one output block x 8 rows per wave, 0 = two output blocks x 2..4 rows (equally fast; see conv3x3_limb_kernel)
+#endif
 #ifndef CV_COST_MODEL
 #define CV_COST_MODEL 2     // rows per tile of the limb convolution: 0 round 1's model, 1 always 4 rows, 2 measured round / row costs (SR stage 31.5 / 32.1 / 32.3 planes/s)
 #endif
 #ifndef CV_ABLATE
 #define CV_ABLATE 0     // variant builds of tools/conv_ablate.sh: 1 weight fragments of tap 0 only, 2 no patch loads, 4 no split + LDS writes
 #endif
-template <int PB, int CO_WAVES = 4>
+#ifndef CV_LDS_LAYOUT
+#define CV_LDS_LAYOUT 1     // patch items in LDS: 1 = [row][octet][col] (conflict-free reads), 0 = rounds 1-2's [row][col][octet] (A/B builds)
+#endif
+#if CV_LDS_LAYOUT
+#define CV_ITEM(R, O, COL) (((R) * 2 + (O)) * PC + (COL))
+#else
+#define CV_ITEM(R, O, COL) (((R) * PC + (COL)) * 2 + (O))
+#endif
+// CBW = output blocks per wave: 2 x PB rows (the default: a wave streams 6 KB of weight fragments per tap for 12 PB MFMAs), or 1 x 8 rows
+// (round 3, rows_per_tile = 8): the same 128 accumulators and 48 MFMAs per tap on HALF the weight fragments -- the workgroup is 128 output
+// channels x 8 rows x 32 pixels, two of them cover the 256 channels of a pixel tile and are neighbours in the tile list.  Built to test whether
+// the weight stream (the kernel's largest mover of bytes) holds the kernel back: it does not -- 254.8 vs 257.2 TFLOP/s on a 1024^2 layer
+// (16 full rounds), 86.2 vs 85.7 ms for the SR stage, FETCH_SIZE 26.8 vs 26.6 GB, same bits.  The kernel runs the matrix pipe at 81-82 % of its
+// cycles and the chip clocks it at 1.76-1.78 GHz (power; profiles/r03_conv_issue_counters.txt): 0.82 x 1.77 / 2.4 = 0.60 is the fraction of the
+// 2.4 GHz roof a launch without tile rounding reaches.
+template <int PB, int CO_WAVES = 4, int CBW = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     constexpr int PX_WAVES = 4 / CO_WAVES, ROWS = PX_WAVES * PB;
     constexpr int PR = ROWS + 2, PC = 34;
@@ -285,9 +316,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int Ho = p.H - 2, Wo = p.W - 2;
-    unsigned bx, by, bz;
-    conv_tile_of_block(bx, by, bz);
-    const int x0 = bx * 32, y0 = by * ROWS, cg = bz % p.ncg, bi = bz / p.ncg;
+    // tile of this workgroup: the XCD-contiguous linear tile index (conv_tile_index), co-group FASTEST -- the co-groups of one pixel tile
+    // read the same input patch and sit next to each other in an XCD's share of the list --, then column chunk, row tile, plane
+    const unsigned blk = conv_tile_index();
+    const unsigned ncg = (unsigned)p.ncg;
+    const int cg = (int)(blk % ncg);
+    const unsigned pt = blk / ncg, bx = pt % gridDim.x, by = (pt / gridDim.x) % gridDim.y, bi = pt / (gridDim.x * gridDim.y);
+    const int x0 = bx * 32, y0 = by * ROWS;
     p.in += bi * p.in_bs;
     p.out += bi * p.out_bs;
     if (p.skip) p.skip += bi * p.skip_bs;
@@ -295,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     const long HW = (long)Hr * Wr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int cw = wave_u / PX_WAVES, rg = wave_u % PX_WAVES;   // co-wave, pixel-row group
-    const int cb0 = (cg * CO_WAVES + cw) * 2;                   // first of this wave's two output blocks
+    const int cb0 = (cg * CO_WAVES + cw) * CBW;                 // first of this wave's output blocks
 
     // staging items: every load is unconditional (clamped source, uniform channel base + one 32-bit lane offset); border pixels and the
     // threads past the last item are handled by ONE select / ONE store predicate per item
@@ -310,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         const int yr = min(y0 + r, p.H - 1) - p.pad, xr = min(x0 + c, p.W - 1) - p.pad;
         inside[i] = yr >= 0 && yr < Hr && xr >= 0 && xr < Wr;
         voff[i] = o * 8 * (int)HW + (inside[i] ? yr * Wr + xr : 0);
-        sl[i] = ((r * PC + c) * 2 + o) * 4;
+        sl[i] = CV_ITEM(r, o, c) * 4;                  // [row][octet][col]: the 32 lanes of a half wave read 32 CONSECUTIVE 16-byte items
     }
     float st[IT][8];
     auto gload = [&](int chunk) {
@@ -336,9 +371,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         }
     };
 
-    f32x16 acc[2][PB];
+    f32x16 acc[CBW][PB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < CBW; ++a)
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
@@ -354,25 +389,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks && !(CV_ABLATE & 2)) gload(chunk + 1);          // in flight during this chunk's MFMAs
         const u32x4* wa = wbase + chunk * wchunk;
-        const unsigned* pl = lds + buf * BUF + (j * 2 + h) * 4;
+        const unsigned* pl = lds + buf * BUF + CV_ITEM(0, h, j) * 4;
         // A fragments one tap ahead (the sched_barriers keep hipcc from hoisting every load of the chunk to its top: 95+ spills)
-        u32x4 A[2][3], An[2][3];
+        u32x4 A[CBW][3], An[CBW][3];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
             for (int t = 0; t < 3; ++t) A[cb][t] = wa[((cb * 9 + 0) * 3 + t) * 64 + lane];
         // B fragments of a tap's FIRST row come from the previous tap (round 3): the sched_barriers at the tap boundaries keep hipcc from
         // hoisting them, and every tap used to open with an exposed LDS round trip (9 per chunk)
         u32x4 B0[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB) * PC) * 8);
+        for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV_ITEM(rg * PB, 0, 0) * 4);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9 && !(CV_ABLATE & 1)) {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * 3 + t) * 64 + lane];
             }
@@ -384,21 +419,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
                 u32x4 B[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    B[t] = pb == 0 ? B0[t] : *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + pb + ky) * PC + kx) * 8);
+                    B[t] = pb == 0 ? B0[t] : *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV_ITEM(rg * PB + pb + ky, 0, kx) * 4);
                 if (pb == PB - 1 && tap + 1 < 9) {
                     const int ky1 = (tap + 1) / 3, kx1 = (tap + 1) % 3;
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + ((rg * PB + ky1) * PC + kx1) * 8);
+                    for (int t = 0; t < 3; ++t) B0[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV_ITEM(rg * PB + ky1, 0, kx1) * 4);
                 }
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
                     for (int q = 0; q < 6; ++q) acc[cb][pb] = mfma_bf16(A[cb][limb_w(3, q)], B[limb_x(3, q)], acc[cb][pb]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9 && !(CV_ABLATE & 1)) {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) A[cb][t] = An[cb][t];
             }
@@ -406,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
         if (chunk + 1 < nchunks && !(CV_ABLATE & 4)) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);
+    conv_write_out<PB, CBW>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);
 }
 
 // limb fragments of a conv's weights: [chunk of 16 ci][cb][tap][limb][lane][4 words]; lane (co = 32 cb + (l & 31), h = l >> 5) holds
@@ -510,7 +545,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                 hipStream_t stream, int pad, int batch, ConvExec cx) {
     const int arith = conv_resolve_arith(cx.arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
-    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4)) return NVSR_ERR_SHAPE;
+    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
@@ -525,6 +560,14 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         p.ncg = 1;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
         hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
+        return NVSR_CHECK_LAUNCH();
+    }
+    if (cx.rows == 8 && !(wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2)) return NVSR_ERR_SHAPE;   // (only the wide limb kernel has it)
+    if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2 && (cx.rows == 8 || (cx.rows == 0 && CV_WIDE_ROWS8))) {
+        // bf16-limb kernel, 1 output block x 8 rows per wave: 4-wave workgroups of 128 output channels x 8 rows x 32 pixels
+        p.ncg = p.ncb_total / 4;
+        dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
+        hipLaunchKernelGGL((conv3x3_limb_kernel<8, 4, 1>), grid, dim3(256), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
     if (wlimb && arith != NVSR_ARITH_F32) {
