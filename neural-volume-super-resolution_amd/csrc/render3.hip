@@ -52,6 +52,10 @@
 #define R3_MARKH(i)
 #define R3_RESETH
 #endif
+#ifndef R3_NO_VIEW_HOIST
+#define R3_NO_VIEW_HOIST 1
+#endif
+
 namespace nvsr {
 
 constexpr int RAY3_FLOATS = 20;      // ro, rd, |rd|, near | view-plane taps | far (+ 3 spare): the per-ray constants of a tile
@@ -315,6 +319,13 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     unsigned* cw = const_cast<unsigned*>(ring3_issue<LIMBS, 3>(rs, KB_RGB0));      // chunk 0 of sample 0; every later one is issued during the previous sample
     for (int s = 0; s < S; ++s) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
+#if R3_NO_VIEW_HOIST
+        // The view features are loop-invariant and so are their limbs: hipcc hoists the two split_feat(V) of a step out of the sample loop
+        // (72 registers of limbs), runs out of registers and spills 8 of them plus the two depth-row pointers -- 4 scratch reloads per
+        // sample, each behind an s_waitcnt vmcnt(0) that also waits for every gather and weight copy in flight.  Opaque per iteration.
+#pragma unroll
+        for (int c = 0; c < HALF_C; ++c) asm volatile("" : "+v"(X.V[c]), "+v"(Y.V[c]));
+#endif
         const int lane = rs.lane, h = lane >> 5;
         const bool last = (s + 1 == S);
         X.zn = depth_of(zX, rcX, last ? s : s + 1);            // (unconditional loads unless ZCOMP: ring3_sync<2> below counts them)
