@@ -316,12 +316,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int Ho = p.H - 2, Wo = p.W - 2;
-    // tile of this workgroup: the XCD-contiguous linear tile index (conv_tile_index), co-group FASTEST -- the co-groups of one pixel tile
-    // read the same input patch and sit next to each other in an XCD's share of the list --, then column chunk, row tile, plane
+    // tile of this workgroup from the XCD-contiguous linear tile index (conv_tile_index): column chunk, row tile, then (plane, co-group) --
+    // co-group SLOWEST for the 2-block wave tile: the workgroups that run together on an XCD then stream ONE co-group's 3.5 MB of weight
+    // fragments through its 4 MB L2 (with the co-group fastest the four co-groups of a 256 -> 1024 layer keep 14 MB live and FETCH_SIZE of
+    // those layers doubles: measured, 2.1 -> 4.1 GB); co-group FASTEST for the 1-block x 8-row wave tile, whose two co-groups share a patch and
+    // together stream the same 3.5 MB
     const unsigned blk = conv_tile_index();
-    const unsigned ncg = (unsigned)p.ncg;
-    const int cg = (int)(blk % ncg);
-    const unsigned pt = blk / ncg, bx = pt % gridDim.x, by = (pt / gridDim.x) % gridDim.y, bi = pt / (gridDim.x * gridDim.y);
+    const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
+    unsigned pt, bi;
+    int cg;
+    if (CBW == 1) { cg = (int)(blk % ncg); const unsigned q = blk / ncg; pt = q % npt; bi = q / npt; }
+    else { pt = blk % npt; const unsigned q = blk / npt; cg = (int)(q % ncg); bi = q / ncg; }
+    const unsigned bx = pt % gridDim.x, by = pt / gridDim.x;
     const int x0 = bx * 32, y0 = by * ROWS;
     p.in += bi * p.in_bs;
     p.out += bi * p.out_bs;
