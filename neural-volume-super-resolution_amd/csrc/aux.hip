@@ -194,14 +194,18 @@ __global__ __launch_bounds__(WPB * 64) void sample_pdf_kernel(long N, int nb, in
                     [&](int j, float v) { out[j] = v; });
 }
 
-// rank sort of n <= 512 values held in LDS: rank = #smaller + #equal-with-lower-index (values only matter, like torch.sort)
+// rank sort of n <= 512 values held in LDS: rank = #smaller + #equal-with-lower-index (values only matter, like torch.sort).  NaNs order
+// like torch.sort's: after every number, among themselves by index (round 3: with plain < / == every NaN got rank 0 and the row lost
+// elements).
 __device__ __forceinline__ void rank_sort_wave(const float* vals /*LDS[n]*/, int n, float* __restrict__ out, int lane) {
     for (int e = lane; e < n; e += 64) {
         const float v = vals[e];
+        const bool vnan = v != v;
         int rank = 0;
         for (int k = 0; k < n; ++k) {
             const float o = vals[k];
-            rank += (o < v) || (o == v && k < e);
+            const bool onan = o != o;
+            rank += (o < v) || (!onan && vnan) || ((o == v || (onan && vnan)) && k < e);
         }
         out[rank] = v;
     }
@@ -215,11 +219,13 @@ __device__ __forceinline__ void rank_sort_wave(const float* vals /*LDS[n]*/, int
 __device__ __forceinline__ void merge_sort_wave(const float* all /*LDS[na+nb]*/, int na, int nb, float* __restrict__ out, int lane) {
     const float* a = all;
     const float* b = all + na;
-    bool oka = true, okb = true;
+    bool oka = true, okb = true, finite = true;
     for (int i = lane; i + 1 < na; i += 64) oka = oka && (a[i] <= a[i + 1]);
     for (int j = lane; j + 1 < nb; j += 64) okb = okb && (b[j] <= b[j + 1]);
+    for (int j = lane; j < na + nb; j += 64) finite = finite && (all[j] == all[j]);
     const bool sa = __builtin_amdgcn_ballot_w64(!oka) == 0, sb = __builtin_amdgcn_ballot_w64(!okb) == 0;
-    if (!sa) { rank_sort_wave(all, na + nb, out, lane); return; }
+    // (a NaN anywhere -- the searches below count with < / <= -- takes the NaN-aware rank sort)
+    if (!sa || __builtin_amdgcn_ballot_w64(!finite) != 0) { rank_sort_wave(all, na + nb, out, lane); return; }
     for (int i = lane; i < na; i += 64) {
         const float v = a[i];
         int cnt = 0;
@@ -289,13 +295,102 @@ __global__ __launch_bounds__(WPB * 64) void sort_rows_kernel(long N, int n, cons
     rank_sort_wave(vals[wave], n, out + row * n, lane);
 }
 
+// The inference shape of the resampler (round 3): deterministic u (linspace), Nc <= 64 coarse depths in all[0..Nc), Nf <= 128 samples.
+// The general path below spends ~700 VALU instructions per ray, most of them in data-dependent binary-search loops (it is VALU-issue-bound:
+// one ray per ~2 000 cycles and SIMD with 10 waves resident).  Here every search is either a fixed 6-step branch-free one or replaced:
+//   * searchsorted(cdf, u, right): lo = #(cdf <= u), 6 steps over the cdf padded to 64 entries with +inf (valid because the pdf is checked
+//     to be non-negative and NaN-free, i.e. the cdf is non-decreasing);
+//   * rank of sample j in the merged row = j + #(a <= b_j): b_j lies in bin `below` whose edges are mid-points of a, so the count is
+//     below + 1 plus at most two compares -- then VERIFIED against the definition (a[k-1] <= b_j < a[k]);
+//   * rank of coarse depth i = i + #(b < a_i) = i + #{j : #(a <= b_j) <= i} (a is sorted): a 65-bin histogram of the counts above (LDS
+//     atomics) and one wave scan, no search at all.
+// Same samples (same operations in the same order as sample_pdf_wave) and the same ranks as merge_sort_wave, i.e. the same bits as
+// torch.sort(cat(z, samples)).  Returns false -- nothing written -- when a precondition fails (a NaN, a negative weight, unsorted depths or
+// samples, a failed verification): the caller then runs the general path.
+__device__ __forceinline__ bool resample_fast_wave(int Nc, int Nf, float* all, float* zm, float* cdf, const float* __restrict__ w, int lane,
+                                                   float* __restrict__ out) {
+    const int nb = Nc - 1, nw = Nc - 2;
+    const float a_i = lane < Nc ? all[lane] : 0.0f;
+    const float a_n = lane + 1 < Nc ? all[lane + 1] : 0.0f;
+    bool ok = !(lane + 1 < Nc) || (a_i <= a_n);                          // coarse depths sorted (and not NaN)
+    if (lane < nb) zm[lane] = __fmul_rn(0.5f, __fadd_rn(a_n, a_i));
+    // pdf / cdf exactly as sample_pdf_wave (one 64-lane pass: nw <= 62)
+    const float wi = lane < nw ? __fadd_rn(w[lane + 1], 1e-5f) : 0.0f;
+    const float total = wave_sum(wi);
+    const float p = lane < nw ? __fdiv_rn(wi, total) : 0.0f;
+    ok = ok && (p >= 0.0f);                                              // (false for NaN)
+    const float sc = wave_scan_add(p, lane) + 0.0f;
+    if (lane == 0) cdf[0] = 0.0f;
+    if (lane < nw) cdf[lane + 1] = sc;
+    if (lane >= nb) cdf[lane] = __builtin_inff();                        // pad to 64 entries
+    int* hist = reinterpret_cast<int*>(cdf) + 64;                        // 65 bins behind the cdf
+    hist[lane] = 0;
+    if (lane == 0) hist[64] = 0;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return false;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float smp[2];
+    int cntb[2];
+    bool good = true;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        const bool live = j < Nf;
+        const float uj = linspace01(live ? j : 0, Nf);
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) lo += (cdf[lo + step - 1] <= uj) ? step : 0;
+        const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+        const float c0 = cdf[below], c1 = cdf[above];
+        float denom = __fsub_rn(c1, c0);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = __fdiv_rn(__fsub_rn(uj, c0), denom);
+        const float b0 = zm[below], b1 = zm[above];
+        const float v = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+        smp[q] = v;
+        if (live) all[Nc + j] = v;
+        // #(a <= v): a[0..below] <= zm[below] <= v; then at most a[below + 1], a[below + 2]
+        int k = min(below + 1, Nc);
+        k += (k < Nc && all[k] <= v) ? 1 : 0;
+        k += (k < Nc && all[k] <= v) ? 1 : 0;
+        const bool lo_ok = (k == 0) || (all[k - 1] <= v), hi_ok = (k == Nc) || !(all[k] <= v);
+        good = good && (!live || (lo_ok && hi_ok && v == v));
+        cntb[q] = k;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // samples sorted?  (always, for a non-decreasing cdf and increasing u -- checked, not assumed)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j + 1 < Nf) good = good && (smp[q] <= all[Nc + j + 1]);
+    }
+    if (__builtin_amdgcn_ballot_w64(!good) != 0) return false;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (lane + 64 * q < Nf) atomicAdd(&hist[cntb[q]], 1);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int below_or_at = (int)wave_scan_add((float)hist[lane], lane);   // #{j : cnt_b[j] <= lane} (<= 128: exact in f32)
+    if (lane < Nc) out[lane + below_or_at] = a_i;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j < Nf) out[j + cntb[q]] = smp[q];
+    }
+    return true;
+}
+
 // train_utils.py:144-155 fused: z_mid -> sample_pdf(z_mid, w[1:-1]) -> sort(cat(z, samples))
 // zc == NULL: the coarse depths are the un-jittered ones of train_utils.py:95-100 and are recomputed from the ray's near / far (packed rays
 // columns 6, 7) -- bit for bit what nvsr_coarse_z writes -- so that an inference frame never stores them
+#ifndef NVSR_RESAMPLE_GENERAL_ONLY
+#define NVSR_RESAMPLE_GENERAL_ONLY 0
+#endif
 __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, int Nc, int Nf, const float* __restrict__ zc,
                                                                       const float* __restrict__ rays, int lindisp,
                                                                       const float* __restrict__ weights,
-                                                                      const float* __restrict__ u, float* __restrict__ zf) {
+                                                                      const float* __restrict__ u, float* __restrict__ zf, int force_general) {
     __shared__ float cdf_s[WPB][256];
     __shared__ float zmid_s[WPB][256];
     __shared__ float all_s[WPB][512];
@@ -314,6 +409,11 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
+#if !NVSR_RESAMPLE_GENERAL_ONLY
+    if (!u && Nc >= 3 && Nc <= 64 && Nf >= 1 && Nf <= 128 && !force_general)
+        if (resample_fast_wave(Nc, Nf, all, zm, cdf_s[wave], w, lane, zf + ray * (Nc + Nf))) return;
+    __builtin_amdgcn_wave_barrier();
+#endif
     for (int i = lane; i < Nc - 1; i += 64) zm[i] = __fmul_rn(0.5f, __fadd_rn(all[i + 1], all[i]));
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -496,13 +596,20 @@ int nvsr_sort_rows(int64_t N, int n, const float* in, float* out, nvsr_stream_t 
     return NVSR_CHECK_LAUNCH();
 }
 
+// NVSR_RESAMPLE_GENERAL=1 (environment, read once): every ray takes the general path of importance_resample_kernel (A/B timing)
+static int resample_general_only() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NVSR_RESAMPLE_GENERAL"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, const float* weights, const float* u, float* z_fine,
                              nvsr_stream_t stream) {
     if (!z_coarse || !weights || !z_fine) return NVSR_ERR_NULL;
     if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
-                       z_coarse, (const float*)nullptr, 0, weights, u, z_fine);
+                       z_coarse, (const float*)nullptr, 0, weights, u, z_fine, resample_general_only());
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -512,7 +619,7 @@ int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, 
     if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
-                       (const float*)nullptr, rays, lindisp, weights, u, z_fine);
+                       (const float*)nullptr, rays, lindisp, weights, u, z_fine, resample_general_only());
     return NVSR_CHECK_LAUNCH();
 }
 

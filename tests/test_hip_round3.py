@@ -256,3 +256,60 @@ def test_run_network_mirror_matches_golden_raw_field(hip):
     # and it agrees with what the fused coarse pass composites from: the same points through the decode operator
     flat = torch.cat([T(g["pts"]).reshape(-1, 3), T(g["ray_batch"])[:, None, -3:].expand(40, 32, 3).reshape(-1, 3)], -1)
     assert torch.equal(mf(flat).reshape(40, 32, 4), raw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# resampler: the deterministic-u fast path (csrc/aux.hip resample_fast_wave)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_resampler_fast_path_is_bit_identical_to_the_separate_kernels(hip):
+    """Inference frames (deterministic u, Nc <= 64, Nf <= 128) take resample_fast_wave: branch-free 6-step searches, sample ranks from the
+    bin index + two verified compares, coarse-depth ranks from a histogram + wave scan.  Whatever the ray -- spiked pdfs that put every
+    sample into one bin, flat pdfs (samples exactly on bin edges), runs of equal depths, zero-width rays (near == far), lindisp depths
+    computed in the kernel -- and on the rays that must FALL BACK to the general path (NaN or negative weights, unsorted depths), the
+    result is bit for bit sort(cat(z, sample_pdf(z_mid, w[1:-1]))) as the separate kernels produce it (train_utils.py:144-155)."""
+    capi = hip.capi
+    rng = np.random.default_rng(33)
+    for (N, Nc, Nf) in ((2051, 64, 128), (300, 64, 64), (257, 17, 128), (129, 3, 5), (64, 64, 1)):
+        z = np.sort(rng.uniform(2, 6, (N, Nc)).astype(np.float32), -1)
+        z[1::7, Nc // 3:] = z[1::7, Nc // 3 - 1: Nc // 3]               # long runs of equal depths
+        z[2::11] = 3.25                                                  # zero-width rays
+        w = (rng.uniform(0, 1, (N, Nc)) ** 6).astype(np.float32)
+        w[::3] = 0.0                                                     # flat pdf
+        w[4::9] = 0.0
+        w[4::9, min(Nc - 2, 1 + Nc // 2)] = 50.0                         # one spike: (almost) every sample in one bin
+        w[5::13, Nc // 2] = np.nan                                       # fallback: NaN
+        w[6::17, 1:] = -0.5                                              # fallback: negative pdf
+        zz = z.copy()
+        zz[7::19] = rng.permuted(z[7::19], axis=-1)                      # fallback: unsorted depths
+        z_d, w_d = T(zz), T(w)
+        zf = torch.empty((N, Nc + Nf), device=DEV)
+        capi.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_d), capi.ptr(w_d), None, capi.ptr(zf), capi.stream())
+        zm = (0.5 * (z_d[:, 1:] + z_d[:, :-1])).contiguous()
+        smp = torch.empty((N, Nf), device=DEV)
+        capi.call("nvsr_sample_pdf", N, Nc - 1, Nf, capi.ptr(zm), capi.ptr(w_d[:, 1:-1].contiguous()), None, capi.ptr(smp), capi.stream())
+        cat = torch.cat([z_d, smp], -1).contiguous()
+        ref = torch.empty_like(cat)
+        capi.call("nvsr_sort_rows", N, Nc + Nf, capi.ptr(cat), capi.ptr(ref), capi.stream())
+        # (rows poisoned by a NaN weight: NaNs sort last like torch.sort's, in the fused kernel and in nvsr_sort_rows alike)
+        tref = torch.sort(cat.cpu(), -1).values.to(DEV)     # (the documented order -- NaNs last -- as the CPU implementation gives it)
+        assert torch.equal(torch.isnan(zf), torch.isnan(tref)) and torch.equal(torch.isnan(ref), torch.isnan(tref))
+        assert torch.equal(zf.nan_to_num(nan=-1.0), tref.nan_to_num(nan=-1.0)), (N, Nc, Nf)
+        assert torch.equal(ref.nan_to_num(nan=-1.0), tref.nan_to_num(nan=-1.0))
+    # depths computed in the kernel from the packed rays' near / far (nvsr_importance_resample_rays), linear and lindisp
+    N, Nc, Nf = 1000, 64, 128
+    rays = torch.zeros((N, 11), device=DEV)
+    rays[:, 6] = T(rng.uniform(0.5, 2.5, N).astype(np.float32))
+    rays[:, 7] = rays[:, 6] + T(rng.uniform(0.0, 5.0, N).astype(np.float32))
+    w_d = T((rng.uniform(0, 1, (N, Nc)) ** 3).astype(np.float32))
+    for lindisp in (0, 1):
+        z_d = torch.empty((N, Nc), device=DEV)
+        capi.call("nvsr_coarse_z", N, Nc, capi.ptr(rays), lindisp, None, capi.ptr(z_d), capi.stream())
+        a = torch.empty((N, Nc + Nf), device=DEV)
+        b = torch.empty_like(a)
+        capi.call("nvsr_importance_resample_rays", N, Nc, Nf, capi.ptr(rays), lindisp, capi.ptr(w_d), None, capi.ptr(a), capi.stream())
+        capi.call("nvsr_importance_resample", N, Nc, Nf, capi.ptr(z_d), capi.ptr(w_d), None, capi.ptr(b), capi.stream())
+        zm = (0.5 * (z_d[:, 1:] + z_d[:, :-1])).contiguous()
+        smp = torch.empty((N, Nf), device=DEV)
+        capi.call("nvsr_sample_pdf", N, Nc - 1, Nf, capi.ptr(zm), capi.ptr(w_d[:, 1:-1].contiguous()), None, capi.ptr(smp), capi.stream())
+        ref = torch.sort(torch.cat([z_d, smp], -1), -1).values
+        assert torch.equal(a, ref) and torch.equal(b, ref), lindisp
