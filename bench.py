@@ -416,7 +416,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
                          "plane_memory_format": "NCHW" if args.nchw_planes else "channels_last (same [1,48,R,R] parameters, native [H][W][C] memory)",
                          "partition": par,
-                         "parallelism": "rays sharded by rank; one coalesced in-place all-reduce of the %s per step"
+                         "parallelism": "rays sharded by rank; in-place asynchronous all-reduces of the %s (one per tensor, one wait) per step"
                                         % ("plane + decoder gradients" if "decoder" in what else "plane gradients (23 MB)")}}
     if rank == 0:
         # dominant kernel: gate-driven backward of the fine pass (transposed layers + plane scatter + gradient half of the record), S = 128

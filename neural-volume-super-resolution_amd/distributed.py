@@ -164,9 +164,9 @@ def super_resolve_planes_sharded(sr_model, plane_names, group=None, sr_fn=None):
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):
     """Sum (or average) a list of gradient tensors over the ranks.  The loss is a mean over rays (train_nerf.py:884-891), so with rays
     sharded evenly the data-parallel gradient is the average of the per-rank gradients.
-    RCCL: every dense tensor (row-major or channels_last -- the plane gradients are channels_last views) is reduced IN PLACE, all of them
-    inside one coalesced group (one ncclGroup launch): no flattening copy in, none out (round 2 concatenated the 23 MB of plane gradients
-    into a bucket and copied them back every step).  Other backends (gloo rehearsals) and non-dense tensors go through flat buckets of
+    RCCL: every dense tensor (row-major or channels_last -- the plane gradients are channels_last views) is reduced IN PLACE by its own
+    asynchronous all-reduce, all queued before the first wait: no flattening copy in, none out (round 2 concatenated the 23 MB of plane
+    gradients into a bucket and copied them back every step).  Other backends (gloo rehearsals) and non-dense tensors go through flat buckets of
     ~bucket_bytes, staged through the host when the backend needs it."""
     rank, world = world_info(group)
     if world == 1:
@@ -179,10 +179,10 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True
 
     direct = [t for t in tensors if t.is_cuda and dense(t)] if dist.get_backend(group) == "nccl" else []
     if direct:
-        with dist._coalescing_manager(group=group, device=direct[0].device, async_ops=True) as cm:
-            for t in direct:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        cm.wait()
+        # one asynchronous collective per tensor, queued back to back on RCCL's stream (4 planes + 2 decoder blobs per step), then one wait
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in direct]
+        for wk in works:
+            wk.wait()
         if scale is not None:
             torch._foreach_mul_(direct, scale)
     ids = {id(t) for t in direct}
