@@ -65,13 +65,24 @@ __device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* b
 }
 // the layer's ReLU gate in relu_publish's format: bit (ib & 1) * 16 + r of word ib >> 1  <=>  pre-activation > 0
 __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* __restrict__ rec, int layer) {
+    // act = max(., 0) is +0 or a positive number (never -0: v_max_f32 of (x, +0) returns +0 for x = -0): act > 0  <=>  its bits, read as
+    // a signed integer, are >= 1.  clamp(bits, 0, 1) is one v_med3_i32 and the insertion one v_lshl_or_b32: 2 instructions per element, no
+    // VCC.  (The compare + select form cost 3.5 issue slots per element -- v_cmp, 1-2 wait-state s_nops, v_cndmask from one of 32 constant
+    // registers, half a v_or3 -- 1 800 of the 9 700 VALU issue slots of a tile, none of them in an MFMA gap.  Inline asm, four elements per
+    // statement: written in C++ hipcc canonicalises clamp(bits, 0, 1) << k back into compare + select, and between two asm statements it
+    // pads an s_nop.)
     unsigned m0 = 0u, m1 = 0u;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned bit = act[ib][r] > 0.0f ? (1u << ((ib & 1) * 16 + r)) : 0u;
-            if (ib < 2) m0 |= bit; else m1 |= bit;
+        for (int r = 0; r < 16; r += 4) {
+            unsigned t0, t1, t2, t3;
+            unsigned& m = ib < 2 ? m0 : m1;
+            asm("v_med3_i32 %1, %5, 0, 1\n\tv_med3_i32 %2, %6, 0, 1\n\tv_med3_i32 %3, %7, 0, 1\n\tv_med3_i32 %4, %8, 0, 1\n\t"
+                "v_lshl_or_b32 %0, %1, %9, %0\n\tv_lshl_or_b32 %0, %2, %10, %0\n\tv_lshl_or_b32 %0, %3, %11, %0\n\tv_lshl_or_b32 %0, %4, %12, %0"
+                : "+v"(m), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                : "v"(act[ib][r]), "v"(act[ib][r + 1]), "v"(act[ib][r + 2]), "v"(act[ib][r + 3]), "n"((ib & 1) * 16 + r), "n"((ib & 1) * 16 + r + 1),
+                  "n"((ib & 1) * 16 + r + 2), "n"((ib & 1) * 16 + r + 3));
         }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};
@@ -213,8 +224,9 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
                                                                     const float* __restrict__ rays, const float* __restrict__ z,
                                                                     float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) unsigned lds[L3_LDS];
+    // (wave index as a SCALAR: the LDS destination of every weight-copy piece then is scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
     RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(3)), 0, KB_TOTAL * kb_words(3) * 4, 0x00020000), lds, 0,
-             (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+             __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += L3_TPB) ldsf[L3_SMALL + i] = packed[P_SMALL + i];   // published by the first ring barrier
     const float* small = ldsf + L3_SMALL;
