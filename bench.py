@@ -43,6 +43,12 @@ FLOP_PER_EVAL = 259072          # 129 536 MAC per decoded point
 GATHER_BYTES_PER_EVAL = 3072    # 16 texels x 48 ch x 4 B
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16 in 32 clk) x 2.4 GHz
+# What bare MFMA streams sustain on this chip (profiles/r03_mfma_power_roof.txt, tools/mfma_power_roof.hip; builder-run, NOT measured by this process): at
+# 100 % matrix-pipe occupancy the clock is a power limit -- 2.38 GHz on all-zero operands, 1.65 GHz on random bf16 operands.  Informational only:
+# `roofline.frac` stays priced against the 2.4 GHz dense peak.
+SUSTAINED_BF16_MFMA = {"tflops_random_operands": 1734.9, "tflops_zero_operands": 2493.3, "frac_of_peak_random": 0.689,
+                       "source": "profiles/r03_mfma_power_roof.txt (tools/mfma_power_roof.hip: bare v_mfma_f32_32x32x16_bf16 streams, 256 CUs; builder-run "
+                                 "on another MI355X box, not measured by this process)"}
 # Arithmetic of the fused render pass (include/nvsr.h NVSR_ARITH_*): kernel, executed MFMA work per algorithmic FLOP, pipe peak.
 # The roofline peak of a limb mode is the bf16 pipe's dense peak divided by the bf16 products it spends per f32 product.
 ARITHMETIC = {
@@ -780,6 +786,8 @@ def main():
                               "peak_note": "algorithmic f32 FLOP; peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product"
                                            % (arith["pipe_peak"], arith["products"]),
                               "executed_mfma_tflops": achieved * arith["products"], "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        if arith["pipe_peak"] == PEAK_BF16_MFMA_TFLOPS:
+            result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_random=achieved * arith["products"] / SUSTAINED_BF16_MFMA["tflops_random_operands"])
         # bandwidth-bound stages: the helper kernels alone, and the fused pass's plane sampling + compositing as the HBM traffic the
         # counters saw (profiles/pmc_latest.json) over the live kernel time
         result["hbm_stages"] = hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws)
