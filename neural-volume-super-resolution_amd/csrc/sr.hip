@@ -30,6 +30,7 @@ struct ConvParams {
     const float* in;      // [Cin][H-2pad][W-2pad]
     const float* wpk;     // packed weights [chunk][cb][t][lane]
     const unsigned* wpk_limb;   // bf16-limb fragments behind them (conv_limb_eligible layers), else NULL
+    const unsigned* wpk_limb16; // 16x16x32 fragments behind those (conv_limb16_eligible layers), else NULL
     float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
     const float* skip;    // EPI_RESIDUAL: identity [Cout][H+2][W+2] (block input); EPI_MASK_SCALE: forward activation
                           // [Cout][H-2][W-2] whose sign gates the result; EPI_ADD_CENTER: [Cout][H-6][W-6] added to the centre
@@ -280,6 +281,9 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV_USE_16X16X32
+#define CV_USE_16X16X32 1   // limb layers with Cin % 32 == 0 and Cout % 128 == 0 (all of EDSR's trunk and up-sampling convolutions): 1 = conv3x3_limb16_kernel
+#endif
 #ifndef CV_WIDE_ROWS8
 #define CV_WIDE_ROWS8 0     // wide layers: 1 = one output block x 8 rows per wave, 0 = two output blocks x 2..4 rows (equally fast; see conv3x3_limb_kernel)
 #endif
@@ -450,6 +454,235 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     conv_write_out<PB, CBW>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);
 }
 
+// ---- the same conv on v_mfma_f32_16x16x32_bf16 (round 3) -------------------------------------------------------------------------------------
+// Why another shape: these kernels run at the chip's power limit, and bare MFMA streams at two waves per SIMD sustain 2 050 TFLOP/s with the
+// 16x16x32 instruction against 1 793 with 32x32x16 on random operands (tools/mfma_power_roof.hip, profiles/r03_mfma_power_roof.txt): the
+// smaller accumulator tile moves a quarter of the accumulator bytes per FLOP.
+// D[16 co][16 pixels] += W[16 co][32 ci] x X[32 ci][16 pixels]: lane (i = l & 15, g = l >> 4) holds A = 8 input channels 8g..8g+7 of output
+// channel i, B = the same 8 channels of pixel i, and D rows 4g..4g+3 (output channels) of column i (pixel).  Input channels stream 32 at a
+// time; the patch sits in LDS as [limb][row][octet 0..3][col][8 bf16].  Wave = 2 co-blocks (32 channels) x PB rows x 2 half-rows of 16 pixels
+// (64 accumulator registers at PB = 4), workgroup = 4 waves = 128 output channels of one PB x 32 pixel tile, two workgroups per CU.
+// Per tap a wave reads 6 weight fragments (one tap ahead) and, per (row, half-row), 3 B fragments for 12 MFMAs.  Same limb products in the same
+// order per (ci block, tap), but the K dimension of an instruction spans 32 channels instead of 16: the f32 accumulation order differs from
+// conv3x3_limb_kernel's, results agree to rounding (both are held to the oracle at 3e-5).
+template <int PB>
+__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[2][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo) {
+    float* __restrict__ const out = p.out;
+    const float* __restrict__ const skip = p.skip;
+    const int i = lane & 15, g = lane >> 4;
+    auto write_out = [&](auto kind) {
+        constexpr int EPI = decltype(kind)::value;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    const int y = y0 + pb, x = x0 + 16 * hx + i;
+                    if (!(y < Ho && x < Wo)) continue;
+                    const int cbase = co0 + 16 * cb + 4 * g;                 // channel of register r: cbase + r
+                    float sk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (EPI == EPI_RESIDUAL || EPI == EPI_MASK_SCALE || EPI == EPI_ADD_CENTER) {
+                        const int sH = EPI == EPI_RESIDUAL ? Ho + 4 : EPI == EPI_MASK_SCALE ? Ho : Ho - 4;
+                        const int sW = EPI == EPI_RESIDUAL ? Wo + 4 : EPI == EPI_MASK_SCALE ? Wo : Wo - 4;
+                        const int sy = EPI == EPI_RESIDUAL ? y + 2 : EPI == EPI_MASK_SCALE ? y : y - 2;
+                        const int sx = EPI == EPI_RESIDUAL ? x + 2 : EPI == EPI_MASK_SCALE ? x : x - 2;
+                        const bool sin = sy >= 0 && sy < sH && sx >= 0 && sx < sW;
+                        const int splane = sH * sW, s0 = cbase * splane + sy * sW + sx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float ld = skip[sin ? s0 + r * splane : 0];
+                            sk[r] = sin ? ld : 0.0f;
+                        }
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = acc[cb][pb][hx][r];
+                        if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
+                        if (EPI == EPI_RESIDUAL) t = t * 0.1f + sk[r];
+                        if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;
+                        if (EPI == EPI_ADD_CENTER) t += sk[r];
+                        v[r] = t;
+                    }
+                    if (EPI == EPI_PIXEL_SHUFFLE) {        // co -> (co >> 2, 2y + ((co >> 1) & 1), 2x + (co & 1)); cbase is a multiple of 4
+                        const int oplane = 4 * Ho * Wo, o0 = (cbase >> 2) * oplane + (2 * y) * (2 * Wo) + 2 * x;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[o0 + ((r >> 1) & 1) * (2 * Wo) + (r & 1)] = v[r];
+                    } else {
+                        const int oplane = Ho * Wo, o0 = cbase * oplane + y * Wo + x;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[o0 + r * oplane] = v[r];
+                    }
+                }
+    };
+    switch (p.epilogue) {
+        case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
+        case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
+        case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
+        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
+        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
+        default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int PB>
+__global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
+    constexpr int PR = PB + 2, PC = 34;
+    constexpr int ITEMS = 4 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
+    constexpr int IT = (ITEMS + 255) / 256;
+    constexpr int LIMB_WORDS = PR * PC * 4 * 4;           // one limb of the patch
+    constexpr int BUF = 3 * LIMB_WORDS;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
+#define CV16_ITEM(R, O, COL) (((R) * 4 + (O)) * PC + (COL))
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+    const int Ho = p.H - 2, Wo = p.W - 2;
+    const unsigned blk = conv_tile_index();
+    const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
+    const unsigned pt = blk % npt, q = blk / npt, bx = pt % gridDim.x, by = pt / gridDim.x;      // co-group slowest (one co-group's weights per XCD at a time)
+    const int cg = (int)(q % ncg);
+    const unsigned bi = q / ncg;
+    const int x0 = bx * 32, y0 = by * PB;
+    p.in += bi * p.in_bs;
+    p.out += bi * p.out_bs;
+    if (p.skip) p.skip += bi * p.skip_bs;
+    const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
+    const long HW = (long)Hr * Wr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int cb0 = (cg * 4 + wave_u) * 2;                      // first of this wave's two 16-channel output blocks
+    const int ncb16 = p.Cout / 16;
+
+    int voff[IT], sl[IT];
+    bool inside[IT], item[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int e = k * 256 + tid;
+        item[k] = e < ITEMS;
+        const int ee = item[k] ? e : 0;
+        const int o = ee / (PR * PC), rem = ee - o * (PR * PC), r = rem / PC, c = rem - r * PC;
+        const int yr = min(y0 + r, p.H - 1) - p.pad, xr = min(x0 + c, p.W - 1) - p.pad;
+        inside[k] = yr >= 0 && yr < Hr && xr >= 0 && xr < Wr;
+        voff[k] = o * 8 * (int)HW + (inside[k] ? yr * Wr + xr : 0);
+        sl[k] = CV16_ITEM(r, o, c) * 4;
+    }
+    float st[IT][8];
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const float* cbase = p.in + (long)(chunk * 32 + c8) * HW;        // wave-uniform
+#pragma unroll
+            for (int k = 0; k < IT; ++k) st[k][c8] = cbase[voff[k]];
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            Limbs<3> L;
+            float e[8];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) e[c8] = inside[k] ? st[k][c8] : 0.0f;
+            split8(e, L);
+            if (item[k]) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(lds + buf * BUF + t * LIMB_WORDS + sl[k]) = L.v[t];
+            }
+        }
+    };
+
+    f32x4 acc[2][PB][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int nchunks = p.Cin / 32;
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wpk_limb16) + ((long)cb0 * 27) * 64;     // wave-uniform
+    const long wchunk = (long)ncb16 * 27 * 64;              // u32x4 per chunk
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) gload(chunk + 1);          // in flight during this chunk's MFMAs
+        const u32x4* wa = wbase + chunk * wchunk;
+        const unsigned* pl = lds + buf * BUF + CV16_ITEM(0, g, i16) * 4;
+        u32x4 A[2][3], An[2][3];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) A[cb][t] = wa[((cb * 9 + 0) * 3 + t) * 64 + lane];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * 3 + t) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    u32x4 B[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV16_ITEM(pb + ky, 0, 16 * hx + kx) * 4);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int qq = 0; qq < 6; ++qq) acc[cb][pb][hx] = mfma16_bf16(A[cb][limb_w(3, qq)], B[limb_x(3, qq)], acc[cb][pb][hx]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) A[cb][t] = An[cb][t];
+            }
+        }
+        if (chunk + 1 < nchunks) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    conv_write_out16<PB>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo);
+#undef CV16_ITEM
+}
+
+// limb fragments for conv3x3_limb16_kernel: [chunk of 32 ci][cb16][tap][limb][lane][4 words]; lane (co = 16 cb + (l & 15), g = l >> 4) holds the
+// 8 input channels 32 chunk + 8 g + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
+__global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int transposed) {
+    const int ncb = Cout / 16;
+    const long n = (long)(Cin / 32) * ncb * CL_FRAG_WORDS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % 3), tap = (int)((idx / 768) % 9);
+    const long rest = idx / CL_FRAG_WORDS;
+    const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
+    const int co = 16 * cb + (lane & 15), g = lane >> 4;
+    unsigned word = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int ci = 32 * chunk + 8 * g + 2 * wd + half;
+        float v = transposed ? w[((long)ci * Cout + co) * 9 + (8 - tap)] : w[((long)co * Cin + ci) * 9 + tap];
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == t) bits = __float_as_uint(v) >> 16;
+            v = limb_rest(v);
+        }
+        word |= bits << (16 * half);
+    }
+    out[idx] = word;
+}
+
 // limb fragments of a conv's weights: [chunk of 16 ci][cb][tap][limb][lane][4 words]; lane (co = 32 cb + (l & 31), h = l >> 5) holds
 // the 8 input channels 16 chunk + 8 h + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
 __global__ void pack_conv_limbs_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int ncb, int transposed) {
@@ -551,7 +784,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                 hipStream_t stream, int pad, int batch, ConvExec cx) {
     const int arith = conv_resolve_arith(cx.arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
-    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8) return NVSR_ERR_SHAPE;
+    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
@@ -560,12 +793,21 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     const long skip_bs = epilogue == EPI_RESIDUAL ? (long)Cout * (Ho + 4) * (Wo + 4)
                          : epilogue == EPI_ADD_CENTER ? (long)Cout * (Ho - 4) * (Wo - 4) : out_bs;
     const unsigned* wlimb = conv_limb_eligible(Cin, Cout) ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) : nullptr;
-    ConvParams p{in, wpk, wlimb, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    const unsigned* wlimb16 = conv_limb16_eligible(Cin, Cout)
+                                  ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) + conv_packed_limb_words(Cin, Cout) : nullptr;
+    ConvParams p{in, wpk, wlimb, wlimb16, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
     if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
         hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
+        return NVSR_CHECK_LAUNCH();
+    }
+    if (cx.rows == 16 && !(wlimb16 && arith != NVSR_ARITH_F32)) return NVSR_ERR_SHAPE;            // (16 = the 16x16x32 kernel: eligible limb layers only)
+    if (wlimb16 && arith != NVSR_ARITH_F32 && (cx.rows == 16 || (cx.rows == 0 && CV_USE_16X16X32))) {
+        p.ncg = Cout / 128;
+        dim3 grid((Wo + 31) / 32, (Ho + 3) / 4, p.ncg * batch);
+        hipLaunchKernelGGL((conv3x3_limb16_kernel<4>), grid, dim3(256), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
     if (cx.rows == 8 && !(wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2)) return NVSR_ERR_SHAPE;   // (only the wide limb kernel has it)
@@ -653,6 +895,9 @@ int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_str
     if (const int64_t nl = conv_packed_limb_words(Cin, Cout))
         hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n), Cin, Cout, conv_ncb(Cout), 0);
+    if (const int64_t n16 = conv_packed_limb16_words(Cin, Cout))
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cin, Cout), Cin, Cout, 0);
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -668,6 +913,9 @@ int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nv
     if (const int64_t nl = conv_packed_limb_words(Cout, Cin))
         hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n), Cout, Cin, conv_ncb(Cin), 1);
+    if (const int64_t n16 = conv_packed_limb16_words(Cout, Cin))
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cout, Cin), Cout, Cin, 1);
     return NVSR_CHECK_LAUNCH();
 }
 

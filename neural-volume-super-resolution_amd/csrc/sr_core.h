@@ -24,7 +24,16 @@ inline bool conv_limb_eligible(int Cin, int Cout) { return Cin % 16 == 0 && (con
 inline int64_t conv_packed_limb_words(int Cin, int Cout) {
     return conv_limb_eligible(Cin, Cout) ? (int64_t)(Cin / 16) * conv_ncb(Cout) * CL_FRAG_WORDS : 0;
 }
-inline int64_t conv_packed_floats(int Cin, int Cout) { return conv_packed_f32_floats(Cin, Cout) + conv_packed_limb_words(Cin, Cout); }
+// bf16-limb fragments for v_mfma_f32_16x16x32_bf16 (sr.hip, conv3x3_limb16_kernel; round 3): layers with Cin % 32 == 0 and Cout % 128 == 0 carry a
+// third region, [chunk of 32 input channels][16-channel co-block][tap 0..8][limb 0..2][lane][4 words]; lane (co = 16 cb + (l & 15),
+// g = l >> 4) holds input channels 32 chunk + 8 g + 0..7 as bf16 pairs
+inline bool conv_limb16_eligible(int Cin, int Cout) { return Cin % 32 == 0 && Cout % 128 == 0; }
+inline int64_t conv_packed_limb16_words(int Cin, int Cout) {
+    return conv_limb16_eligible(Cin, Cout) ? (int64_t)(Cin / 32) * (Cout / 16) * CL_FRAG_WORDS : 0;
+}
+inline int64_t conv_packed_floats(int Cin, int Cout) {
+    return conv_packed_f32_floats(Cin, Cout) + conv_packed_limb_words(Cin, Cout) + conv_packed_limb16_words(Cin, Cout);
+}
 
 // conv_input, (conv1, conv2) x nblocks, conv_mid, n_up x up-conv, conv_output  (state-dict order, models.py:802-816)
 inline void edsr_layers(int Cin, int Cout, int hid, int nblocks, int n_up, ConvLayer* L, int* n) {

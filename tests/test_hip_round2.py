@@ -41,19 +41,25 @@ def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
         skd = None if skip is None else T(skip)
         results = {}
         for mode in ("bf16x3", "f32"):
-            for rows in ((2, 3, 4, 8) if mode == "bf16x3" else (2, 3, 4)):     # (8: round 3's one-output-block x 8-row wave tile, limb kernel only)
+            # (8: round 3's one-output-block x 8-row wave tile; 16: the 16x16x32-MFMA kernel -- limb arithmetic only, 16 only where Cin % 32 == 0
+            #  and Cout % 128 == 0; 0 = what the launcher picks, i.e. 16 for those layers)
+            limb16 = mode == "bf16x3" and Cin % 32 == 0 and Cout % 128 == 0
+            for rows in ((2, 3, 4, 8) + ((16, 0) if limb16 else ()) if mode == "bf16x3" else (2, 3, 4)):
                 out = torch.full(ref.shape, -7.0, device=DEV)
                 capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, capi.ptr(skd), capi.ptr(out), ARITH[mode],
                           rows, capi.stream())
                 np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi, mode, rows)))
                 results[(mode, rows)] = out
-            # the row tiling does not change the arithmetic of an output element: the instantiations agree bit for bit
-            assert all(torch.equal(results[(mode, 2)], results[k]) for k in results if k[0] == mode)
+            # the row tiling does not change the arithmetic of an output element: the instantiations agree bit for bit (the 16x16x32 kernel sums
+            # 32 input channels per instruction instead of 16: same products, another f32 accumulation order)
+            assert all(torch.equal(results[(mode, 2)], results[k]) for k in results if k[0] == mode and k[1] in (2, 3, 4, 8))
+            if limb16:
+                assert torch.equal(results[(mode, 16)], results[(mode, 0)]) and not torch.equal(results[(mode, 16)], results[(mode, 4)])
     # invalid rows_per_tile / arithmetic are refused, nothing is written
     out = torch.full((256, 13, 43), -7.0, device=DEV)
     x = T(rng.standard_normal((48, 15, 45), dtype=np.float32))
     pk = torch.zeros(capi.lib().nvsr_conv3x3_packed_floats(48, 256), device=DEV)
-    for arith, rows in ((3, 5), (3, 1), (7, 0), (2, 0), (0, 8)):          # (the 8-row wave tile exists in the limb kernel only)
+    for arith, rows in ((3, 5), (3, 1), (7, 0), (2, 0), (0, 8), (3, 16), (0, 16)):   # (8 / 16 exist in the limb kernel only; 16 needs Cin % 32 == 0: 48 is not)
         st = capi.lib().nvsr_conv3x3_arith(capi.ptr(x), 48, 15, 45, capi.ptr(pk), 256, 0, None, capi.ptr(out), arith, rows, capi.stream())
         assert st == 1 and float(out.min()) == -7.0
     # data gradient (virtual zero border, flipped + transposed kernel): every row-tile variant, both kernels
@@ -66,7 +72,7 @@ def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
         ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
         dyd = T(dy)
         for mode in ("bf16x3", "f32"):
-            for rows in (0, 2, 3, 4):
+            for rows in (0, 2, 3, 4) + ((16,) if (mode == "bf16x3" and Cout % 32 == 0 and Cin % 128 == 0) else ()):
                 dx = torch.full((Cin, H, W), -7.0, device=DEV)
                 capi.call("nvsr_conv3x3_dgrad_arith", capi.ptr(dyd), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), ARITH[mode], rows, capi.stream())
                 np.testing.assert_allclose(N_(dx), ref, rtol=0, atol=3e-5 * max(1.0, np.sqrt(Cout / Cin)),

@@ -16,7 +16,7 @@ out = torch.empty((B, Cout, H - 2, W - 2), device=dev)
 flop = 2.0 * 9 * Cin * Cout * (H - 2) * (W - 2) * B
 ref = None
 for mode, code in (("bf16x3", 3), ("f32", 0)):
-    for rows in ((0, 2, 3, 4, 8) if mode == "bf16x3" else (0, 2, 3, 4)):
+    for rows in ((0, 2, 3, 4, 8, 16) if mode == "bf16x3" else (0, 2, 3, 4)):
         ts = []
         for rep in range(6):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,6 +26,6 @@ for mode, code in (("bf16x3", 3), ("f32", 0)):
             e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         if mode == "bf16x3":
             ref = out.clone() if ref is None else ref
-            same = torch.equal(ref, out)
+            same = torch.equal(ref, out) if rows != 4 else "max|d| vs default %.2e" % float((ref - out).abs().max())
         t = min(ts[1:])
         print("%-7s rows %d: %.3f ms  %.1f TFLOP/s %s" % (mode, rows, t, flop / t / 1e9, ("same=%s" % same) if mode == "bf16x3" else ""))

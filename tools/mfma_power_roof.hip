@@ -44,6 +44,57 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void roof(float* out, int 
     if (s == 12345.678f) out[t] = s;       // (never true: keeps the loop alive)
 }
 
+// the same with v_mfma_f32_16x16x32_bf16 (half the FLOP per instruction, 4 accumulator registers instead of 16)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int WAVES_PER_SIMD, int NACC>
+__global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void roof16(float* out, int iters, int zeros) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int w = 0; w < 4; ++w) {
+            a[i][w] = zeros ? 0u : rnd_pair(t * 64u + i * 8u + w);
+            b[i][w] = zeros ? 0u : rnd_pair(t * 64u + 32u + i * 8u + w);
+        }
+    f32x4 acc[NACC];
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 4; ++r) acc[k][r] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int k = 0; k < NACC; ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[(u + k) & 3]), __builtin_bit_cast(bf16x8, b[(u * 3 + k) & 3]), acc[k], 0, 0, 0);
+        if (!zeros) a[it & 3][it & 3] ^= 0x00010001u;
+    }
+    float s = 0.0f;
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 4; ++r) s += acc[k][r];
+    if (s == 12345.678f) out[t] = s;
+}
+template <int WPS, int NACC>
+static void run16(const char* name, int zeros) {
+    float* out;
+    hipMalloc(&out, 256 * 512 * sizeof(float));
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int dev_cus = p.multiProcessorCount, iters = 40000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f, last = 0.0f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((roof16<WPS, NACC>), dim3(dev_cus), dim3(256 * WPS), 0, 0, out, iters, zeros);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        last = ms; if (rep >= 2 && ms < best) best = ms;
+    }
+    const double mfmas = (double)dev_cus * 4 * WPS * iters * 16 * NACC;
+    const double flop = mfmas * 2.0 * 16 * 16 * 32;
+    printf("16x16x32 %-35s %s: %8.2f ms (last %8.2f)  %7.1f TFLOP/s dense bf16 = %5.1f %% of 2516.6 ; / 6 = %6.1f TFLOP/s of 3-limb f32 work ; %.2f ns per MFMA and SIMD -> %.2f GHz x (16 cycles)\n",
+           name, zeros ? "zeros " : "random", best, last, flop / best / 1e9, 100.0 * flop / best / 1e9 / 2516.6, flop / best / 1e9 / 6.0,
+           best * 1e6 / (iters * 16.0 * NACC * WPS), 16.0 / (best * 1e6 / (iters * 16.0 * NACC * WPS)));
+    hipFree(out);
+}
+
 template <int WPS, int NACC>
 static void run(const char* name, int zeros) {
     float* out;
@@ -77,5 +128,9 @@ int main() {
     run<1, 4>("1 wave / SIMD, 4 accumulators", 1);
     run<1, 1>("1 wave / SIMD, 1 accumulator (dependent chain)", 0);
     run<2, 4>("2 waves / SIMD, 4 accumulators", 0);
+    run16<1, 8>("1 wave / SIMD, 8 accumulators", 0);
+    run16<1, 8>("1 wave / SIMD, 8 accumulators", 1);
+    run16<1, 1>("1 wave / SIMD, 1 accumulator", 0);
+    run16<2, 8>("2 waves / SIMD, 8 accumulators", 0);
     return 0;
 }
