@@ -281,6 +281,10 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV16_ROWCOST3
+#define CV16_ROWCOST3 1.05   // cost of an output row in a 3-row / 2-row tile of conv3x3_limb16_kernel relative to a 4-row tile (measured: 4.68 / 4.47 ms, 4.93 / 4.47 ms)
+#define CV16_ROWCOST2 1.10
+#endif
 #ifndef CV_USE_16X16X32
 #define CV_USE_16X16X32 1   // limb layers with Cin % 32 == 0 and Cout % 128 == 0 (all of EDSR's trunk and up-sampling convolutions): 1 = conv3x3_limb16_kernel
 #endif
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 // smaller accumulator tile moves a quarter of the accumulator bytes per FLOP.
 // D[16 co][16 pixels] += W[16 co][32 ci] x X[32 ci][16 pixels]: lane (i = l & 15, g = l >> 4) holds A = 8 input channels 8g..8g+7 of output
 // channel i, B = the same 8 channels of pixel i, and D rows 4g..4g+3 (output channels) of column i (pixel).  Input channels stream 32 at a
-// time; the patch sits in LDS as [limb][row][octet 0..3][col][8 bf16].  Wave = 2 co-blocks (32 channels) x PB rows x 2 half-rows of 16 pixels
+// time; the patch sits in LDS as [limb][octet 0..3][row][col][8 bf16].  Wave = 2 co-blocks (32 channels) x PB rows x 2 half-rows of 16 pixels
 // (64 accumulator registers at PB = 4), workgroup = 4 waves = 128 output channels of one PB x 32 pixel tile, two workgroups per CU.
 // Per tap a wave reads 6 weight fragments (one tap ahead) and, per (row, half-row), 3 B fragments for 12 MFMAs.  Same limb products in the same
 // order per (ci block, tap), but the K dimension of an instruction spans 32 channels instead of 16: the f32 accumulation order differs from
@@ -535,10 +539,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
     constexpr int PR = PB + 2, PC = 34;
     constexpr int ITEMS = 4 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
     constexpr int IT = (ITEMS + 255) / 256;
-    constexpr int LIMB_WORDS = PR * PC * 4 * 4;           // one limb of the patch
+    // patch items (16 bytes = 8 channels of a pixel) as [octet][row][col], the octets a multiple of 16 items apart: the hardware serves a
+    // ds_read_b128 in four groups of 16 lanes, each of which holds all 16 values of l & 15 (12 from one octet, 4 from its neighbour), so with
+    // the bank quad of an item a function of the pixel alone every group is conflict-free ([row][octet][col] with 34-item rows measured
+    // SQ_LDS_BANK_CONFLICT = 48 % of the LDS-active cycles)
+    constexpr int OSTR = (PR * PC + 15) / 16 * 16;
+    constexpr int LIMB_WORDS = 4 * OSTR * 4;              // one limb of the patch
     constexpr int BUF = 3 * LIMB_WORDS;
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
-#define CV16_ITEM(R, O, COL) (((R) * 4 + (O)) * PC + (COL))
+#define CV16_ITEM(R, O, COL) ((O) * OSTR + (R) * PC + (COL))
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int Ho = p.H - 2, Wo = p.W - 2;
@@ -784,7 +793,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                 hipStream_t stream, int pad, int batch, ConvExec cx) {
     const int arith = conv_resolve_arith(cx.arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
-    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16) return NVSR_ERR_SHAPE;
+    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16 && !(cx.rows >= 18 && cx.rows <= 20)) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
@@ -803,11 +812,27 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
-    if (cx.rows == 16 && !(wlimb16 && arith != NVSR_ARITH_F32)) return NVSR_ERR_SHAPE;            // (16 = the 16x16x32 kernel: eligible limb layers only)
-    if (wlimb16 && arith != NVSR_ARITH_F32 && (cx.rows == 16 || (cx.rows == 0 && CV_USE_16X16X32))) {
+    // rows 16 = the 16x16x32 kernel with its own choice of rows per tile, 18 / 19 / 20 = that kernel with 2 / 3 / 4 rows forced
+    if (cx.rows >= 16 && !(wlimb16 && arith != NVSR_ARITH_F32)) return NVSR_ERR_SHAPE;            // (eligible limb layers only)
+    if (wlimb16 && arith != NVSR_ARITH_F32 && (cx.rows >= 16 || (cx.rows == 0 && CV_USE_16X16X32))) {
         p.ncg = Cout / 128;
-        dim3 grid((Wo + 31) / 32, (Ho + 3) / 4, p.ncg * batch);
-        hipLaunchKernelGGL((conv3x3_limb16_kernel<4>), grid, dim3(256), 0, stream, p);
+        dim3 grid((Wo + 31) / 32, 1, p.ncg * batch);
+        int best_pb = 4;
+        double best_cost = 1e300;
+        for (int pb = 4; pb >= 2; --pb) {
+            // rounds of the 512 workgroup slots x rows x the measured cost of a row in a pb-row tile relative to a 4-row tile (tools/conv_time.py
+            // rows 18 / 19 / 20 on a layer of full rounds); a last round of at most 256 tiles has every CU to itself (~0.62 of a round's time)
+            const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+            const long full = tiles / 512, rest = tiles % 512;
+            const double rounds = (double)full + (rest == 0 ? 0.0 : rest <= 256 ? 0.62 : 1.0);
+            const double cost = rounds * pb * (pb == 4 ? 1.0 : pb == 3 ? CV16_ROWCOST3 : CV16_ROWCOST2);
+            if (cost < best_cost) { best_cost = cost; best_pb = pb; }
+        }
+        if (cx.rows >= 18) best_pb = cx.rows - 16;
+        grid.y = (Ho + best_pb - 1) / best_pb;
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4>), grid, dim3(256), 0, stream, p);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_limb16_kernel<2>), grid, dim3(256), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
     if (cx.rows == 8 && !(wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2)) return NVSR_ERR_SHAPE;   // (only the wide limb kernel has it)

@@ -16,7 +16,7 @@ out = torch.empty((B, Cout, H - 2, W - 2), device=dev)
 flop = 2.0 * 9 * Cin * Cout * (H - 2) * (W - 2) * B
 ref = None
 for mode, code in (("bf16x3", 3), ("f32", 0)):
-    for rows in ((0, 2, 3, 4, 8, 16) if mode == "bf16x3" else (0, 2, 3, 4)):
+    for rows in ((0, 2, 3, 4, 8, 16, 18, 19, 20) if mode == "bf16x3" else (0, 2, 3, 4)):
         ts = []
         for rep in range(6):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
