@@ -552,10 +552,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int Ho = p.H - 2, Wo = p.W - 2;
     const unsigned blk = conv_tile_index();
+    // tile order: the two 128-channel co-groups of a 256-channel set FASTEST (they read the same patch: the second one's loads hit the XCD's L2;
+    // their weights together are the 3.5 MB per layer that the 2-block kernel streamed), then the pixel tile, then the 256-channel set and the
+    // plane slowest (the sets of a 256 -> 1024 layer would otherwise keep 14 MB of weights live per XCD).  Measured FETCH_SIZE of the SR stage:
+    // 34.0 GB with all co-groups slowest
     const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
-    const unsigned pt = blk % npt, q = blk / npt, bx = pt % gridDim.x, by = pt / gridDim.x;      // co-group slowest (one co-group's weights per XCD at a time)
-    const int cg = (int)(q % ncg);
-    const unsigned bi = q / ncg;
+    const unsigned G = (ncg & 1u) ? 1u : 2u, nset = ncg / G;
+    const unsigned cg_lo = blk % G, r1 = blk / G, pt = r1 % npt, q = r1 / npt, bx = pt % gridDim.x, by = pt / gridDim.x;
+    const int cg = (int)((q % nset) * G + cg_lo);
+    const unsigned bi = q / nset;
     const int x0 = bx * 32, y0 = by * PB;
     p.in += bi * p.in_bs;
     p.out += bi * p.out_bs;
