@@ -47,6 +47,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CUs x 4 SIMDs x 1024 FLOP/clk 
 # 100 % matrix-pipe occupancy the clock is a power limit -- 2.38 GHz on all-zero operands, 1.65 GHz on random bf16 operands.  Informational only:
 # `roofline.frac` stays priced against the 2.4 GHz dense peak.
 SUSTAINED_BF16_MFMA = {"tflops_random_operands": 1734.9, "tflops_zero_operands": 2493.3, "frac_of_peak_random": 0.689,
+                       "tflops_random_operands_16x16x32_two_waves_per_simd": 2050.0,
                        "source": "profiles/r03_mfma_power_roof.txt (tools/mfma_power_roof.hip: bare v_mfma_f32_32x32x16_bf16 streams, 256 CUs; builder-run "
                                  "on another MI355X box, not measured by this process)"}
 # Arithmetic of the fused render pass (include/nvsr.h NVSR_ARITH_*): kernel, executed MFMA work per algorithmic FLOP, pipe peak.
@@ -536,6 +537,10 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
                                            % (arith["pipe_peak"], arith["products"]),
                               "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
         result["roofline"]["traffic_source"] = None if result["roofline"]["traffic"] is None else pmc_source()
+        if mode != "f32":
+            result["roofline"]["kernel"] = "conv3x3_limb16_kernel (v_mfma_f32_16x16x32_bf16; 67 of the 70 launches per step) + conv3x3_limb_kernel (3)"
+            result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_16x16x32=ach * arith["products"] /
+                                                             SUSTAINED_BF16_MFMA["tflops_random_operands_16x16x32_two_waves_per_simd"])
         if world == 1 and not args.no_modes:
             modes = {}
             for m2 in ("f32", "bf16x3"):

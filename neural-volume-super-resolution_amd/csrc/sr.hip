@@ -281,6 +281,9 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // Weight fragments are not staged: each wave streams its own two co-blocks from L2 (coalesced 1-KiB reads, 6 per tap).
 // CO_WAVES = 4: the 4 waves take 4 x 2 output blocks of the same PB rows; CO_WAVES = 1 (layers with <= 64 output channels): the 4 waves
 // take the same 2 output blocks of 4 consecutive groups of PB rows.
+#ifndef CV16_WAVES
+#define CV16_WAVES 4
+#endif
 #ifndef CV16_ROWCOST3
 #define CV16_ROWCOST3 1.05   // cost of an output row in a 3-row / 2-row tile of conv3x3_limb16_kernel relative to a 4-row tile (measured: 4.68 / 4.47 ms, 4.93 / 4.47 ms)
 #define CV16_ROWCOST2 1.10
@@ -534,11 +537,14 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int PB>
-__global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
+// WAVES = 4: 128 output channels per workgroup, two workgroups per CU; WAVES = 8 (experiment, -DCV16_WAVES=8): 256 channels per workgroup, one
+// workgroup per CU -- the patch is staged once for all 256 channels
+template <int PB, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p) {
+    constexpr int TPB = 64 * WAVES;
     constexpr int PR = PB + 2, PC = 34;
     constexpr int ITEMS = 4 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
-    constexpr int IT = (ITEMS + 255) / 256;
+    constexpr int IT = (ITEMS + TPB - 1) / TPB;
     // patch items (16 bytes = 8 channels of a pixel) as [octet][row][col], the octets a multiple of 16 items apart: the hardware serves a
     // ds_read_b128 in four groups of 16 lanes, each of which holds all 16 values of l & 15 (12 from one octet, 4 from its neighbour), so with
     // the bank quad of an item a function of the pixel alone every group is conflict-free ([row][octet][col] with 34-item rows measured
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
     // plane slowest (the sets of a 256 -> 1024 layer would otherwise keep 14 MB of weights live per XCD).  Measured FETCH_SIZE of the SR stage:
     // 34.0 GB with all co-groups slowest
     const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
-    const unsigned G = (ncg & 1u) ? 1u : 2u, nset = ncg / G;
+    const unsigned G = (WAVES == 8 || (ncg & 1u)) ? 1u : 2u, nset = ncg / G;
     const unsigned cg_lo = blk % G, r1 = blk / G, pt = r1 % npt, q = r1 / npt, bx = pt % gridDim.x, by = pt / gridDim.x;
     const int cg = (int)((q % nset) * G + cg_lo);
     const unsigned bi = q / nset;
@@ -568,14 +574,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb16_kernel(ConvParams p) {
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int cb0 = (cg * 4 + wave_u) * 2;                      // first of this wave's two 16-channel output blocks
+    const int cb0 = (cg * WAVES + wave_u) * 2;                      // first of this wave's two 16-channel output blocks
     const int ncb16 = p.Cout / 16;
 
     int voff[IT], sl[IT];
     bool inside[IT], item[IT];
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
-        const int e = k * 256 + tid;
+        const int e = k * TPB + tid;
         item[k] = e < ITEMS;
         const int ee = item[k] ? e : 0;
         const int o = ee / (PR * PC), rem = ee - o * (PR * PC), r = rem / PC, c = rem - r * PC;
@@ -820,7 +826,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     // rows 16 = the 16x16x32 kernel with its own choice of rows per tile, 18 / 19 / 20 = that kernel with 2 / 3 / 4 rows forced
     if (cx.rows >= 16 && !(wlimb16 && arith != NVSR_ARITH_F32)) return NVSR_ERR_SHAPE;            // (eligible limb layers only)
     if (wlimb16 && arith != NVSR_ARITH_F32 && (cx.rows >= 16 || (cx.rows == 0 && CV_USE_16X16X32))) {
-        p.ncg = Cout / 128;
+        p.ncg = Cout / (32 * CV16_WAVES);
         dim3 grid((Wo + 31) / 32, 1, p.ncg * batch);
         int best_pb = 4;
         double best_cost = 1e300;
@@ -828,16 +834,17 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             // rounds of the 512 workgroup slots x rows x the measured cost of a row in a pb-row tile relative to a 4-row tile (tools/conv_time.py
             // rows 18 / 19 / 20 on a layer of full rounds); a last round of at most 256 tiles has every CU to itself (~0.62 of a round's time)
             const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
-            const long full = tiles / 512, rest = tiles % 512;
-            const double rounds = (double)full + (rest == 0 ? 0.0 : rest <= 256 ? 0.62 : 1.0);
+            constexpr long SLOTS = CV16_WAVES == 4 ? 512 : 256;
+            const long full = tiles / SLOTS, rest = tiles % SLOTS;
+            const double rounds = (double)full + (rest == 0 ? 0.0 : (CV16_WAVES == 4 && rest <= 256) ? 0.62 : 1.0);
             const double cost = rounds * pb * (pb == 4 ? 1.0 : pb == 3 ? CV16_ROWCOST3 : CV16_ROWCOST2);
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
         if (cx.rows >= 18) best_pb = cx.rows - 16;
         grid.y = (Ho + best_pb - 1) / best_pb;
-        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4>), grid, dim3(256), 0, stream, p);
-        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv3x3_limb16_kernel<2>), grid, dim3(256), 0, stream, p);
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
         return NVSR_CHECK_LAUNCH();
     }
     if (cx.rows == 8 && !(wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2)) return NVSR_ERR_SHAPE;   // (only the wide limb kernel has it)
