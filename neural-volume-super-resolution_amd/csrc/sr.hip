@@ -841,6 +841,11 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
         if (cx.rows >= 18) best_pb = cx.rows - 16;
+        {   // NVSR_CV16_ROWS=2|3|4 (environment, read once): force the row count of every launch (tools: per-layer comparison of the variants)
+            static int forced = -1;
+            if (forced < 0) { const char* e = getenv("NVSR_CV16_ROWS"); forced = e ? atoi(e) : 0; }
+            if (forced >= 2 && forced <= 4 && cx.rows < 18) best_pb = forced;
+        }
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
         else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
