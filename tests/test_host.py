@@ -413,7 +413,7 @@ def test_no_spills_on_benchmarked_kernels(pkg):
     spec.loader.exec_module(kr)
     table = kr.kernel_table(pkg.capi.LIB_PATH)
     names = " ".join(k["name"] for k in table)
-    for must in ("render_pass3_kernel", "render_pass_backward_gates_limb_kernel", "decode_rays_limb_kernel", "conv3x3_limb_kernel"):
+    for must in ("render_pass3_kernel", "render_pass_backward_gates_limb_kernel", "decode_rays_limb_kernel", "conv3x3_limb_kernel", "conv3x3_limb16_kernel"):
         assert must in names, "kernel table is missing %s" % must
     bad = kr.violations(table)
     assert not bad, "spilling kernels on benchmarked paths: " + "; ".join(

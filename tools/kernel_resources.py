@@ -25,7 +25,7 @@ BENCHMARKED = [
     "render_pass3_kernel", "render_pass3_coarse", "importance_resample", "ray_bundle_kernel", "pack_rays_kernel",
     "decode_rays_limb_kernel", "render_pass_backward_gates_limb_kernel", "composite_kernel", "composite_backward_kernel",
     "view_reduce_scatter", "decoder_wgrad_limb_kernel", "head_wgrad_kernel",
-    "conv3x3_limb_kernel", "conv3x3_wgrad_limb_kernel", "sr_prepare_kernel", "sr_finish_kernel",
+    "conv3x3_limb_kernel", "conv3x3_limb16_kernel", "conv3x3_wgrad_limb_kernel", "sr_prepare_kernel", "sr_finish_kernel",
 ]
 # name substring -> spilled VGPRs tolerated (a kernel not listed: 0).  What is listed is debt, with the round that recorded it:
 #   decoder_wgrad_limb_kernel<4>: 35 in the flush epilogue of its 256 accumulators (outside the row loop), round 2
