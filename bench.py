@@ -57,8 +57,9 @@ ARITHMETIC = {
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
     "bf16x3": {"kernel": "render_pass3_kernel<3>", "products": 6, "pipe_peak": PEAK_BF16_MFMA_TFLOPS,
                "dtype": "f32 (GEMM operands split exactly into 3 bf16 limbs, 6 of 9 limb products on v_mfma_f32_32x32x16_bf16, f32 accumulation)"},
-    "bf16x2": {"kernel": "render_pass3_kernel<2>", "products": 3, "pipe_peak": PEAK_BF16_MFMA_TFLOPS,
-               "dtype": "f32 storage, GEMM operands rounded to 2 bf16 limbs (16 significant bits), f32 accumulation"},
+    "f16x2": {"kernel": "render_pass3_kernel<2>", "products": 3, "pipe_peak": PEAK_BF16_MFMA_TFLOPS,      # (f16 and bf16 MFMAs run at the same rate)
+              "dtype": "f32 (GEMM operands split into 2 round-to-nearest f16 limbs: |x - hi - lo| <= 2^-23 |x|; 3 of 4 limb products on "
+                       "v_mfma_f32_32x32x16_f16, f32 accumulation; as close to float64 as the 3-bf16-limb arithmetic or closer, include/nvsr.h)"},
 }
 CAMERA_ANGLE_X = 0.6911112
 
@@ -221,6 +222,41 @@ def hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws, reps=5):
     for name, (nbytes, fn) in stages.items():
         dt = timed(fn)
         out[name] = {"ms": dt * 1e3, "algorithmic_bytes": nbytes, "GB/s": nbytes / dt / 1e9, "frac_of_hbm_peak": nbytes / dt / 1e9 / PEAK_HBM_GBS}
+    return out
+
+
+def decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine, n_rays=16384, n_check=1024):
+    """Decoder outputs (rgb logits, sigma) of one fused fine pass in every arithmetic against the float64 checker AT THE SAME DEPTHS, on
+    the first n_check of n_rays rays of the frame: max / rms error relative to the output range.  (The frame PSNR regenerates the fine
+    depths per arithmetic, so rays whose importance samples flip bins dominate it; this is the arithmetic alone.)"""
+    import ctypes as C
+    from oracle.oracle import Oracle, decoder_blob
+    capi = nvsr_amd.capi
+    dev = rays.device
+    r, z = rays[:n_rays].contiguous(), z_fine[:n_rays].contiguous()
+    N, S = z.shape
+    chk = Oracle(f32=False)
+    planes = [mf.planes_[nvsr_amd.models.get_plane_name(sid, d)].detach().cpu().numpy() for d in range(4)]
+    osc = chk.scene(planes, mf.box_coords[sid].numpy())
+    dec = chk.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
+    ref = chk.render_given_z(osc, dec, r[:n_check].cpu().numpy(), z[:n_check].cpu().numpy(), want_raw=True)["raw"].astype(np.float64)
+    sc, keep = mf.native_scene()
+    out = {}
+    for mode in ("f32", "bf16x3", "f16x2"):
+        o = [torch.empty((N, 3), device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+        raw = torch.empty((N, S, 4), device=dev)
+        capi.call("nvsr_render_pass_arith", C.byref(sc), capi.ptr(mf.packed_decoder()), N, S, capi.ptr(r), capi.ptr(z), None, 0,
+                  *[capi.ptr(b) for b in o], None, None, capi.ptr(raw), capi.ARITHMETIC[mode], capi.stream())
+        torch.cuda.synchronize()
+        d = raw[:n_check].cpu().numpy().astype(np.float64) - ref
+        e = {}
+        for name, ch in (("rgb_logits", slice(0, 3)), ("sigma", slice(3, 4))):
+            rng = float(np.abs(ref[..., ch]).max())
+            e[name] = {"max": float(np.abs(d[..., ch]).max() / rng), "rms": float(np.sqrt((d[..., ch] ** 2).mean()) / rng),
+                       "mean": float(d[..., ch].mean() / rng)}
+        out[mode] = e
+    out["note"] = ("|raw - float64 checker| / range over %d rays x %d samples of the frame's fine pass, same depths for every arithmetic "
+                   "(render_pass3 / render_pass2 kernels through nvsr_render_pass_arith)" % (n_check, S))
     return out
 
 
@@ -803,7 +839,7 @@ def main():
         if world == 1 and not args.no_modes:
             # the same frame in the other arithmetic modes (2 steps each), so that every number of this line can be re-based
             modes, frames = {}, {}
-            for m2 in ("f32", "bf16x3", "bf16x2"):
+            for m2 in ("f32", "bf16x3", "f16x2"):
                 nvsr_amd.capi.set_decoder_arithmetic(m2)
                 frames[m2] = step()[3]
                 torch.cuda.synchronize()
@@ -824,6 +860,7 @@ def main():
                 for m2, fr in frames.items():
                     result["arithmetic_modes"][m2]["psnr_vs_oracle_db"] = cpu_baseline.psnr_of(fr)
                 result["psnr_vs_oracle_db_by_arithmetic"] = {m2: v["psnr_vs_oracle_db"] for m2, v in result["arithmetic_modes"].items()}
+                result["decoder_error_vs_float64_by_arithmetic"] = decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine)
         if world == 1 and not args.no_modes and not args.no_other_workloads and H == 800 and args.plane_res == 800:
             # The other BASELINE configurations of the same path, measured in this same driver-timed process (short runs; each is also its
             # own `--workload`): configs[3] = the 4 096-ray Feature_Planes_Only optimisation step, configs[2]'s SR stage = EDSR 256 x 32 on

@@ -73,20 +73,38 @@ int nvsr_version(void);
  *                         MFMA), <= 2^-24 each -- the products are exact, the sums are ordinary f32 sums.
  *                     Measured on adversarial operands (every mantissa 0x7FFFFF or 0x00FFFF, equal signs, K = 192; tests/
  *                     test_hip_round2.py::test_limb_error_bound): max error 9.8e-7 (2^-20), mean -1.8e-7, against 5.6e-7 / +1.8e-8 for
- *                     the exact-f32 kernel.  NOT bit-grade f32; it is the default because every parity tolerance of the path holds in
- *                     it (2e-5 on decoder outputs; PSNR of the 800^2 frame vs the double-precision oracle 89.2 dB against 90.8 dB).
- *   NVSR_ARITH_BF16X2 2 limbs (16 significant bits per operand), 3 products, 5.3x; error <= 2^-15 |W||x| per product (opt-in)
+ *                     the exact-f32 kernel.  NOT bit-grade f32; every parity tolerance of the path holds in it (2e-5 on decoder outputs;
+ *                     PSNR of the 800^2 frame vs the double-precision oracle 89.2 dB against 90.8 dB).  Default of rounds 1-3 for the
+ *                     render pass; still what every training kernel runs (no exponent-range limits: gradients span many decades).
+ *   NVSR_ARITH_F16X2  every f32 operand split into 2 f16 limbs by ROUNDING TO NEAREST: hi = RN(x) (11 significant bits), lo = RN(x - hi)
+ *                     (x - hi is exact in f32); |x - hi - lo| <= 2^-23 |x| (one f32 ulp, and zero for three operands in four).  Products
+ *                     Wh xh + Wh xl + Wl xh on v_mfma_f32_32x32x16_f16 (f16 x f16 products are exact in f32, f32 accumulation): 3 MFMAs
+ *                     per f32 product block, 5.3x the f32 matrix rate and twice the rate of NVSR_ARITH_BF16X3.  Error per product
+ *                     <= (2^-23 + 2^-23 + 2^-22) |W||x| = 2^-21 |W||x| at worst (the same bound as BF16X3), but with limbs of either sign:
+ *                     the dropped Wl xl and the representation errors average out over K instead of adding up, and the sum takes half as
+ *                     many f32 roundings (3 K / 16).  Measured against float64 it is as close as BF16X3 or closer (tests/
+ *                     test_hip_round3.py::test_limb_gemm_error_bounds; frame PSNR and decoder-output errors in bench.py's line).
+ *                     RANGE: f16 has 5 exponent bits, so the kernels carry static power-of-two scales (exact): weights are packed as
+ *                     W 2^8 and activations / features are held as x 2^4.  Both limbs are normal numbers for 2^-10 <= |W| < 255 and
+ *                     2^-6 <= |x| < 4094; below that the low limb is subnormal (honoured by the matrix pipe) and the error is absolute,
+ *                     <= 2^-33 per weight and <= 2^-29 per activation; a weight >= 255 or an activation >= 4094 overflows to inf and
+ *                     the pixel comes out NaN -- loud, never a wrong number (use BF16X3 or F32 for such a network).
+ *                     The fused render pass only (inference); the training kernels run BF16X3 when F16X2 is selected.
  * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
- * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | bf16x2
+ * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | f16x2
  * and which nvsr_set_decoder_arithmetic changes.  Nothing but that default is process-global: calls with explicit modes are re-entrant
  * across threads and streams. */
 #define NVSR_ARITH_INHERIT (-1)
 #define NVSR_ARITH_F32 0
-#define NVSR_ARITH_BF16X2 2
+#define NVSR_ARITH_F16X2 2
 #define NVSR_ARITH_BF16X3 3
-#define NVSR_ARITH_DEFAULT NVSR_ARITH_BF16X3
+#define NVSR_ARITH_DEFAULT NVSR_ARITH_F16X2
 int nvsr_get_decoder_arithmetic(void);
 int nvsr_set_decoder_arithmetic(int mode);
+/* The arithmetic primitive alone (test hook, one wavefront): Y[32][32] = W[32][K] X[K][32] (row-major f32, K a multiple of 16) with the
+ * operands split and multiplied exactly as the kernels of `arithmetic` do it (NVSR_ARITH_F32 | _BF16X3 | _F16X2, incl. the static scales of
+ * F16X2) -- lets a test put chosen mantissas / magnitudes through the products that replace models.py:381-421's nn.Linear GEMMs. */
+int nvsr_limb_gemm_probe(int arithmetic, int K, const float* W, const float* X, float* Y, nvsr_stream_t stream);
 /* Same for the 3x3 convolutions of the SR network (process default + *_arith twins): forward and data gradient of the layers with
  * Cin % 16 == 0 and a multiple of 256, or at most 64, output channels (every layer of EDSR(256); other shapes always use the f32 kernel),
  * and every weight gradient: NVSR_ARITH_F32 or NVSR_ARITH_BF16X3 (same error bound as above).
@@ -352,7 +370,7 @@ int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* 
 
 /* ---- per-call arithmetic -----------------------------------------------------------------------------------------------------
  * Twins of the entry points above that run decoder GEMMs or SR convolutions, with the arithmetic as an explicit argument
- * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_BF16X2 (decoder forward only) | NVSR_ARITH_INHERIT).  Same arguments, same
+ * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_F16X2 (decoder forward only) | NVSR_ARITH_INHERIT).  Same arguments, same
  * semantics; the un-suffixed entry points are these called with NVSR_ARITH_INHERIT.  A backward call must be given the mode of the
  * forward whose gates / record / activations it consumes (the host mirror stores it with the autograd context).
  * rows_per_tile (convolutions): 0 = the launcher's choice, 2 | 3 | 4 = force that row-tile instantiation of the wide kernels (two output

@@ -44,6 +44,7 @@ _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _PROTOS = {
     "nvsr_version": ([], C.c_int),
     "nvsr_fused_min_rays": ([], C.c_int64),
+    "nvsr_limb_gemm_probe": ([_i, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_get_decoder_arithmetic": ([], C.c_int),
     "nvsr_set_decoder_arithmetic": ([_i], _i),
     "nvsr_get_conv_arithmetic": ([], C.c_int),
@@ -147,12 +148,12 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
 _lib = None
 
 
-ARITHMETIC = {"f32": 0, "bf16x2": 2, "bf16x3": 3}
+ARITHMETIC = {"f32": 0, "f16x2": 2, "bf16x3": 3}
 ARITH_INHERIT = -1
 
 
 def arith_code(mode):
-    """'f32' | 'bf16x3' | 'bf16x2' | None (= the process default) | an NVSR_ARITH_* code -> the int the *_arith entry points take"""
+    """'f32' | 'bf16x3' | 'f16x2' | None (= the process default) | an NVSR_ARITH_* code -> the int the *_arith entry points take"""
     if mode is None:
         return ARITH_INHERIT
     if isinstance(mode, str):
@@ -172,7 +173,7 @@ def resolve_conv_arithmetic(mode=None):
 
 
 def set_decoder_arithmetic(mode):
-    """Arithmetic of the decoder GEMMs inside the fused render pass: 'f32' | 'bf16x3' | 'bf16x2' (include/nvsr.h, NVSR_ARITH_*)."""
+    """Arithmetic of the decoder GEMMs inside the fused render pass: 'f32' | 'bf16x3' | 'f16x2' (include/nvsr.h, NVSR_ARITH_*)."""
     call("nvsr_set_decoder_arithmetic", ARITHMETIC[mode])
 
 

@@ -23,6 +23,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 // (always_inline: inside a very large kernel the inliner otherwise leaves these as CALLS, and an operand index that is not a compile-time
 //  constant turns every fragment selection into a chain of v_cndmask over a merged register array)
@@ -58,6 +60,36 @@ __device__ __forceinline__ unsigned round_pair(float e1, float e0) {          //
     return __builtin_bit_cast(unsigned, v);
 }
 
+// ---- LIMBS = 2: two f16 limbs, round to nearest, statically scaled ----------------------------------------------------------------
+// hi = RN_f16(x) keeps 11 significant bits, x - hi is exact in f32 (|x - hi| <= 2^-11 |x|, either sign) and lo = RN_f16(x - hi) leaves
+// |x - hi - lo| <= 2^-23 |x| (one f32 ulp; 0 unless the 13-bit remainder is odd at full width).  W x = Wh xh + Wh xl + Wl xh + [Wl xl]:
+// three v_mfma_f32_32x32x16_f16 per f32 product block, total error <= (2^-23 + 2^-23 + 2^-22) |W||x| = 2^-21 |W||x| per product in the
+// worst case, signs random (no bias that adds up over K, unlike truncation limbs).  f16 has 5 exponent bits, so both operands carry a
+// static power-of-two scale (exact): weights are packed as W 2^F16_SW, activations and features live in registers as x 2^F16_SX, and the
+// accumulator of a layer holds 2^(SW+SX) W x -- undone for free in act = max(fma(acc, 2^-SW, bias 2^SX), 0).  Both limbs are normal f16
+// numbers for 2^-10 <= |W| < 255 and 2^-6 <= |x| < 4094; below, the low limb is a subnormal with an absolute error <= 2^-25-SW resp.
+// 2^-25-SX (1.2e-10 |x| / 1.9e-9 |W|: below an f32 ulp of any activation > 0.03); above, the conversion overflows to inf and the pixel
+// comes out NaN (loud, never a wrong number).
+constexpr int F16_SW = 8, F16_SX = 4;
+constexpr float F16_W_SCALE = 256.0f, F16_X_SCALE = 16.0f, F16_ACC_UNSCALE = 1.0f / 256.0f, F16_HEAD_SCALE = 1.0f / 16.0f;
+__device__ __forceinline__ unsigned f16_pair(float e1, float e0) {            // v_cvt_pk_f16_f32, round to nearest even
+    const f16x2_t v = __builtin_convertvector(f32x2_t{e0, e1}, f16x2_t);
+    return __builtin_bit_cast(unsigned, v);
+}
+// x minus half HI of an f16 pair, exact: one v_fma_mix_f32 (the f16 operand is widened inside the instruction)
+template <int HI>
+__device__ __forceinline__ float f16_rest(float x, unsigned pair) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+    return r;
+}
+template <int LIMBS>
+__device__ __forceinline__ f32x16 mfma_limb(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (LIMBS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return mfma_bf16(a, b, c);
+}
+
 template <int LIMBS> struct Limbs { u32x4 v[LIMBS]; };
 struct SplitPend { float r0, r1; };
 
@@ -76,9 +108,9 @@ __device__ __forceinline__ void split_slice(int slice, Get get, Limbs<LIMBS>& ou
         if (st == 4) { p.r1 = limb_rest(p.r1); }
         if (st == 5) { out.v[2][j] = trunc_pair(p.r1, p.r0); }
     } else {
-        if (st == 0) { out.v[0][j] = trunc_pair(get(2 * j + 1), get(2 * j)); p.r0 = limb_rest(get(2 * j)); }
-        if (st == 1) { p.r1 = limb_rest(get(2 * j + 1)); }
-        if (st == 2) { out.v[1][j] = round_pair(p.r1, p.r0); }
+        if (st == 0) { out.v[0][j] = f16_pair(get(2 * j + 1), get(2 * j)); p.r0 = f16_rest<0>(get(2 * j), out.v[0][j]); }
+        if (st == 1) { p.r1 = f16_rest<1>(get(2 * j + 1), out.v[0][j]); }
+        if (st == 2) { out.v[1][j] = f16_pair(p.r1, p.r0); }
     }
 }
 template <int LIMBS, class Get>
@@ -143,9 +175,9 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
                 const int q = kb * 4 + ob;
                 if (ZERO && kb == 0 && p == 0) {
                     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    acc[ob] = mfma_bf16(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], zero);
+                    acc[ob] = mfma_limb<LIMBS>(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], zero);
                 } else {
-                    acc[ob] = mfma_bf16(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], acc[ob]);
+                    acc[ob] = mfma_limb<LIMBS>(fa.v[limb_w(LIMBS, p)], cur.v[limb_x(LIMBS, p)], acc[ob]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #if defined(R3_ABLATE) && (R3_ABLATE & 128)       // timing experiment (render3.hip): no A-fragment reads after the block's first

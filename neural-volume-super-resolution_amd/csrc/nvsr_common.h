@@ -49,6 +49,7 @@ constexpr int S_BIAS = 0;                                       // 8 * 128
 constexpr int S_ALPHA_W = 8 * HID;                              // 1024
 constexpr int S_RGB_W = S_ALPHA_W + HID;                        // 1152
 constexpr int S_HEAD_B = S_RGB_W + 3 * HID;                     // 1536: alpha_b, rgb_b[3]
+constexpr int S_F16_POISON = S_HEAD_B + 4;                      // 0, or NaN when a weight does not fit the f16 limbs (render3.hip packer)
 constexpr int SMALL_FLOATS = 1552;                              // padded to a multiple of 16 B
 static_assert(P_SMALL + SMALL_FLOATS == NVSR_DECODER_PACKED_F32_FLOATS, "packed blob size");
 

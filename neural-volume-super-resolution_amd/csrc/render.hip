@@ -242,7 +242,7 @@ int nvsr_get_decoder_arithmetic(void) {
         g_decoder_arithmetic = NVSR_ARITH_DEFAULT;
         if (e && !strcmp(e, "f32")) g_decoder_arithmetic = NVSR_ARITH_F32;
         if (e && !strcmp(e, "bf16x3")) g_decoder_arithmetic = NVSR_ARITH_BF16X3;
-        if (e && !strcmp(e, "bf16x2")) g_decoder_arithmetic = NVSR_ARITH_BF16X2;
+        if (e && !strcmp(e, "f16x2")) g_decoder_arithmetic = NVSR_ARITH_F16X2;
     }
     return g_decoder_arithmetic;
 }
@@ -250,11 +250,11 @@ int nvsr_get_decoder_arithmetic(void) {
 /* NVSR_ARITH_INHERIT -> the process default; anything that is not a mode -> -1 */
 int nvsr_internal_resolve_decoder_arith(int arithmetic) {
     if (arithmetic == NVSR_ARITH_INHERIT) return nvsr_get_decoder_arithmetic();
-    return (arithmetic == NVSR_ARITH_F32 || arithmetic == NVSR_ARITH_BF16X3 || arithmetic == NVSR_ARITH_BF16X2) ? arithmetic : -1;
+    return (arithmetic == NVSR_ARITH_F32 || arithmetic == NVSR_ARITH_BF16X3 || arithmetic == NVSR_ARITH_F16X2) ? arithmetic : -1;
 }
 
 int nvsr_set_decoder_arithmetic(int mode) {
-    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_BF16X2) return NVSR_ERR_SHAPE;
+    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
     g_decoder_arithmetic = mode;
     return NVSR_OK;
 }

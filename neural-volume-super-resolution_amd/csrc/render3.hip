@@ -52,6 +52,12 @@
 #define R3_MARKH(i)
 #define R3_RESETH
 #endif
+#ifndef R3_RELU_PK
+#define R3_RELU_PK 0      // f16-limb ReLU: 1 = pairs through v_pk_fma_f32, 0 = two v_fma_f32.  Same-box A/B: the packed form is SLOWER (88.1 vs 83.6 ms
+#endif                    // fine pass): a v_pk_fma_f32 costs the wave more issue time than the two v_fma_f32 it replaces
+#ifndef R3_BLEND_PK
+#define R3_BLEND_PK 0     // bilinear blends of the f16-limb kernels through v_pk_mul_f32 / v_pk_fma_f32 (A/B)
+#endif
 #ifndef R3_NO_VIEW_HOIST
 #define R3_NO_VIEW_HOIST 1
 #endif
@@ -104,7 +110,7 @@ __device__ __forceinline__ void gather4_blend(int c, const GatherJob& job, const
 //     F = T0 nw;  F = fma(T1, ne, F);  F = fma(T2, sw, F);  F = fma(T3, se, F)          (the same operations as gather24)
 // 54 steps behind the loads: pass 0 of gather j in the last quarter of block j, passes 1..3 in the first three quarters of block j + 1,
 // each just before the next gather's loads of that tap reuse the registers.
-template <int NS, bool LOADS, bool BLENDS>
+template <int NS, bool LOADS, bool BLENDS, bool PK = false>
 __device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float (&Fl)[HALF_C], const GatherJob& jb, float (&Fb)[HALF_C], int h,
                                             RawTaps4& rt) {
     spread<72, 0, NS>(slot, [&](int v) {
@@ -129,10 +135,27 @@ __device__ __forceinline__ void gather_roll(int slot, const GatherJob& jl, float
 #endif
         }
         const int w = v / 18, u = v % 18;
+        if constexpr (PK) {
+            // f16-limb kernels: channel pairs through v_pk_mul_f32 / v_pk_fma_f32 (12 pairs over the 18 steps of a quarter)
+            if (u % 3 != 2) {
+                const int c = 2 * ((u / 3) * 2 + u % 3);
+                if (LOADS && w == 3) {
+                    f32x2_t m = f32x2_t{rt.r[0][c >> 2][c & 3], rt.r[0][c >> 2][(c & 3) + 1]} * f32x2_t{jl.t.nw, jl.t.nw};
+                    Fl[c] = m[0]; Fl[c + 1] = m[1];
+                }
+                if (BLENDS && w < 3) {
+                    const float wt = w == 0 ? jb.t.ne : w == 1 ? jb.t.sw : jb.t.se;
+                    f32x2_t f = f32x2_t{Fb[c], Fb[c + 1]};
+                    f32x2_t m = __builtin_elementwise_fma(f32x2_t{rt.r[w + 1][c >> 2][c & 3], rt.r[w + 1][c >> 2][(c & 3) + 1]}, f32x2_t{wt, wt}, f);
+                    Fb[c] = m[0]; Fb[c + 1] = m[1];
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = (u * 4) / 3; c < ((u + 1) * 4) / 3; ++c) {                         // 24 channels over the 18 steps of a quarter
             if (LOADS && w == 3) Fl[c] = rt.r[0][c >> 2][c & 3] * jl.t.nw;
             if (BLENDS && w < 3) Fb[c] = fmaf(rt.r[w + 1][c >> 2][c & 3], w == 0 ? jb.t.ne : w == 1 ? jb.t.sw : jb.t.se, Fb[c]);
+        }
         }
     });
 }
@@ -154,11 +177,32 @@ __device__ __forceinline__ void ring3_sync() {
 // act = max(acc + bias, 0): 64 elements in 68 steps (a bias quad is read 4 steps before its first use)
 constexpr int RELU_STEPS = 68;
 struct BiasPend4 { f32x4 v[2]; };
-__device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, const f32x16 (&acc)[4], f32x16 (&act)[4], BiasPend4& pend) {
+// LIMBS = 2 (f16 limbs): act = relu(acc 2^-SW + bias 2^SX) must let a NaN through -- an operand beyond the f16 range turns a layer's
+// accumulators into NaNs (the matrix pipe always returns the default NaN 0xFFC00000, whatever the sign of a NaN it was fed), and v_max_f32
+// would return its non-NaN operand: the overflow would render as a finite, wrong pixel.  So the ReLU is an INTEGER max on the bits (equal to
+// max(x, 0) for every number: negative floats are negative integers; a POSITIVE NaN is a large positive integer and survives), and the FMA in
+// front of it computes (-acc) (-2^-SW) + bias -- the same value, but the source-negation modifier turns the pipe's negative NaN into a
+// positive one.  `nsc` = {-2^-SW, -2^-SW} in a scalar register pair; element pairs go through ONE v_pk_fma_f32.
+template <int LIMBS>
+__device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, const f32x16 (&acc)[4], f32x16 (&act)[4], BiasPend4& pend, f32x2_t nsc) {
     if ((k & 3) == 0 && k < 64) pend.v[(k >> 2) & 1] = *reinterpret_cast<const f32x4*>(bias + (k >> 2) * 8 + h * 4);
     if (k >= 4) {
         const int r = k - 4;
-        act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15] + pend.v[(r >> 2) & 1][r & 3], 0.0f);
+        if constexpr (LIMBS == 2) {
+            if (r & 1) {
+                const int q = r - 1;
+                const f32x2_t a = f32x2_t{acc[q >> 4][q & 15], acc[r >> 4][r & 15]}, b = f32x2_t{pend.v[(q >> 2) & 1][q & 3], pend.v[(r >> 2) & 1][r & 3]};
+                f32x2_t v;          // (written out: the compiler materialises the negation of a pair as two v_xor_b32 and splits the fma)
+#if R3_RELU_PK
+                asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(v) : "v"(a), "s"(nsc), "v"(b));
+#else
+                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v[0]) : "v"(a[0]), "s"(nsc[0]), "v"(b[0]));
+                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v[1]) : "v"(a[1]), "s"(nsc[0]), "v"(b[1]));
+#endif
+                act[q >> 4][q & 15] = __int_as_float(max(__float_as_int(v[0]), 0));
+                act[r >> 4][r & 15] = __int_as_float(max(__float_as_int(v[1]), 0));
+            }
+        } else act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15] + pend.v[(r >> 2) & 1][r & 3], 0.0f);
     }
 }
 
@@ -238,7 +282,14 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     Ring3<LIMBS> rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LIMBS)), 0, KB_TOTAL * kb_words(LIMBS) * 4, 0x00020000),
                     lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
-    for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) ldsf[L::SMALL + i] = packed[P_SMALL + i];
+    // (f16 limbs: activations are held as x 2^F16_SX -- biases scaled up, head weights scaled down, all exact; limb_core.h)
+    // A weight beyond the f16 range was packed as inf: the packer then left a NaN in the blob's spare slot S_F16_POISON, which goes into
+    // the head biases here -- every output of such a decoder is NaN instead of a wrong number.
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) {
+        float v = packed[P_SMALL + i] * (LIMBS != 2 ? 1.0f : i < S_ALPHA_W ? F16_X_SCALE : i < S_HEAD_B ? F16_HEAD_SCALE : 1.0f);
+        if (LIMBS == 2 && i >= S_HEAD_B && i < S_HEAD_B + 4) v += packed[P_SMALL + S_F16_POISON];
+        ldsf[L::SMALL + i] = v;
+    }
     const float* small = ldsf + L::SMALL;
 
     const int lane0 = rs.lane;
@@ -289,12 +340,17 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
         n2 = norm_coord(__fadd_rn(c0[2], __fmul_rn(c1[1], zc)), sc.lo[2], sc.range[2]);
     };
+    // f16 limbs: features carry the activation scale 2^F16_SX, put on the four blend weights (exact; D = (F0 + F1 + F2) / 3 inherits it)
+    auto scale_taps = [](Taps& t) {
+        if constexpr (LIMBS == 2) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; }
+    };
     auto view_job = [&](const float* rc) {
         const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
         GatherJob j;
         j.plane = sc.plane[3];
         j.t.o00 = __float_as_int(c2[0]); j.t.o01 = __float_as_int(c2[1]); j.t.o10 = __float_as_int(c2[2]); j.t.o11 = __float_as_int(c2[3]);
         j.t.nw = c3[0]; j.t.ne = c3[1]; j.t.sw = c3[2]; j.t.se = c3[3];
+        scale_taps(j.t);
         return j;
     };
 
@@ -312,6 +368,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         for (int c = 0; c < HALF_C; ++c) gather4_blend(c, vj, rt, t.V);
     }
     Limbs<LIMBS> cur, fa;
+    f32x2_t nsc = {-F16_ACC_UNSCALE, -F16_ACC_UNSCALE};                  // relu_bias_step
+    asm volatile("" : "+s"(nsc));
 #if R3_STAMP
     float stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -358,16 +416,16 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         unsigned* nw = ring3_take(rs);
         R3_MARK(1)      // first ring wait
         R3_RESET
-#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS>(slot, JL, TL.F, JB, TB.F, h, rt); }
+#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); }
 #define NVSR_ROLL_DMA(TL, JL, TB, JB, LOADS, BLENDS, NKB, KB0) \
-        [&](int slot) { gather_roll<NSF, LOADS, BLENDS>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
+        [&](int slot) { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
         // X view | loads X plane 0
-        ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2);
+        ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.V);
         limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL_DMA(X, ja, Y, jb, true, false, 3, KB_RGB0 + 3), NoTail{});
         R3_MARKB(0)
         // Y view | blends X plane 0, loads Y plane 0
-        jb.plane = sc.plane[0]; jb.t = pos_taps2(sc, 0, yn0, yn1, yn2);
+        jb.plane = sc.plane[0]; jb.t = pos_taps2(sc, 0, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.V);
         limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.V), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(1)
@@ -377,14 +435,14 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // X plane 0 | blends Y plane 0, loads X plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
-        ja.plane = sc.plane[1]; ja.t = pos_taps2(sc, 1, xn0, xn1, xn2);
+        ja.plane = sc.plane[1]; ja.t = pos_taps2(sc, 1, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.F);
         limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 6), NoTail{});
         R3_MARKB(2)
         // Y plane 0 | blends X plane 1, loads Y plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = Y.F[c];
-        jb.plane = sc.plane[1]; jb.t = pos_taps2(sc, 1, yn0, yn1, yn2);
+        jb.plane = sc.plane[1]; jb.t = pos_taps2(sc, 1, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.F);
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(3)
@@ -394,14 +452,14 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // X plane 1 | blends Y plane 1, loads X plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = __fadd_rn(X.D[c], X.F[c]);
-        ja.plane = sc.plane[2]; ja.t = pos_taps2(sc, 2, xn0, xn1, xn2);
+        ja.plane = sc.plane[2]; ja.t = pos_taps2(sc, 2, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.F);
         limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 9), NoTail{});
         R3_MARKB(4)
         // Y plane 1 | blends X plane 2, loads Y plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = __fadd_rn(Y.D[c], Y.F[c]);
-        jb.plane = sc.plane[2]; jb.t = pos_taps2(sc, 2, yn0, yn1, yn2);
+        jb.plane = sc.plane[2]; jb.t = pos_taps2(sc, 2, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.F);
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(5)
@@ -419,7 +477,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = div3(__fadd_rn(Y.D[c], Y.F[c]));
         split_feat(Y.F);
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F),
-                                           [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp); }); },
+                                           [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp, nsc); }); },
                                            tail_of(X.act, 0));
         R3_MARKB(7)
         cw = nw;
@@ -428,7 +486,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // ---- hidden layers.  Layer l of a decoder = chunks a (K-blocks 0..3), b (4..7):
         //   X a | Y: act of layer l-1; tail Y kb 0        Y a | tail X kb 4        X b | tail Y kb 4        Y b | X: act of layer l; tail X kb 0
         auto relu_side = [&](Tile3& t, int bias_vec) {
-            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp); }); };
+            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc); }); };
         };
         // hidden layer with bias vectors: vprev (layer l-1, finishing Y) and vthis (layer l, finishing X); kbn = next chunk to issue (two per layer)
 #define NVSR_HIDDEN_LAYER_(SYNC, XA_SIDE, VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                \
@@ -471,7 +529,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         split_feat(X.D);
         limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.D),
                                          [&](int slot) {
-                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp); });
+                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp, nsc); });
                                              spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
                                              dma_side<LIMBS, 4>(slot, rs, nw, KB_DEN1);
                                          },
@@ -484,7 +542,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.D),
                                           [&](int slot) {
                                               spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
-                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp); });
+                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp, nsc); });
                                           },
                                           tail_of(X.act, 0));
 #pragma unroll
@@ -501,7 +559,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         NVSR_HIDDEN_LAYER(2, 3, KB_DEN1 + 20, 4, KB_RGB0, 3,
                           (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4),
                                                               [&](int slot) {
-                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_bias_step(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp); });
+                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc); });
                                                                   spread<64, NSH / 2, NSH>(slot, [&](int k) { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
                                                               },
                                                               NoTail{})))
@@ -515,7 +573,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
 
         // ---- epilogue (exposed): Y's last activation + sigma head, both tiles' compositing -----------------------------------------
 #pragma unroll
-        for (int k = 0; k < RELU_STEPS; ++k) relu_bias_step(k, small + S_BIAS + 3 * HID, h, Y.acc, Y.act, bp);
+        for (int k = 0; k < RELU_STEPS; ++k) relu_bias_step<LIMBS>(k, small + S_BIAS + 3 * HID, h, Y.acc, Y.act, bp, nsc);
         {
             float hd[1];
             head_dots<1>(small + S_ALPHA_W, h, Y.act, hd);
@@ -616,7 +674,7 @@ __global__ void pack_decoder_limbs_kernel(const float* __restrict__ nat, unsigne
             src = (is_rgb ? N_RGB_W1 : N_DEN_W1) + l * N_HID_STRIDE + i * HID + k;
         }
         float v = nat[src];
-        unsigned bits;
+        unsigned bits = 0;
         if (LIMBS == 3) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -624,16 +682,56 @@ __global__ void pack_decoder_limbs_kernel(const float* __restrict__ nat, unsigne
                 v = limb_rest(v);
             }
         } else {
-            bits = (t == 0) ? (__float_as_uint(v) >> 16) : (round_pair(0.0f, limb_rest(v)) & 0xffffu);
+            v *= F16_W_SCALE;                                   // limb_core.h: W 2^F16_SW as hi + lo, both rounded to nearest
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            if (!(fabsf(v) <= 65504.0f)) reinterpret_cast<float*>(out)[P_SMALL + S_F16_POISON - P_LIMB2] = __builtin_nanf("");   // (out = packed + P_LIMB2)
+            bits = __builtin_bit_cast(unsigned short, t == 0 ? hi : lo);
         }
         word |= bits << (16 * half);
     }
     out[idx] = word;
 }
 
+// ---- the arithmetic primitive alone: Y[32 x 32] = W[32 x K] X[K x 32] by one wave, operands split exactly as the kernels / the pack
+// kernel split them (LIMBS = 0: v_mfma_f32_32x32x2_f32).  Test hook (nvsr_limb_gemm_probe): error bounds on chosen operands.
+template <int LIMBS>
+__global__ void limb_gemm_probe_kernel(int K, const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ Y) {
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float unscale = 1.0f;
+    if constexpr (LIMBS == 0) {
+        for (int k = 0; k < K; k += 2) acc = mfma32(W[m * K + k + h], X[(k + h) * 32 + m], acc);
+    } else {
+        const float sw = LIMBS == 2 ? F16_W_SCALE : 1.0f, sx = LIMBS == 2 ? F16_X_SCALE : 1.0f;
+        unscale = 1.0f / (sw * sx);
+        for (int kb = 0; kb < K / 16; ++kb) {
+            Limbs<LIMBS> a, b;
+            float wa[8], xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wa[i] = W[m * K + 16 * kb + 8 * h + i] * sw; xb[i] = X[(16 * kb + 8 * h + i) * 32 + m] * sx; }
+            split_all<LIMBS>([&](int i) { return wa[i]; }, a);
+            split_all<LIMBS>([&](int i) { return xb[i]; }, b);
+#pragma unroll
+            for (int p = 0; p < limb_products(LIMBS); ++p) acc = mfma_limb<LIMBS>(a.v[limb_w(LIMBS, p)], b.v[limb_x(LIMBS, p)], acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[(8 * (r >> 2) + 4 * h + (r & 3)) * 32 + m] = acc[r] * unscale;
+}
+
 }  // namespace nvsr
 
 using namespace nvsr;
+
+extern "C" int nvsr_limb_gemm_probe(int arithmetic, int K, const float* W, const float* X, float* Y, nvsr_stream_t stream) {
+    if (!W || !X || !Y) return NVSR_ERR_NULL;
+    if (K < 16 || K % 16) return NVSR_ERR_SHAPE;
+    if (arithmetic == NVSR_ARITH_F32) hipLaunchKernelGGL(limb_gemm_probe_kernel<0>, dim3(1), dim3(64), 0, (hipStream_t)stream, K, W, X, Y);
+    else if (arithmetic == NVSR_ARITH_BF16X3) hipLaunchKernelGGL(limb_gemm_probe_kernel<3>, dim3(1), dim3(64), 0, (hipStream_t)stream, K, W, X, Y);
+    else if (arithmetic == NVSR_ARITH_F16X2) hipLaunchKernelGGL(limb_gemm_probe_kernel<2>, dim3(1), dim3(64), 0, (hipStream_t)stream, K, W, X, Y);
+    else return NVSR_ERR_SHAPE;
+    return NVSR_CHECK_LAUNCH();
+}
 
 extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packed, nvsr_stream_t stream) {
     unsigned* out = reinterpret_cast<unsigned*>(packed);

@@ -68,7 +68,10 @@ __device__ __forceinline__ void heads_side(int g, int j, const float* w, int h, 
 template <class TileT>
 __device__ __forceinline__ void composite_sample(TileT& t, float nrm, float noise, bool last) {
     const float dist = __fmul_rn(last ? 1e10f : __fsub_rn(t.zn, t.zc), nrm);
-    const float sig = fmaxf(__fadd_rn(t.raw[3], noise), 0.0f);
+    // relu(sigma + noise) by compare + select: a NaN stays a NaN like torch.relu's (volume_rendering_utils.py:30) instead of becoming an
+    // empty sample (v_max_f32 returns its non-NaN operand)
+    const float sn = __fadd_rn(t.raw[3], noise);
+    const float sig = sn < 0.0f ? 0.0f : sn;
     const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sig, dist)));
     const float w = __fmul_rn(alpha, t.T);
     t.T = __fmul_rn(t.T, __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f));

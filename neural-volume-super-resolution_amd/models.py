@@ -195,7 +195,7 @@ class TwoDimPlanesModel(nn.Module):
 
         self.skip_SR_ = False
         self._packed_cache = None  # (source key, packed blob)
-        # arithmetic of the decoder GEMMs for the calls made through this model: 'f32' | 'bf16x3' | 'bf16x2' | None = the process default
+        # arithmetic of the decoder GEMMs for the calls made through this model: 'f32' | 'bf16x3' | 'f16x2' | None = the process default
         # (capi.set_decoder_arithmetic / NVSR_DECODER_ARITHMETIC).  Passed to every kernel launch explicitly; a training forward stores
         # the mode it ran in and its backward uses that one.
         self.arithmetic = None

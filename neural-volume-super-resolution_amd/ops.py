@@ -10,7 +10,7 @@ Conventions
   * a scene is passed as `planes` = 4 CHANNEL-LAST [H,W,48] tensors (position planes D0..D2, view-direction plane) and `consts` = 28
     python floats: lo[5], range[5], proj[3][6] (struct nvsr_scene, include/nvsr.h);
   * `arithmetic` is the NVSR_ARITH_* code of the decoder GEMMs / SR convolutions for THIS call (-1 = the process default): a per-call
-    argument, nothing global (capi.arith_code turns 'f32' / 'bf16x3' / 'bf16x2' / None into it);
+    argument, nothing global (capi.arith_code turns 'f32' / 'bf16x3' / 'f16x2' / None into it);
   * operators cannot return None: an output that was not asked for comes back as an empty tensor.
 
 Reference functions behind the operators: models.py:381-421 (decoder), train_utils.py:71-182 (render passes), volume_rendering_utils.py:6-51

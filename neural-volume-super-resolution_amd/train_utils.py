@@ -248,7 +248,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
         # a limb mode trains with 3 limbs (what feeds a gradient stays close to f32): the 2-limb mode is a rendering-only option
-        t3 = lambda a: capi.ARITHMETIC["bf16x3"] if a == capi.ARITHMETIC["bf16x2"] else a
+        t3 = lambda a: capi.ARITHMETIC["bf16x3"] if a == capi.ARITHMETIC["f16x2"] else a
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=lindisp, white=white, t_rand=t_rand, u=u, noise_c=n_c, noise_f=n_f,
                    planes_c=planes_c, planes_f=planes_f, consts=consts, packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,

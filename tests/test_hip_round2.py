@@ -10,7 +10,7 @@ import torch
 from test_hip_parity import DEV, N_, T, build_model
 
 pytestmark = pytest.mark.gpu
-ARITH = {"f32": 0, "bf16x3": 3, "bf16x2": 2}
+ARITH = {"f32": 0, "bf16x3": 3, "f16x2": 2}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -773,14 +773,15 @@ def test_inference_frame_computes_coarse_depths_in_kernel(hip):
     rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
     planes, consts = mc.scene_args()
     bits = lambda t: t.contiguous().view(torch.int32)
+    arith = hip.capi.ARITHMETIC[hip.capi.get_decoder_arithmetic()]          # the explicit passes below in the arithmetic eval_nerf runs in
     for lindisp in (False, True):
         opts, scfg = render_options(64, 128)
         opts.nerf.validation.lindisp = lindisp
         got = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
         z_c = nv.coarse_z(rays, 64, lindisp, None)
-        rgb_c, disp_c, acc_c, w_c = nv.render_pass(planes, consts, mc.packed_decoder(), rays, z_c, None, False, True, 3)
+        rgb_c, disp_c, acc_c, w_c = nv.render_pass(planes, consts, mc.packed_decoder(), rays, z_c, None, False, True, arith)
         z_f = nv.importance_resample(z_c, w_c, 128, None)
-        rgb_f, *_ = nv.render_pass(planes, consts, mf.packed_decoder(), rays, z_f, None, False, False, 3)
+        rgb_f, *_ = nv.render_pass(planes, consts, mf.packed_decoder(), rays, z_f, None, False, False, arith)
         assert torch.equal(bits(got[0].reshape(-1, 3)), bits(rgb_c)) and torch.equal(bits(got[3].reshape(-1, 3)), bits(rgb_f)), lindisp
         # the resampler alone: depths recomputed from the rays == depths read
         z_f2 = torch.empty_like(z_f)

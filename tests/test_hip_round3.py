@@ -313,3 +313,125 @@ def test_resampler_fast_path_is_bit_identical_to_the_separate_kernels(hip):
         capi.call("nvsr_sample_pdf", N, Nc - 1, Nf, capi.ptr(zm), capi.ptr(w_d[:, 1:-1].contiguous()), None, capi.ptr(smp), capi.stream())
         ref = torch.sort(torch.cat([z_d, smp], -1), -1).values
         assert torch.equal(a, ref) and torch.equal(b, ref), lindisp
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the limb arithmetics as a primitive (csrc/limb_core.h; include/nvsr.h NVSR_ARITH_*): error against float64 on chosen operands
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _gemm_probe(hip, mode, W, X):
+    Y, Wd, Xd = torch.empty((32, 32), device=DEV), T(np.ascontiguousarray(W)), T(np.ascontiguousarray(X))
+    hip.capi.call("nvsr_limb_gemm_probe", hip.capi.ARITHMETIC[mode], W.shape[1], hip.capi.ptr(Wd), hip.capi.ptr(Xd), hip.capi.ptr(Y),
+                  hip.capi.stream())
+    return N_(Y).astype(np.float64)
+
+
+def test_limb_gemm_error_bounds(hip):
+    """Y = W X through the products of every decoder arithmetic -- the operands split exactly as the render kernels and the weight packer
+    split them -- against float64, relative to sum_k |W_k||X_k| per output.  K = 192 (the widest decoder layer, models.py:409-413).
+    Operand sets: random; adversarial mantissas (all ones / low 16 bits set -- the worst case of truncation limbs) with all products of
+    a row positive; magnitudes spread over 2^-12 .. 2^8 (activations) to exercise F16X2's static scales and its subnormal low limbs.
+    Asserted per arithmetic (include/nvsr.h):
+        f32     <= (K / 2) 2^-24                                   one rounding per accumulating MFMA
+        bf16x3  <= 2^-21 + 2^-30 + (6 K / 16) 2^-24                 dropped limb products + accumulation
+        f16x2   <= 2^-21 + (3 K / 16) 2^-24 + floor                 representation 2 x 2^-23 + dropped Wl xl 2^-22 + accumulation; floor =
+                                                                     the absolute error of subnormal low limbs (2^-29 per activation,
+                                                                     2^-33 per weight) relative to the row's sum |W||X|
+    and: F16X2 is not worse than BF16X3 on the random and the adversarial sets (max and rms), which is what makes it the default."""
+    rng = np.random.default_rng(11)
+    K = 192
+
+    def adversarial(shape, pattern, sign=None):
+        e = rng.integers(-3, 3, size=shape)
+        mant = {"ones": 0x7FFFFF, "low16": 0x00FFFF}[pattern]
+        bits = ((127 + e).astype(np.uint32) << 23) | np.uint32(mant)
+        v = bits.view(np.float32)
+        s = np.where(rng.random(shape) < 0.5, -1.0, 1.0).astype(np.float32) if sign is None else sign
+        return (v * s).astype(np.float32)
+
+    sets = {}
+    sets["random"] = (rng.standard_normal((32, K)).astype(np.float32) * 0.1, np.maximum(rng.standard_normal((K, 32)), 0).astype(np.float32))
+    for pat in ("ones", "low16"):
+        X = adversarial((K, 32), pat)
+        W = adversarial((32, K), pat, sign=np.sign(X[:, 0])[None, :].repeat(32, 0)) / np.float32(64)        # column 0: every product positive
+        sets["adversarial " + pat] = (W, X)
+    mag = np.exp2(rng.uniform(-12, 8, size=(K, 32))).astype(np.float32)
+    sets["wide range"] = (rng.standard_normal((32, K)).astype(np.float32) * np.exp2(rng.uniform(-9, 2, size=(32, K))).astype(np.float32),
+                          (mag * np.where(rng.random((K, 32)) < 0.5, -1, 1)).astype(np.float32))
+    bound = {"f32": lambda floor: (K // 2) * 2.0 ** -24, "bf16x3": lambda floor: 2.0 ** -21 + 2.0 ** -30 + (6 * K // 16) * 2.0 ** -24,
+             "f16x2": lambda floor: 2.0 ** -21 + (3 * K // 16) * 2.0 ** -24 + floor}
+    report = {}
+    for name, (W, X) in sets.items():
+        ref = W.astype(np.float64) @ X.astype(np.float64)
+        magn = np.abs(W.astype(np.float64)) @ np.abs(X.astype(np.float64))
+        floor = (2.0 ** -29 * np.abs(W.astype(np.float64)).sum(1)[:, None] + 2.0 ** -33 * np.abs(X.astype(np.float64)).sum(0)[None, :]) / magn
+        for mode in ("f32", "bf16x3", "f16x2"):
+            rel = (_gemm_probe(hip, mode, W, X) - ref) / magn
+            report[(name, mode)] = (np.abs(rel).max(), np.sqrt((rel ** 2).mean()), rel.mean())
+            assert np.all(np.abs(rel) <= bound[mode](floor if mode == "f16x2" else 0.0)), (name, mode, np.abs(rel).max())
+    for (name, mode), (mx, rms, mean) in report.items():
+        print("%-18s %-7s max %.3g  rms %.3g  mean %+.3g   (of sum |w||x|)" % (name, mode, mx, rms, mean))
+    for name in ("random", "adversarial ones", "adversarial low16"):
+        assert report[(name, "f16x2")][0] <= report[(name, "bf16x3")][0] * 1.05, name
+        assert report[(name, "f16x2")][1] <= report[(name, "bf16x3")][1] * 1.05, name
+    # an activation beyond the static range (>= 4094) must come out non-finite, never as a wrong number
+    W, X = sets["random"][0].copy(), sets["random"][1].copy()
+    X[5, 7] = 5000.0
+    W[:, 5] = np.where(W[:, 5] == 0, 0.1, W[:, 5])
+    bad = _gemm_probe(hip, "f16x2", W, X).astype(np.float32)
+    assert not np.isfinite(bad[:, 7]).any()
+    # ... as the matrix pipe's default NaN, 0xFFC00000 (negative): csrc/render3.hip's ReLU relies on it (source negation + integer max)
+    assert (bad[:, 7].view(np.uint32) == 0xFFC00000).all(), [hex(v) for v in bad[:, 7].view(np.uint32)[:4]]
+    assert np.isfinite(_gemm_probe(hip, "bf16x3", W, X)).all()
+
+
+def test_f16_limb_range_overflow_is_loud(hip):
+    """NVSR_ARITH_F16X2 carries static scales (include/nvsr.h): a feature / activation >= 4094 or a weight >= 255 does not fit its f16 limbs.
+    Such a render must come out NaN -- never a finite wrong number (max(NaN, 0) = 0 inside the decoder would otherwise hide the overflow:
+    csrc/render3.hip reads the conversion's sticky IEEE overflow flag per sample; the weight packer poisons the blob) -- while BF16X3 renders
+    the same scene with finite pixels, and an in-range scene is untouched by the checks (finite, equal to a second launch)."""
+    from bench import make_synthetic_scene
+    capi = hip.capi
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=64, view_res=16, seed=3)
+    H = W = 136                                               # 18 496 rays: the fused kernels
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    N, S = rays.shape[0], 24
+    z = torch.sort(torch.rand(N, S, device=DEV) * 4 + 2, -1).values.contiguous()
+
+    def render(mode):
+        sc, keep = mf.native_scene()
+        o = [torch.empty((N, 3), device=DEV), torch.empty(N, device=DEV), torch.empty(N, device=DEV)]
+        capi.call("nvsr_render_pass_arith", C.byref(sc), capi.ptr(mf.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), None, 1,
+                  *[capi.ptr(b) for b in o], None, None, None, capi.ARITHMETIC[mode], capi.stream())
+        torch.cuda.synchronize()
+        return o[0]
+
+    a, b = render("f16x2"), render("f16x2")
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert (a - render("bf16x3")).abs().max() < 2e-5
+    # (1) features beyond the range: planes x 20000
+    name = hip.models.get_plane_name(sid, 0)
+    with torch.no_grad():
+        saved = mf.planes_[name].detach().clone()
+        mf.planes_[name].mul_(20000.0)
+    try:
+        assert torch.isfinite(render("bf16x3")).all()
+        bad = render("f16x2")
+        assert torch.isnan(bad).all(), "an out-of-range feature produced finite pixels"
+    finally:
+        with torch.no_grad():
+            mf.planes_[name].copy_(saved)
+    assert torch.equal(render("f16x2"), a)
+    # (2) a weight beyond the range
+    with torch.no_grad():
+        w = mf.rgb_dec["0"][2].weight
+        keep_w = float(w[5, 7])
+        w[5, 7] = 300.0
+    try:
+        assert torch.isfinite(render("bf16x3")).all()
+        assert torch.isnan(render("f16x2")).all(), "an out-of-range weight produced finite pixels"
+    finally:
+        with torch.no_grad():
+            w[5, 7] = keep_w
+    assert torch.equal(render("f16x2"), a)

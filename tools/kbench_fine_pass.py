@@ -9,6 +9,8 @@ mc,mf,sid,pose=make_synthetic_scene(dev,800,32,seed=0)
 H=W=800; focal=0.5*W/np.tan(0.5*0.6911112)
 ro,rd=nvsr_amd.nerf_helpers.get_ray_bundle(H,W,focal,pose)
 rays=nvsr_amd.train_utils.pack_rays(ro,rd,2.0,6.0); N=rays.shape[0]
+if not os.environ.get("KBENCH_ROW_ORDER"):      # the bench renders a frame in patch order (train_utils.patch_order)
+    rays=rays[nvsr_amd.train_utils.patch_order(N,W,dev)[0]].contiguous()
 capi=nvsr_amd.capi
 ws=torch.empty(capi.lib().nvsr_render_workspace_floats(N,64,128),device=dev)
 bufs=[torch.empty((N,3),device=dev),torch.empty(N,device=dev),torch.empty(N,device=dev),torch.empty((N,3),device=dev),torch.empty(N,device=dev),torch.empty(N,device=dev)]
@@ -25,4 +27,5 @@ for i in range(reps):
     capi.call("nvsr_render_pass",C.byref(sc),capi.ptr(packed),N,192,capi.ptr(rays),capi.ptr(zf),None,0,capi.ptr(bufs[3]),capi.ptr(bufs[4]),capi.ptr(bufs[5]),None,None,capi.stream())
     b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 fl=259072*N*192
+print(capi.get_decoder_arithmetic(), os.environ.get("NVSR_HIP_LIB","product"), end=" ")
 print("fine pass: min %.2f ms  med %.2f ms -> %.1f TFLOP/s (%.1f%% of 157.3)  same=%s  mean rgb %.4f"%(min(ts),np.median(ts),fl/min(ts)/1e9,100*fl/min(ts)/1e9/157.3, torch.equal(ref,bufs[3]), float(bufs[3].mean())))

@@ -24,7 +24,7 @@ z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), d
 sc, keep = mf.native_scene()
 packed = mf.packed_decoder()
 outs = {}
-for mode in ("f32", "bf16x3", "bf16x2"):
+for mode in ("f32", "bf16x3", "f16x2"):
     capi.set_decoder_arithmetic(mode)
     o = dict(rgb=torch.full((N, 3), -7.0, device=dev), disp=torch.full((N,), -7.0, device=dev), acc=torch.full((N,), -7.0, device=dev),
              w=torch.full((N, S), -7.0, device=dev), depth=torch.full((N,), -7.0, device=dev), raw=torch.full((N, S, 4), -7.0, device=dev))
@@ -36,7 +36,7 @@ for mode in ("f32", "bf16x3", "bf16x2"):
     outs[mode] = {k: v.cpu().numpy().astype(np.float64) for k, v in o.items()}
     print(mode, "%.2f ms" % (dt * 1e3), "raw range", outs[mode]["raw"].min(), outs[mode]["raw"].max())
 ref = outs["f32"]
-for mode in ("bf16x3", "bf16x2"):
+for mode in ("bf16x3", "f16x2"):
     for k in ("raw", "rgb", "acc", "w", "depth"):
         d = np.abs(outs[mode][k] - ref[k])
         print("%-7s %-5s max|d| %.3e  mean|d| %.3e   (max|ref| %.3e)" % (mode, k, d.max(), d.mean(), np.abs(ref[k]).max()))

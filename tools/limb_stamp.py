@@ -27,6 +27,8 @@ H = W = 800
 focal = 0.5 * W / np.tan(0.5 * 0.6911112)
 ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
 rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0).contiguous()
+if not os.environ.get("KBENCH_ROW_ORDER"):      # the bench renders a frame in patch order
+    rays = rays[hip.train_utils.patch_order(rays.shape[0], W, dev)[0]].contiguous()
 N, S = rays.shape[0], 192
 rng = np.random.default_rng(17)
 z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), device=dev)
@@ -37,7 +39,7 @@ if "R3_STAMP=4" in os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", ""):
     names = ["sync a (x6)", "issue a", "X a (Y relu)", "Y a", "sync+issue b", "X b", "Y b (X relu)"]
 if "R3_STAMP=3" in os.environ.get("NVSR_EXTRA_HIPCC_FLAGS", ""):
     names = ["B0 X view", "B1 Y view", "B2 X p0", "B3 Y p0", "B4 X p1", "B5 Y p1", "B6 X p2"]
-for mode in sys.argv[1:] or ["bf16x3", "bf16x2"]:
+for mode in sys.argv[1:] or ["bf16x3", "f16x2"]:
     capi.set_decoder_arithmetic(mode)
     o = dict(rgb=torch.empty((N, 3), device=dev), disp=torch.empty((N,), device=dev), acc=torch.empty((N,), device=dev), raw=torch.zeros((N, S, 4), device=dev))
     for rep in range(2):

@@ -22,7 +22,7 @@ rays_all = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0).contiguous()
 sc, keep = mf.native_scene()
 packed = mf.packed_decoder()
 rng = np.random.default_rng(1)
-worst = {"bf16x3": 0.0, "bf16x2": 0.0}
+worst = {"bf16x3": 0.0, "f16x2": 0.0}
 for trial in range(24):
     N = int(rng.integers(16384, 50000))
     S = int(rng.choice([1, 2, 3, 5, 17, 64, 129, 192]))
@@ -31,7 +31,7 @@ for trial in range(24):
     z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), device=dev)
     noise = torch.as_tensor((rng.standard_normal((N, S)) * 0.3).astype(np.float32), device=dev) if use_noise else None
     res = {}
-    for mode in ("f32", "bf16x3", "bf16x2", "bf16x3"):
+    for mode in ("f32", "bf16x3", "f16x2", "bf16x3"):
         capi.set_decoder_arithmetic(mode)
         o = dict(rgb=torch.full((N, 3), -7.0, device=dev), disp=torch.full((N,), -7.0, device=dev), acc=torch.full((N,), -7.0, device=dev),
                  w=torch.full((N, S), -7.0, device=dev), depth=torch.full((N,), -7.0, device=dev), raw=torch.full((N, S, 4), -7.0, device=dev))
@@ -46,7 +46,7 @@ for trial in range(24):
     # the last interval is 1e10 long: alpha of the last sample is a step function of the sign of its sigma -- rays whose last sigma is within
     # the arithmetic's noise of zero are excluded (as in tests/test_hip_parity.py)
     sig_last = res["f32"]["raw"][:, -1, 3] + (noise[:, -1] if use_noise else 0.0)
-    for mode in ("bf16x3", "bf16x2"):
+    for mode in ("bf16x3", "f16x2"):
         ok = sig_last.abs() > (1e-4 if mode == "bf16x3" else 5e-3)
         for k in ("rgb", "acc") + (("raw", "w") if want else ()):
             d = float((res[mode][k] - res["f32"][k])[ok].abs().max())
