@@ -574,12 +574,13 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
                               "vs_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
         result["roofline"]["traffic_source"] = None if result["roofline"]["traffic"] is None else pmc_source()
         if mode != "f32":
-            result["roofline"]["kernel"] = "conv3x3_limb16_kernel (v_mfma_f32_16x16x32_bf16; 67 of the 70 launches per step) + conv3x3_limb_kernel (3)"
+            result["roofline"]["kernel"] = ("conv3x3_limb16_kernel<., ., %d> (v_mfma_f32_16x16x32_%s; 67 of the 70 launches per step) + conv3x3_limb_kernel (3 launches, 3 bf16 limbs)"
+                                            % ((2, "f16") if mode == "f16x2" else (3, "bf16")))
             result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_16x16x32=ach * arith["products"] /
                                                              SUSTAINED_BF16_MFMA["tflops_random_operands_16x16x32_two_waves_per_simd"])
         if world == 1 and not args.no_modes:
             modes = {}
-            for m2 in ("f32", "bf16x3"):
+            for m2 in ("f32", "bf16x3", "f16x2"):
                 nvsr_amd.capi.set_conv_arithmetic(m2)
                 one(); torch.cuda.synchronize()
                 t1 = time.perf_counter()

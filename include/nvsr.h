@@ -107,9 +107,12 @@ int nvsr_set_decoder_arithmetic(int mode);
 int nvsr_limb_gemm_probe(int arithmetic, int K, const float* W, const float* X, float* Y, nvsr_stream_t stream);
 /* Same for the 3x3 convolutions of the SR network (process default + *_arith twins): forward and data gradient of the layers with
  * Cin % 16 == 0 and a multiple of 256, or at most 64, output channels (every layer of EDSR(256); other shapes always use the f32 kernel),
- * and every weight gradient: NVSR_ARITH_F32 or NVSR_ARITH_BF16X3 (same error bound as above).
- * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3. */
-#define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_BF16X3
+ * and every weight gradient: NVSR_ARITH_F32, NVSR_ARITH_BF16X3 (same error bound as above) or NVSR_ARITH_F16X2 -- the FORWARD convolutions
+ * of the layers with Cin % 32 == 0 and Cout % 128 == 0 (EDSR's 65 trunk and 2 up-sampling convolutions, 97 % of the FLOPs) on 2 f16 limbs
+ * (3 MFMAs per product block instead of 6; weights packed as W 2^8, the input patch held as x 2^4, same ranges and the same NaN-on-overflow
+ * rule as above); every data / weight gradient and the narrow input / output layers run 3 bf16 limbs in that mode.
+ * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3 | f16x2. */
+#define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_F16X2
 int nvsr_get_conv_arithmetic(void);
 int nvsr_set_conv_arithmetic(int mode);
 

@@ -183,7 +183,7 @@ def get_decoder_arithmetic():
 
 
 def set_conv_arithmetic(mode):
-    """Arithmetic of the wide 3x3 conv layers of the SR network: 'f32' | 'bf16x3'."""
+    """Arithmetic of the wide 3x3 conv layers of the SR network: 'f32' | 'bf16x3' | 'f16x2' (forward convolutions; gradients stay 3-limb)."""
     call("nvsr_set_conv_arithmetic", ARITHMETIC[mode])
 
 

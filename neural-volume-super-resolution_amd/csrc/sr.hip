@@ -31,6 +31,7 @@ struct ConvParams {
     const float* wpk;     // packed weights [chunk][cb][t][lane]
     const unsigned* wpk_limb;   // bf16-limb fragments behind them (conv_limb_eligible layers), else NULL
     const unsigned* wpk_limb16; // 16x16x32 fragments behind those (conv_limb16_eligible layers), else NULL
+    const unsigned* wpk_f16;    // 16x16x32 fragments of the 2-f16-limb arithmetic behind those (same layers), else NULL
     float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
     const float* skip;    // EPI_RESIDUAL: identity [Cout][H+2][W+2] (block input); EPI_MASK_SCALE: forward activation
                           // [Cout][H-2][W-2] whose sign gates the result; EPI_ADD_CENTER: [Cout][H-6][W-6] added to the centre
@@ -472,7 +473,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 // Per tap a wave reads 6 weight fragments (one tap ahead) and, per (row, half-row), 3 B fragments for 12 MFMAs.  Same limb products in the same
 // order per (ci block, tap), but the K dimension of an instruction spans 32 channels instead of 16: the f32 accumulation order differs from
 // conv3x3_limb_kernel's, results agree to rounding (both are held to the oracle at 3e-5).
-template <int PB>
+// F16 (the 2-f16-limb arithmetic): the accumulators carry 2^(F16_SW + F16_SX) and the ReLU lets a NaN through (an operand beyond the f16
+// range turns the accumulators into NaNs; fmaxf would return 0)
+template <int PB, bool F16 = false>
 __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[2][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo) {
     float* __restrict__ const out = p.out;
     const float* __restrict__ const skip = p.skip;
@@ -506,7 +509,8 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float t = acc[cb][pb][hx][r];
-                        if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
+                        if (F16) t *= 1.0f / (F16_W_SCALE * F16_X_SCALE);
+                        if (EPI == EPI_RELU) t = F16 ? (t < 0.0f ? 0.0f : t) : fmaxf(t, 0.0f);
                         if (EPI == EPI_RESIDUAL) t = t * 0.1f + sk[r];
                         if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;
                         if (EPI == EPI_ADD_CENTER) t += sk[r];
@@ -527,19 +531,26 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
         case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
         case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
         case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
-        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
-        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
+        case EPI_MASK_SCALE: if constexpr (!F16) write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;      // (backward epilogues: 3-limb kernel only)
+        case EPI_ADD_CENTER: if constexpr (!F16) write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
         default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
     }
 }
 
+template <int LIMBS>
+__device__ __forceinline__ f32x4 mfma16_limb(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (LIMBS == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // WAVES = 4: 128 output channels per workgroup, two workgroups per CU; WAVES = 8 (experiment, -DCV16_WAVES=8): 256 channels per workgroup, one
 // workgroup per CU -- the patch is staged once for all 256 channels
-template <int PB, int WAVES = 4>
+// LIMBS = 3: bf16 limbs (6 products); LIMBS = 2: f16 limbs rounded to nearest with the static scales of limb_core.h (3 products; forward
+// convolutions only -- gradients span too many decades for 5 exponent bits)
+template <int PB, int WAVES = 4, int LIMBS = 3>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p) {
     constexpr int TPB = 64 * WAVES;
     constexpr int PR = PB + 2, PC = 34;
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
     // SQ_LDS_BANK_CONFLICT = 48 % of the LDS-active cycles)
     constexpr int OSTR = (PR * PC + 15) / 16 * 16;
     constexpr int LIMB_WORDS = 4 * OSTR * 4;              // one limb of the patch
-    constexpr int BUF = 3 * LIMB_WORDS;
+    constexpr int BUF = LIMBS * LIMB_WORDS;
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
 #define CV16_ITEM(R, O, COL) ((O) * OSTR + (R) * PC + (COL))
 
@@ -602,14 +613,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            Limbs<3> L;
+            Limbs<LIMBS> L;
             float e[8];
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) e[c8] = inside[k] ? st[k][c8] : 0.0f;
-            split8(e, L);
+            for (int c8 = 0; c8 < 8; ++c8) e[c8] = inside[k] ? (LIMBS == 2 ? st[k][c8] * F16_X_SCALE : st[k][c8]) : 0.0f;
+            if constexpr (LIMBS == 3) split8(e, L);
+            else split_all<2>([&](int i8) { return e[i8]; }, L);
             if (item[k]) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(lds + buf * BUF + t * LIMB_WORDS + sl[k]) = L.v[t];
+                for (int t = 0; t < LIMBS; ++t) *reinterpret_cast<u32x4*>(lds + buf * BUF + t * LIMB_WORDS + sl[k]) = L.v[t];
             }
         }
     };
@@ -623,8 +635,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
             for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int nchunks = p.Cin / 32;
-    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wpk_limb16) + ((long)cb0 * 27) * 64;     // wave-uniform
-    const long wchunk = (long)ncb16 * 27 * 64;              // u32x4 per chunk
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(LIMBS == 2 ? p.wpk_f16 : p.wpk_limb16) + ((long)cb0 * 9 * LIMBS) * 64;     // wave-uniform
+    const long wchunk = (long)ncb16 * 9 * LIMBS * 64;       // u32x4 per chunk
     gload(0);
     sstore(0);
     __syncthreads();
@@ -633,11 +645,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         if (chunk + 1 < nchunks) gload(chunk + 1);          // in flight during this chunk's MFMAs
         const u32x4* wa = wbase + chunk * wchunk;
         const unsigned* pl = lds + buf * BUF + CV16_ITEM(0, g, i16) * 4;
-        u32x4 A[2][3], An[2][3];
+        u32x4 A[2][LIMBS], An[2][LIMBS];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) A[cb][t] = wa[((cb * 9 + 0) * 3 + t) * 64 + lane];
+            for (int t = 0; t < LIMBS; ++t) A[cb][t] = wa[((cb * 9 + 0) * LIMBS + t) * 64 + lane];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -646,45 +658,48 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * 3 + t) * 64 + lane];
+                    for (int t = 0; t < LIMBS; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * LIMBS + t) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
                 for (int hx = 0; hx < 2; ++hx) {
-                    u32x4 B[3];
+                    u32x4 B[LIMBS];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV16_ITEM(pb + ky, 0, 16 * hx + kx) * 4);
+                    for (int t = 0; t < LIMBS; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV16_ITEM(pb + ky, 0, 16 * hx + kx) * 4);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int qq = 0; qq < 6; ++qq) acc[cb][pb][hx] = mfma16_bf16(A[cb][limb_w(3, qq)], B[limb_x(3, qq)], acc[cb][pb][hx]);
+                        for (int qq = 0; qq < limb_products(LIMBS); ++qq)
+                            acc[cb][pb][hx] = mfma16_limb<LIMBS>(A[cb][limb_w(LIMBS, qq)], B[limb_x(LIMBS, qq)], acc[cb][pb][hx]);
                 }
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) A[cb][t] = An[cb][t];
+                    for (int t = 0; t < LIMBS; ++t) A[cb][t] = An[cb][t];
             }
         }
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out16<PB>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo);
+    conv_write_out16<PB, LIMBS == 2>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo);
 #undef CV16_ITEM
 }
 
 // limb fragments for conv3x3_limb16_kernel: [chunk of 32 ci][cb16][tap][limb][lane][4 words]; lane (co = 16 cb + (l & 15), g = l >> 4) holds the
 // 8 input channels 32 chunk + 8 g + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
+template <int LIMBS = 3>
 __global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int transposed) {
+    constexpr int FRAG = 9 * LIMBS * 256;
     const int ncb = Cout / 16;
-    const long n = (long)(Cin / 32) * ncb * CL_FRAG_WORDS;
+    const long n = (long)(Cin / 32) * ncb * FRAG;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % 3), tap = (int)((idx / 768) % 9);
-    const long rest = idx / CL_FRAG_WORDS;
+    const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % LIMBS), tap = (int)((idx / (256 * LIMBS)) % 9);
+    const long rest = idx / FRAG;
     const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
     const int co = 16 * cb + (lane & 15), g = lane >> 4;
     unsigned word = 0;
@@ -693,10 +708,16 @@ __global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* 
         const int ci = 32 * chunk + 8 * g + 2 * wd + half;
         float v = transposed ? w[((long)ci * Cout + co) * 9 + (8 - tap)] : w[((long)co * Cin + ci) * 9 + tap];
         unsigned bits = 0;
+        if constexpr (LIMBS == 2) {          // f16 limbs of W 2^F16_SW, both rounded to nearest (limb_core.h); a weight >= 255 packs as inf -> NaN outputs
+            v *= F16_W_SCALE;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            bits = __builtin_bit_cast(unsigned short, t == 0 ? hi : lo);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k == t) bits = __float_as_uint(v) >> 16;
-            v = limb_rest(v);
+            for (int k = 0; k < 3; ++k) {
+                if (k == t) bits = __float_as_uint(v) >> 16;
+                v = limb_rest(v);
+            }
         }
         word |= bits << (16 * half);
     }
@@ -789,11 +810,12 @@ extern "C" int nvsr_get_conv_arithmetic(void) {
         g_conv_arithmetic = NVSR_CONV_ARITH_DEFAULT;
         if (e && !strcmp(e, "f32")) g_conv_arithmetic = NVSR_ARITH_F32;
         if (e && !strcmp(e, "bf16x3")) g_conv_arithmetic = NVSR_ARITH_BF16X3;
+        if (e && !strcmp(e, "f16x2")) g_conv_arithmetic = NVSR_ARITH_F16X2;
     }
     return g_conv_arithmetic;
 }
 extern "C" int nvsr_set_conv_arithmetic(int mode) {
-    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
     g_conv_arithmetic = mode;
     return NVSR_OK;
 }
@@ -803,7 +825,10 @@ int conv_resolve_arith(int arith) { return arith == NVSR_ARITH_INHERIT ? nvsr_ge
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad, int batch, ConvExec cx) {
     const int arith = conv_resolve_arith(cx.arith);
-    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
+    // NVSR_ARITH_F16X2: the forward convolutions of the wide layers (16x16x32 kernel) on 2 f16 limbs; everything else that runs limbs -- the
+    // narrow input / output layers, every data gradient (pad = 2, backward epilogues) -- stays on 3 bf16 limbs
+    const bool f16 = arith == NVSR_ARITH_F16X2 && pad == 0 && epilogue != EPI_MASK_SCALE && epilogue != EPI_ADD_CENTER;
     if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16 && !(cx.rows >= 18 && cx.rows <= 20)) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
@@ -815,7 +840,8 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     const unsigned* wlimb = conv_limb_eligible(Cin, Cout) ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) : nullptr;
     const unsigned* wlimb16 = conv_limb16_eligible(Cin, Cout)
                                   ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) + conv_packed_limb_words(Cin, Cout) : nullptr;
-    ConvParams p{in, wpk, wlimb, wlimb16, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    const unsigned* wf16 = wlimb16 ? wlimb16 + conv_packed_limb16_words(Cin, Cout) : nullptr;
+    ConvParams p{in, wpk, wlimb, wlimb16, wf16, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
     if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
@@ -847,6 +873,12 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             if (forced >= 2 && forced <= 4 && cx.rows < 18) best_pb = forced;
         }
         grid.y = (Ho + best_pb - 1) / best_pb;
+        if (f16) {
+            if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            return NVSR_CHECK_LAUNCH();
+        }
         if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
         else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
         else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
@@ -937,9 +969,12 @@ int nvsr_pack_conv3x3(const float* w, int Cin, int Cout, float* packed, nvsr_str
     if (const int64_t nl = conv_packed_limb_words(Cin, Cout))
         hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n), Cin, Cout, conv_ncb(Cout), 0);
-    if (const int64_t n16 = conv_packed_limb16_words(Cin, Cout))
-        hipLaunchKernelGGL(pack_conv_limbs16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                           reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cin, Cout), Cin, Cout, 0);
+    if (const int64_t n16 = conv_packed_limb16_words(Cin, Cout)) {
+        unsigned* r16 = reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cin, Cout);
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel<3>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, r16, Cin, Cout, 0);
+        const int64_t nf = conv_packed_f16_words(Cin, Cout);
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel<2>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, r16 + n16, Cin, Cout, 0);
+    }
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -955,8 +990,8 @@ int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nv
     if (const int64_t nl = conv_packed_limb_words(Cout, Cin))
         hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n), Cout, Cin, conv_ncb(Cin), 1);
-    if (const int64_t n16 = conv_packed_limb16_words(Cout, Cin))
-        hipLaunchKernelGGL(pack_conv_limbs16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+    if (const int64_t n16 = conv_packed_limb16_words(Cout, Cin))            // (the data gradient never runs the f16 limbs: that region of the blob stays unwritten)
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel<3>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cout, Cin), Cout, Cin, 1);
     return NVSR_CHECK_LAUNCH();
 }

@@ -531,8 +531,8 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     const int Ho = H - 2, Wo = W - 2;
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
     arith = conv_resolve_arith(arith);
-    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
-    const bool limb = arith != NVSR_ARITH_F32;
+    if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
+    const bool limb = arith != NVSR_ARITH_F32;          // (weight gradients: 3 bf16 limbs in either limb mode)
     const long n = 9L * Cout * Cin;
     if (limb) {
         int n_wg = wgrad_pieces(Cin, Cout, Ho, Wo);

@@ -31,8 +31,12 @@ inline bool conv_limb16_eligible(int Cin, int Cout) { return Cin % 32 == 0 && Co
 inline int64_t conv_packed_limb16_words(int Cin, int Cout) {
     return conv_limb16_eligible(Cin, Cout) ? (int64_t)(Cin / 32) * (Cout / 16) * CL_FRAG_WORDS : 0;
 }
+// the same fragments in the 2-f16-limb arithmetic (limb_core.h: W 2^8 as hi + lo, round to nearest), a fourth region: [..][limb 0..1][lane][4 words]
+inline int64_t conv_packed_f16_words(int Cin, int Cout) {
+    return conv_limb16_eligible(Cin, Cout) ? (int64_t)(Cin / 32) * (Cout / 16) * (9 * 2 * 256) : 0;
+}
 inline int64_t conv_packed_floats(int Cin, int Cout) {
-    return conv_packed_f32_floats(Cin, Cout) + conv_packed_limb_words(Cin, Cout) + conv_packed_limb16_words(Cin, Cout);
+    return conv_packed_f32_floats(Cin, Cout) + conv_packed_limb_words(Cin, Cout) + conv_packed_limb16_words(Cin, Cout) + conv_packed_f16_words(Cin, Cout);
 }
 
 // conv_input, (conv1, conv2) x nblocks, conv_mid, n_up x up-conv, conv_output  (state-dict order, models.py:802-816)

@@ -460,7 +460,7 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
     tolerance; the others always on the f32 kernel)"""
     rng = np.random.default_rng(3)
     capi = hip.capi
-    assert capi.get_conv_arithmetic() == "bf16x3"
+    assert capi.get_conv_arithmetic() == "f16x2"            # include/nvsr.h NVSR_CONV_ARITH_DEFAULT
     try:
         for Cin, Cout, H, W, epi in [(48, 256, 21, 45, 0), (256, 256, 14, 40, 1), (256, 48, 37, 35, 0), (16, 64, 9, 70, 3), (5, 7, 3, 3, 0),
                                      (256, 1024, 9, 37, 3), (256, 256, 5, 131, 0)]:
@@ -472,7 +472,7 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
             ref = oracle.conv3x3(x, w, relu=(epi == 1))
             if epi == 3:
                 ref = ref.reshape(Cout // 4, 2, 2, H - 2, W - 2).transpose(0, 3, 1, 4, 2).reshape(Cout // 4, 2 * (H - 2), 2 * (W - 2))
-            for mode in ("bf16x3", "f32"):
+            for mode in ("f16x2", "bf16x3", "f32"):
                 capi.set_conv_arithmetic(mode)
                 out = torch.full(ref.shape, -7.0, device=DEV)
                 capi.call("nvsr_conv3x3", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, None, capi.ptr(out), capi.stream())
@@ -486,13 +486,13 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
         capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(T(w)), Cin, Cout, capi.ptr(pk), capi.stream())
         wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
         ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
-        for mode in ("bf16x3", "f32"):
+        for mode in ("f16x2", "bf16x3", "f32"):               # (f16x2: data gradients run the 3-bf16-limb kernel)
             capi.set_conv_arithmetic(mode)
             dx = torch.full((Cin, H, W), -7.0, device=DEV)
             capi.call("nvsr_conv3x3_dgrad", capi.ptr(T(dy)), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), capi.stream())
             np.testing.assert_allclose(N_(dx), ref, rtol=0, atol=3e-5, err_msg="dgrad " + mode)
     finally:
-        capi.set_conv_arithmetic("bf16x3")
+        capi.set_conv_arithmetic("f16x2")
 
 
 def test_planes_sr_batch_is_bit_identical_to_one_by_one(hip):

@@ -55,11 +55,30 @@ def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
             assert all(torch.equal(results[(mode, 2)], results[k]) for k in results if k[0] == mode and k[1] in (2, 3, 4, 8))
             if limb16:
                 assert torch.equal(results[(mode, 16)], results[(mode, 0)]) and not torch.equal(results[(mode, 16)], results[(mode, 4)])
+        # NVSR_ARITH_F16X2 (round 3): the 16x16x32 kernel on 2 f16 limbs for the eligible layers -- every row instantiation, same tolerance, bit-identical
+        # to each other, and at least as close to the (double-accumulating) oracle as the 3-bf16-limb kernel; other layers run the bf16x3 kernels
+        if Cin % 32 == 0 and Cout % 128 == 0:
+            f16 = {}
+            for rows in (0, 16, 18, 19, 20):
+                out = torch.full(ref.shape, -7.0, device=DEV)
+                capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, capi.ptr(skd), capi.ptr(out), ARITH["f16x2"],
+                          rows, capi.stream())
+                np.testing.assert_allclose(N_(out), ref, rtol=0, atol=3e-5, err_msg=str((Cin, Cout, H, W, epi, "f16x2", rows)))
+                f16[rows] = out
+            assert all(torch.equal(f16[0], v) for v in f16.values())
+            e16, e3 = np.abs(N_(f16[0]).astype(np.float64) - ref).max(), np.abs(N_(results[("bf16x3", 16)]).astype(np.float64) - ref).max()
+            print("conv %s: max |out - oracle|  f16x2 %.3g  bf16x3 %.3g  f32 %.3g" % ((Cin, Cout, H, W, epi), e16, e3,
+                                                                                        np.abs(N_(results[("f32", 4)]).astype(np.float64) - ref).max()))
+            assert e16 <= 1.25 * e3 + 1e-7
+        else:
+            out = torch.full(ref.shape, -7.0, device=DEV)
+            capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, capi.ptr(skd), capi.ptr(out), ARITH["f16x2"], 0, capi.stream())
+            assert torch.equal(out, results[("bf16x3", 4)])
     # invalid rows_per_tile / arithmetic are refused, nothing is written
     out = torch.full((256, 13, 43), -7.0, device=DEV)
     x = T(rng.standard_normal((48, 15, 45), dtype=np.float32))
     pk = torch.zeros(capi.lib().nvsr_conv3x3_packed_floats(48, 256), device=DEV)
-    for arith, rows in ((3, 5), (3, 1), (7, 0), (2, 0), (0, 8), (3, 16), (0, 16)):   # (8 / 16 exist in the limb kernel only; 16 needs Cin % 32 == 0: 48 is not)
+    for arith, rows in ((3, 5), (3, 1), (7, 0), (1, 0), (0, 8), (3, 16), (0, 16), (2, 16)):   # (8 / 16 exist in the limb kernel only; 16 needs Cin % 32 == 0: 48 is not)
         st = capi.lib().nvsr_conv3x3_arith(capi.ptr(x), 48, 15, 45, capi.ptr(pk), 256, 0, None, capi.ptr(out), arith, rows, capi.stream())
         assert st == 1 and float(out.min()) == -7.0
     # data gradient (virtual zero border, flipped + transposed kernel): every row-tile variant, both kernels
@@ -116,7 +135,7 @@ def test_full_size_edsr_windows_vs_oracle(hip, oracle):
         up = oracle.upsample_bilinear(lrs[pl], sf)
         refs.append(diff[:, over:-over, over:-over] + up[:, sf * ay: sf * ay + 32, sf * ax: sf * ax + 32])
     scale = max(float(np.abs(r).max()) for r in refs)
-    for mode, tol in (("bf16x3", 1e-4), ("f32", 1e-4)):
+    for mode, tol in (("f16x2", 1e-4), ("bf16x3", 1e-4), ("f32", 1e-4)):
         sr.inner_model.arithmetic = mode
         sr.clear_SR_planes(all_planes=True)
         for n, lr in zip(names, lrs):
@@ -374,8 +393,9 @@ def test_torch_library_ops_exist_and_opcheck(hip):
     assert y.requires_grad
     gy = torch.randn_like(y)
     (y * gy).sum().backward()
-    o_, acts = nv.edsr_train(xg.detach(), net.natural_blob(), net.packed_weights(), net.packed_dgrad_weights(), list(net.geometry), 3)
-    gnat, dx = nv.edsr_backward(xg.detach(), acts, net.packed_dgrad_weights(), list(net.geometry), gy, True, 3)
+    ca = hip.capi.resolve_conv_arithmetic(None)          # the arithmetic net(xg) ran in (the process default)
+    o_, acts = nv.edsr_train(xg.detach(), net.natural_blob(), net.packed_weights(), net.packed_dgrad_weights(), list(net.geometry), ca)
+    gnat, dx = nv.edsr_backward(xg.detach(), acts, net.packed_dgrad_weights(), list(net.geometry), gy, True, ca)
     assert torch.equal(o_, y.detach()) and torch.equal(dx, xg.grad)
     assert torch.equal(gnat, torch.cat([w_.grad.reshape(-1) for w_ in net.conv_weights()]))
     # the operators trace with FakeTensors (what torch.compile / export see): shapes and dtypes without touching the GPU

@@ -32,6 +32,15 @@ if not os.environ.get("KBENCH_ROW_ORDER"):      # the bench renders a frame in p
 N, S = rays.shape[0], 192
 rng = np.random.default_rng(17)
 z = torch.as_tensor(np.sort(rng.uniform(2, 6, (N, S)).astype(np.float32), -1), device=dev)
+if not os.environ.get("STAMP_UNIFORM_Z"):       # the frame's own importance-sampled fine depths (what the bench's fine pass runs on)
+    ws = torch.empty(capi.lib().nvsr_render_workspace_floats(N, 64, 128), device=dev)
+    bufs = [torch.empty((N, 3), device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty((N, 3), device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+    sc0, keep0 = mc.native_scene()
+    capi.call("nvsr_render_rays", C.byref(sc0), capi.ptr(mc.packed_decoder()), capi.ptr(mf.packed_decoder()), N, 64, 128, capi.ptr(rays), 0, 0, None, None, None, None,
+              *[capi.ptr(b) for b in bufs], capi.ptr(ws), capi.stream())
+    torch.cuda.synchronize()
+    z = ws[2 * N * 64: 2 * N * 64 + N * 192].view(N, 192).clone()
+    del ws
 sc, keep = mf.native_scene()
 packed = mf.packed_decoder()
 names = ["top+gather", "ring wait", "rgb0", "rgb1-3", "den0", "den1-3", "epilogue"]
