@@ -182,26 +182,27 @@ struct BiasPend4 { f32x4 v[2]; };
 // would return its non-NaN operand: the overflow would render as a finite, wrong pixel.  So the ReLU is an INTEGER max on the bits (equal to
 // max(x, 0) for every number: negative floats are negative integers; a POSITIVE NaN is a large positive integer and survives), and the FMA in
 // front of it computes (-acc) (-2^-SW) + bias -- the same value, but the source-negation modifier turns the pipe's negative NaN into a
-// positive one.  `nsc` = {-2^-SW, -2^-SW} in a scalar register pair; element pairs go through ONE v_pk_fma_f32.
+// positive one.  `nsc` = {-2^-SW, -2^-SW} in a scalar register pair (opaque to the compiler, which would fold the two negations away).
 template <int LIMBS>
 __device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, const f32x16 (&acc)[4], f32x16 (&act)[4], BiasPend4& pend, f32x2_t nsc) {
     if ((k & 3) == 0 && k < 64) pend.v[(k >> 2) & 1] = *reinterpret_cast<const f32x4*>(bias + (k >> 2) * 8 + h * 4);
     if (k >= 4) {
         const int r = k - 4;
         if constexpr (LIMBS == 2) {
+#if R3_RELU_PK
             if (r & 1) {
                 const int q = r - 1;
                 const f32x2_t a = f32x2_t{acc[q >> 4][q & 15], acc[r >> 4][r & 15]}, b = f32x2_t{pend.v[(q >> 2) & 1][q & 3], pend.v[(r >> 2) & 1][r & 3]};
-                f32x2_t v;          // (written out: the compiler materialises the negation of a pair as two v_xor_b32 and splits the fma)
-#if R3_RELU_PK
+                f32x2_t v;
                 asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(v) : "v"(a), "s"(nsc), "v"(b));
-#else
-                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v[0]) : "v"(a[0]), "s"(nsc[0]), "v"(b[0]));
-                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v[1]) : "v"(a[1]), "s"(nsc[0]), "v"(b[1]));
-#endif
                 act[q >> 4][q & 15] = __int_as_float(max(__float_as_int(v[0]), 0));
                 act[r >> 4][r & 15] = __int_as_float(max(__float_as_int(v[1]), 0));
             }
+#else
+            float v;            // (written out: the compiler would fold the two negations away)
+            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v) : "v"(acc[r >> 4][r & 15]), "s"(nsc[0]), "v"(pend.v[(r >> 2) & 1][r & 3]));
+            act[r >> 4][r & 15] = __int_as_float(max(__float_as_int(v), 0));
+#endif
         } else act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15] + pend.v[(r >> 2) & 1][r & 3], 0.0f);
     }
 }

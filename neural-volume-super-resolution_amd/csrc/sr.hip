@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 // (64 accumulator registers at PB = 4), workgroup = 4 waves = 128 output channels of one PB x 32 pixel tile, two workgroups per CU.
 // Per tap a wave reads 6 weight fragments (one tap ahead) and, per (row, half-row), 3 B fragments for 12 MFMAs.  Same limb products in the same
 // order per (ci block, tap), but the K dimension of an instruction spans 32 channels instead of 16: the f32 accumulation order differs from
-// conv3x3_limb_kernel's, results agree to rounding (both are held to the oracle at 3e-5).
+// conv3x3_limb_kernel's, results agree to rounding (both are held to the CPU checker of the test suite at 3e-5).
 // F16 (the 2-f16-limb arithmetic): the accumulators carry 2^(F16_SW + F16_SX) and the ReLU lets a NaN through (an operand beyond the f16
 // range turns the accumulators into NaNs; fmaxf would return 0)
 template <int PB, bool F16 = false>
