@@ -64,15 +64,24 @@
 
 namespace nvsr {
 
-constexpr int RAY3_FLOATS = 20;      // ro, rd, |rd|, near | view-plane taps | far (+ 3 spare): the per-ray constants of a tile
+// per-ray constants of a tile: ro, rd, |rd|, near | view-plane taps | far.  3 bf16 limbs: 20 floats per ray (far = rc[16], 3 spare);
+// f16 limbs: 16 floats per ray + far in its own array (3 KB less: what the resident weights below need to fit)
+// f16 limbs: the weights of the first 9 K-blocks of a step -- the view plane's and planes 0 and 1's share of rgb layer 0, 72 KB -- stay in LDS
+// for the whole launch.  Those are the blocks that issue the plane gathers: weight copies issued beside the gathers go through the same
+// texture path and cost the step ~9 k of its 94 k cycles (stamps with -DR3_ABLATE=32); resident, the gather blocks issue no copy at all and the
+// step streams 432 instead of 504 KB.  (3 bf16 limbs: 108 KB would not fit beside the 96 KB ring.)
 template <int LIMBS>
 struct Lds3 {
     static constexpr int SLOT = 4 * kb_words(LIMBS);                 // words: 48 KB (3 limbs) / 32 KB
     static constexpr int SMALL = 2 * SLOT;
     static constexpr int RAYS = SMALL + SMALL_FLOATS;
-    static constexpr int TOTAL = RAYS + RAYS2 * RAY3_FLOATS;
+    static constexpr int RAY_FLOATS = LIMBS == 2 ? 16 : 20;
+    static constexpr int FAR = LIMBS == 2 ? RAYS + RAYS2 * RAY_FLOATS : -1;
+    static constexpr int RES = RAYS + RAYS2 * RAY_FLOATS + (LIMBS == 2 ? RAYS2 : 0);
+    static constexpr int RES_KB = LIMBS == 2 ? 9 : 0;
+    static constexpr int TOTAL = RES + RES_KB * kb_words(LIMBS);
 };
-static_assert(Lds3<3>::TOTAL * 4 <= 160 * 1024, "LDS budget");
+static_assert(Lds3<3>::TOTAL * 4 <= 160 * 1024 && Lds3<2>::TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 struct Tile3 {
     f32x16 acc[4];   // layer accumulators (AGPRs), written by MFMAs only
@@ -231,6 +240,17 @@ __device__ __forceinline__ const unsigned* ring3_issue(Ring3<LIMBS>& rs, int kb0
     return dst;
 }
 
+// NKB K-blocks from kb0 on into the resident region `dst` (once per launch; waited for by the first ring wait)
+template <int LIMBS, int NKB>
+__device__ __forceinline__ void ring3_load_resident(const Ring3<LIMBS>& rs, unsigned* dst, int kb0) {
+    constexpr int BLOCKS = NKB * 4 * LIMBS;                 // 1-KiB pieces, NW2 per round
+    static_assert(BLOCKS % NW2 == 0, "region must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < BLOCKS / NW2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * NW2 + rs.wave) * 256), 16,
+                                                 (int)rs.voff, kb0 * kb_words(LIMBS) * 4 + i * (NW2 * 1024), 0, R3_DMA_AUX);
+}
+
 // The same copy issued piece by piece from the gaps of the block that follows the ring wait: a chunk is 36-48 KB, the 4 waves push it
 // through the texture path at its 64 B/clk -- issued as a burst that is ~700 cycles in which the wave issues nothing else (12 chunks of
 // hidden layers per sample: 8 k cycles); one piece every third gap overlaps with the MFMAs.
@@ -303,6 +323,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     const bool validX = rayX < N, validY = rayY < N;
     if (!validX) rayX = N - 1;
     if (!validY) rayY = N - 1;
+    constexpr int RAY3_FLOATS = L::RAY_FLOATS;
     float* rcX = ldsf + L::RAYS + (rs.wave * 64 + (lane0 & 31)) * RAY3_FLOATS;
     float* rcY = rcX + 32 * RAY3_FLOATS;
 #pragma unroll
@@ -315,7 +336,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         if (lane0 < 32) {
             reinterpret_cast<f32x4*>(rc)[0] = f32x4{r[0], r[1], r[2], dx};
             reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, r[6]};
-            rc[16] = r[7];
+            if constexpr (L::FAR >= 0) ldsf[L::FAR + rs.wave * 64 + (lane0 & 31) + 32 * k] = r[7];
+            else rc[16] = r[7];
             reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
             reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
         }
@@ -323,7 +345,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     const float* zX = ZCOMP ? nullptr : z + rayX * S;
     const float* zY = ZCOMP ? nullptr : z + rayY * S;
     auto depth_of = [&](const float* zp, const float* rc, int k) {
-        if constexpr (ZCOMP) return coarse_depth(rc[7], rc[16], k, S, lindisp);
+        if constexpr (ZCOMP) return coarse_depth(rc[7], L::FAR >= 0 ? ldsf[L::FAR + rs.wave * 64 + (rs.lane & 31) + (rc == rcX ? 0 : 32)] : rc[16], k, S, lindisp);
         else return zp[k];
     };
 
@@ -375,7 +397,11 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     float stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-    unsigned* cw = const_cast<unsigned*>(ring3_issue<LIMBS, 3>(rs, KB_RGB0));      // chunk 0 of sample 0; every later one is issued during the previous sample
+    constexpr bool RESIDENT = L::RES_KB > 0;
+    constexpr int KB_FIRST = RESIDENT ? KB_RGB0 + 9 : KB_RGB0;      // the first chunk of a step that goes through the ring
+    unsigned* const res = lds + L::RES;
+    if constexpr (RESIDENT) ring3_load_resident<LIMBS, L::RES_KB>(rs, res, KB_RGB0);
+    unsigned* cw = const_cast<unsigned*>(ring3_issue<LIMBS, 3>(rs, KB_FIRST));     // first ring chunk of sample 0; every later one is issued during the previous sample
     for (int s = 0; s < S; ++s) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
 #if R3_NO_VIEW_HOIST
@@ -413,8 +439,11 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // multiplies plane p - 1 of a tile loads plane p of the same tile, the next block blends it.
         GatherJob ja, jb;
         R3_MARK(0)      // loop top
-        ring3_sync<ZCOMP ? 0 : 2>();                             // chunk 0 (issued during the previous sample) -- younger: the two z loads above
-        unsigned* nw = ring3_take(rs);
+        ring3_sync<ZCOMP ? 0 : 2>();                             // the step's first ring chunk (issued during the previous sample) -- younger: the two z loads above
+        // RESIDENT (f16 limbs): view plane, planes 0 and 1 multiply out of the resident region; the ring chunk that has just landed is plane 2's,
+        // and the blocks that issue gathers (B0 .. B5) issue no weight copy and need no ring wait
+        unsigned* nw = RESIDENT ? nullptr : ring3_take(rs);
+        const unsigned* const w_view = RESIDENT ? res : cw;
         R3_MARK(1)      // first ring wait
         R3_RESET
 #define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); }
@@ -423,50 +452,63 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // X view | loads X plane 0
         ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.V);
-        limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL_DMA(X, ja, Y, jb, true, false, 3, KB_RGB0 + 3), NoTail{});
+        if constexpr (RESIDENT) limb_block<LIMBS, 3, true, true>(w_view, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL(X, ja, Y, jb, true, false), NoTail{});
+        else limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.V), NVSR_ROLL_DMA(X, ja, Y, jb, true, false, 3, KB_RGB0 + 3), NoTail{});
         R3_MARKB(0)
         // Y view | blends X plane 0, loads Y plane 0
         jb.plane = sc.plane[0]; jb.t = pos_taps2(sc, 0, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.V);
-        limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.V), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        limb_block<LIMBS, 3, true, false>(w_view, lane, Y.acc, cur, fa, feat(Y.V), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(1)
-        cw = nw;
-        ring3_sync<YOUNGER_THAN_CHUNK>();
-        nw = ring3_take(rs);
+        const unsigned* w_p0 = res + 3 * kb_words(LIMBS);
+        if constexpr (!RESIDENT) {
+            cw = nw;
+            ring3_sync<YOUNGER_THAN_CHUNK>();
+            nw = ring3_take(rs);
+            w_p0 = cw;
+        }
         // X plane 0 | blends Y plane 0, loads X plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = X.F[c];
         ja.plane = sc.plane[1]; ja.t = pos_taps2(sc, 1, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 6), NoTail{});
+        if constexpr (RESIDENT) limb_block<LIMBS, 3, false, true>(w_p0, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        else limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 6), NoTail{});
         R3_MARKB(2)
         // Y plane 0 | blends X plane 1, loads Y plane 1
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = Y.F[c];
         jb.plane = sc.plane[1]; jb.t = pos_taps2(sc, 1, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.F);
-        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        limb_block<LIMBS, 3, false, false>(w_p0, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(3)
-        cw = nw;
-        ring3_sync<YOUNGER_THAN_CHUNK>();
-        nw = ring3_take(rs);
+        const unsigned* w_p1 = res + 6 * kb_words(LIMBS);
+        if constexpr (!RESIDENT) {
+            cw = nw;
+            ring3_sync<YOUNGER_THAN_CHUNK>();
+            nw = ring3_take(rs);
+            w_p1 = cw;
+        }
         // X plane 1 | blends Y plane 1, loads X plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = __fadd_rn(X.D[c], X.F[c]);
         ja.plane = sc.plane[2]; ja.t = pos_taps2(sc, 2, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.F);
-        limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 9), NoTail{});
+        if constexpr (RESIDENT) limb_block<LIMBS, 3, false, true>(w_p1, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL(X, ja, Y, jb, true, true), NoTail{});
+        else limb_block<LIMBS, 3, false, true>(cw, lane, X.acc, cur, fa, feat(X.F), NVSR_ROLL_DMA(X, ja, Y, jb, true, true, 3, KB_RGB0 + 9), NoTail{});
         R3_MARKB(4)
         // Y plane 1 | blends X plane 2, loads Y plane 2
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = __fadd_rn(Y.D[c], Y.F[c]);
         jb.plane = sc.plane[2]; jb.t = pos_taps2(sc, 2, yn0, yn1, yn2); scale_taps(jb.t);
         split_feat(Y.F);
-        limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
+        limb_block<LIMBS, 3, false, false>(w_p1, lane, Y.acc, cur, fa, feat(Y.F), NVSR_ROLL(Y, jb, X, ja, true, true), NoTail{});
         R3_MARKB(5)
-        cw = nw;
-        ring3_sync<YOUNGER_THAN_CHUNK>();
-        nw = ring3_take(rs);
+        if constexpr (!RESIDENT) {
+            cw = nw;
+            ring3_sync<YOUNGER_THAN_CHUNK>();
+        }
+        nw = ring3_take(rs);                                     // (RESIDENT: cw is plane 2's chunk since the top of the step)
         // X plane 2 | blends Y plane 2;  D = (D + F) / 3   (combine_pos_planes 'avg', models.py:358-359)
 #pragma unroll
         for (int c = 0; c < HALF_C; ++c) X.D[c] = div3(__fadd_rn(X.D[c], X.F[c]));
@@ -557,7 +599,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         // density layer 3: the chunk issued last is chunk 0 of the NEXT sample (after the last sample: a harmless copy);
         // Y b | X: act, then the sigma head
         float sx[1] = {0.0f};
-        NVSR_HIDDEN_LAYER(2, 3, KB_DEN1 + 20, 4, KB_RGB0, 3,
+        NVSR_HIDDEN_LAYER(2, 3, KB_DEN1 + 20, 4, KB_FIRST, 3,
                           (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4),
                                                               [&](int slot) {
                                                                   spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc); });
