@@ -58,8 +58,8 @@ typedef struct nvsr_scene {
 int nvsr_version(void);
 
 /* Arithmetic of the decoder GEMMs: the fused render pass (nvsr_render_pass*, N >= 16384 rays) and the training kernels
- * (nvsr_decode_rays*, nvsr_render_pass_backward_gates, nvsr_decoder_weight_grad -- these use 3 limbs whenever a limb mode is selected:
- * what feeds a gradient stays close to f32; a forward and the backward that consumes its gates / record must run in the same mode).
+ * (nvsr_decode_rays*, nvsr_render_pass_backward_gates, nvsr_decoder_weight_grad -- what computes a gradient uses 3 limbs whenever a limb
+ * mode is selected; a forward and the backward that consumes its gates / record must both run limb modes or both run f32).
  * Inputs, outputs, accumulation and everything outside the GEMMs are f32 in every mode.
  *   NVSR_ARITH_F32    v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation -- the reference's arithmetic
  *   NVSR_ARITH_BF16X3 every f32 operand split exactly into 3 bf16 limbs (8 + 8 + 8 significant bits, by truncation), the products
@@ -89,7 +89,11 @@ int nvsr_version(void);
  *                     2^-6 <= |x| < 4094; below that the low limb is subnormal (honoured by the matrix pipe) and the error is absolute,
  *                     <= 2^-33 per weight and <= 2^-29 per activation; a weight >= 255 or an activation >= 4094 overflows to inf and
  *                     the pixel comes out NaN -- loud, never a wrong number (use BF16X3 or F32 for such a network).
- *                     The fused render pass only (inference); the training kernels run BF16X3 when F16X2 is selected.
+ *                     The fused render pass (inference) and the training FORWARD of a pass whose decoder is not being trained
+ *                     (nvsr_decode_rays* without a weight-gradient record); everything that computes a gradient -- the backward, the
+ *                     forward that writes the record, the weight gradients -- runs BF16X3 when F16X2 is selected: gradients span too
+ *                     many decades for 5 exponent bits.  The gates a forward publishes are signs of pre-activations and are consumed
+ *                     by the 3-limb backward whichever forward arithmetic found them.
  * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
  * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | f16x2
  * and which nvsr_set_decoder_arithmetic changes.  Nothing but that default is process-global: calls with explicit modes are re-entrant

@@ -21,10 +21,15 @@
 namespace nvsr {
 
 constexpr int L3_TPB = 256, L3_WAVES = L3_TPB / 64, L3_PTS = L3_WAVES * 32;
-constexpr int L3_SLOT = 3 * kb_words(3);                      // words: 36 KB
-constexpr int L3_SMALL = 2 * L3_SLOT;
-constexpr int L3_LDS = L3_SMALL + SMALL_FLOATS;
-static_assert(2 * L3_LDS * 4 <= 160 * 1024, "two workgroups per CU");
+// LF = limbs of the forward: 3 bf16 limbs, or 2 f16 limbs (limb_core.h: round to nearest, static scales; round 3) when no weight-gradient
+// record is wanted -- the gates a forward publishes are signs of pre-activations and feed the 3-limb backward whatever arithmetic found them
+template <int LF>
+struct L3 {
+    static constexpr int SLOT = 3 * kb_words(LF);             // words: 36 KB (3 limbs) / 24 KB
+    static constexpr int SMALL = 2 * SLOT;
+    static constexpr int LDS = SMALL + SMALL_FLOATS;
+};
+static_assert(2 * L3<3>::LDS * 4 <= 160 * 1024, "two workgroups per CU");
 
 struct RingL {
     __amdgpu_buffer_rsrc_t rsrc;   // 3-limb fragment region of the packed blob
@@ -35,15 +40,15 @@ struct RingL {
 };
 
 // chunk = K-blocks kb0 .. kb0 + NKB - 1 -> the free slot, in 1-KiB pieces round-robin over the waves
-template <int NKB>
+template <int NKB, int LF = 3>
 __device__ __forceinline__ const unsigned* ringl_issue(RingL& rs, int kb0) {
-    unsigned* dst = rs.lds + rs.slot * L3_SLOT;
-    constexpr int PIECES = NKB * 4 * 3;
+    unsigned* dst = rs.lds + rs.slot * L3<LF>::SLOT;
+    constexpr int PIECES = NKB * 4 * LF;
     static_assert(PIECES % L3_WAVES == 0, "chunk must split evenly over the waves");
 #pragma unroll
     for (int i = 0; i < PIECES / L3_WAVES; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * L3_WAVES + rs.wave) * 256), 16,
-                                                 (int)rs.voff, kb0 * kb_words(3) * 4 + i * (L3_WAVES * 1024), 0, 0);
+                                                 (int)rs.voff, kb0 * kb_words(LF) * 4 + i * (L3_WAVES * 1024), 0, 0);
     rs.slot ^= 1;
     return dst;
 }
@@ -55,12 +60,20 @@ __device__ __forceinline__ void ringl_sync() {
 }
 
 // act = max(acc + bias, 0)   (bias packed in accumulator-register order: [group of 4 registers][lane half][4])
-__device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* bias, int h, f32x16 (&act)[4]) {
+// LF = 2: act 2^SX = relu(acc 2^-SW + bias 2^SX) with the NaN-propagating ReLU of render3.hip (negated-source FMA + integer max)
+template <int LF>
+__device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* bias, int h, f32x16 (&act)[4], float nsc) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + g * 8 + h * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) act[g >> 2][4 * (g & 3) + j] = fmaxf(acc[g >> 2][4 * (g & 3) + j] + b[j], 0.0f);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (LF == 2) {
+                float v;
+                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v) : "v"(acc[g >> 2][4 * (g & 3) + j]), "s"(nsc), "v"(b[j]));
+                act[g >> 2][4 * (g & 3) + j] = __int_as_float(max(__float_as_int(v), 0));
+            } else act[g >> 2][4 * (g & 3) + j] = fmaxf(acc[g >> 2][4 * (g & 3) + j] + b[j], 0.0f);
+        }
     }
 }
 // the layer's ReLU gate in relu_publish's format: bit (ib & 1) * 16 + r of word ib >> 1  <=>  pre-activation > 0
@@ -88,9 +101,15 @@ __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* 
     *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};
 }
 
-template <bool MASKS, bool RECORD>
-__device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, const float* small, float px, float py, float pz, const Taps& vt,
-                                                 float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok) {
+template <bool MASKS, bool RECORD, int LF>
+__device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, const float* small, float px, float py, float pz, const Taps& vt_,
+                                                 float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok, float nsc) {
+    static_assert(LF == 3 || !RECORD, "the weight-gradient record holds unscaled f32 layer inputs: 3-limb forward only");
+    auto scaled = [](Taps t) {          // f16 limbs: features carry 2^F16_SX, put on the four blend weights (exact)
+        if constexpr (LF == 2) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; }
+        return t;
+    };
+    const Taps vt = scaled(vt_);
     asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));       // (see decode_step: keeps hipcc from hoisting per-lane addresses out of the tile loop)
     const int lane = rs.lane, h = lane >> 5;
     const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
@@ -98,17 +117,17 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     const float n2 = norm_coord(pz, sc.lo[2], sc.range[2]);
     f32x16 acc[4], act[4];
     float D[HALF_C], F[HALF_C];
-    Limbs<3> cur, fa;
+    Limbs<LF> cur, fa;
     auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
     auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
     auto none = [](int) {};
     SplitPend tp;
     auto tail_of = [&tp](const f32x16 (&a)[4], int kb) {
-        return [&a, kb, &tp](int slice, Limbs<3>& nxt) { split_slice<3>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+        return [&a, kb, &tp](int slice, Limbs<LF>& nxt) { split_slice<LF>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
     };
     auto pos_taps = [&](int d) {
         const float* M = sc.proj + 6 * d;
-        return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        return scaled(make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]));
     };
     // Nothing moves across the end of a block: left alone hipcc hoists the next plane's 24 gather loads (96 registers) above the block's
     // MFMAs -- good for latency, but with the accumulators, D, F and the limbs live it spills 120 registers; the other workgroup's wave on
@@ -128,22 +147,23 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     {                                                                                          \
         ringl_sync();                                                                          \
         const unsigned* nw = NEXT;                                                             \
-        if (FIRST) { auto s_ = SRC; split_all<3>([&](int i) { return s_(0, i); }, cur); }      \
-        limb_block<3, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, TAIL);               \
+        if (FIRST) { auto s_ = SRC; split_all<LF>([&](int i) { return s_(0, i); }, cur); }      \
+        limb_block<LF, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, TAIL);               \
         cw = nw;                                                                               \
         L3_FENCE                                                                               \
     }
+#define L3_ISSUE(NKB_, KB_) (ringl_issue<NKB_, LF>(rs, KB_))
 #define L3_BLOCK(NKB, ZERO, SRC, NEXT) L3_BLOCK_(NKB, ZERO, true, SRC, NEXT, NoTail{})
     // a hidden layer = 3 + 3 + 2 K-blocks of the previous activation; NEXT = the chunk that follows the layer
 #ifdef NVSR_NO_TAILS      // A/B switch (tools/): every block splits its first K-block itself
 #define L3_HIDDEN(KB0, NEXT)                                                                   \
-    L3_BLOCK(3, true, hid(act, 0), ringl_issue<3>(rs, (KB0) + 3))                              \
-    L3_BLOCK(3, false, hid(act, 3), ringl_issue<2>(rs, (KB0) + 6))                             \
+    L3_BLOCK(3, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3))                              \
+    L3_BLOCK(3, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6))                             \
     L3_BLOCK(2, false, hid(act, 6), NEXT)
 #else
 #define L3_HIDDEN(KB0, NEXT)                                                                   \
-    L3_BLOCK_(3, true, true, hid(act, 0), ringl_issue<3>(rs, (KB0) + 3), tail_of(act, 3))      \
-    L3_BLOCK_(3, false, false, hid(act, 3), ringl_issue<2>(rs, (KB0) + 6), tail_of(act, 6))    \
+    L3_BLOCK_(3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), tail_of(act, 3))      \
+    L3_BLOCK_(3, false, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6), tail_of(act, 6))    \
     L3_BLOCK_(2, false, false, hid(act, 6), NEXT, NoTail{})
 #endif
     auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
@@ -151,7 +171,7 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) act[ib] = acc[ib];
         } else {
-            bias_relu(acc, small + S_BIAS + vec * HID, h, act);
+            bias_relu<LF>(acc, small + S_BIAS + vec * HID, h, act, nsc);
         }
         if (MASKS && !(L3_ABLATE & 2)) publish_gates(act, gates, vec);
         if (RECORD && rec_ok) record128(hrow, q, h, act);
@@ -159,20 +179,20 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     const long LP = (long)HID * rec.Pp;
 
     // ---- rgb layer 0: K = 192 in the limb blob's order [f_view | f0 | f1 | f2], one plane = one chunk ---------------------------------
-    const unsigned* cw = ringl_issue<3>(rs, KB_RGB0);
+    const unsigned* cw = L3_ISSUE(3, KB_RGB0);
     L3_GATHER(sc.plane[3], vt, h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
-    L3_BLOCK(3, true, feat(F), ringl_issue<3>(rs, KB_RGB0 + 3))
+    L3_BLOCK(3, true, feat(F), L3_ISSUE(3, KB_RGB0 + 3))
     L3_GATHER(sc.plane[0], pos_taps(0), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C), h, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
-    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 6))
+    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 6))
     L3_GATHER(sc.plane[1], pos_taps(1), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + C, h, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
-    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB0 + 9))
+    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 9))
     L3_GATHER(sc.plane[2], pos_taps(2), h, F);
     if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
@@ -183,14 +203,14 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    L3_BLOCK(3, false, feat(F), ringl_issue<3>(rs, KB_RGB1))
+    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB1))
     finish(4, rec.Hr);
     // ---- rgb layers 1..3, rgb head ---------------------------------------------------------------------------------------------------
-    L3_HIDDEN(KB_RGB1, ringl_issue<3>(rs, KB_RGB1 + 8))
+    L3_HIDDEN(KB_RGB1, L3_ISSUE(3, KB_RGB1 + 8))
     finish(5, rec.Hr + LP);
-    L3_HIDDEN(KB_RGB1 + 8, ringl_issue<3>(rs, KB_RGB1 + 16))
+    L3_HIDDEN(KB_RGB1 + 8, L3_ISSUE(3, KB_RGB1 + 16))
     finish(6, rec.Hr + 2 * LP);
-    L3_HIDDEN(KB_RGB1 + 16, ringl_issue<3>(rs, KB_DEN0))
+    L3_HIDDEN(KB_RGB1 + 16, L3_ISSUE(3, KB_DEN0))
     finish(7, rec.Hr + 3 * LP);
     {
         float hd[3];
@@ -199,11 +219,11 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         for (int c = 0; c < 3; ++c) raw[c] = hd[c] + small[S_HEAD_B + 1 + c];
     }
     // ---- density decoder: 48 -> 128 x 4 -> 1 -----------------------------------------------------------------------------------------
-    L3_BLOCK(3, true, feat(D), ringl_issue<3>(rs, KB_DEN1))
+    L3_BLOCK(3, true, feat(D), L3_ISSUE(3, KB_DEN1))
     finish(0, rec.Hd);
-    L3_HIDDEN(KB_DEN1, ringl_issue<3>(rs, KB_DEN1 + 8))
+    L3_HIDDEN(KB_DEN1, L3_ISSUE(3, KB_DEN1 + 8))
     finish(1, rec.Hd + LP);
-    L3_HIDDEN(KB_DEN1 + 8, ringl_issue<3>(rs, KB_DEN1 + 16))
+    L3_HIDDEN(KB_DEN1 + 8, L3_ISSUE(3, KB_DEN1 + 16))
     finish(2, rec.Hd + 2 * LP);
     L3_HIDDEN(KB_DEN1 + 16, (const unsigned*)nullptr)
     finish(3, rec.Hd + 3 * LP);
@@ -213,22 +233,30 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         raw[3] = hd[0] + small[S_HEAD_B];
     }
 #undef L3_GATHER
+#undef L3_ISSUE
 #undef L3_HIDDEN
 #undef L3_BLOCK
 #undef L3_BLOCK_
 #undef L3_FENCE
 }
 
-template <bool MASKS, bool RECORD>
+template <bool MASKS, bool RECORD, int LF = 3>
 __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                                     const float* __restrict__ rays, const float* __restrict__ z,
                                                                     float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
-    __shared__ __attribute__((aligned(16))) unsigned lds[L3_LDS];
+    constexpr int L3_SMALL = L3<LF>::SMALL;
+    __shared__ __attribute__((aligned(16))) unsigned lds[L3<LF>::LDS];
     // (wave index as a SCALAR: the LDS destination of every weight-copy piece then is scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
-    RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(3)), 0, KB_TOTAL * kb_words(3) * 4, 0x00020000), lds, 0,
+    RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LF)), 0, KB_TOTAL * kb_words(LF) * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
-    for (int i = threadIdx.x; i < SMALL_FLOATS; i += L3_TPB) ldsf[L3_SMALL + i] = packed[P_SMALL + i];   // published by the first ring barrier
+    for (int i = threadIdx.x; i < SMALL_FLOATS; i += L3_TPB) {   // published by the first ring barrier.  f16 limbs: biases x 2^SX, head weights x 2^-SX, the packer's poison (render3.hip)
+        float v = packed[P_SMALL + i] * (LF != 2 ? 1.0f : i < S_ALPHA_W ? F16_X_SCALE : i < S_HEAD_B ? F16_HEAD_SCALE : 1.0f);
+        if (LF == 2 && i >= S_HEAD_B && i < S_HEAD_B + 4) v += packed[P_SMALL + S_F16_POISON];
+        ldsf[L3_SMALL + i] = v;
+    }
+    float nscale = -F16_ACC_UNSCALE;                 // bias_relu<2>: opaque, or the compiler folds the two negations away
+    asm volatile("" : "+s"(nscale));
     const float* small = ldsf + L3_SMALL;
     // start-up stagger of the two workgroups of a CU (decode_prologue): the one in an odd wave slot starts half a phase late
     unsigned hw_id;
@@ -252,8 +280,8 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
         float raw[4];
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
-        decode_step_limb<MASKS, RECORD>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
-                                        __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, record_row(ray, s, N, S), valid);
+        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
+                                            __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, record_row(ray, s, N, S), valid, nscale);
         if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 }
@@ -263,10 +291,19 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
 using namespace nvsr;
 
 // nvsr_decode_rays_ex (render.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
-extern "C" int nvsr_decode_rays_limb_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                             const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
     const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + L3_WAVES - 1) / L3_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (limbs == 2 && !record) {        // f16 limbs: no weight-gradient record (it holds unscaled f32 layer inputs)
+        if (gates)
+            hipLaunchKernelGGL((decode_rays_limb_kernel<true, false, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                               (long)N, S, rays, z, raw, gates, DecRecord{});
+        else
+            hipLaunchKernelGGL((decode_rays_limb_kernel<false, false, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                               packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{});
+        return NVSR_CHECK_LAUNCH();
+    }
     if (record)
         hipLaunchKernelGGL((decode_rays_limb_kernel<true, true>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
                            (long)N, S, rays, z, raw, gates, make_record(record, (long)N, S));

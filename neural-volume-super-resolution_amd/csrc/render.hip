@@ -228,7 +228,7 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
                                         const float* z, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
                                         float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
 extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packed, nvsr_stream_t stream);
-extern "C" int nvsr_decode_rays_limb_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
+extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                             const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream);
 
 // arithmetic of the fused render pass (process-wide): -1 = not yet read from the environment
@@ -312,9 +312,10 @@ int nvsr_decode_rays_arith(const nvsr_scene* scene, const float* packed_decoder,
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
-    // bf16-limb matrix pipe (decode_limb.hip), always with 3 limbs: the gates and the record feed gradients
+    // limb matrix pipe (decode_limb.hip): 3 bf16 limbs, or -- NVSR_ARITH_F16X2 without a weight-gradient record -- 2 f16 limbs (the gates are
+    // signs of pre-activations: the 3-limb backward consumes them whichever forward arithmetic found them)
     if (arith != NVSR_ARITH_F32)
-        return nvsr_decode_rays_limb_launch(scene, packed_decoder, N, S, rays, z, raw, gates, record, stream);
+        return nvsr_decode_rays_limb_launch(arith == NVSR_ARITH_F16X2 ? 2 : 3, scene, packed_decoder, N, S, rays, z, raw, gates, record, stream);
     const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     if (record)

@@ -247,13 +247,13 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
-        # a limb mode trains with 3 limbs (what feeds a gradient stays close to f32): the 2-limb mode is a rendering-only option
-        t3 = lambda a: capi.ARITHMETIC["bf16x3"] if a == capi.ARITHMETIC["f16x2"] else a
+        # 'f16x2': the library runs the FORWARD of a pass whose decoder is not trained (no weight-gradient record) on 2 f16 limbs and everything
+        # that computes a gradient on 3 bf16 limbs (include/nvsr.h); the gates a forward publishes are signs, valid for either backward
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=lindisp, white=white, t_rand=t_rand, u=u, noise_c=n_c, noise_f=n_f,
                    planes_c=planes_c, planes_f=planes_f, consts=consts, packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
                    plane_shapes=[tuple(k.shape) for k in planes_f], plane_leaves=leaves[:4], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
-                   dec_f_grad=dec_f_grad, arith_c=t3(arith_c), arith_f=t3(arith_f))
+                   dec_f_grad=dec_f_grad, arith_c=arith_c, arith_f=arith_f)
         outs = _RenderRaysFn.apply(cfg, *leaves)
         if Nf > 0:
             return outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], None, None, None
