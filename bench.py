@@ -454,7 +454,10 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, %s, Adam)" % label, "value": value,
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-              "dtype": ARITHMETIC["bf16x3" if capi.get_decoder_arithmetic() != "f32" else "f32"]["dtype"], "data": "synthetic",
+              "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
+                        "f16x2": "f32 (forward of a pass whose decoder is not trained: GEMM operands split into 2 round-to-nearest f16 limbs, 3 products; every "
+                                 "backward / weight-gradient kernel and the recording forward: 3 exact bf16 limbs, 6 products; f32 accumulation)"}[capi.get_decoder_arithmetic()],
+              "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
                          "plane_memory_format": "NCHW" if args.nchw_planes else "channels_last (same [1,48,R,R] parameters, native [H][W][C] memory)",
