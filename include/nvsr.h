@@ -271,6 +271,11 @@ int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t
 /* backward of volume_render_radiance_field (volume_rendering_utils.py:18-49): g_rgb [N,3], g_acc [N] or NULL -> g_raw [N,S,4]; S <= 512 */
 int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                             const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);
+/* the same with the gradient of depth_map (volume_rendering_utils.py:42-43: depth_map = sum_s w_s z_s; mip_nerf: z [N,S+1], z_s = interval
+ * midpoints) as a third incoming gradient, g_depth [N] or NULL.  disp_map = 1 / max(1e-10, depth_map / acc_map) (:46) is a function of
+ * depth_map and acc_map: its gradient is folded into g_depth / g_acc by the caller (ops.py `composite` does). */
+int nvsr_composite_backward_depth(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                                  const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream);
 /* the same for nvsr_composite_mip (z [N,S+1]) */
 int nvsr_composite_backward_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                                 const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);

@@ -92,6 +92,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_pack_decoder_bwd": ([_vp, _vp, _vp], _i),
     "nvsr_composite_backward": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_backward_mip": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
+    "nvsr_composite_backward_depth": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "nvsr_render_pass_backward": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp], _i),
     "nvsr_decode_rays_ex": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass_backward_gates": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp], _i),

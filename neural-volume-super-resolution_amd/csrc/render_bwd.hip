@@ -463,13 +463,14 @@ __global__ __launch_bounds__(256) void view_reduce_scatter_kernel(SceneDev sc, l
 }
 
 // =====================================================================================================================
-// volume_render_radiance_field backward: (g_rgb [N,3], g_acc [N] or NULL) -> g_raw [N,S,4]; one wave per ray, S <= 512
+// volume_render_radiance_field backward: (g_rgb [N,3], g_acc [N] or NULL, g_dep [N] or NULL) -> g_raw [N,S,4]; one wave per ray, S <= 512
+// (g_dep = gradient of depth_map = sum_s w_s z_s, volume_rendering_utils.py:42-43; disp_map's gradient reaches this kernel through g_dep / g_acc)
 // =====================================================================================================================
 constexpr int CB_WPB = 4;
 __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
                                                                         const float* __restrict__ rd, const float* __restrict__ noise, int white,
                                                                         const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
-                                                                        float* __restrict__ g_raw, int mip) {
+                                                                        const float* __restrict__ g_dep, float* __restrict__ g_raw, int mip) {
     __shared__ float sT[CB_WPB][512], sA[CB_WPB][512], sG[CB_WPB][512];   // T_s, alpha_s, dL/dw_s
     const int zp = S + (mip ? 1 : 0);                                      // mip: z holds S + 1 interval edges, no 1e10 tail
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
     const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     const float g0 = g_rgb[ray * 3], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
     const float ga = (g_acc ? g_acc[ray] : 0.0f) - (white ? (g0 + g1 + g2) : 0.0f);
+    const float gd = g_dep ? g_dep[ray] : 0.0f;
     const f32x4* rr = reinterpret_cast<const f32x4*>(raw) + ray * S;
     f32x4* gout = reinterpret_cast<f32x4*>(g_raw) + ray * S;
     // forward sweep: T_s (exclusive running product), alpha_s, dL/dw_s
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
             alpha = 1.0f - expf(-sig * dist);
             fac = (1.0f - alpha) + 1e-10f;
             gw = g0 / (1.0f + expf(-rv[0])) + g1 / (1.0f + expf(-rv[1])) + g2 / (1.0f + expf(-rv[2])) + ga;
+            if (g_dep) gw += gd * (mip ? 0.5f * (z[ray * zp + s] + z[ray * zp + s + 1]) : z[ray * zp + s]);      // d depth_map / d w_s = the sample's depth
         }
         float incl = fac;
 #pragma unroll
@@ -559,26 +562,25 @@ int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t
     return nvsr_pack_decoder_bwd_limbs_launch(natural, packed_bwd, stream);      // the bf16-limb fragments behind the f32 ones
 }
 
-int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
-                            const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream) {
+int nvsr_composite_backward_depth(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                                  const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream) {
     if (!raw || !z || !rd || !g_rgb || !g_raw) return NVSR_ERR_NULL;
     if (!aligned16(raw) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
-                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw, 0);
+                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_depth, g_raw, mip_nerf ? 1 : 0);
     return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                            const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream) {
+    return nvsr_composite_backward_depth(N, S, raw, z, rd, noise, white_bkgd, g_rgb, g_acc, nullptr, 0, g_raw, stream);
 }
 
 int nvsr_composite_backward_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                                 const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream) {
-    if (!raw || !z || !rd || !g_rgb || !g_raw) return NVSR_ERR_NULL;
-    if (!aligned16(raw) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
-    if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
-    if (N == 0) return NVSR_OK;
-    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
-                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_raw, 1);
-    return NVSR_CHECK_LAUNCH();
+    return nvsr_composite_backward_depth(N, S, raw, z, rd, noise, white_bkgd, g_rgb, g_acc, nullptr, 1, g_raw, stream);
 }
 
 int64_t nvsr_decoder_record_floats(int64_t N, int S) {

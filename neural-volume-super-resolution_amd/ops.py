@@ -487,39 +487,54 @@ def _(raw, z, rays, noise, white, want_weights):
 
 @custom_op("nvsr::composite_backward", mutates_args=(), device_types="cuda")
 def composite_backward(raw: Tensor, z: Tensor, rd: Tensor, noise: Optional[Tensor], white: bool, mip: bool, g_rgb: Tensor,
-                       g_acc: Optional[Tensor]) -> Tensor:
-    """gradient of rgb_map / acc_map with respect to the radiance field: -> g_raw [N,S,4]; S <= 512"""
-    raw, z, rd, noise, g_rgb, g_acc = _c(raw), _c(z), _c(rd), _c(noise), _c(g_rgb), _c(g_acc)
+                       g_acc: Optional[Tensor], g_depth: Optional[Tensor] = None) -> Tensor:
+    """gradient of rgb_map / acc_map / depth_map with respect to the radiance field: -> g_raw [N,S,4]; S <= 512"""
+    raw, z, rd, noise, g_rgb, g_acc, g_depth = _c(raw), _c(z), _c(rd), _c(noise), _c(g_rgb), _c(g_acc), _c(g_depth)
     N = z.shape[0]
     S = z.shape[1] - (1 if mip else 0)
     g_raw = torch.zeros_like(raw)
     if N:
         if S > 512:
             raise NotImplementedError("nvsr_composite_backward handles up to 512 samples per ray")
-        capi.call("nvsr_composite_backward_mip" if mip else "nvsr_composite_backward", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd),
-                  capi.ptr(noise), int(white), capi.ptr(g_rgb), capi.ptr(g_acc), capi.ptr(g_raw), capi.stream())
+        capi.call("nvsr_composite_backward_depth", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rd), capi.ptr(noise), int(white), capi.ptr(g_rgb),
+                  capi.ptr(g_acc), capi.ptr(g_depth), int(mip), capi.ptr(g_raw), capi.stream())
     return g_raw
 
 
 @composite_backward.register_fake
-def _(raw, z, rd, noise, white, mip, g_rgb, g_acc):
+def _(raw, z, rd, noise, white, mip, g_rgb, g_acc, g_depth=None):
     return torch.empty_like(raw)
+
+
+def fold_disp_grad(g_disp, q, acc, depth, g_acc, g_depth):
+    """disp_map = 1 / max(1e-10, q), q = depth_map / acc_map (volume_rendering_utils.py:46): the incoming gradient of disp_map as additions to
+    those of depth_map and acc_map (per-ray scalars; torch.max passes the gradient to the larger operand, q = NaN (acc = 0) passes none)
+    -> (g_acc, g_depth)"""
+    live = q > 1e-10
+    dq = torch.where(live, -capi.f32c(g_disp) / (q * q), torch.zeros_like(q))
+    gd = torch.where(live, dq / acc, torch.zeros_like(q))
+    ga = torch.where(live, -dq * depth / (acc * acc), torch.zeros_like(q))
+    return (ga if g_acc is None else g_acc + ga), (gd if g_depth is None else g_depth + gd)
 
 
 def _composite_setup(ctx, inputs, output):
     raw, z, rd, noise, white, mip = inputs
-    ctx.save_for_backward(raw, z, rd, noise)
+    ctx.save_for_backward(raw, z, rd, noise, output[2], output[4])      # + acc_map, depth_map: disp_map's chain rule
     ctx.white, ctx.mip = white, mip
-    ctx.mark_non_differentiable(output[1], output[3], output[4])
+    ctx.mark_non_differentiable(output[3])
 
 
 def _composite_bwd(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
-    # rgb_map and acc_map are differentiable; disp, weights and depth carry no gradient path (the reference's losses use rgb only,
-    # train_nerf.py:884-891)
-    raw, z, rd, noise = ctx.saved_tensors
+    # rgb_map, acc_map, depth_map and disp_map = 1 / max(1e-10, depth_map / acc_map) are differentiable like the reference's
+    # (volume_rendering_utils.py:38-46); the per-sample weights output is not (nothing downstream of the reference's renderer uses it).
+    # disp's gradient is folded into those of depth and acc here -- per-ray scalars, plumbing; the kernel sums over the samples.
+    raw, z, rd, noise, acc, depth = ctx.saved_tensors
     g_rgb = torch.zeros((z.shape[0], 3), dtype=torch.float32, device=raw.device) if g_rgb is None else capi.f32c(g_rgb)
     g_acc = None if g_acc is None else capi.f32c(g_acc)
-    return torch.ops.nvsr.composite_backward(raw, z, rd, noise, ctx.white, ctx.mip, g_rgb, g_acc), None, None, None, None, None
+    g_depth = None if g_depth is None else capi.f32c(g_depth)
+    if g_disp is not None:
+        g_acc, g_depth = fold_disp_grad(g_disp, depth / acc, acc, depth, g_acc, g_depth)
+    return torch.ops.nvsr.composite_backward(raw, z, rd, noise, ctx.white, ctx.mip, g_rgb, g_acc, g_depth), None, None, None, None, None
 
 
 composite.register_autograd(_composite_bwd, setup_context=_composite_setup)

@@ -102,7 +102,10 @@ class _RenderRaysFn(torch.autograd.Function):
             outs += [rgb_f, disp_f, acc_f]
             saved.update(z_f=z_f, raw_f=raw_f, gates_f=none_if_empty(gates_f), rec_f=none_if_empty(rec_f))
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
-        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 == 1])    # disparity: no gradient path implemented
+        # disp_map is differentiable like the reference's (volume_rendering_utils.py:46): its gradient is folded into those of depth / acc
+        saved.update(disp_c=disp_c, acc_c=acc_c)
+        if Nf > 0:
+            saved.update(disp_f=disp_f, acc_f=acc_f)
         return tuple(outs)
 
     @staticmethod
@@ -121,13 +124,17 @@ class _RenderRaysFn(torch.autograd.Function):
                 if need_planes[d]:
                     gplanes[d] = g if gplanes[d] is None else gplanes[d].add_(g)
 
-        def one_pass(S, z, raw, noise, planes, packed, packed_bwd, g_rgb, g_acc, want_dec, gates, fwd_rec, arith):
+        def one_pass(S, z, raw, noise, planes, packed, packed_bwd, g_rgb, g_disp, g_acc, disp, acc, want_dec, gates, fwd_rec, arith):
             """-> decoder gradient of this pass (state-dict order) or None"""
-            if (g_rgb is None and g_acc is None) or (not any(need_planes) and not want_dec):
+            if (g_rgb is None and g_acc is None and g_disp is None) or (not any(need_planes) and not want_dec):
                 return None
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
             g_acc = None if g_acc is None else capi.f32c(g_acc)
-            g_raw = nv.composite_backward(raw, z, rd, noise, bool(cfg["white"]), False, g_rgb, g_acc)
+            g_depth = None
+            if g_disp is not None:
+                q = 1.0 / disp                      # disp = 1 / max(1e-10, q): q itself wherever the gradient is not zero (NaN stays NaN)
+                g_acc, g_depth = ops.fold_disp_grad(g_disp, q, acc, q * acc, g_acc, None)
+            g_raw = nv.composite_backward(raw, z, rd, noise, bool(cfg["white"]), False, g_rgb, g_acc, g_depth)
             if gates is not None and (not want_dec or fwd_rec is not None):
                 # gate-driven backward (no recomputation); with the forward's record it adds the gradient half, then ONE contraction
                 rec = fwd_rec if want_dec else None
@@ -148,11 +155,11 @@ class _RenderRaysFn(torch.autograd.Function):
 
         gdec_c = gdec_f = None
         if cfg["coarse_grad"]:
-            gdec_c = one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["planes_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[2],
-                              bool(need[5]), sv["gates_c"], sv["rec_c"], cfg["arith_c"])
+            gdec_c = one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["planes_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[1],
+                              grads[2], sv["disp_c"], sv["acc_c"], bool(need[5]), sv["gates_c"], sv["rec_c"], cfg["arith_c"])
         if Nf > 0:
-            gdec_f = one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["planes_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[5],
-                              bool(need[6]), sv["gates_f"], sv["rec_f"], cfg["arith_f"])
+            gdec_f = one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["planes_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[4],
+                              grads[5], sv["disp_f"], sv["acc_f"], bool(need[6]), sv["gates_f"], sv["rec_f"], cfg["arith_f"])
         out = [None]
         for d, src in enumerate(cfg["plane_leaves"]):
             g = gplanes[d]

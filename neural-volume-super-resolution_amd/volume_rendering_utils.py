@@ -20,8 +20,8 @@ def volume_render_radiance_field(radiance_field, depth_values, ray_directions, r
         noise = (torch.randn(raw[..., 3].shape) * radiance_field_noise_std).to(raw)
     if noise is not None:
         noise = capi.f32c(noise)
-    # torch.ops.nvsr.composite: differentiable in the radiance field (rgb_map and acc_map carry gradients; disp, weights and depth are
-    # returned without a gradient path -- the reference's losses use rgb only, train_nerf.py:884-891)
+    # torch.ops.nvsr.composite: differentiable in the radiance field through rgb_map, disp_map, acc_map and depth_map like the reference's
+    # (the per-sample weights are returned without a gradient path)
     rgb, disp, acc, weights, depth = torch.ops.nvsr.composite(raw.reshape(N, S, 4), z.reshape(N, z.shape[-1]), rd.reshape(N, 3),
                                                               None if noise is None else noise.reshape(N, S), bool(white_background), mip)
     lead = list(lead)

@@ -381,7 +381,7 @@ def test_torch_library_ops_exist_and_opcheck(hip):
     # differentiable operators: gradients flow through the registered formulas
     rawp = raw.clone().requires_grad_(True)
     rgb, disp, acc, wts, depth = nv.composite(rawp, z, rd3, None, False, False)
-    assert rgb.requires_grad and acc.requires_grad and not disp.requires_grad and not wts.requires_grad and not depth.requires_grad
+    assert rgb.requires_grad and acc.requires_grad and disp.requires_grad and depth.requires_grad and not wts.requires_grad      # (round 3: disp / depth carry gradients)
     gout = torch.randn_like(rgb)
     (rgb * gout).sum().backward()
     # the registered autograd formula IS the backward operator (whose numerics the golden / oracle tests of test_hip_parity.py pin)
