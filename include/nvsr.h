@@ -389,7 +389,8 @@ int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* 
  * blocks per wave), 8 = the bf16-limb kernel's one-output-block x 8-row wave tile (round 3; equally fast; 2 | 3 | 4 | 8 give the same
  * bits), 16 = the bf16-limb kernel on v_mfma_f32_16x16x32_bf16 (round 3; layers with Cin % 32 == 0 and Cout % 128 == 0 only, their default:
  * the K dimension of an instruction spans 32 input channels, so the f32 accumulation order -- not the limb products -- differs from the
- * other instantiations; same tolerance against the oracle)
+ * other instantiations; same tolerance against the oracle), 18 | 19 | 20 = that kernel with 2 | 3 | 4 rows forced, 22 = its 6-row tile
+ * (NVSR_ARITH_F16X2 only)
  * (the results are identical; the parity tests force every instantiation). */
 int nvsr_render_pass_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
                            const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth,

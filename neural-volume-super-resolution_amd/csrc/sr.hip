@@ -289,6 +289,9 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 #define CV16_ROWCOST3 1.05   // cost of an output row in a 3-row / 2-row tile of conv3x3_limb16_kernel relative to a 4-row tile (measured: 4.68 / 4.47 ms, 4.93 / 4.47 ms)
 #define CV16_ROWCOST2 1.10
 #endif
+#ifndef CV16_ROWCOST6
+#define CV16_ROWCOST6 0.90   // f16 limbs: cost of an output row in a 6-row tile relative to a 4-row tile (first guess; measured below)
+#endif
 #ifndef CV_USE_16X16X32
 #define CV_USE_16X16X32 1   // limb layers with Cin % 32 == 0 and Cout % 128 == 0 (all of EDSR's trunk and up-sampling convolutions): 1 = conv3x3_limb16_kernel
 #endif
@@ -829,7 +832,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     // NVSR_ARITH_F16X2: the forward convolutions of the wide layers (16x16x32 kernel) on 2 f16 limbs; everything else that runs limbs -- the
     // narrow input / output layers, every data gradient (pad = 2, backward epilogues) -- stays on 3 bf16 limbs
     const bool f16 = arith == NVSR_ARITH_F16X2 && pad == 0 && epilogue != EPI_MASK_SCALE && epilogue != EPI_ADD_CENTER;
-    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16 && !(cx.rows >= 18 && cx.rows <= 20)) return NVSR_ERR_SHAPE;
+    if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16 && !(cx.rows >= 18 && cx.rows <= 20) && cx.rows != 22) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
     if (H < 3 || W < 3 || batch < 1 || batch > 1024) return NVSR_ERR_SHAPE;
@@ -856,25 +859,30 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         dim3 grid((Wo + 31) / 32, 1, p.ncg * batch);
         int best_pb = 4;
         double best_cost = 1e300;
-        for (int pb = 4; pb >= 2; --pb) {
+        // f16 limbs: a 6-row tile too (96 accumulator registers, 2 x 35 KB of LDS: still two workgroups per CU) -- with half the MFMAs per weight
+        // fragment the stream of fragments out of L2 (4 KB per wave and tap) is what a row costs, and 6 rows amortise it over 1.5 x the MFMAs
+        for (int pb = f16 ? 6 : 4; pb >= 2; --pb) {
+            if (pb == 5) continue;
             // rounds of the 512 workgroup slots x rows x the measured cost of a row in a pb-row tile relative to a 4-row tile (tools/conv_time.py
             // rows 18 / 19 / 20 on a layer of full rounds); a last round of at most 256 tiles has every CU to itself (~0.62 of a round's time)
             const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
             constexpr long SLOTS = CV16_WAVES == 4 ? 512 : 256;
             const long full = tiles / SLOTS, rest = tiles % SLOTS;
             const double rounds = (double)full + (rest == 0 ? 0.0 : (CV16_WAVES == 4 && rest <= 256) ? 0.62 : 1.0);
-            const double cost = rounds * pb * (pb == 4 ? 1.0 : pb == 3 ? CV16_ROWCOST3 : CV16_ROWCOST2);
+            const double cost = rounds * pb * (pb == 6 ? CV16_ROWCOST6 : pb == 4 ? 1.0 : pb == 3 ? CV16_ROWCOST3 : CV16_ROWCOST2);
             if (cost < best_cost) { best_cost = cost; best_pb = pb; }
         }
         if (cx.rows >= 18) best_pb = cx.rows - 16;
+        if (best_pb == 6 && !f16) return NVSR_ERR_SHAPE;
         {   // NVSR_CV16_ROWS=2|3|4 (environment, read once): force the row count of every launch (tools: per-layer comparison of the variants)
             static int forced = -1;
             if (forced < 0) { const char* e = getenv("NVSR_CV16_ROWS"); forced = e ? atoi(e) : 0; }
-            if (forced >= 2 && forced <= 4 && cx.rows < 18) best_pb = forced;
+            if (((forced >= 2 && forced <= 4) || (forced == 6 && f16)) && cx.rows < 18) best_pb = forced;
         }
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (f16) {
-            if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            if (best_pb == 6) hipLaunchKernelGGL((conv3x3_limb16_kernel<6, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            else if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
             else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
             else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
             return NVSR_CHECK_LAUNCH();

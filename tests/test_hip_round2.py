@@ -59,7 +59,7 @@ def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
         # to each other, and at least as close to the (double-accumulating) oracle as the 3-bf16-limb kernel; other layers run the bf16x3 kernels
         if Cin % 32 == 0 and Cout % 128 == 0:
             f16 = {}
-            for rows in (0, 16, 18, 19, 20):
+            for rows in (0, 16, 18, 19, 20, 22):            # (22: the 6-row tile, f16 limbs only)
                 out = torch.full(ref.shape, -7.0, device=DEV)
                 capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, capi.ptr(skd), capi.ptr(out), ARITH["f16x2"],
                           rows, capi.stream())
@@ -78,7 +78,7 @@ def test_conv3x3_every_row_tile_variant_vs_oracle(hip, oracle):
     out = torch.full((256, 13, 43), -7.0, device=DEV)
     x = T(rng.standard_normal((48, 15, 45), dtype=np.float32))
     pk = torch.zeros(capi.lib().nvsr_conv3x3_packed_floats(48, 256), device=DEV)
-    for arith, rows in ((3, 5), (3, 1), (7, 0), (1, 0), (0, 8), (3, 16), (0, 16), (2, 16)):   # (8 / 16 exist in the limb kernel only; 16 needs Cin % 32 == 0: 48 is not)
+    for arith, rows in ((3, 5), (3, 1), (7, 0), (1, 0), (0, 8), (3, 16), (0, 16), (2, 16), (2, 21)):   # (8 / 16 exist in the limb kernel only; 16 needs Cin % 32 == 0: 48 is not)
         st = capi.lib().nvsr_conv3x3_arith(capi.ptr(x), 48, 15, 45, capi.ptr(pk), 256, 0, None, capi.ptr(out), arith, rows, capi.stream())
         assert st == 1 and float(out.min()) == -7.0
     # data gradient (virtual zero border, flipped + transposed kernel): every row-tile variant, both kernels
