@@ -449,6 +449,41 @@ class TwoDimPlanesModel(nn.Module):
         """NVSR_ARITH_* code of this model's calls (-1 = the process default)"""
         return capi.arith_code(self.arithmetic)
 
+    # |value| limits of NVSR_ARITH_F16X2's static scales (include/nvsr.h): weights are packed as W 2^8, features held as x 2^4
+    F16_WEIGHT_LIMIT, F16_FEATURE_LIMIT = 255.0, 4094.0
+
+    def f16_operands_in_range(self, planes):
+        """True if the decoder weights and the given channel-last planes fit NVSR_ARITH_F16X2's ranges.  One reduction + one host read per
+        tensor VERSION (cached): evaluation renders call it, training steps (whose planes change every iteration) do not -- there an
+        out-of-range operand shows as a NaN loss, never as a wrong number (csrc/render3.hip)."""
+        cache = self.__dict__.setdefault("_f16_range_cache", {})
+        ok = True
+        # the matrices the matrix pipe multiplies: the hidden / feature layers' weights (heads and biases stay f32 vector arithmetic)
+        mats = [p for n, p in self.named_parameters() if n.endswith(".weight") and (n.startswith("density_dec.") or n.startswith("rgb_dec."))]
+        for t, limit in [(w, self.F16_WEIGHT_LIMIT) for w in mats] + [(p, self.F16_FEATURE_LIMIT) for p in planes]:
+            key = (t.data_ptr(), t._version, tuple(t.shape))
+            hit = cache.get(key)
+            if hit is None:
+                if len(cache) > 64:
+                    cache.clear()
+                hit = cache[key] = bool(torch.isfinite(t).all()) and float(t.detach().abs().max()) < limit if t.numel() else True
+            ok = ok and hit
+        return ok
+
+    def render_arithmetic(self, planes, training):
+        """the NVSR_ARITH_* code a render of `planes` through this model runs in: the model's / the process's choice, except that an
+        EVALUATION render whose operands do not fit the f16 limbs falls back to the 3-bf16-limb arithmetic (warned once) instead of
+        rendering NaN pixels.  Hidden activations beyond the range cannot be known beforehand: those still render NaN."""
+        code = capi.resolve_decoder_arithmetic(self.arithmetic)
+        if code == capi.ARITHMETIC["f16x2"] and not training and not self.f16_operands_in_range(planes):
+            if not self.__dict__.get("_f16_warned"):
+                import warnings
+                warnings.warn("decoder weights or plane values beyond NVSR_ARITH_F16X2's range (|W| < 255, |feature| < 4094): rendering this "
+                              "model in 'bf16x3' (set model.arithmetic to silence)")
+                self.__dict__["_f16_warned"] = True
+            return capi.ARITHMETIC["bf16x3"]
+        return code
+
     def forward(self, x):
         """models.py:381-421: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb, sigma] (pre-activation)"""
         x = capi.f32c(x)

@@ -234,8 +234,12 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
             same = all(a.data_ptr() == b.data_ptr() for a, b in zip(planes_c, planes_f))
         else:
             planes_f, same = planes_c, True
-    arith_c = capi.resolve_decoder_arithmetic(model_coarse.arithmetic)
-    arith_f = capi.resolve_decoder_arithmetic(model_fine.arithmetic) if Nf > 0 else arith_c
+    if train_path:
+        arith_c = capi.resolve_decoder_arithmetic(model_coarse.arithmetic)
+        arith_f = capi.resolve_decoder_arithmetic(model_fine.arithmetic) if Nf > 0 else arith_c
+    else:       # evaluation: operands beyond the f16 limbs' range render in the 3-limb arithmetic instead of NaN (models.render_arithmetic)
+        arith_c = model_coarse.render_arithmetic(planes_c, training=False)
+        arith_f = model_fine.render_arithmetic(planes_f, training=False) if Nf > 0 else arith_c
     white, lindisp = bool(m.white_background), bool(m.lindisp)
 
     if train_path:

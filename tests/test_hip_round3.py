@@ -511,3 +511,32 @@ def test_disparity_and_depth_gradients(hip):
     (out[4] * 0.01).sum().backward()
     gp = [p.grad for p in mf.planes_.values() if p.grad is not None]
     assert gp and all(torch.isfinite(g_).all() for g_ in gp) and sum(float(g_.abs().sum()) for g_ in gp) > 0
+
+
+def test_evaluation_falls_back_to_bf16x3_outside_the_f16_range(hip):
+    """eval_nerf / run_one_iter_of_nerf(mode='validation') of a model whose planes or weights do not fit NVSR_ARITH_F16X2's static scales
+    renders in the 3-bf16-limb arithmetic (models.render_arithmetic; one cached reduction per tensor version) instead of NaN pixels; an explicit
+    model.arithmetic = 'f16x2' ... still renders through the check (the choice is about range, not preference), in range nothing changes."""
+    import warnings
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=64, view_res=16, seed=4)
+    H = W = 136
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    opts, scfg = render_options(16, 24)
+    code = hip.capi.ARITHMETIC
+    planes, _ = mf.scene_args()
+    assert mf.render_arithmetic(planes, training=False) == code["f16x2"]
+    base = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    assert torch.isfinite(base[3]).all()
+    name = hip.models.get_plane_name(sid, 1)
+    with torch.no_grad():
+        mf.planes_[name].mul_(20000.0)          # (mc and mf share the planes)
+    planes, _ = mf.scene_args()
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        assert mf.render_arithmetic(planes, training=False) == code["bf16x3"]
+        assert mf.render_arithmetic(planes, training=True) == code["f16x2"]       # training: no host read per step; NaN is the signal there
+        out = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    assert any("bf16x3" in str(w.message) for w in wl)
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[3]).all()
