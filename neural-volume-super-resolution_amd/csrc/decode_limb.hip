@@ -69,9 +69,9 @@ __device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* b
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (LF == 2) {
-                float v;
-                asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v) : "v"(acc[g >> 2][4 * (g & 3) + j]), "s"(nsc), "v"(b[j]));
-                act[g >> 2][4 * (g & 3) + j] = __int_as_float(max(__float_as_int(v), 0));
+                float v;        // (one statement: hipcc pads an s_nop between an asm statement and a dependent instruction)
+                asm("v_fma_f32 %0, -%1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=v"(v) : "v"(acc[g >> 2][4 * (g & 3) + j]), "s"(nsc), "v"(b[j]));
+                act[g >> 2][4 * (g & 3) + j] = v;
             } else act[g >> 2][4 * (g & 3) + j] = fmaxf(acc[g >> 2][4 * (g & 3) + j] + b[j], 0.0f);
         }
     }

@@ -183,7 +183,9 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
 #if defined(R3_ABLATE) && (R3_ABLATE & 128)       // timing experiment (render3.hip): no A-fragment reads after the block's first
                 if (p < LIMBS) { fn.v[p] = fa.v[p]; fn.v[p][0] ^= (unsigned)(q + 1); }     // (distinct per output block: no CSE of the MFMAs)
 #else
-                if (p < LIMBS) fn.v[p] = wv[(((q + 1) % NQ) * LIMBS + p) * 64];
+                // (f16 limbs: the two fragments of the next group are read lo first, hi second -- the next group's first product uses hi, so ONE
+                //  s_waitcnt for the younger read covers both; hi first costs a second wait in front of the lo product: an issue slot per group)
+                if (p < LIMBS) { const int t_ = LIMBS == 2 ? LIMBS - 1 - p : p; fn.v[t_] = wv[(((q + 1) % NQ) * LIMBS + t_) * 64]; }
 #endif
                 if (kb + 1 < NKB) split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
                 else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);

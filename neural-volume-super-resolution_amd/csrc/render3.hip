@@ -208,9 +208,10 @@ __device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, 
                 act[r >> 4][r & 15] = __int_as_float(max(__float_as_int(v[1]), 0));
             }
 #else
-            float v;            // (written out: the compiler would fold the two negations away)
-            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(v) : "v"(acc[r >> 4][r & 15]), "s"(nsc[0]), "v"(pend.v[(r >> 2) & 1][r & 3]));
-            act[r >> 4][r & 15] = __int_as_float(max(__float_as_int(v), 0));
+            float v;            // (written out: the compiler would fold the two negations away -- and both instructions in ONE statement: behind
+                                // an asm statement hipcc pads an s_nop in front of a dependent instruction, 600 of them per step)
+            asm("v_fma_f32 %0, -%1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=v"(v) : "v"(acc[r >> 4][r & 15]), "s"(nsc[0]), "v"(pend.v[(r >> 2) & 1][r & 3]));
+            act[r >> 4][r & 15] = v;
 #endif
         } else act[r >> 4][r & 15] = fmaxf(acc[r >> 4][r & 15] + pend.v[(r >> 2) & 1][r & 3], 0.0f);
     }
