@@ -183,9 +183,10 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
 #if defined(R3_ABLATE) && (R3_ABLATE & 128)       // timing experiment (render3.hip): no A-fragment reads after the block's first
                 if (p < LIMBS) { fn.v[p] = fa.v[p]; fn.v[p][0] ^= (unsigned)(q + 1); }     // (distinct per output block: no CSE of the MFMAs)
 #else
-                // (f16 limbs: the two fragments of the next group are read lo first, hi second -- the next group's first product uses hi, so ONE
-                //  s_waitcnt for the younger read covers both; hi first costs a second wait in front of the lo product: an issue slot per group)
-                if (p < LIMBS) { const int t_ = LIMBS == 2 ? LIMBS - 1 - p : p; fn.v[t_] = wv[(((q + 1) % NQ) * LIMBS + t_) * 64]; }
+                // (the fragments of the next group are read LOWEST LIMB FIRST: the next group's first product uses limb 0, so ONE s_waitcnt for
+                //  the youngest read covers them all; limb 0 first costs another wait in front of every later limb's first product -- an issue
+                //  slot each, 1 767 -> 1 066 waits per step of the 3-limb render pass, 1 401 -> 1 040 of the f16 one)
+                if (p < LIMBS) { const int t_ = LIMBS - 1 - p; fn.v[t_] = wv[(((q + 1) % NQ) * LIMBS + t_) * 64]; }
 #endif
                 if (kb + 1 < NKB) split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
                 else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);
