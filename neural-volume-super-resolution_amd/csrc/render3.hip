@@ -302,7 +302,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     constexpr int NSF = 3 * 4 * NP, NSH = 4 * 4 * NP;          // slots of a feature block / of half a hidden layer
     __shared__ __attribute__((aligned(16))) unsigned lds[L::TOTAL];
     Ring3<LIMBS> rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LIMBS)), 0, KB_TOTAL * kb_words(LIMBS) * 4, 0x00020000),
-                    lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+                    lds, 0, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
+    // (wave index as a SCALAR: the LDS destination of every weight-copy piece is then scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
     float* ldsf = reinterpret_cast<float*>(lds);
     // (f16 limbs: activations are held as x 2^F16_SX -- biases scaled up, head weights scaled down, all exact; limb_core.h)
     // A weight beyond the f16 range was packed as inf: the packer then left a NaN in the blob's spare slot S_F16_POISON, which goes into
