@@ -103,9 +103,11 @@ class _RenderRaysFn(torch.autograd.Function):
             saved.update(z_f=z_f, raw_f=raw_f, gates_f=none_if_empty(gates_f), rec_f=none_if_empty(rec_f))
         ctx.cfg, ctx.saved = cfg, saved          # (ctx.saved is also what the parity tests read the fine depths from)
         # disp_map is differentiable like the reference's (volume_rendering_utils.py:46): its gradient is folded into those of depth / acc
-        saved.update(disp_c=disp_c, acc_c=acc_c)
+        # (detached views: the outputs themselves would close a reference cycle ctx -> saved -> output -> grad_fn -> ctx, and every step's
+        #  7 GB of forward record would wait for the cyclic garbage collector)
+        saved.update(disp_c=disp_c.detach(), acc_c=acc_c.detach())
         if Nf > 0:
-            saved.update(disp_f=disp_f, acc_f=acc_f)
+            saved.update(disp_f=disp_f.detach(), acc_f=acc_f.detach())
         return tuple(outs)
 
     @staticmethod

@@ -540,3 +540,38 @@ def test_evaluation_falls_back_to_bf16x3_outside_the_f16_range(hip):
         out = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
     assert any("bf16x3" in str(w.message) for w in wl)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[3]).all()
+
+
+def test_training_steps_do_not_retain_their_graphs(hip):
+    """A train step with decoder gradients keeps a multi-GB forward record alive in its autograd context; nothing may hold that context past
+    the step.  (Round 3 regression: the differentiable-disparity change stored OUTPUT tensors in the context -- a reference cycle ctx -> saved
+    -> output -> grad_fn -> ctx that only the cyclic garbage collector breaks: 29 steps of the bench filled 288 GB and the step went from 5 to
+    200 ms.)  With the collector disabled the allocated memory after step 6 must equal that after step 2."""
+    import gc
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=48, view_res=16, seed=6)
+    for m in (mc, mf):
+        for n, p in m.named_parameters():
+            p.requires_grad_("rot_mats" not in n)
+        m.train()
+    H = W = 32
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd_ = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    batch = torch.stack([ro.reshape(-1, 3)[:512], rd_.reshape(-1, 3)[:512]], 0)
+    opts, scfg = render_options(16, 16)
+    gc.collect()
+    gc.disable()
+    try:
+        mem = []
+        for it in range(6):
+            for m in (mc, mf):
+                m.zero_grad(set_to_none=True)
+            out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+            assert out[3].grad_fn.saved["rec_f"] is not None            # the step does carry a record
+            (out[0].sum() + out[3].sum()).backward()
+            del out
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert mem[5] == mem[1], mem
