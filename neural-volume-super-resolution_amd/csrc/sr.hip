@@ -290,7 +290,7 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 #define CV16_ROWCOST2 1.10
 #endif
 #ifndef CV16_ROWCOST6
-#define CV16_ROWCOST6 0.90   // f16 limbs: cost of an output row in a 6-row tile relative to a 4-row tile (first guess; measured below)
+#define CV16_ROWCOST6 0.97   // f16 limbs: cost of an output row in a 6-row tile relative to a 4-row tile (measured on a 1024^2 layer: 2.547 / 2.636 ms)
 #endif
 #ifndef CV_USE_16X16X32
 #define CV_USE_16X16X32 1   // limb layers with Cin % 32 == 0 and Cout % 128 == 0 (all of EDSR's trunk and up-sampling convolutions): 1 = conv3x3_limb16_kernel
