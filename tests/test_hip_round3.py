@@ -575,3 +575,39 @@ def test_training_steps_do_not_retain_their_graphs(hip):
     finally:
         gc.enable()
     assert mem[5] == mem[1], mem
+
+
+def test_f16_conv_range_overflow_is_loud(hip):
+    """The f16-limb SR convolution (csrc/sr.hip conv3x3_limb16_kernel<., ., 2>) carries the same static scales as the render pass: an input
+    value >= 4094 or a weight >= 255 must give NaN outputs where it contributes (its ReLU epilogue is a compare + select, not v_max_f32) and
+    leave every other output untouched; the 3-bf16-limb kernel computes the same layer with finite outputs."""
+    rng = np.random.default_rng(2)
+    capi = hip.capi
+    Cin, Cout, H, W = 64, 128, 12, 40
+    x = rng.standard_normal((Cin, H, W), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+
+    def conv(xa, wa, mode, epi):
+        pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cin, Cout), device=DEV)
+        wd, xd = T(wa), T(xa)
+        capi.call("nvsr_pack_conv3x3", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+        out = torch.full((Cout, H - 2, W - 2), -7.0, device=DEV)
+        capi.call("nvsr_conv3x3_arith", capi.ptr(xd), Cin, H, W, capi.ptr(pk), Cout, epi, None, capi.ptr(out), capi.ARITHMETIC[mode], 0, capi.stream())
+        torch.cuda.synchronize()
+        return N_(out)
+
+    for epi in (0, 1):                                   # no epilogue / ReLU
+        base = conv(x, w, "f16x2", epi)
+        assert np.isfinite(base).all()
+        xb = x.copy()
+        xb[5, 6, 20] = 6000.0                            # reaches outputs (.., 4..6, 18..20)
+        bad = conv(xb, w, "f16x2", epi)
+        hit = np.zeros_like(bad, bool)
+        hit[:, 4:7, 18:21] = True
+        assert np.isnan(bad[hit]).all() and np.array_equal(bad[~hit], base[~hit]), epi
+        assert np.isfinite(conv(xb, w, "bf16x3", epi)).all()
+        wb = w.copy()
+        wb[17, 3, 1, 1] = 300.0                          # output channel 17
+        bad = conv(x, wb, "f16x2", epi)
+        assert np.isnan(bad[17]).all() and np.array_equal(np.delete(bad, 17, 0), np.delete(base, 17, 0)), epi
+        assert np.isfinite(conv(x, wb, "bf16x3", epi)).all()
