@@ -18,7 +18,7 @@ PLANE_CHANNELS = 48
 DEC_CHANNELS = 128
 DECODER_NATURAL_FLOATS = 130564
 DECODER_PACKED_FLOATS = 453136
-DECODER_PACKED_BWD_FLOATS = 348160
+DECODER_PACKED_BWD_FLOATS = 487424
 
 _STATUS = {1: "NVSR_ERR_SHAPE (argument out of the supported range)", 2: "NVSR_ERR_LAUNCH (kernel launch failed)",
            3: "NVSR_ERR_NULL (required pointer is NULL)", 4: "NVSR_ERR_ALIGN (pointer not 16-byte aligned)"}

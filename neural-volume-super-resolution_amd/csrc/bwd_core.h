@@ -27,7 +27,17 @@ constexpr int BL_FRAGS = 6 * 96 + 5 * 48;                // 816
 constexpr int BL_CHUNK_WORDS = 24 * 256;                 // 6144
 constexpr int BL_CHUNKS = BL_FRAGS / 24;                 // 34
 constexpr int BL_WORDS = BL_FRAGS * 256;                 // 208896
-static_assert(B_TOTAL + BL_WORDS == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
+// ---- and, behind those, the same fragments as 2 f16 limbs (round 3; limb_core.h: round to nearest, UNSCALED -- a transposed weight's low
+// limb is a subnormal below |w| = 0.125, absolute error <= 2^-25: about 1e-6 of a typical weight, three orders inside the tolerance of a
+// gradient, and the accumulator of one layer is the operand of the next without a rescaling multiply): the same 34 chunks, 16 fragments each
+template <int LF>
+struct BLimb {
+    static constexpr int HID_FRAGS = 32 * LF, L0_FRAGS = 16 * LF, CHUNK_FRAGS = 8 * LF;
+    static constexpr int FRAGS = 6 * HID_FRAGS + 5 * L0_FRAGS, CHUNK_WORDS = CHUNK_FRAGS * 256, WORDS = FRAGS * 256;
+    static constexpr int OFFSET = LF == 3 ? 0 : 6 * 96 * 256 + 5 * 48 * 256;      // words behind B_TOTAL
+};
+static_assert(BLimb<3>::WORDS == BL_WORDS && BLimb<3>::CHUNK_WORDS == BL_CHUNK_WORDS, "3-limb region");
+static_assert(B_TOTAL + BL_WORDS + BLimb<2>::WORDS == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
 
 __device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
 #pragma unroll

@@ -546,7 +546,7 @@ using namespace nvsr;
 
 // render_bwd_limb.hip
 extern "C" int nvsr_pack_decoder_bwd_limbs_launch(const float* natural, float* packed_bwd, nvsr_stream_t stream);
-extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
+extern "C" int nvsr_render_pass_backward_gates_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
                                                            int64_t N, int S, const float* rays, const float* z, const float* g_raw,
                                                            const uint32_t* gates, float* const* grad_planes, float* view_ws, float* record,
                                                            nvsr_stream_t stream);
@@ -650,9 +650,9 @@ int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* 
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    if (arith != NVSR_ARITH_F32) {       // bf16-limb matrix pipe, always 3 limbs (render_bwd_limb.hip)
-        if (int e = nvsr_render_pass_backward_gates_limb_launch(scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw, gates, grad_planes,
-                                                                view_ws, record, stream))
+    if (arith != NVSR_ARITH_F32) {       // limb matrix pipe (render_bwd_limb.hip): 3 bf16 limbs; NVSR_ARITH_F16X2 without a record: 2 f16 limbs, per-tile scale
+        if (int e = nvsr_render_pass_backward_gates_limb_launch(arith == NVSR_ARITH_F16X2 ? 2 : 3, scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw,
+                                                                gates, grad_planes, view_ws, record, stream))
             return e;
         // the limb kernel leaves one pre-summed row per (ray, 32-sample chunk) in view_ws
         if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, (S + 31) / 32, rays, view_ws, gp.p[3], (hipStream_t)stream);

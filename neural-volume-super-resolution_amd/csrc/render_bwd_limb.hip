@@ -34,45 +34,57 @@ namespace nvsr {
 #endif
 constexpr int BL_TPB = 64 * BL_WAVES_N, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
 constexpr int BL_WG_PER_CU = BL_WAVES_N == 4 ? 2 : 1;
-constexpr int BL_SMALL = 2 * BL_CHUNK_WORDS;
-constexpr int BL_TILES = BL_SMALL + SMALL_FLOATS;
-constexpr int BL_LDS = BL_TILES + BL_WAVES * TILE_FLOATS;
-static_assert(BL_WG_PER_CU * BL_LDS * 4 <= 160 * 1024, "workgroups per CU");
+// LF = limbs of the transposed-layer products: 3 bf16 limbs, or (round 3; no weight-gradient record) 2 f16 limbs with the gradients of a wave
+// tile scaled by a power of two so that their largest magnitude is in [1, 2) -- gradients span many decades, a tile's do not
+template <int LF>
+struct BLds {
+    static constexpr int SMALL = 2 * BLimb<LF>::CHUNK_WORDS;
+    static constexpr int TILES = SMALL + SMALL_FLOATS;
+    static constexpr int LDS = TILES + BL_WAVES * TILE_FLOATS;
+};
+static_assert(BL_WG_PER_CU * BLds<3>::LDS * 4 <= 160 * 1024, "workgroups per CU");
 
-// natural blob -> limb fragments of the transposed layers
+// natural blob -> limb fragments of the transposed layers (LF = 3: bf16 limbs by truncation; LF = 2: f16 limbs, round to nearest, unscaled)
+template <int LF>
 __global__ void pack_decoder_bwd_limbs_kernel(const float* __restrict__ nat, unsigned* __restrict__ out) {
+    constexpr int FH = BLimb<LF>::HID_FRAGS, F0 = BLimb<LF>::L0_FRAGS;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= BL_WORDS) return;
+    if (idx >= BLimb<LF>::WORDS) return;
     const int w = idx & 3, lane = (idx >> 2) & 63, h = lane >> 5;
     int f = idx >> 8;                                   // fragment
-    // region: 0 density hidden (3 x 96), 1 density layer 0 (48), 2 rgb hidden (3 x 96), 3 rgb layer 0 (4 x 48)
-    const bool rgb = f >= 3 * 96 + 48;
-    if (rgb) f -= 3 * 96 + 48;
-    const bool hidden = f < 3 * 96;
+    // region: 0 density hidden (3 x FH), 1 density layer 0 (F0), 2 rgb hidden (3 x FH), 3 rgb layer 0 (4 x F0)
+    const bool rgb = f >= 3 * FH + F0;
+    if (rgb) f -= 3 * FH + F0;
+    const bool hidden = f < 3 * FH;
     unsigned word = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int e = 2 * w + half;
         float v = 0.0f;
         if (hidden) {
-            const int li = f / 96, r = f % 96;          // li 0 -> layer 3, 1 -> layer 2, 2 -> layer 1
-            const int t_ob = r % 12, kb = r / 12, ob = t_ob / 3;
+            const int li = f / FH, r = f % FH;          // li 0 -> layer 3, 1 -> layer 2, 2 -> layer 1
+            const int t_ob = r % (4 * LF), kb = r / (4 * LF), ob = t_ob / LF;
             const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);       // output feature = the MFMA's K
             const int m = 32 * ob + (lane & 31);                                                   // input feature = the row of W^T
             v = nat[(rgb ? N_RGB_W1 : N_DEN_W1) + (2 - li) * N_HID_STRIDE + k * HID + m];
         } else {
-            const int g = f - 3 * 96, p = g / 48, r = g % 48;
-            const int kb = r / 6, ob = (r % 6) / 3;
+            const int g = f - 3 * FH, p = g / F0, r = g % F0;
+            const int kb = r / (2 * LF), ob = (r % (2 * LF)) / LF;
             const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
             const int c = 32 * ob + (lane & 31);
             if (c < C) v = rgb ? nat[N_RGB_W0 + k * (4 * C) + C * p + c] : nat[N_DEN_W0 + k * C + c];
         }
-        const int t = hidden ? (f % 96) % 3 : ((f - 3 * 96) % 48) % 3;
+        const int t = hidden ? (f % FH) % LF : ((f - 3 * FH) % F0) % LF;
         unsigned bits = 0;
+        if constexpr (LF == 2) {
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            bits = __builtin_bit_cast(unsigned short, t == 0 ? hi : lo);
+        } else {
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            if (l == t) bits = __float_as_uint(v) >> 16;
-            v = limb_rest(v);
+            for (int l = 0; l < 3; ++l) {
+                if (l == t) bits = __float_as_uint(v) >> 16;
+                v = limb_rest(v);
+            }
         }
         word |= bits << (16 * half);
     }
@@ -86,7 +98,9 @@ struct RingB {
     int wave, lane;
     unsigned voff;
 };
+template <int LF = 3>
 __device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
+    constexpr int BL_CHUNK_WORDS = BLimb<LF>::CHUNK_WORDS;
     // The chunk's byte offset and the slot go through an opaque asm: as compile-time constants of a call site they are loop-invariant,
     // hipcc hoists the 204 scalar offsets / LDS addresses of a step out of the tile loop and spills them (one scratch reload per DMA).
     int base = chunk * (BL_CHUNK_WORDS * 4), slot = rs.slot;
@@ -94,7 +108,7 @@ __device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
     unsigned* dst = rs.lds + slot * BL_CHUNK_WORDS;
 #if !(BL_ABLATE & 32)         // (32: no weight copies at all -- the matrix work runs on whatever the slots hold)
 #pragma unroll
-    for (int i = 0; i < 24 / BL_WAVES; ++i)
+    for (int i = 0; i < BLimb<LF>::CHUNK_FRAGS / BL_WAVES; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.rsrc, (__attribute__((address_space(3))) void*)(dst + (i * BL_WAVES + rs.wave) * 256), 16,
                                                  (int)rs.voff, base + i * (BL_WAVES * 1024), 0, 0);
 #endif
@@ -111,51 +125,54 @@ __device__ __forceinline__ void ringb_sync() {
 }
 
 // acc2[ob] += W0^T fragments [K-block 4][channel block 2][limb 3] x limbs of src(kb, 0..7): 4 x 2 x 6 MFMAs
-template <class Src>
+template <int LF, class Src>
 __device__ __forceinline__ void limb_mm2(const unsigned* wl, int lane, f32x16 (&acc2)[2], Src src) {
+    constexpr int NP = limb_products(LF);
     const u32x4* wv = reinterpret_cast<const u32x4*>(wl) + lane;
-    Limbs<3> cur, fa;
-    split_all<3>([&](int i) { return src(0, i); }, cur);
+    Limbs<LF> cur, fa;
+    split_all<LF>([&](int i) { return src(0, i); }, cur);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) fa.v[t] = wv[t * 64];
+    for (int t = 0; t < LF; ++t) fa.v[t] = wv[t * 64];
     SplitPend sp;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        Limbs<3> nxt;
+        Limbs<LF> nxt;
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob) {
-            Limbs<3> fn;
+            Limbs<LF> fn;
 #pragma unroll
-            for (int p = 0; p < 6; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const int q = kb * 2 + ob;
-                acc2[ob] = mfma_bf16(fa.v[limb_w(3, p)], cur.v[limb_x(3, p)], acc2[ob]);
+                acc2[ob] = mfma_limb<LF>(fa.v[limb_w(LF, p)], cur.v[limb_x(LF, p)], acc2[ob]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (p < 3) fn.v[p] = wv[(((q + 1) % 8) * 3 + p) * 64];
-                if (kb + 1 < 4) {
-                    split_slice<3>(2 * (ob * 6 + p), [&](int i) { return src(kb + 1, i); }, nxt, sp);
-                    split_slice<3>(2 * (ob * 6 + p) + 1, [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                if (p < LF) fn.v[p] = wv[(((q + 1) % 8) * LF + p) * 64];
+                if (kb + 1 < 4) {      // the 4 NP slices of the next K-block's split over the 2 NP slots of this K-block
+                    split_slice<LF>(2 * (ob * NP + p), [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                    split_slice<LF>(2 * (ob * NP + p) + 1, [&](int i) { return src(kb + 1, i); }, nxt, sp);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fa.v[t] = fn.v[t];
+            for (int t = 0; t < LF; ++t) fa.v[t] = fn.v[t];
         }
         if (kb + 1 < 4) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) cur.v[t] = nxt.v[t];
+            for (int t = 0; t < LF; ++t) cur.v[t] = nxt.v[t];
         }
     }
 }
 
-template <bool RECORD>
+template <bool RECORD, int LF = 3>
 __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gates_limb_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                                    const float* __restrict__ packed_bwd, long N, int S,
                                                                                    const float* __restrict__ rays, const float* __restrict__ z,
                                                                                    const float* __restrict__ g_raw,
                                                                                    const unsigned* __restrict__ gates, GradPlanes gp,
                                                                                    float* __restrict__ gview, DecRecord rec) {
-    __shared__ __attribute__((aligned(16))) unsigned lds[BL_LDS];
-    RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL), 0, BL_WORDS * 4, 0x00020000), lds, 0,
+    static_assert(LF == 3 || !RECORD, "the weight-gradient record is contracted from unscaled f32 gradients: 3-limb backward only");
+    constexpr int BL_SMALL = BLds<LF>::SMALL, BL_TILES = BLds<LF>::TILES;
+    __shared__ __attribute__((aligned(16))) unsigned lds[BLds<LF>::LDS];
+    RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL + BLimb<LF>::OFFSET), 0, BLimb<LF>::WORDS * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += BL_TPB) ldsf[BL_SMALL + i] = packed[P_SMALL + i];   // head weights of the FORWARD blob
@@ -181,11 +198,25 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         const bool valid = ray0 < N && s0 < S;
         const long ray = ray0 < N ? ray0 : N - 1;
         const int s = s0 < S ? s0 : S - 1;
-        const unsigned* cw = ringb_issue(rs, 0);
+        const unsigned* cw = ringb_issue<LF>(rs, 0);
         const float* r = rays + ray * 11;
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // f16 limbs: the tile's gradients times 2^-floor(log2(max |dL/draw|)) (exact; wave-uniform), undone on the feature gradients below.
+        // Through the four transposed layers a gradient changes by a few binades at most: it stays inside the f16 limbs' 30; if not, the
+        // overflow reaches the planes as NaN.
+        float gscale = 1.0f, gunscale = 1.0f;
+        if constexpr (LF == 2) {
+            float m = fmaxf(fmaxf(fabsf(graw[0]), fabsf(graw[1])), fmaxf(fabsf(graw[2]), fabsf(graw[3])));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);              // biased exponent of the tile's largest magnitude (0: all zero)
+            const int eu = __builtin_amdgcn_readfirstlane(e == 0 || e == 255 ? 127 : e);
+            gscale = __uint_as_float((unsigned)(254 - eu) << 23);                  // 2^-(e - 127)
+            gunscale = __uint_as_float((unsigned)eu << 23);
+            graw = graw * gscale;
+        }
         const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
@@ -208,11 +239,11 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             return t;
         };
         f32x16 accA[4], accB[4];
-        Limbs<3> cur, fa;
+        Limbs<LF> cur, fa;
         SplitPend tp;
         // tail of a block: split K-block kb of the same gradient into the limbs the next block starts with
         auto tail_of = [&tp](const f32x16 (&a)[4], int kb) {
-            return [&a, kb, &tp](int slice, Limbs<3>& nxt) { split_slice<3>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+            return [&a, kb, &tp](int slice, Limbs<LF>& nxt) { split_slice<LF>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
         };
         // one chunk of a hidden^T layer (2 K-blocks): wait, start the next copy, split the first K-block of G, multiply
 #define BL_FENCE(ACC)                                                                                   \
@@ -222,9 +253,9 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #define BL_HBLOCK(ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL)                                            \
         {                                                                                               \
             ringb_sync();                                                                               \
-            const unsigned* nw = ringb_issue(rs, NEXT_CHUNK);                                           \
-            if (FIRST && !(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<3>([&](int i) { return s_(0, i); }, cur); } \
-            limb_block<3, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, TAIL);               \
+            const unsigned* nw = ringb_issue<LF>(rs, NEXT_CHUNK);                                           \
+            if (FIRST && !(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<LF>([&](int i) { return s_(0, i); }, cur); } \
+            limb_block<LF, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, TAIL);               \
             cw = nw;                                                                                    \
             BL_FENCE(GN)                                                                                \
         }
@@ -248,14 +279,14 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #define BL_LAYER0_T(G, ACC2, C0, LAST)                                                                  \
         {                                                                                               \
             ringb_sync();                                                                               \
-            const unsigned* nw = ringb_issue(rs, (C0) + 1);                                             \
-            limb_mm2(cw, lane, ACC2, hid(G, 0));                                                        \
+            const unsigned* nw = ringb_issue<LF>(rs, (C0) + 1);                                             \
+            limb_mm2<LF>(cw, lane, ACC2, hid(G, 0));                                                        \
             cw = nw;                                                                                    \
             asm volatile("" : "+v"(ACC2[0]), "+v"(ACC2[1]) : : "memory");                               \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             ringb_sync();                                                                               \
-            if (!(LAST)) nw = ringb_issue(rs, (C0) + 2);                                                \
-            limb_mm2(cw, lane, ACC2, hid(G, 4));                                                        \
+            if (!(LAST)) nw = ringb_issue<LF>(rs, (C0) + 2);                                                \
+            limb_mm2<LF>(cw, lane, ACC2, hid(G, 4));                                                        \
             cw = nw;                                                                                    \
             asm volatile("" : "+v"(ACC2[0]), "+v"(ACC2[1]) : : "memory");                               \
             __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -288,11 +319,12 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);        // (f16 limbs: still times the tile's scale, like the rgb branch's gF it is added to)
         // ---- rgb branch
         asm volatile("" ::: "memory");
         graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (LF == 2) graw = graw * gscale;
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -321,6 +353,12 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? gD[b][rr] : 0.0f;
             BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
+            if constexpr (LF == 2) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) gF[b][rr] *= gunscale;
+            }
             if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {
                     // every sample of the ray taps the same four view-plane texels: the tile's 32 gradient rows are summed here, ONE row
@@ -371,13 +409,15 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 using namespace nvsr;
 
 extern "C" int nvsr_pack_decoder_bwd_limbs_launch(const float* natural, float* packed_bwd, nvsr_stream_t stream) {
-    hipLaunchKernelGGL(pack_decoder_bwd_limbs_kernel, dim3((BL_WORDS + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural,
+    hipLaunchKernelGGL(pack_decoder_bwd_limbs_kernel<3>, dim3((BL_WORDS + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural,
                        reinterpret_cast<unsigned*>(packed_bwd) + B_TOTAL);
+    hipLaunchKernelGGL(pack_decoder_bwd_limbs_kernel<2>, dim3((BLimb<2>::WORDS + 255) / 256), dim3(256), 0, (hipStream_t)stream, natural,
+                       reinterpret_cast<unsigned*>(packed_bwd) + B_TOTAL + BLimb<2>::OFFSET);
     return NVSR_CHECK_LAUNCH();
 }
 
 // nvsr_render_pass_backward_gates (render_bwd.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
-extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
+extern "C" int nvsr_render_pass_backward_gates_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd,
                                                            int64_t N, int S, const float* rays, const float* z, const float* g_raw,
                                                            const uint32_t* gates, float* const* grad_planes, float* view_ws, float* record,
                                                            nvsr_stream_t stream) {
@@ -385,7 +425,10 @@ extern "C" int nvsr_render_pass_backward_gates_limb_launch(const nvsr_scene* sce
     for (int d = 0; d < 4; ++d) gp.p[d] = grad_planes ? grad_planes[d] : nullptr;
     const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + BL_WAVES - 1) / BL_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
     const int64_t grid = ntiles < 2048 ? ntiles : 2048;
-    if (record)
+    if (limbs == 2 && !record)      // f16 limbs: planes-only training (no weight-gradient record)
+        hipLaunchKernelGGL((render_pass_backward_gates_limb_kernel<false, 2>), dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, DecRecord{});
+    else if (record)
         hipLaunchKernelGGL(render_pass_backward_gates_limb_kernel<true>, dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));
     else

@@ -611,3 +611,41 @@ def test_f16_conv_range_overflow_is_loud(hip):
         bad = conv(x, wb, "f16x2", epi)
         assert np.isnan(bad[17]).all() and np.array_equal(np.delete(bad, 17, 0), np.delete(base, 17, 0)), epi
         assert np.isfinite(conv(x, wb, "bf16x3", epi)).all()
+
+
+def test_f16_backward_matches_the_f32_backward(hip):
+    """The gate-driven backward without a weight-gradient record on 2 f16 limbs (csrc/render_bwd_limb.hip, LF = 2: unscaled transposed weights,
+    every wave tile's gradients scaled by its own power of two) against the exact-f32 backward ON THE SAME GATES, with dL/draw magnitudes spread
+    over 8 decades from ray to ray: relative L2 error of the plane gradients <= 2e-5 and not worse than the 3-bf16-limb backward's (both sit at
+    the float-atomics' ordering noise, ~1e-6)."""
+    from bench import make_synthetic_scene
+    capi = hip.capi
+    lib = capi.lib()
+    rng = np.random.default_rng(3)
+    for pr, N, S in ((40, 1500, 65), (200, 3000, 32), (17, 700, 128)):
+        mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=pr, view_res=8, seed=int(rng.integers(1 << 20)), channels_last=True)
+        H = W = 80
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+        rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)[torch.from_numpy(rng.integers(0, H * W, N)).to(DEV)].contiguous()
+        z = torch.sort(torch.rand(N, S, device=DEV) * 4 + 2, -1).values.contiguous()
+        mag = T(np.exp(rng.uniform(np.log(1e-6), np.log(1e2), (N, 1, 1))).astype(np.float32))
+        g_raw = (torch.randn(N, S, 4, device=DEV) * mag).contiguous()
+        sc, keep = mf.native_scene()
+        raw = torch.empty((N, S, 4), device=DEV)
+        gates = torch.zeros(N * S * 32, dtype=torch.int32, device=DEV)
+        capi.call("nvsr_decode_rays_arith", C.byref(sc), capi.ptr(mf.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw),
+                  capi.ptr(gates), None, capi.ARITHMETIC["f32"], capi.stream())
+        res = {}
+        for mode in ("f32", "bf16x3", "f16x2"):
+            gpl = [torch.zeros_like(k) for k in keep]
+            gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
+            vws = torch.zeros(lib.nvsr_view_grad_workspace_floats(N, S), device=DEV)
+            capi.call("nvsr_render_pass_backward_gates_arith", C.byref(sc), capi.ptr(mf.packed_decoder()), capi.ptr(mf.packed_decoder_bwd()), N, S,
+                      capi.ptr(rays), capi.ptr(z), capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(vws), None, capi.ARITHMETIC[mode], capi.stream())
+            torch.cuda.synchronize()
+            res[mode] = torch.cat([g.reshape(-1).double() for g in gpl])
+            assert torch.isfinite(res[mode]).all(), mode
+        rel = {m: float((res[m] - res["f32"]).norm() / res["f32"].norm()) for m in ("bf16x3", "f16x2")}
+        print("planes %d N %d S %d: relative L2 vs the f32 backward %s" % (pr, N, S, rel))
+        assert rel["f16x2"] <= 2e-5 and rel["f16x2"] <= 3.0 * rel["bf16x3"] + 1e-6, rel
