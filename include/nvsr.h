@@ -119,7 +119,9 @@ int nvsr_limb_gemm_probe(int arithmetic, int K, const float* W, const float* X, 
  * and every weight gradient: NVSR_ARITH_F32, NVSR_ARITH_BF16X3 (same error bound as above) or NVSR_ARITH_F16X2 -- the FORWARD convolutions
  * of the layers with Cin % 32 == 0 and Cout % 128 == 0 (EDSR's 65 trunk and 2 up-sampling convolutions, 97 % of the FLOPs) on 2 f16 limbs
  * (3 MFMAs per product block instead of 6; weights packed as W 2^8, the input patch held as x 2^4, same ranges and the same NaN-on-overflow
- * rule as above); every data / weight gradient and the narrow input / output layers run 3 bf16 limbs in that mode.
+ * rule as above) -- and their data gradients too, with the power of two that puts the largest |dy| of the layer's whole gradient tensor into
+ * [2^12, 2^13) in place of the static activation scale (one reduction per layer: gradients span many decades from layer to layer and step to
+ * step, a tensor's values a few); weight gradients and the narrow input / output layers run 3 bf16 limbs in that mode.
  * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3 | f16x2. */
 #define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_F16X2
 int nvsr_get_conv_arithmetic(void);

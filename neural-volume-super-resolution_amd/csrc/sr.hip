@@ -11,6 +11,7 @@
 // chunk.  A wave owns 2 co-blocks x 4 pixel-blocks (128 accumulator registers); a workgroup = 8 waves arranged
 // CO_WAVES x PX_WAVES: (4,2) = 256 channels x (8 rows x 32 cols) for the wide layers, (1,8) = 64 channels x (32 x 32) for the
 // narrow heads.  Epilogues fuse ReLU, the residual block's x0.1 + centre-cropped identity, and PixelShuffle(2).
+#include <atomic>
 #include <type_traits>
 
 #include <cstdlib>
@@ -32,6 +33,7 @@ struct ConvParams {
     const unsigned* wpk_limb;   // bf16-limb fragments behind them (conv_limb_eligible layers), else NULL
     const unsigned* wpk_limb16; // 16x16x32 fragments behind those (conv_limb16_eligible layers), else NULL
     const unsigned* wpk_f16;    // 16x16x32 fragments of the 2-f16-limb arithmetic behind those (same layers), else NULL
+    const unsigned* absmax;     // f16 limbs, data gradient: bits of max |in| over the whole input (absmax_kernel) -> the input's power-of-two scale; else NULL
     float* out;           // [Cout][H-2][W-2]  (pixel shuffle: [Cout/4][2(H-2)][2(W-2)])
     const float* skip;    // EPI_RESIDUAL: identity [Cout][H+2][W+2] (block input); EPI_MASK_SCALE: forward activation
                           // [Cout][H-2][W-2] whose sign gates the result; EPI_ADD_CENTER: [Cout][H-6][W-6] added to the centre
@@ -479,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 // F16 (the 2-f16-limb arithmetic): the accumulators carry 2^(F16_SW + F16_SX) and the ReLU lets a NaN through (an operand beyond the f16
 // range turns the accumulators into NaNs; fmaxf would return 0)
 template <int PB, bool F16 = false>
-__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[2][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo) {
+__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[2][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo,
+                                                 float unscale = 1.0f) {
     float* __restrict__ const out = p.out;
     const float* __restrict__ const skip = p.skip;
     const int i = lane & 15, g = lane >> 4;
@@ -512,7 +515,7 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float t = acc[cb][pb][hx][r];
-                        if (F16) t *= 1.0f / (F16_W_SCALE * F16_X_SCALE);
+                        if (F16) t *= unscale;
                         if (EPI == EPI_RELU) t = F16 ? (t < 0.0f ? 0.0f : t) : fmaxf(t, 0.0f);
                         if (EPI == EPI_RESIDUAL) t = t * 0.1f + sk[r];
                         if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;
@@ -534,8 +537,8 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
         case EPI_RELU: write_out(std::integral_constant<int, EPI_RELU>{}); break;
         case EPI_RESIDUAL: write_out(std::integral_constant<int, EPI_RESIDUAL>{}); break;
         case EPI_PIXEL_SHUFFLE: write_out(std::integral_constant<int, EPI_PIXEL_SHUFFLE>{}); break;
-        case EPI_MASK_SCALE: if constexpr (!F16) write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;      // (backward epilogues: 3-limb kernel only)
-        case EPI_ADD_CENTER: if constexpr (!F16) write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
+        case EPI_MASK_SCALE: write_out(std::integral_constant<int, EPI_MASK_SCALE>{}); break;
+        case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
         default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
     }
 }
@@ -604,6 +607,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         voff[k] = o * 8 * (int)HW + (inside[k] ? yr * Wr + xr : 0);
         sl[k] = CV16_ITEM(r, o, c) * 4;
     }
+    // f16 limbs: the input's power-of-two scale -- static 2^F16_SX for activations; for a data gradient (p.absmax) the one that puts the largest
+    // |dy| of the whole tensor into [2^12, 2^13): gradients span many decades from layer to layer and step to step, a tensor's values a few
+    float xscale = F16_X_SCALE;
+    if (LIMBS == 2 && p.absmax) {
+        const int e = (int)((__builtin_amdgcn_readfirstlane((int)*p.absmax) >> 23) & 0xff);
+        xscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+    }
+
     float st[IT][8];
     auto gload = [&](int chunk) {
 #pragma unroll
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
             Limbs<LIMBS> L;
             float e[8];
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) e[c8] = inside[k] ? (LIMBS == 2 ? st[k][c8] * F16_X_SCALE : st[k][c8]) : 0.0f;
+            for (int c8 = 0; c8 < 8; ++c8) e[c8] = inside[k] ? (LIMBS == 2 ? st[k][c8] * xscale : st[k][c8]) : 0.0f;
             if constexpr (LIMBS == 3) split8(e, L);
             else split_all<2>([&](int i8) { return e[i8]; }, L);
             if (item[k]) {
@@ -636,7 +647,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
     const int nchunks = p.Cin / 32;
     const u32x4* wbase = reinterpret_cast<const u32x4*>(LIMBS == 2 ? p.wpk_f16 : p.wpk_limb16) + ((long)cb0 * 9 * LIMBS) * 64;     // wave-uniform
     const long wchunk = (long)ncb16 * 9 * LIMBS * 64;       // u32x4 per chunk
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out16<PB, LIMBS == 2>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo);
+    conv_write_out16<PB, LIMBS == 2>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo, 1.0f / (F16_W_SCALE * xscale));
 #undef CV16_ITEM
 }
 
@@ -825,13 +835,51 @@ extern "C" int nvsr_set_conv_arithmetic(int mode) {
 
 int conv_resolve_arith(int arith) { return arith == NVSR_ARITH_INHERIT ? nvsr_get_conv_arithmetic() : arith; }
 
+// max |x| of a tensor as the bits of a non-negative float (they order like unsigned integers): the scale of an f16-limb data gradient.
+// A ring of result words so that launches queued on different streams never share one; a word is zeroed by a memset queued in front.
+constexpr int ABSMAX_SLOTS = 1024;
+__device__ unsigned g_absmax[ABSMAX_SLOTS];
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    // 16-byte loads over the aligned body, scalars over head / tail; one atomic per workgroup
+    float m = 0.0f;
+    const long head = (4 - ((reinterpret_cast<uintptr_t>(x) >> 2) & 3)) & 3, body = n > head ? (n - head) / 4 : 0;
+    const f32x4* xv = reinterpret_cast<const f32x4*>(x + head);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < body; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = xv[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) {            // at most 3 scalars in front of the aligned body, 3 behind it
+        const long i = threadIdx.x < 4 ? (long)threadIdx.x : head + 4 * body + (threadIdx.x - 4);
+        if ((threadIdx.x < 4 ? i < head : i < n) && i < n) m = fmaxf(m, fabsf(x[i]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // (a NaN input: fmaxf drops it -- the convolution itself then propagates it through its products)
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+static const unsigned* launch_absmax(const float* x, long n, hipStream_t stream) {
+    static std::atomic<unsigned> next{0};
+    unsigned* base = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_absmax)) != hipSuccess) return nullptr;
+    unsigned* slot = base + (next.fetch_add(1) % ABSMAX_SLOTS);
+    if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
+    const int blocks = (int)((n + 256 * 32 - 1) / (256 * 32) < 1024 ? (n + 256 * 32 - 1) / (256 * 32) : 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, x, n, slot);
+    return slot;
+}
+
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad, int batch, ConvExec cx) {
     const int arith = conv_resolve_arith(cx.arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
     // NVSR_ARITH_F16X2: the forward convolutions of the wide layers (16x16x32 kernel) on 2 f16 limbs; everything else that runs limbs -- the
     // narrow input / output layers, every data gradient (pad = 2, backward epilogues) -- stays on 3 bf16 limbs
-    const bool f16 = arith == NVSR_ARITH_F16X2 && pad == 0 && epilogue != EPI_MASK_SCALE && epilogue != EPI_ADD_CENTER;
+    // (round 3, end: the data gradients of those layers too -- pad = 2, backward epilogues -- with the scale of the whole dy tensor, absmax_kernel)
+    const bool f16 = arith == NVSR_ARITH_F16X2;
+    const bool f16_dgrad = f16 && (pad != 0 || epilogue == EPI_MASK_SCALE || epilogue == EPI_ADD_CENTER);
     if (cx.rows != 0 && (cx.rows < 2 || cx.rows > 4) && cx.rows != 8 && cx.rows != 16 && !(cx.rows >= 18 && cx.rows <= 20) && cx.rows != 22) return NVSR_ERR_SHAPE;
     const long in_bs = (long)Cin * H * W;
     H += 2 * pad; W += 2 * pad;
@@ -844,7 +892,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
     const unsigned* wlimb16 = conv_limb16_eligible(Cin, Cout)
                                   ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) + conv_packed_limb_words(Cin, Cout) : nullptr;
     const unsigned* wf16 = wlimb16 ? wlimb16 + conv_packed_limb16_words(Cin, Cout) : nullptr;
-    ConvParams p{in, wpk, wlimb, wlimb16, wf16, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    ConvParams p{in, wpk, wlimb, wlimb16, wf16, nullptr, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
     if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
@@ -881,6 +929,10 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         }
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (f16) {
+            if (f16_dgrad) {
+                p.absmax = launch_absmax(in, in_bs * batch, stream);
+                if (!p.absmax) return NVSR_ERR_LAUNCH;
+            }
             if (best_pb == 6) hipLaunchKernelGGL((conv3x3_limb16_kernel<6, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
             else if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
             else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
@@ -998,9 +1050,12 @@ int nvsr_pack_conv3x3_dgrad(const float* w, int Cin, int Cout, float* packed, nv
     if (const int64_t nl = conv_packed_limb_words(Cout, Cin))
         hipLaunchKernelGGL(pack_conv_limbs_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                            reinterpret_cast<unsigned*>(packed + n), Cout, Cin, conv_ncb(Cin), 1);
-    if (const int64_t n16 = conv_packed_limb16_words(Cout, Cin))            // (the data gradient never runs the f16 limbs: that region of the blob stays unwritten)
-        hipLaunchKernelGGL(pack_conv_limbs16_kernel<3>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                           reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cout, Cin), Cout, Cin, 1);
+    if (const int64_t n16 = conv_packed_limb16_words(Cout, Cin)) {
+        unsigned* r16 = reinterpret_cast<unsigned*>(packed + n) + conv_packed_limb_words(Cout, Cin);
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel<3>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, r16, Cout, Cin, 1);
+        const int64_t nf = conv_packed_f16_words(Cout, Cin);
+        hipLaunchKernelGGL(pack_conv_limbs16_kernel<2>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, r16 + n16, Cout, Cin, 1);
+    }
     return NVSR_CHECK_LAUNCH();
 }
 

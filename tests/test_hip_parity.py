@@ -486,7 +486,7 @@ def test_conv3x3_shapes_vs_oracle(hip, oracle):
         capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(T(w)), Cin, Cout, capi.ptr(pk), capi.stream())
         wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
         ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
-        for mode in ("f16x2", "bf16x3", "f32"):               # (f16x2: data gradients run the 3-bf16-limb kernel)
+        for mode in ("f16x2", "bf16x3", "f32"):               # (f16x2: the data gradient runs 2 f16 limbs with the dy tensor's own scale)
             capi.set_conv_arithmetic(mode)
             dx = torch.full((Cin, H, W), -7.0, device=DEV)
             capi.call("nvsr_conv3x3_dgrad", capi.ptr(T(dy)), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), capi.stream())

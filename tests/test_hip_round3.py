@@ -649,3 +649,31 @@ def test_f16_backward_matches_the_f32_backward(hip):
         rel = {m: float((res[m] - res["f32"]).norm() / res["f32"].norm()) for m in ("bf16x3", "f16x2")}
         print("planes %d N %d S %d: relative L2 vs the f32 backward %s" % (pr, N, S, rel))
         assert rel["f16x2"] <= 2e-5 and rel["f16x2"] <= 3.0 * rel["bf16x3"] + 1e-6, rel
+
+
+def test_f16_conv_data_gradient_scales_with_the_gradient(hip, oracle):
+    """The data gradient of a wide SR convolution on 2 f16 limbs (csrc/sr.hip: the dy tensor scaled by the power of two that puts its largest
+    magnitude into [2^12, 2^13), absmax_kernel) against the oracle, for gradients of magnitude 1, 1e-7 and 1e+5: the error relative to the
+    largest |dx| stays at the 3-bf16-limb kernel's level whatever the magnitude (a static scale would flush a 1e-7 gradient to zero)."""
+    rng = np.random.default_rng(8)
+    capi = hip.capi
+    Cin, Cout, H, W = 256, 256, 13, 40
+    w = (rng.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(9 * Cin)).astype(np.float32)
+    pk = torch.empty(capi.lib().nvsr_conv3x3_packed_floats(Cout, Cin), device=DEV)
+    wd = T(w)
+    capi.call("nvsr_pack_conv3x3_dgrad", capi.ptr(wd), Cin, Cout, capi.ptr(pk), capi.stream())
+    wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
+    dy0 = rng.standard_normal((Cout, H - 2, W - 2), dtype=np.float32)
+    for mag in (1.0, 1e-7, 1e5):
+        dy = (dy0 * np.float32(mag)).astype(np.float32)
+        ref = oracle.conv3x3(np.pad(dy, ((0, 0), (2, 2), (2, 2))), wt)
+        dyd = T(dy)
+        err = {}
+        for mode in ("bf16x3", "f16x2"):
+            for rows in ((0,) if mode == "bf16x3" else (0, 18, 19, 20, 22)):
+                dx = torch.full((Cin, H, W), -7.0, device=DEV)
+                capi.call("nvsr_conv3x3_dgrad_arith", capi.ptr(dyd), Cin, H, W, capi.ptr(pk), Cout, capi.ptr(dx), capi.ARITHMETIC[mode], rows, capi.stream())
+                e = float(np.abs(N_(dx).astype(np.float64) - ref).max() / np.abs(ref).max())
+                err[(mode, rows)] = e
+                assert e <= 1e-5, (mag, mode, rows, e)
+        assert max(v for k, v in err.items() if k[0] == "f16x2") <= 1.5 * err[("bf16x3", 0)] + 2e-7, (mag, err)
