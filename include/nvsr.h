@@ -121,7 +121,8 @@ int nvsr_limb_gemm_probe(int arithmetic, int K, const float* W, const float* X, 
  * (3 MFMAs per product block instead of 6; weights packed as W 2^8, the input patch held as x 2^4, same ranges and the same NaN-on-overflow
  * rule as above) -- and their data gradients too, with the power of two that puts the largest |dy| of the layer's whole gradient tensor into
  * [2^12, 2^13) in place of the static activation scale (one reduction per layer: gradients span many decades from layer to layer and step to
- * step, a tensor's values a few); weight gradients and the narrow input / output layers run 3 bf16 limbs in that mode.
+ * step, a tensor's values a few) and their weight gradients (X with the static scale, dy with its tensor's); the narrow input / output layers run
+ * 3 bf16 limbs in that mode.
  * Environment: NVSR_CONV_ARITHMETIC = f32 | bf16x3 | f16x2. */
 #define NVSR_CONV_ARITH_DEFAULT NVSR_ARITH_F16X2
 int nvsr_get_conv_arithmetic(void);

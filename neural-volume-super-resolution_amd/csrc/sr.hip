@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     // (a NaN input: fmaxf drops it -- the convolution itself then propagates it through its products)
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
-static const unsigned* launch_absmax(const float* x, long n, hipStream_t stream) {
+const unsigned* launch_absmax(const float* x, long n, hipStream_t stream) {
     static std::atomic<unsigned> next{0};
     unsigned* base = nullptr;
     if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_absmax)) != hipSuccess) return nullptr;

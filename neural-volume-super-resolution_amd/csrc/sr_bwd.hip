@@ -31,6 +31,7 @@ struct WgradParams {
     float* partial;      // [nslab][9][Cout][Cin]
     int Cin, Cout, Ho, Wo;
     int rows_per_slab;
+    const unsigned* dy_absmax;   // f16 limbs: bits of max |dy| over the whole tensor (sr.hip absmax_kernel) -> dy's power-of-two scale; else NULL
     int n_wg;            // conv3x3_wgrad_limb_kernel: workgroups = pieces of the linear range of `total` row steps
     long total;
 };
@@ -143,6 +144,16 @@ __device__ __forceinline__ void split4(const float (&e)[4], u32x2 (&out)[3]) {  
         out[2][j] = trunc_pair(r1, r0);
     }
 }
+// 2 f16 limbs (round to nearest, limb_core.h) of 4 values times a power of two
+__device__ __forceinline__ void split4_f16(const float (&e)[4], float scale, u32x2 (&out)[3]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float v0 = e[2 * j] * scale, v1 = e[2 * j + 1] * scale;
+        const unsigned hi = f16_pair(v1, v0);
+        out[0][j] = hi;
+        out[1][j] = f16_pair(f16_rest<1>(v1, hi), f16_rest<0>(v0, hi));
+    }
+}
 constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels
 constexpr int WL_DY_WORDS = WG_CO * WL_ROW;               // one limb of dy
 constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
@@ -168,13 +179,14 @@ constexpr int WL_X_WORDS = WG_CI * 3 * WL_ROW;            // one limb of X
 __device__ __forceinline__ long wgrad_piece_start(long w, long total, int n_wg) { return w * total / n_wg; }
 
 // rows [ya, yb) of column chunk x0 of tile (co0, ci0), accumulated into acc.
-__device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* lds, f32x16 (&acc)[9], int co0, int ci0, int x0, int ya, int yb
+template <int LF>
+__device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* lds, f32x16 (&acc)[9], int co0, int ci0, int x0, int ya, int yb, float dscale
 #if WG_STAMP
                                                 , float (&stamp)[8]
 #endif
                                                 ) {
     unsigned* dyl = lds;                                  // [limb][co][WL_ROW]
-    unsigned* xl = lds + 3 * WL_DY_WORDS;                 // [limb][ci][row][WL_ROW]
+    unsigned* xl = lds + LF * WL_DY_WORDS;                // [limb][ci][row][WL_ROW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
     const int W = p.Wo + 2;
@@ -233,10 +245,10 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             u32x2 L[3];
-            split4(src[k], L);
+            if constexpr (LF == 2) split4_f16(src[k], F16_X_SCALE, L); else split4(src[k], L);
             if (x_lane && xr + 28 * k < WG_CI) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(x_st + t * WL_X_WORDS + (28 * k * 3 + slot) * WL_ROW) = L[t];
+                for (int t = 0; t < LF; ++t) *reinterpret_cast<u32x2*>(x_st + t * WL_X_WORDS + (28 * k * 3 + slot) * WL_ROW) = L[t];
             }
         }
     };
@@ -259,9 +271,9 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) rdy[k][j] = j < dy_valid ? rdy[k][j] : 0.0f;
             u32x2 L[3];
-            split4(rdy[k], L);
+            if constexpr (LF == 2) split4_f16(rdy[k], dscale, L); else split4(rdy[k], L);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dy_st + t * WL_DY_WORDS + 32 * k * WL_ROW) = L[t];
+            for (int t = 0; t < LF; ++t) *reinterpret_cast<u32x2*>(dy_st + t * WL_DY_WORDS + 32 * k * WL_ROW) = L[t];
         }
     };
 
@@ -318,6 +330,36 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
         // 6 groups g = (K-block kb of 16 pixels, ky): 18 MFMAs each, products in the order of limb_w / limb_x (small terms first), which
         // starts with X limb 2: that limb's words of group g + 1 are requested before the MFMAs of group g, limbs 1 and 0 at the start of
         // their own group, under its first MFMAs
+        if constexpr (LF == 2) {
+            // 2 f16 limbs: 9 MFMAs per group -- dy_hi X_lo, dy_hi X_hi, dy_lo X_hi (limb_w / limb_x of 2 limbs); X_lo of the next group is
+            // requested before this group's MFMAs
+            static_assert(limb_x(2, 0) == 1 && limb_x(2, 1) == 0 && limb_x(2, 2) == 0 && limb_w(2, 0) == 0 && limb_w(2, 1) == 0 && limb_w(2, 2) == 1, "");
+            Raw nxt = read_x(1, rowoff[0]);
+            u32x4 A[2];
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int kb = g / 3, ky = g % 3, off = rowoff[ky] + kb * 8;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ky == 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) A[t] = *reinterpret_cast<const u32x4*>(Ap + t * WL_DY_WORDS + kb * 8);
+                }
+                Raw r0 = read_x(0, off);
+                u32x4 B1[3], B0[3];
+                taps(nxt, B1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_limb<2>(A[0], B1[kx], acc[ky * 3 + kx]);
+                if (g < 5) nxt = read_x(1, rowoff[(g + 1) % 3] + ((g + 1) / 3) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                taps(r0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_limb<2>(A[0], B0[kx], acc[ky * 3 + kx]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = mfma_limb<2>(A[1], B0[kx], acc[ky * 3 + kx]);
+            }
+        } else {
         Raw nxt = read_x(2, rowoff[0]);
         u32x4 A[3];
 #pragma unroll
@@ -360,6 +402,7 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
             for (int t = 0; t < 3; ++t) asm volatile("" :: "v"(A[t]), "v"(B0[t]), "v"(B1[t]), "v"(B2[t]));
 #endif
         }
+        }
         WG_MARK(4)
 #if WG_STAMP
         stamp[6] += 1.0f;
@@ -367,8 +410,14 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
     }
 }
 
+template <int LF>
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned lds[3 * (WL_DY_WORDS + WL_X_WORDS)];
+    __shared__ __attribute__((aligned(16))) unsigned lds[LF * (WL_DY_WORDS + WL_X_WORDS)];
+    float dscale = 1.0f;          // f16 limbs: the power of two that puts the largest |dy| of the tensor into [2^12, 2^13) (sr.hip, the data gradient's rule)
+    if (LF == 2 && p.dy_absmax) {
+        const int e = (int)((__builtin_amdgcn_readfirstlane((int)*p.dy_absmax) >> 23) & 0xff);
+        dscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
     const int nxc = (p.Wo + WG_PX - 1) / WG_PX, n_ci = (p.Cin + WG_CI - 1) / WG_CI;
@@ -397,9 +446,9 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
         const int cob = __builtin_amdgcn_readfirstlane(tile / n_ci);
         const int co0 = cob * WG_CO, ci0 = (tile - cob * n_ci) * WG_CI, x0 = chunk * WG_PX;
 #if WG_STAMP
-        wgrad_limb_rows(p, lds, acc, co0, ci0, x0, ya, yb, stamp);
+        wgrad_limb_rows<LF>(p, lds, acc, co0, ci0, x0, ya, yb, dscale, stamp);
 #else
-        wgrad_limb_rows(p, lds, acc, co0, ci0, x0, ya, yb);
+        wgrad_limb_rows<LF>(p, lds, acc, co0, ci0, x0, ya, yb, dscale);
 #endif
         s = seg_end;
         if (s == s1 || s == (tile + 1) * TS) {
@@ -423,7 +472,12 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 
 // dw[co][ci][tap] += scale * (sum over the pieces that overlap the element's tile, in piece order, of their slot for that tile)
 __global__ void wgrad_reduce_pieces_kernel(const float* __restrict__ partial, int n_wg, long total, long TS, int Cout, int Cin, float scale,
-                                           float* __restrict__ dw) {
+                                           float* __restrict__ dw, const unsigned* __restrict__ dy_absmax) {
+    if (dy_absmax) {          // f16 limbs: the partial sums carry 2^F16_SX (X) times dy's scale
+        const int e = (int)((*dy_absmax >> 23) & 0xff);
+        const float dscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+        scale *= 1.0f / (F16_X_SCALE * dscale);
+    }
     const int n_ci = (Cin + WG_CI - 1) / WG_CI;
     const int ci = blockIdx.x * 64 + (threadIdx.x & 63), co = blockIdx.y * 4 + (threadIdx.x >> 6), t = blockIdx.z;
     if (ci >= Cin || co >= Cout) return;
@@ -532,7 +586,7 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
     arith = conv_resolve_arith(arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
-    const bool limb = arith != NVSR_ARITH_F32;          // (weight gradients: 3 bf16 limbs in either limb mode)
+    const bool limb = arith != NVSR_ARITH_F32;
     const long n = 9L * Cout * Cin;
     if (limb) {
         int n_wg = wgrad_pieces(Cin, Cout, Ho, Wo);
@@ -541,13 +595,19 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
 #ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py; the tool sizes the workspace itself)
         if (getenv("NVSR_WGRAD_PIECES")) n_wg = atoi(getenv("NVSR_WGRAD_PIECES"));
 #endif
-        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, 0, n_wg, total};
-        hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
+        const unsigned* am = nullptr;
+        if (arith == NVSR_ARITH_F16X2) {       // 2 f16 limbs: X with the static activation scale, dy with its tensor's own (one reduction)
+            am = launch_absmax(dy, (long)Cout * Ho * Wo, stream);
+            if (!am) return NVSR_ERR_LAUNCH;
+        }
+        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, 0, am, n_wg, total};
+        if (am) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<2>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
+        else hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<3>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
         hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, stream, partial, n_wg, total, TS, Cout,
-                           Cin, scale, dw);
+                           Cin, scale, dw, am);
     } else {
         const int ns = wgrad_slabs(Cin, Cout, Ho);
-        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, 0, 0};
+        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, nullptr, 0, 0};
         hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns), dim3(WG_TPB), 0, stream, p);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
     }

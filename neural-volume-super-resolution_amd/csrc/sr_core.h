@@ -110,6 +110,9 @@ inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
 // kernels (the parity tests force every instantiation).
 struct ConvExec { int arith = -1; int rows = 0; };
 int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
+// bits of max |x| over a tensor, in a device word that stays valid for the launches queued behind it (sr.hip): the power-of-two scale of an
+// f16-limb gradient operand; NULL on a launch error
+const unsigned* launch_absmax(const float* x, long n, hipStream_t stream);
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{});
 

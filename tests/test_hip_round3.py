@@ -677,3 +677,15 @@ def test_f16_conv_data_gradient_scales_with_the_gradient(hip, oracle):
                 err[(mode, rows)] = e
                 assert e <= 1e-5, (mag, mode, rows, e)
         assert max(v for k, v in err.items() if k[0] == "f16x2") <= 1.5 * err[("bf16x3", 0)] + 2e-7, (mag, err)
+        # ... and the weight gradient dW = sum_pixels dy (x) X (csrc/sr_bwd.hip conv3x3_wgrad_limb_kernel<2>: X with the static scale, dy with its tensor's)
+        if mag == 1.0:
+            xin = rng.standard_normal((Cin, H, W), dtype=np.float32)
+            xd = T(xin)
+        _, dw_ref = oracle.conv3x3_backward(xin, w, dy)
+        ws = torch.empty(capi.lib().nvsr_conv3x3_wgrad_workspace_floats(Cin, H, W, Cout), device=DEV)
+        rel = {}
+        for mode in ("bf16x3", "f16x2"):
+            dw = torch.zeros((Cout, Cin, 3, 3), device=DEV)
+            capi.call("nvsr_conv3x3_wgrad_arith", capi.ptr(dyd), capi.ptr(xd), Cin, H, W, Cout, 1.0, capi.ptr(dw), capi.ptr(ws), capi.ARITHMETIC[mode], capi.stream())
+            rel[mode] = float(np.linalg.norm(N_(dw).astype(np.float64) - dw_ref) / np.linalg.norm(dw_ref))
+        assert rel["f16x2"] < 2e-6 and rel["f16x2"] <= 1.5 * rel["bf16x3"] + 2e-7, (mag, rel)
