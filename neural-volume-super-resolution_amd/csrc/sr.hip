@@ -930,7 +930,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (f16) {
             if (f16_dgrad) {
-                p.absmax = launch_absmax(in, in_bs * batch, stream);
+                p.absmax = cx.in_absmax ? cx.in_absmax : launch_absmax(in, in_bs * batch, stream);
                 if (!p.absmax) return NVSR_ERR_LAUNCH;
             }
             if (best_pb == 6) hipLaunchKernelGGL((conv3x3_limb16_kernel<6, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);

@@ -581,7 +581,7 @@ static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho, int Wo) {
 
 // dw += scale * dW(dy, x);  H, W = size of x
 static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* partial,
-                        hipStream_t stream, int arith) {
+                        hipStream_t stream, int arith, const unsigned* dy_absmax = nullptr) {
     const int Ho = H - 2, Wo = W - 2;
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
     arith = conv_resolve_arith(arith);
@@ -597,7 +597,7 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
 #endif
         const unsigned* am = nullptr;
         if (arith == NVSR_ARITH_F16X2) {       // 2 f16 limbs: X with the static activation scale, dy with its tensor's own (one reduction)
-            am = launch_absmax(dy, (long)Cout * Ho * Wo, stream);
+            am = dy_absmax ? dy_absmax : launch_absmax(dy, (long)Cout * Ho * Wo, stream);
             if (!am) return NVSR_ERR_LAUNCH;
         }
         WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, 0, am, n_wg, total};
@@ -705,6 +705,10 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
     int gi = -1;                   // index of g in buf (-1: the caller's d_out)
     auto next_buf = [&](int a, int b) { for (int k = 0; k < 3; ++k) if (k != a && k != b) return k; return 0; };
     int e;
+    // f16 limbs: ONE reduction per gradient tensor serves its weight-gradient and its data-gradient launch
+    const bool f16 = conv_resolve_arith(arith) == NVSR_ARITH_F16X2;
+    auto amax = [&](const float* gt, long n) -> const unsigned* { return f16 ? launch_absmax(gt, n, stream) : nullptr; };
+    auto with = [&](const unsigned* am) { ConvExec c = cx; c.in_absmax = am; return c; };
     for (int l = P.n - 1; l >= 0; --l) {
         const int ci = P.L[l].Cin, co = P.L[l].Cout, ih = P.ih[l], iw = P.iw[l];
         const bool need_dx = l > 0 || dx;
@@ -712,27 +716,31 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
             const long n = (long)co * (ih - 2) * (iw - 2);
             hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, co / 4, ih - 2, iw - 2, unsh);
             if ((e = NVSR_CHECK_LAUNCH())) return e;
-            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith))) return e;
+            const unsigned* am = amax(unsh, n);
+            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, am))) return e;
             const int o = next_buf(gi, -1);
-            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, cx))) return e;
+            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, with(am)))) return e;
             g = buf[o]; gi = o;
         } else if (P.epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
             const float* t1 = input_of(l);             // relu(conv1(xb)), [hid][ih][iw]
             const float* xb = input_of(l - 1);         // [hid][ih+2][iw+2]
-            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith))) return e;
+            const unsigned* am = amax(g, (long)co * (ih - 2) * (iw - 2));
+            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith, am))) return e;
             const int o1 = next_buf(gi, -1);
-            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, cx))) return e;
+            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, with(am)))) return e;
             const int l1 = l - 1;
-            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith))) return e;
+            const unsigned* am1 = amax(buf[o1], (long)P.L[l1].Cout * ih * iw);
+            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith, am1))) return e;
             const int o2 = next_buf(gi, o1);
-            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, cx))) return e;
+            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, with(am1)))) return e;
             g = buf[o2]; gi = o2;
             --l;                                        // conv1 is done too
         } else {                                        // plain conv (conv_input, conv_mid, conv_output)
-            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith))) return e;
+            const unsigned* am = amax(g, (long)co * (ih - 2) * (iw - 2));
+            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, am))) return e;
             if (need_dx) {
                 float* o = (l == 0) ? dx : buf[next_buf(gi, -1)];
-                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2, 1, cx))) return e;
+                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2, 1, with(am)))) return e;
                 if (l) { gi = next_buf(gi, -1); g = buf[gi]; }
             }
         }

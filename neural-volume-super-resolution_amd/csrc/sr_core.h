@@ -108,7 +108,7 @@ inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
 // ConvExec: per-call execution options of the convolutions (include/nvsr.h, the *_arith entry points).  arith = NVSR_ARITH_* or
 // NVSR_ARITH_INHERIT (the process default of nvsr_set_conv_arithmetic); rows = 0 (cost model) or 2 / 3 / 4 rows per workgroup tile of the wide
 // kernels (the parity tests force every instantiation).
-struct ConvExec { int arith = -1; int rows = 0; };
+struct ConvExec { int arith = -1; int rows = 0; const unsigned* in_absmax = nullptr; };      // in_absmax: launch_absmax of the input, if the caller has it already (f16 data gradients)
 int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
 // bits of max |x| over a tensor, in a device word that stays valid for the launches queued behind it (sr.hip): the power-of-two scale of an
 // f16-limb gradient operand; NULL on a launch error
