@@ -845,7 +845,7 @@ def test_plane_gradients_golden(hip):
                                                    randoms=rnd)
         np.testing.assert_allclose(N_(out[0]), g["c%d_rgb_coarse" % ci], rtol=0, atol=2e-5)
         loss = torch.nn.functional.mse_loss(out[0], target) + torch.nn.functional.mse_loss(out[3], target)
-        assert abs(float(loss) - float(g["c%d_loss" % ci])) < 2e-4
+        assert abs(float(loss.detach()) - float(g["c%d_loss" % ci])) < 2e-4
         loss.backward()
         for d in range(4):
             got = N_(mc.planes_[hip.models.get_plane_name(sid, d)].grad)
