@@ -328,29 +328,6 @@ def _sync_time(dist, dev, fn, warmup, steps):
     return elapsed
 
 
-def sample_without_replacement(total, n, dev, gen, margin=512):
-    """n distinct indices of range(total), uniform, in draw order -- the first n entries of a random permutation (what the reference's
-    np.random.choice(total, n, replace=False) returns, train_nerf.py:836-838) -- without permuting all `total` of them: drawing uniform
-    integers and dropping every repeat of an earlier draw is the same distribution.  n + margin draws, static shapes, no host sync; with
-    n = 4096 of 640 000 about 13 repeats are expected (fewer than n distinct values among n + 512 draws: probability < 1e-300).
-    (torch.randperm(640000)[:4096] costs 0.17 ms of device sorting per step, 6 % of the whole train step.)"""
-    if n + margin >= total:
-        return torch.randperm(total, device=dev, generator=gen)[:n]
-    m = n + margin
-    draws = torch.randint(0, total, (m,), device=dev, generator=gen)
-    order = torch.argsort(draws, stable=True)                      # equal values stay in draw order
-    sv = draws[order]
-    first = torch.ones(m, dtype=torch.bool, device=dev)
-    first[1:] = sv[1:] != sv[:-1]                                  # the earliest draw of every value
-    keep = torch.zeros(m, dtype=torch.bool, device=dev)
-    keep[order] = first
-    rank = torch.cumsum(keep, 0) - 1                               # position among the distinct draws, in draw order
-    sel = keep & (rank < n)
-    buf = torch.zeros(n + 1, dtype=draws.dtype, device=dev)        # slot n swallows the draws that are not selected
-    buf.scatter_(0, torch.where(sel, rank, torch.full_like(rank, n)), draws)
-    return buf[:n]
-
-
 def train_partition_check(nvsr_amd, dist, dev, rank, world, mc, mf, sid, scfg, opts, pose, H, W, focal, N, Nc, Nf, planes, dec, what):
     """Rehearsal only (NVSR_BENCH_REHEARSAL=1, tests/test_hip_round3.py): the 8e training partition is exact -- the gradients of a step on
     this rank's N rays, averaged over the ranks by distributed.allreduce_gradients, equal the one-rank gradients of the step on all
@@ -422,12 +399,9 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     # (fused=True: one kernel per parameter group instead of five multi-tensor passes over the 23 MB of planes)
     opt, popt = (torch.optim.Adam(dec, lr=5e-4, fused=True) if "decoder" in what else None), torch.optim.Adam(planes, lr=4e-3, fused=True)
     sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in planes + dec if p.grad is not None])) if world > 1 else None
-    def device_sampler(img, n_rays, consistency_ds=None):
-        # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the
-        # device: the host permutation of 640 000 indices costs more than the whole GPU step
-        flat = sample_without_replacement(img.shape[0] * img.shape[1], n_draw, dev, g)[lo: lo + n_rays]
-        sel = torch.stack([flat % img.shape[0], flat // img.shape[0]], -1)
-        return sel, img[sel[:, 0], sel[:, 1], :]
+    # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the device
+    # by the library's sampler (one kernel: pixels + targets): the host permutation of 640 000 indices costs more than the whole GPU step
+    device_sampler = nvsr_amd.training.DevicePixelSampler(seed=100 + (0 if strong else rank), n_draw=n_draw if strong else None, lo=lo)
 
     step = nvsr_amd.training.TrainStep(mc, mf, opts, what, optimizer=opt, planes_optimizer=popt, grad_sync=sync, pixel_sampler=device_sampler)
     np.random.seed(rank)
@@ -437,7 +411,8 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         # the random draws of the train mode come from the device generator here: the reference draws them on the host, which on
         # this box costs more than the whole GPU step
         rnd = dict(t_rand=torch.rand(n_draw, Nc, device=dev, generator=g), u=torch.rand(n_draw, Nf, device=dev, generator=g),
-                   noise_coarse=0.2 * torch.randn(n_draw, Nc, device=dev, generator=g), noise_fine=0.2 * torch.randn(n_draw, Nc + Nf, device=dev, generator=g))
+                   noise_coarse=torch.empty(n_draw, Nc, device=dev).normal_(0.0, 0.2, generator=g),
+                   noise_fine=torch.empty(n_draw, Nc + Nf, device=dev).normal_(0.0, 0.2, generator=g))
         if strong:
             rnd = {k: v[lo: lo + N].contiguous() for k, v in rnd.items()}
         step(it[0], target, pose, H, W, focal, 1, sid, scfg, N, randoms=rnd)

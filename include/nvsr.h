@@ -147,6 +147,27 @@ int nvsr_get_ray_bundle(int H, int W, double focal_x, double focal_y, const floa
  * lie outside the image (padding).  Bit-identical to the corresponding rows of nvsr_get_ray_bundle. */
 int nvsr_get_ray_bundle_at(int H, int W, double focal_x, double focal_y, const float* c2w, double offset, int64_t N, const int32_t* row_col,
                            float* ro, float* rd, nvsr_stream_t stream);
+/* Training pixels drawn on the device: entries [first, first + n) of a keyed pseudo-random PERMUTATION of range(total), total = H*W --
+ * n distinct pixels, the first n draws of `np.random.choice(H*W, n, replace=False)` (train_nerf.py:836-838) with the device as the
+ * generator (the reference permutes all H*W indices on the host every iteration: 640 000 for an 800x800 view, more than a whole step
+ * of this library).  Ranks that pass the same key and disjoint [first, first + n) draw disjoint shares of one global batch.
+ *   permutation: x -> F(x) repeated until F(x) < total ("cycle walking"), F = 8-round balanced Feistel network on 2*hb bits,
+ *   hb = the smallest integer >= 1 with 2^(2 hb) >= total; halves L = x >> hb, R = x & (2^hb - 1); round r = 0..7:
+ *     h = (uint32) R * 0x9E3779B1 + k_r;  h ^= h >> 15;  h *= 0x85EBCA77;  h ^= h >> 13;  h *= 0xC2B2AE3D;  h ^= h >> 16;
+ *     (L, R) <- (R, L ^ (h & (2^hb - 1)));      F(x) = L << hb | R after round 7;
+ *   k_r = high 32 bits of splitmix64(key + r)  (splitmix64(x): x += 0x9E3779B97F4A7C15; x = (x ^ x >> 30) * 0xBF58476D1CE4E5B9;
+ *   x = (x ^ x >> 27) * 0x94D049BB133111EB; x ^ x >> 31).  Integer arithmetic only: bit-exact against the CPU restatement.
+ * Index k of the permutation is pixel (row k % H, col k / H) -- the reference's column-by-column `coords` (train_nerf.py:818-828).
+ * row_col [n,2] int32 (what nvsr_get_ray_bundle_at takes).  target (or NULL) [n,channels] = image[row, col, :] of image [H,W,channels]
+ * (train_nerf.py:845 `target_s = img_target[select_inds...]`). */
+int nvsr_sample_pixels(int64_t total, int H, int W, uint64_t key, int64_t first, int64_t n, const float* image, int channels,
+                       int32_t* row_col, float* target, nvsr_stream_t stream);
+/* img2mse of two images against one target in one launch (train_nerf.py:893-905 computes F.mse_loss(rgb_coarse, target) and
+ * F.mse_loss(rgb_fine, target) separately): losses[0] = mean((a - t)^2), losses[1] = mean((b - t)^2) (b may be NULL: losses[1] untouched);
+ * g_a / g_b (or NULL) [n] = 2 (x - t) / n, the gradient of the loss with respect to its image.  n <= NVSR_MSE_PAIR_MAX_ELEMS elements
+ * (one workgroup sums them; a training batch is 3 x 4096). */
+#define NVSR_MSE_PAIR_MAX_ELEMS (1 << 22)
+int nvsr_mse_pair(int64_t n, const float* a, const float* b, const float* target, float* losses, float* g_a, float* g_b, nvsr_stream_t stream);
 /* ndc_rays (nerf_helpers.py:578-605) */
 int nvsr_ndc_rays(int H, int W, double focal, double near_, int64_t N, const float* ro, const float* rd, float* ro_out,
                   float* rd_out, nvsr_stream_t stream);

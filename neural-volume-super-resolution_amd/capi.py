@@ -19,6 +19,7 @@ DEC_CHANNELS = 128
 DECODER_NATURAL_FLOATS = 130564
 DECODER_PACKED_FLOATS = 453136
 DECODER_PACKED_BWD_FLOATS = 487424
+MSE_PAIR_MAX_ELEMS = 1 << 22          # NVSR_MSE_PAIR_MAX_ELEMS
 
 _STATUS = {1: "NVSR_ERR_SHAPE (argument out of the supported range)", 2: "NVSR_ERR_LAUNCH (kernel launch failed)",
            3: "NVSR_ERR_NULL (required pointer is NULL)", 4: "NVSR_ERR_ALIGN (pointer not 16-byte aligned)"}
@@ -54,6 +55,8 @@ _PROTOS = {
     "nvsr_pack_decoder": ([_vp, _vp, _vp], _i),
     "nvsr_get_ray_bundle": ([_i, _i, _d, _d, _vp, _i, _d, _vp, _vp, _vp], _i),
     "nvsr_get_ray_bundle_at": ([_i, _i, _d, _d, _vp, _d, _i64, _vp, _vp, _vp, _vp], _i),
+    "nvsr_sample_pixels": ([_i64, _i, _i, C.c_uint64, _i64, _i64, _vp, _i, _vp, _vp, _vp], _i),
+    "nvsr_mse_pair": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_ndc_rays": ([_i, _i, _d, _d, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_pack_rays": ([_i64, _vp, _vp, _vp, _d, _d, _vp, _vp], _i),
     "nvsr_coarse_z": ([_i64, _i, _vp, _i, _vp, _vp, _vp], _i),

@@ -100,6 +100,80 @@ __global__ void ray_bundle_at_kernel(int H, int W, float fx, float fy, const flo
     }
 }
 
+// ---- training inputs ---------------------------------------------------------------------------------------------------
+// Keyed bijection of [0, 2^(2*hb)): an 8-round balanced Feistel network over two hb-bit halves (nvsr.h: nvsr_sample_pixels states the
+// round function bit by bit; the CPU checker restates it).  Walking the cycle until the value is below `total` restricts it to a
+// bijection of [0, total): entries [first, first + n) of that permutation are n DISTINCT pixels, uniform over the keys.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ unsigned long long feistel8(unsigned long long x, int hb, const unsigned* __restrict__ rk) {
+    const unsigned mask = (hb >= 32) ? 0xFFFFFFFFu : ((1u << hb) - 1u);
+    unsigned L = (unsigned)(x >> hb) & mask, R = (unsigned)x & mask;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        unsigned h = R * 0x9E3779B1u + rk[r];
+        h ^= h >> 15; h *= 0x85EBCA77u;
+        h ^= h >> 13; h *= 0xC2B2AE3Du;
+        h ^= h >> 16;
+        const unsigned t = L ^ (h & mask);
+        L = R; R = t;
+    }
+    return ((unsigned long long)L << hb) | R;
+}
+
+__global__ void sample_pixels_kernel(long total, int hb, int H, int Wd, unsigned long long key, long first, long n,
+                                     const float* __restrict__ image, int C, int* __restrict__ rc, float* __restrict__ target) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned rk[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rk[r] = (unsigned)(splitmix64(key + (unsigned long long)r) >> 32);
+    unsigned long long x = (unsigned long long)(first + i);
+    do { x = feistel8(x, hb, rk); } while (x >= (unsigned long long)total);      // (x started below total: its cycle comes back below it)
+    // coords = stack(meshgrid_xy(arange(H), arange(W)), -1).reshape(-1, 2) enumerates pixels column by column (train_nerf.py:818-828)
+    const int row = (int)(x % (unsigned long long)H), col = (int)(x / (unsigned long long)H);
+    rc[2 * i] = row; rc[2 * i + 1] = col;
+    if (target) {
+        const float* px = image + ((long)row * Wd + col) * C;
+        for (int c = 0; c < C; ++c) target[i * C + c] = px[c];
+    }
+}
+
+// img2mse of the coarse and the fine image against one target in ONE launch, with the gradients the backward will want
+// (train_nerf.py:893-905: two F.mse_loss calls; here 2 (x - t) / n is written beside the forward sums): one 1024-thread workgroup.
+__global__ void __launch_bounds__(1024) mse_pair_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ t,
+                                                        float* __restrict__ losses, float* __restrict__ ga, float* __restrict__ gb) {
+    __shared__ float red[2][16];
+    const float inv = 1.0f / (float)n, two_inv = 2.0f / (float)n;
+    float sa = 0.0f, sb = 0.0f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float tv = t[i];
+        const float da = a[i] - tv;
+        sa += da * da;
+        if (ga) ga[i] = two_inv * da;
+        if (b) {
+            const float db = b[i] - tv;
+            sb += db * db;
+            if (gb) gb[i] = two_inv * db;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float s = 0.0f;
+        for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
+        if (threadIdx.x == 0 || b) losses[threadIdx.x] = s * inv;
+    }
+}
+
 __global__ void ndc_rays_kernel(float sx, float sy, float nr, float two_near, float m_two_near, long N, const float* __restrict__ ro,
                                 const float* __restrict__ rd, float* __restrict__ ro_out, float* __restrict__ rd_out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,6 +602,25 @@ int nvsr_get_ray_bundle_at(int H, int W, double focal_x, double focal_y, const f
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(ray_bundle_at_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, H, W, (float)focal_x, (float)focal_y,
                        c2w, (float)offset, (long)N, row_col, ro, rd);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_sample_pixels(int64_t total, int H, int W, uint64_t key, int64_t first, int64_t n, const float* image, int channels,
+                       int32_t* row_col, float* target, nvsr_stream_t stream) {
+    if (!row_col || (target && !image)) return NVSR_ERR_NULL;
+    if (H < 1 || W < 1 || total != (int64_t)H * W || first < 0 || n < 0 || first + n > total || (target && channels < 1)) return NVSR_ERR_SHAPE;
+    if (n == 0) return NVSR_OK;
+    int hb = 1;
+    while (hb < 31 && (1ll << (2 * hb)) < total) ++hb;          // 2^(2 hb) >= total, at most 4 total: < 4 walks expected
+    hipLaunchKernelGGL(sample_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (long)total, hb, H, W,
+                       (unsigned long long)key, (long)first, (long)n, image, channels, row_col, target);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_mse_pair(int64_t n, const float* a, const float* b, const float* target, float* losses, float* g_a, float* g_b, nvsr_stream_t stream) {
+    if (!a || !target || !losses || (g_b && !b)) return NVSR_ERR_NULL;
+    if (n < 1 || n > NVSR_MSE_PAIR_MAX_ELEMS) return NVSR_ERR_SHAPE;
+    hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)n, a, b, target, losses, g_a, g_b);
     return NVSR_CHECK_LAUNCH();
 }
 

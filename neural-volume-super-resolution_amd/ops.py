@@ -356,6 +356,25 @@ def _decode_rays_backward_launch(planes, consts, packed, packed_bwd, rays, z, g_
               capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(view_ws), capi.ptr(record), arithmetic, capi.stream())
 
 
+def zero_planes_like(planes, need, like):
+    """zero gradient planes laid out like `planes` (empty tensors where need[d] is False) for decode_rays_backward_: contiguous planes are
+    carved out of ONE zero-filled allocation (one fill kernel per step instead of four; every plane starts on a 16-byte boundary).  (An
+    operator may not RETURN tensors that share a storage, so the functional decode_rays_backward fills its four planes one by one.)"""
+    wanted = [p for d, p in enumerate(planes) if need[d]]
+    if len(wanted) < 2 or not all(p.is_contiguous() and p.dtype == torch.float32 for p in wanted):
+        return [torch.zeros_like(p) if need[d] else _f(0, like=like) for d, p in enumerate(planes)]
+    sizes = [(p.numel() + 3) // 4 * 4 for p in wanted]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=wanted[0].device)
+    out, off = [], 0
+    for d, p in enumerate(planes):
+        if not need[d]:
+            out.append(_f(0, like=like))
+            continue
+        out.append(flat[off: off + p.numel()].view(p.shape))
+        off += (p.numel() + 3) // 4 * 4
+    return out
+
+
 @custom_op("nvsr::decode_rays_backward", mutates_args=("record",), device_types="cuda")
 def decode_rays_backward(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, packed_bwd: Tensor, rays: Tensor, z: Tensor,
                          g_raw: Tensor, gates: Tensor, record: Optional[Tensor], need: Sequence[bool], arithmetic: int) -> List[Tensor]:
@@ -492,7 +511,7 @@ def composite_backward(raw: Tensor, z: Tensor, rd: Tensor, noise: Optional[Tenso
     raw, z, rd, noise, g_rgb, g_acc, g_depth = _c(raw), _c(z), _c(rd), _c(noise), _c(g_rgb), _c(g_acc), _c(g_depth)
     N = z.shape[0]
     S = z.shape[1] - (1 if mip else 0)
-    g_raw = torch.zeros_like(raw)
+    g_raw = torch.empty_like(raw)          # (the kernel writes all four channels of every sample)
     if N:
         if S > 512:
             raise NotImplementedError("nvsr_composite_backward handles up to 512 samples per ray")

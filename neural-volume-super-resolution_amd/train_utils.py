@@ -76,6 +76,9 @@ class _RenderRaysFn(torch.autograd.Function):
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
         nv = torch.ops.nvsr
         arith_c, arith_f = cfg["arith_c"], cfg["arith_f"]
+        # an output the loss does not use hands None to backward() instead of a zero tensor: the disparity / opacity chain rules are
+        # skipped for them (a dozen per-ray kernels per pass otherwise)
+        ctx.set_materialize_grads(False)
         _, fwd_max = _record_limits()
         z_c = nv.coarse_z(rays, Nc, bool(cfg["lindisp"]), cfg["t_rand"])
         # training batches are a few thousand rays: the sample-parallel decoder + the wave-per-ray compositor fill the chip, the fused
@@ -141,6 +144,12 @@ class _RenderRaysFn(torch.autograd.Function):
                 # gate-driven backward (no recomputation); with the forward's record it adds the gradient half, then ONE contraction
                 rec = fwd_rec if want_dec else None
                 have = [gplanes[d] is not None for d in range(4) if need_planes[d]]
+                if have and not any(have):
+                    # first pass of the step: one zero-filled allocation holds all gradient planes
+                    for d, g in enumerate(ops.zero_planes_like(planes, need_planes, rays)):
+                        if need_planes[d]:
+                            gplanes[d] = g
+                    have = [True] * len(have)
                 if have and all(have) and all(gplanes[d].shape == planes[d].shape and gplanes[d].stride() == planes[d].stride()
                                               for d in range(4) if need_planes[d]):
                     # a second pass over the same planes scatters into the first pass's gradient planes (no second zero-fill, no add)

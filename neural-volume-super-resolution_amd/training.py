@@ -6,7 +6,9 @@ What changes against the reference:
     and gathers `num_random_rays` of them (:814,:842-844); results are bit-identical;
   * everything else is the reference's arithmetic in the reference's order: pixel selection with numpy's global RNG (:816-846),
     coarse / fine MSE gating by `what2train` and `super_resolution.training.loss` (:884-891), virtual batches and per-module
-    optimizer gating (:848-853, :905-914), the SR-vs-no-SR double render and PSNR bookkeeping of `evaluate()` (:655-713)."""
+    optimizer gating (:848-853, :905-914), the SR-vs-no-SR double render and PSNR bookkeeping of `evaluate()` (:655-713);
+  * optional: `DevicePixelSampler` draws the pixels on the device (`nvsr_sample_pixels`: one kernel instead of a host permutation of H*W
+    indices), and the coarse + fine MSE of one step come from one launch (`mse_loss_pair`)."""
 from collections.abc import Mapping
 
 import numpy as np
@@ -78,11 +80,80 @@ def select_training_pixels(img_target, num_random_rays, consistency_ds=None):
     flat = np.random.choice(h * w, size=(n), replace=False)
     corners = torch.from_numpy(np.stack([flat % h, flat // h], -1)).to(dev)
     target_s = img_target[corners[:, 0], corners[:, 1], :]
+    return _expand_consistency_patches(corners, ds), target_s
+
+
+def _expand_consistency_patches(corners, ds):
+    """train_nerf.py:829-835: every drawn LR pixel becomes its (ds x ds) patch of HR pixel coordinates"""
     corners = ds * corners[:, None, None, :]
-    ar = torch.arange(ds, device=dev, dtype=corners.dtype)
+    ar = torch.arange(ds, device=corners.device, dtype=corners.dtype)
     rows = corners[..., :1] + ar.reshape(1, -1, 1, 1).repeat(1, 1, ds, 1)
     cols = corners[..., 1:] + ar.reshape(1, 1, -1, 1).repeat(1, ds, 1, 1)
-    return torch.cat([rows, cols], -1).reshape(-1, 2), target_s
+    return torch.cat([rows, cols], -1).reshape(-1, 2)
+
+
+class DevicePixelSampler:
+    """`pixel_sampler` of TrainStep drawing on the device: n distinct pixels of the target image, uniform, per call -- the reference's
+    `np.random.choice(H * W, n, replace=False)` (train_nerf.py:836-838) with `nvsr_sample_pixels` as the generator: ONE kernel writes the
+    (row, col) pairs in the reference's column-by-column enumeration and gathers `target_s`, where the reference permutes all H*W indices
+    on the host (640 000 for an 800 x 800 view: several ms, more than the whole step here).  Not the reference's random stream: a seeded run
+    trains on different (equally distributed) pixels than a seeded reference run; `select_training_pixels` keeps the reference's draws.
+
+    seed     the draws of call k are entries of the permutation keyed by (seed, k)
+    n_draw, lo   data-parallel training on ONE global batch: every rank constructs the sampler with the same seed, n_draw = the global
+             number of rays and lo = its first ray; a call then returns rays [lo, lo + num_random_rays) of the global draw."""
+
+    def __init__(self, seed=0, n_draw=None, lo=0):
+        self.seed, self.n_draw, self.lo, self.calls = int(seed), n_draw, int(lo), 0
+
+    def key(self):
+        return (self.seed * 0x9E3779B97F4A7C15 + self.calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def __call__(self, img_target, num_random_rays, consistency_ds=None):
+        img = capi.f32c(img_target)
+        if not img.is_cuda:
+            raise RuntimeError("DevicePixelSampler draws on the GPU: the target image must be a CUDA tensor (select_training_pixels draws on the host)")
+        h, w, ch = img.shape
+        ds = 1 if consistency_ds is None else int(consistency_ds)
+        n = min(h * w, num_random_rays // (ds ** 2))
+        first = self.lo if self.n_draw is not None else 0
+        if first + n > h * w:
+            raise ValueError("DevicePixelSampler: rays [%d, %d) of a draw from %d pixels" % (first, first + n, h * w))
+        rc = torch.empty((n, 2), dtype=torch.int32, device=img.device)
+        target_s = torch.empty((n, ch), dtype=torch.float32, device=img.device)
+        capi.call("nvsr_sample_pixels", h * w, h, w, self.key(), first, n, capi.ptr(img), ch, capi.ptr(rc), capi.ptr(target_s), capi.stream())
+        self.calls += 1
+        return (rc if consistency_ds is None else _expand_consistency_patches(rc, ds)), target_s
+
+
+class _MsePair(torch.autograd.Function):
+    """(F.mse_loss(a, t), F.mse_loss(b, t)) from one launch; the gradients 2 (x - t) / n are written by the same kernel"""
+
+    @staticmethod
+    def forward(ctx, a, b, t):
+        a, b, t = capi.f32c(a), capi.f32c(b), capi.f32c(t)
+        losses = torch.empty(2, dtype=torch.float32, device=a.device)
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ga = torch.empty_like(a) if need_a else None
+        gb = torch.empty_like(b) if need_b else None
+        capi.call("nvsr_mse_pair", a.numel(), capi.ptr(a), capi.ptr(b), capi.ptr(t), capi.ptr(losses), capi.ptr(ga), capi.ptr(gb), capi.stream())
+        ctx.save_for_backward(ga, gb)
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        ga, gb = ctx.saved_tensors
+        return (None if ga is None or g0 is None else ga * g0), (None if gb is None or g1 is None else gb * g1), None
+
+
+def mse_loss_pair(a, b, target):
+    """(mse_loss(a, target), mse_loss(b, target)) -- train_nerf.py:893-905's coarse and fine losses.  One `nvsr_mse_pair` launch for float32
+    CUDA images of one shape (a training batch); anything else goes through torch like mse_loss()."""
+    if (a.is_cuda and a.shape == b.shape == target.shape and a.dtype == b.dtype == target.dtype == torch.float32
+            and 0 < a.numel() <= capi.MSE_PAIR_MAX_ELEMS and not target.requires_grad):
+        return _MsePair.apply(a, b, target)
+    return mse_loss(a, target), mse_loss(b, target)
 
 
 class StepMetrics(Mapping):
@@ -187,12 +258,17 @@ class TrainStep:
         coarse_loss = fine_loss = None
         trains_scene = bool(self.what & {"decoder", "LR_planes"})
         if self.rendering_loss_w is not None:
-            if trains_scene or self.sr_loss != "fine":
+            want_c = trains_scene or self.sr_loss != "fine"
+            want_f = rgb_fine is not None and (trains_scene or self.sr_loss != "coarse")
+            if want_c and want_f:
+                coarse_loss, fine_loss = mse_loss_pair(rgb_coarse, rgb_fine, target)
+            elif want_c:
                 coarse_loss = mse_loss(rgb_coarse, target)
-            if rgb_fine is not None and (trains_scene or self.sr_loss != "coarse"):
+            elif want_f:
                 fine_loss = mse_loss(rgb_fine, target)
         rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
-        loss = (self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w) * rendering_loss
+        loss_w = self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w
+        loss = rendering_loss if loss_w == 1.0 else loss_w * rendering_loss        # (x * 1.0 is x: one kernel and its backward less)
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()

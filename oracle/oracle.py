@@ -304,3 +304,49 @@ class Oracle:
         out = np.empty((x.shape[0], 4), np.float32)
         self.lib.orc_flexible_nerf(C.c_long(x.shape[0]), _p(x), dim_xyz, dim_dir, hidden, num_layers, skip_every, _p(blob), _p(out))
         return out
+
+
+# ---- training inputs: the device pixel sampler (include/nvsr.h: nvsr_sample_pixels) and the paired MSE ---------------------------
+# Not a restatement of reference code (the reference draws with numpy's host generator, train_nerf.py:836-838): the restatement of the
+# permutation nvsr.h specifies, in numpy integer arithmetic, so that the HIP kernel is checked bit for bit.
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def pixel_permutation(total, key, first, n):
+    """entries [first, first + n) of the keyed permutation of range(total): 8-round balanced Feistel network + cycle walking -> int64 [n]"""
+    hb = 1
+    while hb < 31 and (1 << (2 * hb)) < total:
+        hb += 1
+    mask = np.uint64((1 << hb) - 1)
+    rk = [np.uint64(_splitmix64((key + r) & _M64) >> 32) for r in range(8)]
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def feistel(x):
+        L, R = (x >> np.uint64(hb)) & mask, x & mask
+        for r in range(8):
+            h = (R * np.uint64(0x9E3779B1) + rk[r]) & m32
+            h ^= h >> np.uint64(15); h = (h * np.uint64(0x85EBCA77)) & m32
+            h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE3D)) & m32
+            h ^= h >> np.uint64(16)
+            L, R = R, L ^ (h & mask)
+        return (L << np.uint64(hb)) | R
+
+    x = feistel(np.arange(first, first + n, dtype=np.uint64))
+    while True:
+        out = x >= np.uint64(total)
+        if not out.any():
+            return x.astype(np.int64)
+        x[out] = feistel(x[out])
+
+
+def sample_pixels(total, H, key, first, n):
+    """-> (row, col) [n,2] of nvsr_sample_pixels: index k of the permutation is pixel (k % H, k // H) (train_nerf.py:818-828)"""
+    k = pixel_permutation(total, key, first, n)
+    return np.stack([k % H, k // H], -1)

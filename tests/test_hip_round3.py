@@ -689,3 +689,86 @@ def test_f16_conv_data_gradient_scales_with_the_gradient(hip, oracle):
             capi.call("nvsr_conv3x3_wgrad_arith", capi.ptr(dyd), capi.ptr(xd), Cin, H, W, Cout, 1.0, capi.ptr(dw), capi.ptr(ws), capi.ARITHMETIC[mode], capi.stream())
             rel[mode] = float(np.linalg.norm(N_(dw).astype(np.float64) - dw_ref) / np.linalg.norm(dw_ref))
         assert rel["f16x2"] < 2e-6 and rel["f16x2"] <= 1.5 * rel["bf16x3"] + 2e-7, (mag, rel)
+
+
+def test_device_pixel_sampler_is_the_specified_permutation(hip):
+    """nvsr_sample_pixels (include/nvsr.h) against its numpy restatement: integer work, bit-exact -- (row, col) pairs of entries
+    [first, first + n) of the keyed permutation, for the training size (4096 of 800 x 800), a window in the middle of it, a whole small
+    non-square image (every pixel exactly once) and a one-pixel image; the gathered targets are image[row, col, :]."""
+    from oracle.oracle import sample_pixels
+    capi = hip.capi
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for H, W, key, first, n in ((800, 800, 0x1234567890ABCDEF, 0, 4096), (800, 800, 7, 300000, 4096), (5, 7, 99, 0, 35), (1, 1, 5, 0, 1),
+                                (37, 3, 2 ** 64 - 1, 11, 50)):
+        img = torch.rand(H, W, 4, device=DEV, generator=g)
+        rc = torch.full((n, 2), -1, dtype=torch.int32, device=DEV)
+        tgt = torch.empty((n, 4), device=DEV)
+        capi.call("nvsr_sample_pixels", H * W, H, W, key, first, n, capi.ptr(img), 4, capi.ptr(rc), capi.ptr(tgt), capi.stream())
+        want = sample_pixels(H * W, H, key, first, n)
+        got = rc.cpu().numpy()
+        assert np.array_equal(got, want), (H, W, key)
+        assert torch.equal(tgt, img[rc[:, 0].long(), rc[:, 1].long()])
+        assert len({(int(r), int(c)) for r, c in got}) == n and got[:, 0].max() < H and got[:, 1].max() < W and got.min() >= 0
+    # argument checks of the boundary
+    lib = capi.lib()
+    assert lib.nvsr_sample_pixels(10, 5, 2, 0, 8, 4, None, 0, rc.data_ptr(), None, None) != 0        # first + n > total
+    assert lib.nvsr_sample_pixels(11, 5, 2, 0, 0, 4, None, 0, rc.data_ptr(), None, None) != 0        # total != H * W
+    assert lib.nvsr_sample_pixels(10, 5, 2, 0, 0, 4, None, 3, rc.data_ptr(), tgt.data_ptr(), None) != 0   # targets without an image
+
+
+def test_device_pixel_sampler_in_a_train_step(hip):
+    """training.DevicePixelSampler as TrainStep's pixel_sampler: a new draw per call, the same draws for the same seed, rank shares of one
+    global draw are disjoint and tile it; image-consistency iterations expand every drawn LR pixel to its ds x ds patch like
+    select_training_pixels; uniformity over many calls (chi-square over 64 column bands, 63 degrees of freedom: < 120 is p > 1e-5)."""
+    tr = hip.training
+    img = torch.rand(96, 64, 3, device=DEV)
+    a, b = tr.DevicePixelSampler(seed=5), tr.DevicePixelSampler(seed=5)
+    s1, t1 = a(img, 512)
+    s2, _ = a(img, 512)
+    r1, _ = b(img, 512)
+    assert s1.dtype == torch.int32 and s1.shape == (512, 2) and torch.equal(s1, r1) and not torch.equal(s1, s2)
+    assert torch.equal(t1, img[s1[:, 0].long(), s1[:, 1].long()])
+    assert len(set(map(tuple, s1.tolist()))) == 512
+    whole, _ = tr.DevicePixelSampler(seed=9, n_draw=512, lo=0)(img, 512)
+    parts = [tr.DevicePixelSampler(seed=9, n_draw=512, lo=lo)(img, 128)[0] for lo in (0, 128, 256, 384)]
+    assert torch.equal(torch.cat(parts, 0), whole)
+    sel, tgt = tr.DevicePixelSampler(seed=1)(img[:48, :32], 64, consistency_ds=2)
+    assert sel.shape == (64, 2) and tgt.shape == (16, 3)
+    blocks = sel.reshape(16, 2, 2, 2)
+    assert bool((blocks[:, :, :, 0] == blocks[:, :1, :1, 0] + torch.arange(2, device=DEV).reshape(1, 2, 1)).all())
+    assert bool((blocks[:, :, :, 1] == blocks[:, :1, :1, 1] + torch.arange(2, device=DEV).reshape(1, 1, 2)).all())
+    assert torch.equal(tgt, img[:48, :32][(blocks[:, 0, 0, 0] // 2).long(), (blocks[:, 0, 0, 1] // 2).long()])
+    big = torch.zeros(800, 800, 3, device=DEV)
+    smp = tr.DevicePixelSampler(seed=2)
+    cnt = torch.zeros(64, device=DEV)
+    for _ in range(100):
+        s, _ = smp(big, 4096)
+        cnt += torch.bincount((s[:, 1].long() * 64) // 800, minlength=64)
+    e = float(cnt.sum()) / 64
+    assert float(((cnt - e) ** 2 / e).sum()) < 120.0
+    with pytest.raises(RuntimeError):
+        smp(big.cpu(), 16)
+
+
+def test_mse_loss_pair_matches_two_mse_losses(hip):
+    """training.mse_loss_pair = (F.mse_loss(a, t), F.mse_loss(b, t)) in one launch, values and gradients (float32 sums in another order:
+    relative 1e-6); a loss that is not used gets no gradient; shapes the kernel does not take fall back to torch."""
+    tr = hip.training
+    g = torch.Generator(device=DEV).manual_seed(8)
+    for n in (1, 7, 4096, 70001):
+        a = torch.rand(n, 3, device=DEV, generator=g, requires_grad=True)
+        b = torch.rand(n, 3, device=DEV, generator=g, requires_grad=True)
+        t = torch.rand(n, 3, device=DEV, generator=g)
+        la, lb = tr.mse_loss_pair(a, b, t)
+        ra, rb = torch.nn.functional.mse_loss(a.double(), t.double()), torch.nn.functional.mse_loss(b.double(), t.double())
+        assert abs(float(la) - float(ra)) <= 2e-6 * float(ra) and abs(float(lb) - float(rb)) <= 2e-6 * float(rb)
+        (0.25 * la + 3.0 * lb).backward()
+        assert torch.allclose(a.grad, 0.25 * 2 * (a.detach() - t) / (3 * n), rtol=1e-6, atol=1e-12)
+        assert torch.allclose(b.grad, 3.0 * 2 * (b.detach() - t) / (3 * n), rtol=1e-6, atol=1e-12)
+    a = torch.rand(64, 3, device=DEV, requires_grad=True)
+    b = torch.rand(64, 3, device=DEV, requires_grad=True)
+    la, lb = tr.mse_loss_pair(a, b, torch.rand(64, 3, device=DEV))
+    la.backward()
+    assert b.grad is None and a.grad is not None
+    la, lb = tr.mse_loss_pair(a.cpu(), b.cpu(), torch.rand(64, 3))                 # not a CUDA batch: torch's own mse_loss
+    assert la.device.type == "cpu" and la.requires_grad

@@ -245,27 +245,27 @@ def test_dataset_loaders_match_reference(pkg, tmp_path):
     assert hwf[0] == images.shape[1] and hwf[1] == images.shape[2]
 
 
-def test_bench_pixel_sampler_is_a_permutation_prefix():
-    """bench.sample_without_replacement: the n distinct values are exactly the draws in draw order with every repeat of an earlier draw
-    dropped (= a prefix of a uniform random permutation); small ranges fall back to randperm"""
+def test_pixel_permutation_restatement_is_a_uniform_bijection():
+    """The checker's restatement of nvsr_sample_pixels' permutation (include/nvsr.h; the GPU test holds the kernel to it bit for bit):
+    every size is a bijection of range(total) -- also sizes right at / above a power of four, where the cycle walk is longest --, windows
+    of it are slices of the whole, another key is another permutation, and the first 4096 of 640 000 are uniform over 200 keys
+    (chi-square over 64 bands, 63 degrees of freedom)."""
     import sys
     sys.path.insert(0, ROOT)
-    from bench import sample_without_replacement
-    g = torch.Generator().manual_seed(7)
-    total, n = 5000, 900                                  # small range: ~80 repeats among the first 900 draws
-    state = g.get_state()
-    out = sample_without_replacement(total, n, "cpu", g, margin=512)
-    g.set_state(state)
-    draws = torch.randint(0, total, (n + 512,), generator=g).tolist()
-    seen, ref = set(), []
-    for v in draws:
-        if v not in seen:
-            seen.add(v); ref.append(v)
-    assert out.tolist() == ref[:n] and len(set(out.tolist())) == n
-    full = sample_without_replacement(100, 100, "cpu", g)
-    assert sorted(full.tolist()) == list(range(100))
-    big = sample_without_replacement(640000, 4096, "cpu", g)
-    assert big.shape == (4096,) and len(set(big.tolist())) == 4096 and 0 <= int(big.min()) and int(big.max()) < 640000
+    from oracle.oracle import pixel_permutation, sample_pixels
+    for total in (1, 2, 5, 16, 17, 1000, 4096, 4097, 65537):
+        p = pixel_permutation(total, 0xABCDEF0123456789, 0, total)
+        assert sorted(p.tolist()) == list(range(total))
+    whole = pixel_permutation(640000, 42, 0, 20000)
+    assert np.array_equal(pixel_permutation(640000, 42, 5000, 300), whole[5000:5300])
+    assert not np.array_equal(pixel_permutation(640000, 43, 0, 20000), whole)
+    rc = sample_pixels(35, 5, 3, 0, 35)
+    assert sorted((r * 7 + c) for r, c in rc.tolist()) == list(range(35)) and rc[:, 0].max() == 4 and rc[:, 1].max() == 6
+    cnt = np.zeros(64)
+    for k in range(200):
+        cnt += np.bincount(pixel_permutation(640000, (k * 0x9E3779B97F4A7C15) % 2 ** 64, 0, 4096) * 64 // 640000, minlength=64)
+    e = cnt.sum() / 64
+    assert ((cnt - e) ** 2 / e).sum() < 120.0
 
 
 # ---- files written by the reference itself (tests/golden/g17_store/, generated by gen_golden.py::g17_store) --------------------------
