@@ -48,6 +48,8 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CUs x 4 SIMDs x 1024 FLOP/clk 
 # `roofline.frac` stays priced against the 2.4 GHz dense peak.
 SUSTAINED_BF16_MFMA = {"tflops_random_operands": 1734.9, "tflops_zero_operands": 2493.3, "frac_of_peak_random": 0.689,
                        "tflops_random_operands_16x16x32_two_waves_per_simd": 2050.0,
+                       # the f16 instructions of the 2-limb arithmetic sustain less (11-bit multipliers): third run of the same file
+                       "f16_tflops_random_operands": 1609.2, "f16_tflops_random_operands_16x16x32_two_waves_per_simd": 1837.2,
                        "source": "profiles/r03_mfma_power_roof.txt (tools/mfma_power_roof.hip: bare v_mfma_f32_32x32x16_bf16 streams, 256 CUs; builder-run "
                                  "on another MI355X box, not measured by this process)"}
 # Arithmetic of the fused render pass (include/nvsr.h NVSR_ARITH_*): kernel, executed MFMA work per algorithmic FLOP, pipe peak.
@@ -559,7 +561,7 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
             result["roofline"]["kernel"] = ("conv3x3_limb16_kernel<., ., %d> (v_mfma_f32_16x16x32_%s; 67 of the 70 launches per step) + conv3x3_limb_kernel (3 launches, 3 bf16 limbs)"
                                             % ((2, "f16") if mode == "f16x2" else (3, "bf16")))
             result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_16x16x32=ach * arith["products"] /
-                                                             SUSTAINED_BF16_MFMA["tflops_random_operands_16x16x32_two_waves_per_simd"])
+                                                             SUSTAINED_BF16_MFMA[("f16_" if mode == "f16x2" else "") + "tflops_random_operands_16x16x32_two_waves_per_simd"])
         if world == 1 and not args.no_modes:
             modes = {}
             for m2 in ("f32", "bf16x3", "f16x2"):
@@ -811,7 +813,8 @@ def main():
                                            % (arith["pipe_peak"], arith["products"]),
                               "executed_mfma_tflops": achieved * arith["products"], "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
         if arith["pipe_peak"] == PEAK_BF16_MFMA_TFLOPS:
-            result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_random=achieved * arith["products"] / SUSTAINED_BF16_MFMA["tflops_random_operands"])
+            result["roofline"]["sustained_pipe_rate"] = dict(SUSTAINED_BF16_MFMA, executed_over_sustained_random=achieved * arith["products"] /
+                                                             SUSTAINED_BF16_MFMA[("f16_" if arith["products"] == 3 else "") + "tflops_random_operands"])
         # bandwidth-bound stages: the helper kernels alone, and the fused pass's plane sampling + compositing as the HBM traffic the
         # counters saw (profiles/pmc_latest.json) over the live kernel time
         result["hbm_stages"] = hbm_stage_rates(nvsr_amd, H, W, focal, pose, ro, rd, rays, ws)

@@ -9,11 +9,31 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// -DROOF_F16=1: the same streams with v_mfma_f32_{32x32x16,16x16x32}_f16 (the 2-f16-limb arithmetic's instruction): an 11-bit significand
+// multiplier array toggles more than bf16's 8-bit one
+#ifndef ROOF_F16
+#define ROOF_F16 0
+#endif
+#if ROOF_F16
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+#define ROOF_TYPE "f16"
+#else
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+#define ROOF_TYPE "bf16"
+#endif
 
 __device__ __forceinline__ unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 // two bf16 values with random sign / mantissa and exponent 126..127 (|v| in [0.5, 2))
 __device__ __forceinline__ unsigned rnd_pair(unsigned s) {
     const unsigned r = hash(s);
+#if ROOF_F16
+    // f16: random sign and 10-bit mantissa, exponent field 14..15 (|v| in [0.5, 2))
+    const unsigned l16 = (r & 0x83ffu) | (0x3800u + ((r >> 2) & 0x400u)), h16 = ((r >> 16) & 0x83ffu) | (0x3800u + ((r >> 18) & 0x400u));
+    return l16 | (h16 << 16);
+#endif
     const unsigned lo = (r & 0x807fu) | (0x3f00u + ((r >> 8) & 0x80u)), hi = ((r >> 16) & 0x807fu) | (0x3f00u + ((r >> 24) & 0x80u));
     return lo | (hi << 16);
 }
@@ -34,7 +54,7 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void roof(float* out, int 
         for (int u = 0; u < 16; ++u)
 #pragma unroll
             for (int k = 0; k < NACC; ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(u + k) & 3]), __builtin_bit_cast(bf16x8, b[(u * 3 + k) & 3]), acc[k], 0, 0, 0);
+                acc[k] = MFMA32(a[(u + k) & 3], b[(u * 3 + k) & 3], acc[k]);
         if (!zeros) {           // keep the accumulators bounded (values stay O(1): random-sign products) and the operands changing
             a[it & 3][it & 3] ^= 0x00010001u;
         }
@@ -62,7 +82,7 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void roof16(float* out, in
         for (int u = 0; u < 16; ++u)
 #pragma unroll
             for (int k = 0; k < NACC; ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[(u + k) & 3]), __builtin_bit_cast(bf16x8, b[(u * 3 + k) & 3]), acc[k], 0, 0, 0);
+                acc[k] = MFMA16(a[(u + k) & 3], b[(u * 3 + k) & 3], acc[k]);
         if (!zeros) a[it & 3][it & 3] ^= 0x00010001u;
     }
     float s = 0.0f;
@@ -89,8 +109,8 @@ static void run16(const char* name, int zeros) {
     }
     const double mfmas = (double)dev_cus * 4 * WPS * iters * 16 * NACC;
     const double flop = mfmas * 2.0 * 16 * 16 * 32;
-    printf("16x16x32 %-35s %s: %8.2f ms (last %8.2f)  %7.1f TFLOP/s dense bf16 = %5.1f %% of 2516.6 ; / 6 = %6.1f TFLOP/s of 3-limb f32 work ; %.2f ns per MFMA and SIMD -> %.2f GHz x (16 cycles)\n",
-           name, zeros ? "zeros " : "random", best, last, flop / best / 1e9, 100.0 * flop / best / 1e9 / 2516.6, flop / best / 1e9 / 6.0,
+    printf("16x16x32 %-35s %s: %8.2f ms (last %8.2f)  %7.1f TFLOP/s dense " ROOF_TYPE " = %5.1f %% of 2516.6 ; / 6 = %6.1f, / 3 = %6.1f TFLOP/s of limb f32 work ; %.2f ns per MFMA and SIMD -> %.2f GHz x (16 cycles)\n",
+           name, zeros ? "zeros " : "random", best, last, flop / best / 1e9, 100.0 * flop / best / 1e9 / 2516.6, flop / best / 1e9 / 6.0, flop / best / 1e9 / 3.0,
            best * 1e6 / (iters * 16.0 * NACC * WPS), 16.0 / (best * 1e6 / (iters * 16.0 * NACC * WPS)));
     hipFree(out);
 }
@@ -117,8 +137,8 @@ static void run(const char* name, int zeros) {
     }
     const double mfmas = (double)dev_cus * 4 * WPS * iters * 16 * NACC;          // per launch
     const double flop = mfmas * 2.0 * 32 * 32 * 16;
-    printf("%-44s %s: %8.2f ms (last %8.2f)  %7.1f TFLOP/s dense bf16 = %5.1f %% of 2516.6 ; / 6 = %6.1f TFLOP/s of 3-limb f32 work ; %.2f ns per MFMA and SIMD -> %.2f GHz x (32 cycles)\n",
-           name, zeros ? "zeros " : "random", best, last, flop / best / 1e9, 100.0 * flop / best / 1e9 / 2516.6, flop / best / 1e9 / 6.0,
+    printf("%-44s %s: %8.2f ms (last %8.2f)  %7.1f TFLOP/s dense " ROOF_TYPE " = %5.1f %% of 2516.6 ; / 6 = %6.1f, / 3 = %6.1f TFLOP/s of limb f32 work ; %.2f ns per MFMA and SIMD -> %.2f GHz x (32 cycles)\n",
+           name, zeros ? "zeros " : "random", best, last, flop / best / 1e9, 100.0 * flop / best / 1e9 / 2516.6, flop / best / 1e9 / 6.0, flop / best / 1e9 / 3.0,
            best * 1e6 / (iters * 16.0 * NACC * WPS), 32.0 / (best * 1e6 / (iters * 16.0 * NACC * WPS)));
     hipFree(out);
 }
