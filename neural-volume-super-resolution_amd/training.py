@@ -238,7 +238,7 @@ class TrainStep:
             H, W, focal, cur_ds_factor = H * self.ds_factor, W * self.ds_factor, focal * self.ds_factor, cur_ds_factor // self.ds_factor
         sel, target_s = self.pixel_sampler(img_target, num_random_rays, self.ds_factor if im_consistency_iter else None)
         ro, rd = get_ray_bundle_at(H, W, focal, pose_target, sel, downsampling_offset=downsampling_offset(cur_ds_factor))
-        batch_rays = torch.stack([ro, rd], 0)
+        batch_rays = (ro, rd)               # (run_one_iter_of_nerf indexes [0] / [1]: the reference's stacked tensor costs a copy kernel)
         if first_v:
             for o in (self.optimizer, self.SR_optimizer):
                 if o is not None:
