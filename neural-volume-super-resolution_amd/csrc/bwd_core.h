@@ -217,6 +217,75 @@ __device__ __forceinline__ void scatter_plane_cached(const f32x16 (&acc2)[2], fl
     __builtin_amdgcn_wave_barrier();
 }
 
+// scatter_plane_cached with the per-point bookkeeping done ONCE PER TILE on the vector unit (lane = point) instead of per point on the scalar
+// unit: the parity permutation of (texel, weight) is 16 selects per tile instead of 16 s_cselect per point, "slot j changes at this point" is
+// one compare against the previous point's lane (ds_bpermute) packed into 4 flag bits.  The loop then reads 1 flag word + 4 weights per point
+// (v_readlane; the texel offsets only when a slot is flushed) -- 5 lane reads, 4 FMAs and 4 bit tests per point where the scalar version spent
+// 8 lane reads, ~16 conditional moves and 4 compares.  Same sums in the same order: the results differ only through the order of the atomics.
+__device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], float* tile, const Taps& t, float* __restrict__ gplane, int lane,
+                                                      bool valid) {
+    const int h = lane >> 5, pt = lane & 31;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
+            const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+            tile[pt * C + c] = acc2[b][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    // this lane's point: (texel, weight) of slot j = tap j ^ par
+    const int par = t.o00 & 3;
+    const bool sx = par & 1, sy = par & 2;
+    const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
+    const int q0 = t.o00 & ~3, q1 = t.o01, q2 = t.o10, q3 = t.o11;
+    const int x0 = sx ? q1 : q0, x1 = sx ? q0 : q1, x2 = sx ? q3 : q2, x3 = sx ? q2 : q3;
+    const float y0 = sx ? w1 : w0, y1 = sx ? w0 : w1, y2 = sx ? w3 : w2, y3 = sx ? w2 : w3;
+    const int o0 = sy ? x2 : x0, o1 = sy ? x3 : x1, o2 = sy ? x0 : x2, o3 = sy ? x1 : x3;
+    const float a0 = sy ? y2 : y0, a1 = sy ? y3 : y1, a2 = sy ? y0 : y2, a3 = sy ? y1 : y3;
+    // bit j: slot j holds another texel than at the previous point (point 0: every slot starts)
+    const int prev = (lane & 32) | (pt > 0 ? pt - 1 : 0);
+    const int fl = pt == 0 ? 15 : ((o0 != __shfl(o0, prev)) ? 1 : 0) | ((o1 != __shfl(o1, prev)) ? 2 : 0) | ((o2 != __shfl(o2, prev)) ? 4 : 0) |
+                                  ((o3 != __shfl(o3, prev)) ? 8 : 0);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;              // this lane's channel of slot j
+    float* const gl = gplane + lane;
+#define NVSR_SLOT_V(BIT, S, O, A)                                                                        \
+        if (f & BIT) {                                             /* (wave-uniform) */                  \
+            if (p > 0) {                                                                                 \
+                const int k_ = __builtin_amdgcn_readlane(O, p - 1);                                      \
+                if (lane < C) NVSR_BWD_ATOMIC(gl + k_, S);                                               \
+            }                                                                                            \
+            S = 0.0f;                                                                                    \
+        }                                                                                                \
+        S = fmaf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
+    const int li = lane < C ? lane : lane - 16;
+#pragma unroll 2
+    for (int p0 = 0; p0 < 32; p0 += 4) {
+        float vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + li];                  // 4 points' rows in flight
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            const int f = __builtin_amdgcn_readlane(fl, p);
+            const float v = vv[j];
+            NVSR_SLOT_V(1, s0, o0, a0)
+            NVSR_SLOT_V(2, s1, o1, a1)
+            NVSR_SLOT_V(4, s2, o2, a2)
+            NVSR_SLOT_V(8, s3, o3, a3)
+        }
+    }
+#undef NVSR_SLOT_V
+    if (lane < C) {
+        NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o0, 31), s0);
+        NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o1, 31), s1);
+        NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o2, 31), s2);
+        NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o3, 31), s3);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // View-direction plane: every sample of a ray hits the SAME 4 texels of a 32 x 32 plane, so direct atomics pile ~2 000 adds on each
 // address (measured: +1.2 ms on a 1.2 ms kernel).  Instead the feature gradient of each point is written as a plain 192-byte row
 // gview[ray*S + s][48]; view_reduce_scatter_kernel sums a ray's S rows and does the 4 x 48 atomics once per ray.

@@ -21,7 +21,7 @@
                       // (tools/bwd_limb_ablate.sh, tools/bwd_limb_kernel_ablate.sh)
 
 #ifndef BL_SCATTER
-#define BL_SCATTER 2  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once
+#define BL_SCATTER 3  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once (bookkeeping per point on the scalar unit), 3 the same with the bookkeeping per tile on the vector unit
 #endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
 #include "limb_core.h"
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             const float* M = sc.proj + 6 * d;
             int ix, iy;
             Taps t = make_taps_cell(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], ix, iy);
-#if BL_SCATTER == 2
+#if BL_SCATTER >= 2
             t.o00 |= (ix & 1) | ((iy & 1) << 1);             // the cell's parity rides in the low bits (scatter_plane_cached)
 #endif
             return t;
@@ -385,7 +385,10 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     const Taps t = (d < 3) ? pos_taps(d) : view_taps(sc, r[8], r[9], r[10]);
-#if BL_SCATTER == 2
+#if BL_SCATTER == 3
+                    if (d < 3) scatter_plane_cached_v(gF, tile, t, gp.p[d], lane, valid);
+                    else scatter_plane_runs(gF, tile, t, gp.p[d], lane, valid);
+#elif BL_SCATTER == 2
                     if (d < 3) scatter_plane_cached(gF, tile, t, gp.p[d], lane, valid);
                     else scatter_plane_runs(gF, tile, t, gp.p[d], lane, valid);          // (view plane without a row workspace: one cell per ray)
 #elif BL_SCATTER == 1
