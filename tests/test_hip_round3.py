@@ -760,7 +760,7 @@ def test_mse_loss_pair_matches_two_mse_losses(hip):
         b = torch.rand(n, 3, device=DEV, generator=g, requires_grad=True)
         t = torch.rand(n, 3, device=DEV, generator=g)
         la, lb = tr.mse_loss_pair(a, b, t)
-        ra, rb = torch.nn.functional.mse_loss(a.double(), t.double()), torch.nn.functional.mse_loss(b.double(), t.double())
+        ra, rb = torch.nn.functional.mse_loss(a.detach().double(), t.double()), torch.nn.functional.mse_loss(b.detach().double(), t.double())
         assert abs(float(la.detach()) - float(ra)) <= 2e-6 * float(ra) and abs(float(lb.detach()) - float(rb)) <= 2e-6 * float(rb)
         (0.25 * la + 3.0 * lb).backward()
         assert torch.allclose(a.grad, 0.25 * 2 * (a.detach() - t) / (3 * n), rtol=1e-6, atol=1e-12)
