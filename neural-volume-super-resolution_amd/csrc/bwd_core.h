@@ -252,19 +252,17 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
     float* const gl = gplane + lane;
 #define NVSR_SLOT_V(BIT, S, O, A)                                                                        \
         if (f & BIT) {                                             /* (wave-uniform) */                  \
-            if (p > 0) {                                                                                 \
-                const int k_ = __builtin_amdgcn_readlane(O, p - 1);                                      \
-                if (lane < C) NVSR_BWD_ATOMIC(gl + k_, S);                                               \
-            }                                                                                            \
+            if (p > 0) NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(O, p - 1), S);                     \
             S = 0.0f;                                                                                    \
         }                                                                                                \
         S = fmaf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
-    const int li = lane < C ? lane : lane - 16;
+    // lanes 48..63 sit the whole loop out (one exec mask around it instead of one around every atomic; v_readlane ignores exec)
+    if (lane < C) {
 #pragma unroll 2
     for (int p0 = 0; p0 < 32; p0 += 4) {
         float vv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + li];                  // 4 points' rows in flight
+        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + lane];                // 4 points' rows in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p0 + j;
@@ -277,7 +275,6 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
         }
     }
 #undef NVSR_SLOT_V
-    if (lane < C) {
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o0, 31), s0);
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o1, 31), s1);
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o2, 31), s2);
