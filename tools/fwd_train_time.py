@@ -1,0 +1,26 @@
+"""times the training forward kernel alone (decode_rays_limb_kernel with gate words; 4096 rays x 128 importance-like depths, planes 200^2):
+   python tools/fwd_train_time.py      (NVSR_HIP_LIB=<variant built with -DL3_ABLATE=bits> for tools/fwd_limb_ablate.sh's decomposition)"""
+import sys, os, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import nvsr_amd
+from bench import make_synthetic_scene
+dev = torch.device("cuda", 0); capi = nvsr_amd.capi
+mc, mf, sid, pose = make_synthetic_scene(dev, 200, 32, seed=0)
+H = W = 800; focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+g = torch.Generator(device=dev).manual_seed(1)
+sel = torch.randint(0, H, (4096, 2), device=dev, generator=g)
+ro, rd = nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, sel)
+rays = nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+sc, keep = mf.native_scene()
+for S in (64, 128):
+    N = 4096
+    z = torch.sort(torch.rand(N, S, device=dev, generator=g) * 4 + 2, -1)[0].contiguous()
+    raw = torch.empty(N, S, 4, device=dev); gates = torch.empty(N, S, 32, dtype=torch.int32, device=dev)
+    ts = []
+    for i in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(mf.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), None, capi.stream())
+        b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    t = min(ts[1:])
+    print("S=%d: %.3f ms = %.1f TFLOP/s of f32 work (%s)" % (S, t, 259072.0 * N * S / t / 1e9, capi.get_decoder_arithmetic()))
