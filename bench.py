@@ -432,9 +432,9 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
               "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
-                        "f16x2": "f32 (forward and gate-driven backward of a pass whose decoder is not trained: GEMM operands split into 2 round-to-nearest f16 "
-                                 "limbs, 3 products, the backward with a power-of-two scale per wave tile; the recording forward, its backward and the weight "
-                                 "gradients: 3 exact bf16 limbs, 6 products; f32 accumulation)"}[capi.get_decoder_arithmetic()],
+                        "f16x2": "f32 (gate-driven backward of every pass and forward of a pass whose decoder is not trained: GEMM operands split into 2 "
+                                 "round-to-nearest f16 limbs, 3 products, the backward with a power-of-two scale per wave tile; the recording forward and the "
+                                 "weight-gradient contraction: 3 exact bf16 limbs, 6 products; f32 accumulation)"}[capi.get_decoder_arithmetic()],
               "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
                                      "what = %s, Adam" % sorted(what), "rays_per_step_per_gpu": N, "train_what": args.train_what,
@@ -466,8 +466,8 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
         flops = FLOP_PER_EVAL * N * S              # the transposed layers move exactly the forward's 129 536 MAC per point
         ach = flops / dt / 1e12
         limb = capi.get_decoder_arithmetic() != "f32"
-        # products per f32 product of the launch just timed: 2 f16 limbs (3) when f16x2 is selected and no record is carried, else 3 bf16 limbs (6)
-        nprod = 3 if (capi.get_decoder_arithmetic() == "f16x2" and sv.get("rec_f") is None) else 6
+        # products per f32 product of the launch just timed: 2 f16 limbs (3) under f16x2 (with or without the gradient half of the record), else 3 bf16 limbs (6)
+        nprod = 3 if capi.get_decoder_arithmetic() == "f16x2" else 6
         peak = PEAK_BF16_MFMA_TFLOPS / nprod if limb else PEAK_F32_MFMA_TFLOPS
         result["roofline"] = {"kernel": "render_pass_backward_gates_%skernel<%s%s> (fine pass, S=128; incl. its view-plane reduce)"
                                         % ("limb_" if limb else "", "record" if sv.get("rec_f") is not None else "no record",

@@ -89,15 +89,16 @@ int nvsr_version(void);
  *                     2^-6 <= |x| < 4094; below that the low limb is subnormal (honoured by the matrix pipe) and the error is absolute,
  *                     <= 2^-33 per weight and <= 2^-29 per activation; a weight >= 255 or an activation >= 4094 overflows to inf and
  *                     the pixel comes out NaN -- loud, never a wrong number (use BF16X3 or F32 for such a network).
- *                     The fused render pass (inference), and -- for a pass whose decoder is not being trained, i.e. without a
- *                     weight-gradient record -- the training forward (nvsr_decode_rays*) and the gate-driven backward
- *                     (nvsr_render_pass_backward_gates*): gradients span many decades from ray to ray but not inside a wave tile of 32
+ *                     The fused render pass (inference), the training forward (nvsr_decode_rays*) of a pass whose decoder is not being
+ *                     trained, i.e. without a weight-gradient record, and the gate-driven backward (nvsr_render_pass_backward_gates*)
+ *                     with or without the record: gradients span many decades from ray to ray but not inside a wave tile of 32
  *                     samples of one ray, so the backward scales every tile by its own power of two (largest |dL/draw| of the tile in
  *                     [1, 2), undone on the feature gradients before they are scattered) and multiplies by UNSCALED transposed weights
  *                     (low limb subnormal below |w| = 0.125: absolute error <= 2^-25, ~1e-6 of a typical weight).  Against the exact-f32
  *                     backward on the same gates its plane gradients are as close as the 3-limb backward's (relative L2 ~1e-6: the
- *                     float atomics' ordering noise; tests/test_hip_round3.py::test_f16_backward_matches_the_f32_backward).  The
- *                     recording forward, the backward that fills the record and the weight gradients run BF16X3 when F16X2 is selected.
+ *                     float atomics' ordering noise; tests/test_hip_round3.py::test_f16_backward_matches_the_f32_backward); the
+ *                     gradient half of the record is written UNSCALED.  The recording forward (the record holds unscaled f32 layer
+ *                     inputs and the pass is bound by writing them) and the weight-gradient contraction run BF16X3 when F16X2 is selected.
  *                     The gates a forward publishes are signs of pre-activations: any limb backward consumes any limb forward's.
  * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
  * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | f16x2

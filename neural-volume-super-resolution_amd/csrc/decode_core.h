@@ -183,6 +183,15 @@ __device__ __forceinline__ void record128(float* __restrict__ base, long q, int 
         for (int qq = 0; qq < 4; ++qq)
             *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
 }
+// the same with every value multiplied by a (wave-uniform) factor on its way out: accumulators that carry a power-of-two scale
+__device__ __forceinline__ void record128_scaled(float* __restrict__ base, long q, int h, const f32x16 (&a)[4], float f) {
+    float* row = base + q * HID + 4 * h;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq] * f, a[ib][4 * qq + 1] * f, a[ib][4 * qq + 2] * f, a[ib][4 * qq + 3] * f};
+}
 // a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[24h ..]
 __device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
 #pragma unroll

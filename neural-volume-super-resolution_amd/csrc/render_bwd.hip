@@ -650,7 +650,7 @@ int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* 
     if (!aligned16(packed_decoder) || !aligned16(packed_bwd) || !aligned16(g_raw) || !aligned16(gates) || !aligned16(record)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 4096) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
-    if (arith != NVSR_ARITH_F32) {       // limb matrix pipe (render_bwd_limb.hip): 3 bf16 limbs; NVSR_ARITH_F16X2 without a record: 2 f16 limbs, per-tile scale
+    if (arith != NVSR_ARITH_F32) {       // limb matrix pipe (render_bwd_limb.hip): 3 bf16 limbs; NVSR_ARITH_F16X2: 2 f16 limbs, per-tile scale
         if (int e = nvsr_render_pass_backward_gates_limb_launch(arith == NVSR_ARITH_F16X2 ? 2 : 3, scene, packed_decoder, packed_bwd, N, S, rays, z, g_raw,
                                                                 gates, grad_planes, view_ws, record, stream))
             return e;

@@ -34,7 +34,7 @@ namespace nvsr {
 #endif
 constexpr int BL_TPB = 64 * BL_WAVES_N, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
 constexpr int BL_WG_PER_CU = BL_WAVES_N == 4 ? 2 : 1;
-// LF = limbs of the transposed-layer products: 3 bf16 limbs, or (round 3; no weight-gradient record) 2 f16 limbs with the gradients of a wave
+// LF = limbs of the transposed-layer products: 3 bf16 limbs, or (round 3) 2 f16 limbs with the gradients of a wave
 // tile scaled by a power of two so that their largest magnitude is in [1, 2) -- gradients span many decades, a tile's do not
 template <int LF>
 struct BLds {
@@ -169,7 +169,6 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                                                                                    const float* __restrict__ g_raw,
                                                                                    const unsigned* __restrict__ gates, GradPlanes gp,
                                                                                    float* __restrict__ gview, DecRecord rec) {
-    static_assert(LF == 3 || !RECORD, "the weight-gradient record is contracted from unscaled f32 gradients: 3-limb backward only");
     constexpr int BL_SMALL = BLds<LF>::SMALL, BL_TILES = BLds<LF>::TILES;
     __shared__ __attribute__((aligned(16))) unsigned lds[BLds<LF>::LDS];
     RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL + BLimb<LF>::OFFSET), 0, BLimb<LF>::WORDS * 4, 0x00020000), lds, 0,
@@ -219,7 +218,12 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         }
         const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
-        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
+        // (f16 limbs: the accumulators carry the tile's power-of-two scale; the weight-gradient contraction reads unscaled f32 rows)
+        auto record_grad = [&](float* base, long q_, int h_, const f32x16 (&a)[4]) {
+            if constexpr (LF == 2) record128_scaled(base, q_, h_, a, gunscale);
+            else record128(base, q_, h_, a);
+        };
+        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = LF == 2 ? graw * gunscale : graw;     // (the record holds UNSCALED gradients)
         // Everything below is re-read where it is used instead of being kept across the step (two accumulator sets, gD and the limbs
         // already fill the 256 registers of a wave at two waves per SIMD): a layer's two gate words (slot 0..3 density, 4..7 rgb) ...
         typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -303,13 +307,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         apply_mask(gate(3), accA);
         BL_FENCE(accA)      // the masked gradient is a value of its own: without the fence hipcc keeps mask AND unmasked value alive to fold
                             // `(g & keep) & 0xffff0000` of the limb split into one v_bitop3 -- 128 more live registers, 165 spills
-        if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
+        if (rok) record_grad(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 2, accB, 0)
-        if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
+        if (rok) record_grad(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
         BL_HIDDEN_T(accB, 1, accA, 4)
-        if (rok) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
+        if (rok) record_grad(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 0, accB, 8)
-        if (rok) record128(rec.Gd, q, h, accB);
+        if (rok) record_grad(rec.Gd, q, h, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -338,13 +342,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             }
         apply_mask(gate(7), accA);
         BL_FENCE(accA)
-        if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
+        if (rok) record_grad(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 6, accB, 14)
-        if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
+        if (rok) record_grad(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
         BL_HIDDEN_T(accB, 5, accA, 18)
-        if (rok) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
+        if (rok) record_grad(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 4, accB, 22)
-        if (rok) record128(rec.Gr, q, h, accB);
+        if (rok) record_grad(rec.Gr, q, h, accB);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             f32x16 gF[2];
@@ -428,9 +432,12 @@ extern "C" int nvsr_render_pass_backward_gates_limb_launch(int limbs, const nvsr
     for (int d = 0; d < 4; ++d) gp.p[d] = grad_planes ? grad_planes[d] : nullptr;
     const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + BL_WAVES - 1) / BL_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
     const int64_t grid = ntiles < 2048 ? ntiles : 2048;
-    if (limbs == 2 && !record)      // f16 limbs: planes-only training (no weight-gradient record)
+    if (limbs == 2 && !record)      // f16 limbs
         hipLaunchKernelGGL((render_pass_backward_gates_limb_kernel<false, 2>), dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, DecRecord{});
+    else if (limbs == 2)            // f16 limbs + the gradient half of the weight-gradient record (written unscaled)
+        hipLaunchKernelGGL((render_pass_backward_gates_limb_kernel<true, 2>), dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
+                           packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));
     else if (record)
         hipLaunchKernelGGL(render_pass_backward_gates_limb_kernel<true>, dim3((unsigned)grid), dim3(BL_TPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));

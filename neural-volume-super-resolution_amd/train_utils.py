@@ -269,8 +269,9 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
-        # 'f16x2': the library runs the FORWARD of a pass whose decoder is not trained (no weight-gradient record) on 2 f16 limbs and everything
-        # that computes a gradient on 3 bf16 limbs (include/nvsr.h); the gates a forward publishes are signs, valid for either backward
+        # 'f16x2': the library runs the forward of a pass whose decoder is not trained (no weight-gradient record) and every gate-driven
+        # backward on 2 f16 limbs, the recording forward and the weight-gradient contraction on 3 bf16 limbs (include/nvsr.h); the gates a
+        # forward publishes are signs, valid for either backward
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=lindisp, white=white, t_rand=t_rand, u=u, noise_c=n_c, noise_f=n_f,
                    planes_c=planes_c, planes_f=planes_f, consts=consts, packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
