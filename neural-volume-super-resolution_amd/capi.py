@@ -187,7 +187,8 @@ def get_decoder_arithmetic():
 
 
 def set_conv_arithmetic(mode):
-    """Arithmetic of the wide 3x3 conv layers of the SR network: 'f32' | 'bf16x3' | 'f16x2' (forward convolutions; gradients stay 3-limb)."""
+    """Arithmetic of the wide 3x3 conv layers of the SR network: 'f32' | 'bf16x3' | 'f16x2' (forward convolutions, data and weight gradients; a
+    gradient tensor is scaled by the power of two of its largest magnitude)."""
     call("nvsr_set_conv_arithmetic", ARITHMETIC[mode])
 
 
