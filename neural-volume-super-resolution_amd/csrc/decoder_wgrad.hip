@@ -260,49 +260,62 @@ __global__ __launch_bounds__(WG_TPB, 1) void decoder_wgrad_limb_kernel(WJobs job
     wgrad_limb_block<NB>(jobs.j[job0 + blockIdx.y], P, slab, tile, grad);
 }
 
-// fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k].  Thread = feature f of one branch for one of the
-// workgroup's 4 row groups; the groups are summed through LDS, so a workgroup of 1024 threads adds its 516 partial sums once per 4 x slab
-// rows (every workgroup adds into the same 516 addresses: with one 256-thread workgroup per slab the adds of 4 096 workgroups queued up
-// on them).
-constexpr int HW_GROUPS = 4;
-__global__ __launch_bounds__(256 * HW_GROUPS) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
-                                                                     const float* __restrict__ g4, long Pp, int slab, float* __restrict__ grad) {
-    __shared__ float part[HW_GROUPS][256][3];
-    __shared__ float bsum[HW_GROUPS][2][3];
-    const int f = threadIdx.x & 127, rgb = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;
-    const float* H = rgb ? Hr3 : Hd3;
-    const long q0 = ((long)blockIdx.x * HW_GROUPS + grp) * slab;
-    const long q1 = (q0 + slab < Pp) ? q0 + slab : Pp;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-#pragma unroll 8
-    for (long q = q0; q < q1; ++q) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(g4 + 4 * q);
-        const float hv = H[q * HID + f];
-        if (rgb) {
-            a0 = fmaf(g[0], hv, a0); a1 = fmaf(g[1], hv, a1); a2 = fmaf(g[2], hv, a2);
-            s0 += g[0]; s1 += g[1]; s2 += g[2];
-        } else {
-            a0 = fmaf(g[3], hv, a0);
-            s0 += g[3];
-        }
-    }
-    part[grp][threadIdx.x & 255][0] = a0; part[grp][threadIdx.x & 255][1] = a1; part[grp][threadIdx.x & 255][2] = a2;
-    if (f == 0) { bsum[grp][rgb][0] = s0; bsum[grp][rgb][1] = s1; bsum[grp][rgb][2] = s2; }
-    __syncthreads();
-    if (grp != 0) return;
+// fc_alpha / fc_rgb: dW[k][f] = sum_q g4[q][k] * H3[q][f], db[k] = sum_q g4[q][k].  HBM-bound: 1 040 bytes of record per point.  A wave reads
+// ONE row of both branches per step as 16-byte loads -- lanes 0..31 the density row, lanes 32..63 the rgb row, 4 features per lane -- and the
+// workgroup's 8 waves take rows q0 + wave, q0 + wave + 8, ...; their sums meet in LDS and the workgroup adds its 516 partial sums once
+// (every workgroup adds into the same 516 addresses).  (Round 3: one feature per thread with 4-byte loads ran at 2.3 TB/s.)
+constexpr int HW_WAVES = 8;
+__global__ __launch_bounds__(64 * HW_WAVES) void head_wgrad_kernel(const float* __restrict__ Hd3, const float* __restrict__ Hr3,
+                                                                   const float* __restrict__ g4, long Pp, int rows, float* __restrict__ grad) {
+    __shared__ float part[HW_WAVES][12][64];
+    __shared__ float bsum[HW_WAVES][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rgb = lane >> 5, f4 = (lane & 31) * 4;
+    const float* H = (rgb ? Hr3 : Hd3) + f4;
+    const long q0 = (long)blockIdx.x * rows;
+    const long q1 = (q0 + rows < Pp) ? q0 + rows : Pp;
+    float a[3][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (long q = q0 + wave; q < q1; q += HW_WAVES) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(g4 + 4 * q);          // (wave-uniform address)
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(H + q * HID);
+        // density lanes: the alpha head (g[3]) in slot 0; rgb lanes: the three colour heads
+        const float c0 = rgb ? g[0] : g[3];
 #pragma unroll
-    for (int g_ = 1; g_ < HW_GROUPS; ++g_) {
-        a0 += part[g_][threadIdx.x][0]; a1 += part[g_][threadIdx.x][1]; a2 += part[g_][threadIdx.x][2];
-        if (f == 0) { s0 += bsum[g_][rgb][0]; s1 += bsum[g_][rgb][1]; s2 += bsum[g_][rgb][2]; }
+        for (int i = 0; i < 4; ++i) {
+            a[0][i] = fmaf(c0, hv[i], a[0][i]);
+            a[1][i] = fmaf(g[1], hv[i], a[1][i]);
+            a[2][i] = fmaf(g[2], hv[i], a[2][i]);
+        }
+        s[0] += g[0]; s[1] += g[1]; s[2] += g[2]; s[3] += g[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave][k * 4 + i][lane] = a[k][i];
+    if (lane == 0) { bsum[wave][0] = s[0]; bsum[wave][1] = s[1]; bsum[wave][2] = s[2]; bsum[wave][3] = s[3]; }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < HW_WAVES; ++w) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[k][i] += part[w][k * 4 + i][lane];
+        if (lane == 0) { s[0] += bsum[w][0]; s[1] += bsum[w][1]; s[2] += bsum[w][2]; s[3] += bsum[w][3]; }
     }
     if (rgb) {
-        unsafeAtomicAdd(grad + N_FCRGB_W + f, a0);
-        unsafeAtomicAdd(grad + N_FCRGB_W + HID + f, a1);
-        unsafeAtomicAdd(grad + N_FCRGB_W + 2 * HID + f, a2);
-        if (f == 0) { unsafeAtomicAdd(grad + N_FCRGB_B, s0); unsafeAtomicAdd(grad + N_FCRGB_B + 1, s1); unsafeAtomicAdd(grad + N_FCRGB_B + 2, s2); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) unsafeAtomicAdd(grad + N_FCRGB_W + k * HID + f4 + i, a[k][i]);
     } else {
-        unsafeAtomicAdd(grad + N_ALPHA_W + f, a0);
-        if (f == 0) unsafeAtomicAdd(grad + N_ALPHA_B, s0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(grad + N_ALPHA_W + f4 + i, a[0][i]);
+    }
+    if (lane == 0) {
+        unsafeAtomicAdd(grad + N_FCRGB_B, s[0]); unsafeAtomicAdd(grad + N_FCRGB_B + 1, s[1]); unsafeAtomicAdd(grad + N_FCRGB_B + 2, s[2]);
+        unsafeAtomicAdd(grad + N_ALPHA_B, s[3]);
     }
 }
 
@@ -369,8 +382,8 @@ extern "C" int nvsr_decoder_weight_grad_arith(int64_t N, int S, const float* rec
         const unsigned nslabs = (unsigned)((P + slab - 1) / slab);
         hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(nslabs, WJOBS), dim3(WG_TPB), 0, (hipStream_t)stream, jobs, P, (int)slab, grad_natural);
     }
-    const int hslab = 128;        // rows per thread: 1 024 workgroups of 4 row groups at 524k rows
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + HW_GROUPS * hslab - 1) / (HW_GROUPS * hslab))), dim3(256 * HW_GROUPS), 0,
-                       (hipStream_t)stream, rec.Hd + 3 * LP, rec.Hr + 3 * LP, rec.g4, P, hslab, grad_natural);
+    const int hrows = 1024;       // rows per workgroup (8 waves x 128 rows): 512 workgroups at 524k rows
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)((P + hrows - 1) / hrows)), dim3(64 * HW_WAVES), 0, (hipStream_t)stream, rec.Hd + 3 * LP,
+                       rec.Hr + 3 * LP, rec.g4, P, hrows, grad_natural);
     return NVSR_CHECK_LAUNCH();
 }
