@@ -318,6 +318,7 @@ def _sync_time(dist, dev, fn, warmup, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    _sync_time.issue_s = time.perf_counter() - t0        # the host's share: enqueueing the K steps (the GPU is still working on them)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -425,12 +426,15 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
 
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
     value = world * N * args.steps / elapsed
+    host_issue_ms = 1e3 * _sync_time.issue_s / args.steps
     label = "planes + decoder gradients" if "decoder" in what else "plane gradients (Feature_Planes_Only.yml: what = ['LR_planes'])"
     par = ("%d rays per iteration split %d per rank (same pixels and random numbers on every rank: the step equals the one-rank step on the "
            "whole batch)" % (N * world, N)) if strong else "every rank draws its own %d rays (global batch %d)" % (N, N * world)
     result = {"metric": "training rays/sec (4096 rays/iter, 64+64 samples, planes 200^2, %s, Adam)" % label, "value": value,
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+              # time the host needed to ENQUEUE a step (python + launches; the GPU runs behind): a value near ms_per_step = the step waits for the host
+              "host_issue_ms_per_step": host_issue_ms,
               "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
                         "f16x2": "f32 (gate-driven backward of every pass and forward of a pass whose decoder is not trained: GEMM operands split into 2 "
                                  "round-to-nearest f16 limbs, 3 products, the backward with a power-of-two scale per wave tile; the recording forward and the "

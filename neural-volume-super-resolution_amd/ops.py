@@ -833,3 +833,19 @@ cumprod_exclusive.register_autograd(_cumprod_bwd, setup_context=_cumprod_setup)
 FORWARD_OPS = ["plane_to_channel_last", "plane_from_channel_last", "pack_decoder", "coarse_z", "importance_resample", "triplane_decode",
                "triplane_decode_generic", "ray_points",
                "render_pass", "render_rays", "decode_rays", "composite", "composite_rays", "edsr", "planes_sr", "cumprod_exclusive"]
+
+
+class _Direct:
+    """The operators' Python bodies without the dispatcher round trip (torch.ops.nvsr.X(...) costs tens of microseconds of host time per call
+    in schema matching and boxing; a 1.7 ms training step makes a dozen of them).  For callers that need none of what the dispatcher adds --
+    train_utils._RenderRaysFn runs them inside an autograd.Function, where gradient mode is off and the tensors are already CUDA float32 --
+    and only there: everything else goes through torch.ops.nvsr (fake implementations, registered autograd, opcheck)."""
+
+    def __getattr__(self, name):
+        op = globals()[name]
+        fn = getattr(op, "_init_fn", op)          # (CustomOpDef keeps the decorated function; fall back to the operator itself)
+        setattr(self, name, fn)
+        return fn
+
+
+direct = _Direct()

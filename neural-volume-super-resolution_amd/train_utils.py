@@ -60,6 +60,12 @@ def _record_limits():
     return me.RECORD_RAYS, me.RECORD_FORWARD_MAX_POINTS
 
 
+def _NV():
+    """the operator namespace _RenderRaysFn calls: the operators' bodies (ops.direct: no dispatcher round trip inside the Function);
+    NVSR_OPS_DISPATCH=1 routes the calls through torch.ops.nvsr instead (host-time A/B)"""
+    return torch.ops.nvsr if os.environ.get("NVSR_OPS_DISPATCH") == "1" else ops.direct
+
+
 class _RenderRaysFn(torch.autograd.Function):
     """Differentiable predict_and_render_radiance, written against torch.ops.nvsr.*.  Leaves: the four planes of the current scene and
     the decoder parameters of the coarse / fine model, the latter as flat blobs in state-dict order
@@ -74,7 +80,7 @@ class _RenderRaysFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, p0, p1, p2, pv, nat_c, nat_f):
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
-        nv = torch.ops.nvsr
+        nv = _NV()
         arith_c, arith_f = cfg["arith_c"], cfg["arith_f"]
         # an output the loss does not use hands None to backward() instead of a zero tensor: the disparity / opacity chain rules are
         # skipped for them (a dozen per-ray kernels per pass otherwise)
@@ -117,7 +123,7 @@ class _RenderRaysFn(torch.autograd.Function):
     def backward(ctx, *grads):
         cfg, sv = ctx.cfg, ctx.saved
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
-        nv = torch.ops.nvsr
+        nv = _NV()
         dev = rays.device
         rd = rays[:, 3:6].contiguous()
         need = ctx.needs_input_grad
