@@ -400,7 +400,11 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
     planes = list(mc.planes_.values())
     # (fused=True: one kernel per parameter group instead of five multi-tensor passes over the 23 MB of planes)
-    opt, popt = (torch.optim.Adam(dec, lr=5e-4, fused=True) if "decoder" in what else None), torch.optim.Adam(planes, lr=4e-3, fused=True)
+    # one rank: the iteration is captured into a HIP graph and replayed (training.GraphedTrainStep); --no-graph and multi-rank runs launch it
+    # kernel by kernel (the RCCL all-reduce of a multi-rank step has never run on this pool: it stays out of a capture)
+    graphed = world == 1 and not args.no_graph
+    opt, popt = (torch.optim.Adam(dec, lr=5e-4, fused=True, capturable=graphed) if "decoder" in what else None), \
+        torch.optim.Adam(planes, lr=4e-3, fused=True, capturable=graphed)
     sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in planes + dec if p.grad is not None])) if world > 1 else None
     # uniform without replacement like the reference's np.random.choice(H*W, n, replace=False) (train_nerf.py:836-838), drawn on the device
     # by the library's sampler (one kernel: pixels + targets): the host permutation of 640 000 indices costs more than the whole GPU step
@@ -410,7 +414,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
     np.random.seed(rank)
     it = [0]
 
-    def one():
+    def draw():
         # the random draws of the train mode come from the device generator here: the reference draws them on the host, which on
         # this box costs more than the whole GPU step
         rnd = dict(t_rand=torch.rand(n_draw, Nc, device=dev, generator=g), u=torch.rand(n_draw, Nf, device=dev, generator=g),
@@ -418,8 +422,14 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
                    noise_fine=torch.empty(n_draw, Nc + Nf, device=dev).normal_(0.0, 0.2, generator=g))
         if strong:
             rnd = {k: v[lo: lo + N].contiguous() for k, v in rnd.items()}
-        step(it[0], target, pose, H, W, focal, 1, sid, scfg, N, randoms=rnd)
+        return rnd
+
+    def one():
+        step(it[0], target, pose, H, W, focal, 1, sid, scfg, N, randoms=draw())
         it[0] += 1
+
+    if graphed:
+        one = nvsr_amd.training.GraphedTrainStep(step, target, pose, H, W, focal, 1, sid, scfg, N, randoms_fn=draw, generators=(g,))
 
     if strong and world > 1 and os.environ.get("NVSR_BENCH_REHEARSAL", "0") == "1":
         train_partition_check(nvsr_amd, dist, dev, rank, world, mc, mf, sid, scfg, opts, pose, H, W, focal, N, Nc, Nf, planes, dec, what)
@@ -435,6 +445,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
               # time the host needed to ENQUEUE a step (python + launches; the GPU runs behind): a value near ms_per_step = the step waits for the host
               "host_issue_ms_per_step": host_issue_ms,
+              "launch": "one HIP graph replay per iteration (training.GraphedTrainStep)" if graphed else "kernel by kernel",
               "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
                         "f16x2": "f32 (gate-driven backward of every pass and forward of a pass whose decoder is not trained: GEMM operands split into 2 "
                                  "round-to-nearest f16 limbs, 3 products, the backward with a power-of-two scale per wave tile; the recording forward and the "
@@ -651,6 +662,7 @@ def main():
     ap.add_argument("--res", type=int, default=800, help="image side (default 800 = BASELINE config)")
     ap.add_argument("--plane-res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="train workload: launch the iteration kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="--workload render, N = 1: do not append the short train / sr runs (`other_workloads` of the line)")

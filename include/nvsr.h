@@ -163,6 +163,15 @@ int nvsr_get_ray_bundle_at(int H, int W, double focal_x, double focal_y, const f
  * (train_nerf.py:845 `target_s = img_target[select_inds...]`). */
 int nvsr_sample_pixels(int64_t total, int H, int W, uint64_t key, int64_t first, int64_t n, const float* image, int channels,
                        int32_t* row_col, float* target, nvsr_stream_t stream);
+/* The key of draw number `calls` of a sampler seeded with `seed`: splitmix64(splitmix64(seed) ^ calls) (host function, integer only).
+ * DevicePixelSampler passes it to nvsr_sample_pixels; nvsr_sample_pixels_seq derives the same key on the device. */
+uint64_t nvsr_sample_key(uint64_t seed, uint64_t calls);
+/* nvsr_sample_pixels for launches replayed from a HIP graph (training.GraphedTrainStep): the key is nvsr_sample_key(state[0], state[1]) read
+ * from DEVICE memory, and the launch advances state[1] by one when all its workgroups have read it -- replay k of one captured launch
+ * draws what the k-th eager nvsr_sample_pixels call of a sampler with the same seed draws.  state: 4 x uint64 on the device
+ * {seed, calls, 0 (arrival counter, must be 0 between launches), unused}; launches sharing a state must be ordered on one stream.  n >= 1. */
+int nvsr_sample_pixels_seq(int64_t total, int H, int W, uint64_t* state, int64_t first, int64_t n, const float* image, int channels,
+                           int32_t* row_col, float* target, nvsr_stream_t stream);
 /* img2mse of two images against one target in one launch (train_nerf.py:893-905 computes F.mse_loss(rgb_coarse, target) and
  * F.mse_loss(rgb_fine, target) separately): losses[0] = mean((a - t)^2), losses[1] = mean((b - t)^2) (b may be NULL: losses[1] untouched);
  * g_a / g_b (or NULL) [n] = 2 (x - t) / n, the gradient of the loss with respect to its image.  n <= NVSR_MSE_PAIR_MAX_ELEMS elements

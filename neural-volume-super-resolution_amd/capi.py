@@ -56,6 +56,8 @@ _PROTOS = {
     "nvsr_get_ray_bundle": ([_i, _i, _d, _d, _vp, _i, _d, _vp, _vp, _vp], _i),
     "nvsr_get_ray_bundle_at": ([_i, _i, _d, _d, _vp, _d, _i64, _vp, _vp, _vp, _vp], _i),
     "nvsr_sample_pixels": ([_i64, _i, _i, C.c_uint64, _i64, _i64, _vp, _i, _vp, _vp, _vp], _i),
+    "nvsr_sample_key": ([C.c_uint64, C.c_uint64], C.c_uint64),
+    "nvsr_sample_pixels_seq": ([_i64, _i, _i, _vp, _i64, _i64, _vp, _i, _vp, _vp, _vp], _i),
     "nvsr_mse_pair": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_ndc_rays": ([_i, _i, _d, _d, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_pack_rays": ([_i64, _vp, _vp, _vp, _d, _d, _vp, _vp], _i),

@@ -144,6 +144,48 @@ __global__ void sample_pixels_kernel(long total, int hb, int H, int Wd, unsigned
     }
 }
 
+// key of draw number `calls` of a sampler seeded with `seed` (nvsr.h: nvsr_sample_key)
+__host__ __device__ inline unsigned long long sample_key(unsigned long long seed, unsigned long long calls) {
+    auto mix = [](unsigned long long x) {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    return mix(mix(seed) ^ calls);
+}
+
+// nvsr_sample_pixels with the key derived on the device from state = {seed, calls, arrivals, -}: a launch that a HIP graph replays draws
+// a new batch every replay.  Every thread reads `calls` before its workgroup arrives at the counter; the workgroup that arrives last
+// (all others have read) advances `calls` and resets the counter for the next launch on the stream.
+__global__ void sample_pixels_seq_kernel(long total, int hb, int H, int Wd, unsigned long long* __restrict__ state, long first, long n,
+                                         const float* __restrict__ image, int C, int* __restrict__ rc, float* __restrict__ target) {
+    const unsigned long long seed = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long calls = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long key = sample_key(seed, calls);
+    __syncthreads();                       // every thread of the workgroup holds `calls` in a register
+    if (threadIdx.x == 0) {
+        const unsigned long long prev = __hip_atomic_fetch_add(state + 2, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == (unsigned long long)gridDim.x) {
+            __hip_atomic_store(state + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state + 1, calls + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned rk[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rk[r] = (unsigned)(splitmix64(key + (unsigned long long)r) >> 32);
+    unsigned long long x = (unsigned long long)(first + i);
+    do { x = feistel8(x, hb, rk); } while (x >= (unsigned long long)total);
+    const int row = (int)(x % (unsigned long long)H), col = (int)(x / (unsigned long long)H);
+    rc[2 * i] = row; rc[2 * i + 1] = col;
+    if (target) {
+        const float* px = image + ((long)row * Wd + col) * C;
+        for (int c = 0; c < C; ++c) target[i * C + c] = px[c];
+    }
+}
+
 // img2mse of the coarse and the fine image against one target in ONE launch, with the gradients the backward will want
 // (train_nerf.py:893-905: two F.mse_loss calls; here 2 (x - t) / n is written beside the forward sums): one 1024-thread workgroup.
 __global__ void __launch_bounds__(1024) mse_pair_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ t,
@@ -614,6 +656,19 @@ int nvsr_sample_pixels(int64_t total, int H, int W, uint64_t key, int64_t first,
     while (hb < 31 && (1ll << (2 * hb)) < total) ++hb;          // 2^(2 hb) >= total, at most 4 total: < 4 walks expected
     hipLaunchKernelGGL(sample_pixels_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (long)total, hb, H, W,
                        (unsigned long long)key, (long)first, (long)n, image, channels, row_col, target);
+    return NVSR_CHECK_LAUNCH();
+}
+
+uint64_t nvsr_sample_key(uint64_t seed, uint64_t calls) { return sample_key(seed, calls); }
+
+int nvsr_sample_pixels_seq(int64_t total, int H, int W, uint64_t* state, int64_t first, int64_t n, const float* image, int channels,
+                           int32_t* row_col, float* target, nvsr_stream_t stream) {
+    if (!state || !row_col || (target && !image)) return NVSR_ERR_NULL;
+    if (H < 1 || W < 1 || total != (int64_t)H * W || first < 0 || n < 1 || first + n > total || (target && channels < 1)) return NVSR_ERR_SHAPE;
+    int hb = 1;
+    while (hb < 31 && (1ll << (2 * hb)) < total) ++hb;
+    hipLaunchKernelGGL(sample_pixels_seq_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (long)total, hb, H, W,
+                       reinterpret_cast<unsigned long long*>(state), (long)first, (long)n, image, channels, row_col, target);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -105,9 +105,21 @@ class DevicePixelSampler:
 
     def __init__(self, seed=0, n_draw=None, lo=0):
         self.seed, self.n_draw, self.lo, self.calls = int(seed), n_draw, int(lo), 0
+        self.state = None        # device words {seed, calls, 0, 0} once use_device_state() was called (HIP-graph replays)
 
     def key(self):
-        return (self.seed * 0x9E3779B97F4A7C15 + self.calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        """key of the next draw: nvsr_sample_key(seed, calls) = splitmix64(splitmix64(seed) ^ calls) (include/nvsr.h)"""
+        return int(capi.lib().nvsr_sample_key(self.seed & 0xFFFFFFFFFFFFFFFF, self.calls & 0xFFFFFFFFFFFFFFFF))
+
+    def use_device_state(self, device):
+        """keep (seed, calls) in device memory from now on: every draw is an `nvsr_sample_pixels_seq` launch that derives the key on the
+        device and advances `calls` itself, so a launch captured into a HIP graph draws a new batch at every replay -- the batch the eager
+        sampler with the same seed draws at that call."""
+        def s64(v):
+            v &= 0xFFFFFFFFFFFFFFFF
+            return v - (1 << 64) if v >= 1 << 63 else v
+        self.state = torch.tensor([s64(self.seed), s64(self.calls), 0, 0], dtype=torch.int64, device=device)
+        return self
 
     def __call__(self, img_target, num_random_rays, consistency_ds=None):
         img = capi.f32c(img_target)
@@ -116,12 +128,20 @@ class DevicePixelSampler:
         h, w, ch = img.shape
         ds = 1 if consistency_ds is None else int(consistency_ds)
         n = min(h * w, num_random_rays // (ds ** 2))
-        first = self.lo if self.n_draw is not None else 0
+        # a rank's window [lo, lo + n) of one global draw; on an image-consistency iteration the draw is of LR pixels, ds^2 rays each
+        first = (self.lo // (ds ** 2)) if self.n_draw is not None else 0
+        if self.n_draw is not None and (self.lo % (ds ** 2) or first + n > self.n_draw // (ds ** 2)):
+            raise ValueError("DevicePixelSampler: rays [%d, %d) do not tile a global draw of %d rays in %d x %d patches"
+                             % (self.lo, self.lo + num_random_rays, self.n_draw, ds, ds))
         if first + n > h * w:
             raise ValueError("DevicePixelSampler: rays [%d, %d) of a draw from %d pixels" % (first, first + n, h * w))
         rc = torch.empty((n, 2), dtype=torch.int32, device=img.device)
         target_s = torch.empty((n, ch), dtype=torch.float32, device=img.device)
-        capi.call("nvsr_sample_pixels", h * w, h, w, self.key(), first, n, capi.ptr(img), ch, capi.ptr(rc), capi.ptr(target_s), capi.stream())
+        if self.state is not None:
+            capi.call("nvsr_sample_pixels_seq", h * w, h, w, capi.ptr(self.state), first, n, capi.ptr(img), ch, capi.ptr(rc), capi.ptr(target_s),
+                      capi.stream())
+        else:
+            capi.call("nvsr_sample_pixels", h * w, h, w, self.key(), first, n, capi.ptr(img), ch, capi.ptr(rc), capi.ptr(target_s), capi.stream())
         self.calls += 1
         return (rc if consistency_ds is None else _expand_consistency_patches(rc, ds)), target_s
 
@@ -227,6 +247,13 @@ class TrainStep:
 
     def __call__(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
                  im_consistency_iter=False, confinements=(), randoms=None):
+        return StepMetrics(*self.run(it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter,
+                                     im_consistency_iter, confinements, randoms))
+
+    def run(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
+            im_consistency_iter=False, confinements=(), randoms=None):
+        """the iteration itself -> (loss, rendering_loss, coarse_loss, fine_loss, with_psnr), device scalars (what __call__ wraps in StepMetrics);
+        nothing here waits for the device or allocates host memory: GraphedTrainStep captures it into a HIP graph"""
         first_v, last_v = it % self.vbs == 0, it % self.vbs == self.vbs - 1
         if "SR" in self.what and self.SR_model is not None:
             self.SR_model.train()
@@ -283,7 +310,93 @@ class TrainStep:
                     self.optimizer.step()
             if self.SR_optimizer is not None and sr_iter and "SR" not in confinements:
                 self.SR_optimizer.step()
-        return StepMetrics(loss, rendering_loss, coarse_loss, fine_loss, with_psnr=not im_consistency_iter)
+        return loss, rendering_loss, coarse_loss, fine_loss, not im_consistency_iter
+
+
+class GraphedTrainStep:
+    """One TrainStep iteration captured into a HIP graph and replayed: the ~30 kernel launches, the autograd graph and the Python of a step
+    (0.9-1.1 ms of host time against 1.7 ms of kernels for Feature_Planes_Only.yml) become ONE hipGraphLaunch.  train_nerf.py:790-923 is the
+    iteration being replayed; what a replay cannot do is change its mind: the arguments below are fixed at capture.
+
+    step         a TrainStep with virtual_batch_size 1 whose torch optimizers were built with capturable=True and whose pixel_sampler is a
+                 DevicePixelSampler (its key moves to device memory: every replay draws a new batch, the batch the eager step would draw)
+    img_target, pose_target   CUDA tensors; the graph reads them at every replay (copy a new view / pose INTO them to change the view)
+    randoms_fn   callable() -> the `randoms` dict of TrainStep, drawn with torch's device generators (torch advances a captured generator's
+                 offset per replay; pass other generators than the default one in `generators`), or a dict of static tensors the caller refills
+    The captured iteration is `step.run(0, ...)`; metrics() reads loss / psnr / coarse_loss / fine_loss of the last replay."""
+
+    def __init__(self, step, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, randoms_fn=None,
+                 generators=(), warmup=3, **step_kwargs):
+        if step.vbs != 1:
+            raise ValueError("GraphedTrainStep: virtual_batch_size > 1 alternates between two different iterations; capture needs one")
+        for o in (step.optimizer, step.SR_optimizer, step.planes_optimizer):
+            if isinstance(o, torch.optim.Optimizer) and not all(g.get("capturable", True) for g in o.param_groups):
+                raise ValueError("GraphedTrainStep: build %s with capturable=True (its step counter must live on the device)" % type(o).__name__)
+        if not isinstance(step.pixel_sampler, DevicePixelSampler):
+            raise ValueError("GraphedTrainStep: the pixel sampler must be a DevicePixelSampler (a host draw cannot be replayed)")
+        if not (img_target.is_cuda and torch.as_tensor(pose_target).is_cuda):
+            raise ValueError("GraphedTrainStep: img_target and pose_target must be CUDA tensors (the graph reads them at every replay)")
+        self.step, self.sampler = step, step.pixel_sampler
+        dev = img_target.device
+        if self.sampler.state is None:
+            self.sampler.use_device_state(dev)
+        args = (img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays)
+        draw = randoms_fn if callable(randoms_fn) else (lambda: randoms_fn)
+
+        def iteration():
+            out = step.run(0, *args, randoms=draw(), **step_kwargs)
+            vals = [(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
+                     else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in out[:4]]
+            return torch.stack(vals), out
+
+        # decoder training re-packs the weights every iteration, NCHW planes are converted: those kernels must be IN the graph, not skipped
+        # by the models' version-keyed caches at capture time
+        def forget_caches():
+            from . import models
+            for m in (step.mc, step.mf):
+                if m is None:
+                    continue
+                m._packed_cache = None
+                m._packed_bwd_cache = None
+                for k in (getattr(m, "planes_", None) or {}):
+                    models._PLANE_CACHE.pop(k, None)
+                    models._PLANE_CACHE.pop(k + "/SR", None)
+                # (the host copy of the box / projection constants stays: reading it back is a device-to-host copy, illegal in a capture)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):          # allocator, caches and optimizer state settle before the capture
+                iteration()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        forget_caches()
+        self.graph = torch.cuda.CUDAGraph()
+        for g in generators:
+            self.graph.register_generator_state(g)
+        with torch.cuda.graph(self.graph, stream=side):
+            self._vals, out = iteration()
+        forget_caches()
+        self.sampler.calls -= 1          # (the capture ran the sampler's Python, not its kernel: the device counter did not move)
+        self._present = dict(loss=True, psnr=bool(out[4]) and isinstance(out[1], torch.Tensor), coarse_loss=out[2] is not None,
+                             fine_loss=out[3] is not None)
+        self.replays = 0
+
+    def __call__(self):
+        """replay the iteration once (asynchronous, on the current stream)"""
+        self.graph.replay()
+        self.sampler.calls += 1          # host mirror of the device counter
+        self.replays += 1
+
+    def metrics(self):
+        """loss / psnr / coarse_loss / fine_loss of the last replay, python floats (waits for the device)"""
+        v = self._vals.tolist()
+        d = dict(zip(StepMetrics.KEYS, v))
+        d["psnr"] = mse2psnr(v[1]) if self._present["psnr"] else None
+        for k in ("coarse_loss", "fine_loss"):
+            if not self._present[k]:
+                d[k] = None
+        return d
 
 
 def evaluate_view(model_coarse, model_fine, options, scene_id, scene_config, img_target, pose_target, H, W, focal, cur_ds_factor=1,

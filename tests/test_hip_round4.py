@@ -1,0 +1,100 @@
+"""GPU parity tests added in round 4 (-m gpu): the HIP-graph replay of a training iteration against the eager iteration, the device-side
+f16-range flag (self-healing evaluation renders, loud training steps), the tile-pair training kernels against the one-tile kernels."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_hip_parity import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _train_setup(hip, what, seed, plane_res=64, n_rays=1024, nc=32, nf=32):
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=plane_res, view_res=16, seed=seed, channels_last=True)
+    for m in (mc, mf):
+        for n, p in m.named_parameters():
+            p.requires_grad_("rot_mats" not in n and ("planes_" in n or "decoder" in what))
+        m.train()
+    opts, scfg = render_options(nc, nf, perturb=True, noise=0.2)
+    planes = list(mc.planes_.values())
+    dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
+    if "decoder" in what:
+        # (SGD: Adam divides by the gradient's own magnitude, so the ordering noise of the plane scatter's float atomics -- the only difference
+        #  between two runs of one iteration -- becomes a full +-lr step wherever a gradient is near zero, and the second iteration's loss moves by
+        #  1e-4; with SGD the second iteration checks that the replay re-packs the updated decoder weights, to 1e-5)
+        popt = torch.optim.SGD(planes, lr=0.5)
+        opt = torch.optim.SGD(dec, lr=2e-2)
+    else:
+        popt = torch.optim.Adam(planes, lr=4e-3, fused=True, capturable=True)
+        opt = None
+    sampler = hip.training.DevicePixelSampler(seed=77)
+    step = hip.training.TrainStep(mc, mf, opts, what, optimizer=opt, planes_optimizer=popt, pixel_sampler=sampler)
+    return dict(mc=mc, mf=mf, sid=sid, pose=pose, scfg=scfg, planes=planes, dec=dec, popt=popt, opt=opt, sampler=sampler, step=step,
+                n_rays=n_rays, nc=nc, nf=nf)
+
+
+@pytest.mark.parametrize("what", [("LR_planes",), ("LR_planes", "decoder")])
+def test_graph_replay_equals_the_eager_iteration(hip, what):
+    """training.GraphedTrainStep (one hipGraphLaunch per iteration) against TrainStep (train_nerf.py:790-923 launch by launch) from the same
+    parameters, optimizer state, sampler position and random inputs: the pixel draws are the same integers; the gradients agree to the
+    ordering noise of the scatter's float atomics (two eager runs differ by as much: relative L2 <= 1e-5; decoder gradients are sums in a
+    fixed order: 1e-6) and so do the losses.  Two replays: the second one must draw new pixels and read the refilled random inputs."""
+    what = set(what)
+    H = W = 96
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    img = torch.rand(H, W, 3, device=DEV, generator=g)
+    a, b = _train_setup(hip, what, seed=11), _train_setup(hip, what, seed=11)
+    N, Nc, Nf = a["n_rays"], a["nc"], a["nf"]
+    rnd = dict(t_rand=torch.rand(N, Nc, device=DEV, generator=g), u=torch.rand(N, Nf, device=DEV, generator=g),
+               noise_coarse=0.2 * torch.randn(N, Nc, device=DEV, generator=g), noise_fine=0.2 * torch.randn(N, Nc + Nf, device=DEV, generator=g))
+    graphed = hip.training.GraphedTrainStep(b["step"], img, b["pose"], H, W, focal, 1, b["sid"], b["scfg"], N, randoms_fn=rnd, warmup=2)
+    # the eager twin starts where the capture left the graphed one: same parameters, optimizer state, sampler position
+    with torch.no_grad():
+        for pa, pb in zip(a["planes"] + a["dec"], b["planes"] + b["dec"]):
+            pa.copy_(pb)
+    a["popt"].load_state_dict(copy.deepcopy(b["popt"].state_dict()))
+    if a["opt"] is not None:
+        a["opt"].load_state_dict(copy.deepcopy(b["opt"].state_dict()))
+    a["sampler"].calls = b["sampler"].calls
+    assert int(b["sampler"].state[1]) == b["sampler"].calls == 2 and int(b["sampler"].state[2]) == 0
+    seen = []
+    for k in range(2):
+        if k == 1:
+            for v in rnd.values():          # new random inputs in the same (static) tensors
+                v.copy_(torch.rand(v.shape, device=DEV, generator=g) if v is rnd["t_rand"] or v is rnd["u"] else 0.2 * torch.randn(v.shape, device=DEV, generator=g))
+        sel_a, _ = copy.copy(a["sampler"])(img, N)           # what the eager sampler draws at this call (a copy: no side effect)
+        m_a = a["step"](k, img, a["pose"], H, W, focal, 1, a["sid"], a["scfg"], N, randoms=rnd)
+        graphed()
+        m_b = graphed.metrics()
+        seen.append(sel_a)
+        for key in ("loss", "coarse_loss", "fine_loss", "psnr"):
+            assert abs(m_a[key] - m_b[key]) <= 1e-5 * max(1.0, abs(m_a[key])), (k, key, m_a[key], m_b[key])
+        for i, (pa, pb) in enumerate(zip(a["planes"] + (a["dec"] if "decoder" in what else []), b["planes"] + (b["dec"] if "decoder" in what else []))):
+            ga, gb = pa.grad, pb.grad
+            assert ga is not None and gb is not None and float(ga.norm()) > 0
+            rel = float((ga - gb).norm() / ga.norm())
+            assert rel <= 1e-5, (k, i, rel)
+    assert not torch.equal(seen[0], seen[1])
+    assert int(b["sampler"].state[1]) == b["sampler"].calls == a["sampler"].calls == 4
+
+
+def test_graphed_step_refuses_what_it_cannot_replay(hip):
+    s = _train_setup(hip, {"LR_planes"}, seed=3)
+    img = torch.rand(32, 32, 3, device=DEV)
+    args = (img, s["pose"], 32, 32, 30.0, 1, s["sid"], s["scfg"], 256)
+    s["step"].vbs = 2
+    with pytest.raises(ValueError, match="virtual_batch_size"):
+        hip.training.GraphedTrainStep(s["step"], *args)
+    s["step"].vbs = 1
+    s["step"].planes_optimizer = torch.optim.Adam(s["planes"], lr=1e-3)
+    with pytest.raises(ValueError, match="capturable"):
+        hip.training.GraphedTrainStep(s["step"], *args)
+    s["step"].planes_optimizer = s["popt"]
+    s["step"].pixel_sampler = hip.training.select_training_pixels
+    with pytest.raises(ValueError, match="DevicePixelSampler"):
+        hip.training.GraphedTrainStep(s["step"], *args)
