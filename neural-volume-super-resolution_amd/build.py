@@ -46,7 +46,7 @@ def _stale():
 # re-schedules the whole block at IR level -- every pure instruction (the MFMAs included) sinks below the block's loads and
 # sched_barriers, the hand-placed interleave is gone and hundreds of registers spill.
 # decode_limb.hip: same blocks, same reason (250 spilled registers with the vectorizer, none without).
-PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"], "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"], "decode_pair.hip": ["-fno-slp-vectorize"], "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(CSRC, "_obj")      # (of the product build; experiment variants use <out_path>.obj)
 
 

@@ -15,7 +15,7 @@ constexpr int B_RGB_H = B_DEN0 + 8192;                   // 57344: rgb L3^T, L2^
 constexpr int B_RGB0 = B_RGB_H + 3 * P_HID_FLOATS;       // 106496: planes 0..3
 constexpr int B_TOTAL = B_RGB0 + 4 * 8192;               // 139264
 
-struct Masks { unsigned m[2]; };   // bit (ib&1)*16 + r of m[ib>>1]  <=>  post-ReLU activation acc[ib][r] > 0
+struct Masks { unsigned m[2]; };   // bit gate_bit(ib, r) of m[ib>>1]  <=>  post-ReLU activation acc[ib][r] > 0
 struct GradPlanes { float* p[4]; };
 
 // ---- the bf16-limb fragments of the same transposed layers (render_bwd_limb.hip), behind the f32 blob; 816 fragments of 256 words
@@ -45,7 +45,7 @@ __device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // gate bit sign-extended to 0 / ~0 (v_bfe_i32), then one v_and: 2 VALU per element instead of extract + compare + select
-            const int keep = __builtin_amdgcn_sbfe((int)k.m[ib >> 1], (ib & 1) * 16 + r, 1);
+            const int keep = __builtin_amdgcn_sbfe((int)k.m[ib >> 1], gate_bit(ib, r), 1);
             g[ib][r] = __int_as_float(__float_as_int(g[ib][r]) & keep);
         }
 }

@@ -141,8 +141,8 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) {
             const bool on = acc[ib][r] > 0.0f;
             acc[ib][r] = on ? acc[ib][r] : 0.0f;
-            if (ib < 2) m0 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
-            else m1 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            if (ib < 2) m0 |= on ? (1u << gate_bit(ib, r)) : 0u;
+            else m1 |= on ? (1u << gate_bit(ib, r)) : 0u;
         }
     asm volatile("" :: "v"(m0), "v"(m1));
 #else
@@ -166,8 +166,8 @@ __device__ __forceinline__ void relu_publish(f32x16 (&acc)[4], unsigned* __restr
         for (int r = 0; r < 16; ++r) {
             const bool on = acc[ib][r] > 0.0f;
             acc[ib][r] = on ? acc[ib][r] : 0.0f;
-            if (ib < 2) m0 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
-            else m1 |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            if (ib < 2) m0 |= on ? (1u << gate_bit(ib, r)) : 0u;
+            else m1 |= on ? (1u << gate_bit(ib, r)) : 0u;
         }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};

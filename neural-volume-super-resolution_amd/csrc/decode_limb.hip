@@ -76,7 +76,7 @@ __device__ __forceinline__ void bias_relu(const f32x16 (&acc)[4], const float* b
         }
     }
 }
-// the layer's ReLU gate in relu_publish's format: bit (ib & 1) * 16 + r of word ib >> 1  <=>  pre-activation > 0
+// the layer's ReLU gate in relu_publish's format: bit gate_bit(ib, r) of word ib >> 1  <=>  pre-activation > 0
 __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* __restrict__ rec, int layer) {
     // act = max(., 0) is +0 or a positive number (never -0: v_max_f32 of (x, +0) returns +0 for x = -0): act > 0  <=>  its bits, read as
     // a signed integer, are >= 1.  clamp(bits, 0, 1) is one v_med3_i32 and the insertion one v_lshl_or_b32: 2 instructions per element, no
@@ -94,8 +94,8 @@ __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* 
             asm("v_med3_i32 %1, %5, 0, 1\n\tv_med3_i32 %2, %6, 0, 1\n\tv_med3_i32 %3, %7, 0, 1\n\tv_med3_i32 %4, %8, 0, 1\n\t"
                 "v_lshl_or_b32 %0, %1, %9, %0\n\tv_lshl_or_b32 %0, %2, %10, %0\n\tv_lshl_or_b32 %0, %3, %11, %0\n\tv_lshl_or_b32 %0, %4, %12, %0"
                 : "+v"(m), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                : "v"(act[ib][r]), "v"(act[ib][r + 1]), "v"(act[ib][r + 2]), "v"(act[ib][r + 3]), "n"((ib & 1) * 16 + r), "n"((ib & 1) * 16 + r + 1),
-                  "n"((ib & 1) * 16 + r + 2), "n"((ib & 1) * 16 + r + 3));
+                : "v"(act[ib][r]), "v"(act[ib][r + 1]), "v"(act[ib][r + 2]), "v"(act[ib][r + 3]), "n"(gate_bit(ib, r)), "n"(gate_bit(ib, r + 1)),
+                  "n"(gate_bit(ib, r + 2)), "n"(gate_bit(ib, r + 3)));
         }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(rec + 2 * layer) = u32x2{m0, m1};

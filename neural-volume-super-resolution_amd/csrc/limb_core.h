@@ -145,6 +145,21 @@ __device__ __forceinline__ void spread(int slot, F f) {
 }
 
 struct NoTail {};
+struct NoGate {};
+
+// gates of the element pair whose packed f16 high limbs are `hi` (post-ReLU values: +0, positive, or NaN) -> bits (pos, pos + 16) of m:
+// min(half, 1) is 1 exactly when the half is not zero -- one v_pk_min_u16 and one v_lshl_or_b32 per PAIR (nvsr_common.h: gate_bit).
+// `ones` = 0x00010001 in a scalar register (VOP3P takes no literal).  Inline asm, both instructions in one statement: written in C++ hipcc
+// canonicalises min(x, 1) into compare + select per half (5 instructions per pair), and between two asm statements it pads an s_nop.
+__device__ __forceinline__ void gate_pair(unsigned hi, int pos, unsigned& m, unsigned ones) {
+    unsigned t;
+    asm("v_pk_min_u16 %1, %2, %3\n\tv_lshl_or_b32 %0, %1, %4, %0" : "+v"(m), "=&v"(t) : "v"(hi), "s"(ones), "n"(pos));
+}
+__device__ __forceinline__ unsigned gate_ones() {
+    unsigned ones = 0x00010001u;
+    asm volatile("" : "+s"(ones));
+    return ones;
+}
 
 // One block: acc[0..3] (+)= W[chunk K-blocks 0..NKB-1] x (limbs of the source), 4 * NKB * NP MFMAs.
 //   cur   : limbs of K-block 0 on entry; on exit the limbs the tail produced (the next block's K-block 0) -- unchanged without a tail
@@ -153,11 +168,13 @@ struct NoTail {};
 //   src(kb, i): value i of K-block kb of this block (read when K-block kb - 1 is being multiplied)
 //   side(slot): the other tile's work, slot = ((kb * 4 + ob) * NP + p)
 //   tail(slice, nxt): 4 * NP slices during the last K-block, to split the next block's first K-block into nxt
-template <int LIMBS, int NKB, bool ZERO, bool LOAD_FIRST, class Src, class Side, class Tail>
+//   gate(kb, j, hi): optional; called once per pair j = 0..3 of every K-block kb >= 1 split inside the block, with the pair's packed high limbs
+template <int LIMBS, int NKB, bool ZERO, bool LOAD_FIRST, class Src, class Side, class Tail, class Gate = NoGate>
 __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 (&acc)[4], Limbs<LIMBS>& cur, Limbs<LIMBS>& fa, Src src,
-                                           Side side, Tail tail) {
+                                           Side side, Tail tail, Gate gate = Gate{}) {
     constexpr int NP = limb_products(LIMBS), NQ = NKB * 4;
     constexpr bool HAS_TAIL = !std::is_same<Tail, NoTail>::value;
+    constexpr bool HAS_GATE = !std::is_same<Gate, NoGate>::value;
     const u32x4* wv = reinterpret_cast<const u32x4*>(wl) + lane;
     if (LOAD_FIRST) {
 #pragma unroll
@@ -188,8 +205,10 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
                 //  slot each, 1 767 -> 1 066 waits per step of the 3-limb render pass, 1 401 -> 1 040 of the f16 one)
                 if (p < LIMBS) { const int t_ = LIMBS - 1 - p; fn.v[t_] = wv[(((q + 1) % NQ) * LIMBS + t_) * 64]; }
 #endif
-                if (kb + 1 < NKB) split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
-                else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);
+                if (kb + 1 < NKB) {
+                    split_slice<LIMBS>(ob * NP + p, [&](int i) { return src(kb + 1, i); }, nxt, sp);
+                    if constexpr (HAS_GATE) { if ((ob * NP + p) % NP == 0 && (ob * NP + p) / NP < 4) gate(kb + 1, (ob * NP + p) / NP, nxt.v[0][(ob * NP + p) / NP]); }
+                } else if constexpr (HAS_TAIL) tail(ob * NP + p, nxt);
                 side(q * NP + p);
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -112,6 +112,12 @@ __host__ __device__ inline long record_row(long ray, int s, long N, int S) { (vo
 __host__ __device__ inline long record_row(long ray, int s, long N, int S) { (void)N; return ray * S + s; }
 #endif
 
+// ReLU gates of a layer (published by the training forwards, consumed by the gate-driven backwards): two words per lane and layer; the
+// gate of accumulator element acc[ib][r] is bit gate_bit(ib, r) of word ib >> 1.  An element pair (r, r + 1), r even, sits at bits
+// (p, p + 16): the two halves of a packed f16 pair -- the f16-limb forward takes a pair's two gates from the high limbs it has split
+// anyway (v_pk_min_u16 + v_lshl_or_b32 per PAIR, decode_pair.hip).
+__host__ __device__ constexpr int gate_bit(int ib, int r) { return (ib & 1) * 8 + (r >> 1) + 16 * (r & 1); }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t round4(int64_t n) { return (n + 3) / 4 * 4; }      // floats -> a multiple of 16 bytes
 

@@ -231,6 +231,9 @@ extern "C" int nvsr_pack_decoder_limbs_launch(const float* natural, float* packe
 extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                             const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream);
 
+extern "C" int nvsr_decode_rays_pair_launch(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays, const float* z,
+                                            float* raw, uint32_t* gates, nvsr_stream_t stream);
+
 // arithmetic of the fused render pass (process-wide): -1 = not yet read from the environment
 static int g_decoder_arithmetic = -1;
 
@@ -314,6 +317,14 @@ int nvsr_decode_rays_arith(const nvsr_scene* scene, const float* packed_decoder,
     if (record && !gates) return NVSR_ERR_NULL;      // the record is consumed together with the gates
     // limb matrix pipe (decode_limb.hip): 3 bf16 limbs, or -- NVSR_ARITH_F16X2 without a weight-gradient record -- 2 f16 limbs (the gates are
     // signs of pre-activations: the 3-limb backward consumes them whichever forward arithmetic found them)
+    // NVSR_ARITH_F16X2 without a record: the tile-pair kernel (decode_pair.hip; same gates, same raw to the rounding of the heads' summation
+    // order) where it is the faster one -- from four 32-sample chunks per ray on (same-box A/B, 4 096 rays: S = 128 0.395-0.408 against
+    // 0.408-0.413 ms, S = 64 0.224-0.238 against 0.219-0.227; profiles/r04_pair_forward_ablation.txt).  NVSR_DECODE_PAIR=0 / =1 force one kernel.
+    if (arith == NVSR_ARITH_F16X2 && !record && S > 32) {
+        static const char* env = getenv("NVSR_DECODE_PAIR");
+        const bool pair = env ? !strcmp(env, "1") : S >= 128;
+        if (pair) return nvsr_decode_rays_pair_launch(scene, packed_decoder, N, S, rays, z, raw, gates, stream);
+    }
     if (arith != NVSR_ARITH_F32)
         return nvsr_decode_rays_limb_launch(arith == NVSR_ARITH_F16X2 ? 2 : 3, scene, packed_decoder, N, S, rays, z, raw, gates, record, stream);
     const int64_t ntiles = ((N + PTS_PER_WG - 1) / PTS_PER_WG) * S;

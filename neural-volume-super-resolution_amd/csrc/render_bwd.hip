@@ -60,7 +60,7 @@ __device__ __forceinline__ Masks relu_masks(f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) {
             const bool on = acc[ib][r] > 0.0f;
             acc[ib][r] = on ? acc[ib][r] : 0.0f;
-            k.m[ib >> 1] |= on ? (1u << ((ib & 1) * 16 + r)) : 0u;
+            k.m[ib >> 1] |= on ? (1u << gate_bit(ib, r)) : 0u;
         }
     return k;
 }

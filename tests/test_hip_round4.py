@@ -53,17 +53,22 @@ def test_graph_replay_equals_the_eager_iteration(hip, what):
     rnd = dict(t_rand=torch.rand(N, Nc, device=DEV, generator=g), u=torch.rand(N, Nf, device=DEV, generator=g),
                noise_coarse=0.2 * torch.randn(N, Nc, device=DEV, generator=g), noise_fine=0.2 * torch.randn(N, Nc + Nf, device=DEV, generator=g))
     graphed = hip.training.GraphedTrainStep(b["step"], img, b["pose"], H, W, focal, 1, b["sid"], b["scfg"], N, randoms_fn=rnd, warmup=2)
-    # the eager twin starts where the capture left the graphed one: same parameters, optimizer state, sampler position
-    with torch.no_grad():
-        for pa, pb in zip(a["planes"] + a["dec"], b["planes"] + b["dec"]):
-            pa.copy_(pb)
-    a["popt"].load_state_dict(copy.deepcopy(b["popt"].state_dict()))
-    if a["opt"] is not None:
-        a["opt"].load_state_dict(copy.deepcopy(b["opt"].state_dict()))
-    a["sampler"].calls = b["sampler"].calls
+    def sync_twin():
+        # the eager twin starts every iteration where the graphed one stands: same parameters, optimizer state, sampler position
+        # (Adam turns the ordering noise of the scatter's float atomics into +-lr steps wherever a gradient nearly cancels: two runs of
+        #  SEVERAL iterations drift apart by 1e-4 whatever launches them)
+        with torch.no_grad():
+            for pa, pb in zip(a["planes"] + a["dec"], b["planes"] + b["dec"]):
+                pa.copy_(pb)
+        a["popt"].load_state_dict(copy.deepcopy(b["popt"].state_dict()))
+        if a["opt"] is not None:
+            a["opt"].load_state_dict(copy.deepcopy(b["opt"].state_dict()))
+        a["sampler"].calls = b["sampler"].calls
+
     assert int(b["sampler"].state[1]) == b["sampler"].calls == 2 and int(b["sampler"].state[2]) == 0
     seen = []
     for k in range(2):
+        sync_twin()
         if k == 1:
             for v in rnd.values():          # new random inputs in the same (static) tensors
                 v.copy_(torch.rand(v.shape, device=DEV, generator=g) if v is rnd["t_rand"] or v is rnd["u"] else 0.2 * torch.randn(v.shape, device=DEV, generator=g))
@@ -98,3 +103,57 @@ def test_graphed_step_refuses_what_it_cannot_replay(hip):
     s["step"].pixel_sampler = hip.training.select_training_pixels
     with pytest.raises(ValueError, match="DevicePixelSampler"):
         hip.training.GraphedTrainStep(s["step"], *args)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# tile-pair training forward (decode_pair.hip) against the one-tile kernel (decode_limb.hip) and the oracle
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _pair_setup(hip, N, S, seed):
+    from bench import make_synthetic_scene
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=48, view_res=16, seed=seed)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    H = W = 64
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    sel = torch.randint(0, H, (N, 2), device=DEV, generator=g)
+    ro, rd = hip.training.get_ray_bundle_at(H, W, focal, pose, sel)
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    z = torch.sort(torch.rand(N, S, device=DEV, generator=g) * 4 + 2, -1)[0].contiguous()
+    return mf, rays, z
+
+
+@pytest.mark.parametrize("N,S", [(1, 33), (5, 37), (3, 64), (7, 65), (9, 97), (64, 128), (33, 192)])
+def test_pair_forward_matches_the_one_tile_forward(hip, N, S):
+    """decode_rays_pair_kernel (two 32-sample tiles per wave) against decode_rays_limb_kernel<.,false,2> (one tile per wave), same 2-f16-limb
+    arithmetic, on ragged shapes: one chunk pair with a partly / wholly empty second tile (S = 33, 37, 65), pair counts that do not fill the
+    four waves of a workgroup, odd chunk counts (S = 65, 97: the last pair of a ray has no second tile).  The layers accumulate in the same
+    order in both kernels; the heads do not (two half-wave partial sums): raw within 2e-6 of its range.  Gates: the pair kernel takes a gate
+    from the f16 high limb of the activation (a positive activation below 2^-29 reads as closed): identical words but for such elements --
+    none on these inputs."""
+    capi = hip.capi
+    lib = capi.lib()
+    mf, rays, z = _pair_setup(hip, N, S, seed=N + S)
+    sc, keep = mf.native_scene()
+    packed = mf.packed_decoder()
+    outs = []
+    for fn in ("nvsr_decode_rays_limb_launch", "nvsr_decode_rays_pair_launch"):
+        raw = torch.full((N, S, 4), float("nan"), device=DEV)
+        gates = torch.full((N, S, 32), -1, dtype=torch.int32, device=DEV)
+        f = getattr(lib, fn)
+        f.restype = C.c_int
+        if "limb" in fn:
+            st = f(C.c_int(2), C.byref(sc), capi.ptr(packed), C.c_int64(N), C.c_int(S), capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), None,
+                   capi.stream())
+        else:
+            st = f(C.byref(sc), capi.ptr(packed), C.c_int64(N), C.c_int(S), capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), capi.stream())
+        assert st == 0
+        outs.append((raw, gates))
+    (raw_a, gates_a), (raw_b, gates_b) = outs
+    assert bool(torch.isfinite(raw_b).all())
+    scale = float(raw_a.abs().max())
+    assert float((raw_a - raw_b).abs().max()) <= 2e-6 * scale, float((raw_a - raw_b).abs().max()) / scale
+    assert torch.equal(gates_a, gates_b), int(((gates_a ^ gates_b) != 0).sum())
+    # without gates: the same raw, bit for bit, as with them
+    raw_c = torch.empty_like(raw_b)
+    f = lib.nvsr_decode_rays_pair_launch
+    assert f(C.byref(sc), capi.ptr(packed), C.c_int64(N), C.c_int(S), capi.ptr(rays), capi.ptr(z), capi.ptr(raw_c), None, capi.stream()) == 0
+    assert torch.equal(raw_c, raw_b)
