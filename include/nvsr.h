@@ -111,6 +111,17 @@ int nvsr_version(void);
 #define NVSR_ARITH_DEFAULT NVSR_ARITH_F16X2
 int nvsr_get_decoder_arithmetic(void);
 int nvsr_set_decoder_arithmetic(int mode);
+/* Range flag of NVSR_ARITH_F16X2 (round 4).  A launch in that mode whose operands leave the ranges above produces NaN -- which the caller
+ * would otherwise have to find by reading its outputs.  With a device word registered here, every F16X2 launch that WRITES A NON-FINITE
+ * RESULT also ORs a bit into that word (1 -- the fused render passes: a non-finite rgb / opacity of a ray; nvsr_decode_rays*: a non-finite raw
+ * row; 2 -- the SR network: a non-finite value of an output plane inside its region of interest): the host mirror zeroes the word before a frame / an iteration, reads it back
+ * asynchronously and re-renders in NVSR_ARITH_BF16X3 or raises (train_utils.py, training.py).  The reference renders any f32 model
+ * (models.py:395-421); this is what keeps the drop-in's default arithmetic from ever returning NaN where the reference returns a number.
+ * NULL (the initial state) disables the reporting.  The pointer is process-global like the default arithmetic and is read when a launch is
+ * enqueued; the word must stay allocated until every launch enqueued while it was registered has finished.  Modes other than F16X2 never
+ * touch it (they have no range limit; a NaN they return was a NaN in their inputs). */
+int nvsr_set_range_flag(uint32_t* device_word);
+uint32_t* nvsr_get_range_flag(void);
 /* The arithmetic primitive alone (test hook, one wavefront): Y[32][32] = W[32][K] X[K][32] (row-major f32, K a multiple of 16) with the
  * operands split and multiplied exactly as the kernels of `arithmetic` do it (NVSR_ARITH_F32 | _BF16X3 | _F16X2, incl. the static scales of
  * F16X2) -- lets a test put chosen mantissas / magnitudes through the products that replace models.py:381-421's nn.Linear GEMMs. */

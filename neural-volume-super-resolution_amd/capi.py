@@ -48,6 +48,8 @@ _PROTOS = {
     "nvsr_limb_gemm_probe": ([_i, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_get_decoder_arithmetic": ([], C.c_int),
     "nvsr_set_decoder_arithmetic": ([_i], _i),
+    "nvsr_set_range_flag": ([_vp], _i),
+    "nvsr_get_range_flag": ([], _vp),
     "nvsr_get_conv_arithmetic": ([], C.c_int),
     "nvsr_set_conv_arithmetic": ([_i], _i),
     "nvsr_plane_to_channel_last": ([_vp, _vp, _i, _i, _i, _vp], _i),
@@ -196,6 +198,48 @@ def set_conv_arithmetic(mode):
 
 def get_conv_arithmetic():
     return {v: k for k, v in ARITHMETIC.items()}[lib().nvsr_get_conv_arithmetic()]
+
+
+class RangeFlag:
+    """The device word F16X2 launches OR a 1 into when they write a non-finite result (include/nvsr.h: nvsr_set_range_flag), with a pinned
+    host mirror.  One per process (the registration is process-global like the default arithmetic); created on first use.
+        reset()        zero the word on the current stream
+        read_async()   enqueue the copy of the word to pinned memory -> a ticket
+        raised(ticket, wait=True)   the word's value at the ticket: 0, or bits 1 (decoder kernels) | 2 (SR network) (waits for the copy;
+                       wait=False: None while the copy is still in flight)"""
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        call("nvsr_set_range_flag", ptr(self.word))
+
+    def reset(self):
+        self.word.zero_()
+
+    def read_async(self):
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self.word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    @staticmethod
+    def raised(ticket, wait=True):
+        host, ev = ticket
+        if not wait and not ev.query():
+            return None
+        ev.synchronize()
+        return int(host[0])
+
+
+_range_flag = None
+
+
+def range_flag(device=None):
+    """the process's RangeFlag (created and registered with the library on first use)"""
+    global _range_flag
+    if _range_flag is None:
+        _range_flag = RangeFlag(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    return _range_flag
 
 
 def exported_symbols():

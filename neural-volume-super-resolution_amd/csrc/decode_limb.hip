@@ -243,7 +243,8 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
 template <bool MASKS, bool RECORD, int LF = 3>
 __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                                     const float* __restrict__ rays, const float* __restrict__ z,
-                                                                    float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
+                                                                    float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec,
+                                                                    unsigned* __restrict__ flag) {
     constexpr int L3_SMALL = L3<LF>::SMALL;
     __shared__ __attribute__((aligned(16))) unsigned lds[L3<LF>::LDS];
     // (wave index as a SCALAR: the LDS destination of every weight-copy piece then is scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
@@ -282,7 +283,11 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
         decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
                                             __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, record_row(ray, s, N, S), valid, nscale);
-        if (valid && rs.lane < 32) *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+        if (valid && rs.lane < 32) {
+            *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+            // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag)
+            if (LF == 2 && flag && !(fabsf(raw[0] + raw[1] + raw[2] + raw[3]) <= 3.0e38f)) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -298,20 +303,20 @@ extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, 
     if (limbs == 2 && !record) {        // f16 limbs: no weight-gradient record (it holds unscaled f32 layer inputs)
         if (gates)
             hipLaunchKernelGGL((decode_rays_limb_kernel<true, false, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                               (long)N, S, rays, z, raw, gates, DecRecord{});
+                               (long)N, S, rays, z, raw, gates, DecRecord{}, nvsr_get_range_flag());
         else
             hipLaunchKernelGGL((decode_rays_limb_kernel<false, false, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene),
-                               packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{});
+                               packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{}, nvsr_get_range_flag());
         return NVSR_CHECK_LAUNCH();
     }
     if (record)
         hipLaunchKernelGGL((decode_rays_limb_kernel<true, true>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, z, raw, gates, make_record(record, (long)N, S));
+                           (long)N, S, rays, z, raw, gates, make_record(record, (long)N, S), (unsigned*)nullptr);
     else if (gates)
         hipLaunchKernelGGL((decode_rays_limb_kernel<true, false>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, z, raw, gates, DecRecord{});
+                           (long)N, S, rays, z, raw, gates, DecRecord{}, (unsigned*)nullptr);
     else
         hipLaunchKernelGGL((decode_rays_limb_kernel<false, false>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene),
-                           packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{});
+                           packed_decoder, (long)N, S, rays, z, raw, (unsigned*)nullptr, DecRecord{}, (unsigned*)nullptr);
     return NVSR_CHECK_LAUNCH();
 }

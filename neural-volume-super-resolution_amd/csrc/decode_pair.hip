@@ -64,7 +64,7 @@ __device__ __forceinline__ void relu_gate_step(int k, const float* bias, int h, 
 template <bool MASKS>
 __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float* __restrict__ packed, long N, int S,
                                                  const float* __restrict__ rays, const float* __restrict__ z,
-                                                 float* __restrict__ raw_out, unsigned* __restrict__ gates) {
+                                                 float* __restrict__ raw_out, unsigned* __restrict__ gates, unsigned* __restrict__ flag) {
     constexpr int LIMBS = 2;
     using L = LdsP;
     constexpr int NP = limb_products(LIMBS);
@@ -327,6 +327,10 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         if (lane < 32) {
             if (validX) *reinterpret_cast<f32x4*>(raw_out + (ray * S + sX) * 4) = f32x4{X.raw[0], X.raw[1], X.raw[2], X.raw[3]};
             if (validY) *reinterpret_cast<f32x4*>(raw_out + (ray * S + sY) * 4) = f32x4{Y.raw[0], Y.raw[1], Y.raw[2], Y.raw[3]};
+            // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag)
+            const float tx = X.raw[0] + X.raw[1] + X.raw[2] + X.raw[3], ty = Y.raw[0] + Y.raw[1] + Y.raw[2] + Y.raw[3];
+            if (flag && ((validX && !(fabsf(tx) <= 3.0e38f)) || (validY && !(fabsf(ty) <= 3.0e38f))))
+                __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the copy issued for a step after the last one must land before the wave ends
@@ -334,16 +338,16 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
 
 __global__ __launch_bounds__(TPB2, 1) void decode_rays_pair_gates_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                                         const float* __restrict__ rays, const float* __restrict__ z,
-                                                                        float* __restrict__ raw_out, unsigned* __restrict__ gates) {
+                                                                        float* __restrict__ raw_out, unsigned* __restrict__ gates, unsigned* __restrict__ flag) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    decode_pair_body<true>(sc, packed, N, S, rays, z, raw_out, gates);
+    decode_pair_body<true>(sc, packed, N, S, rays, z, raw_out, gates, flag);
 #endif
 }
 __global__ __launch_bounds__(TPB2, 1) void decode_rays_pair_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                                   const float* __restrict__ rays, const float* __restrict__ z,
-                                                                  float* __restrict__ raw_out) {
+                                                                  float* __restrict__ raw_out, unsigned* __restrict__ flag) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    decode_pair_body<false>(sc, packed, N, S, rays, z, raw_out, nullptr);
+    decode_pair_body<false>(sc, packed, N, S, rays, z, raw_out, nullptr, flag);
 #endif
 }
 
@@ -362,9 +366,9 @@ extern "C" int nvsr_decode_rays_pair_launch(const nvsr_scene* scene, const float
     const int grid = (int)((nsteps + per - 1) / per);
     if (gates)
         hipLaunchKernelGGL(decode_rays_pair_gates_kernel, dim3(grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N, S,
-                           rays, z, raw, gates);
+                           rays, z, raw, gates, nvsr_get_range_flag());
     else
         hipLaunchKernelGGL(decode_rays_pair_kernel, dim3(grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder, (long)N, S,
-                           rays, z, raw);
+                           rays, z, raw, nvsr_get_range_flag());
     return NVSR_CHECK_LAUNCH();
 }

@@ -256,6 +256,10 @@ int nvsr_internal_resolve_decoder_arith(int arithmetic) {
     return (arithmetic == NVSR_ARITH_F32 || arithmetic == NVSR_ARITH_BF16X3 || arithmetic == NVSR_ARITH_F16X2) ? arithmetic : -1;
 }
 
+static uint32_t* g_range_flag = nullptr;
+int nvsr_set_range_flag(uint32_t* device_word) { g_range_flag = device_word; return NVSR_OK; }
+uint32_t* nvsr_get_range_flag(void) { return g_range_flag; }
+
 int nvsr_set_decoder_arithmetic(int mode) {
     if (mode != NVSR_ARITH_F32 && mode != NVSR_ARITH_BF16X3 && mode != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
     g_decoder_arithmetic = mode;

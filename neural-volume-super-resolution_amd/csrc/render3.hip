@@ -25,7 +25,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
                                                   const float* __restrict__ noise, int white,
                                                   float* __restrict__ rgb, float* __restrict__ disp,
                                                   float* __restrict__ acc, float* __restrict__ weights,
-                                                  float* __restrict__ depth, float* __restrict__ raw_out) {
+                                                  float* __restrict__ depth, float* __restrict__ raw_out, unsigned* __restrict__ flag) {
     constexpr int LIMBS = LZ & 7;
     constexpr bool ZCOMP = (LZ & 8) != 0;
     using L = Lds3<LIMBS>;
@@ -387,6 +387,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
             if (white) { const float bg = 1.0f - t.ac; cr += bg; cg += bg; cb += bg; }
             rgb[ray * 3 + 0] = cr; rgb[ray * 3 + 1] = cg; rgb[ray * 3 + 2] = cb;
             acc[ray] = t.ac;
+            // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag): a non-finite colour / opacity is an operand beyond the static scales
+            if (LIMBS == 2 && flag && !(fabsf(cr + cg + cb + t.ac) <= 3.0e38f)) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (depth) depth[ray] = t.dep;
         }
     }
@@ -399,8 +401,8 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_coarse_kernel(SceneDev s
                                                                      const float* __restrict__ noise, int white,
                                                                      float* __restrict__ rgb, float* __restrict__ disp,
                                                                      float* __restrict__ acc, float* __restrict__ weights,
-                                                                     float* __restrict__ depth, float* __restrict__ raw_out) {
-    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, weights, depth, raw_out);
+                                                                     float* __restrict__ depth, float* __restrict__ raw_out, unsigned* __restrict__ flag) {
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, weights, depth, raw_out, flag);
 }
 // coarse pass of an inference frame: un-jittered depths computed in registers (no [N,S] depth tensor is written or read)
 template <int LIMBS>
@@ -409,9 +411,9 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_coarse_z_kernel(SceneDev
                                                                        const float* __restrict__ noise, int white,
                                                                        float* __restrict__ rgb, float* __restrict__ disp,
                                                                        float* __restrict__ acc, float* __restrict__ weights,
-                                                                       float* __restrict__ depth, float* __restrict__ raw_out) {
+                                                                       float* __restrict__ depth, float* __restrict__ raw_out, unsigned* __restrict__ flag) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (hipcc's host pass cannot resolve the LDS-DMA helpers inside this instantiation; it only needs the stub)
-    render_pass3_body<LIMBS + 8>(sc, packed, N, S, rays, nullptr, lindisp, noise, white, rgb, disp, acc, weights, depth, raw_out);
+    render_pass3_body<LIMBS + 8>(sc, packed, N, S, rays, nullptr, lindisp, noise, white, rgb, disp, acc, weights, depth, raw_out, flag);
 #endif
 }
 // fine pass (or any pass whose weights are not wanted)
@@ -421,8 +423,8 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass3_kernel(SceneDev sc, cons
                                                               const float* __restrict__ noise, int white,
                                                               float* __restrict__ rgb, float* __restrict__ disp,
                                                               float* __restrict__ acc, float* __restrict__ depth,
-                                                              float* __restrict__ raw_out) {
-    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, nullptr, depth, raw_out);
+                                                              float* __restrict__ raw_out, unsigned* __restrict__ flag) {
+    render_pass3_body<LIMBS>(sc, packed, N, S, rays, z, 0, noise, white, rgb, disp, acc, nullptr, depth, raw_out, flag);
 }
 
 // ---- natural blob -> bf16 limb fragments (the tail of the packed blob) -----------------------------------------------------------
@@ -525,10 +527,10 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
 #define NVSR_LAUNCH3(LIMBS_)                                                                                                               \
     if (weights)                                                                                                                           \
         hipLaunchKernelGGL(render_pass3_coarse_kernel<LIMBS_>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene),    \
-                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out);               \
+                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, nvsr_get_range_flag());               \
     else                                                                                                                                   \
         hipLaunchKernelGGL(render_pass3_kernel<LIMBS_>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene),           \
-                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, depth, raw_out)
+                           packed_decoder, (long)N, S, rays, z, noise, white_bkgd, rgb, disp, acc, depth, raw_out, nvsr_get_range_flag())
     if (limbs == 3) { NVSR_LAUNCH3(3); } else { NVSR_LAUNCH3(2); }
 #undef NVSR_LAUNCH3
     return NVSR_CHECK_LAUNCH();
@@ -542,9 +544,9 @@ extern "C" int nvsr_render_pass3_coarse_z_launch(int limbs, const nvsr_scene* sc
     if (grid > 0x7fffffff || (limbs != 2 && limbs != 3) || !weights) return NVSR_ERR_SHAPE;
     if (limbs == 3)
         hipLaunchKernelGGL(render_pass3_coarse_z_kernel<3>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr);
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr, nvsr_get_range_flag());
     else
         hipLaunchKernelGGL(render_pass3_coarse_z_kernel<2>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr);
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr, nvsr_get_range_flag());
     return NVSR_CHECK_LAUNCH();
 }

@@ -796,7 +796,7 @@ __global__ void sr_prepare_kernel(const float* __restrict__ lr, int Cc, int R0, 
 // PlanesSR output (models.py:915-923): canvas = NaN; canvas[roi] = difference[over:-over] + bilinear_x{sf}(LR)[roi]
 // (F.interpolate(mode='bilinear', align_corners=True), :858-859)
 __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo, int over, const float* __restrict__ lr, int Cc, int R0,
-                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out) {
+                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out, unsigned* __restrict__ flag) {
     const int HR0 = R0 * sf, HR1 = R1 * sf;
     const long n = (long)Cc * HR0 * HR1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -812,7 +812,11 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
     const float* q = lr + ((long)c * R0 + y0) * R1 + x0;
     const float res = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * R1] + lx1 * q[(long)yp * R1 + xp]);
     const int dy = oy - lo0 * sf + over, dx = ox - lo1 * sf + over;
-    out[i] = diff[((long)c * Ho + dy) * Wo + dx] + res;
+    const float v = diff[((long)c * Ho + dy) * Wo + dx] + res;
+    out[i] = v;
+    // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag): a non-finite value inside the region of interest is a weight / activation of
+    // the network beyond the static scales (flag = NULL in every other arithmetic)
+    if (flag && !(fabsf(v) <= 3.0e38f)) __hip_atomic_fetch_or(flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (bit 1: the SR network)
 }
 
 // arithmetic of the eligible conv layers (process-wide): -1 = not yet read from the environment
@@ -1260,7 +1264,7 @@ int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, in
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
-                           Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b]);
+                           Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b], conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
     return NVSR_OK;
@@ -1331,7 +1335,7 @@ static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* 
     } else if (int e = nvsr_edsr_forward_batch_arith(xin, 1, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, arithmetic, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
-                       lo[0], lo[1], hi[0], hi[1], out);
+                       lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -202,7 +202,7 @@ def _decoder_needs_grad(model):
 
 
 def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, scene_id, mode="train", encode_position_fn=None,
-                                encode_direction_fn=None, randoms=None):
+                                encode_direction_fn=None, randoms=None, force_arith=None):
     """train_utils.py:71-182 on packed rays [N,11].  `randoms` (extension) = dict(t_rand, u, noise_coarse, noise_fine) of
     explicit random inputs; when absent they are drawn on the CPU generator in the reference's order."""
     if _cfg(options.nerf, "encode_position_fn", None) == "mip":
@@ -251,12 +251,10 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
             same = all(a.data_ptr() == b.data_ptr() for a, b in zip(planes_c, planes_f))
         else:
             planes_f, same = planes_c, True
-    if train_path:
-        arith_c = capi.resolve_decoder_arithmetic(model_coarse.arithmetic)
-        arith_f = capi.resolve_decoder_arithmetic(model_fine.arithmetic) if Nf > 0 else arith_c
-    else:       # evaluation: operands beyond the f16 limbs' range render in the 3-limb arithmetic instead of NaN (models.render_arithmetic)
-        arith_c = model_coarse.render_arithmetic(planes_c, training=False)
-        arith_f = model_fine.render_arithmetic(planes_f, training=False) if Nf > 0 else arith_c
+    # (an evaluation render whose operands leave the f16 limbs' range is found by the library's range flag and rendered again with
+    #  force_arith = bf16x3: run_one_iter_of_nerf; a training step raises: training.TrainStep)
+    arith_c = capi.resolve_decoder_arithmetic(model_coarse.arithmetic if force_arith is None else force_arith)
+    arith_f = capi.resolve_decoder_arithmetic(model_fine.arithmetic if force_arith is None else force_arith) if Nf > 0 else arith_c
     white, lindisp = bool(m.white_background), bool(m.lindisp)
 
     if train_path:
@@ -342,6 +340,45 @@ def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n
         raw_f = model_fine(nv.ray_points(rays, z_f)).reshape(N, Nc + Nf, 4)
         rgb_f, disp_f, acc_f, _ = composite(raw_f, z_f, n_f, False)
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
+
+
+def _sr_of(model):
+    return model.SR_model if hasattr(model, "SR_model") and not model.skip_SR_ else None
+
+
+def _f16_in_play(*ms):
+    """does an evaluation of these models launch anything in NVSR_ARITH_F16X2?"""
+    f16 = capi.ARITHMETIC["f16x2"]
+    for m in ms:
+        if capi.resolve_decoder_arithmetic(m.arithmetic) == f16:
+            return True
+        sr = _sr_of(m)
+        if sr is not None and capi.resolve_conv_arithmetic(sr.inner_model.arithmetic) == f16:
+            return True
+    return False
+
+
+def _range_key(*ms):
+    """(storage, version) of everything an evaluation reads: decoder parameters, planes, SR weights"""
+    key = []
+    for m in ms:
+        ts = list(m.decoder_parameters()) + list((getattr(m, "planes_", None) or {}).values())
+        sr = _sr_of(m)
+        if sr is not None:
+            ts += list(sr.inner_model.parameters())
+        key += [(t.data_ptr(), t._version) for t in ts]
+    return tuple(key)
+
+
+def _sr_fallback(*ms, redo=False):
+    """the SR networks of these models super-resolve in 'bf16x3'; redo: planes cached from an F16X2 pass (NaN inside) are dropped"""
+    for m in ms:
+        sr = _sr_of(m)
+        if sr is not None and capi.resolve_conv_arithmetic(sr.inner_model.arithmetic) == capi.ARITHMETIC["f16x2"]:
+            sr.inner_model.arithmetic = "bf16x3"
+            redo = True
+        if sr is not None and redo:
+            sr.clear_SR_planes()
 
 
 def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None, no_ndc=True):
@@ -439,11 +476,45 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
     step = MAX_RAYS_PER_LAUNCH if native else MAX_RAYS_PER_LAUNCH_GENERIC
     if inv is not None:
         step -= step % (PATCH_H * SUPER_H * int(ray_grid_width))       # launches split between rows of super-blocks
-    for a in range(0, max(N, 1), step):
-        b = min(a + step, N)
-        sub = None if randoms is None else {k: v[a:b] for k, v in randoms.items()}
-        outs.append(predict_and_render_radiance(rays[a:b], model_coarse, model_fine, options, scene_id, mode=mode, randoms=sub if sub is not None else {}))
-    out = outs[0] if len(outs) == 1 else tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs], 0) for i in range(9))
+    def launch_all(force_arith=None):
+        outs = []
+        for a in range(0, max(N, 1), step):
+            b = min(a + step, N)
+            sub = None if randoms is None else {k: v[a:b] for k, v in randoms.items()}
+            outs.append(predict_and_render_radiance(rays[a:b], model_coarse, model_fine, options, scene_id, mode=mode, randoms=sub if sub is not None else {},
+                                                    force_arith=force_arith))
+        return outs[0] if len(outs) == 1 else tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs], 0) for i in range(9))
+
+    # Evaluation in NVSR_ARITH_F16X2 heals itself: the reference renders finite pixels for any f32 model (models.py:395-421); the f16 limbs
+    # have ranges (|W| < 255, |feature / activation| < 4094), beyond which the kernels write NaN and raise the library's range flag.  One
+    # device word, zeroed before the frame and read back after it (the only host wait of an evaluation frame; a frame is >= 100 ms of
+    # kernels at 800 x 800): raised -> the frame is rendered again in the 3-bf16-limb arithmetic (warned once), and later frames of the same
+    # parameters go there directly.  Covers hidden activations, which no check of the operands could see beforehand.
+    range_checked = mode != "train" and native and N > 0 and _f16_in_play(model_coarse, model_fine)
+    force = None
+    if range_checked:
+        key = _range_key(model_coarse, model_fine)
+        if model_fine.__dict__.get("_f16_unfit") == key:
+            force = "bf16x3"
+            _sr_fallback(model_coarse, model_fine)
+        else:
+            flag = capi.range_flag(rays.device)
+            flag.reset()
+    out = launch_all(force)
+    if range_checked and force is None:
+        bits = capi.RangeFlag.raised(flag.read_async())
+        if bits:
+            import warnings
+            if not model_fine.__dict__.get("_f16_unfit_warned"):
+                warnings.warn("weights, plane values or activations beyond NVSR_ARITH_F16X2's range (|W| < 255, |feature / activation| < 4094): this "
+                              "model renders in 'bf16x3' while its parameters stay as they are (set model.arithmetic = 'bf16x3' to render there in "
+                              "the first place)")
+                model_fine.__dict__["_f16_unfit_warned"] = True
+            model_fine.__dict__["_f16_unfit"] = key
+            if bits & 2:
+                _sr_fallback(model_coarse, model_fine, redo=True)
+            out = launch_all("bf16x3")
+            flag.reset()
     if inv is not None:
         out = tuple(None if t is None else t.index_select(0, inv) for t in out)
     return out

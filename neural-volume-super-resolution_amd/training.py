@@ -186,16 +186,21 @@ class StepMetrics(Mapping):
     never waits on the others."""
 
     KEYS = ("loss", "psnr", "coarse_loss", "fine_loss")
+    RANGE_ERROR = ("NVSR_ARITH_F16X2 range exceeded in training iteration %s (a weight >= 255, a feature or activation >= 4094, or a non-finite "
+                   "parameter): the kernels wrote NaN; set model.arithmetic = 'bf16x3' (capi.set_decoder_arithmetic('bf16x3')) for this model")
 
-    def __init__(self, loss, rendering_loss, coarse_loss, fine_loss, with_psnr):
+    def __init__(self, loss, rendering_loss, coarse_loss, fine_loss, with_psnr, range_word=None, it=None):
         self._present = dict(loss=True, psnr=with_psnr and isinstance(rendering_loss, torch.Tensor), coarse_loss=coarse_loss is not None,
                              fine_loss=fine_loss is not None)
         src = [loss, rendering_loss, coarse_loss, fine_loss]
         dev = loss.device
+        # (5th value: the library's range flag as it stands at the end of this iteration -- capi.RangeFlag; read with the others)
+        src.append(range_word.reshape(()) if range_word is not None else 0.0)
+        self._it = it
         vals = torch.stack([(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
                              else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in src])
         if dev.type == "cuda":
-            self._host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+            self._host = torch.empty(5, dtype=torch.float32, pin_memory=True)
             self._host.copy_(vals, non_blocking=True)
             self._event = torch.cuda.Event()
             self._event.record()
@@ -208,7 +213,15 @@ class StepMetrics(Mapping):
             if self._event is not None:
                 self._event.synchronize()
             self._vals = self._host.tolist()
+        if self._vals[4] != 0.0:
+            raise capi.NvsrError(self.RANGE_ERROR % ("?" if self._it is None else self._it))
         return self._vals
+
+    def poll(self):
+        """raise if this iteration has finished with the range flag up; never waits"""
+        if self._vals is None and self._event is not None and not self._event.query():
+            return
+        self._read()
 
     def __getitem__(self, k):
         if k not in self._present:
@@ -244,11 +257,33 @@ class TrainStep:
         self.sr_loss, self.ds_factor, self.separate_decoder_sr = sr_loss, int(ds_factor), separate_decoder_sr
         self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
         self.pixel_sampler = pixel_sampler or select_training_pixels   # (img_target, num_random_rays, consistency_ds) -> (rows_cols, target_s)
+        import collections
+        self._pending, self._range_reset = collections.deque(), False
 
     def __call__(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
                  im_consistency_iter=False, confinements=(), randoms=None):
-        return StepMetrics(*self.run(it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter,
-                                     im_consistency_iter, confinements, randoms))
+        # an iteration whose operands left NVSR_ARITH_F16X2's range wrote NaN into the loss and the parameters: found without a host wait,
+        # from the metrics of the iterations that have finished by now (each carries the range flag of its end), and raised
+        while self._pending and (self._pending[0]._vals is not None or self._pending[0]._event is None or self._pending[0]._event.query()):
+            self._pending.popleft().poll()
+        word = self._range_word(img_target.device)
+        out = self.run(it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter,
+                       im_consistency_iter, confinements, randoms)
+        m = StepMetrics(*out, range_word=word, it=it)
+        if m._event is not None:
+            self._pending.append(m)
+            if len(self._pending) > 64:          # (a consumer that never lets the queue drain: wait for the oldest)
+                self._pending.popleft()._read()
+        return m
+
+    def _range_word(self, device):
+        if device.type != "cuda":
+            return None
+        flag = capi.range_flag(device)
+        if not self._range_reset:
+            flag.reset()          # (whatever raised the flag before this step object's first iteration is not its business)
+            self._range_reset = True
+        return flag.word
 
     def run(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
             im_consistency_iter=False, confinements=(), randoms=None):
@@ -343,11 +378,13 @@ class GraphedTrainStep:
         args = (img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays)
         draw = randoms_fn if callable(randoms_fn) else (lambda: randoms_fn)
 
+        flag = capi.range_flag(dev)
+
         def iteration():
             out = step.run(0, *args, randoms=draw(), **step_kwargs)
             vals = [(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
                      else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in out[:4]]
-            return torch.stack(vals), out
+            return torch.stack(vals + [flag.word.to(torch.float32).reshape(())]), out      # (5th: the range flag, as in StepMetrics)
 
         # decoder training re-packs the weights every iteration, NCHW planes are converted: those kernels must be IN the graph, not skipped
         # by the models' version-keyed caches at capture time
@@ -374,6 +411,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             self.graph.register_generator_state(g)
+        flag.reset()
         with torch.cuda.graph(self.graph, stream=side):
             self._vals, out = iteration()
         forget_caches()
@@ -391,6 +429,8 @@ class GraphedTrainStep:
     def metrics(self):
         """loss / psnr / coarse_loss / fine_loss of the last replay, python floats (waits for the device)"""
         v = self._vals.tolist()
+        if v[4] != 0.0:
+            raise capi.NvsrError(StepMetrics.RANGE_ERROR % ("(replay %d)" % self.replays))
         d = dict(zip(StepMetrics.KEYS, v))
         d["psnr"] = mse2psnr(v[1]) if self._present["psnr"] else None
         for k in ("coarse_loss", "fine_loss"):

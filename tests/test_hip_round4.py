@@ -157,3 +157,122 @@ def test_pair_forward_matches_the_one_tile_forward(hip, N, S):
     f = lib.nvsr_decode_rays_pair_launch
     assert f(C.byref(sc), capi.ptr(packed), C.c_int64(N), C.c_int(S), capi.ptr(rays), capi.ptr(z), capi.ptr(raw_c), None, capi.stream()) == 0
     assert torch.equal(raw_c, raw_b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# NVSR_ARITH_F16X2 heals itself: the library's range flag (include/nvsr.h: nvsr_set_range_flag), evaluation re-renders, training raises
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_evaluation_heals_hidden_activation_overflow(hip):
+    """The reference renders any f32 model (models.py:395-421).  Here: weights and planes INSIDE the f16 limbs' ranges (the host-side operand
+    check passes) but a hidden layer's bias of 5000 -- activations beyond 4094, which only the kernels can see.  eval_nerf must return the
+    pixels of the 'bf16x3' render (bit for bit: it IS that render), warn, go to 'bf16x3' directly while the parameters stay as they are
+    (no second F16X2 attempt), and return to 'f16x2' once they change back."""
+    import warnings
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=64, view_res=16, seed=4)
+    H = W = 136                               # 18 496 rays: the fused passes
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    opts, scfg = render_options(16, 24)
+    ev = lambda: hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    base = ev()
+    assert torch.isfinite(base[3]).all() and "_f16_unfit" not in mf.__dict__
+    b = mf.density_dec["0"][1].bias
+    with torch.no_grad():
+        keep = b.detach().clone()
+        b[3] = 5000.0
+    planes, _ = mf.scene_args()
+    assert mf.f16_operands_in_range(planes)                     # nothing a check of the operands could find
+    flag = hip.capi.range_flag()
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        out = ev()
+    assert any("bf16x3" in str(w.message) for w in wl)
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[3]).all() and "_f16_unfit" in mf.__dict__
+    assert int(flag.word) == 0                                  # left clean for whoever checks next
+    mc.arithmetic = mf.arithmetic = "bf16x3"
+    want = ev()
+    mc.arithmetic = mf.arithmetic = None
+    assert torch.equal(out[0], want[0]) and torch.equal(out[3], want[3])
+    # the same parameters again: straight to bf16x3 (the flag is not even reset: plant a value and find it untouched)
+    flag.word.fill_(4)
+    again = ev()
+    assert int(flag.word) == 4 and torch.equal(again[3], want[3])
+    flag.reset()
+    # the fine pass alone in F16X2 really is NaN (the healing is not a no-op)
+    sc, keep_alive = mf.native_scene()
+    rays = hip.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+    N, S = rays.shape[0], 24
+    z = torch.sort(torch.rand(N, S, device=DEV) * 4 + 2, -1).values.contiguous()
+    o = [torch.empty((N, 3), device=DEV), torch.empty(N, device=DEV), torch.empty(N, device=DEV)]
+    hip.capi.call("nvsr_render_pass_arith", C.byref(sc), hip.capi.ptr(mf.packed_decoder()), N, S, hip.capi.ptr(rays), hip.capi.ptr(z), None, 1,
+                  *[hip.capi.ptr(t) for t in o], None, None, None, hip.capi.ARITHMETIC["f16x2"], hip.capi.stream())
+    assert torch.isnan(o[0]).any() and int(flag.word) == 1
+    flag.reset()
+    with torch.no_grad():
+        b.copy_(keep)
+    back = ev()
+    assert torch.equal(back[3], base[3]) and int(flag.word) == 0
+
+
+def test_training_raises_when_the_f16_range_is_exceeded(hip):
+    """TrainStep / GraphedTrainStep with a hidden bias of 5000: the loss would be NaN (and Adam would write NaN into the planes).  The
+    metrics of the iteration carry the range flag of its end: reading any of them raises NvsrError naming 'bf16x3'; a loop that never reads its
+    metrics gets the error from a later iteration's call (no host wait: the check polls finished iterations)."""
+    for graphed in (False, True):
+        s = _train_setup(hip, {"LR_planes"}, seed=21)
+        H = W = 96
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        img = torch.rand(H, W, 3, device=DEV)
+        with torch.no_grad():
+            s["mf"].rgb_dec["0"][2].bias[7] = 5000.0
+        args = (img, s["pose"], H, W, focal, 1, s["sid"], s["scfg"], s["n_rays"])
+        if graphed:
+            g = hip.training.GraphedTrainStep(s["step"], *args, randoms_fn={}, warmup=1)
+            g()
+            with pytest.raises(hip.capi.NvsrError, match="bf16x3"):
+                g.metrics()
+        else:
+            m = s["step"](0, *args, randoms={})
+            with pytest.raises(hip.capi.NvsrError, match="bf16x3"):
+                m["loss"]
+            with pytest.raises(hip.capi.NvsrError, match="bf16x3"):      # never reading the metrics: a later call raises
+                for it in range(1, 40):
+                    s["step"](it, *args, randoms={})
+                    torch.cuda.synchronize()
+        hip.capi.range_flag().reset()
+    # in range: nothing raises, the flag stays down
+    s = _train_setup(hip, {"LR_planes"}, seed=22)
+    img = torch.rand(96, 96, 3, device=DEV)
+    for it in range(3):
+        m = s["step"](it, img, s["pose"], 96, 96, 0.5 * 96 / np.tan(0.5 * 0.6911112), 1, s["sid"], s["scfg"], s["n_rays"], randoms={})
+    assert np.isfinite(m["loss"]) and int(hip.capi.range_flag().word) == 0
+
+
+def test_evaluation_heals_an_sr_network_beyond_the_f16_range(hip):
+    """A trunk weight of 300 in the SR network (EDSR 128 channels: the f16-limb convolution kernels): the super-resolved planes come out NaN
+    inside, the SR stage raises bit 2 of the range flag, eval_nerf drops the cached planes, super-resolves and renders again in 'bf16x3'."""
+    import warnings
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=24, view_res=8, seed=9)
+    torch.manual_seed(3)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 128, "n_blocks": 1}}, "bilinear").to(DEV)
+    sr.eval()
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    opts, scfg = render_options(16, 16)
+    ev = lambda: hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    base = ev()
+    assert torch.isfinite(base[3]).all() and sr.inner_model.arithmetic is None
+    with torch.no_grad():
+        sr.inner_model.residual[0].conv1.weight[17, 3, 1, 1] = 300.0
+    sr.clear_SR_planes()
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        out = ev()
+    assert any("bf16x3" in str(w.message) for w in wl)
+    assert torch.isfinite(out[3]).all() and sr.inner_model.arithmetic == "bf16x3" and int(hip.capi.range_flag().word) == 0
+    assert not torch.equal(out[3], base[3])                     # (the changed weight changes the planes)
