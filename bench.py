@@ -262,6 +262,72 @@ def decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine, n_rays=16384, n
     return out
 
 
+FLIP_DEPTH_TOL = 1e-3      # a ray whose fine depths differ from the checker's by more than this (1.6 % of a coarse bin of the 2..6 range) "flipped"
+
+
+def frame_error_evidence(nvsr_amd, mc, mf, sid, rays, n_rays=16384, nc=64, nf=128, seed=0):
+    """Where a frame's error against the float64 checker comes from, per arithmetic (the default arithmetic's frame PSNR
+    sat 3.8 dB under the exact-f32 kernels' although its decoder outputs are closer to float64).  n_rays rays of the frame are rendered pass
+    by pass (the kernels and depths of the frame path) in every arithmetic and by the checker (C oracle, double accumulation); per arithmetic:
+      flipped rays   rays with a fine depth more than FLIP_DEPTH_TOL from the checker's: an importance sample landed in another coarse bin
+                     (inverse-CDF sampling is discontinuous in the coarse weights: nerf_helpers.py:688-700; a rounding-level change of a
+                     weight moves a sample by a bin where u meets a knot of the cdf) -- such a ray's pixel is a DIFFERENT correct render,
+                     its error is the field's variation along the ray, not the arithmetic's;
+      |rgb error|    50 / 99 / 99.9-th percentile and maximum over the checked rays (max over the 3 channels);
+      psnr           over all checked rays, over the rays that did not flip, and over the rays that flipped in NO arithmetic (same set for all)."""
+    from oracle.oracle import Oracle, decoder_blob
+    nv = torch.ops.nvsr
+    capi = nvsr_amd.capi
+    N = rays.shape[0]
+    rng = np.random.default_rng(seed)
+    ids = np.sort(rng.choice(N, size=min(N, n_rays), replace=False))
+    r = rays[torch.from_numpy(ids).to(rays.device)].contiguous()
+    chk = Oracle(f32=False)
+    planes = [mc.planes_[nvsr_amd.models.get_plane_name(sid, d)].detach().cpu().numpy() for d in range(4)]
+    osc = chk.scene(planes, mc.box_coords[sid].numpy())
+    dc = chk.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
+    df = chk.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
+    t0 = time.perf_counter()
+    ref = chk.render_rays(osc, dc, df, r.cpu().numpy(), nc, nf, want_aux=True)
+    t_ref = time.perf_counter() - t0
+    ref_rgb, ref_z = ref["rgb_fine"].astype(np.float64), ref["z_fine"].astype(np.float64)
+    planes_c, consts = mc.scene_args()
+    planes_f, _ = mf.scene_args()
+    res, flipped = {}, {}
+    for mode in ("f32", "bf16x3", "f16x2"):
+        a = capi.ARITHMETIC[mode]
+        z_c = nv.coarse_z(r, nc, False, None)
+        _, _, _, w_c = nv.render_pass(planes_c, consts, mc.packed_decoder(), r, z_c, None, False, True, a)
+        z_f = nv.importance_resample(z_c, w_c, nf, None)
+        rgb_f = nv.render_pass(planes_f, consts, mf.packed_decoder(), r, z_f, None, False, False, a)[0]
+        torch.cuda.synchronize()
+        dz = np.abs(z_f.cpu().numpy().astype(np.float64) - ref_z).max(-1)
+        err = np.abs(rgb_f.cpu().numpy().astype(np.float64) - ref_rgb)
+        flipped[mode] = dz > FLIP_DEPTH_TOL
+        res[mode] = (err, dz, np.abs(w_c.cpu().numpy().astype(np.float64) - ref["weights_coarse"]).max())
+    none_flipped = ~(flipped["f32"] | flipped["bf16x3"] | flipped["f16x2"])
+
+    def psnr(err, keep):
+        e = err[keep]
+        mse = float(np.mean(e ** 2)) if e.size else 0.0
+        return 200.0 if mse == 0 else -10.0 * np.log10(mse)
+
+    out = {"rays_checked": int(len(ids)), "flip_depth_tolerance": FLIP_DEPTH_TOL, "rays_flipped_in_no_arithmetic": int(none_flipped.sum()),
+           "checker": "C oracle, double accumulation, %d rays in %.1f s" % (len(ids), t_ref)}
+    for mode, (err, dz, dw) in res.items():
+        e1 = err.max(-1)
+        fl = flipped[mode]
+        out[mode] = {"flipped_rays": int(fl.sum()), "flipped_fraction": float(fl.mean()),
+                     "coarse_weight_max_abs_error": float(dw),
+                     "rgb_abs_error_percentiles": {"p50": float(np.percentile(e1, 50)), "p99": float(np.percentile(e1, 99)),
+                                                   "p99.9": float(np.percentile(e1, 99.9)), "max": float(e1.max())},
+                     "rgb_abs_error_max_over_non_flipped": float(e1[~fl].max()) if (~fl).any() else 0.0,
+                     "psnr_db_all": psnr(err, np.ones_like(fl)), "psnr_db_non_flipped": psnr(err, ~fl),
+                     "psnr_db_rays_flipped_in_no_arithmetic": psnr(err, none_flipped),
+                     "share_of_squared_error_in_flipped_rays": float((err[fl] ** 2).sum() / max((err ** 2).sum(), 1e-300))}
+    return out
+
+
 def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
     """The oracle (plain-C port of the reference algorithm, fp32, OpenMP over all host cores) on a bounded sample of the same
     rays; also the PSNR of the GPU pixels against the (double-accumulating) checker on that sample."""
@@ -707,9 +773,19 @@ def main():
     import nvsr_amd
     nvsr_amd.capi.lib()  # fail loudly if the HIP library is not built
 
+    # what the collectives of this run really are: backend, its world size and every rank's device, gathered THROUGH the process group
+    # (a SCALE line carries them: "rccl_ranks": N with N distinct devices, or the rehearsal's gloo / shared cuda:0)
+    comm = {"backend": "none", "rccl_ranks": 0, "world_size": 1, "rank_devices": [str(dev)]}
+    if dist is not None:
+        devs = [None] * world
+        dist.all_gather_object(devs, "%s (%s)" % (dev, torch.cuda.get_device_properties(dev).name))
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0, "rank_devices": devs}
+
     if args.workload != "render":
         res = (bench_train if args.workload == "train" else bench_sr)(args, nvsr_amd, dist, dev, rank, world)
         if res is not None:          # rank 0
+            res["collectives"] = comm
             print(json.dumps(res), flush=True)
         if dist is not None:
             dist.barrier()
@@ -877,6 +953,8 @@ def main():
                     result["arithmetic_modes"][m2]["psnr_vs_oracle_db"] = cpu_baseline.psnr_of(fr)
                 result["psnr_vs_oracle_db_by_arithmetic"] = {m2: v["psnr_vs_oracle_db"] for m2, v in result["arithmetic_modes"].items()}
                 result["decoder_error_vs_float64_by_arithmetic"] = decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine)
+                # where the frame error sits: rays whose importance samples land in other bins than the checker's, per arithmetic
+                result["frame_error_evidence"] = frame_error_evidence(nvsr_amd, mc, mf, sid, rays_row)
         if world == 1 and not args.no_modes and not args.no_other_workloads and H == 800 and args.plane_res == 800:
             # The other BASELINE configurations of the same path, measured in this same driver-timed process (short runs; each is also its
             # own `--workload`): configs[3] = the 4 096-ray Feature_Planes_Only optimisation step, configs[2]'s SR stage = EDSR 256 x 32 on
@@ -897,6 +975,7 @@ def main():
                     other[wl] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
             result["other_workloads"] = other
+        result["collectives"] = comm
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

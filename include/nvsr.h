@@ -221,9 +221,13 @@ int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, 
                                   float* z_fine, nvsr_stream_t stream);
 
 /* ---- tri-plane decoder -------------------------------------------------------------------------------------------- */
-/* TwoDimPlanesModel.forward (models.py:381-421): x [P,6] = [xyz, viewdir] -> out [P,4] = [rgb_raw, sigma_raw] */
+/* TwoDimPlanesModel.forward (models.py:381-421): x [P,6] = [xyz, viewdir] -> out [P,4] = [rgb_raw, sigma_raw].  In the process's default
+ * arithmetic (round 4: the limb modes run the training forward's kernel on tiles of 32 consecutive points; NVSR_ARITH_F32 the exact-f32
+ * MFMA kernel); nvsr_triplane_decode_arith takes the mode per call. */
 int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out,
                          nvsr_stream_t stream);
+int nvsr_triplane_decode_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out, int arithmetic,
+                               nvsr_stream_t stream);
 
 /* ---- compositing -------------------------------------------------------------------------------------------------- */
 /* volume_render_radiance_field (volume_rendering_utils.py:6-51), mip_nerf=False.  raw [N,S,4], z [N,S], rd [N,3],

@@ -71,6 +71,7 @@ _PROTOS = {
     "nvsr_importance_resample": ([_i64, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_importance_resample_rays": ([_i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_triplane_decode": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _vp], _i),
+    "nvsr_triplane_decode_arith": ([C.POINTER(Scene), _vp, _i64, _vp, _vp, _i, _vp], _i),
     "nvsr_composite": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_rays": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_mip": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),

@@ -266,23 +266,29 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
     // A wave's tile = 32 CONSECUTIVE SAMPLES OF ONE RAY (like render_bwd_limb.hip): their bilinear taps fall into the same or neighbouring
     // texel cells, so the 64 lanes of a gather load share cache lines (tools/gather_ubench.hip: 90 vs 30 GB/s per CU against 32 unrelated
     // rays); the ray, its gates and raw rows are contiguous per tile.
+    // S = 1 -- a list of POINTS handed over as one-sample rays (TwoDimPlanesModel.forward stand-alone, models.py:381-421): a tile is 32
+    // consecutive points, not the one sample of one ray
     const int nsc = (S + 31) / 32;                                     // sample chunks per ray
-    const long ntiles = (N * nsc + L3_WAVES - 1) / L3_WAVES;
+    const long nwt = S == 1 ? (N + 31) / 32 : N * nsc;                 // wave tiles
+    const long ntiles = (nwt + L3_WAVES - 1) / L3_WAVES;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
         const long wt = tile * L3_WAVES + rs.wave;
-        const long ray0 = wt / nsc;
-        const int s0 = (int)(wt - ray0 * nsc) * 32 + (rs.lane & 31);
+        const long ray0 = S == 1 ? wt * 32 + (rs.lane & 31) : wt / nsc;
+        const int s0 = S == 1 ? 0 : (int)(wt - ray0 * nsc) * 32 + (rs.lane & 31);
         const bool valid = ray0 < N && s0 < S;
         const long ray = ray0 < N ? ray0 : N - 1;
         const int s = s0 < S ? s0 : S - 1;
-        const float* r = rays + ray * 11;
-        const float zc = z[ray * S + s];
-        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
+        // z = NULL: `rays` is a list of points [N,6] = [xyz, viewdir] (S = 1; nvsr_triplane_decode)
+        const float* r = rays + ray * (z ? 11 : 6);
+        const float zc = z ? z[ray * S + s] : 0.0f;
+        const Taps vt = z ? view_taps(sc, r[8], r[9], r[10]) : view_taps(sc, r[3], r[4], r[5]);
+        const float ppx = z ? __fadd_rn(r[0], __fmul_rn(r[3], zc)) : r[0];
+        const float ppy = z ? __fadd_rn(r[1], __fmul_rn(r[4], zc)) : r[1];
+        const float ppz = z ? __fadd_rn(r[2], __fmul_rn(r[5], zc)) : r[2];
         float raw[4];
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
-        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, __fadd_rn(r[0], __fmul_rn(r[3], zc)), __fadd_rn(r[1], __fmul_rn(r[4], zc)),
-                                            __fadd_rn(r[2], __fmul_rn(r[5], zc)), vt, raw, gl, rec, record_row(ray, s, N, S), valid, nscale);
+        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, ppx, ppy, ppz, vt, raw, gl, rec, record_row(ray, s, N, S), valid, nscale);
         if (valid && rs.lane < 32) {
             *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
             // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag)
@@ -298,7 +304,8 @@ using namespace nvsr;
 // nvsr_decode_rays_ex (render.hip) with the decoder arithmetic set to bf16 limbs; arguments already validated there
 extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                             const float* z, float* raw, uint32_t* gates, float* record, nvsr_stream_t stream) {
-    const int64_t ntiles = (N * (int64_t)((S + 31) / 32) + L3_WAVES - 1) / L3_WAVES;       // 4 wave tiles (ray, 32 samples) per workgroup step
+    const int64_t nwt = S == 1 ? (N + 31) / 32 : N * (int64_t)((S + 31) / 32);            // wave tiles: (ray, 32 samples), or 32 points when S = 1
+    const int64_t ntiles = (nwt + L3_WAVES - 1) / L3_WAVES;                                // 4 wave tiles per workgroup step
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     if (limbs == 2 && !record) {        // f16 limbs: no weight-gradient record (it holds unscaled f32 layer inputs)
         if (gates)

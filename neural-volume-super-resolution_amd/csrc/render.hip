@@ -287,11 +287,21 @@ static int check_scene(const nvsr_scene* s) {
 
 int nvsr_triplane_decode(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out,
                          nvsr_stream_t stream) {
+    return nvsr_triplane_decode_arith(scene, packed_decoder, P, x, out, NVSR_ARITH_INHERIT, stream);
+}
+
+int nvsr_triplane_decode_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t P, const float* x, float* out, int arithmetic,
+                               nvsr_stream_t stream) {
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    if (arith < 0) return NVSR_ERR_SHAPE;
     if (int e = check_scene(scene)) return e;
     if (!packed_decoder || !x || !out) return NVSR_ERR_NULL;
     if (!aligned16(packed_decoder) || !aligned16(out)) return NVSR_ERR_ALIGN;
     if (P < 0) return NVSR_ERR_SHAPE;
     if (P == 0) return NVSR_OK;
+    // limb arithmetics: the training forward's kernel on the point list (z = NULL, one sample per "ray": tiles of 32 consecutive points)
+    if (arith != NVSR_ARITH_F32)
+        return nvsr_decode_rays_limb_launch(arith == NVSR_ARITH_F16X2 ? 2 : 3, scene, packed_decoder, P, 1, x, nullptr, out, nullptr, nullptr, stream);
     const int64_t ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(triplane_decode_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,

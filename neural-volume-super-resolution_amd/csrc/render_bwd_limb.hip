@@ -24,6 +24,10 @@
 #define BL_SCATTER 3  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once (bookkeeping per point on the scalar unit), 3 the same with the bookkeeping per tile on the vector unit
 #endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
+#ifndef BL_F16_UP
+#define BL_F16_UP 3   // f16-limb backward: power of two put on top of a point's normalised gradient (see pow2_scales)
+#endif
+
 #include "limb_core.h"
 #include "bwd_core.h"
 
@@ -34,8 +38,8 @@ namespace nvsr {
 #endif
 constexpr int BL_TPB = 64 * BL_WAVES_N, BL_WAVES = BL_TPB / 64, BL_PTS = BL_WAVES * 32;
 constexpr int BL_WG_PER_CU = BL_WAVES_N == 4 ? 2 : 1;
-// LF = limbs of the transposed-layer products: 3 bf16 limbs, or (round 3) 2 f16 limbs with the gradients of a wave
-// tile scaled by a power of two so that their largest magnitude is in [1, 2) -- gradients span many decades, a tile's do not
+// LF = limbs of the transposed-layer products: 3 bf16 limbs, or (round 3) 2 f16 limbs with the gradient of every POINT
+// scaled by a power of two so that its largest magnitude is in [1, 2) -- gradients span many decades, a point's 128 features do not
 template <int LF>
 struct BLds {
     static constexpr int SMALL = 2 * BLimb<LF>::CHUNK_WORDS;
@@ -202,28 +206,41 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         const float zc = z[ray * S + s];
         f32x4 graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // f16 limbs: the tile's gradients times 2^-floor(log2(max |dL/draw|)) (exact; wave-uniform), undone on the feature gradients below.
-        // Through the four transposed layers a gradient changes by a few binades at most: it stays inside the f16 limbs' 30; if not, the
-        // overflow reaches the planes as NaN.
-        float gscale = 1.0f, gunscale = 1.0f;
+        // f16 limbs: every POINT's gradient times 2^-floor(log2(max |dL/draw| of the point)) (exact), undone on the feature gradients below.
+        // A point is a column of every product of the chain (D[:, pt] = W^T G[:, pt]): a scale per column is exact, and both lane halves of
+        // a column hold the same dL/draw, so no reduction is needed.  Round 3 scaled a whole wave tile (32 samples of one ray) by the tile's
+        // largest magnitude: behind a surface dL/draw falls with the transmittance by more than 2^24 INSIDE a tile, and the samples far below
+        // the largest lost their low limb, then their high one (relative error of a texel up to 1.3 % where the 3-bf16-limb backward has 0.1 %:
+        // tests/test_hip_round4.py::test_f16_backward_with_the_dynamic_range_of_an_opaque_ray).  Through the four transposed layers
+        // a point's gradient changes by a few binades at most: it stays inside the f16 limbs' 30; if not, the overflow reaches the planes as
+        // NaN.  The exponent is clamped to [1, 253]: both factors stay normal numbers (a largest magnitude of 2^127 would give a scale of 0).
+        // The two chains of a point -- density (from dL/dsigma) and rgb (from the three dL/drgb) -- carry a scale each: behind a surface
+        // dL/dsigma and dL/drgb of ONE sample differ by many binades too; they meet as true f32 magnitudes (gD is unscaled when the density
+        // chain ends, a plane's rgb part by the FMA that adds gD).
+        float gs_d = 1.0f, gu_d = 1.0f, gs_r = 1.0f, gu_r = 1.0f;
+        const f32x4 graw_true = graw;
         if constexpr (LF == 2) {
-            float m = fmaxf(fmaxf(fabsf(graw[0]), fabsf(graw[1])), fmaxf(fabsf(graw[2]), fabsf(graw[3])));
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);              // biased exponent of the tile's largest magnitude (0: all zero)
-            const int eu = __builtin_amdgcn_readfirstlane(e == 0 || e == 255 ? 127 : e);
-            gscale = __uint_as_float((unsigned)(254 - eu) << 23);                  // 2^-(e - 127)
-            gunscale = __uint_as_float((unsigned)eu << 23);
-            graw = graw * gscale;
+            auto pow2_scales = [](float m, float& sc_, float& un_) {
+                const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent of the largest magnitude (0: all zero)
+                // BL_F16_UP: the largest magnitude goes to [2^UP, 2^(UP+1)) instead of [1, 2) -- the chain shrinks a gradient by ~0.4 per
+                // layer on typical weights and nothing rescales between layers, so from [1, 2) the low limbs of the last layers would be
+                // subnormal; f16 overflows at 2^16: 2^(15 - UP) of growth over head + 4 layers remain
+                const int eu = ((e == 0 || e == 255) ? 127 : (e > 253 ? 253 : (e < 1 + BL_F16_UP ? 1 + BL_F16_UP : e))) - BL_F16_UP;
+                sc_ = __uint_as_float((unsigned)(254 - eu) << 23);                 // 2^-(e - UP - 127)
+                un_ = __uint_as_float((unsigned)eu << 23);
+            };
+            pow2_scales(fabsf(graw[3]), gs_d, gu_d);
+            pow2_scales(fmaxf(fabsf(graw[0]), fmaxf(fabsf(graw[1]), fabsf(graw[2]))), gs_r, gu_r);
         }
         const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
         // (f16 limbs: the accumulators carry the tile's power-of-two scale; the weight-gradient contraction reads unscaled f32 rows)
+        float gunscale = gu_d;        // unscale of the chain being walked (record rows)
         auto record_grad = [&](float* base, long q_, int h_, const f32x16 (&a)[4]) {
             if constexpr (LF == 2) record128_scaled(base, q_, h_, a, gunscale);
             else record128(base, q_, h_, a);
         };
-        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = LF == 2 ? graw * gunscale : graw;     // (the record holds UNSCALED gradients)
+        if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw_true;     // (the record holds UNSCALED gradients)
         // Everything below is re-read where it is used instead of being kept across the step (two accumulator sets, gD and the limbs
         // already fill the 256 registers of a wave at two waves per SIMD): a layer's two gate words (slot 0..3 density, 4..7 rgb) ...
         typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             for (int qq = 0; qq < 4; ++qq) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(small + S_ALPHA_W + (ib * 4 + qq) * 8 + h * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = wv[j] * graw[3];
+                for (int j = 0; j < 4; ++j) accA[ib][4 * qq + j] = wv[j] * (graw[3] * gs_d);
             }
         apply_mask(gate(3), accA);
         BL_FENCE(accA)      // the masked gradient is a value of its own: without the fence hipcc keeps mask AND unmasked value alive to fold
@@ -323,12 +340,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);        // (f16 limbs: still times the tile's scale, like the rgb branch's gF it is added to)
+            for (int rr = 0; rr < 16; ++rr) gD[b][rr] = LF == 2 ? div3(gD[b][rr]) * gu_d : div3(gD[b][rr]);     // (f16 limbs: back to its true magnitude)
         // ---- rgb branch
         asm volatile("" ::: "memory");
         graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
         if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (LF == 2) graw = graw * gscale;
+        if constexpr (LF == 2) graw = graw * gs_r;
+        gunscale = gu_r;
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -355,13 +373,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? gD[b][rr] : 0.0f;
+                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3 && LF != 2) ? gD[b][rr] : 0.0f;
             BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
-            if constexpr (LF == 2) {
+            if constexpr (LF == 2) {        // the rgb part back to its true magnitude, plus the density part (position planes)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) gF[b][rr] *= gunscale;
+                    for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? fmaf(gF[b][rr], gu_r, gD[b][rr]) : gF[b][rr] * gu_r;
             }
             if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {

@@ -42,6 +42,9 @@ def gather_row_blocks(local, counts, group=None, out=None):
     index_select.  A backend that only moves host buffers (gloo rehearsals) stages through the host."""
     rank, world = world_info(group)
     if world == 1:
+        if out is not None:
+            out.copy_(local)
+            return out
         return local
     assert local.shape[0] == counts[rank]
     cdev = _collective_device(local, group)
@@ -161,6 +164,28 @@ def super_resolve_planes_sharded(sr_model, plane_names, group=None, sr_fn=None):
     return [sr_model.SR_planes[n] for n in plane_names]
 
 
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def allreduce_in_place(tensors, group=None, scale=None):
+    """Sum DENSE tensors (row-major, or channels_last like the plane gradients) over the ranks IN PLACE: one asynchronous all-reduce per
+    tensor, all queued before the first wait, no flattening copy in and none out; then one fused multiply by `scale`.  A channels_last
+    [N,C,H,W] tensor is handed to the collective as its row-major [N,H,W,C] view (same storage): every backend reduces a plain contiguous
+    buffer.  This is the RCCL path of allreduce_gradients; tests/test_distributed.py runs it over gloo on host tensors."""
+    if not tensors:
+        return
+    for t in tensors:
+        if not _dense(t):
+            raise ValueError("allreduce_in_place: tensor with strides %s is not dense" % (tuple(t.stride()),))
+    views = [t if t.is_contiguous() else t.permute(0, 2, 3, 1) for t in tensors]
+    works = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in views]
+    for wk in works:
+        wk.wait()
+    if scale is not None:
+        torch._foreach_mul_(list(tensors), scale)
+
+
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):
     """Sum (or average) a list of gradient tensors over the ranks.  The loss is a mean over rays (train_nerf.py:884-891), so with rays
     sharded evenly the data-parallel gradient is the average of the per-rank gradients.
@@ -174,17 +199,9 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True
     tensors = [t for t in tensors if t is not None]
     scale = 1.0 / world if average else None
 
-    def dense(t):
-        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
-
-    direct = [t for t in tensors if t.is_cuda and dense(t)] if dist.get_backend(group) == "nccl" else []
-    if direct:
-        # one asynchronous collective per tensor, queued back to back on RCCL's stream (4 planes + 2 decoder blobs per step), then one wait
-        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in direct]
-        for wk in works:
-            wk.wait()
-        if scale is not None:
-            torch._foreach_mul_(direct, scale)
+    # RCCL: one asynchronous collective per tensor, queued back to back on its stream (4 planes + 2 decoder blobs per step), then one wait
+    direct = [t for t in tensors if t.is_cuda and _dense(t)] if dist.get_backend(group) == "nccl" else []
+    allreduce_in_place(direct, group, scale)
     ids = {id(t) for t in direct}
     bucket, size = [], 0
 

@@ -507,7 +507,7 @@ class TwoDimPlanesModel(nn.Module):
                 out = _DecodePointsFn.apply(self, x.reshape(P, 6), *planes, self.natural_blob(differentiable=True) if dec else None)
                 return out.reshape(list(x.shape[:-1]) + [4])
         planes, consts = self.scene_args()
-        out = torch.ops.nvsr.triplane_decode(planes, consts, self.packed_decoder(), x.reshape(P, 6))
+        out = torch.ops.nvsr.triplane_decode(planes, consts, self.packed_decoder(), x.reshape(P, 6), self.arith())
         return out.reshape(list(x.shape[:-1]) + [4])
 
 

@@ -176,19 +176,20 @@ def _(z_coarse, weights, Nf, u):
 # tri-plane decoder (models.py:381-421) and the render passes (train_utils.py:71-182)
 # =====================================================================================================================================
 @custom_op("nvsr::triplane_decode", mutates_args=(), device_types="cuda")
-def triplane_decode(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, x: Tensor) -> Tensor:
-    """TwoDimPlanesModel.forward on points: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb_raw, sigma_raw] (exact-f32 MFMA kernel)"""
+def triplane_decode(planes: Sequence[Tensor], consts: Sequence[float], packed: Tensor, x: Tensor, arith: int = -1) -> Tensor:
+    """TwoDimPlanesModel.forward on points: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb_raw, sigma_raw].  arith: NVSR_ARITH_* (-1 = the process
+    default): the limb modes run the training forward's kernel on tiles of 32 points, 0 the exact-f32 MFMA kernel"""
     x = _c(x)
     sc = _scene(planes, consts)
     P = x.shape[0]
     out = _f(P, 4, like=x)
     if P:
-        capi.call("nvsr_triplane_decode", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), capi.stream())
+        capi.call("nvsr_triplane_decode_arith", C.byref(sc), capi.ptr(packed), P, capi.ptr(x), capi.ptr(out), int(arith), capi.stream())
     return out
 
 
 @triplane_decode.register_fake
-def _(planes, consts, packed, x):
+def _(planes, consts, packed, x, arith=-1):
     return x.new_empty((x.shape[0], 4))
 
 

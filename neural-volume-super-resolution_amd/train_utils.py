@@ -117,10 +117,17 @@ class _RenderRaysFn(torch.autograd.Function):
         saved.update(disp_c=disp_c.detach(), acc_c=acc_c.detach())
         if Nf > 0:
             saved.update(disp_f=disp_f.detach(), acc_f=acc_f.detach())
+        # autograd's version check: everything the backward reads -- the forward's intermediates and the channel-last planes (views of the
+        # plane parameters, sharing their version counters) -- also goes through save_for_backward, so an in-place update of a plane or of a
+        # saved tensor between forward and backward raises instead of producing the gradient of another function
+        guarded = [t for t in list(saved.values()) + list(cfg["planes_c"]) + list(cfg["planes_f"]) + [rays, cfg["packed_c"], cfg["packed_f"]]
+                   if isinstance(t, torch.Tensor)]
+        ctx.save_for_backward(*guarded)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
+        ctx.saved_tensors          # (raises if a tensor saved by the forward was modified in place since)
         cfg, sv = ctx.cfg, ctx.saved
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
         nv = _NV()

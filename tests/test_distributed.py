@@ -47,6 +47,29 @@ def _worker(rank, world, port, tmp):
     grads = [torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(rank + 1)), torch.full((70000,), float(rank + 1))]
     D.allreduce_gradients(grads, bucket_bytes=1 << 16)
     assert all(torch.allclose(g, torch.full_like(g, 1.5)) for g in grads)
+    # the RCCL branch of allreduce_gradients (allreduce_in_place: one in-place asynchronous all-reduce per dense tensor, queued, then waited
+    # for, then ONE fused scale) on this backend: row-major and channels_last tensors -- the plane gradients are channels_last -- with values
+    # that tell a transposed reduction from a correct one; a non-dense tensor is refused
+    base = torch.arange(2 * 6 * 4 * 5, dtype=torch.float32).reshape(2, 6, 4, 5)
+    cl = (base * (rank + 1)).contiguous(memory_format=torch.channels_last)
+    rm = torch.arange(37, dtype=torch.float32) * (rank + 1)
+    plane = (base[:1] * (rank + 2)).contiguous(memory_format=torch.channels_last)
+    assert not cl.is_contiguous() and cl.is_contiguous(memory_format=torch.channels_last)
+    ptrs = [t.data_ptr() for t in (cl, rm, plane)]
+    D.allreduce_in_place([cl, rm, plane], scale=0.5)
+    assert torch.equal(cl, base * 1.5) and torch.equal(rm, torch.arange(37, dtype=torch.float32) * 1.5) and torch.equal(plane, base[:1] * 2.5)
+    assert [t.data_ptr() for t in (cl, rm, plane)] == ptrs and cl.is_contiguous(memory_format=torch.channels_last)     # in place, layout kept
+    D.allreduce_in_place([])
+    try:
+        D.allreduce_in_place([base[:, ::2]])
+        raise AssertionError("a strided tensor was accepted")
+    except ValueError:
+        pass
+    # gather_row_blocks into a caller's buffer: ragged split (3 + 4 rows) and the one-rank case
+    mine = torch.full((3 + rank, 2), float(rank + 1))
+    out = torch.empty(7, 2)
+    got = D.gather_row_blocks(mine, [3, 4], out=out)
+    assert got is out and torch.equal(out[:3], torch.full((3, 2), 1.0)) and torch.equal(out[3:], torch.full((4, 2), 2.0))
     # band-sharded SR stage: a stand-in SR function whose value depends on the HR position only (like the real net, whose output
     # does not depend on the ROI), NaN outside the ROI it was asked for; R0 = 7 rows is not divisible by 2
     sf, R0, R1 = 4, 7, 6
@@ -74,6 +97,14 @@ def _worker(rank, world, port, tmp):
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+def test_gather_row_blocks_fills_the_callers_buffer_on_one_rank():
+    sys.path.insert(0, ROOT)
+    import nvsr_amd
+    local, out = torch.arange(6.0).reshape(3, 2), torch.zeros(3, 2)
+    got = nvsr_amd.distributed.gather_row_blocks(local, [3], out=out)
+    assert got is out and torch.equal(out, local)
 
 
 def test_shard_bounds_cover_everything():

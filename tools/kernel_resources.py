@@ -5,8 +5,8 @@
 
 The code objects are unbundled with `llvm-objdump --offloading` into a TEMPORARY directory (the tool drops them into its working
 directory -- never run it inside the source tree) and their `amdhsa.kernels` notes are parsed.  --check applies the spill gate of
-tests/test_host.py::test_no_spills_on_benchmarked_kernels: kernels on a benchmarked path must not spill vector registers beyond
-ALLOW (name substring -> max spilled VGPRs)."""
+tests/test_host.py::test_no_spills_on_benchmarked_kernels to EVERY kernel: no scratch, no spilled vector registers, except the listed
+exact-f32 opt-in kernels and ALLOW (name substring -> max spilled VGPRs)."""
 import argparse
 import json
 import os
@@ -27,11 +27,15 @@ BENCHMARKED = [
     "view_reduce_scatter", "decoder_wgrad_limb_kernel", "head_wgrad_kernel",
     "conv3x3_limb_kernel", "conv3x3_limb16_kernel", "conv3x3_wgrad_limb_kernel", "sr_prepare_kernel", "sr_finish_kernel",
 ]
-# name substring -> spilled VGPRs tolerated (a kernel not listed: 0).  What is listed is debt, with the round that recorded it:
-#   decoder_wgrad_limb_kernel<4>: 35 in the flush epilogue of its 256 accumulators (outside the row loop), round 2
-# (round 2 also listed render_pass3_*<3> with 14-16: hipcc had hoisted the limb split of the loop-invariant view features out of the sample
-#  loop and spilled part of it; round 3 makes the features opaque per iteration -- 0 spills, 0 scratch)
+# The gate covers EVERY kernel of the library (round 4; round 3 covered the benchmarked ones): no scratch memory, no spilled VGPRs -- except:
+#   ALLOW  name substring -> spilled VGPRs tolerated.  What is listed is debt, with the round that recorded it:
+#     decoder_wgrad_limb_kernel<4>: 35 in the flush epilogue of its 256 accumulators (outside the row loop), round 2
+#   F32_OPT_IN  the exact-f32 MFMA kernels of rounds 1-2.  Since round 4 no default path reaches them (TwoDimPlanesModel.forward stand-alone
+#     runs the limb kernel too): they run only when a caller selects NVSR_ARITH_F32 explicitly, as the bit-grade reference arithmetic that
+#     the limb modes are measured against, never in a benchmarked configuration.  Listed by name so that a NEW kernel cannot hide here.
+#   Spilled VGPRs with 0 bytes of scratch are copies into free AGPRs (v_accvgpr_write): no memory traffic; tolerated up to 16.
 ALLOW = {"decoder_wgrad_limb_kernelILi4": 35}
+F32_OPT_IN = ["render_pass_kernel", "decode_rays_kernelILb", "triplane_decode_kernel", "render_pass_backward_gates_kernelILb"]
 
 
 def _tool(name):
@@ -68,20 +72,25 @@ def kernel_table(lib=DEFAULT_LIB):
     if filt and names:
         dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
     for r, d in zip([r for r in rows if "vgpr_count" in r], dem):
-        out.append({"name": d, "vgpr": int(r.get("vgpr_count", 0)), "agpr": int(r.get("agpr_count", 0)), "sgpr": int(r.get("sgpr_count", 0)),
+        out.append({"name": d, "mangled": r.get("name", ""), "vgpr": int(r.get("vgpr_count", 0)), "agpr": int(r.get("agpr_count", 0)), "sgpr": int(r.get("sgpr_count", 0)),
                     "vgpr_spill": int(r.get("vgpr_spill_count", 0)), "sgpr_spill": int(r.get("sgpr_spill_count", 0)),
                     "scratch": int(r.get("private_segment_fixed_size", 0)), "lds": int(r.get("group_segment_fixed_size", 0)),
                     "wg_max": int(r.get("max_flat_workgroup_size", 0))})
     return out
 
 
-def violations(table):
+def violations(table, raw_names=None):
+    """kernels that break the gate.  table rows carry demangled names; F32_OPT_IN / ALLOW match mangled-name substrings (kept in `mangled`)."""
     bad = []
     for k in table:
-        if not any(b in k["name"] for b in BENCHMARKED):
+        key = k.get("mangled", k["name"])
+        if any(s in key for s in F32_OPT_IN):
             continue
-        allow = max([v for s, v in ALLOW.items() if s in k["name"]] or [0])
-        if k["vgpr_spill"] > allow or (allow == 0 and k["scratch"] > 0 and k["vgpr_spill"] > 0):
+        allow = max([v for s, v in ALLOW.items() if s in key] or [0])
+        if allow:
+            if k["vgpr_spill"] > allow:
+                bad.append(k)
+        elif k["scratch"] > 0 or k["vgpr_spill"] > 16:
             bad.append(k)
     return bad
 
