@@ -89,22 +89,28 @@ int nvsr_version(void);
  *                     2^-6 <= |x| < 4094; below that the low limb is subnormal (honoured by the matrix pipe) and the error is absolute,
  *                     <= 2^-33 per weight and <= 2^-29 per activation; a weight >= 255 or an activation >= 4094 overflows to inf and
  *                     the pixel comes out NaN -- loud, never a wrong number (use BF16X3 or F32 for such a network).
- *                     The fused render pass (inference), the training forward (nvsr_decode_rays*) of a pass whose decoder is not being
- *                     trained, i.e. without a weight-gradient record, and the gate-driven backward (nvsr_render_pass_backward_gates*)
- *                     with or without the record: gradients span many decades from ray to ray but not inside a wave tile of 32
- *                     samples of one ray, so the backward scales every tile by its own power of two (largest |dL/draw| of the tile in
- *                     [1, 2), undone on the feature gradients before they are scattered) and multiplies by UNSCALED transposed weights
- *                     (low limb subnormal below |w| = 0.125: absolute error <= 2^-25, ~1e-6 of a typical weight).  Against the exact-f32
- *                     backward on the same gates its plane gradients are as close as the 3-limb backward's (relative L2 ~1e-6: the
- *                     float atomics' ordering noise; tests/test_hip_round3.py::test_f16_backward_matches_the_f32_backward); the
- *                     gradient half of the record is written UNSCALED.  The recording forward (the record holds unscaled f32 layer
- *                     inputs and the pass is bound by writing them) and the weight-gradient contraction run BF16X3 when F16X2 is selected.
+ *                     The fused render pass (inference), the training forward (nvsr_decode_rays*) and the gate-driven backward
+ *                     (nvsr_render_pass_backward_gates*), each with or without the weight-gradient record.  Gradients span many decades --
+ *                     from ray to ray and, behind a surface, from sample to sample of one ray and between dL/dsigma and dL/drgb of one
+ *                     sample -- but the 128 features of one chain of one POINT do not: the backward scales every point's density chain
+ *                     and rgb chain by their own powers of two (exact: a point is a column of every product; the largest |dL/draw| of
+ *                     the chain goes to [2^3, 2^4), undone when the chains meet and before the feature gradients are scattered) and
+ *                     multiplies by UNSCALED transposed weights (low limb subnormal below |w| = 0.125: absolute error <= 2^-25, ~1e-6
+ *                     of a typical weight).  Against the exact-f32 backward on the same gates its plane gradients are as close as the
+ *                     3-limb backward's -- relative L2 ~1e-6, worst texel 0.1 % on the gradients of an opaque scene (round 3 scaled
+ *                     whole wave tiles: 7e-6 / 1.3 % there; tests/test_hip_round4.py::test_f16_backward_with_the_dynamic_range_of_an_
+ *                     opaque_ray, tests/test_hip_round3.py::test_f16_backward_matches_the_f32_backward); the
+ *                     gradient half of the record is written UNSCALED, and so is the layer-input half by the recording
+ *                     forward (round 4: a pass runs ONE arithmetic, forward and backward, with or without a record).  The weight-gradient
+ *                     contraction (nvsr_decoder_weight_grad*) reads that f32 record and runs BF16X3 when F16X2 is selected.
  *                     The gates a forward publishes are signs of pre-activations: any limb backward consumes any limb forward's.
  * The mode is a per-call argument of the *_arith entry points below (NVSR_ARITH_INHERIT = the process default); every other entry point
  * uses the process default, whose initial value comes from the environment variable NVSR_DECODER_ARITHMETIC = f32 | bf16x3 | f16x2
  * and which nvsr_set_decoder_arithmetic changes.  Nothing but that default is process-global: calls with explicit modes are re-entrant
  * across threads and streams. */
 #define NVSR_ARITH_INHERIT (-1)
+#define NVSR_ARITH_INVALID (-2)     /* what nvsr_get_*_arithmetic returns when the environment variable holds an unknown string: every call
+                                       that inherits the process default then fails with NVSR_ERR_SHAPE until nvsr_set_*_arithmetic is called */
 #define NVSR_ARITH_F32 0
 #define NVSR_ARITH_F16X2 2
 #define NVSR_ARITH_BF16X3 3
@@ -436,7 +442,7 @@ int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* 
 
 /* ---- per-call arithmetic -----------------------------------------------------------------------------------------------------
  * Twins of the entry points above that run decoder GEMMs or SR convolutions, with the arithmetic as an explicit argument
- * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_F16X2 (decoder forward only) | NVSR_ARITH_INHERIT).  Same arguments, same
+ * (NVSR_ARITH_F32 | NVSR_ARITH_BF16X3 | NVSR_ARITH_F16X2 | NVSR_ARITH_INHERIT).  Same arguments, same
  * semantics; the un-suffixed entry points are these called with NVSR_ARITH_INHERIT.  A backward call must be given the mode of the
  * forward whose gates / record / activations it consumes (the host mirror stores it with the autograd context).
  * rows_per_tile (convolutions): 0 = the launcher's choice, 2 | 3 | 4 = force that row-tile instantiation of the wide kernels (two output

@@ -258,6 +258,10 @@ def lib():
         for name, (args, res) in {**_PROTOS, **_PROTOS_OPTIONAL}.items():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, res
+        for var, get in (("NVSR_DECODER_ARITHMETIC", _lib.nvsr_get_decoder_arithmetic), ("NVSR_CONV_ARITHMETIC", _lib.nvsr_get_conv_arithmetic)):
+            if get() not in ARITHMETIC.values():          # (NVSR_ARITH_INVALID: an unknown string must not quietly select the default)
+                bad, _lib = _lib, None
+                raise NvsrError("%s=%r is not one of %s" % (var, os.environ.get(var), " | ".join(ARITHMETIC)))
     return _lib
 
 

@@ -199,6 +199,12 @@ __device__ __forceinline__ void record24(float* __restrict__ row, int h, const f
         *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
 }
 
+__device__ __forceinline__ void record24_scaled(float* __restrict__ row, int h, const float (&f)[HALF_C], float k) {
+#pragma unroll
+    for (int i = 0; i < HALF_C / 4; ++i)
+        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i] * k, f[4 * i + 1] * k, f[4 * i + 2] * k, f[4 * i + 3] * k};
+}
+
 // MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
 // wl[g] (256 floats [lane][j], one conflict-free ds_read_b128) and the 4 B registers b(g, j).  Pinned order per group: MFMA,
 // ds_read of the NEXT fragment, 3 MFMAs -- hipcc waits with lgkmcnt(0) in front of a group's first MFMA, i.e. for every

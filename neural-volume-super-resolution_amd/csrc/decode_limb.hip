@@ -104,7 +104,6 @@ __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* 
 template <bool MASKS, bool RECORD, int LF>
 __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, const float* small, float px, float py, float pz, const Taps& vt_,
                                                  float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok, float nsc) {
-    static_assert(LF == 3 || !RECORD, "the weight-gradient record holds unscaled f32 layer inputs: 3-limb forward only");
     auto scaled = [](Taps t) {          // f16 limbs: features carry 2^F16_SX, put on the four blend weights (exact)
         if constexpr (LF == 2) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; }
         return t;
@@ -112,6 +111,13 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     const Taps vt = scaled(vt_);
     asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));       // (see decode_step: keeps hipcc from hoisting per-lane addresses out of the tile loop)
     const int lane = rs.lane, h = lane >> 5;
+    const int& lane_h = h;
+    // (f16 limbs: features and activations carry 2^F16_SX in registers; the weight-gradient record holds UNSCALED f32 layer inputs: every
+    //  recorded value is multiplied by 2^-F16_SX on its way out -- exact)
+    constexpr float REC_UNSCALE = LF == 2 ? 1.0f / F16_X_SCALE : 1.0f;
+    auto rec24 = [&](float* row, const float (&f)[HALF_C]) {
+        if constexpr (LF == 2) record24_scaled(row, lane_h, f, REC_UNSCALE); else record24(row, lane_h, f);
+    };
     const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
     const float n1 = norm_coord(py, sc.lo[1], sc.range[1]);
     const float n2 = norm_coord(pz, sc.lo[2], sc.range[2]);
@@ -174,32 +180,32 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
             bias_relu<LF>(acc, small + S_BIAS + vec * HID, h, act, nsc);
         }
         if (MASKS && !(L3_ABLATE & 2)) publish_gates(act, gates, vec);
-        if (RECORD && rec_ok) record128(hrow, q, h, act);
+        if (RECORD && rec_ok) { if constexpr (LF == 2) record128_scaled(hrow, q, h, act, REC_UNSCALE); else record128(hrow, q, h, act); }
     };
     const long LP = (long)HID * rec.Pp;
 
     // ---- rgb layer 0: K = 192 in the limb blob's order [f_view | f0 | f1 | f2], one plane = one chunk ---------------------------------
     const unsigned* cw = L3_ISSUE(3, KB_RGB0);
     L3_GATHER(sc.plane[3], vt, h, F);
-    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 3 * C, h, F);
+    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + 3 * C, F);
     L3_BLOCK(3, true, feat(F), L3_ISSUE(3, KB_RGB0 + 3))
     L3_GATHER(sc.plane[0], pos_taps(0), h, F);
-    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C), h, F);
+    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C), F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
     L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 6))
     L3_GATHER(sc.plane[1], pos_taps(1), h, F);
-    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + C, h, F);
+    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + C, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
     L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 9))
     L3_GATHER(sc.plane[2], pos_taps(2), h, F);
-    if (RECORD && rec_ok) record24(rec.Xr + q * (4 * C) + 2 * C, h, F);
+    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + 2 * C, F);
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
     if (RECORD && rec_ok) {
-        record24(rec.Xd + q * 64, h, D);
+        rec24(rec.Xd + q * 64, D);
         *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
@@ -307,7 +313,12 @@ extern "C" int nvsr_decode_rays_limb_launch(int limbs, const nvsr_scene* scene, 
     const int64_t nwt = S == 1 ? (N + 31) / 32 : N * (int64_t)((S + 31) / 32);            // wave tiles: (ray, 32 samples), or 32 points when S = 1
     const int64_t ntiles = (nwt + L3_WAVES - 1) / L3_WAVES;                                // 4 wave tiles per workgroup step
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-    if (limbs == 2 && !record) {        // f16 limbs: no weight-gradient record (it holds unscaled f32 layer inputs)
+    if (limbs == 2 && record) {         // f16 limbs with the layer-input half of the weight-gradient record (written unscaled)
+        hipLaunchKernelGGL((decode_rays_limb_kernel<true, true, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
+                           (long)N, S, rays, z, raw, gates, make_record(record, (long)N, S), nvsr_get_range_flag());
+        return NVSR_CHECK_LAUNCH();
+    }
+    if (limbs == 2 && !record) {        // f16 limbs
         if (gates)
             hipLaunchKernelGGL((decode_rays_limb_kernel<true, false, 2>), dim3(grid), dim3(L3_TPB), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
                                (long)N, S, rays, z, raw, gates, DecRecord{}, nvsr_get_range_flag());

@@ -15,6 +15,7 @@
 //     B-fragment registers (channel-last planes), blends in registers;
 //   * the render pass walks the samples of its 32 rays front to back, so transmittance is a running product in a register
 //     (the reference's exclusive cumprod, in the same order) and only per-ray results are written.
+#include <stdio.h>
 #include <cstdlib>
 
 #include <cstring>
@@ -239,20 +240,27 @@ static int g_decoder_arithmetic = -1;
 
 extern "C" {
 
+// "f32" | "bf16x3" | "f16x2" -> the mode; unset or empty -> dflt; anything else -> NVSR_ARITH_INVALID (said once on stderr): every call that
+// inherits the process default then fails with NVSR_ERR_SHAPE instead of silently running the default (round 3 renamed bf16x2 -> f16x2:
+// a stale NVSR_DECODER_ARITHMETIC=bf16x2 must not quietly select another arithmetic)
+extern "C" int nvsr_internal_parse_arith_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    if (!strcmp(e, "f32")) return NVSR_ARITH_F32;
+    if (!strcmp(e, "bf16x3")) return NVSR_ARITH_BF16X3;
+    if (!strcmp(e, "f16x2")) return NVSR_ARITH_F16X2;
+    fprintf(stderr, "nvsr: %s=%s is not one of f32 | bf16x3 | f16x2\n", name, e);
+    return NVSR_ARITH_INVALID;
+}
+
 int nvsr_get_decoder_arithmetic(void) {
-    if (g_decoder_arithmetic < 0) {
-        const char* e = getenv("NVSR_DECODER_ARITHMETIC");
-        g_decoder_arithmetic = NVSR_ARITH_DEFAULT;
-        if (e && !strcmp(e, "f32")) g_decoder_arithmetic = NVSR_ARITH_F32;
-        if (e && !strcmp(e, "bf16x3")) g_decoder_arithmetic = NVSR_ARITH_BF16X3;
-        if (e && !strcmp(e, "f16x2")) g_decoder_arithmetic = NVSR_ARITH_F16X2;
-    }
+    if (g_decoder_arithmetic == -1) g_decoder_arithmetic = nvsr_internal_parse_arith_env("NVSR_DECODER_ARITHMETIC", NVSR_ARITH_DEFAULT);
     return g_decoder_arithmetic;
 }
 
 /* NVSR_ARITH_INHERIT -> the process default; anything that is not a mode -> -1 */
 int nvsr_internal_resolve_decoder_arith(int arithmetic) {
-    if (arithmetic == NVSR_ARITH_INHERIT) return nvsr_get_decoder_arithmetic();
+    if (arithmetic == NVSR_ARITH_INHERIT) arithmetic = nvsr_get_decoder_arithmetic();
     return (arithmetic == NVSR_ARITH_F32 || arithmetic == NVSR_ARITH_BF16X3 || arithmetic == NVSR_ARITH_F16X2) ? arithmetic : -1;
 }
 

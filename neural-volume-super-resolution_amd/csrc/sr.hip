@@ -611,8 +611,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
     // |dy| of the whole tensor into [2^12, 2^13): gradients span many decades from layer to layer and step to step, a tensor's values a few
     float xscale = F16_X_SCALE;
     if (LIMBS == 2 && p.absmax) {
-        const int e = (int)((__builtin_amdgcn_readfirstlane((int)*p.absmax) >> 23) & 0xff);
-        xscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+        xscale = f16_gradient_scale((unsigned)__builtin_amdgcn_readfirstlane((int)*p.absmax));
     }
 
     float st[IT][8];
@@ -821,14 +820,9 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
 
 // arithmetic of the eligible conv layers (process-wide): -1 = not yet read from the environment
 static int g_conv_arithmetic = -1;
+extern "C" int nvsr_internal_parse_arith_env(const char* name, int dflt);      // render.hip
 extern "C" int nvsr_get_conv_arithmetic(void) {
-    if (g_conv_arithmetic < 0) {
-        const char* e = getenv("NVSR_CONV_ARITHMETIC");
-        g_conv_arithmetic = NVSR_CONV_ARITH_DEFAULT;
-        if (e && !strcmp(e, "f32")) g_conv_arithmetic = NVSR_ARITH_F32;
-        if (e && !strcmp(e, "bf16x3")) g_conv_arithmetic = NVSR_ARITH_BF16X3;
-        if (e && !strcmp(e, "f16x2")) g_conv_arithmetic = NVSR_ARITH_F16X2;
-    }
+    if (g_conv_arithmetic == -1) g_conv_arithmetic = nvsr_internal_parse_arith_env("NVSR_CONV_ARITHMETIC", NVSR_CONV_ARITH_DEFAULT);
     return g_conv_arithmetic;
 }
 extern "C" int nvsr_set_conv_arithmetic(int mode) {
@@ -840,8 +834,10 @@ extern "C" int nvsr_set_conv_arithmetic(int mode) {
 int conv_resolve_arith(int arith) { return arith == NVSR_ARITH_INHERIT ? nvsr_get_conv_arithmetic() : arith; }
 
 // max |x| of a tensor as the bits of a non-negative float (they order like unsigned integers): the scale of an f16-limb data gradient.
-// A ring of result words so that launches queued on different streams never share one; a word is zeroed by a memset queued in front.
-constexpr int ABSMAX_SLOTS = 1024;
+// A ring of result words handed out round-robin; a word is zeroed by a memset queued in front of its reduction.  A word is reused after
+// ABSMAX_SLOTS launches of this function in the process: 16 384 -- the backward of EDSR(32 blocks) takes ~70 per plane, so a kernel still
+// reading a word would have to be ~230 plane-backwards behind the host (on any stream) when the ring comes round; nothing tracks completion.
+constexpr int ABSMAX_SLOTS = 16384;
 __device__ unsigned g_absmax[ABSMAX_SLOTS];
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     // 16-byte loads over the aligned body, scalars over head / tail; one atomic per workgroup

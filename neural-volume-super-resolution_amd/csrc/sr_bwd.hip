@@ -415,8 +415,7 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
     __shared__ __attribute__((aligned(16))) unsigned lds[LF * (WL_DY_WORDS + WL_X_WORDS)];
     float dscale = 1.0f;          // f16 limbs: the power of two that puts the largest |dy| of the tensor into [2^12, 2^13) (sr.hip, the data gradient's rule)
     if (LF == 2 && p.dy_absmax) {
-        const int e = (int)((__builtin_amdgcn_readfirstlane((int)*p.dy_absmax) >> 23) & 0xff);
-        dscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+        dscale = f16_gradient_scale((unsigned)__builtin_amdgcn_readfirstlane((int)*p.dy_absmax));
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
@@ -474,8 +473,7 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 __global__ void wgrad_reduce_pieces_kernel(const float* __restrict__ partial, int n_wg, long total, long TS, int Cout, int Cin, float scale,
                                            float* __restrict__ dw, const unsigned* __restrict__ dy_absmax) {
     if (dy_absmax) {          // f16 limbs: the partial sums carry 2^F16_SX (X) times dy's scale
-        const int e = (int)((*dy_absmax >> 23) & 0xff);
-        const float dscale = (e == 0 || e == 255) ? 1.0f : __uint_as_float((unsigned)(254 + 12 - e) << 23);
+        const float dscale = f16_gradient_scale(*dy_absmax);
         scale *= 1.0f / (F16_X_SCALE * dscale);
     }
     const int n_ci = (Cin + WG_CI - 1) / WG_CI;

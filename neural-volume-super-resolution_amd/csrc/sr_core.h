@@ -6,6 +6,22 @@
 
 namespace nvsr {
 
+// f16-limb data / weight gradients of the SR network: the power of two that puts the largest |dy| of a gradient tensor (its bits in
+// `absmax_bits`, absmax_kernel) into [2^12, 2^13).  Exponent field clamped to 254 (a tensor whose largest magnitude is below 2^-115 would
+// otherwise ask for a scale beyond the largest finite power of two); an all-zero or non-finite tensor is not scaled.
+__host__ __device__ inline float f16_gradient_scale(unsigned absmax_bits) {
+    const int e = (int)((absmax_bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    const int s = 254 + 12 - e;
+    const unsigned bits = (unsigned)(s > 254 ? 254 : s) << 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(bits);
+#else
+    float f; __builtin_memcpy(&f, &bits, 4); return f;
+#endif
+}
+
+
 constexpr int K_PER_CHUNK = 18;                 // MFMA k-steps per 4-channel chunk (36 k / 2)
 constexpr int FRAG_FLOATS = K_PER_CHUNK * 64;   // 1152 floats per (chunk, co-block)
 

@@ -421,3 +421,17 @@ def test_no_spills_on_benchmarked_kernels(pkg):
     assert len(table) >= 60 and sum(any(s_ in k["mangled"] for s_ in kr.F32_OPT_IN) for k in table) <= 10       # the exemption list stays a list of names
     assert not bad, "spilling kernels: " + "; ".join(
         "%s: %d VGPRs, %d B scratch" % (k["name"][:90], k["vgpr_spill"], k["scratch"]) for k in bad)
+
+
+def test_unknown_arithmetic_in_the_environment_is_refused(pkg):
+    """NVSR_DECODER_ARITHMETIC / NVSR_CONV_ARITHMETIC holding anything but f32 | bf16x3 | f16x2 (round 3 renamed bf16x2 -> f16x2: a stale
+    setting must not quietly select another arithmetic): the library reports NVSR_ARITH_INVALID and the binding refuses to load."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import nvsr_amd; nvsr_amd.capi.lib()" % ROOT
+    for var in ("NVSR_DECODER_ARITHMETIC", "NVSR_CONV_ARITHMETIC"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{var: "bf16x2"}), capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "bf16x2" in p.stderr and "f16x2" in p.stderr, p.stderr[-500:]
+    p = subprocess.run([sys.executable, "-c", code + "; print(nvsr_amd.capi.get_decoder_arithmetic())"],
+                       env=dict(os.environ, NVSR_DECODER_ARITHMETIC="bf16x3"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip() == "bf16x3", p.stderr[-500:]
