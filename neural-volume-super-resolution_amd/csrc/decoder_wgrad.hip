@@ -143,7 +143,10 @@ __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, lo
 template <int NB>
 __device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int slab, float* tile, float* __restrict__ grad) {
     typedef float xvec __attribute__((ext_vector_type(NB)));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    // (wave index in a scalar register, lane from the hardware counter: with 256 accumulators + two row sets in flight every vector register
+    //  counts, and threadIdx.x kept alive across the row loop for the flush was one of 5 that spilled)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), i = lane & 31, kh = lane >> 5;
     const int per_wave = slab / 4;                                   // a multiple of 64 (the host makes slab a multiple of 256)
     const long q0 = (long)blockIdx.x * slab + (long)wave * per_wave;
     long q1 = q0 + per_wave;
@@ -222,16 +225,31 @@ __device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int sla
             }
         }
     }
+    // the bias sums first (they die here: the flush below needs every vector register); lane indices recomputed, not kept across the loop
+    const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), i2 = lane2 & 31, kh2 = lane2 >> 5;
+    if (jb.b_off >= 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float v = bs[a] + __shfl_xor(bs[a], 32);
+            if (kh2 == 0) unsafeAtomicAdd(grad + jb.b_off + 4 * i2 + a, v);
+        }
+    }
     // acc[a][b][r]: out = 4 * ((r&3) + 8(r>>2) + 4kh) + a,  column = NB * i + b.   Sum the 4 waves in LDS (same element per lane in every wave).
     constexpr int TW = 32 * NB;
+    // (ONE copy of the flush: unrolled four times hipcc moved all 256 accumulators out of their AGPRs ahead of the four copies and spilled 33)
+#pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
+            // (an LDS pointer with compile-time offsets: as a generic pointer the 64 addresses were computed as 64-bit values ahead of the
+            //  stores and 35 of them spilled -- the kernel's only scratch traffic)
+            typedef __attribute__((address_space(3))) xvec* lds_xvec_p;
+            const lds_xvec_p tb = (lds_xvec_p)(tile + 16 * kh2 * TW + NB * i2);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int out = 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + a;
-                    xvec* t = reinterpret_cast<xvec*>(tile + out * TW + NB * i);
+                    const int out0 = 4 * ((r & 3) + 8 * (r >> 2)) + a;          // out = out0 + 16 kh
+                    lds_xvec_p t = tb + out0 * (TW / NB);
                     xvec v;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) v[b] = acc[a][b][r];
@@ -241,16 +259,9 @@ __device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int sla
         }
         __syncthreads();
     }
-    for (int idx = threadIdx.x; idx < 128 * TW; idx += WG_TPB) {
+    for (int idx = wave * 64 + lane2; idx < 128 * TW; idx += WG_TPB) {
         const int out = idx / TW, col = jb.col0 + (idx % TW);
         if (col < jb.in_total) unsafeAtomicAdd(grad + jb.w_off + out * jb.in_total + col, tile[idx]);
-    }
-    if (jb.b_off >= 0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float v = bs[a] + __shfl_xor(bs[a], 32);
-            if (kh == 0) unsafeAtomicAdd(grad + jb.b_off + 4 * i + a, v);
-        }
     }
 }
 

@@ -29,12 +29,14 @@ BENCHMARKED = [
 ]
 # The gate covers EVERY kernel of the library (round 4; round 3 covered the benchmarked ones): no scratch memory, no spilled VGPRs -- except:
 #   ALLOW  name substring -> spilled VGPRs tolerated.  What is listed is debt, with the round that recorded it:
-#     decoder_wgrad_limb_kernel<4>: 35 in the flush epilogue of its 256 accumulators (outside the row loop), round 2
+#     decoder_wgrad_limb_kernel<4>: 1 (8 B of scratch, one store before the row loop and three loads outside it); rounds 2-3 carried 35 in the
+#       flush of its 256 accumulators -- the flush loop was unrolled four times with every accumulator copied out of its AGPR ahead of the copies,
+#       and its LDS addresses were computed as 64-bit generic pointers (round 4: one copy, LDS-typed pointer with immediate offsets)
 #   F32_OPT_IN  the exact-f32 MFMA kernels of rounds 1-2.  Since round 4 no default path reaches them (TwoDimPlanesModel.forward stand-alone
 #     runs the limb kernel too): they run only when a caller selects NVSR_ARITH_F32 explicitly, as the bit-grade reference arithmetic that
 #     the limb modes are measured against, never in a benchmarked configuration.  Listed by name so that a NEW kernel cannot hide here.
 #   Spilled VGPRs with 0 bytes of scratch are copies into free AGPRs (v_accvgpr_write): no memory traffic; tolerated up to 16.
-ALLOW = {"decoder_wgrad_limb_kernelILi4": 35}
+ALLOW = {"decoder_wgrad_limb_kernelILi4": 1}
 F32_OPT_IN = ["render_pass_kernel", "decode_rays_kernelILb", "triplane_decode_kernel", "render_pass_backward_gates_kernelILb"]
 
 
