@@ -265,7 +265,7 @@ def decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine, n_rays=16384, n
 FLIP_DEPTH_TOL = 1e-3      # a ray whose fine depths differ from the checker's by more than this (1.6 % of a coarse bin of the 2..6 range) "flipped"
 
 
-def frame_error_evidence(nvsr_amd, mc, mf, sid, rays, n_rays=16384, nc=64, nf=128, seed=0):
+def frame_error_evidence(nvsr_amd, mc, mf, sid, rays, n_rays=16384, nc=64, nf=128, seed=0, budget_s=None):
     """Where a frame's error against the float64 checker comes from, per arithmetic (the default arithmetic's frame PSNR
     sat 3.8 dB under the exact-f32 kernels' although its decoder outputs are closer to float64).  n_rays rays of the frame are rendered pass
     by pass (the kernels and depths of the frame path) in every arithmetic and by the checker (C oracle, double accumulation); per arithmetic:
@@ -287,6 +287,13 @@ def frame_error_evidence(nvsr_amd, mc, mf, sid, rays, n_rays=16384, nc=64, nf=12
     osc = chk.scene(planes, mc.box_coords[sid].numpy())
     dc = chk.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
     df = chk.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
+    if budget_s is not None and len(ids) > 2048:
+        # bounded checker time (the default bench run must stay within minutes on any host): probe 1 024 rays, keep what fits the budget
+        t0 = time.perf_counter()
+        chk.render_rays(osc, dc, df, r[:1024].cpu().numpy(), nc, nf)
+        keep = int(min(len(ids), max(2048, 1024 * budget_s / max(time.perf_counter() - t0, 1e-3)))) // 256 * 256
+        sel = np.linspace(0, len(ids) - 1, keep).astype(np.int64)            # (evenly over the sorted sample: no image region preferred)
+        ids, r = ids[sel], r[torch.from_numpy(sel).to(r.device)].contiguous()
     t0 = time.perf_counter()
     ref = chk.render_rays(osc, dc, df, r.cpu().numpy(), nc, nf, want_aux=True)
     t_ref = time.perf_counter() - t0
@@ -954,7 +961,7 @@ def main():
                 result["psnr_vs_oracle_db_by_arithmetic"] = {m2: v["psnr_vs_oracle_db"] for m2, v in result["arithmetic_modes"].items()}
                 result["decoder_error_vs_float64_by_arithmetic"] = decoder_error_by_arithmetic(nvsr_amd, mf, sid, rays, z_fine)
                 # where the frame error sits: rays whose importance samples land in other bins than the checker's, per arithmetic
-                result["frame_error_evidence"] = frame_error_evidence(nvsr_amd, mc, mf, sid, rays_row)
+                result["frame_error_evidence"] = frame_error_evidence(nvsr_amd, mc, mf, sid, rays_row, budget_s=25.0)
         if world == 1 and not args.no_modes and not args.no_other_workloads and H == 800 and args.plane_res == 800:
             # The other BASELINE configurations of the same path, measured in this same driver-timed process (short runs; each is also its
             # own `--workload`): configs[3] = the 4 096-ray Feature_Planes_Only optimisation step, configs[2]'s SR stage = EDSR 256 x 32 on
