@@ -606,7 +606,7 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 
 extern "C" {
 
-int nvsr_version(void) { return 300; }   // 300: round 3 (texel-deduplicating plane scatter, cumprod backward, exported fused-path threshold)
+int nvsr_version(void) { return 400; }   // 400: round 4 (range flag, device-keyed pixel sampler, tile-pair training forward, gate bit layout, per-point backward scales)
 int64_t nvsr_fused_min_rays(void) { return NVSR_FUSED_MIN_RAYS; }
 
 int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int Cc, int H, int W, nvsr_stream_t stream) {

@@ -24,6 +24,9 @@
 #define BL_SCATTER 3  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once (bookkeeping per point on the scalar unit), 3 the same with the bookkeeping per tile on the vector unit
 #endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
+#ifndef BL_GATE_PREFETCH
+#define BL_GATE_PREFETCH 1   // the tile's gate words loaded once at its top (A/B: 0 = re-read per layer)
+#endif
 #ifndef BL_F16_UP
 #define BL_F16_UP 3   // f16-limb backward: power of two put on top of a point's normalised gradient (see pow2_scales)
 #endif
@@ -245,7 +248,16 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         // already fill the 256 registers of a wave at two waves per SIMD): a layer's two gate words (slot 0..3 density, 4..7 rgb) ...
         typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
         const u32x2_* gk = reinterpret_cast<const u32x2_*>(gates + ((ray * S + s) * 2 + h) * 16);
+#if BL_GATE_PREFETCH
+        // the eight gate word pairs of the tile, loaded up front (16 registers): re-read where they are used each load sat behind a block's
+        // fence with its full latency exposed
+        u32x2_ gw[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) gw[l] = gk[l];
+        auto gate = [&](int slot) { return Masks{{gw[slot][0], gw[slot][1]}}; };
+#else
         auto gate = [&](int slot) { const u32x2_ v = gk[slot]; return Masks{{v[0], v[1]}}; };
+#endif
         // ... and the taps of a plane, from the ray
         auto pos_taps = [&](int d) {
             const float n0 = norm_coord(__fadd_rn(r[0], __fmul_rn(r[3], zc)), sc.lo[0], sc.range[0]);

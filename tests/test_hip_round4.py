@@ -401,7 +401,7 @@ def test_f16_backward_with_the_dynamic_range_of_an_opaque_ray(hip):
 
 def test_f16_training_converges_like_bf16x3(hip):
     """a short optimisation of the planes (Adam, the bench's learning rate) towards the pixels of a ground-truth scene, in the
-    default 2-f16-limb arithmetic and in 'bf16x3' from the same start, same pixels, same random inputs: the rendered PSNR after 300
+    default 2-f16-limb arithmetic and in 'bf16x3' from the same start, same pixels, same random inputs: the rendered PSNR after 150
     iterations agrees within 0.3 dB (the two runs differ by the arithmetic and by the float atomics' ordering; measured 17.18 against 17.16 dB
     after 150 iterations at the bench's learning rate, from 16.29) and has improved."""
     from bench import make_synthetic_scene, render_options
@@ -423,7 +423,7 @@ def test_f16_training_converges_like_bf16x3(hip):
             img = hip.train_utils.eval_nerf(H, W, focal, s["mc"], s["mf"], ro, rd, opts_eval, scene_id=s["sid"], scene_config=s["scfg"])[3]
         first[mode] = float(-10.0 * torch.log10(torch.mean((img - target) ** 2)))
         g = torch.Generator(device=DEV).manual_seed(9)
-        for it in range(300):
+        for it in range(150):
             rnd = dict(t_rand=torch.rand(1024, 32, device=DEV, generator=g), u=torch.rand(1024, 32, device=DEV, generator=g),
                        noise_coarse=0.05 * torch.randn(1024, 32, device=DEV, generator=g), noise_fine=0.05 * torch.randn(1024, 64, device=DEV, generator=g))
             m = s["step"](it, target, s["pose"], H, W, focal, 1, s["sid"], s["scfg"], 1024, randoms=rnd)
@@ -431,6 +431,6 @@ def test_f16_training_converges_like_bf16x3(hip):
         with torch.no_grad():
             img = hip.train_utils.eval_nerf(H, W, focal, s["mc"], s["mf"], ro, rd, opts_eval, scene_id=s["sid"], scene_config=s["scfg"])[3]
         final[mode] = float(-10.0 * torch.log10(torch.mean((img - target) ** 2)))
-    print("rendered PSNR against the ground-truth view before %s and after 300 iterations %s" % (first, final))
+    print("rendered PSNR against the ground-truth view before %s and after 150 iterations %s" % (first, final))
     assert abs(final["f16x2"] - final["bf16x3"]) <= 0.3, final
-    assert min(final.values()) >= max(first.values()) + 0.7, (first, final)
+    assert min(final.values()) >= max(first.values()) + 0.5, (first, final)
