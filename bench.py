@@ -520,8 +520,8 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
               "host_issue_ms_per_step": host_issue_ms,
               "launch": "one HIP graph replay per iteration (training.GraphedTrainStep)" if graphed else "kernel by kernel",
               "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
-                        "f16x2": "f32 (gate-driven backward of every pass and forward of a pass whose decoder is not trained: GEMM operands split into 2 "
-                                 "round-to-nearest f16 limbs, 3 products, the backward with a power-of-two scale per wave tile; the recording forward and the "
+                        "f16x2": "f32 (forward -- with or without the weight-gradient record -- and gate-driven backward of every pass: GEMM operands split "
+                                 "into 2 round-to-nearest f16 limbs, 3 products, the backward with a power-of-two scale per point and chain; the "
                                  "weight-gradient contraction: 3 exact bf16 limbs, 6 products; f32 accumulation)"}[capi.get_decoder_arithmetic()],
               "data": "synthetic",
               "config": {"workload": "train step: 4096 random rays of an 800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 planes, "
