@@ -834,7 +834,8 @@ extern "C" int nvsr_set_conv_arithmetic(int mode) {
 int conv_resolve_arith(int arith) { return arith == NVSR_ARITH_INHERIT ? nvsr_get_conv_arithmetic() : arith; }
 
 // max |x| of a tensor as the bits of a non-negative float (they order like unsigned integers): the scale of an f16-limb data gradient.
-// A ring of result words handed out round-robin; a word is zeroed by a memset queued in front of its reduction.  A word is reused after
+// The result word is the caller's (`owned`: the EDSR backward keeps one per gradient tensor in its workspace) or, for the stand-alone entry
+// points, one of a ring handed out round-robin; a word is zeroed by a memset queued in front of its reduction.  A ring word is reused after
 // ABSMAX_SLOTS launches of this function in the process: 16 384 -- the backward of EDSR(32 blocks) takes ~70 per plane, so a kernel still
 // reading a word would have to be ~230 plane-backwards behind the host (on any stream) when the ring comes round; nothing tracks completion.
 constexpr int ABSMAX_SLOTS = 16384;
@@ -860,11 +861,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     // (a NaN input: fmaxf drops it -- the convolution itself then propagates it through its products)
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
-const unsigned* launch_absmax(const float* x, long n, hipStream_t stream) {
+const unsigned* launch_absmax(const float* x, long n, hipStream_t stream, unsigned* owned) {
     static std::atomic<unsigned> next{0};
-    unsigned* base = nullptr;
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_absmax)) != hipSuccess) return nullptr;
-    unsigned* slot = base + (next.fetch_add(1) % ABSMAX_SLOTS);
+    unsigned* slot = owned;          // a word of the caller's workspace (the EDSR backward), or one of the ring
+    if (!slot) {
+        unsigned* base = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_absmax)) != hipSuccess) return nullptr;
+        slot = base + (next.fetch_add(1) % ABSMAX_SLOTS);
+    }
     if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
     const int blocks = (int)((n + 256 * 32 - 1) / (256 * 32) < 1024 ? (n + 256 * 32 - 1) / (256 * 32) : 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, x, n, slot);

@@ -667,7 +667,9 @@ int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblo
         if (f > part) part = f;
     }
     const int64_t t = (P.max_tensor + 3) / 4 * 4;
-    return 4 * t + part;
+    // + one word per gradient tensor for its largest magnitude (f16 limbs: absmax_kernel) -- caller-owned, so that backward passes queued on
+    // different streams never share a result word
+    return 4 * t + (part + 3) / 4 * 4 + (P.n + 7) / 4 * 4;
 }
 
 /* Backward of nvsr_edsr_forward_train.  x, acts: the forward's input and activation record; d_out [Cout][Ho][Wo];
@@ -691,6 +693,13 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
     float* buf[3] = {workspace, workspace + t, workspace + 2 * t};
     float* unsh = workspace + 3 * t;
     float* partial = workspace + 4 * t;
+    int64_t part_floats = 0;
+    for (int l = 0; l < P.n; ++l) {
+        const int64_t f = wgrad_partial_floats(P.L[l].Cin, P.L[l].Cout, P.ih[l] - 2, P.iw[l] - 2);
+        if (f > part_floats) part_floats = f;
+    }
+    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + (part_floats + 3) / 4 * 4);     // P.n + 4 words, one per gradient tensor
+    int amax_next = 0;
     // per-layer offsets into the natural gradient blob and the packed data-gradient blob
     int64_t goff[EDSR_MAX_LAYERS], poff[EDSR_MAX_LAYERS], go = 0, po = 0;
     for (int l = 0; l < P.n; ++l) {
@@ -705,7 +714,7 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
     int e;
     // f16 limbs: ONE reduction per gradient tensor serves its weight-gradient and its data-gradient launch
     const bool f16 = conv_resolve_arith(arith) == NVSR_ARITH_F16X2;
-    auto amax = [&](const float* gt, long n) -> const unsigned* { return f16 ? launch_absmax(gt, n, stream) : nullptr; };
+    auto amax = [&](const float* gt, long n) -> const unsigned* { return f16 ? launch_absmax(gt, n, stream, amax_words + amax_next++) : nullptr; };
     auto with = [&](const unsigned* am) { ConvExec c = cx; c.in_absmax = am; return c; };
     for (int l = P.n - 1; l >= 0; --l) {
         const int ci = P.L[l].Cin, co = P.L[l].Cout, ih = P.ih[l], iw = P.iw[l];

@@ -128,7 +128,7 @@ struct ConvExec { int arith = -1; int rows = 0; const unsigned* in_absmax = null
 int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
 // bits of max |x| over a tensor, in a device word that stays valid for the launches queued behind it (sr.hip): the power-of-two scale of an
 // f16-limb gradient operand; NULL on a launch error
-const unsigned* launch_absmax(const float* x, long n, hipStream_t stream);
+const unsigned* launch_absmax(const float* x, long n, hipStream_t stream, unsigned* owned = nullptr);
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{});
 
