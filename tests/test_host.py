@@ -435,3 +435,23 @@ def test_unknown_arithmetic_in_the_environment_is_refused(pkg):
     p = subprocess.run([sys.executable, "-c", code + "; print(nvsr_amd.capi.get_decoder_arithmetic())"],
                        env=dict(os.environ, NVSR_DECODER_ARITHMETIC="bf16x3"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.strip() == "bf16x3", p.stderr[-500:]
+
+
+def test_sample_key_is_the_specified_hash(pkg):
+    """nvsr_sample_key(seed, calls) = splitmix64(splitmix64(seed) ^ calls) (include/nvsr.h): the key of a DevicePixelSampler's draw, computed by the
+    library on the host for eager launches and by nvsr_sample_pixels_seq on the device for graph replays (the GPU test holds the two to the same
+    pixels).  Integer arithmetic: exact against the checker's splitmix64; different (seed, calls) pairs that collided under round 3's linear
+    combination get different keys."""
+    from oracle.oracle import _splitmix64
+    lib = pkg.capi.lib()
+    M = (1 << 64) - 1
+    for seed, calls in ((0, 0), (1, 0), (0, 1), (77, 123456), (M, M), (0x9E3779B97F4A7C15, 3)):
+        assert int(lib.nvsr_sample_key(seed, calls)) == _splitmix64(_splitmix64(seed) ^ calls)
+    s = pkg.training.DevicePixelSampler(seed=5)
+    s.calls = 9
+    assert s.key() == _splitmix64(_splitmix64(5) ^ 9)
+    # round 3's key = seed * A + calls * B collides for (seed + B', calls - A') style pairs; e.g. these two were equal under it
+    A, B = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03
+    s1, c1, s2, c2 = 0, A, B, 0                      # 0 * A + A * B == B * A + 0 * B  (mod 2^64)
+    assert (s1 * A + c1 * B) & M == (s2 * A + c2 * B) & M
+    assert int(lib.nvsr_sample_key(s1, c1 & M)) != int(lib.nvsr_sample_key(s2, c2))
