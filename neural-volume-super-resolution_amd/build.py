@@ -46,7 +46,11 @@ def _stale():
 # re-schedules the whole block at IR level -- every pure instruction (the MFMAs included) sinks below the block's loads and
 # sched_barriers, the hand-placed interleave is gone and hundreds of registers spill.
 # decode_limb.hip: same blocks, same reason (250 spilled registers with the vectorizer, none without).
-PER_FILE_FLAGS = {"render3.hip": ["-fno-slp-vectorize"], "decode_pair.hip": ["-fno-slp-vectorize"], "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
+# -pragma-unroll-threshold: the blocks of the tile-pair kernels are `#pragma unroll` loops whose side work is selected by the (constant) slot
+# index; before the selection folds away the body counts every alternative, and beyond 16 k instructions LLVM ignores the pragma -- the slot
+# index then reaches an asm immediate ("constraint 'n' expects an integer constant expression") or a register index as a run-time value.
+_PAIR_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]
+PER_FILE_FLAGS = {"render3.hip": _PAIR_FLAGS, "decode_pair.hip": _PAIR_FLAGS, "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(CSRC, "_obj")      # (of the product build; experiment variants use <out_path>.obj)
 
 

@@ -30,7 +30,8 @@ namespace nvsr {
 struct LdsP {                                                       // Lds3<2> without the ray cache
     static constexpr int SLOT = Lds3<2>::SLOT;                      // 32 KB ring slot (4 K-blocks)
     static constexpr int SMALL = 2 * SLOT;
-    static constexpr int RES = SMALL + SMALL_FLOATS;
+    static constexpr int BOUNCE = SMALL + SMALL_FLOATS;              // 1 KB per wave: the accumulators' way to the VALU (relu_bias_step)
+    static constexpr int RES = BOUNCE + (R3_BOUNCE ? NW2 * 256 : 0);
     static constexpr int RES_KB = 9;                                // view plane, planes 0 and 1 of rgb layer 0 stay resident
     static constexpr int TOTAL = RES + RES_KB * kb_words(2);
 };
@@ -97,7 +98,7 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
     ring3_load_resident<LIMBS, L::RES_KB>(rs, res, KB_RGB0);
     unsigned* cw = const_cast<unsigned*>(ring3_issue<LIMBS, 3>(rs, KB_FIRST));     // first ring chunk of the first step; every later one is issued during the previous step
 
-    auto scale_taps = [](Taps& t) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; };
+    auto scale_taps = [](Taps& t) NVSR_INL { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; };
 
     for (long step = blockIdx.x; step < nsteps; step += gridDim.x) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
@@ -142,36 +143,37 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         u32x2* const glX = MASKS ? reinterpret_cast<u32x2*>(gates + ((ray * S + sX) * 2 + h) * 16) : nullptr;
         u32x2* const glY = MASKS ? reinterpret_cast<u32x2*>(gates + ((ray * S + sY) * 2 + h) * 16) : nullptr;
         BiasPend4 bp;
+        bp.slot = bounce_slot(reinterpret_cast<float*>(lds) + LdsP::BOUNCE + rs.wave * 256 + lane * 4);
         HeadPend<3> hp3;
         HeadPend<1> hp1;
         SplitPend tp;
 
         // side-work pieces
-        auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
-        auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
-        auto split_feat = [&](const float (&f)[HALF_C]) { split_all<LIMBS>([&f](int i) { return f[i]; }, cur); };
+        auto feat = [](const float (&f)[HALF_C]) NVSR_INL { return [&f](int kb, int i) NVSR_INL { return f[8 * kb + i]; }; };
+        auto hid = [](const f32x16 (&a)[4], int kb0) NVSR_INL { return [&a, kb0](int kb, int i) NVSR_INL { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
+        auto split_feat = [&](const float (&f)[HALF_C]) NVSR_INL { split_all<LIMBS>([&f](int i) NVSR_INL { return f[i]; }, cur); };
         // gates of the pairs of hidden K-block k (0..7) of a tile: pair j -> bits (4 (k & 3) + j, + 16) of word k >> 2
-        auto gate_of = [ones](TileP& t, int kb0) {
-            return [&t, kb0, ones](int kb, int j, unsigned hi) {
+        auto gate_of = [ones](TileP& t, int kb0) NVSR_INL {
+            return [&t, kb0, ones](int kb, int j, unsigned hi) NVSR_INL {
                 if constexpr (MASKS && !(DP_ABLATE & 1)) { const int k = kb0 + kb; gate_pair(hi, 4 * (k & 3) + j, k < 4 ? t.g0 : t.g1, ones); }
             };
         };
         // tail: split K-block kb of t.act into the limbs the next block starts with (+ its gates)
-        auto tail_of = [&](TileP& t, int kb) {
-            return [&t, kb, &tp, ones](int slice, Limbs<LIMBS>& nxt) {
-                split_slice<LIMBS>(slice, [&t, kb](int i) { return t.act[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp);
+        auto tail_of = [&](TileP& t, int kb) NVSR_INL {
+            return [&t, kb, &tp, ones](int slice, Limbs<LIMBS>& nxt) NVSR_INL {
+                split_slice<LIMBS>(slice, [&t, kb](int i) NVSR_INL { return t.act[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp);
                 if constexpr (MASKS && !(DP_ABLATE & 1)) { if (slice % NP == 0 && slice / NP < 4) gate_pair(nxt.v[0][slice / NP], 4 * (kb & 3) + slice / NP, kb < 4 ? t.g0 : t.g1, ones); }
             };
         };
-        auto none = [](int) {};
+        auto none = [](int) NVSR_INL {};
 
         // ---- rgb layer 0: (view plane, planes 0..2) x (X block, Y block); the gathers roll through the blocks (gather_roll) -------------
         GatherJob ja, jb;
         ring3_sync<0>();                                         // the step's first ring chunk (issued during the previous step); the resident region
         unsigned* nw = nullptr;
-#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS, false>(slot, JL, TL.F, JB, TB.F, h, rt); }
+#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) NVSR_INL { gather_roll<NSF, LOADS, BLENDS, false>(slot, JL, TL.F, JB, TB.F, h, rt); }
 #define NVSR_ROLL_DMA(TL, JL, TB, JB, LOADS, BLENDS, NKB, KB0) \
-        [&](int slot) { gather_roll<NSF, LOADS, BLENDS, false>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
+        [&](int slot) NVSR_INL { gather_roll<NSF, LOADS, BLENDS, false>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
         // X view | loads X plane 0
         ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(V);
@@ -218,19 +220,19 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         split_feat(Y.F);
         X.g0 = X.g1 = 0u;
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F),
-                                           [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp, nsc2); }); },
+                                           [&](int slot) NVSR_INL { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp, nsc2); }); },
                                            tail_of(X, 0));
         cw = nw;
 
         // ---- hidden layers.  Layer l of a decoder = chunks a (K-blocks 0..3), b (4..7):
         //   X a | Y: act of layer l-1; tail Y kb 0        Y a | tail X kb 4        X b | tail Y kb 4        Y b | X: act of layer l; tail X kb 0
         // the gate words of layer l-1 are complete (and stored) when the tile's K-blocks 5..7 have been split: X after X b, Y after Y b
-        auto relu_side = [&](TileP& t, int bias_vec) {
-            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc2); }); };
+        auto relu_side = [&](TileP& t, int bias_vec) NVSR_INL {
+            return [&, bias_vec](int slot) NVSR_INL { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc2); }); };
         };
         // last hidden layer of a decoder (feeds the heads, is not split): bias + ReLU with its gates
-        auto relu_gate_side = [&](TileP& t, int bias_vec) {
-            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc2, t.g0, t.g1, ones); }); };
+        auto relu_gate_side = [&](TileP& t, int bias_vec) NVSR_INL {
+            return [&, bias_vec](int slot) NVSR_INL { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) NVSR_INL { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc2, t.g0, t.g1, ones); }); };
         };
 #define NVSR_STORE_GATES(T, GL, VEC) if constexpr (MASKS) { GL[VEC] = u32x2{T.g0, T.g1}; }
         // VPREV: the layer whose activations this layer consumes (its bias vector finishes Y in block X a; its gates are collected here)
@@ -239,13 +241,13 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         nw = ring3_take(rs);                                                                                                        \
         Y.g0 = Y.g1 = 0u;                                                                                                           \
         limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0),                                                   \
-                                         [&](int slot) { relu_side(Y, VPREV)(slot); dma_side<LIMBS, NKB_A>(slot, rs, nw, KB_NEXT_A); }, tail_of(Y, 0), gate_of(X, 0)); \
+                                         [&](int slot) NVSR_INL { relu_side(Y, VPREV)(slot); dma_side<LIMBS, NKB_A>(slot, rs, nw, KB_NEXT_A); }, tail_of(Y, 0), gate_of(X, 0)); \
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X, 4), gate_of(Y, 0));             \
         cw = nw;                                                                                                                    \
         ring3_sync<0>();                                                                                                            \
         nw = ring3_take(rs);                                                                                                        \
         limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4),                                                  \
-                                          [&](int slot) { dma_side<LIMBS, NKB_B>(slot, rs, nw, KB_NEXT_B); }, tail_of(Y, 4), gate_of(X, 4)); \
+                                          [&](int slot) NVSR_INL { dma_side<LIMBS, NKB_B>(slot, rs, nw, KB_NEXT_B); }, tail_of(Y, 4), gate_of(X, 4)); \
         NVSR_STORE_GATES(X, glX, VPREV)                                                                                             \
         Y_B_BLOCK;                                                                                                                  \
         NVSR_STORE_GATES(Y, glY, VPREV)                                                                                             \
@@ -269,9 +271,9 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         split_feat(X.D);
         Y.g0 = Y.g1 = 0u;
         limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.D),
-                                         [&](int slot) {
-                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp, nsc2, Y.g0, Y.g1, ones); });
-                                             spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
+                                         [&](int slot) NVSR_INL {
+                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp, nsc2, Y.g0, Y.g1, ones); });
+                                             spread<64, 0, NSF>(slot, [&](int k) NVSR_INL { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
                                              dma_side<LIMBS, 4>(slot, rs, nw, KB_DEN1);
                                          },
                                          NoTail{});
@@ -283,9 +285,9 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         split_feat(Y.D);
         X.g0 = X.g1 = 0u;
         limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.D),
-                                          [&](int slot) {
-                                              spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
-                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp, nsc2); });
+                                          [&](int slot) NVSR_INL {
+                                              spread<64, 0, NSF>(slot, [&](int k) NVSR_INL { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
+                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp, nsc2); });
                                           },
                                           tail_of(X, 0));
 #pragma unroll
@@ -301,9 +303,9 @@ __device__ __forceinline__ void decode_pair_body(const SceneDev& sc, const float
         NVSR_HIDDEN_LAYER(2, KB_DEN1 + 20, 4, KB_FIRST, 3,
                           X.g0 = X.g1 = 0u;
                           (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4),
-                                                              [&](int slot) {
-                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc2, X.g0, X.g1, ones); });
-                                                                  spread<64, NSH / 2, NSH>(slot, [&](int k) { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
+                                                              [&](int slot) NVSR_INL {
+                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) NVSR_INL { relu_gate_step<MASKS && !(DP_ABLATE & 1)>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc2, X.g0, X.g1, ones); });
+                                                                  spread<64, NSH / 2, NSH>(slot, [&](int k) NVSR_INL { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
                                                               },
                                                               NoTail{}, gate_of(Y, 4))))
         NVSR_STORE_GATES(X, glX, 3)

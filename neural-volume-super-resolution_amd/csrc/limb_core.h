@@ -29,6 +29,9 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 // (always_inline: inside a very large kernel the inliner otherwise leaves these as CALLS, and an operand index that is not a compile-time
 //  constant turns every fragment selection into a chain of v_cndmask over a merged register array)
 #define NVSR_CX __host__ __device__ __attribute__((always_inline)) constexpr
+// side-work lambdas take their step index as an argument and use it as a register index or an instruction immediate: they must be inlined
+// whatever their size (left to its cost model, the inliner keeps the larger ones as calls and the index stops being a constant)
+#define NVSR_INL __attribute__((always_inline))
 NVSR_CX int limb_products(int limbs) { return limbs == 3 ? 6 : 3; }
 // product p of a (weight limb, activation limb) set, small terms first
 NVSR_CX int limb_w(int limbs, int p) { return limbs == 3 ? (p < 3 ? 0 : p < 5 ? 1 : 2) : (p < 2 ? 0 : 1); }
@@ -100,6 +103,9 @@ __device__ __forceinline__ void split_slice(int slice, Get get, Limbs<LIMBS>& ou
     constexpr int NP = limb_products(LIMBS);
     const int j = slice / NP, st = slice % NP;
     if (j >= 4) return;
+#if defined(R3_ABLATE) && (R3_ABLATE & 4096)      // timing experiment: no limb split (the limbs of the previous K-block are reused)
+    return;
+#endif
     if (LIMBS == 3) {
         if (st == 0) { out.v[0][j] = trunc_pair(get(2 * j + 1), get(2 * j)); p.r0 = limb_rest(get(2 * j)); }
         if (st == 1) { p.r1 = limb_rest(get(2 * j + 1)); }
@@ -184,6 +190,9 @@ __device__ __forceinline__ void limb_block(const unsigned* wl, int lane, f32x16 
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         Limbs<LIMBS> nxt;
+#if defined(R3_ABLATE) && (R3_ABLATE & 4096)
+        nxt = cur;
+#endif
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             Limbs<LIMBS> fn;

@@ -8,7 +8,7 @@
 #define R3_DMA_AUX 0      // cache-policy bits of the weight copies (experiment: 2 = nt, 1 = sc0, 16 = sc1)
 #endif
 #ifndef R3_ABLATE
-#define R3_ABLATE 0   // timing experiments (wrong results): 1 no gather loads, 2 / 4 see gather_roll, 32 no weight copies, 64 no ring barriers, 128 no A-fragment reads
+#define R3_ABLATE 0   // timing experiments (wrong results): 1 no gather loads, 2 / 4 see gather_roll, 32 no weight copies, 64 no ring barriers, 128 no A-fragment reads, 1024 ReLU reads VGPRs (no v_accvgpr_read), 2048 no bias + ReLU, 4096 no limb split
 #endif
 #include "limb_core.h"
 #include "side_work.h"
@@ -67,9 +67,13 @@ struct Lds3 {
     static constexpr int SLOT = 4 * kb_words(LIMBS);                 // words: 48 KB (3 limbs) / 32 KB
     static constexpr int SMALL = 2 * SLOT;
     static constexpr int RAYS = SMALL + SMALL_FLOATS;
-    static constexpr int RAY_FLOATS = LIMBS == 2 ? 16 : 20;
-    static constexpr int FAR = LIMBS == 2 ? RAYS + RAYS2 * RAY_FLOATS : -1;
-    static constexpr int RES = RAYS + RAYS2 * RAY_FLOATS + (LIMBS == 2 ? RAYS2 : 0);
+    // ray cache: RAY_FLOATS per ray (origin, direction, norm, near) + TAP_FLOATS (the view plane's four tap offsets and weights).  f16 limbs: the
+    // taps live in a region of their own, 2 KB per wave, that is dead after the prologue -- the wave's accumulator bounce slot (relu_bias_step)
+    static constexpr int RAY_FLOATS = LIMBS == 2 ? 8 : 20;
+    static constexpr int TAP_FLOATS = LIMBS == 2 ? 8 : 0;
+    static constexpr int VTAPS = RAYS + RAYS2 * RAY_FLOATS;
+    static constexpr int FAR = LIMBS == 2 ? VTAPS + RAYS2 * TAP_FLOATS : -1;
+    static constexpr int RES = VTAPS + RAYS2 * TAP_FLOATS + (LIMBS == 2 ? RAYS2 : 0);
     static constexpr int RES_KB = LIMBS == 2 ? 9 : 0;
     static constexpr int TOTAL = RES + RES_KB * kb_words(LIMBS);
 };
@@ -177,7 +181,15 @@ __device__ __forceinline__ void ring3_sync() {
 
 // act = max(acc + bias, 0): 64 elements in 68 steps (a bias quad is read 4 steps before its first use)
 constexpr int RELU_STEPS = 68;
-struct BiasPend4 { f32x4 v[2]; };
+#ifndef R3_BOUNCE
+#define R3_BOUNCE 0       // f16-limb ReLU: 1 = accumulators reach the VALU through LDS (ds_write_b128 straight from AGPRs, ds_read_b128 back) instead of
+#endif                    // one v_accvgpr_read per element: 2 LDS instructions per 4 elements replace 4 VALU instructions (7 548 -> 7 293 VALU
+                          // in the fine-pass kernel).  Same-box A/B: SLOWER, fine pass 79.6 -> 83.6 ms, training forward S=128 0.433 -> 0.452 ms:
+                          // 512 more 1-KB LDS transfers per wave and step queue behind the fragment reads, and the 176 extra waits cost an
+                          // issue slot each
+typedef __attribute__((address_space(3))) f32x4* lds_f32x4_p;
+struct BiasPend4 { f32x4 v[2]; f32x4 a[2]; lds_f32x4_p slot; };
+__device__ __forceinline__ lds_f32x4_p bounce_slot(float* p) { return (lds_f32x4_p)p; }
 // LIMBS = 2 (f16 limbs): act = relu(acc 2^-SW + bias 2^SX) must let a NaN through -- an operand beyond the f16 range turns a layer's
 // accumulators into NaNs (the matrix pipe always returns the default NaN 0xFFC00000, whatever the sign of a NaN it was fed), and v_max_f32
 // would return its non-NaN operand: the overflow would render as a finite, wrong pixel.  So the ReLU is an INTEGER max on the bits (equal to
@@ -187,10 +199,38 @@ struct BiasPend4 { f32x4 v[2]; };
 template <int LIMBS>
 __device__ __forceinline__ void relu_bias_step(int k, const float* bias, int h, const f32x16 (&acc)[4], f32x16 (&act)[4], BiasPend4& pend, f32x2_t nsc) {
     if ((k & 3) == 0 && k < 64) pend.v[(k >> 2) & 1] = *reinterpret_cast<const f32x4*>(bias + (k >> 2) * 8 + h * 4);
+#if R3_BOUNCE
+    if constexpr (LIMBS == 2) {
+        // quad j = k / 4 leaves the accumulators at step 4 j, comes back at 4 j + 2 and is used at 4 j + 4 .. 4 j + 7 (one wave's LDS operations
+        // execute in order: the slot is free again when the next quad is written)
+        if ((k & 3) == 0 && k < 64) {
+            const int q = k >> 2;
+            *pend.slot = f32x4{acc[q >> 2][4 * (q & 3)], acc[q >> 2][4 * (q & 3) + 1], acc[q >> 2][4 * (q & 3) + 2], acc[q >> 2][4 * (q & 3) + 3]};
+        }
+        if ((k & 3) == 2 && k < 66) {
+            asm volatile("" : "+v"(pend.slot));        // (opaque: no store-to-load forwarding, which would be the v_accvgpr_read again)
+            pend.a[(k >> 2) & 1] = *pend.slot;
+        }
+        if (k >= 4) {
+            const int r = k - 4;
+            float v;
+            asm("v_fma_f32 %0, -%1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=v"(v) : "v"(pend.a[(r >> 2) & 1][r & 3]), "s"(nsc[0]), "v"(pend.v[(r >> 2) & 1][r & 3]));
+            act[r >> 4][r & 15] = v;
+        }
+        return;
+    }
+#endif
+#if R3_ABLATE & 2048      // (one element of every accumulator block keeps the MFMAs alive)
+    if (k >= 4 && ((k - 4) & 15) != 0) return;
+#endif
     if (k >= 4) {
         const int r = k - 4;
         if constexpr (LIMBS == 2) {
-#if R3_RELU_PK
+#if R3_ABLATE & 1024
+            float v;
+            asm("v_fma_f32 %0, -%1, %2, %3\n\tv_max_i32 %0, 0, %0" : "=v"(v) : "v"((r & 15) == 0 ? acc[r >> 4][0] : act[r >> 4][r & 15]), "s"(nsc[0]), "v"(pend.v[(r >> 2) & 1][r & 3]));
+            act[r >> 4][r & 15] = v;
+#elif R3_RELU_PK
             if (r & 1) {
                 const int q = r - 1;
                 const f32x2_t a = f32x2_t{acc[q >> 4][q & 15], acc[r >> 4][r & 15]}, b = f32x2_t{pend.v[(q >> 2) & 1][q & 3], pend.v[(r >> 2) & 1][r & 3]};

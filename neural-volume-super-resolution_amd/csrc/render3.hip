@@ -59,10 +59,13 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     constexpr int RAY3_FLOATS = L::RAY_FLOATS;
     float* rcX = ldsf + L::RAYS + (rs.wave * 64 + (lane0 & 31)) * RAY3_FLOATS;
     float* rcY = rcX + 32 * RAY3_FLOATS;
+    float* rtX = LIMBS == 2 ? ldsf + L::VTAPS + (rs.wave * 64 + (lane0 & 31)) * L::TAP_FLOATS : rcX + 8;     // view-plane taps of the ray
+    float* rtY = rtX + 32 * (LIMBS == 2 ? L::TAP_FLOATS : RAY3_FLOATS);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float* r = rays + (k ? rayY : rayX) * 11;
         float* rc = k ? rcY : rcX;
+        float* rtp = k ? rtY : rtX;
         const float dx = r[3], dy = r[4], dz = r[5];
         const Taps vt = view_taps(sc, r[8], r[9], r[10]);
         const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
@@ -71,13 +74,13 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
             reinterpret_cast<f32x4*>(rc)[1] = f32x4{dy, dz, nrm, r[6]};
             if constexpr (L::FAR >= 0) ldsf[L::FAR + rs.wave * 64 + (lane0 & 31) + 32 * k] = r[7];
             else rc[16] = r[7];
-            reinterpret_cast<f32x4*>(rc)[2] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
-            reinterpret_cast<f32x4*>(rc)[3] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
+            reinterpret_cast<f32x4*>(rtp)[0] = f32x4{__int_as_float(vt.o00), __int_as_float(vt.o01), __int_as_float(vt.o10), __int_as_float(vt.o11)};
+            reinterpret_cast<f32x4*>(rtp)[1] = f32x4{vt.nw, vt.ne, vt.sw, vt.se};
         }
     }
     const float* zX = ZCOMP ? nullptr : z + rayX * S;
     const float* zY = ZCOMP ? nullptr : z + rayY * S;
-    auto depth_of = [&](const float* zp, const float* rc, int k) {
+    auto depth_of = [&](const float* zp, const float* rc, int k) NVSR_INL {
         if constexpr (ZCOMP) return coarse_depth(rc[7], L::FAR >= 0 ? ldsf[L::FAR + rs.wave * 64 + (rs.lane & 31) + (rc == rcX ? 0 : 32)] : rc[16], k, S, lindisp);
         else return zp[k];
     };
@@ -90,18 +93,18 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
     X.zc = depth_of(zX, rcX, 0); Y.zc = depth_of(zY, rcY, 0);
     RawTaps4 rt;
 
-    auto point_norm = [&](const float* rc, float zc, float& n0, float& n1, float& n2) {
+    auto point_norm = [&](const float* rc, float zc, float& n0, float& n1, float& n2) NVSR_INL {
         const f32x4 c0 = reinterpret_cast<const f32x4*>(rc)[0], c1 = reinterpret_cast<const f32x4*>(rc)[1];
         n0 = norm_coord(__fadd_rn(c0[0], __fmul_rn(c0[3], zc)), sc.lo[0], sc.range[0]);
         n1 = norm_coord(__fadd_rn(c0[1], __fmul_rn(c1[0], zc)), sc.lo[1], sc.range[1]);
         n2 = norm_coord(__fadd_rn(c0[2], __fmul_rn(c1[1], zc)), sc.lo[2], sc.range[2]);
     };
     // f16 limbs: features carry the activation scale 2^F16_SX, put on the four blend weights (exact; D = (F0 + F1 + F2) / 3 inherits it)
-    auto scale_taps = [](Taps& t) {
+    auto scale_taps = [](Taps& t) NVSR_INL {
         if constexpr (LIMBS == 2) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; }
     };
-    auto view_job = [&](const float* rc) {
-        const f32x4 c2 = reinterpret_cast<const f32x4*>(rc)[2], c3 = reinterpret_cast<const f32x4*>(rc)[3];
+    auto view_job = [&](const float* rtp) NVSR_INL {
+        const f32x4 c2 = reinterpret_cast<const f32x4*>(rtp)[0], c3 = reinterpret_cast<const f32x4*>(rtp)[1];
         GatherJob j;
         j.plane = sc.plane[3];
         j.t.o00 = __float_as_int(c2[0]); j.t.o01 = __float_as_int(c2[1]); j.t.o10 = __float_as_int(c2[2]); j.t.o11 = __float_as_int(c2[3]);
@@ -117,7 +120,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         Tile3& t = k2 ? Y : X;
-        const GatherJob vj = view_job(k2 ? rcY : rcX);
+        const GatherJob vj = view_job(k2 ? rtY : rtX);
 #pragma unroll
         for (int k = 0; k < 12; ++k) gather4_load(k, vj, lane0 >> 5, rt);
 #pragma unroll
@@ -154,19 +157,20 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         point_norm(rcX, X.zc, xn0, xn1, xn2);
         point_norm(rcY, Y.zc, yn0, yn1, yn2);
         BiasPend4 bp;
+        bp.slot = bounce_slot(ldsf + L::VTAPS + rs.wave * 64 * L::TAP_FLOATS + lane * 4);     // (f16 limbs: the wave's tap region, dead since the prologue)
         HeadPend<3> hp3;
         HeadPend<1> hp1;
         SplitPend tp;
 
         // side-work pieces
-        auto feat = [](const float (&f)[HALF_C]) { return [&f](int kb, int i) { return f[8 * kb + i]; }; };
-        auto hid = [](const f32x16 (&a)[4], int kb0) { return [&a, kb0](int kb, int i) { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
-        auto split_feat = [&](const float (&f)[HALF_C]) { split_all<LIMBS>([&f](int i) { return f[i]; }, cur); };
+        auto feat = [](const float (&f)[HALF_C]) NVSR_INL { return [&f](int kb, int i) NVSR_INL { return f[8 * kb + i]; }; };
+        auto hid = [](const f32x16 (&a)[4], int kb0) NVSR_INL { return [&a, kb0](int kb, int i) NVSR_INL { const int k = kb0 + kb; return a[k >> 1][8 * (k & 1) + i]; }; };
+        auto split_feat = [&](const float (&f)[HALF_C]) NVSR_INL { split_all<LIMBS>([&f](int i) NVSR_INL { return f[i]; }, cur); };
         // tail: split K-block kb of t.act into the limbs the next block starts with
-        auto tail_of = [&](const f32x16 (&a)[4], int kb) {
-            return [&a, kb, &tp](int slice, Limbs<LIMBS>& nxt) { split_slice<LIMBS>(slice, [&a, kb](int i) { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
+        auto tail_of = [&](const f32x16 (&a)[4], int kb) NVSR_INL {
+            return [&a, kb, &tp](int slice, Limbs<LIMBS>& nxt) NVSR_INL { split_slice<LIMBS>(slice, [&a, kb](int i) NVSR_INL { return a[kb >> 1][8 * (kb & 1) + i]; }, nxt, tp); };
         };
-        auto none = [](int) {};
+        auto none = [](int) NVSR_INL {};
 
         // ---- rgb layer 0: (view plane, planes 0..2) x (X block, Y block).  The gathers roll through the blocks (gather_roll): the block that
         // multiplies plane p - 1 of a tile loads plane p of the same tile, the next block blends it.
@@ -179,9 +183,9 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         const unsigned* const w_view = RESIDENT ? res : cw;
         R3_MARK(1)      // first ring wait
         R3_RESET
-#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); }
+#define NVSR_ROLL(TL, JL, TB, JB, LOADS, BLENDS) [&](int slot) NVSR_INL { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); }
 #define NVSR_ROLL_DMA(TL, JL, TB, JB, LOADS, BLENDS, NKB, KB0) \
-        [&](int slot) { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
+        [&](int slot) NVSR_INL { gather_roll<NSF, LOADS, BLENDS, LIMBS == 2 && R3_BLEND_PK>(slot, JL, TL.F, JB, TB.F, h, rt); dma_side<LIMBS, NKB>(slot, rs, nw, KB0); }
         // X view | loads X plane 0
         ja.plane = sc.plane[0]; ja.t = pos_taps2(sc, 0, xn0, xn1, xn2); scale_taps(ja.t);
         split_feat(X.V);
@@ -253,7 +257,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         for (int c = 0; c < HALF_C; ++c) Y.D[c] = div3(__fadd_rn(Y.D[c], Y.F[c]));
         split_feat(Y.F);
         limb_block<LIMBS, 3, false, false>(cw, lane, Y.acc, cur, fa, feat(Y.F),
-                                           [&](int slot) { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp, nsc); }); },
+                                           [&](int slot) NVSR_INL { spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 4 * HID, h, X.acc, X.act, bp, nsc); }); },
                                            tail_of(X.act, 0));
         R3_MARKB(7)
         cw = nw;
@@ -261,8 +265,8 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
 
         // ---- hidden layers.  Layer l of a decoder = chunks a (K-blocks 0..3), b (4..7):
         //   X a | Y: act of layer l-1; tail Y kb 0        Y a | tail X kb 4        X b | tail Y kb 4        Y b | X: act of layer l; tail X kb 0
-        auto relu_side = [&](Tile3& t, int bias_vec) {
-            return [&, bias_vec](int slot) { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc); }); };
+        auto relu_side = [&](Tile3& t, int bias_vec) NVSR_INL {
+            return [&, bias_vec](int slot) NVSR_INL { spread<RELU_STEPS, 0, NSH>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + bias_vec * HID, h, t.acc, t.act, bp, nsc); }); };
         };
         // hidden layer with bias vectors: vprev (layer l-1, finishing Y) and vthis (layer l, finishing X); kbn = next chunk to issue (two per layer)
 #define NVSR_HIDDEN_LAYER_(SYNC, XA_SIDE, VPREV, VTHIS, KB_NEXT_A, NKB_A, KB_NEXT_B, NKB_B, X_B_SIDE)                                \
@@ -272,7 +276,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         nw = ring3_take(rs);                                                                                                        \
         R3_MARKH(1)                                                                                                                 \
         limb_block<LIMBS, 4, true, true>(cw, lane, X.acc, cur, fa, hid(X.act, 0),                                                   \
-                                         [&](int slot) { (XA_SIDE)(slot); dma_side<LIMBS, NKB_A>(slot, rs, nw, KB_NEXT_A); }, tail_of(Y.act, 0)); \
+                                         [&](int slot) NVSR_INL { (XA_SIDE)(slot); dma_side<LIMBS, NKB_A>(slot, rs, nw, KB_NEXT_A); }, tail_of(Y.act, 0)); \
         R3_MARKH(2)                                                                                                                 \
         limb_block<LIMBS, 4, true, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 0), none, tail_of(X.act, 4));                        \
         R3_MARKH(3)                                                                                                                 \
@@ -281,7 +285,7 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         nw = ring3_take(rs);                                                                                                        \
         R3_MARKH(4)                                                                                                                 \
         limb_block<LIMBS, 4, false, true>(cw, lane, X.acc, cur, fa, hid(X.act, 4),                                                  \
-                                          [&](int slot) { dma_side<LIMBS, NKB_B>(slot, rs, nw, KB_NEXT_B); }, tail_of(Y.act, 4));   \
+                                          [&](int slot) NVSR_INL { dma_side<LIMBS, NKB_B>(slot, rs, nw, KB_NEXT_B); }, tail_of(Y.act, 4));   \
         R3_MARKH(5)                                                                                                                 \
         X_B_SIDE;                                                                                                                   \
         R3_MARKH(6)                                                                                                                 \
@@ -304,9 +308,9 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         float hx[3] = {0.0f, 0.0f, 0.0f};
         split_feat(X.D);
         limb_block<LIMBS, 3, true, true>(cw, lane, X.acc, cur, fa, feat(X.D),
-                                         [&](int slot) {
-                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp, nsc); });
-                                             spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
+                                         [&](int slot) NVSR_INL {
+                                             spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 7 * HID, h, Y.acc, Y.act, bp, nsc); });
+                                             spread<64, 0, NSF>(slot, [&](int k) NVSR_INL { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, X.act, hx, hp3); });
                                              dma_side<LIMBS, 4>(slot, rs, nw, KB_DEN1);
                                          },
                                          NoTail{});
@@ -316,9 +320,9 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         float hy[3] = {0.0f, 0.0f, 0.0f};
         split_feat(Y.D);
         limb_block<LIMBS, 3, true, false>(cw, lane, Y.acc, cur, fa, feat(Y.D),
-                                          [&](int slot) {
-                                              spread<64, 0, NSF>(slot, [&](int k) { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
-                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp, nsc); });
+                                          [&](int slot) NVSR_INL {
+                                              spread<64, 0, NSF>(slot, [&](int k) NVSR_INL { heads_side<3>(k >> 2, k & 3, small + S_RGB_W, h, Y.act, hy, hp3); });
+                                              spread<RELU_STEPS, 0, NSF>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 0 * HID, h, X.acc, X.act, bp, nsc); });
                                           },
                                           tail_of(X.act, 0));
 #pragma unroll
@@ -334,9 +338,9 @@ __device__ __forceinline__ void render_pass3_body(const SceneDev& sc, const floa
         float sx[1] = {0.0f};
         NVSR_HIDDEN_LAYER(2, 3, KB_DEN1 + 20, 4, KB_FIRST, 3,
                           (limb_block<LIMBS, 4, false, false>(cw, lane, Y.acc, cur, fa, hid(Y.act, 4),
-                                                              [&](int slot) {
-                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) { relu_bias_step<LIMBS>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc); });
-                                                                  spread<64, NSH / 2, NSH>(slot, [&](int k) { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
+                                                              [&](int slot) NVSR_INL {
+                                                                  spread<RELU_STEPS, 0, NSH / 2>(slot, [&](int k) NVSR_INL { relu_bias_step<LIMBS>(k, small + S_BIAS + 3 * HID, h, X.acc, X.act, bp, nsc); });
+                                                                  spread<64, NSH / 2, NSH>(slot, [&](int k) NVSR_INL { heads_side<1>(k >> 2, k & 3, small + S_ALPHA_W, h, X.act, sx, hp1); });
                                                               },
                                                               NoTail{})))
 #undef NVSR_HIDDEN_LAYER
@@ -487,8 +491,8 @@ __global__ void limb_gemm_probe_kernel(int K, const float* __restrict__ W, const
             float wa[8], xb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { wa[i] = W[m * K + 16 * kb + 8 * h + i] * sw; xb[i] = X[(16 * kb + 8 * h + i) * 32 + m] * sx; }
-            split_all<LIMBS>([&](int i) { return wa[i]; }, a);
-            split_all<LIMBS>([&](int i) { return xb[i]; }, b);
+            split_all<LIMBS>([&](int i) NVSR_INL { return wa[i]; }, a);
+            split_all<LIMBS>([&](int i) NVSR_INL { return xb[i]; }, b);
 #pragma unroll
             for (int p = 0; p < limb_products(LIMBS); ++p) acc = mfma_limb<LIMBS>(a.v[limb_w(LIMBS, p)], b.v[limb_x(LIMBS, p)], acc);
         }

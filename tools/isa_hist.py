@@ -17,8 +17,9 @@ with tempfile.TemporaryDirectory(prefix="nvsr_isa_") as tmp:
     copy = os.path.join(tmp, "in.o")
     shutil.copyfile(obj, copy)
     subprocess.run([LLVM + "/llvm-objdump", "--offloading", copy], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
-    co = [f for f in os.listdir(tmp) if "gfx950" in f][0]
-    text = subprocess.run([LLVM + "/llvm-objdump", "-d", os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+    # (a library holds one code object per translation unit)
+    text = "".join(subprocess.run([LLVM + "/llvm-objdump", "-d", os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+                   for co in sorted(os.listdir(tmp)) if "gfx950" in co)
 cur, bodies = None, {}
 for line in text.splitlines():
     m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
