@@ -437,6 +437,36 @@ int64_t nvsr_generic_decode_backward_workspace_floats(const nvsr_decoder_geometr
 int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P, const float* x,
                                  const float* d_out, float* d_natural, float* d_plane0, float* d_plane1, float* d_plane2, float* d_plane3,
                                  float* workspace, nvsr_stream_t stream);
+/* ---- generic decoder, extended scene (round 4) ------------------------------------------------------------------------------------
+ * The options of TwoDimPlanesModel that nvsr_scene cannot express, for the generic kernels only (the MFMA kernels of the shipped
+ * geometry keep nvsr_scene):
+ *   - any number of position planes with their projections (num_planes_or_rot_mats > 3: models.py:140,471-490 -- CoordProjector draws
+ *     random orthonormal frames; grid_d = n_xyz @ rot_mats[d][:, 1:]); combine_pos_planes sums / averages / concatenates all of them;
+ *   - grid_sample(align_corners=False) (models.py:303-309,320-326);
+ *   - point_coords_noise (models.py:291-293): `coord_noise` [P,3] (device; NULL = none) is ADDED TO THE NORMALISED sample position
+ *     before the projections -- the caller draws it (the reference: torch.normal(0, point_coords_noise * 2 / (1 + plane resolution)) on
+ *     the CPU generator, once per model call, training only).
+ * planes[0 .. num_position_planes-1] are the position planes, planes[num_position_planes] is the view-direction plane. */
+#define NVSR_MAX_POSITION_PLANES 15
+typedef struct nvsr_scene_ext {
+    int32_t num_position_planes;                          /* 1 .. NVSR_MAX_POSITION_PLANES */
+    int32_t align_corners;                                /* grid_sample's align_corners: 1 = True (every shipped config), 0 = False */
+    const float* planes[NVSR_MAX_POSITION_PLANES + 1];    /* device, channel-last */
+    int32_t ph[NVSR_MAX_POSITION_PLANES + 1], pw[NVSR_MAX_POSITION_PLANES + 1];
+    float lo[5], range[5];                                /* as in nvsr_scene */
+    float proj[NVSR_MAX_POSITION_PLANES][6];              /* row-major 3x2 per position plane */
+} nvsr_scene_ext;
+int64_t nvsr_generic_decoder_natural_floats_ext(const nvsr_decoder_geometry* geometry, int num_position_planes);
+int64_t nvsr_generic_decode_workspace_floats_ext(const nvsr_decoder_geometry* geometry, int num_position_planes, int64_t P);
+int64_t nvsr_generic_decode_backward_workspace_floats_ext(const nvsr_decoder_geometry* geometry, int num_position_planes, int64_t P);
+/* nvsr_generic_decode / nvsr_generic_decode_backward on an extended scene; d_planes: num_position_planes + 1 device pointers (host
+ * array; NULL array or NULL entries = not wanted), accumulated into like d_plane0..3 */
+int nvsr_generic_decode_ext(const nvsr_scene_ext* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P, const float* x,
+                            const float* coord_noise, float* out, float* workspace, nvsr_stream_t stream);
+int nvsr_generic_decode_backward_ext(const nvsr_scene_ext* scene, const nvsr_decoder_geometry* geometry, const float* natural, int64_t P,
+                                     const float* x, const float* coord_noise, const float* d_out, float* d_natural, float* const* d_planes,
+                                     float* workspace, nvsr_stream_t stream);
+
 /* run_network's model input for a pass (train_utils.py:15-64,111): x [N*S,6] = [ro + rd * z, viewdir] from packed rays [N,11], z [N,S] */
 int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* x, nvsr_stream_t stream);
 

@@ -35,6 +35,16 @@ class Scene(C.Structure):
                 ("range", C.c_float * 5), ("proj", (C.c_float * 6) * 3)]
 
 
+MAX_POSITION_PLANES = 15
+
+
+class SceneExt(C.Structure):
+    """struct nvsr_scene_ext: any number of position planes, grid_sample's align_corners (generic kernels only)"""
+    _fields_ = [("num_position_planes", C.c_int32), ("align_corners", C.c_int32), ("planes", C.c_void_p * (MAX_POSITION_PLANES + 1)),
+                ("ph", C.c_int32 * (MAX_POSITION_PLANES + 1)), ("pw", C.c_int32 * (MAX_POSITION_PLANES + 1)), ("lo", C.c_float * 5),
+                ("range", C.c_float * 5), ("proj", (C.c_float * 6) * MAX_POSITION_PLANES)]
+
+
 class DecoderGeometry(C.Structure):
     """struct nvsr_decoder_geometry"""
     _fields_ = [(n, C.c_int32) for n in ("plane_channels", "viewdir_channels", "hidden", "density_layers", "rgb_layers", "skip_connect_every",
@@ -131,6 +141,12 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_generic_decode": ([C.POINTER(Scene), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "nvsr_generic_decode_backward_workspace_floats": ([C.POINTER(DecoderGeometry), _i64], _i64),
     "nvsr_generic_decode_backward": ([C.POINTER(Scene), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_generic_decoder_natural_floats_ext": ([C.POINTER(DecoderGeometry), _i], _i64),
+    "nvsr_generic_decode_workspace_floats_ext": ([C.POINTER(DecoderGeometry), _i, _i64], _i64),
+    "nvsr_generic_decode_backward_workspace_floats_ext": ([C.POINTER(DecoderGeometry), _i, _i64], _i64),
+    "nvsr_generic_decode_ext": ([C.POINTER(SceneExt), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_generic_decode_backward_ext": ([C.POINTER(SceneExt), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p),
+                                          _vp, _vp], _i),
     "nvsr_ray_points": ([_i64, _i, _vp, _vp, _vp, _vp], _i),
     # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")
     "nvsr_render_pass_arith": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),

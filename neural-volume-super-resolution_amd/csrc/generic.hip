@@ -25,12 +25,43 @@ namespace nvsr {
 struct GenGeom {
     int C, Cv, hidden, nd, nr, skip, proj, view;      // proj: 0 sum 1 avg 2 concat; view: 0 sum 1 avg 2 mult 3 concat 4 concat_pos
     int Kd, Kr;
+    int np;                                           // position planes (num_density_planes, models.py:140): 3 unless a scene_ext says otherwise
 };
+
+// the scene of the generic kernels: up to NVSR_MAX_POSITION_PLANES position planes with their projections, then the view-direction plane;
+// grid_sample's align_corners; the optional jitter of the normalised sample positions (models.py:291-293)
+struct SceneDevN {
+    const float* plane[NVSR_MAX_POSITION_PLANES + 1];
+    int ph[NVSR_MAX_POSITION_PLANES + 1], pw[NVSR_MAX_POSITION_PLANES + 1];
+    float lo[5], range[5];
+    float proj[NVSR_MAX_POSITION_PLANES * 6];
+    int np, align;
+};
+struct GradPlanesN { float* g[NVSR_MAX_POSITION_PLANES + 1]; };
+
+static SceneDevN gen_scene(const nvsr_scene* s) {
+    SceneDevN d = {};
+    for (int i = 0; i < 4; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
+    for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
+    for (int i = 0; i < 18; ++i) d.proj[i] = (&s->proj[0][0])[i];
+    d.np = 3; d.align = 1;
+    return d;
+}
+static SceneDevN gen_scene(const nvsr_scene_ext* s) {
+    SceneDevN d = {};
+    for (int i = 0; i <= s->num_position_planes; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
+    for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
+    for (int i = 0; i < 6 * s->num_position_planes; ++i) d.proj[i] = (&s->proj[0][0])[i];
+    d.np = s->num_position_planes; d.align = s->align_corners ? 1 : 0;
+    return d;
+}
 
 __host__ __device__ inline bool gen_skip_layer(int layer_num, int skip) { return skip > 0 && layer_num % skip == 0 && layer_num > 0; }
 
-static int gen_resolve(const nvsr_decoder_geometry* g, GenGeom* o) {
+static int gen_resolve(const nvsr_decoder_geometry* g, GenGeom* o, int np = 3) {
     if (!g) return NVSR_ERR_NULL;
+    if (np < 1 || np > NVSR_MAX_POSITION_PLANES) return NVSR_ERR_SHAPE;
+    o->np = np;
     o->C = g->plane_channels; o->Cv = g->viewdir_channels; o->hidden = g->hidden; o->nd = g->density_layers; o->nr = g->rgb_layers;
     o->skip = g->skip_connect_every; o->proj = g->proj_combination; o->view = g->viewdir_combination;
     if (o->C < 1 || o->C > 1024 || o->Cv < 1 || o->Cv > 1024 || o->hidden < 1 || o->hidden > 4096 || o->nd < 1 || o->nd > 64 || o->nr < 1 || o->nr > 64)
@@ -40,8 +71,8 @@ static int gen_resolve(const nvsr_decoder_geometry* g, GenGeom* o) {
     const bool concat_like = o->proj == 2 || o->view == 4;
     if (o->view == 3 && o->proj != 2) return NVSR_ERR_SHAPE;              // 'concat' view needs concatenated position features
     if (o->view <= 2 && (o->proj == 2 || o->Cv != o->C)) return NVSR_ERR_SHAPE;   // sum / avg / mult combine equal-sized vectors
-    o->Kd = o->C * (o->proj == 2 ? 3 : 1);
-    o->Kr = o->Cv + (concat_like ? 3 * o->C : 0);
+    o->Kd = o->C * (o->proj == 2 ? np : 1);
+    o->Kr = o->Cv + (concat_like ? np * o->C : 0);
     if (o->view <= 2) o->Kr = o->C;
     return NVSR_OK;
 }
@@ -54,10 +85,14 @@ static int gen_layer_in(const GenGeom& g, bool rgb, int l) {
 }
 
 struct GenTaps { int o[4]; float w[4]; };
-__device__ __forceinline__ GenTaps gen_taps(int H, int W, int Cc, float gx, float gy) {
-    // grid_sample(align_corners=True, padding_mode='border'): unnormalise, clip, floor; a clamped neighbour carries weight 0
+__device__ __forceinline__ GenTaps gen_taps(int H, int W, int Cc, float gx, float gy, int align) {
+    // grid_sample(padding_mode='border'): unnormalise, clip, floor; a clamped neighbour carries weight 0.  align_corners=True maps -1 / +1 to
+    // the centres of the corner texels, (g + 1) (size - 1) / 2; False to their outer edges, (g + 1) size / 2 - 0.5 (the CPU kernel's
+    // ComputeLocation: one product with the pre-divided scale, then the shift)
     const float mx = (float)(W - 1), my = (float)(H - 1);
-    float x = (gx + 1.0f) * (mx / 2.0f), y = (gy + 1.0f) * (my / 2.0f);
+    float x, y;
+    if (align) { x = (gx + 1.0f) * (mx / 2.0f); y = (gy + 1.0f) * (my / 2.0f); }
+    else { x = __fsub_rn(__fmul_rn(gx + 1.0f, (float)W / 2.0f), 0.5f); y = __fsub_rn(__fmul_rn(gy + 1.0f, (float)H / 2.0f), 0.5f); }
     x = fminf(mx, fmaxf(x, 0.0f));
     y = fminf(my, fmaxf(y, 0.0f));
     const float xw = floorf(x), yn = floorf(y);
@@ -72,35 +107,44 @@ __device__ __forceinline__ float gen_blend(const float* __restrict__ plane, cons
     return fmaf(plane[t.o[3] + c], t.w[3], fmaf(plane[t.o[2] + c], t.w[2], fmaf(plane[t.o[1] + c], t.w[1], plane[t.o[0] + c] * t.w[0])));
 }
 
-__global__ void generic_inputs_kernel(SceneDev sc, GenGeom g, long P, const float* __restrict__ x, float* __restrict__ Xd, float* __restrict__ Xr) {
+// normalised sample position (models.py:261-268) + the optional jitter the reference adds to it in training (:291-293)
+__device__ __forceinline__ void gen_position(const SceneDevN& sc, const float* q, const float* noise, long p, float& n0, float& n1, float& n2) {
+    n0 = norm_coord(q[0], sc.lo[0], sc.range[0]); n1 = norm_coord(q[1], sc.lo[1], sc.range[1]); n2 = norm_coord(q[2], sc.lo[2], sc.range[2]);
+    if (noise) { n0 = __fadd_rn(n0, noise[3 * p]); n1 = __fadd_rn(n1, noise[3 * p + 1]); n2 = __fadd_rn(n2, noise[3 * p + 2]); }
+}
+
+__global__ void generic_inputs_kernel(SceneDevN sc, GenGeom g, long P, const float* __restrict__ x, const float* __restrict__ noise,
+                                      float* __restrict__ Xd, float* __restrict__ Xr) {
     const int K = g.Kd + g.Kr;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * K) return;
     const long p = idx / K;
     const int j = (int)(idx - p * K);
     const float* q = x + p * 6;
-    // normalised coordinates (models.py:261-268; cart2az_el nerf_helpers.py:492-496)
-    const float n0 = norm_coord(q[0], sc.lo[0], sc.range[0]), n1 = norm_coord(q[1], sc.lo[1], sc.range[1]), n2 = norm_coord(q[2], sc.lo[2], sc.range[2]);
+    // (cart2az_el nerf_helpers.py:492-496)
+    float n0, n1, n2;
+    gen_position(sc, q, noise, p, n0, n1, n2);
     auto pos_feat = [&](int d, int c) {
         const float* M = sc.proj + 6 * d;
-        const GenTaps t = gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        const GenTaps t = gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.align);
         return gen_blend(sc.plane[d], t, c);
     };
     auto view_feat = [&](int c) {
         const float az = atan2f(q[4], q[3]);
         const float el = atan2f(q[5], sqrtf(__fadd_rn(__fmul_rn(q[3], q[3]), __fmul_rn(q[4], q[4]))));
-        const GenTaps t = gen_taps(sc.ph[3], sc.pw[3], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]));
-        return gen_blend(sc.plane[3], t, c);
+        const GenTaps t = gen_taps(sc.ph[g.np], sc.pw[g.np], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.align);
+        return gen_blend(sc.plane[g.np], t, c);
     };
-    auto combined_pos = [&](int c) {                       // combine_pos_planes, column c of its result
+    auto combined_pos = [&](int c) {                       // combine_pos_planes, column c of its result (stack(...).sum(0) / .mean(0): plane by plane)
         if (g.proj == 2) return pos_feat(c / g.C, c % g.C);
-        const float s = __fadd_rn(__fadd_rn(pos_feat(0, c), pos_feat(1, c)), pos_feat(2, c));
-        return g.proj == 1 ? __fdiv_rn(s, 3.0f) : s;
+        float s = pos_feat(0, c);
+        for (int d = 1; d < g.np; ++d) s = __fadd_rn(s, pos_feat(d, c));
+        return g.proj == 1 ? __fdiv_rn(s, (float)g.np) : s;
     };
     if (j < g.Kd) { Xd[p * g.Kd + j] = combined_pos(j); return; }
     const int c = j - g.Kd;
     float v;
-    if (g.view == 4) v = c < 3 * g.C ? pos_feat(c / g.C, c % g.C) : view_feat(c - 3 * g.C);             // cat(pos_planes + [viewdir])
+    if (g.view == 4) v = c < g.np * g.C ? pos_feat(c / g.C, c % g.C) : view_feat(c - g.np * g.C);       // cat(pos_planes + [viewdir])
     else if (g.view == 3) v = c < g.Kd ? combined_pos(c) : view_feat(c - g.Kd);                        // cat([combined, viewdir])
     else {
         const float pp = combined_pos(c), vv = view_feat(c);
@@ -248,62 +292,62 @@ __global__ __launch_bounds__(256) void generic_wgrad_kernel(long P, int M, int K
 }
 
 // gradients of the decoder inputs -> gradient planes: the transpose of generic_inputs_kernel, one thread per (point, input column)
-__global__ void generic_inputs_backward_kernel(SceneDev sc, GenGeom g, long P, const float* __restrict__ x, const float* __restrict__ dXd,
-                                               const float* __restrict__ dXr, float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2,
-                                               float* __restrict__ g3) {
+__global__ void generic_inputs_backward_kernel(SceneDevN sc, GenGeom g, long P, const float* __restrict__ x, const float* __restrict__ noise,
+                                               const float* __restrict__ dXd, const float* __restrict__ dXr, GradPlanesN gp) {
     const int K = g.Kd + g.Kr;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * K) return;
     const long p = idx / K;
     const int j = (int)(idx - p * K);
     const float* q = x + p * 6;
-    const float n0 = norm_coord(q[0], sc.lo[0], sc.range[0]), n1 = norm_coord(q[1], sc.lo[1], sc.range[1]), n2 = norm_coord(q[2], sc.lo[2], sc.range[2]);
-    float* gp[4] = {g0, g1, g2, g3};
+    float n0, n1, n2;
+    gen_position(sc, q, noise, p, n0, n1, n2);
     auto pos_taps = [&](int d) {
         const float* M = sc.proj + 6 * d;
-        return gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
+        return gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.align);
     };
     auto view_taps = [&]() {
         const float az = atan2f(q[4], q[3]);
         const float el = atan2f(q[5], sqrtf(__fadd_rn(__fmul_rn(q[3], q[3]), __fmul_rn(q[4], q[4]))));
-        return gen_taps(sc.ph[3], sc.pw[3], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]));
+        return gen_taps(sc.ph[g.np], sc.pw[g.np], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.align);
     };
     auto scatter = [&](int d, const GenTaps& t, int c, float v) {
-        if (!gp[d] || v == 0.0f) return;
+        if (!gp.g[d] || v == 0.0f) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (t.w[i] != 0.0f) unsafeAtomicAdd(gp[d] + t.o[i] + c, v * t.w[i]);
+            if (t.w[i] != 0.0f) unsafeAtomicAdd(gp.g[d] + t.o[i] + c, v * t.w[i]);
     };
     auto scatter_pos = [&](int c, float v) {                 // combine_pos_planes transposed, column c of its result
         if (g.proj == 2) { scatter(c / g.C, pos_taps(c / g.C), c % g.C, v); return; }
-        const float f = g.proj == 1 ? v / 3.0f : v;
-        for (int d = 0; d < 3; ++d) scatter(d, pos_taps(d), c, f);
+        const float f = g.proj == 1 ? v / (float)g.np : v;
+        for (int d = 0; d < g.np; ++d) scatter(d, pos_taps(d), c, f);
     };
     auto combined_pos = [&](int c) {
         if (g.proj == 2) return gen_blend(sc.plane[c / g.C], pos_taps(c / g.C), c % g.C);
-        const float s = __fadd_rn(__fadd_rn(gen_blend(sc.plane[0], pos_taps(0), c), gen_blend(sc.plane[1], pos_taps(1), c)), gen_blend(sc.plane[2], pos_taps(2), c));
-        return g.proj == 1 ? __fdiv_rn(s, 3.0f) : s;
+        float s = gen_blend(sc.plane[0], pos_taps(0), c);
+        for (int d = 1; d < g.np; ++d) s = __fadd_rn(s, gen_blend(sc.plane[d], pos_taps(d), c));
+        return g.proj == 1 ? __fdiv_rn(s, (float)g.np) : s;
     };
     if (j < g.Kd) { scatter_pos(j, dXd[p * g.Kd + j]); return; }
     const int c = j - g.Kd;
     const float v = dXr[p * g.Kr + c];
     if (g.view == 4) {
-        if (c < 3 * g.C) scatter(c / g.C, pos_taps(c / g.C), c % g.C, v);
-        else scatter(3, view_taps(), c - 3 * g.C, v);
+        if (c < g.np * g.C) scatter(c / g.C, pos_taps(c / g.C), c % g.C, v);
+        else scatter(g.np, view_taps(), c - g.np * g.C, v);
     } else if (g.view == 3) {
         if (c < g.Kd) scatter_pos(c, v);
-        else scatter(3, view_taps(), c - g.Kd, v);
+        else scatter(g.np, view_taps(), c - g.Kd, v);
     } else if (g.view == 0) {
         scatter_pos(c, v);
-        scatter(3, view_taps(), c, v);
+        scatter(g.np, view_taps(), c, v);
     } else if (g.view == 1) {
         scatter_pos(c, v * 0.5f);
-        scatter(3, view_taps(), c, v * 0.5f);
+        scatter(g.np, view_taps(), c, v * 0.5f);
     } else {                                                 // mult: pp * (1 + vv)
         const GenTaps tv = view_taps();
-        const float pp = combined_pos(c), vv = gen_blend(sc.plane[3], tv, c);
+        const float pp = combined_pos(c), vv = gen_blend(sc.plane[g.np], tv, c);
         scatter_pos(c, v * __fadd_rn(1.0f, vv));
-        scatter(3, tv, c, v * pp);
+        scatter(g.np, tv, c, v * pp);
     }
 }
 
@@ -316,9 +360,9 @@ using namespace nvsr;
 
 extern "C" {
 
-int64_t nvsr_generic_decoder_natural_floats(const nvsr_decoder_geometry* geom) {
+static int64_t gen_natural_floats(const nvsr_decoder_geometry* geom, int np) {
     GenGeom g;
-    if (gen_resolve(geom, &g)) return -1;
+    if (gen_resolve(geom, &g, np)) return -1;
     int64_t n = 0;
     for (int l = 0; l < g.nd; ++l) n += (int64_t)g.hidden * gen_layer_in(g, false, l) + g.hidden;
     n += g.hidden + 1;
@@ -326,34 +370,47 @@ int64_t nvsr_generic_decoder_natural_floats(const nvsr_decoder_geometry* geom) {
     n += 3 * g.hidden + 3;
     return n;
 }
+int64_t nvsr_generic_decoder_natural_floats(const nvsr_decoder_geometry* geom) { return gen_natural_floats(geom, 3); }
+int64_t nvsr_generic_decoder_natural_floats_ext(const nvsr_decoder_geometry* geom, int num_position_planes) { return gen_natural_floats(geom, num_position_planes); }
 
-int64_t nvsr_generic_decode_workspace_floats(const nvsr_decoder_geometry* geom, int64_t P) {
+static int64_t gen_workspace_floats(const nvsr_decoder_geometry* geom, int np, int64_t P) {
     GenGeom g;
-    if (gen_resolve(geom, &g) || P < 0) return -1;
+    if (gen_resolve(geom, &g, np) || P < 0) return -1;
     const int64_t c = P < GEN_CHUNK ? P : GEN_CHUNK;
     return c * (int64_t)(g.Kd + g.Kr + 2 * g.hidden);
 }
+int64_t nvsr_generic_decode_workspace_floats(const nvsr_decoder_geometry* geom, int64_t P) { return gen_workspace_floats(geom, 3, P); }
+int64_t nvsr_generic_decode_workspace_floats_ext(const nvsr_decoder_geometry* geom, int num_position_planes, int64_t P) {
+    return gen_workspace_floats(geom, num_position_planes, P);
+}
 
-int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x, float* out,
-                        float* workspace, nvsr_stream_t stream_) {
-    GenGeom g;
-    if (int e = gen_resolve(geom, &g)) return e;
-    if (!scene || !natural || !x || !out || !workspace) return NVSR_ERR_NULL;
-    for (int d = 0; d < 4; ++d) {
-        if (!scene->planes[d]) return NVSR_ERR_NULL;
-        const int64_t cc = d < 3 ? g.C : g.Cv;
-        if (scene->ph[d] < 1 || scene->pw[d] < 1 || (int64_t)scene->ph[d] * scene->pw[d] * cc >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
+static int gen_check_scene(const SceneDevN& sc, const GenGeom& g) {
+    for (int d = 0; d <= g.np; ++d) {
+        if (!sc.plane[d]) return NVSR_ERR_NULL;
+        const int64_t cc = d < g.np ? g.C : g.Cv;
+        if (sc.ph[d] < 1 || sc.pw[d] < 1 || (int64_t)sc.ph[d] * sc.pw[d] * cc >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
     }
+    return NVSR_OK;
+}
+static int gen_check_ext(const nvsr_scene_ext* scene) {
+    if (!scene) return NVSR_ERR_NULL;
+    if (scene->num_position_planes < 1 || scene->num_position_planes > NVSR_MAX_POSITION_PLANES) return NVSR_ERR_SHAPE;
+    return NVSR_OK;
+}
+
+static int gen_decode(const SceneDevN& sc, const GenGeom& g, const float* natural, int64_t P, const float* x, const float* coord_noise, float* out,
+                      float* workspace, hipStream_t stream) {
+    if (!natural || !x || !out || !workspace) return NVSR_ERR_NULL;
+    if (int e = gen_check_scene(sc, g)) return e;
     if (P < 0) return NVSR_ERR_SHAPE;
-    hipStream_t stream = (hipStream_t)stream_;
-    const SceneDev sc = to_dev(scene);
     for (int64_t a = 0; a < P; a += GEN_CHUNK) {
         const long n = (long)((P - a) < GEN_CHUNK ? (P - a) : GEN_CHUNK);
         float* Xd = workspace;
         float* Xr = Xd + n * g.Kd;
         float* H[2] = {Xr + n * g.Kr, Xr + n * g.Kr + n * g.hidden};
         const long threads = n * (g.Kd + g.Kr);
-        hipLaunchKernelGGL(generic_inputs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, x + a * 6, Xd, Xr);
+        hipLaunchKernelGGL(generic_inputs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, x + a * 6,
+                           coord_noise ? coord_noise + a * 3 : nullptr, Xd, Xr);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
         const float* w = natural;
         const dim3 pts((unsigned)((n + GL_PTS - 1) / GL_PTS));
@@ -382,30 +439,40 @@ int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* ge
     }
     return NVSR_OK;
 }
+int nvsr_generic_decode(const nvsr_scene* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x, float* out,
+                        float* workspace, nvsr_stream_t stream) {
+    GenGeom g;
+    if (int e = gen_resolve(geom, &g)) return e;
+    if (!scene) return NVSR_ERR_NULL;
+    return gen_decode(gen_scene(scene), g, natural, P, x, nullptr, out, workspace, (hipStream_t)stream);
+}
+int nvsr_generic_decode_ext(const nvsr_scene_ext* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x,
+                            const float* coord_noise, float* out, float* workspace, nvsr_stream_t stream) {
+    if (int e = gen_check_ext(scene)) return e;
+    GenGeom g;
+    if (int e = gen_resolve(geom, &g, scene->num_position_planes)) return e;
+    return gen_decode(gen_scene(scene), g, natural, P, x, coord_noise, out, workspace, (hipStream_t)stream);
+}
 
 static int64_t gen_bwd_floats_per_point(const GenGeom& g) { return 2 * (int64_t)(g.Kd + g.Kr) + (int64_t)(g.nd + g.nr + 2) * g.hidden; }
 
-int64_t nvsr_generic_decode_backward_workspace_floats(const nvsr_decoder_geometry* geom, int64_t P) {
+static int64_t gen_bwd_workspace_floats(const nvsr_decoder_geometry* geom, int np, int64_t P) {
     GenGeom g;
-    if (gen_resolve(geom, &g) || P < 0) return -1;
+    if (gen_resolve(geom, &g, np) || P < 0) return -1;
     return (P < GEN_BWD_CHUNK ? P : GEN_BWD_CHUNK) * gen_bwd_floats_per_point(g);
 }
+int64_t nvsr_generic_decode_backward_workspace_floats(const nvsr_decoder_geometry* geom, int64_t P) { return gen_bwd_workspace_floats(geom, 3, P); }
+int64_t nvsr_generic_decode_backward_workspace_floats_ext(const nvsr_decoder_geometry* geom, int num_position_planes, int64_t P) {
+    return gen_bwd_workspace_floats(geom, num_position_planes, P);
+}
 
-int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x,
-                                 const float* d_out, float* d_natural, float* d_plane0, float* d_plane1, float* d_plane2, float* d_plane3,
-                                 float* workspace, nvsr_stream_t stream_) {
-    GenGeom g;
-    if (int e = gen_resolve(geom, &g)) return e;
-    if (!scene || !natural || !x || !d_out || !workspace) return NVSR_ERR_NULL;
-    for (int d = 0; d < 4; ++d) {
-        if (!scene->planes[d]) return NVSR_ERR_NULL;
-        const int64_t cc = d < 3 ? g.C : g.Cv;
-        if (scene->ph[d] < 1 || scene->pw[d] < 1 || (int64_t)scene->ph[d] * scene->pw[d] * cc >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
-    }
+static int gen_decode_backward(const SceneDevN& sc, const GenGeom& g, const float* natural, int64_t P, const float* x, const float* coord_noise,
+                               const float* d_out, float* d_natural, const GradPlanesN& gp, float* workspace, hipStream_t stream) {
+    if (!natural || !x || !d_out || !workspace) return NVSR_ERR_NULL;
+    if (int e = gen_check_scene(sc, g)) return e;
     if (P < 0 || g.nd + g.nr > 128) return NVSR_ERR_SHAPE;
-    hipStream_t stream = (hipStream_t)stream_;
-    const SceneDev sc = to_dev(scene);
-    const bool want_planes = d_plane0 || d_plane1 || d_plane2 || d_plane3;
+    bool want_planes = false;
+    for (int d = 0; d <= g.np; ++d) want_planes = want_planes || gp.g[d] != nullptr;
     // offsets of the layers in the natural blob (state-dict order: density layers, fc_alpha, rgb layers, fc_rgb; weight then bias)
     long woff[2][65];
     {
@@ -426,7 +493,8 @@ int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geo
         const float* xa = x + a * 6;
         const float* da = d_out + a * 4;
         const long threads = n * (g.Kd + g.Kr);
-        hipLaunchKernelGGL(generic_inputs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, Xin[0], Xin[1]);
+        const float* na = coord_noise ? coord_noise + a * 3 : nullptr;
+        hipLaunchKernelGGL(generic_inputs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, na, Xin[0], Xin[1]);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
         const dim3 pts((unsigned)((n + GL_PTS - 1) / GL_PTS));
         const unsigned slabs = (unsigned)((n + GW_PTS - 1) / GW_PTS);
@@ -489,12 +557,33 @@ int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geo
             }
         }
         if (want_planes) {
-            hipLaunchKernelGGL(generic_inputs_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, dXin[0], dXin[1],
-                               d_plane0, d_plane1, d_plane2, d_plane3);
+            hipLaunchKernelGGL(generic_inputs_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, sc, g, n, xa, na, dXin[0],
+                               dXin[1], gp);
             if (int e = NVSR_CHECK_LAUNCH()) return e;
         }
     }
     return NVSR_OK;
+}
+int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x,
+                                 const float* d_out, float* d_natural, float* d_plane0, float* d_plane1, float* d_plane2, float* d_plane3,
+                                 float* workspace, nvsr_stream_t stream) {
+    GenGeom g;
+    if (int e = gen_resolve(geom, &g)) return e;
+    if (!scene) return NVSR_ERR_NULL;
+    GradPlanesN gp = {};
+    gp.g[0] = d_plane0; gp.g[1] = d_plane1; gp.g[2] = d_plane2; gp.g[3] = d_plane3;
+    return gen_decode_backward(gen_scene(scene), g, natural, P, x, nullptr, d_out, d_natural, gp, workspace, (hipStream_t)stream);
+}
+int nvsr_generic_decode_backward_ext(const nvsr_scene_ext* scene, const nvsr_decoder_geometry* geom, const float* natural, int64_t P, const float* x,
+                                     const float* coord_noise, const float* d_out, float* d_natural, float* const* d_planes, float* workspace,
+                                     nvsr_stream_t stream) {
+    if (int e = gen_check_ext(scene)) return e;
+    GenGeom g;
+    if (int e = gen_resolve(geom, &g, scene->num_position_planes)) return e;
+    GradPlanesN gp = {};
+    if (d_planes)
+        for (int d = 0; d <= scene->num_position_planes; ++d) gp.g[d] = d_planes[d];
+    return gen_decode_backward(gen_scene(scene), g, natural, P, x, coord_noise, d_out, d_natural, gp, workspace, (hipStream_t)stream);
 }
 
 int nvsr_ray_points(int64_t N, int S, const float* rays, const float* z, float* x, nvsr_stream_t stream) {

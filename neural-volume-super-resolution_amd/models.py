@@ -50,20 +50,45 @@ def is_native_layout(plane):
 
 
 class CoordProjector(nn.Module):
-    """models.py:471-497.  Only the axis-aligned N<=3 constructor is reproduced (random rotations for N>3 are not used by
-    any shipped config); pre-built rot_mats of any N are accepted."""
+    """models.py:471-497: one orthonormal frame per position plane (column 0 = the plane's normal, columns 1:3 = the axes a point is
+    projected on).  Up to three planes: the standard basis and two permutations of it.  More: random frames, drawn from NumPy's global
+    generator with the reference's calls in the reference's order -- a seeded construction yields the reference's frames bit for bit
+    (tests: g22 `planes5.rot*`)."""
+
+    SPREAD_TRIALS = 10000
 
     def __init__(self, N: int = None, rot_mats=None) -> None:
         super().__init__()
-        if rot_mats is None:
-            if N > 3:
-                raise NotImplementedError("random plane orientations (N>3) are not part of the hot path")
-            base_mat = torch.eye(3)
-            self.rot_mats_NON_LEARNED = nn.ParameterList(
-                [nn.Parameter(p) for p in [base_mat, base_mat[:, [1, 0, 2]], base_mat[:, [2, 0, 1]]][:N]])
-        else:
+        if rot_mats is not None:
             assert len(rot_mats) == N
             self.rot_mats_NON_LEARNED = rot_mats
+            return
+        if N <= 3:
+            eye = torch.eye(3)
+            frames = [eye, eye[:, [1, 0, 2]], eye[:, [2, 0, 1]]][:N]
+        else:
+            frames = [torch.from_numpy(f) for f in self.spread_frames(N)]
+        self.rot_mats_NON_LEARNED = nn.ParameterList([nn.Parameter(f) for f in frames])
+
+    @classmethod
+    def spread_frames(cls, N):
+        """N plane normals that keep away from each other and from each other's mirror images: of SPREAD_TRIALS random sets of N unit
+        vectors, the set whose 2N directions (every normal and its negative) have the largest sum of squared distances to their nearest
+        neighbour.  Each normal is then completed to an orthonormal frame by the QR factorisation of [normal | random 3x2]."""
+        sets = np.random.uniform(low=-1, high=1, size=[cls.SPREAD_TRIALS, N, 3])
+        sets /= np.sqrt(np.sum(sets ** 2, 2, keepdims=True))
+        both = np.concatenate((sets, -1 * sets), 1)                                        # [trial, 2N, 3]
+        d2 = np.sum((both[..., None, :] - np.expand_dims(both, 1)) ** 2, -1)               # [trial, 2N, 2N] squared distances
+        nearest = np.sort(d2, 1)[:, 1, ...]                                                # (row 0 of the sort is the distance to itself)
+        normals = both[np.argmax(np.sum(nearest, -1))][:N]
+        frames = []
+        for nrm in normals:
+            while True:
+                m = np.concatenate([nrm[:, None], np.random.uniform(size=[3, 2])], 1)
+                if np.linalg.matrix_rank(m) == 3:
+                    break
+            frames.append(np.linalg.qr(m)[0])
+        return frames
 
     def forward(self, points_dim):
         with torch.no_grad():
@@ -136,10 +161,8 @@ class TwoDimPlanesModel(nn.Module):
         self.box_coords = None
         self.use_viewdirs = use_viewdirs
         assert use_viewdirs or (viewdir_proj_combination is None and num_viewdir_plane_channels is None)
-        if point_coords_noise:
-            # models.py:291-293 jitters the normalised coordinates of every training-mode forward; the kernels do not implement it and a
-            # silently ignored regulariser would change training results
-            raise NotImplementedError("point_coords_noise != 0 is not implemented by the gfx950 kernels (0 in every shipped config)")
+        # (models.py:291-293: a training-mode forward jitters the normalised sample positions; such a model trains through the generic kernels,
+        #  which take the jitter as an input -- jitter_std / _generic_forward)
         self.point_coords_noise = point_coords_noise
         self.num_plane_channels = num_plane_channels
         if num_viewdir_plane_channels is None:
@@ -272,7 +295,15 @@ class TwoDimPlanesModel(nn.Module):
                 and self.dec_density_layers == 4 and self.dec_rgb_layers == 4 and self.ensemble_size == 1
                 and self.proj_combination == "avg" and self.viewdir_proj_combination == "concat_pos"
                 and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear" and self.align_corners
-                and not any(self.is_skip_layer(l) for l in range(3)))
+                and not any(self.is_skip_layer(l) for l in range(3)) and not (self.point_coords_noise and self.training))
+
+    def jitter_std(self):
+        """std of the jitter a forward adds to the normalised sample positions right now: point_coords_noise * 2 / (1 + plane resolution) in
+        training mode (models.py:291-293; the resolution is read off the scene id like there), 0 otherwise"""
+        if not (self.point_coords_noise and self.training):
+            return 0.0
+        import re
+        return float(self.point_coords_noise) * 2 / (1 + int(re.search(r"(?<=PlRes)(\d)+(?=_)", self.cur_id).group(0)))
 
     def _check_native_geometry(self):
         if not self.is_native_geometry():
@@ -284,10 +315,10 @@ class TwoDimPlanesModel(nn.Module):
     def generic_geometry(self):
         """[plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every, proj, view] for
         torch.ops.nvsr.triplane_decode_generic (struct nvsr_decoder_geometry)"""
-        if not (self.use_viewdirs and self.num_density_planes == 3 and self.ensemble_size == 1 and self.rgb_dec_input == "projections"
-                and self.plane_interp == "bilinear" and self.align_corners):
-            raise NotImplementedError("the generic decoder kernels cover use_viewdirs=True, 3 axis-aligned position planes, ensemble_size 1, "
-                                      "rgb_dec_input='projections', bilinear planes with align_corners=True")
+        if not (self.use_viewdirs and 1 <= self.num_density_planes <= capi.MAX_POSITION_PLANES and self.ensemble_size == 1
+                and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear"):
+            raise NotImplementedError("the generic decoder kernels cover use_viewdirs=True, 1 .. %d position planes, ensemble_size 1, "
+                                      "rgb_dec_input='projections' and bilinear planes" % capi.MAX_POSITION_PLANES)
         return [self.num_plane_channels, self.num_viewdir_plane_channels, self.dec_channels, self.dec_density_layers, self.dec_rgb_layers,
                 int(self.skip_connect_every or 0), {"sum": 0, "avg": 1, "concat": 2}[self.proj_combination],
                 {"sum": 0, "avg": 1, "mult": 2, "concat": 3, "concat_pos": 4}[self.viewdir_proj_combination]]
@@ -382,8 +413,16 @@ class TwoDimPlanesModel(nn.Module):
             out.append(self.SR_model((saved, roi)))
         return out
 
-    def _generic_forward(self, x):
-        """forward through the generic kernels (any geometry); in training mode with gradients for the planes and the decoder"""
+    def _generic_forward(self, x, coord_noise=None):
+        """forward through the generic kernels (any geometry); in training mode with gradients for the planes and the decoder.
+        coord_noise [P,3]: the jitter of the normalised sample positions (models.py:291-293) when the caller has drawn it (run_one_iter_of_nerf
+        draws in the reference's order of chunks and network batches); None = drawn here like the reference's forward does, one
+        torch.normal call of the input's size on the CPU generator."""
+        std = self.jitter_std()
+        if std and coord_noise is None:
+            coord_noise = torch.normal(mean=0, std=std, size=[x.shape[0], 3])
+        if coord_noise is not None:
+            coord_noise = capi.f32c(coord_noise.to(x.device))
         if torch.is_grad_enabled():                                    # (like any torch module: a graph whenever gradients are on)
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
             dec = any(p.requires_grad for p in self.decoder_parameters())
@@ -393,7 +432,7 @@ class TwoDimPlanesModel(nn.Module):
                 if self.training:
                     np.random.randint(self.ensemble_size)             # models.py:393 (see forward())
                 planes = [self.planes_[n] for n in names]
-                return _GenericDecodeFn.apply(self, x, *planes, self.natural_blob(differentiable=True) if dec else None)
+                return _GenericDecodeFn.apply(self, x, self.natural_blob(differentiable=True) if dec else None, coord_noise, *planes)
         if hasattr(self, "SR_model") and not self.skip_SR_:
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]
             names = [n for n in names if self._should_SR(n)]
@@ -404,12 +443,13 @@ class TwoDimPlanesModel(nn.Module):
         planes, consts = self.scene_args(planes=planes, check_native=False)
         nat = self.natural_blob()
         capi.require_cuda(nat)
-        return torch.ops.nvsr.triplane_decode_generic(planes, consts, nat, self.generic_geometry(), x)
+        return torch.ops.nvsr.triplane_decode_generic(planes, consts, nat, self.generic_geometry(), x, bool(self.align_corners), coord_noise)
 
     def scene_args(self, planes=None, check_native=True):
-        """(planes, consts) of the current scene id as the torch.ops.nvsr operators take them: 4 channel-last planes + the 28 host floats
-        of struct nvsr_scene.  planes: optional explicit channel-last planes (the training path samples tensors that are part of the
-        autograd graph)."""
+        """(planes, consts) of the current scene id as the torch.ops.nvsr operators take them: the channel-last planes (position planes, then
+        the view-direction plane) + the host floats of struct nvsr_scene / nvsr_scene_ext (lo[5], range[5], a 3x2 projection per position
+        plane: 28 for the three planes of the MFMA kernels).  planes: optional explicit channel-last planes (the training path samples
+        tensors that are part of the autograd graph)."""
         if check_native:
             self._check_native_geometry()
         if planes is None:
@@ -424,7 +464,7 @@ class TwoDimPlanesModel(nn.Module):
         # box and projection matrices as host floats: read back once per version (a device-to-host copy drains the queue, and this runs
         # for every pass of every training iteration)
         box_t = self.box_coords[self.cur_id + ""]
-        rots = [self.coord_projector.rot_mats_NON_LEARNED[d] for d in range(3)]
+        rots = [self.coord_projector.rot_mats_NON_LEARNED[d] for d in range(self.num_density_planes)]
         key = (self.cur_id, box_t.data_ptr(), box_t._version) + tuple((r.data_ptr(), r._version) for r in rots)
         cache = self.__dict__.get("_scene_consts")
         if cache is None or cache[0] != key:
@@ -484,15 +524,17 @@ class TwoDimPlanesModel(nn.Module):
             return capi.ARITHMETIC["bf16x3"]
         return code
 
-    def forward(self, x):
-        """models.py:381-421: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb, sigma] (pre-activation)"""
+    def forward(self, x, coord_noise=None):
+        """models.py:381-421: x [P,6] = [xyz, viewdir] -> [P,4] = [rgb, sigma] (pre-activation).  coord_noise (not in the reference's
+        signature): the point_coords_noise jitter of this call, [P,3], when the caller draws it (_generic_forward)."""
         x = capi.f32c(x)
         assert x.shape[-1] == 6, "TwoDimPlanesModel expects [xyz, viewdir] rows"
         P = x.numel() // 6
         if P == 0:
             return torch.empty(list(x.shape[:-1]) + [4], dtype=torch.float32, device=x.device)
         if not self.is_native_geometry():
-            return self._generic_forward(x.reshape(P, 6)).reshape(list(x.shape[:-1]) + [4])
+            return self._generic_forward(x.reshape(P, 6), coord_noise).reshape(list(x.shape[:-1]) + [4])
+        assert coord_noise is None, "a jitter for a forward that does not jitter (point_coords_noise == 0 or evaluation mode)"
         if self.training and torch.is_grad_enabled() and not (hasattr(self, "SR_model") and not self.skip_SR_):
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
             planes = [self.planes_[n] for n in names]
@@ -548,30 +590,32 @@ class _DecodePointsFn(torch.autograd.Function):
 
 
 class _GenericDecodeFn(torch.autograd.Function):
-    """TwoDimPlanesModel.forward for a decoder geometry other than the shipped one, with gradients for the planes and the decoder
-    (torch.ops.nvsr.triplane_decode_generic / _backward: csrc/generic.hip recomputes the forward in the backward)."""
+    """TwoDimPlanesModel.forward for a decoder geometry / option set other than the shipped one, with gradients for the planes and the
+    decoder (torch.ops.nvsr.triplane_decode_generic / _backward: csrc/generic.hip recomputes the forward in the backward).
+    inputs: model, x, natural blob (None = the decoder does not train), jitter (None = none), then the planes of the scene."""
 
     @staticmethod
-    def forward(ctx, model, x, p0, p1, p2, pv, nat):
-        planes_cl = [to_channel_last(p.detach()) for p in (p0, p1, p2, pv)]
+    def forward(ctx, model, x, nat, coord_noise, *plane_srcs):
+        planes_cl = [to_channel_last(p.detach()) for p in plane_srcs]
         planes_cl, consts = model.scene_args(planes=planes_cl, check_native=False)
         natural = model.natural_blob() if nat is None else nat.detach()
         capi.require_cuda(natural)
         geometry = model.generic_geometry()
-        ctx.plane_srcs = (p0, p1, p2, pv)
-        ctx.state = (planes_cl, consts, natural, geometry, x)
-        return torch.ops.nvsr.triplane_decode_generic(planes_cl, consts, natural, geometry, x)
+        ctx.plane_srcs = plane_srcs
+        ctx.state = (planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise)
+        return torch.ops.nvsr.triplane_decode_generic(planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise)
 
     @staticmethod
     def backward(ctx, g_out):
-        planes_cl, consts, natural, geometry, x = ctx.state
+        planes_cl, consts, natural, geometry, x, align, coord_noise = ctx.state
         need = ctx.needs_input_grad
-        need_planes = [bool(n) for n in need[2:6]]
-        if not any(need_planes) and not need[6]:
-            return (None,) * 7
-        g = torch.ops.nvsr.triplane_decode_generic_backward(planes_cl, consts, natural, geometry, x, capi.f32c(g_out), bool(need[6]), need_planes)
-        return (None, None) + tuple(from_channel_last(gp, like=p_) if n else None for gp, p_, n in zip(g[1:], ctx.plane_srcs, need_planes)) + \
-               (g[0] if need[6] else None,)
+        need_planes = [bool(n) for n in need[4:]]
+        if not any(need_planes) and not need[2]:
+            return (None,) * len(need)
+        g = torch.ops.nvsr.triplane_decode_generic_backward(planes_cl, consts, natural, geometry, x, capi.f32c(g_out), bool(need[2]), need_planes,
+                                                            align, coord_noise)
+        return (None, None, g[0] if need[2] else None, None) + \
+               tuple(from_channel_last(gp, like=p_) if n else None for gp, p_, n in zip(g[1:], ctx.plane_srcs, need_planes))
 
 
 # =======================================================================================================================

@@ -193,59 +193,94 @@ def _(planes, consts, packed, x, arith=-1):
     return x.new_empty((x.shape[0], 4))
 
 
-@custom_op("nvsr::triplane_decode_generic", mutates_args=(), device_types="cuda")
-def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor) -> Tensor:
-    """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (csrc/generic.hip).
-    geometry = [plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every (0 = None), proj_combination
-    (0 sum, 1 avg, 2 concat), viewdir_combination (0 sum, 1 avg, 2 mult, 3 concat, 4 concat_pos)]; natural = the parameters in
-    state-dict order; planes channel-last [H,W,plane_channels] x 3 + [H,W,viewdir_channels]."""
-    x, natural = _c(x), _c(natural)
+def _scene_ext(planes, consts, channels, align_corners):
+    """struct nvsr_scene_ext from N + 1 channel-last planes (N position planes, then the view-direction plane) + 10 + 6 N host constants
+    (lo, range, the N 3x2 projections)"""
+    n_pos = len(planes) - 1
+    assert 1 <= n_pos <= capi.MAX_POSITION_PLANES, "1 .. %d position planes" % capi.MAX_POSITION_PLANES
+    assert len(consts) == 10 + 6 * n_pos, "scene constants: lo[5], range[5] and a 3x2 projection per position plane"
+    sc = capi.SceneExt()
+    sc.num_position_planes, sc.align_corners = n_pos, int(bool(align_corners))
+    for d, p in enumerate(planes):
+        capi.require_cuda(p)
+        cc = channels[0 if d < n_pos else 1]
+        assert p.dtype == torch.float32 and p.dim() == 3 and p.shape[2] == cc and p.is_contiguous(), "planes must be channel-last [H,W,%d] f32" % cc
+        sc.planes[d] = p.data_ptr()
+        sc.ph[d], sc.pw[d] = p.shape[0], p.shape[1]
+    for i in range(5):
+        sc.lo[i] = consts[i]
+        sc.range[i] = consts[5 + i]
+    for d in range(n_pos):
+        for j in range(6):
+            sc.proj[d][j] = consts[10 + 6 * d + j]
+    return sc
+
+
+def _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P):
     geo = capi.DecoderGeometry(*[int(v) for v in geometry])
-    n = capi.lib().nvsr_generic_decoder_natural_floats(C.byref(geo))
+    n_pos = len(planes) - 1
+    n = capi.lib().nvsr_generic_decoder_natural_floats_ext(C.byref(geo), n_pos)
     if n < 0:
         raise capi.NvsrError("this decoder geometry is inconsistent (the reference's own layer sizes do not admit it)")
     assert natural.numel() == n, "natural blob: %d floats, the geometry needs %d" % (natural.numel(), n)
-    sc = _scene(planes, consts, channels=(geo.plane_channels, geo.viewdir_channels))
+    if coord_noise is not None:
+        assert tuple(coord_noise.shape) == (P, 3) and coord_noise.dtype == torch.float32, "coord_noise: [P,3] f32"
+        capi.require_cuda(coord_noise)
+    return geo, n_pos, n, _scene_ext(planes, consts, (geo.plane_channels, geo.viewdir_channels), align_corners)
+
+
+@custom_op("nvsr::triplane_decode_generic", mutates_args=(), device_types="cuda")
+def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor,
+                            align_corners: bool = True, coord_noise: Optional[Tensor] = None) -> Tensor:
+    """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (csrc/generic.hip).
+    geometry = [plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every (0 = None), proj_combination
+    (0 sum, 1 avg, 2 concat), viewdir_combination (0 sum, 1 avg, 2 mult, 3 concat, 4 concat_pos)]; natural = the parameters in
+    state-dict order; planes channel-last: N position planes [H,W,plane_channels], then [H,W,viewdir_channels]; consts = lo[5], range[5],
+    N 3x2 projections; align_corners: grid_sample's; coord_noise [P,3]: added to the normalised positions (point_coords_noise,
+    models.py:291-293)."""
+    x, natural = _c(x), _c(natural)
     P = x.shape[0]
+    coord_noise = None if coord_noise is None else _c(coord_noise)
+    geo, n_pos, _, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P)
     out = _f(P, 4, like=x)
     if P:
-        ws = _f(capi.lib().nvsr_generic_decode_workspace_floats(C.byref(geo), P), like=x)
-        capi.call("nvsr_generic_decode", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x), capi.ptr(out), capi.ptr(ws), capi.stream())
+        ws = _f(capi.lib().nvsr_generic_decode_workspace_floats_ext(C.byref(geo), n_pos, P), like=x)
+        capi.call("nvsr_generic_decode_ext", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x),
+                  None if coord_noise is None else capi.ptr(coord_noise), capi.ptr(out), capi.ptr(ws), capi.stream())
     return out
 
 
 @triplane_decode_generic.register_fake
-def _(planes, consts, natural, geometry, x):
+def _(planes, consts, natural, geometry, x, align_corners=True, coord_noise=None):
     return x.new_empty((x.shape[0], 4))
 
 
 @custom_op("nvsr::triplane_decode_generic_backward", mutates_args=(), device_types="cuda")
 def triplane_decode_generic_backward(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor,
-                                     g_out: Tensor, want_natural: bool, want_planes: Sequence[bool]) -> List[Tensor]:
+                                     g_out: Tensor, want_natural: bool, want_planes: Sequence[bool], align_corners: bool = True,
+                                     coord_noise: Optional[Tensor] = None) -> List[Tensor]:
     """Backward of triplane_decode_generic (csrc/generic.hip; the reference: torch.autograd through models.py:381-421): g_out [P,4] ->
-    [d_natural, d_plane0 .. d_plane3] (channel-last like the planes; a gradient that is not wanted comes back as an empty tensor)."""
+    [d_natural, d_plane0 .. d_planeN] (channel-last like the planes; a gradient that is not wanted comes back as an empty tensor)."""
     x, natural, g_out = _c(x), _c(natural), _c(g_out)
-    geo = capi.DecoderGeometry(*[int(v) for v in geometry])
-    n = capi.lib().nvsr_generic_decoder_natural_floats(C.byref(geo))
-    if n < 0:
-        raise capi.NvsrError("this decoder geometry is inconsistent (the reference's own layer sizes do not admit it)")
-    assert natural.numel() == n, "natural blob: %d floats, the geometry needs %d" % (natural.numel(), n)
-    sc = _scene(planes, consts, channels=(geo.plane_channels, geo.viewdir_channels))
     P = x.shape[0]
+    coord_noise = None if coord_noise is None else _c(coord_noise)
+    geo, n_pos, n, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P)
     assert tuple(g_out.shape) == (P, 4)
     want_planes = [bool(w) for w in want_planes]
+    assert len(want_planes) == n_pos + 1
     g_nat = torch.zeros(n if want_natural else 0, dtype=torch.float32, device=x.device)
     g_pl = [torch.zeros_like(pl) if w else _f(0, like=x) for pl, w in zip(planes, want_planes)]
     if P and (want_natural or any(want_planes)):
-        ws = _f(capi.lib().nvsr_generic_decode_backward_workspace_floats(C.byref(geo), P), like=x)
-        capi.call("nvsr_generic_decode_backward", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x), capi.ptr(g_out),
-                  capi.ptr(g_nat) if want_natural else None, *[capi.ptr(g) if w else None for g, w in zip(g_pl, want_planes)], capi.ptr(ws),
-                  capi.stream())
+        ws = _f(capi.lib().nvsr_generic_decode_backward_workspace_floats_ext(C.byref(geo), n_pos, P), like=x)
+        d_planes = (C.c_void_p * (n_pos + 1))(*[g.data_ptr() if w else None for g, w in zip(g_pl, want_planes)])
+        capi.call("nvsr_generic_decode_backward_ext", C.byref(sc), C.byref(geo), capi.ptr(natural), P, capi.ptr(x),
+                  None if coord_noise is None else capi.ptr(coord_noise), capi.ptr(g_out), capi.ptr(g_nat) if want_natural else None, d_planes,
+                  capi.ptr(ws), capi.stream())
     return [g_nat] + g_pl
 
 
 @triplane_decode_generic_backward.register_fake
-def _(planes, consts, natural, geometry, x, g_out, want_natural, want_planes):
+def _(planes, consts, natural, geometry, x, g_out, want_natural, want_planes, align_corners=True, coord_noise=None):
     return [natural.new_empty(natural.numel() if want_natural else 0)] + [pl.new_empty(pl.shape if w else (0,)) for pl, w in zip(planes, want_planes)]
 
 

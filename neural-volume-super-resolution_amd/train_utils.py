@@ -40,6 +40,19 @@ def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn, s
     return out.reshape(pts_shape[:-1] + [out.shape[-1]])
 
 
+def _draw_point_jitter(model, n_rays, S, chunksize):
+    """The point_coords_noise draws of one pass over a ray chunk, in the reference's order: run_network cuts the chunk's n_rays * S points
+    into network batches of `chunksize` points (train_utils.py:47-58) and every model call draws torch.normal of its batch's shape from the
+    CPU generator (models.py:291-293).  -> [n_rays, S, 3] or None when the model does not jitter right now."""
+    std = model.jitter_std()
+    if not std:
+        return None
+    n = n_rays * S
+    step = n if chunksize is None else int(chunksize)
+    parts = [torch.normal(mean=0, std=std, size=[min(step, n - i), 3]) for i in range(0, n, step)]
+    return torch.cat(parts, 0).reshape(n_rays, S, 3) if parts else torch.empty(0, S, 3)
+
+
 def _reference_chunks(n_rays, options, mode, model_coarse, model_fine):
     """Ray-chunk partition of the reference (train_utils.py:228-235); only used to draw random numbers in its order."""
     chunk = _cfg(_cfg(options.nerf, mode), "chunksize")
@@ -254,23 +267,28 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
     if randoms is None:
         # same draws, same order as the reference: t_rand (train_utils.py:108), coarse noise (volume_rendering_utils.py:32),
         # u (nerf_helpers.py:683; only when perturb != 0), fine noise
+        for mdl in (model_coarse, model_fine):
+            mdl.set_cur_scene_id(scene_id)
         if m.perturb:
             r["t_rand"] = torch.rand([N, Nc])
+        r["jitter_coarse"] = _draw_point_jitter(model_coarse, N, Nc, m.chunksize)
         if std > 0.0:
             r["noise_coarse"] = torch.randn([N, Nc]) * std
         if Nf > 0:
             if m.perturb != 0.0:
                 r["u"] = torch.rand([N, Nf])
+            r["jitter_fine"] = _draw_point_jitter(model_fine, N, Nc + Nf, m.chunksize)
             if std > 0.0:
                 r["noise_fine"] = torch.randn([N, Nc + Nf]) * std
     t_rand, u, n_c, n_f = (None if r.get(k) is None else capi.f32c(r[k].to(dev)) for k in ("t_rand", "u", "noise_coarse", "noise_fine"))
+    jit_c, jit_f = (None if r.get(k) is None else capi.f32c(r[k].to(dev)).reshape(-1, 3) for k in ("jitter_coarse", "jitter_fine"))
     if not m.perturb:
         t_rand = None
 
     for mdl in (model_coarse, model_fine):
         mdl.set_cur_scene_id(scene_id)
     if not (model_coarse.is_native_geometry() and (Nf <= 0 or model_fine.is_native_geometry())):
-        return _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f)
+        return _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f, jit_c, jit_f)
     packed_c = model_coarse.packed_decoder()
     packed_f = model_fine.packed_decoder() if Nf > 0 else None
     top = model_fine if Nf > 0 else model_coarse
@@ -351,7 +369,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
 
 
-def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f):
+def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n_f, jit_c=None, jit_f=None):
     """predict_and_render_radiance for decoder geometries other than the shipped one, pass by pass like the reference (train_utils.py:95-180):
     depths -> run_network (the model's generic kernels on the [N*S,6] point list) -> compositing -> importance resampling -> again.
     With gradients enabled the model call and the compositing are the differentiable operators (the importance samples are detached,
@@ -369,12 +387,12 @@ def _render_generic(rays, model_coarse, model_fine, m, Nc, Nf, t_rand, u, n_c, n
         return nv.composite_rays(raw, z, rays, noise, white, want_weights)
 
     z_c = nv.coarse_z(rays, Nc, lindisp, t_rand)
-    raw = model_coarse(nv.ray_points(rays, z_c)).reshape(N, Nc, 4)
+    raw = model_coarse(nv.ray_points(rays, z_c), coord_noise=jit_c).reshape(N, Nc, 4)
     rgb_c, disp_c, acc_c, w_c = composite(raw, z_c, n_c, Nf > 0)
     rgb_f = disp_f = acc_f = None
     if Nf > 0:
         z_f = nv.importance_resample(z_c, w_c, Nf, u)
-        raw_f = model_fine(nv.ray_points(rays, z_f)).reshape(N, Nc + Nf, 4)
+        raw_f = model_fine(nv.ray_points(rays, z_f), coord_noise=jit_f).reshape(N, Nc + Nf, 4)
         rgb_f, disp_f, acc_f, _ = composite(raw_f, z_f, n_f, False)
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, None, None, None
 
@@ -486,7 +504,10 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
                      no_ndc=_cfg(scene_config, "no_ndc"))
     N = rays.shape[0]
     m = _cfg(options.nerf, mode)
-    if randoms is None and (m.perturb or float(m.radiance_field_noise_std) > 0.0):
+    for mdl in (model_coarse, model_fine):
+        mdl.set_cur_scene_id(scene_id)
+    jitters = bool(model_coarse.jitter_std() or (int(m.num_fine) > 0 and model_fine.jitter_std()))
+    if randoms is None and (m.perturb or float(m.radiance_field_noise_std) > 0.0 or jitters):
         # draw per reference ray chunk so that the CPU generator is consumed in the reference's order
         parts = []
         Nc, Nf, std = int(m.num_coarse), int(m.num_fine), float(m.radiance_field_noise_std)
@@ -495,10 +516,14 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
             p = {}
             if m.perturb:
                 p["t_rand"] = torch.rand([n, Nc])
+            if model_coarse.jitter_std():
+                p["jitter_coarse"] = _draw_point_jitter(model_coarse, n, Nc, m.chunksize)
             if std > 0.0:
                 p["noise_coarse"] = torch.randn([n, Nc]) * std
             if Nf > 0 and m.perturb != 0.0:
                 p["u"] = torch.rand([n, Nf])
+            if Nf > 0 and model_fine.jitter_std():
+                p["jitter_fine"] = _draw_point_jitter(model_fine, n, Nc + Nf, m.chunksize)
             if Nf > 0 and std > 0.0:
                 p["noise_fine"] = torch.randn([n, Nc + Nf]) * std
             parts.append(p)

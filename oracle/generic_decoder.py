@@ -2,9 +2,10 @@
 
 The C oracle (nvsr_oracle.c) covers the shipped geometry; this restates the general forward of the reference -- models.py:381-421 with
 normalize_coords :261-268, cart2az_el nerf_helpers.py:492-496, CoordProjector :495-497, project_xyz / project_viewdir :289-326
-(grid_sample bilinear, align_corners=True, padding_mode='border'), combine_pos_planes :355-361, combine_all_planes :363-379, the layer
-lists of the constructor :169-195 and is_skip_layer :203-207 -- for the checks of the generic HIP path (csrc/generic.hip).
-Pinned by tests/golden/g18_decoder_variants.npz (tests/test_oracle.py)."""
+(grid_sample bilinear, padding_mode='border', either align_corners), the training-mode jitter of the normalised positions :291-293, any
+number of position planes (CoordProjector's frames come with the state dict), combine_pos_planes :355-361, combine_all_planes :363-379,
+the layer lists of the constructor :169-195 and is_skip_layer :203-207 -- for the checks of the generic HIP path (csrc/generic.hip).
+Pinned by tests/golden/g18_decoder_variants.npz and g22_model_options.npz (tests/test_oracle.py)."""
 import numpy as np
 
 
@@ -13,13 +14,18 @@ def is_skip_layer(layer_num, skip_connect_every):
     return skip_connect_every is not None and layer_num % skip_connect_every == 0 and layer_num > 0
 
 
-def _bilinear(plane, gx, gy):
-    """F.grid_sample(plane[1,C,H,W], grid (x, y) in [-1,1], bilinear, align_corners=True, padding_mode='border') -> [P,C]
-    (ATen GridSamplerKernel: unnormalise, clip to [0, size-1], floor, the four taps with clamped indices)"""
+def _bilinear(plane, gx, gy, align_corners=True):
+    """F.grid_sample(plane[1,C,H,W], grid (x, y) in [-1,1], bilinear, padding_mode='border') -> [P,C]
+    (ATen GridSamplerKernel: unnormalise -- -1 / +1 are the corner texels' centres with align_corners, their outer edges without --,
+    clip to [0, size-1], floor, the four taps with clamped indices)"""
     C, H, W = plane.shape[-3:]
     p = plane.reshape(C, H, W).astype(np.float64)
-    x = np.clip((gx + 1.0) * 0.5 * (W - 1), 0.0, W - 1.0)
-    y = np.clip((gy + 1.0) * 0.5 * (H - 1), 0.0, H - 1.0)
+    if align_corners:
+        x, y = (gx + 1.0) * 0.5 * (W - 1), (gy + 1.0) * 0.5 * (H - 1)
+    else:
+        x, y = ((gx + 1.0) * W - 1.0) * 0.5, ((gy + 1.0) * H - 1.0) * 0.5
+    x = np.clip(x, 0.0, W - 1.0)
+    y = np.clip(y, 0.0, H - 1.0)
     x0, y0 = np.floor(x), np.floor(y)
     wx, wy = x - x0, y - y0
     x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
@@ -29,8 +35,9 @@ def _bilinear(plane, gx, gy):
 
 
 def decode(sd, planes, box, x, use_viewdirs=True, dec_density_layers=4, dec_rgb_layers=4, skip_connect_every=None, proj_combination="sum",
-           viewdir_proj_combination=None, prefix="", **_ignored):
-    """sd: state dict (numpy arrays, reference key names); planes: 4 arrays [1,C,R,R]; box [2,5]; x [P,6] = [xyz, viewdir] -> [P,4]"""
+           viewdir_proj_combination=None, prefix="", align_corners=True, coord_noise=None, **_ignored):
+    """sd: state dict (numpy arrays, reference key names); planes: the position planes then the view-direction plane, [1,C,R,R] each;
+    box [2,5]; x [P,6] = [xyz, viewdir] -> [P,4].  coord_noise [P,3]: the jitter a training-mode call adds to the normalised positions."""
     assert use_viewdirs
     if viewdir_proj_combination is None:
         viewdir_proj_combination = proj_combination
@@ -41,13 +48,16 @@ def decode(sd, planes, box, x, use_viewdirs=True, dec_density_layers=4, dec_rgb_
     x5 = np.concatenate([xyz, az[:, None], el[:, None]], 1).astype(np.float32)
     box = np.asarray(box, np.float64)
     lo, rng = box[0].astype(np.float32), (box[1] - box[0]).astype(np.float32)
-    n5 = (2 * (x5 - lo) / rng - 1).astype(np.float64)
-    pos = []
-    for dnum in range(3):
-        rot = np.asarray(sd[prefix + "coord_projector.rot_mats_NON_LEARNED.%d" % dnum], np.float64)
+    n5 = (2 * (x5 - lo) / rng - 1)
+    if coord_noise is not None:
+        n5[:, :3] = n5[:, :3] + np.asarray(coord_noise, np.float32)
+    n5 = n5.astype(np.float64)
+    pos, n_pos = [], len(planes) - 1
+    for dnum in range(n_pos):
+        rot = np.asarray(sd[prefix + "coord_projector.rot_mats_NON_LEARNED.%d" % dnum]).astype(np.float32).astype(np.float64)   # (.type(float32) in forward)
         g = n5[:, :3] @ rot[:, 1:]
-        pos.append(_bilinear(np.asarray(planes[dnum]), g[:, 0], g[:, 1]))
-    view = _bilinear(np.asarray(planes[3]), n5[:, 3], n5[:, 4])
+        pos.append(_bilinear(np.asarray(planes[dnum]), g[:, 0], g[:, 1], align_corners))
+    view = _bilinear(np.asarray(planes[n_pos]), n5[:, 3], n5[:, 4], align_corners)
 
     def combine_pos(ts):
         if proj_combination == "sum":

@@ -436,3 +436,137 @@ def test_f16_training_converges_like_bf16x3(hip):
     print("rendered PSNR against the ground-truth view before %s and after 150 iterations %s" % (first, final))
     assert abs(final["f16x2"] - final["bf16x3"]) <= 0.3, final
     assert min(final.values()) >= max(first.values()) + 0.5, (first, final)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# TwoDimPlanesModel options no shipped YAML sets (VERDICT r3 missing #4): through the generic kernels, against the reference (g22)
+# ---------------------------------------------------------------------------------------------------------------------------------
+G22_SID = "lego_DS8_PlRes9_5"
+
+
+def _g22_model(hip, g, name, n_planes=3, state_prefix=None, **over):
+    from test_oracle import G22_BOX, G22_KW
+    from test_hip_parity import T
+    pre = name + ".sd." if state_prefix is None else state_prefix
+    sd = {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+    rots = torch.nn.ParameterList([torch.nn.Parameter(torch.as_tensor(sd["coord_projector.rot_mats_NON_LEARNED.%d" % d])) for d in range(n_planes)])
+    kw = dict(G22_KW)
+    kw.update(over)
+    m = hip.models.TwoDimPlanesModel(use_viewdirs=True, num_planes_or_rot_mats=rots, **kw)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.planes_ = torch.nn.ParameterDict({hip.models.get_plane_name(G22_SID, d): torch.nn.Parameter(T(g["%s.plane%d" % (name, d)])) for d in range(n_planes + 1)})
+    m.box_coords = {G22_SID: torch.as_tensor(G22_BOX, dtype=torch.float64)}
+    m.set_cur_scene_id(G22_SID)
+    return m
+
+
+def _g22_check_forward_and_gradients(hip, g, name, m, n_planes, before_forward=lambda: None):
+    from test_hip_parity import N_, T
+    params = m.decoder_parameters()
+    plist = [m.planes_[hip.models.get_plane_name(G22_SID, d)] for d in range(n_planes + 1)]
+    for t_ in list(params) + plist:
+        t_.requires_grad_(True)
+    before_forward()
+    out = m(T(g[name + ".x"]))
+    ref = g[name + ".out"]
+    np.testing.assert_allclose(N_(out), ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=name)
+    (out * T(g[name + ".gout"])).sum().backward()
+    gnat, refn = np.concatenate([N_(t_.grad).reshape(-1) for t_ in params]), g[name + ".gnat"]
+    assert gnat.shape == refn.shape and np.linalg.norm(gnat - refn) / np.linalg.norm(refn) < 2e-5, name
+    np.testing.assert_allclose(gnat, refn, rtol=0, atol=3e-5 * float(np.abs(refn).max()), err_msg=name + " decoder")
+    for d in range(n_planes + 1):
+        got, refp = N_(plist[d].grad), g[name + ".gplane%d" % d]
+        assert got.shape == refp.shape and np.linalg.norm(got - refp) / np.linalg.norm(refp) < 2e-5, (name, d)
+        np.testing.assert_allclose(got, refp, rtol=0, atol=3e-5 * float(np.abs(refp).max()), err_msg="%s plane %d" % (name, d))
+
+
+def test_grid_sample_without_align_corners_vs_reference(hip):
+    """TwoDimPlanesModel(align_corners=False) (models.py:303-309,320-326: -1 / +1 are the outer edges of the corner texels): forward and the
+    gradients of planes and decoder against the reference's own (g22); not a geometry of the MFMA kernels -> the generic kernels"""
+    from conftest import load_golden
+    g = load_golden("g22_model_options.npz")
+    m = _g22_model(hip, g, "align_false", align_corners=False, dec_channels=64)
+    assert not m.is_native_geometry()
+    _g22_check_forward_and_gradients(hip, g, "align_false", m, 3)
+    # the same model with align_corners=True answers differently by far more than the tolerance
+    m2 = _g22_model(hip, g, "align_false", align_corners=True, dec_channels=64)
+    from test_hip_parity import N_, T
+    with torch.no_grad():
+        assert np.abs(N_(m2(T(g["align_false.x"]))) - g["align_false.out"]).max() > 1e-3
+
+
+def test_five_position_planes_with_random_frames_vs_reference(hip):
+    """num_planes_or_rot_mats = 5 (models.py:140,471-490): CoordProjector's random orthonormal frames (the reference's, from the fixture),
+    'avg' over five planes for the density decoder, 'concat_pos' of five planes + the view plane for the colour decoder: forward and
+    gradients of all six planes and of the decoder against the reference's (g22), and an eval_nerf render of a coarse / fine pair"""
+    from conftest import load_golden
+    from test_hip_parity import N_, T, make_options, psnr
+    g = load_golden("g22_model_options.npz")
+    m = _g22_model(hip, g, "planes5", n_planes=5, dec_channels=64)
+    assert m.num_density_planes == 5 and not m.is_native_geometry()
+    _g22_check_forward_and_gradients(hip, g, "planes5", m, 5)
+    mc = _g22_model(hip, g, "planes5", n_planes=5, state_prefix="planes5.render.coarse.", dec_channels=64)
+    mf = _g22_model(hip, g, "planes5", n_planes=5, state_prefix="planes5.render.fine.", dec_channels=64)
+    mf.planes_ = mc.planes_
+    H, W, focal = int(g["planes5.render.hwf"][0]), int(g["planes5.render.hwf"][1]), float(g["planes5.render.hwf"][2])
+    pose = load_golden("g18_decoder_variants.npz")["pose"]
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(pose))
+    opts, scfg = make_options(16, 16)
+    rgb_c, _, _, rgb_f, *_ = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=G22_SID, scene_config=scfg)
+    np.testing.assert_allclose(N_(rgb_c), g["planes5.render.rgb_coarse"], rtol=0, atol=3e-5)
+    ef = np.abs(N_(rgb_f) - g["planes5.render.rgb_fine"]).max(-1)
+    assert (ef <= 2e-4).mean() >= 0.95 and psnr(N_(rgb_f), g["planes5.render.rgb_fine"]) >= 70.0, ((ef <= 2e-4).mean(), ef.max())
+    # more planes than the scene struct holds: refused loudly
+    with pytest.raises((NotImplementedError, AssertionError)):
+        hip.models.TwoDimPlanesModel(use_viewdirs=True, num_planes_or_rot_mats=16, proj_combination="avg",
+                                     viewdir_proj_combination="concat_pos").generic_geometry()
+
+
+def test_point_coords_noise_vs_reference(hip):
+    """point_coords_noise (models.py:291-293): a training-mode forward adds N(0, (noise * 2 / (1 + plane resolution))^2) to the normalised
+    sample positions, drawn by torch.normal from the CPU generator.  (a) one seeded model call: the jitter drawn here is the reference's,
+    output and gradients are the reference's (g22); evaluation mode does not jitter and runs the MFMA kernels; (b) one training iteration
+    through run_one_iter_of_nerf over three ray chunks and 44 network batches per chunk, with perturbed depths and density noise: every
+    random tensor is drawn in the reference's order, so the rendered colours and the plane gradients are the reference's."""
+    from conftest import load_golden
+    from test_hip_parity import N_, T, Opt
+    g = load_golden("g22_model_options.npz")
+    pcn = float(g["noise.point_coords_noise"])
+    m = _g22_model(hip, g, "noise", point_coords_noise=pcn)
+    assert m.is_native_geometry() and m.jitter_std() == 0.0               # evaluation mode: no jitter, the shipped geometry
+    m.train()
+    assert not m.is_native_geometry() and abs(m.jitter_std() - float(g["noise.std"])) < 1e-12
+    torch.manual_seed(2231)
+    np.testing.assert_array_equal(N_(torch.normal(mean=0, std=m.jitter_std(), size=[g["noise.x"].shape[0], 3])), g["noise.jitter"])
+    _g22_check_forward_and_gradients(hip, g, "noise", m, 3, before_forward=lambda: torch.manual_seed(2231))
+    m.eval()
+    with torch.no_grad():
+        clean = N_(m(T(g["noise.x"])))
+    assert np.abs(clean - g["noise.out"]).max() > 1e-3                    # (the jitter is no rounding matter)
+
+    # (b) a training iteration
+    nc, nf, std, chunk, H, W, focal = (float(v) for v in g["noise.train.params"])
+    nc, nf, chunk, H, W = int(nc), int(nf), int(chunk), int(H), int(W)
+    mc = _g22_model(hip, g, "noise", state_prefix="noise.train.coarse.", point_coords_noise=pcn)
+    mf = _g22_model(hip, g, "noise", state_prefix="noise.train.fine.", point_coords_noise=pcn)
+    mf.planes_ = mc.planes_
+    mode = Opt(chunksize=chunk, perturb=True, num_coarse=nc, num_fine=nf, white_background=False, radiance_field_noise_std=std, lindisp=False)
+    opts, scfg = Opt(nerf=Opt(use_viewdirs=True, train=mode, validation=mode)), Opt(near=2.0, far=6.0, no_ndc=True)
+    mc.train(); mf.train()
+    plist = [mc.planes_[hip.models.get_plane_name(G22_SID, d)] for d in range(4)]
+    for t_ in plist:
+        t_.requires_grad_(True)
+    torch.manual_seed(2233)
+    np.random.seed(2233)
+    rc, _, _, rf, *_ = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, T(g["noise.train.rays"]), opts, G22_SID, mode="train", scene_config=scfg)
+    np.testing.assert_allclose(N_(rc), g["noise.train.rgb_coarse"], rtol=0, atol=3e-5)
+    ef = np.abs(N_(rf) - g["noise.train.rgb_fine"]).max(-1)
+    assert (ef <= 2e-4).mean() >= 0.95, ((ef <= 2e-4).mean(), ef.max())
+    target = T(g["noise.train.target"])
+    loss = torch.nn.functional.mse_loss(rc, target) + torch.nn.functional.mse_loss(rf, target)
+    assert abs(float(loss.detach()) - float(g["noise.train.loss"])) < 2e-4
+    loss.backward()
+    for d in range(4):
+        got, ref = N_(plist[d].grad), g["noise.train.grad_plane%d" % d]
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-2, (d, np.linalg.norm(got - ref) / np.linalg.norm(ref))    # (g11's bar)

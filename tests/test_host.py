@@ -360,10 +360,26 @@ def test_single_member_ensemble_draw_leaves_numpy_stream_alone():
     np.testing.assert_array_equal(a, b)
 
 
-def test_point_coords_noise_is_refused(pkg):
-    """models.py:291-293 jitters the coordinates in training; not implemented natively -> loud, not silently ignored"""
-    with pytest.raises(NotImplementedError):
-        pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", point_coords_noise=0.01)
+def test_point_coords_noise_moves_training_off_the_fused_kernels(pkg):
+    """models.py:291-293 jitters the sample positions of a training-mode forward.  The MFMA kernels compute the positions themselves and take
+    no jitter, so such a model is not their geometry while it trains (it runs the generic kernels, which take the jitter as an input:
+    tests/test_hip_round4.py::test_point_coords_noise_vs_reference) and is again once it evaluates; the std follows the scene id's plane
+    resolution like the reference's"""
+    m = pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", point_coords_noise=0.5)
+    m.cur_id = "lego_DS8_PlRes200_32"
+    m.eval()
+    assert m.is_native_geometry() and m.jitter_std() == 0.0
+    m.train()
+    assert not m.is_native_geometry() and m.jitter_std() == 0.5 * 2 / 201
+    plain = pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos").train()
+    plain.cur_id = m.cur_id
+    assert plain.is_native_geometry() and plain.jitter_std() == 0.0
+    # the draws of a pass: one torch.normal per network batch of `chunksize` points, in order (train_utils.py:47-58)
+    torch.manual_seed(5)
+    got = pkg.train_utils._draw_point_jitter(m, 3, 5, 4)          # 15 points in batches of 4, 4, 4, 3
+    torch.manual_seed(5)
+    ref = torch.cat([torch.normal(mean=0, std=m.jitter_std(), size=[n, 3]) for n in (4, 4, 4, 3)], 0).reshape(3, 5, 3)
+    assert torch.equal(got, ref) and pkg.train_utils._draw_point_jitter(plain, 3, 5, 4) is None
 
 
 def test_plane_cache_evicts_dead_sources_and_sr_planes(pkg):
@@ -455,3 +471,23 @@ def test_sample_key_is_the_specified_hash(pkg):
     s1, c1, s2, c2 = 0, A, B, 0                      # 0 * A + A * B == B * A + 0 * B  (mod 2^64)
     assert (s1 * A + c1 * B) & M == (s2 * A + c2 * B) & M
     assert int(lib.nvsr_sample_key(s1, c1 & M)) != int(lib.nvsr_sample_key(s2, c2))
+
+
+def test_random_plane_frames_are_the_references(pkg):
+    """CoordProjector(N > 3) (models.py:471-490) draws from NumPy's global generator with the reference's calls in the reference's order: the
+    five frames of a construction seeded like the fixture's are the reference's frames bit for bit (g22), orthonormal, in float64"""
+    from conftest import load_golden
+    g = load_golden("g22_model_options.npz")
+    np.random.seed(int(g["planes5.np_seed"]))
+    proj = pkg.models.CoordProjector(5)
+    assert len(proj.rot_mats_NON_LEARNED) == 5
+    for d in range(5):
+        r = proj.rot_mats_NON_LEARNED[d].detach().numpy()
+        assert r.dtype == np.float64
+        np.testing.assert_array_equal(r, g["planes5.rot%d" % d])
+        np.testing.assert_allclose(r.T @ r, np.eye(3), atol=1e-12)
+    # up to three planes: the standard basis and its two permutations, no random draw
+    state = np.random.get_state()[1].copy()
+    three = pkg.models.CoordProjector(3)
+    assert (np.random.get_state()[1] == state).all()
+    assert torch.equal(three.rot_mats_NON_LEARNED[1].detach(), torch.eye(3)[:, [1, 0, 2]])

@@ -371,3 +371,37 @@ def test_generic_decoder_restatement_vs_reference():
         ref = g[name + ".out"]
         assert out.shape == ref.shape
         np.testing.assert_allclose(out, ref, rtol=0, atol=5e-6 * max(1.0, float(np.abs(ref).max())), err_msg=name)
+
+
+G22_KW = dict(skip_connect_every=3, proj_combination="avg", viewdir_proj_combination="concat_pos")
+G22_BOX = np.array([[-4.0, -4.0, -4.0, -np.pi, -np.pi / 2], [4.0, 4.0, 4.0, np.pi, np.pi / 2]], np.float64)
+
+
+def g22_variant(g, name, n_planes=3):
+    sd = {k[len(name) + 4:]: v for k, v in g.items() if k.startswith(name + ".sd.")}
+    planes = [g["%s.plane%d" % (name, d)] for d in range(n_planes + 1)]
+    return sd, planes
+
+
+def test_generic_decoder_restatement_of_the_unshipped_options():
+    """oracle/generic_decoder.py against the reference's outputs (g22) for the TwoDimPlanesModel options no shipped YAML sets:
+    grid_sample(align_corners=False), five position planes with CoordProjector's random frames, and the training-mode jitter of the
+    sample positions (point_coords_noise; the fixture holds the jitter the seeded reference call drew)"""
+    from oracle.generic_decoder import decode
+    g = load_golden("g22_model_options.npz")
+    for name, n_planes, extra in (("align_false", 3, dict(align_corners=False)), ("planes5", 5, {}), ("noise", 3, dict(coord_noise=g["noise.jitter"]))):
+        sd, planes = g22_variant(g, name, n_planes)
+        out = decode(sd, planes, G22_BOX, g[name + ".x"], **G22_KW, **extra)
+        ref = g[name + ".out"]
+        np.testing.assert_allclose(out, ref, rtol=0, atol=5e-6 * max(1.0, float(np.abs(ref).max())), err_msg=name)
+    # the options change the result by far more than the tolerance (the test above would not notice an ignored option otherwise)
+    sd, planes = g22_variant(g, "align_false")
+    assert np.abs(decode(sd, planes, G22_BOX, g["align_false.x"], **G22_KW) - g["align_false.out"]).max() > 1e-3
+    sd, planes = g22_variant(g, "noise")
+    assert np.abs(decode(sd, planes, G22_BOX, g["noise.x"], **G22_KW) - g["noise.out"]).max() > 1e-3
+    assert abs(float(g["noise.jitter"].std()) / float(g["noise.std"]) - 1) < 0.15
+    # the frames CoordProjector drew are orthonormal, and no two planes share a normal
+    rots = [g["planes5.rot%d" % d] for d in range(5)]
+    for r in rots:
+        np.testing.assert_allclose(r.T @ r, np.eye(3), atol=1e-12)
+    assert max(abs(float(rots[i][:, 0] @ rots[j][:, 0])) for i in range(5) for j in range(i)) < 0.99
