@@ -386,13 +386,14 @@ class TwoDimPlanesModel(nn.Module):
             hit = _cache_plane(name, src)
         return hit[2]
 
-    def training_planes(self, rays):
+    def training_planes(self, rays, normalized_points=None):
         """The NCHW tensors a training step samples, as autograd sees them: the raw plane parameters, or -- where a plane is
         super-resolved -- the output of PlanesSR on the region of interest the batch covers (models.py:270-284: the reference takes
         the ROI of every point chunk; the bounding box of the ray segments [near, far] contains all of them, and the super-resolved
-        values do not depend on the ROI).  rays: packed [N,11]."""
+        values do not depend on the ROI).  rays: packed [N,11]; or normalized_points [P,3]: the normalised (and jittered) positions of a
+        model call, whose own bounding box is the ROI like in the reference."""
         names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
-        out, n_ends = [], None
+        out, n_ends = [], normalized_points
         for d, name in enumerate(names):
             if not (d < self.num_density_planes and self._should_SR(name)):
                 out.append(self.planes_[name])
@@ -406,7 +407,7 @@ class TwoDimPlanesModel(nn.Module):
                 lo, rng = box[0, :3].float(), (box[1, :3] - box[0, :3]).float()
                 ends = torch.cat([rays[:, 0:3] + rays[:, 3:6] * rays[:, 6:7], rays[:, 0:3] + rays[:, 3:6] * rays[:, 7:8]], 0)
                 n_ends = 2 * (ends - lo) / rng - 1
-            m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().to(rays.device)[:, 1:]
+            m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().to(n_ends.device)[:, 1:]
             grid = n_ends @ m                                         # [2N, (x, y)]
             gmin, gmax = grid.min(0)[0], grid.max(0)[0]
             roi = torch.stack([torch.stack([gmin[1], gmin[0]]), torch.stack([gmax[1], gmax[0]])], 0)   # rows (min, max), cols (y, x)
@@ -426,12 +427,18 @@ class TwoDimPlanesModel(nn.Module):
         if torch.is_grad_enabled():                                    # (like any torch module: a graph whenever gradients are on)
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
             dec = any(p.requires_grad for p in self.decoder_parameters())
-            if dec or any(self.planes_[n].requires_grad for n in names):
-                if hasattr(self, "SR_model") and not self.skip_SR_:
-                    raise NotImplementedError("training THROUGH super-resolved planes is implemented for the shipped decoder geometry only")
+            sr_on = hasattr(self, "SR_model") and not self.skip_SR_
+            sr_grad = sr_on and self.SR_model.training and self.SR_model.inner_model.wants_grad(*self.SR_model.LR_planes.values())
+            if dec or sr_grad or any(n in self.planes_ and self.planes_[n].requires_grad for n in names):
                 if self.training:
                     np.random.randint(self.ensemble_size)             # models.py:393 (see forward())
-                planes = [self.planes_[n] for n in names]
+                if sr_on:
+                    # training THROUGH super-resolved planes (models.py:270-284): PlanesSR on the region the call's points cover, as part of the graph
+                    box = self.box_coords[self.cur_id + ""].to(x.device)
+                    n = 2 * (x[:, :3] - box[0, :3].float()) / (box[1, :3] - box[0, :3]).float() - 1
+                    planes = self.training_planes(None, normalized_points=n if coord_noise is None else n + coord_noise)
+                else:
+                    planes = [self.planes_[n] for n in names]
                 return _GenericDecodeFn.apply(self, x, self.natural_blob(differentiable=True) if dec else None, coord_noise, *planes)
         if hasattr(self, "SR_model") and not self.skip_SR_:
             names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]

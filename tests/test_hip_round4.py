@@ -570,3 +570,77 @@ def test_point_coords_noise_vs_reference(hip):
     for d in range(4):
         got, ref = N_(plist[d].grad), g["noise.train.grad_plane%d" % d]
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-2, (d, np.linalg.norm(got - ref) / np.linalg.norm(ref))    # (g11's bar)
+
+
+def test_training_through_super_resolved_planes_on_a_generic_geometry(hip, oracle):
+    """models.py:270-284 for a decoder geometry the MFMA kernels are not compiled for (dec_channels 64, 'sum' + 'concat_pos'): a training-mode
+    model call super-resolves the region its points cover as part of the graph, and backward() reaches the EDSR weights and the LR planes.
+    Checked without any backward oracle: the directional derivative of sum(out * G) along a random direction of the SR weights (and of one LR
+    plane), by central differences of the FORWARD oracles (C planes_sr + the float64 decoder restatement), against <gradient, direction>."""
+    from oracle.generic_decoder import decode
+    from test_hip_parity import N_, T
+    from test_oracle import G22_BOX
+    rng = np.random.default_rng(71)
+    R, Rv, hid, nb, C_ = 20, 6, 16, 2, 48
+    kw = dict(skip_connect_every=3, proj_combination="sum", viewdir_proj_combination="concat_pos")
+    torch.manual_seed(8)
+    m = hip.models.TwoDimPlanesModel(use_viewdirs=True, dec_channels=64, **kw).to(DEV)
+    sid = "lego_DS8_PlRes20_6"
+    planes = [rng.standard_normal((1, C_, R, R), dtype=np.float32) * 0.5 for _ in range(3)] + [rng.standard_normal((1, C_, Rv, Rv), dtype=np.float32) * 0.5]
+    m.planes_ = torch.nn.ParameterDict({hip.models.get_plane_name(sid, d): torch.nn.Parameter(T(planes[d])) for d in range(4)})
+    m.box_coords = {sid: torch.as_tensor(G22_BOX, dtype=torch.float64)}
+    m.set_cur_scene_id(sid)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, C_, C_, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    m.assign_SR_model(sr, SR_viewdir=False)
+    m.assign_LR_planes()
+    assert not m.is_native_geometry()
+    for p_ in list(m.decoder_parameters()) + list(m.planes_.values()):
+        p_.requires_grad_(False)
+    lr_names = [hip.models.get_plane_name(sid, d) for d in range(3)]
+    for n_ in lr_names:
+        sr.LR_planes[n_].requires_grad_(True)
+    m.train(); sr.train()
+    P = 300
+    x = np.concatenate([rng.uniform(-1.5, 2.0, (P, 3)), rng.standard_normal((P, 3))], 1).astype(np.float32)     # a sub-box: the ROI is partial
+    G = rng.standard_normal((P, 4)).astype(np.float32)
+    out = m(T(x))
+    (out * T(G)).sum().backward()
+    got_w = np.concatenate([N_(w.grad).reshape(-1) for w in sr.inner_model.conv_weights()]).astype(np.float64)
+    got_lr = N_(sr.LR_planes[lr_names[1]].grad).astype(np.float64)
+    assert np.isfinite(got_w).all() and np.abs(got_w).max() > 0 and np.isfinite(got_lr).all() and np.abs(got_lr).max() > 0
+
+    # ---- forward oracle of the same call as a function of (SR weight blob, LR plane 1)
+    blob0 = np.concatenate([N_(w).reshape(-1) for w in sr.inner_model.conv_weights()])
+    pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+    sd_ = {k: N_(v) for k, v in m.state_dict().items() if "planes_" not in k and "SR_model" not in k}
+    lo, rng_ = G22_BOX[0, :3].astype(np.float32), (G22_BOX[1, :3] - G22_BOX[0, :3]).astype(np.float32)
+    n3 = (2 * (x[:, :3] - lo) / rng_ - 1).astype(np.float32)
+    rois = []
+    for d in range(3):
+        grid = n3 @ N_(m.coord_projector.rot_mats_NON_LEARNED[d]).astype(np.float32)[:, 1:]
+        rois.append(np.array([[grid[:, 1].min(), grid[:, 0].min()], [grid[:, 1].max(), grid[:, 0].max()]], np.float32))
+
+    def loss(blob, lr1):
+        hr = []
+        for d in range(3):
+            lr_d = lr1 if d == 1 else planes[d][0]
+            h = oracle.planes_sr(lr_d, blob.astype(np.float32), hid, nb, 2, pad, over, roi=rois[d])
+            assert np.isnan(h).any()                                  # the ROI path
+            hr.append(np.nan_to_num(h)[None])
+        o = decode(sd_, hr + [planes[3]], G22_BOX, x, dec_channels=64, **kw)
+        return float((o * G.astype(np.float64)).sum())
+
+    o0 = decode(sd_, [np.nan_to_num(oracle.planes_sr(planes[d][0], blob0, hid, nb, 2, pad, over, roi=rois[d]))[None] for d in range(3)] + [planes[3]],
+                G22_BOX, x, dec_channels=64, **kw)
+    np.testing.assert_allclose(N_(out), o0, rtol=0, atol=3e-5 * max(1.0, float(np.abs(o0).max())))
+    dw = rng.standard_normal(blob0.shape) * np.abs(blob0).mean()
+    eps = 2e-4                 # (the loss is piecewise linear in the weights -- ReLUs in the SR network and the decoder --: central differences across
+                               #  kinks carry an O(eps) error; 2e-2 ... 1e-3 scatter by 3 %, 2e-4 is within 0.3 % of the gradient)
+    fd_w = (loss(blob0 + eps * dw, planes[1][0]) - loss(blob0 - eps * dw, planes[1][0])) / (2 * eps)
+    assert abs(fd_w - got_w @ dw) <= 2e-2 * abs(fd_w) + 1e-6, (fd_w, got_w @ dw)
+    dl = rng.standard_normal(planes[1][0].shape).astype(np.float32) * 0.5
+    fd_l = (loss(blob0, planes[1][0] + np.float32(eps) * dl) - loss(blob0, planes[1][0] - np.float32(eps) * dl)) / (2 * eps)
+    assert abs(fd_l - (got_lr.reshape(-1) @ dl.reshape(-1).astype(np.float64))) <= 2e-2 * abs(fd_l) + 1e-6, (fd_l, got_lr.reshape(-1) @ dl.reshape(-1))
