@@ -297,6 +297,11 @@ int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed
  * bilinear_x{sf}(lr) inside the ROI, NaN outside.  roi: NULL = full plane, else 4 HOST floats [[ymin,xmin],[ymax,xmax]] in [-1,1]
  * (models.py:278-279).  pad = EDSR.required_padding, over = HR_overpadding (models.py:836-842).  mean/std: optional [C] device
  * vectors (planes_{mean,std}_NON_LEARNED). */
+/* align_corners of the bilinear residual F.interpolate(LR, scale_factor, 'bilinear', align_corners) (models.py:858-859; PlanesSR.align_corners
+ * is the planes model's, :222): library state like the conv arithmetic, 1 (every shipped config) unless set; read by every nvsr_planes_sr*
+ * call (forward and backward) when it is launched.  A binding with models of both kinds sets it before each call (ops.py does). */
+int nvsr_set_sr_align_corners(int align_corners);
+int nvsr_get_sr_align_corners(void);
 int64_t nvsr_planes_sr_workspace_floats(int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi);
 int nvsr_planes_sr(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* std_, float* out, float* workspace, nvsr_stream_t stream);

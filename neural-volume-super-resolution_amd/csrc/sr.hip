@@ -793,21 +793,18 @@ __global__ void sr_prepare_kernel(const float* __restrict__ lr, int Cc, int R0, 
 }
 
 // PlanesSR output (models.py:915-923): canvas = NaN; canvas[roi] = difference[over:-over] + bilinear_x{sf}(LR)[roi]
-// (F.interpolate(mode='bilinear', align_corners=True), :858-859)
+// (F.interpolate(mode='bilinear', align_corners=PlanesSR.align_corners), :858-859)
 __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo, int over, const float* __restrict__ lr, int Cc, int R0,
-                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out, unsigned* __restrict__ flag) {
+                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out, unsigned* __restrict__ flag, int align) {
     const int HR0 = R0 * sf, HR1 = R1 * sf;
     const long n = (long)Cc * HR0 * HR1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int ox = (int)(i % HR1), oy = (int)((i / HR1) % HR0), c = (int)(i / ((long)HR1 * HR0));
     if (oy < lo0 * sf || oy >= hi0 * sf || ox < lo1 * sf || ox >= hi1 * sf) { out[i] = __builtin_nanf(""); return; }
-    const float sh = HR0 > 1 ? (float)(R0 - 1) / (float)(HR0 - 1) : 0.0f;
-    const float sw = HR1 > 1 ? (float)(R1 - 1) / (float)(HR1 - 1) : 0.0f;
-    const float fy = sh * (float)oy, fx = sw * (float)ox;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int yp = (y0 < R0 - 1) ? 1 : 0, xp = (x0 < R1 - 1) ? 1 : 0;
-    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    const BilinearTap ty = bilinear_tap(oy, R0, HR0, sf, align), tx = bilinear_tap(ox, R1, HR1, sf, align);
+    const int y0 = ty.i0, x0 = tx.i0, yp = ty.step, xp = tx.step;
+    const float ly1 = ty.w1, ly0 = 1.0f - ly1, lx1 = tx.w1, lx0 = 1.0f - lx1;
     const float* q = lr + ((long)c * R0 + y0) * R1 + x0;
     const float res = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * R1] + lx1 * q[(long)yp * R1 + xp]);
     const int dy = oy - lo0 * sf + over, dx = ox - lo1 * sf + over;
@@ -817,6 +814,12 @@ __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo,
     // the network beyond the static scales (flag = NULL in every other arithmetic)
     if (flag && !(fabsf(v) <= 3.0e38f)) __hip_atomic_fetch_or(flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (bit 1: the SR network)
 }
+
+// align_corners of the bilinear residual (process-wide, like the conv arithmetic): 1 unless a binding says otherwise
+static int g_sr_align_corners = 1;
+int sr_align_corners() { return g_sr_align_corners; }
+extern "C" int nvsr_set_sr_align_corners(int align_corners) { g_sr_align_corners = align_corners ? 1 : 0; return NVSR_OK; }
+extern "C" int nvsr_get_sr_align_corners(void) { return g_sr_align_corners; }
 
 // arithmetic of the eligible conv layers (process-wide): -1 = not yet read from the environment
 static int g_conv_arithmetic = -1;
@@ -1264,7 +1267,8 @@ int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, in
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
-                           Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b], conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr);
+                           Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b], conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr,
+                           sr_align_corners());
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
     return NVSR_OK;
@@ -1335,7 +1339,7 @@ static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* 
     } else if (int e = nvsr_edsr_forward_batch_arith(xin, 1, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, arithmetic, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
-                       lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr);
+                       lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr, sr_align_corners());
     return NVSR_CHECK_LAUNCH();
 }
 

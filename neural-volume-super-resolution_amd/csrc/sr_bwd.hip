@@ -516,7 +516,7 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ g, int Cc, int 
 // PlanesSR backward, output side (models.py:915-923): d_out [C][sf R0][sf R1] -> d_diff [C][Ho][Wo] (zero in the over-padding
 // ring) and, when d_lr != NULL, the bilinear residual's share of d_lr (4 float atomics per HR pixel of the ROI)
 __global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int Cc, int R0, int R1, int sf, int lo0, int lo1, int hi0, int hi1,
-                                          int Ho, int Wo, int over, float* __restrict__ d_diff, float* __restrict__ d_lr) {
+                                          int Ho, int Wo, int over, float* __restrict__ d_diff, float* __restrict__ d_lr, int align) {
     const long n = (long)Cc * Ho * Wo;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -529,12 +529,9 @@ __global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int C
     const float g = d_out[((long)c * HR0 + oy) * HR1 + ox];
     d_diff[i] = g;
     if (!d_lr) return;
-    const float sh = HR0 > 1 ? (float)(R0 - 1) / (float)(HR0 - 1) : 0.0f;
-    const float sw = HR1 > 1 ? (float)(R1 - 1) / (float)(HR1 - 1) : 0.0f;
-    const float fy = sh * (float)oy, fx = sw * (float)ox;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int yp = (y0 < R0 - 1) ? 1 : 0, xp = (x0 < R1 - 1) ? 1 : 0;
-    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    const BilinearTap ty = bilinear_tap(oy, R0, HR0, sf, align), tx = bilinear_tap(ox, R1, HR1, sf, align);
+    const int y0 = ty.i0, x0 = tx.i0, yp = ty.step, xp = tx.step;
+    const float ly1 = ty.w1, ly0 = 1.0f - ly1, lx1 = tx.w1, lx0 = 1.0f - lx1;
     float* q = d_lr + ((long)c * R0 + y0) * R1 + x0;
     unsafeAtomicAdd(q, g * ly0 * lx0);
     unsafeAtomicAdd(q + xp, g * ly0 * lx1);
@@ -793,7 +790,7 @@ int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, con
     float* dxin = d_diff + (n_diff + 3) / 4 * 4;
     float* ews = dxin + (n_in + 3) / 4 * 4;
     hipLaunchKernelGGL(sr_finish_backward_kernel, dim3((unsigned)((n_diff + 255) / 256)), dim3(256), 0, stream, d_out, Cc, R0, R1, sf, lo[0],
-                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr);
+                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr, sr_align_corners());
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     const float* xin = keep;
     const float* acts = keep + (n_in + 3) / 4 * 4;

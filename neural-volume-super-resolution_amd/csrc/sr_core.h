@@ -6,6 +6,28 @@
 
 namespace nvsr {
 
+// Source position of output index `o` of F.interpolate(mode='bilinear', scale_factor=sf) along an axis of `in` texels (ATen UpSample.h:
+// area_pixel_compute_source_index + guard_index_and_lambda): align_corners=True maps the first / last output onto the first / last input,
+// src = o (in - 1) / (out - 1); False maps pixel centres, src = (o + 0.5) / sf - 0.5, clamped at 0.  -> first tap i0, offset of the second
+// tap (0 at the last texel), weight of the second tap.
+struct BilinearTap { int i0, step; float w1; };
+__device__ __forceinline__ BilinearTap bilinear_tap(int o, int in, int out, int sf, int align) {
+    float src;
+    if (align) src = (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f) * (float)o;
+    else {
+        src = __fsub_rn(__fmul_rn((float)(1.0 / (double)sf), (float)o + 0.5f), 0.5f);
+        if (src < 0.0f) src = 0.0f;
+    }
+    BilinearTap t;
+    t.i0 = min((int)src, in - 1);
+    t.step = t.i0 < in - 1 ? 1 : 0;
+    t.w1 = fminf(fmaxf(src - (float)t.i0, 0.0f), 1.0f);
+    return t;
+}
+// process-wide: align_corners of PlanesSR's bilinear residual (sr.hip: nvsr_set_sr_align_corners)
+int sr_align_corners();
+
+
 // f16-limb data / weight gradients of the SR network: the power of two that puts the largest |dy| of a gradient tensor (its bits in
 // `absmax_bits`, absmax_kernel) into [2^12, 2^13).  Exponent field clamped to 254 (a tensor whose largest magnitude is below 2^-115 would
 // otherwise ask for a scale beyond the largest finite power of two); an all-zero or non-finite tensor is not scaled.

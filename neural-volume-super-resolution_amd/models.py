@@ -808,7 +808,7 @@ class PlanesSR(nn.Module):
         if len(todo) < 2 or (self.training and (self.input_noise > 0 or self.output_noise > 0)):
             return
         lrs = [capi.f32c(self.LR_planes[n].detach()) for n in todo]
-        if len({tuple(t.shape[-3:]) for t in lrs}) != 1 or not self.align_corners:
+        if len({tuple(t.shape[-3:]) for t in lrs}) != 1:
             return
         Cc, R0, R1 = lrs[0].shape[-3:]
         cin, cout, hid, nb, n_up = self.inner_model.geometry
@@ -819,7 +819,7 @@ class PlanesSR(nn.Module):
         if capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None) < 0:
             return
         outs = torch.ops.nvsr.planes_sr([t.reshape(Cc, R0, R1) for t in lrs], self.inner_model.packed_weights(), list(self.inner_model.geometry),
-                                        pad, over, None, mean, std, self.inner_model.arith())
+                                        pad, over, None, mean, std, self.inner_model.arith(), bool(self.align_corners))
         for n, o in zip(todo, outs):
             self.SR_planes[n] = o
 
@@ -854,8 +854,6 @@ class PlanesSR(nn.Module):
         differentiable = self.training and self.inner_model.wants_grad(lr_src)
         if plane_name in self.SR_planes and not differentiable:      # (a cached plane carries no graph: never serve it to a training step)
             return self.SR_planes[plane_name]
-        if not self.align_corners:
-            raise NotImplementedError("align_corners=False is not used by the planes model")
         noisy = self.training and (self.input_noise > 0 or self.output_noise > 0)
         noise_in = None
         if noisy and self.input_noise > 0:
@@ -883,10 +881,10 @@ class PlanesSR(nn.Module):
             net = self.inner_model
             out, _ = torch.ops.nvsr.planes_sr_train(lr_src if lr_src.dtype == torch.float32 else lr_src.float(), net.natural_blob(differentiable=True),
                                                     net.packed_weights(), net.packed_dgrad_weights(), geometry, pad, over, roi, mean, std,
-                                                    capi.resolve_conv_arithmetic(net.arithmetic))
+                                                    capi.resolve_conv_arithmetic(net.arithmetic), bool(self.align_corners))
             return self._apply_training_noise(out, noise_in, lr_clean) if noisy else out
         out = torch.ops.nvsr.planes_sr([lr.reshape(Cc, R0, R1)], self.inner_model.packed_weights(), geometry, pad, over, roi, mean, std,
-                                       self.inner_model.arith())[0]
+                                       self.inner_model.arith(), bool(self.align_corners))[0]
         if noisy:
             return self._apply_training_noise(out, noise_in, lr_clean)          # (like the reference, a noisy plane is never cached: training only)
         if full_plane:

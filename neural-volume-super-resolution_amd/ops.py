@@ -715,10 +715,10 @@ def _roi_c(roi):
 
 @custom_op("nvsr::planes_sr", mutates_args=(), device_types="cuda")
 def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad: int, over: int, roi: Optional[Sequence[float]],
-              mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int) -> List[Tensor]:
+              mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int, align_corners: bool = True) -> List[Tensor]:
     """PlanesSR.forward for B equally sized LR planes [C,R0,R1] in ONE batched pass: crop + replicate pad -> EDSR -> crop over-padding
-    -> + bilinear x sf of the LR plane, NaN outside the ROI.  roi: None (full plane) or [ymin, xmin, ymax, xmax] in [-1, 1].
-    -> B tensors [1,C,sf R0,sf R1]"""
+    -> + bilinear x sf of the LR plane (F.interpolate's align_corners as given), NaN outside the ROI.  roi: None (full plane) or
+    [ymin, xmin, ymax, xmax] in [-1, 1].  -> B tensors [1,C,sf R0,sf R1]"""
     lr = [_c(t) for t in lr]
     cin, cout, hid, nb, n_up = geometry
     B = len(lr)
@@ -731,6 +731,7 @@ def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad
     sf = 1 << n_up
     outs = [_f(1, Cc, R0 * sf, R1 * sf, like=lr[0]) for _ in lr]
     ws = _f(B * nws, like=lr[0])
+    capi.lib().nvsr_set_sr_align_corners(int(bool(align_corners)))       # (library state, like the conv arithmetic: set for the call that follows)
     if B == 1:
         capi.call("nvsr_planes_sr_arith", capi.ptr(lr[0]), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
                   capi.ptr(std), capi.ptr(outs[0]), capi.ptr(ws), arithmetic, capi.stream())
@@ -743,7 +744,7 @@ def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad
 
 
 @planes_sr.register_fake
-def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic):
+def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True):
     sf = 1 << geometry[4]
     Cc, R0, R1 = lr[0].shape[-3:]
     return [t.new_empty((1, Cc, R0 * sf, R1 * sf)) for t in lr]
@@ -751,7 +752,8 @@ def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic):
 
 @custom_op("nvsr::planes_sr_train", mutates_args=(), device_types="cuda")
 def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: Tensor, geometry: Sequence[int], pad: int, over: int,
-                    roi: Optional[Sequence[float]], mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int) -> Tuple[Tensor, Tensor]:
+                    roi: Optional[Sequence[float]], mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int,
+                    align_corners: bool = True) -> Tuple[Tensor, Tensor]:
     """planes_sr of one plane that keeps the prepared input + activation record (`keep`); differentiable in `lr` and `natural`"""
     lr = _c(lr)
     cin, cout, hid, nb, n_up = geometry
@@ -764,13 +766,14 @@ def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: T
         raise capi.NvsrError("PlanesSR: region of interest too small for the network")
     sf = 1 << n_up
     out, ws, keep = _f(1, Cc, R0 * sf, R1 * sf, like=lr), _f(nws, like=lr), _f(nkeep, like=lr)
+    lib.nvsr_set_sr_align_corners(int(bool(align_corners)))
     capi.call("nvsr_planes_sr_train_arith", capi.ptr(lr), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
               capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), arithmetic, capi.stream())
     return out, keep
 
 
 @planes_sr_train.register_fake
-def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic):
+def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True):
     cin, cout, hid, nb, n_up = geometry
     sf = 1 << n_up
     Cc, R0, R1 = lr.shape[-3:]
@@ -780,7 +783,8 @@ def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, ar
 
 @custom_op("nvsr::planes_sr_backward", mutates_args=(), device_types="cuda")
 def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence[int], geometry: Sequence[int], pad: int, over: int,
-                       roi: Optional[Sequence[float]], std: Optional[Tensor], d_out: Tensor, need_lr: bool, arithmetic: int) -> Tuple[Tensor, Tensor]:
+                       roi: Optional[Sequence[float]], std: Optional[Tensor], d_out: Tensor, need_lr: bool, arithmetic: int,
+                       align_corners: bool = True) -> Tuple[Tensor, Tensor]:
     """-> (EDSR weight gradients in state-dict order, d_lr [1,C,R0,R1] (empty unless need_lr))"""
     d_out = _c(d_out)
     cin, cout, hid, nb, n_up = geometry
@@ -790,13 +794,14 @@ def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence
     gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
     d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if need_lr else _f(0, like=keep)
     ws = _f(lib.nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c), like=keep)
+    lib.nvsr_set_sr_align_corners(int(bool(align_corners)))
     capi.call("nvsr_planes_sr_backward_arith", Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, roi_c, capi.ptr(std),
               capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr) if need_lr else None, capi.ptr(ws), arithmetic, capi.stream())
     return gnat, d_lr
 
 
 @planes_sr_backward.register_fake
-def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, need_lr, arithmetic):
+def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, need_lr, arithmetic, align_corners=True):
     cin, cout, hid, nb, n_up = geometry
     n = 9 * (hid * cin + (2 * nb + 1) * hid * hid + n_up * 4 * hid * hid + cout * hid)
     Cc, R0, R1 = plane_shape
@@ -804,18 +809,18 @@ def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, nee
 
 
 def _planes_sr_train_setup(ctx, inputs, output):
-    lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic = inputs
+    lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners = inputs
     ctx.save_for_backward(output[1], packed_dgrad, std)
     ctx.mark_non_differentiable(output[1])
-    ctx.args = (list(lr.shape[-3:]), list(geometry), pad, over, None if roi is None else list(roi), arithmetic, lr.shape)
+    ctx.args = (list(lr.shape[-3:]), list(geometry), pad, over, None if roi is None else list(roi), arithmetic, lr.shape, bool(align_corners))
 
 
 def _planes_sr_train_bwd(ctx, d_out, d_keep):
     keep, packed_dgrad, std = ctx.saved_tensors
-    shape, geometry, pad, over, roi, arithmetic, lr_shape = ctx.args
+    shape, geometry, pad, over, roi, arithmetic, lr_shape, align_corners = ctx.args
     gnat, d_lr = torch.ops.nvsr.planes_sr_backward(keep, packed_dgrad, shape, geometry, pad, over, roi, std, capi.f32c(d_out),
-                                                   ctx.needs_input_grad[0], arithmetic)
-    return ((d_lr.reshape(lr_shape) if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None)) + (None,) * 9
+                                                   ctx.needs_input_grad[0], arithmetic, align_corners)
+    return ((d_lr.reshape(lr_shape) if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None)) + (None,) * 10
 
 
 planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr_train_setup)

@@ -1169,7 +1169,8 @@ def g22_model_options():
                    the frames, forward, gradients, and an eval_nerf render (chunk size divided by 5/3, train_utils.py:229-230)
       noise        point_coords_noise (models.py:291-293) in training mode: the jitter drawn inside one model call (seeded), forward +
                    gradients; and run_one_iter_of_nerf(mode='train') with perturb + density noise over several ray chunks and network
-                   batches -- every random tensor in the order the reference draws it"""
+                   batches -- every random tensor in the order the reference draws it
+      sr_align_false  PlanesSR(align_corners=False): the bilinear residual F.interpolate(..., align_corners=False) (models.py:858-859)"""
     arrs = {}
     P = 157
 
@@ -1264,6 +1265,39 @@ def g22_model_options():
     arrs["noise.train.rgb_coarse"], arrs["noise.train.rgb_fine"], arrs["noise.train.loss"] = npy(rc), npy(rf), np.array(float(loss))
     for d in range(4):
         arrs["noise.train.grad_plane%d" % d] = npy(plist[d].grad)
+    # ---- PlanesSR with align_corners=False (models.py:858-859: assign_SR_model copies the planes model's flag) ------------------------
+    # the network of g09 / g14 (same seed -> same weights and LR plane): full plane in evaluation mode, then the ROI and the full plane in
+    # training mode with the gradients of the weights and of the (non-detached) LR plane.  Only the bilinear residual differs from g14.
+    torch.manual_seed(9)
+    C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+    sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bilinear")
+    sr.align_corners = False
+    with torch.no_grad():
+        for p in sr.parameters():
+            p.mul_(10.0)
+    lr = torch.randn(1, C, R, R) * 0.5
+    g9 = np.load(os.path.join(HERE, "g09_edsr.npz"))
+    assert np.array_equal(g9["lr"], npy(lr)), "the align_corners=False case must rebuild the g09 network"
+    sr.eval()
+    sr.set_LR_plane(lr, id="p", save_interpolated=False)
+    with torch.no_grad():
+        arrs["sr_align_false.full"] = npy(sr("p")).copy()
+    sr.train()
+    roi = torch.tensor([[-0.35, -0.6], [0.2, 0.15]])
+    arrs["sr_align_false.roi"] = npy(roi)
+    for tag, arg in (("roi", ("p", roi)), ("full", "p")):
+        lrp = nn.Parameter(lr.clone())
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lrp, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(arg)
+        Gp = torch.randn(out.shape, generator=torch.Generator().manual_seed(2290))
+        valid = ~torch.isnan(out)
+        (torch.where(valid, out, torch.zeros_like(out)) * Gp).sum().backward()
+        gw = np.concatenate([npy(p.grad).reshape(-1) for _, p in sr.inner_model.named_parameters()]).astype(np.float32)
+        arrs.update({"sr_align_false.%s_out" % tag: npy(out).copy(), "sr_align_false.%s_gout" % tag: npy(Gp), "sr_align_false.%s_gw" % tag: gw,
+                     "sr_align_false.%s_glr" % tag: npy(lrp.grad).copy()})
+        sr.clear_SR_planes(all_planes=True)
     save("g22_model_options.npz", **arrs)
 
 

@@ -644,3 +644,41 @@ def test_training_through_super_resolved_planes_on_a_generic_geometry(hip, oracl
     dl = rng.standard_normal(planes[1][0].shape).astype(np.float32) * 0.5
     fd_l = (loss(blob0, planes[1][0] + np.float32(eps) * dl) - loss(blob0, planes[1][0] - np.float32(eps) * dl)) / (2 * eps)
     assert abs(fd_l - (got_lr.reshape(-1) @ dl.reshape(-1).astype(np.float64))) <= 2e-2 * abs(fd_l) + 1e-6, (fd_l, got_lr.reshape(-1) @ dl.reshape(-1))
+
+
+def test_planes_sr_without_align_corners_vs_reference(hip):
+    """PlanesSR(align_corners=False) (models.py:858-859: the bilinear residual maps pixel centres): the full plane in evaluation mode, the ROI
+    and the full plane in training mode with the gradients of the EDSR weights and of the LR plane, against the reference's (g22, the network
+    of g09); a second PlanesSR with align_corners=True in the same process keeps answering g09's values (the flag is per call)"""
+    from conftest import load_golden
+    from test_hip_parity import N_, T, _rel, _sr_grad_blob, _sr_model
+    g9, g = load_golden("g09_edsr.npz"), load_golden("g22_model_options.npz")
+    sr, _ = _sr_model(hip, g9)
+    sr.align_corners = False
+    other, _ = _sr_model(hip, g9)
+    sr.eval(); other.eval()
+    sr.set_LR_plane(T(g9["lr"]), id="p", save_interpolated=False)
+    other.set_LR_plane(T(g9["lr"]), id="p", save_interpolated=False)
+    with torch.no_grad():
+        full = N_(sr("p"))
+        np.testing.assert_allclose(N_(other("p")), g9["sr_full"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(full, g["sr_align_false.full"], rtol=0, atol=1e-5)
+    assert np.abs(full - g9["sr_full"]).max() > 1e-2                   # (the option is no rounding matter)
+    sr.train()
+    for tag, roi in (("roi", T(g["sr_align_false.roi"])), ("full", None)):
+        lr = torch.nn.Parameter(T(g9["lr"]))
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lr, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(("p", roi)) if roi is not None else sr("p")
+        ref = g["sr_align_false.%s_out" % tag]
+        valid = ~torch.isnan(out)
+        assert np.array_equal(N_(valid), ~np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(N_(out)), np.nan_to_num(ref), rtol=0, atol=1e-5)
+        with torch.no_grad():
+            other.clear_SR_planes()
+            other("p")                                                # an align_corners=True call between this forward and its backward
+        (torch.where(valid, out, torch.zeros_like(out)) * T(g["sr_align_false.%s_gout" % tag])).sum().backward()
+        assert _rel(_sr_grad_blob(sr), g["sr_align_false.%s_gw" % tag]) < 2e-5, tag
+        assert _rel(N_(lr.grad), g["sr_align_false.%s_glr" % tag]) < 2e-5, tag
+        np.testing.assert_allclose(N_(lr.grad), g["sr_align_false.%s_glr" % tag], rtol=0, atol=2e-5 * np.abs(g["sr_align_false.%s_glr" % tag]).max())
