@@ -647,7 +647,13 @@ class _Residual_Block(nn.Module):
 
 class EDSR(nn.Module):
     """models.py:789-822.  Same constructor, `required_padding` arithmetic and state-dict keys; forward runs nvsr_edsr_forward
-    (MFMA implicit-GEMM convolutions with fused ReLU / residual / PixelShuffle epilogues)."""
+    (MFMA implicit-GEMM convolutions with fused ReLU / residual / PixelShuffle epilogues).
+
+    receptive_field_bound (models.py:793-798): a layer whose 3 x 3 kernel would push the receptive field beyond the bound is a 1 x 1
+    convolution.  The parameters keep the reference's shapes; the kernels run every layer as a 3 x 3 convolution, a 1 x 1 weight sitting in
+    the centre of a zero kernel.  Such a layer returns the true layer's output minus a one-texel border, so the network is fed `_extra_pad`
+    more texels of context per side (they meet zero weights only) and its output is cropped accordingly: same values, nine times the
+    arithmetic in those layers (no shipped config sets the option)."""
 
     def __init__(self, in_channels, out_channels, hidden_size, n_blocks, scale_factor, padding, receptive_field_bound=np.iinfo(np.int32).max,
                  **kwargs):
@@ -655,14 +661,17 @@ class EDSR(nn.Module):
         import math
         KERNEL_SIZE = 3
         self.required_padding, rf_factor = 0, 1
+        self._all3_padding = 0           # required_padding of the network the kernels run (every layer 3 x 3)
         if padding != 0:
             raise NotImplementedError("the SR kernels implement the un-padded convolutions PlanesSR uses (PADDING = 0, models.py:836)")
 
         def kernel_size(num_layers=1):
+            grow = rf_factor * num_layers * (KERNEL_SIZE // 2)
+            self._all3_padding += grow
             if (1 + 2 * (self.required_padding + rf_factor * num_layers * ((KERNEL_SIZE - 1) // 2))) <= receptive_field_bound:
-                self.required_padding += rf_factor * num_layers * (KERNEL_SIZE // 2)
+                self.required_padding += grow
                 return KERNEL_SIZE
-            raise NotImplementedError("receptive_field_bound falls back to 1x1 convolutions, which no shipped config uses")
+            return 1
 
         self.conv_input = nn.Conv2d(in_channels, hidden_size, kernel_size(), stride=1, padding=padding, bias=False)
         self.residual = nn.Sequential()
@@ -677,6 +686,11 @@ class EDSR(nn.Module):
         self.upscale = nn.Sequential(*upscaling_layers)
         self.conv_output = nn.Conv2d(hidden_size, out_channels, kernel_size(), stride=1, padding=padding, bias=False)
         self.geometry = (in_channels, out_channels, hidden_size, n_blocks, int(math.log2(scale_factor)))
+        # stand-alone forward: context the 3 x 3 stand-ins of the 1 x 1 layers consume, in input texels (rounded up; the rest is cropped from the
+        # output, a whole number of output texels because every increment is a multiple of 1 / scale_factor)
+        extra = self._all3_padding - self.required_padding
+        self._extra_pad = int(math.ceil(extra))
+        self._extra_crop = int(round((self._extra_pad - extra) * scale_factor))
         self._packed_cache = None
         self.arithmetic = None     # 'f32' | 'bf16x3' | None = the process default (capi.set_conv_arithmetic / NVSR_CONV_ARITHMETIC)
 
@@ -688,7 +702,8 @@ class EDSR(nn.Module):
     def arith(self):
         return capi.arith_code(self.arithmetic)
 
-    def conv_weights(self):
+    def conv_parameters(self):
+        """the convolution weights in state-dict order, as the reference shapes them (3 x 3 or 1 x 1)"""
         ws = [self.conv_input.weight]
         for blk in self.residual:
             ws += [blk.conv1.weight, blk.conv2.weight]
@@ -697,10 +712,15 @@ class EDSR(nn.Module):
         ws.append(self.conv_output.weight)
         return ws
 
+    def conv_weights(self):
+        """the 3 x 3 kernels the library runs: a 1 x 1 weight (receptive_field_bound) in the centre of a zero kernel -- differentiable, so a
+        gradient of the 3 x 3 blob reaches the 1 x 1 parameter through its centre tap"""
+        return [w if w.shape[-1] == 3 else torch.nn.functional.pad(w, (1, 1, 1, 1)) for w in self.conv_parameters()]
+
     def packed_weights(self):
-        ws = self.conv_weights()
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
         if self._packed_cache is None or self._packed_cache[0] != key:
+            ws = self.conv_weights()
             nat = torch.cat([w.detach().reshape(-1).float() for w in ws])
             capi.require_cuda(nat)
             self._packed_cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), False))
@@ -712,8 +732,7 @@ class EDSR(nn.Module):
 
     def packed_dgrad_weights(self):
         """fragments of every layer's data gradient (flipped, transposed kernels), cached like packed_weights()"""
-        ws = self.conv_weights()
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
         cache = getattr(self, "_packed_dgrad_cache", None)
         if cache is None or cache[0] != key:
             nat = self.natural_blob()
@@ -723,7 +742,7 @@ class EDSR(nn.Module):
         return cache[1]
 
     def wants_grad(self, *inputs):
-        return torch.is_grad_enabled() and (any(w.requires_grad for w in self.conv_weights()) or
+        return torch.is_grad_enabled() and (any(w.requires_grad for w in self.conv_parameters()) or
                                             any(t is not None and t.requires_grad for t in inputs))
 
     def forward(self, x):
@@ -731,12 +750,16 @@ class EDSR(nn.Module):
         lead = x.shape[:-3]
         assert int(np.prod(lead)) == 1, "the SR network runs one plane at a time"
         x4 = x.reshape((1,) + tuple(x.shape[-3:]))
+        if self._extra_pad:                                # (1 x 1 layers run as 3 x 3: see the class comment; the padding meets zero weights only)
+            x4 = torch.nn.functional.pad(x4, (self._extra_pad,) * 4)
         if self.wants_grad(x):
             # gradients for the conv weights (through the flat state-dict-order blob) and the input: torch.ops.nvsr.edsr_train
             out, _ = torch.ops.nvsr.edsr_train(x4, self.natural_blob(differentiable=True), self.packed_weights(), self.packed_dgrad_weights(),
                                                list(self.geometry), capi.resolve_conv_arithmetic(self.arithmetic))
         else:
             out = torch.ops.nvsr.edsr(x4, self.packed_weights(), list(self.geometry), self.arith())
+        if self._extra_crop:
+            out = out[..., self._extra_crop:-self._extra_crop, self._extra_crop:-self._extra_crop]
         return out.reshape(tuple(lead) + tuple(out.shape[-3:]))
 
 
@@ -762,6 +785,10 @@ class PlanesSR(nn.Module):
         self.HR_overpadding = int(self.inner_model.required_padding * self.scale_factor)
         self.inner_model.required_padding = int(np.ceil(self.inner_model.required_padding))
         self.HR_overpadding = self.inner_model.required_padding * self.scale_factor - self.HR_overpadding
+        # the same two numbers for the network the kernels run (all 3 x 3: EDSR's class comment); equal to the above without receptive_field_bound
+        all3 = getattr(self.inner_model, "_all3_padding", self.inner_model.required_padding)
+        self._kernel_pad = int(np.ceil(all3))
+        self._kernel_over = self._kernel_pad * self.scale_factor - int(all3 * self.scale_factor)
         for m in self.modules():       # models.py:843-848
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -815,7 +842,7 @@ class PlanesSR(nn.Module):
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
-        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
+        pad, over = self._kernel_pad, self._kernel_over
         if capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None) < 0:
             return
         outs = torch.ops.nvsr.planes_sr([t.reshape(Cc, R0, R1) for t in lrs], self.inner_model.packed_weights(), list(self.inner_model.geometry),
@@ -874,7 +901,7 @@ class PlanesSR(nn.Module):
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
-        pad, over = int(self.inner_model.required_padding), int(self.HR_overpadding)
+        pad, over = self._kernel_pad, self._kernel_over
         geometry = list(self.inner_model.geometry)
         if differentiable:
             # training: gradients for the EDSR weights and the (non-detached) LR plane; the result is never cached

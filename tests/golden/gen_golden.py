@@ -1170,7 +1170,8 @@ def g22_model_options():
       noise        point_coords_noise (models.py:291-293) in training mode: the jitter drawn inside one model call (seeded), forward +
                    gradients; and run_one_iter_of_nerf(mode='train') with perturb + density noise over several ray chunks and network
                    batches -- every random tensor in the order the reference draws it
-      sr_align_false  PlanesSR(align_corners=False): the bilinear residual F.interpolate(..., align_corners=False) (models.py:858-859)"""
+      sr_align_false  PlanesSR(align_corners=False): the bilinear residual F.interpolate(..., align_corners=False) (models.py:858-859)
+      rf_bound     EDSR(receptive_field_bound=8): a mix of 3 x 3 and 1 x 1 convolutions (models.py:793-798), alone and inside PlanesSR"""
     arrs = {}
     P = 157
 
@@ -1298,6 +1299,48 @@ def g22_model_options():
         arrs.update({"sr_align_false.%s_out" % tag: npy(out).copy(), "sr_align_false.%s_gout" % tag: npy(Gp), "sr_align_false.%s_gw" % tag: gw,
                      "sr_align_false.%s_glr" % tag: npy(lrp.grad).copy()})
         sr.clear_SR_planes(all_planes=True)
+    # ---- EDSR with receptive_field_bound (models.py:789-822: layers beyond the bound fall back to 1 x 1 convolutions) --------------------
+    # bound 8 with 2 blocks and x4: conv_input 3x3, block 0 3x3, block 1 1x1, conv_mid 1x1, first up-scaling conv 1x1, second 3x3 (its
+    # receptive-field increment is halved), conv_output 1x1
+    torch.manual_seed(229)
+    C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+    sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks, "receptive_field_bound": 8}}), "bilinear")
+    sr.align_corners = True
+    with torch.no_grad():
+        for p in sr.parameters():
+            p.mul_(10.0)
+    ks = [int(m.kernel_size[0]) for m in sr.inner_model.modules() if isinstance(m, nn.Conv2d)]
+    assert ks == [3, 3, 3, 1, 1, 1, 1, 3, 1], ks
+    arrs["rf_bound.cfg"] = np.array([C, hidden, nblocks, sf, R, 8, sr.inner_model.required_padding, sr.HR_overpadding])
+    arrs["rf_bound.kernel_sizes"] = np.array(ks)
+    arrs.update({"rf_bound.sd." + k: npy(v).copy() for k, v in sr.state_dict().items()})
+    lr = torch.randn(1, C, R, R) * 0.5
+    arrs["rf_bound.lr"] = npy(lr)
+    sr.train()
+    x = torch.randn(1, C, 30, 26, requires_grad=True)
+    out = sr.inner_model(x)
+    G = torch.randn(out.shape, generator=torch.Generator().manual_seed(2291))
+    sr.zero_grad(set_to_none=True)
+    (out * G).sum().backward()
+    blob_grad = lambda: np.concatenate([npy(p.grad).reshape(-1) for _, p in sr.inner_model.named_parameters()]).astype(np.float32)
+    arrs.update({"rf_bound.edsr_in": npy(x).copy(), "rf_bound.edsr_out": npy(out).copy(), "rf_bound.edsr_gout": npy(G), "rf_bound.edsr_gw": blob_grad(),
+                 "rf_bound.edsr_gin": npy(x.grad).copy()})
+    sr.eval()
+    sr.set_LR_plane(lr, id="p", save_interpolated=False)
+    with torch.no_grad():
+        arrs["rf_bound.full"] = npy(sr("p")).copy()
+    sr.train()
+    roi = torch.tensor([[-0.35, -0.6], [0.2, 0.15]])
+    arrs["rf_bound.roi"] = npy(roi)
+    lrp = nn.Parameter(lr.clone())
+    sr.clear_SR_planes(all_planes=True)
+    sr.set_LR_plane(lrp, id="p", save_interpolated=False)
+    sr.zero_grad(set_to_none=True)
+    out = sr(("p", roi))
+    Gp = torch.randn(out.shape, generator=torch.Generator().manual_seed(2292))
+    valid = ~torch.isnan(out)
+    (torch.where(valid, out, torch.zeros_like(out)) * Gp).sum().backward()
+    arrs.update({"rf_bound.roi_out": npy(out).copy(), "rf_bound.roi_gout": npy(Gp), "rf_bound.roi_gw": blob_grad(), "rf_bound.roi_glr": npy(lrp.grad).copy()})
     save("g22_model_options.npz", **arrs)
 
 

@@ -682,3 +682,48 @@ def test_planes_sr_without_align_corners_vs_reference(hip):
         assert _rel(_sr_grad_blob(sr), g["sr_align_false.%s_gw" % tag]) < 2e-5, tag
         assert _rel(N_(lr.grad), g["sr_align_false.%s_glr" % tag]) < 2e-5, tag
         np.testing.assert_allclose(N_(lr.grad), g["sr_align_false.%s_glr" % tag], rtol=0, atol=2e-5 * np.abs(g["sr_align_false.%s_glr" % tag]).max())
+
+
+def test_edsr_with_a_receptive_field_bound_vs_reference(hip):
+    """EDSR(receptive_field_bound=8) (models.py:793-798): conv_input and the first block stay 3 x 3, the second block, conv_mid and the first
+    up-scaling convolution fall back to 1 x 1, the second up-scaling convolution is 3 x 3 again (its increment is halved), conv_output 1 x 1.
+    State dict shapes, required_padding / HR_overpadding, the network alone (output + gradients of weights and input), PlanesSR on the full
+    plane and on a region with the gradients of the weights and the LR plane -- against the reference (g22)."""
+    from conftest import load_golden
+    from test_hip_parity import N_, T, _rel
+    g = load_golden("g22_model_options.npz")
+    Cc, hid, nblocks, sf, R, bound, pad, over = [int(v) for v in g["rf_bound.cfg"]]
+    sr = hip.models.PlanesSR(hip.models.EDSR, sf, Cc, Cc, {"model": {"hidden_size": hid, "n_blocks": nblocks, "receptive_field_bound": bound}}, "bilinear")
+    assert [int(w.shape[-1]) for w in sr.inner_model.conv_parameters()] == [int(k) for k in g["rf_bound.kernel_sizes"]]
+    assert sr.inner_model.required_padding == pad and sr.HR_overpadding == over
+    sr.load_state_dict({k[len("rf_bound.sd."):]: torch.as_tensor(v) for k, v in g.items() if k.startswith("rf_bound.sd.")}, strict=True)
+    sr = sr.to(DEV)
+    blob = lambda: np.concatenate([N_(w.grad).reshape(-1) for w in sr.inner_model.conv_parameters()])
+    # the network alone
+    sr.train()
+    x = T(g["rf_bound.edsr_in"]).requires_grad_(True)
+    out = sr.inner_model(x)
+    assert tuple(out.shape) == g["rf_bound.edsr_out"].shape
+    np.testing.assert_allclose(N_(out), g["rf_bound.edsr_out"], rtol=0, atol=1e-5)
+    (out * T(g["rf_bound.edsr_gout"])).sum().backward()
+    assert _rel(blob(), g["rf_bound.edsr_gw"]) < 2e-5 and _rel(N_(x.grad), g["rf_bound.edsr_gin"]) < 2e-5
+    with torch.no_grad():
+        np.testing.assert_allclose(N_(sr.inner_model(T(g["rf_bound.edsr_in"]))), g["rf_bound.edsr_out"], rtol=0, atol=1e-5)     # (the no-grad path)
+    # PlanesSR: full plane, evaluation
+    sr.eval()
+    sr.set_LR_plane(T(g["rf_bound.lr"]), id="p", save_interpolated=False)
+    with torch.no_grad():
+        np.testing.assert_allclose(N_(sr("p")), g["rf_bound.full"], rtol=0, atol=1e-5)
+    # PlanesSR: region of interest, training
+    sr.train()
+    lr = torch.nn.Parameter(T(g["rf_bound.lr"]))
+    sr.clear_SR_planes(all_planes=True)
+    sr.set_LR_plane(lr, id="p", save_interpolated=False)
+    sr.zero_grad(set_to_none=True)
+    out = sr(("p", T(g["rf_bound.roi"])))
+    ref = g["rf_bound.roi_out"]
+    valid = ~torch.isnan(out)
+    assert np.array_equal(N_(valid), ~np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(N_(out)), np.nan_to_num(ref), rtol=0, atol=1e-5)
+    (torch.where(valid, out, torch.zeros_like(out)) * T(g["rf_bound.roi_gout"])).sum().backward()
+    assert _rel(blob(), g["rf_bound.roi_gw"]) < 2e-5 and _rel(N_(lr.grad), g["rf_bound.roi_glr"]) < 2e-5
