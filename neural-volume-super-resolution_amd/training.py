@@ -369,6 +369,10 @@ class GraphedTrainStep:
                 raise ValueError("GraphedTrainStep: build %s with capturable=True (its step counter must live on the device)" % type(o).__name__)
         if not isinstance(step.pixel_sampler, DevicePixelSampler):
             raise ValueError("GraphedTrainStep: the pixel sampler must be a DevicePixelSampler (a host draw cannot be replayed)")
+        for m in (step.mc, step.mf):
+            if m is not None and getattr(m, "point_coords_noise", 0):
+                raise ValueError("GraphedTrainStep: point_coords_noise is drawn by torch.normal on the CPU generator for every model call "
+                                 "(models.py:291-293): a host draw cannot be replayed; use TrainStep")
         if not (img_target.is_cuda and torch.as_tensor(pose_target).is_cuda):
             raise ValueError("GraphedTrainStep: img_target and pose_target must be CUDA tensors (the graph reads them at every replay)")
         self.step, self.sampler = step, step.pixel_sampler
