@@ -496,6 +496,17 @@ int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, 
                            const float* rays, int lindisp, int white_bkgd, const float* t_rand, const float* u,
                            const float* noise_coarse, const float* noise_fine, float* rgb_c, float* disp_c, float* acc_c,
                            float* rgb_f, float* disp_f, float* acc_f, float* workspace, int arithmetic, nvsr_stream_t stream);
+/* One decoder for both passes (models.fine.type == 'use_same': train_nerf.py:353-355 makes model_fine the coarse model itself).  Same
+ * arguments and results as nvsr_render_rays_arith with packed_fine == packed_coarse; the fine pass evaluates the decoder on the Nf importance
+ * samples only and takes the Nc coarse samples' outputs from the coarse pass (same decoder, same planes, same points: the reference
+ * recomputes them, train_utils.py:155-170), then composites the merged list.  Taken for frames without stratified jitter on the fused limb
+ * passes (N >= nvsr_fused_min_rays(), t_rand == NULL, a limb arithmetic); otherwise -- and with NVSR_NO_SHARED_DECODER in the environment --
+ * it forwards to nvsr_render_rays_arith.  workspace: nvsr_render_shared_workspace_floats floats. */
+int64_t nvsr_render_shared_workspace_floats(int64_t N, int Nc, int Nf);
+int nvsr_render_rays_shared_arith(const nvsr_scene* scene, const float* packed_decoder, int64_t N, int Nc, int Nf, const float* rays, int lindisp,
+                                  int white_bkgd, const float* t_rand, const float* u, const float* noise_coarse, const float* noise_fine,
+                                  float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f, float* workspace,
+                                  int arithmetic, nvsr_stream_t stream);
 int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* packed_decoder, const float* packed_bwd, int64_t N, int S,
                                           const float* rays, const float* z, const float* g_raw, const uint32_t* gates,
                                           float* const* grad_planes, float* view_ws, float* record, int arithmetic, nvsr_stream_t stream);

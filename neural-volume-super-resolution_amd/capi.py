@@ -148,6 +148,8 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_generic_decode_backward_ext": ([C.POINTER(SceneExt), C.POINTER(DecoderGeometry), _vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p),
                                           _vp, _vp], _i),
     "nvsr_ray_points": ([_i64, _i, _vp, _vp, _vp, _vp], _i),
+    "nvsr_render_shared_workspace_floats": ([_i64, _i, _i], _i64),
+    "nvsr_render_rays_shared_arith": ([C.POINTER(Scene), _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "nvsr_set_sr_align_corners": ([_i], _i),
     "nvsr_get_sr_align_corners": ([], _i),
     # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")

@@ -506,7 +506,8 @@ __device__ __forceinline__ bool resample_fast_wave(int Nc, int Nf, float* all, f
 __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, int Nc, int Nf, const float* __restrict__ zc,
                                                                       const float* __restrict__ rays, int lindisp,
                                                                       const float* __restrict__ weights,
-                                                                      const float* __restrict__ u, float* __restrict__ zf, int force_general) {
+                                                                      const float* __restrict__ u, float* __restrict__ zf, int force_general,
+                                                                      float* __restrict__ z_new) {
     __shared__ float cdf_s[WPB][256];
     __shared__ float zmid_s[WPB][256];
     __shared__ float all_s[WPB][512];
@@ -527,7 +528,11 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
     __builtin_amdgcn_s_waitcnt(0xc07f);
 #if !NVSR_RESAMPLE_GENERAL_ONLY
     if (!u && Nc >= 3 && Nc <= 64 && Nf >= 1 && Nf <= 128 && !force_general)
-        if (resample_fast_wave(Nc, Nf, all, zm, cdf_s[wave], w, lane, zf + ray * (Nc + Nf))) return;
+        if (resample_fast_wave(Nc, Nf, all, zm, cdf_s[wave], w, lane, zf + ray * (Nc + Nf))) {
+            if (z_new)                                                   // (the fast path leaves the samples behind the coarse depths)
+                for (int j = lane; j < Nf; j += 64) z_new[ray * Nf + j] = all[Nc + j];
+            return;
+        }
     __builtin_amdgcn_wave_barrier();
 #endif
     for (int i = lane; i < Nc - 1; i += 64) zm[i] = __fmul_rn(0.5f, __fadd_rn(all[i + 1], all[i]));
@@ -537,7 +542,71 @@ __global__ __launch_bounds__(WPB * 64) void importance_resample_kernel(long N, i
                     cdf_s[wave], lane, [&](int j, float v) { all[Nc + j] = v; });
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (z_new)
+        for (int j = lane; j < Nf; j += 64) z_new[ray * Nf + j] = all[Nc + j];
     merge_sort_wave(all, Nc, Nf, zf + ray * (Nc + Nf), lane);
+}
+
+// Shared-decoder fine pass (models.fine.type == 'use_same', train_nerf.py:353-355: model_fine IS model_coarse): the fine pass evaluates the
+// decoder at sort(cat(z_coarse, z_samples)) (train_utils.py:155-170), a third of which it has already evaluated -- same decoder, same planes,
+// same points -- in the coarse pass.  The decoder runs on the new samples only; this kernel merges the two sorted depth lists of a ray and
+// gathers the two lists of decoder outputs into the merged order, which is then composited.  Positions: a coarse depth goes behind the new
+// samples that are smaller, a new sample behind the coarse depths that are smaller or equal (at equal depths the two points are the same
+// point and their outputs the same numbers).  Unsorted input (NaN weights) falls back to counting.  One wave per ray.
+__global__ __launch_bounds__(WPB * 64) void shared_merge_kernel(long N, int Nc, int Nf, const float* __restrict__ rays, int lindisp,
+                                                               const float* __restrict__ z_new, const float* __restrict__ raw_c,
+                                                               const float* __restrict__ raw_new, float* __restrict__ z_m, float* __restrict__ raw_m) {
+    __shared__ float a_s[WPB][256], b_s[WPB][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * WPB + wave;
+    if (ray >= N) return;
+    float* a = a_s[wave];
+    float* b = b_s[wave];
+    const float nr = rays[ray * 11 + 6], fr = rays[ray * 11 + 7];
+    for (int i = lane; i < Nc; i += 64) a[i] = coarse_depth(nr, fr, i, Nc, lindisp);
+    for (int j = lane; j < Nf; j += 64) b[j] = z_new[ray * Nf + j];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    bool sorted = true;
+    for (int i = lane; i + 1 < Nc; i += 64) sorted = sorted && (a[i] <= a[i + 1]);
+    for (int j = lane; j + 1 < Nf; j += 64) sorted = sorted && (b[j] <= b[j + 1]);
+    const bool fast = __builtin_amdgcn_ballot_w64(!sorted) == 0;
+    float* zo = z_m + ray * (Nc + Nf);
+    f32x4* ro = reinterpret_cast<f32x4*>(raw_m) + ray * (Nc + Nf);
+    const f32x4* rc = reinterpret_cast<const f32x4*>(raw_c) + ray * Nc;
+    const f32x4* rn = reinterpret_cast<const f32x4*>(raw_new) + ray * Nf;
+    for (int i = lane; i < Nc; i += 64) {
+        const float v = a[i];
+        int cnt = 0, rank = i;
+        if (fast) {                                                      // #{j : b[j] < v}
+            int lo = 0, hi = Nf;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (b[mid] < v) lo = mid + 1; else hi = mid; }
+            cnt = lo;
+        } else {
+            for (int j = 0; j < Nf; ++j) cnt += b[j] < v ? 1 : 0;
+            rank = 0;
+            for (int k = 0; k < Nc; ++k) rank += (a[k] < v || (a[k] == v && k < i)) ? 1 : 0;
+        }
+        const int pos = min(rank + cnt, Nc + Nf - 1);
+        zo[pos] = v;
+        ro[pos] = rc[i];
+    }
+    for (int j = lane; j < Nf; j += 64) {
+        const float v = b[j];
+        int cnt = 0, rank = j;
+        if (fast) {                                                      // #{i : a[i] <= v}
+            int lo = 0, hi = Nc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+            cnt = lo;
+        } else {
+            for (int i = 0; i < Nc; ++i) cnt += a[i] <= v ? 1 : 0;
+            rank = 0;
+            for (int k = 0; k < Nf; ++k) rank += (b[k] < v || (b[k] == v && k < j)) ? 1 : 0;
+        }
+        const int pos = min(rank + cnt, Nc + Nf - 1);
+        zo[pos] = v;
+        ro[pos] = rn[j];
+    }
 }
 
 // ---- compositing: one wave per ray, samples across lanes, transmittance by a wave scan ------------------------------------
@@ -606,7 +675,8 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 
 extern "C" {
 
-int nvsr_version(void) { return 400; }   // 400: round 4 (range flag, device-keyed pixel sampler, tile-pair training forward, gate bit layout, per-point backward scales)
+int nvsr_version(void) { return 410; }   // 4xx: round 4 (range flag, device-keyed pixel sampler, tile-pair training forward, gate bit layout, per-point backward scales;
+                                         // 410: nvsr_scene_ext / *_ext generic entry points, nvsr_set_sr_align_corners, nvsr_render_rays_shared_arith)
 int64_t nvsr_fused_min_rays(void) { return NVSR_FUSED_MIN_RAYS; }
 
 int nvsr_plane_to_channel_last(const float* nchw, float* nhwc, int Cc, int H, int W, nvsr_stream_t stream) {
@@ -757,18 +827,22 @@ int nvsr_importance_resample(int64_t N, int Nc, int Nf, const float* z_coarse, c
     if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
-                       z_coarse, (const float*)nullptr, 0, weights, u, z_fine, resample_general_only());
+                       z_coarse, (const float*)nullptr, 0, weights, u, z_fine, resample_general_only(), (float*)nullptr);
     return NVSR_CHECK_LAUNCH();
 }
 
-int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, int lindisp, const float* weights, const float* u,
-                                  float* z_fine, nvsr_stream_t stream) {
+static int importance_resample_rays_impl(int64_t N, int Nc, int Nf, const float* rays, int lindisp, const float* weights, const float* u,
+                                         float* z_fine, float* z_new, nvsr_stream_t stream) {
     if (!rays || !weights || !z_fine) return NVSR_ERR_NULL;
     if (N < 0 || Nc < 3 || Nc > 256 || Nf < 1 || Nf > 256) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(importance_resample_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf,
-                       (const float*)nullptr, rays, lindisp, weights, u, z_fine, resample_general_only());
+                       (const float*)nullptr, rays, lindisp, weights, u, z_fine, resample_general_only(), z_new);
     return NVSR_CHECK_LAUNCH();
+}
+int nvsr_importance_resample_rays(int64_t N, int Nc, int Nf, const float* rays, int lindisp, const float* weights, const float* u,
+                                  float* z_fine, nvsr_stream_t stream) {
+    return importance_resample_rays_impl(N, Nc, Nf, rays, lindisp, weights, u, z_fine, nullptr, stream);
 }
 
 int nvsr_composite(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd, float* rgb,
@@ -815,7 +889,7 @@ int64_t nvsr_render_workspace_floats(int64_t N, int Nc, int Nf) {
 extern "C" int nvsr_internal_resolve_decoder_arith(int arithmetic);      // render.hip
 extern "C" int nvsr_render_pass3_coarse_z_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                                  int lindisp, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
-                                                 float* weights, float* depth, nvsr_stream_t stream);
+                                                 float* weights, float* depth, float* raw_out, nvsr_stream_t stream);
 
 static int render_one_pass(const nvsr_scene* scene, const float* packed, int64_t N, int S, const float* rays, const float* z,
                            const float* noise, int white, float* rgb, float* disp, float* acc, float* weights, float* raw_ws,
@@ -864,7 +938,7 @@ int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, 
         }
         if (!aligned16(packed_coarse)) return NVSR_ERR_ALIGN;
         e = nvsr_render_pass3_coarse_z_launch(arith, scene, packed_coarse, N, Nc, rays, lindisp, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, w_c,
-                                              nullptr, stream);
+                                              nullptr, nullptr, stream);
         if (e) return e;
         e = nvsr_importance_resample_rays(N, Nc, Nf, rays, lindisp, w_c, u, z_f, stream);
         if (e) return e;
@@ -878,6 +952,55 @@ int nvsr_render_rays_arith(const nvsr_scene* scene, const float* packed_coarse, 
     e = nvsr_importance_resample(N, Nc, Nf, z_c, w_c, u, z_f, stream);
     if (e) return e;
     return render_one_pass(scene, packed_fine, N, Nc + Nf, rays, z_f, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, raw_ws, arithmetic, stream);
+}
+
+// ---- one decoder for both passes (models.fine.type == 'use_same') ----------------------------------------------------------------------
+// does this call take the shared path?  (a frame without stratified jitter on the fused limb passes -- the conditions of in_kernel_z above)
+static bool shared_path(int64_t N, int Nf, const float* t_rand, int arithmetic) {
+    return !t_rand && Nf > 0 && N >= NVSR_FUSED_MIN_RAYS && nvsr_internal_resolve_decoder_arith(arithmetic) > 0 && !getenv("NVSR_RENDER_V1") &&
+           !getenv("NVSR_STORE_COARSE_Z") && !getenv("NVSR_NO_SHARED_DECODER");
+}
+int64_t nvsr_render_shared_workspace_floats(int64_t N, int Nc, int Nf) {
+    // w_c [N,Nc], z_new [N,Nf], z_m [N,Nc+Nf], raw_c [N,Nc,4], raw_new [N,Nf,4], raw_m [N,Nc+Nf,4] -- and never less than the two-decoder path
+    const int64_t S = (int64_t)Nc + (Nf > 0 ? Nf : 0);
+    const int64_t shared = round4(N * (int64_t)Nc) + round4(N * (int64_t)Nf) + round4(N * S) + 4 * N * (int64_t)Nc + 4 * N * (int64_t)Nf + 4 * N * S;
+    const int64_t plain = nvsr_render_workspace_floats(N, Nc, Nf);
+    return shared > plain ? shared : plain;
+}
+int nvsr_render_rays_shared_arith(const nvsr_scene* scene, const float* packed, int64_t N, int Nc, int Nf, const float* rays, int lindisp,
+                                  int white_bkgd, const float* t_rand, const float* u, const float* noise_coarse, const float* noise_fine,
+                                  float* rgb_c, float* disp_c, float* acc_c, float* rgb_f, float* disp_f, float* acc_f, float* workspace,
+                                  int arithmetic, nvsr_stream_t stream) {
+    if (!shared_path(N, Nf, t_rand, arithmetic))
+        return nvsr_render_rays_arith(scene, packed, packed, N, Nc, Nf, rays, lindisp, white_bkgd, t_rand, u, noise_coarse, noise_fine, rgb_c, disp_c,
+                                      acc_c, rgb_f, disp_f, acc_f, workspace, arithmetic, stream);
+    if (!workspace || !scene || !packed || !rays || !rgb_c || !disp_c || !acc_c || !rgb_f || !disp_f || !acc_f) return NVSR_ERR_NULL;
+    if (!aligned16(workspace) || !aligned16(packed)) return NVSR_ERR_ALIGN;
+    if (Nc < 3 || Nc > 256 || Nf > 256) return NVSR_ERR_SHAPE;
+    for (int d = 0; d < 4; ++d) {
+        if (!scene->planes[d]) return NVSR_ERR_NULL;
+        if (!aligned16(scene->planes[d])) return NVSR_ERR_ALIGN;
+        if (scene->ph[d] < 1 || scene->pw[d] < 1 || (int64_t)scene->ph[d] * scene->pw[d] * NVSR_PLANE_CHANNELS >= (int64_t)1 << 31) return NVSR_ERR_SHAPE;
+    }
+    const int64_t S = (int64_t)Nc + Nf;
+    float* w_c = workspace;
+    float* z_new = w_c + round4(N * (int64_t)Nc);
+    float* z_m = z_new + round4(N * (int64_t)Nf);
+    float* raw_c = z_m + round4(N * S);
+    float* raw_new = raw_c + 4 * N * (int64_t)Nc;
+    float* raw_m = raw_new + 4 * N * (int64_t)Nf;
+    const int arith = nvsr_internal_resolve_decoder_arith(arithmetic);
+    int e = nvsr_render_pass3_coarse_z_launch(arith, scene, packed, N, Nc, rays, lindisp, noise_coarse, white_bkgd, rgb_c, disp_c, acc_c, w_c, nullptr,
+                                              raw_c, stream);
+    if (e) return e;
+    if ((e = importance_resample_rays_impl(N, Nc, Nf, rays, lindisp, w_c, u, z_m, z_new, stream))) return e;
+    // the decoder on the new samples only (its own compositing lands in the fine outputs and is overwritten below)
+    if ((e = nvsr_render_pass_arith(scene, packed, N, Nf, rays, z_new, nullptr, white_bkgd, rgb_f, disp_f, acc_f, nullptr, nullptr, raw_new, arithmetic, stream)))
+        return e;
+    hipLaunchKernelGGL(shared_merge_kernel, dim3(blocks_for(N, WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, (long)N, Nc, Nf, rays, lindisp, z_new,
+                       raw_c, raw_new, z_m, raw_m);
+    if ((e = NVSR_CHECK_LAUNCH())) return e;
+    return nvsr_composite_rays(N, (int)S, raw_m, z_m, rays, noise_fine, white_bkgd, rgb_f, disp_f, acc_f, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

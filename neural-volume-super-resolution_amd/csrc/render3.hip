@@ -543,14 +543,14 @@ extern "C" int nvsr_render_pass3_launch(int limbs, const nvsr_scene* scene, cons
 // the coarse pass with its depths computed in the kernel (z = coarse_depth(near, far, s, S, lindisp)); weights are always written
 extern "C" int nvsr_render_pass3_coarse_z_launch(int limbs, const nvsr_scene* scene, const float* packed_decoder, int64_t N, int S, const float* rays,
                                                  int lindisp, const float* noise, int white_bkgd, float* rgb, float* disp, float* acc,
-                                                 float* weights, float* depth, nvsr_stream_t stream) {
+                                                 float* weights, float* depth, float* raw_out, nvsr_stream_t stream) {
     const int64_t grid = (N + RAYS2 - 1) / RAYS2;
     if (grid > 0x7fffffff || (limbs != 2 && limbs != 3) || !weights) return NVSR_ERR_SHAPE;
     if (limbs == 3)
         hipLaunchKernelGGL(render_pass3_coarse_z_kernel<3>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr, nvsr_get_range_flag());
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, nvsr_get_range_flag());
     else
         hipLaunchKernelGGL(render_pass3_coarse_z_kernel<2>, dim3((unsigned)grid), dim3(TPB2), 0, (hipStream_t)stream, to_dev(scene), packed_decoder,
-                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, (float*)nullptr, nvsr_get_range_flag());
+                           (long)N, S, rays, lindisp, noise, white_bkgd, rgb, disp, acc, weights, depth, raw_out, nvsr_get_range_flag());
     return NVSR_CHECK_LAUNCH();
 }

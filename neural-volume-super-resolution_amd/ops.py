@@ -336,7 +336,13 @@ def render_rays(planes: Sequence[Tensor], consts: Sequence[float], packed_coarse
         rgb_f, disp_f, acc_f = _f(N, 3, like=rays), _f(N, like=rays), _f(N, like=rays)
     else:
         rgb_f, disp_f, acc_f = _f(0, 3, like=rays), _f(0, like=rays), _f(0, like=rays)
-    if N:
+    # one decoder for both passes (models.fine.type == 'use_same'): the fine pass evaluates the importance samples only (nvsr.h)
+    if N and Nf > 0 and packed_fine is not None and packed_fine.data_ptr() == packed_coarse.data_ptr():
+        ws = _f(capi.lib().nvsr_render_shared_workspace_floats(N, Nc, Nf), like=rays)
+        capi.call("nvsr_render_rays_shared_arith", C.byref(sc), capi.ptr(packed_coarse), N, Nc, Nf, capi.ptr(rays), int(lindisp), int(white),
+                  capi.ptr(t_rand), capi.ptr(u), capi.ptr(noise_coarse), capi.ptr(noise_fine), capi.ptr(rgb_c), capi.ptr(disp_c), capi.ptr(acc_c),
+                  capi.ptr(rgb_f), capi.ptr(disp_f), capi.ptr(acc_f), capi.ptr(ws), arithmetic, capi.stream())
+    elif N:
         ws = _f(capi.lib().nvsr_render_workspace_floats(N, Nc, Nf), like=rays)
         capi.call("nvsr_render_rays_arith", C.byref(sc), capi.ptr(packed_coarse), capi.ptr(packed_fine), N, Nc, Nf, capi.ptr(rays), int(lindisp),
                   int(white), capi.ptr(t_rand), capi.ptr(u), capi.ptr(noise_coarse), capi.ptr(noise_fine), capi.ptr(rgb_c), capi.ptr(disp_c),

@@ -727,3 +727,50 @@ def test_edsr_with_a_receptive_field_bound_vs_reference(hip):
     np.testing.assert_allclose(np.nan_to_num(N_(out)), np.nan_to_num(ref), rtol=0, atol=1e-5)
     (torch.where(valid, out, torch.zeros_like(out)) * T(g["rf_bound.roi_gout"])).sum().backward()
     assert _rel(blob(), g["rf_bound.roi_gw"]) < 2e-5 and _rel(N_(lr.grad), g["rf_bound.roi_glr"]) < 2e-5
+
+
+def test_one_decoder_for_both_passes_reuses_the_coarse_outputs(hip, oracle, monkeypatch):
+    """models.fine.type == 'use_same' (train_nerf.py:353-355: model_fine IS model_coarse): the fine pass needs the decoder at
+    sort(cat(z_coarse, z_samples)), a third of which the coarse pass has just evaluated with the same decoder on the same planes.
+    nvsr_render_rays_shared_arith evaluates the importance samples only, merges the two lists and composites: the frame must agree with the
+    path that recomputes everything (NVSR_NO_SHARED_DECODER=1) to compositing rounding, and with the oracle's render of the same model pair
+    like any other frame; the coarse image is the same bits; white background, lindisp and density noise go through the same merge."""
+    from bench import make_synthetic_scene, render_options
+    from oracle.oracle import decoder_blob
+    from test_hip_parity import N_
+    mc, _, sid, pose = make_synthetic_scene(DEV, plane_res=64, view_res=16, seed=3)
+    H = W = 256                                                         # 65 536 rays: a fused frame (>= nvsr_fused_min_rays)
+    assert H * W >= hip.capi.fused_min_rays()
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    tu = hip.train_utils
+    for white, lindisp in ((False, False), (True, True)):
+        opts, scfg = render_options(64, 128, white=white)
+        opts.nerf.validation.lindisp = lindisp
+        monkeypatch.delenv("NVSR_NO_SHARED_DECODER", raising=False)
+        rgb_c, _, _, rgb_f, *_ = tu.eval_nerf(H, W, focal, mc, mc, ro, rd, opts, scene_id=sid, scene_config=scfg)
+        monkeypatch.setenv("NVSR_NO_SHARED_DECODER", "1")
+        ref_c, _, _, ref_f, *_ = tu.eval_nerf(H, W, focal, mc, mc, ro, rd, opts, scene_id=sid, scene_config=scfg)
+        assert torch.equal(rgb_c, ref_c)
+        d = (rgb_f - ref_f).abs()
+        assert float(d.max()) <= 2e-5 and not torch.equal(rgb_f, torch.zeros_like(rgb_f)), float(d.max())
+    # against the oracle (rows of the last frame: white background, lindisp)
+    planes = [N_(mc.planes_[hip.models.get_plane_name(sid, d_)]) for d_ in range(4)]
+    sc = oracle.scene(planes, mc.box_coords[sid].numpy())
+    dec = oracle.decoder(decoder_blob({k: N_(v) for k, v in mc.state_dict().items()}))
+    rows = slice(120 * W, 123 * W)
+    rays = oracle.pack_rays(N_(ro).reshape(-1, 3)[rows], N_(rd).reshape(-1, 3)[rows], 2.0, 6.0)
+    o = oracle.render_rays(sc, dec, dec, rays, 64, 128, lindisp=True, white_background=True)
+    ef = np.abs(N_(rgb_f).reshape(-1, 3)[rows] - o["rgb_fine"]).max(-1)
+    assert (ef <= 2e-4).mean() >= 0.98 and ef.max() <= 5e-3, ((ef <= 2e-4).mean(), ef.max())
+    # density noise: explicit random inputs through run_one_iter_of_nerf (the merge gathers decoder outputs; the noise is added when compositing)
+    monkeypatch.delenv("NVSR_NO_SHARED_DECODER", raising=False)
+    opts, scfg = render_options(64, 128, noise=0.5)
+    N = H * W
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rnd = dict(noise_coarse=0.5 * torch.randn(N, 64, device=DEV, generator=g), noise_fine=0.5 * torch.randn(N, 192, device=DEV, generator=g))
+    batch = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    a = tu.run_one_iter_of_nerf(H, W, focal, mc, mc, batch, opts, sid, mode="validation", scene_config=scfg, randoms=rnd)
+    monkeypatch.setenv("NVSR_NO_SHARED_DECODER", "1")
+    b = tu.run_one_iter_of_nerf(H, W, focal, mc, mc, batch, opts, sid, mode="validation", scene_config=scfg, randoms=rnd)
+    assert torch.equal(a[0], b[0]) and float((a[3] - b[3]).abs().max()) <= 2e-5
