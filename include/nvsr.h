@@ -297,11 +297,17 @@ int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed
  * bilinear_x{sf}(lr) inside the ROI, NaN outside.  roi: NULL = full plane, else 4 HOST floats [[ymin,xmin],[ymax,xmax]] in [-1,1]
  * (models.py:278-279).  pad = EDSR.required_padding, over = HR_overpadding (models.py:836-842).  mean/std: optional [C] device
  * vectors (planes_{mean,std}_NON_LEARNED). */
+/* plane_interp of the reference (config/TrainModels.yml:72,172): how a plane is sampled (grid_sample) and up-sampled (F.interpolate) */
+#define NVSR_PLANE_INTERP_BILINEAR 0
+#define NVSR_PLANE_INTERP_BICUBIC 1
 /* align_corners of the bilinear residual F.interpolate(LR, scale_factor, 'bilinear', align_corners) (models.py:858-859; PlanesSR.align_corners
  * is the planes model's, :222): library state like the conv arithmetic, 1 (every shipped config) unless set; read by every nvsr_planes_sr*
  * call (forward and backward) when it is launched.  A binding with models of both kinds sets it before each call (ops.py does). */
 int nvsr_set_sr_align_corners(int align_corners);
 int nvsr_get_sr_align_corners(void);
+/* ... and its mode (PlanesSR.plane_interp, models.py:858-859): NVSR_PLANE_INTERP_BILINEAR (every shipped config) | NVSR_PLANE_INTERP_BICUBIC */
+int nvsr_set_sr_plane_interp(int plane_interp);
+int nvsr_get_sr_plane_interp(void);
 int64_t nvsr_planes_sr_workspace_floats(int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* roi);
 int nvsr_planes_sr(const float* lr, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad, int over,
                    const float* roi, const float* mean, const float* std_, float* out, float* workspace, nvsr_stream_t stream);
@@ -447,7 +453,7 @@ int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geo
  * geometry keep nvsr_scene):
  *   - any number of position planes with their projections (num_planes_or_rot_mats > 3: models.py:140,471-490 -- CoordProjector draws
  *     random orthonormal frames; grid_d = n_xyz @ rot_mats[d][:, 1:]); combine_pos_planes sums / averages / concatenates all of them;
- *   - grid_sample(align_corners=False) (models.py:303-309,320-326);
+ *   - grid_sample(align_corners=False) and grid_sample(mode='bicubic') (plane_interp, models.py:303-309,320-326; config/TrainModels.yml:72);
  *   - point_coords_noise (models.py:291-293): `coord_noise` [P,3] (device; NULL = none) is ADDED TO THE NORMALISED sample position
  *     before the projections -- the caller draws it (the reference: torch.normal(0, point_coords_noise * 2 / (1 + plane resolution)) on
  *     the CPU generator, once per model call, training only).
@@ -456,6 +462,7 @@ int nvsr_generic_decode_backward(const nvsr_scene* scene, const nvsr_decoder_geo
 typedef struct nvsr_scene_ext {
     int32_t num_position_planes;                          /* 1 .. NVSR_MAX_POSITION_PLANES */
     int32_t align_corners;                                /* grid_sample's align_corners: 1 = True (every shipped config), 0 = False */
+    int32_t plane_interp;                                 /* grid_sample's mode: NVSR_PLANE_INTERP_BILINEAR (every shipped config) | _BICUBIC */
     const float* planes[NVSR_MAX_POSITION_PLANES + 1];    /* device, channel-last */
     int32_t ph[NVSR_MAX_POSITION_PLANES + 1], pw[NVSR_MAX_POSITION_PLANES + 1];
     float lo[5], range[5];                                /* as in nvsr_scene */

@@ -40,7 +40,8 @@ MAX_POSITION_PLANES = 15
 
 class SceneExt(C.Structure):
     """struct nvsr_scene_ext: any number of position planes, grid_sample's align_corners (generic kernels only)"""
-    _fields_ = [("num_position_planes", C.c_int32), ("align_corners", C.c_int32), ("planes", C.c_void_p * (MAX_POSITION_PLANES + 1)),
+    _fields_ = [("num_position_planes", C.c_int32), ("align_corners", C.c_int32), ("plane_interp", C.c_int32),
+                ("planes", C.c_void_p * (MAX_POSITION_PLANES + 1)),
                 ("ph", C.c_int32 * (MAX_POSITION_PLANES + 1)), ("pw", C.c_int32 * (MAX_POSITION_PLANES + 1)), ("lo", C.c_float * 5),
                 ("range", C.c_float * 5), ("proj", (C.c_float * 6) * MAX_POSITION_PLANES)]
 
@@ -150,6 +151,8 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_ray_points": ([_i64, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_shared_workspace_floats": ([_i64, _i, _i], _i64),
     "nvsr_render_rays_shared_arith": ([C.POINTER(Scene), _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "nvsr_set_sr_plane_interp": ([_i], _i),
+    "nvsr_get_sr_plane_interp": ([], _i),
     "nvsr_set_sr_align_corners": ([_i], _i),
     "nvsr_get_sr_align_corners": ([], _i),
     # per-call arithmetic twins (include/nvsr.h, "per-call arithmetic")

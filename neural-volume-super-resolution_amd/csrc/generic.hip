@@ -22,6 +22,10 @@
 
 namespace nvsr {
 
+// the lambdas of the input kernels read the scene out of the kernel arguments: kept as calls (the inliner's choice once the bicubic taps made them
+// large) they receive the 700-byte scene through scratch memory and lose the planes' address space
+#define GEN_INL __attribute__((always_inline))
+
 struct GenGeom {
     int C, Cv, hidden, nd, nr, skip, proj, view;      // proj: 0 sum 1 avg 2 concat; view: 0 sum 1 avg 2 mult 3 concat 4 concat_pos
     int Kd, Kr;
@@ -35,7 +39,7 @@ struct SceneDevN {
     int ph[NVSR_MAX_POSITION_PLANES + 1], pw[NVSR_MAX_POSITION_PLANES + 1];
     float lo[5], range[5];
     float proj[NVSR_MAX_POSITION_PLANES * 6];
-    int np, align;
+    int np, align, bicubic;
 };
 struct GradPlanesN { float* g[NVSR_MAX_POSITION_PLANES + 1]; };
 
@@ -44,7 +48,7 @@ static SceneDevN gen_scene(const nvsr_scene* s) {
     for (int i = 0; i < 4; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
     for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
     for (int i = 0; i < 18; ++i) d.proj[i] = (&s->proj[0][0])[i];
-    d.np = 3; d.align = 1;
+    d.np = 3; d.align = 1; d.bicubic = 0;
     return d;
 }
 static SceneDevN gen_scene(const nvsr_scene_ext* s) {
@@ -52,7 +56,7 @@ static SceneDevN gen_scene(const nvsr_scene_ext* s) {
     for (int i = 0; i <= s->num_position_planes; ++i) { d.plane[i] = s->planes[i]; d.ph[i] = s->ph[i]; d.pw[i] = s->pw[i]; }
     for (int i = 0; i < 5; ++i) { d.lo[i] = s->lo[i]; d.range[i] = s->range[i]; }
     for (int i = 0; i < 6 * s->num_position_planes; ++i) d.proj[i] = (&s->proj[0][0])[i];
-    d.np = s->num_position_planes; d.align = s->align_corners ? 1 : 0;
+    d.np = s->num_position_planes; d.align = s->align_corners ? 1 : 0; d.bicubic = s->plane_interp == NVSR_PLANE_INTERP_BICUBIC ? 1 : 0;
     return d;
 }
 
@@ -107,6 +111,69 @@ __device__ __forceinline__ float gen_blend(const float* __restrict__ plane, cons
     return fmaf(plane[t.o[3] + c], t.w[3], fmaf(plane[t.o[2] + c], t.w[2], fmaf(plane[t.o[1] + c], t.w[1], plane[t.o[0] + c] * t.w[0])));
 }
 
+// grid_sample(mode='bicubic', padding_mode='border') (ATen GridSampler.h / GridSamplerKernel.cpp): the coordinate is unnormalised but NOT
+// clipped; the 4 x 4 neighbourhood starts at floor - 1 and every TAP's index is clipped to the plane (border padding); the weights are the cubic
+// convolution kernel with A = -0.75 (UpSample.h: get_cubic_upsample_coefficients), rows first: out = sum_i cy[i] (sum_j cx[j] v[i][j]).
+struct CubicTaps { int ix[4], iy[4]; float cx[4], cy[4]; };
+__device__ __forceinline__ void cubic_coefficients(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = x2 + 1.0f;
+    c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+__device__ __forceinline__ CubicTaps gen_cubic_taps(int H, int W, float gx, float gy, int align) {
+    float x, y;
+    if (align) { x = (gx + 1.0f) * ((float)(W - 1) / 2.0f); y = (gy + 1.0f) * ((float)(H - 1) / 2.0f); }
+    else { x = __fsub_rn(__fmul_rn(gx + 1.0f, (float)W / 2.0f), 0.5f); y = __fsub_rn(__fmul_rn(gy + 1.0f, (float)H / 2.0f), 0.5f); }
+    const float fx = floorf(x), fy = floorf(y);
+    CubicTaps t;
+    cubic_coefficients(x - fx, t.cx);
+    cubic_coefficients(y - fy, t.cy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // (clip_coordinates on the float index, then the integer cast: the same texel as clamping the integer; NaN coordinates clamp to 0)
+        const float xi = fminf((float)(W - 1), fmaxf(fx - 1.0f + (float)k, 0.0f)), yi = fminf((float)(H - 1), fmaxf(fy - 1.0f + (float)k, 0.0f));
+        t.ix[k] = (int)xi; t.iy[k] = (int)yi;
+    }
+    return t;
+}
+__device__ __forceinline__ float gen_cubic_blend(const float* __restrict__ plane, int W, int Cc, const CubicTaps& t, int c) {
+    float out = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* row = plane + (long)t.iy[i] * W * Cc + c;
+        const float r = row[t.ix[0] * Cc] * t.cx[0] + row[t.ix[1] * Cc] * t.cx[1] + row[t.ix[2] * Cc] * t.cx[2] + row[t.ix[3] * Cc] * t.cx[3];
+        out += r * t.cy[i];
+    }
+    return out;
+}
+// one feature of one plane in either interpolation
+__device__ __forceinline__ float gen_sample(const SceneDevN& sc, int d, int Cc, float gx, float gy, int c) {
+    if (sc.bicubic) return gen_cubic_blend(sc.plane[d], sc.pw[d], Cc, gen_cubic_taps(sc.ph[d], sc.pw[d], gx, gy, sc.align), c);
+    return gen_blend(sc.plane[d], gen_taps(sc.ph[d], sc.pw[d], Cc, gx, gy, sc.align), c);
+}
+// ... and its transpose: v times the tap weights, added into the gradient plane
+__device__ __forceinline__ void gen_scatter(const SceneDevN& sc, int d, int Cc, float gx, float gy, int c, float v, float* __restrict__ g) {
+    if (!g || v == 0.0f) return;
+    if (sc.bicubic) {
+        const CubicTaps t = gen_cubic_taps(sc.ph[d], sc.pw[d], gx, gy, sc.align);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = t.cx[j] * t.cy[i];
+                if (w != 0.0f) unsafeAtomicAdd(g + ((long)t.iy[i] * sc.pw[d] + t.ix[j]) * Cc + c, v * w);
+            }
+        return;
+    }
+    const GenTaps t = gen_taps(sc.ph[d], sc.pw[d], Cc, gx, gy, sc.align);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (t.w[i] != 0.0f) unsafeAtomicAdd(g + t.o[i] + c, v * t.w[i]);
+}
+
 // normalised sample position (models.py:261-268) + the optional jitter the reference adds to it in training (:291-293)
 __device__ __forceinline__ void gen_position(const SceneDevN& sc, const float* q, const float* noise, long p, float& n0, float& n1, float& n2) {
     n0 = norm_coord(q[0], sc.lo[0], sc.range[0]); n1 = norm_coord(q[1], sc.lo[1], sc.range[1]); n2 = norm_coord(q[2], sc.lo[2], sc.range[2]);
@@ -124,18 +191,16 @@ __global__ void generic_inputs_kernel(SceneDevN sc, GenGeom g, long P, const flo
     // (cart2az_el nerf_helpers.py:492-496)
     float n0, n1, n2;
     gen_position(sc, q, noise, p, n0, n1, n2);
-    auto pos_feat = [&](int d, int c) {
+    auto pos_feat = [&](int d, int c) GEN_INL {
         const float* M = sc.proj + 6 * d;
-        const GenTaps t = gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.align);
-        return gen_blend(sc.plane[d], t, c);
+        return gen_sample(sc, d, g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], c);
     };
-    auto view_feat = [&](int c) {
+    auto view_feat = [&](int c) GEN_INL {
         const float az = atan2f(q[4], q[3]);
         const float el = atan2f(q[5], sqrtf(__fadd_rn(__fmul_rn(q[3], q[3]), __fmul_rn(q[4], q[4]))));
-        const GenTaps t = gen_taps(sc.ph[g.np], sc.pw[g.np], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.align);
-        return gen_blend(sc.plane[g.np], t, c);
+        return gen_sample(sc, g.np, g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), c);
     };
-    auto combined_pos = [&](int c) {                       // combine_pos_planes, column c of its result (stack(...).sum(0) / .mean(0): plane by plane)
+    auto combined_pos = [&](int c) GEN_INL {                       // combine_pos_planes, column c of its result (stack(...).sum(0) / .mean(0): plane by plane)
         if (g.proj == 2) return pos_feat(c / g.C, c % g.C);
         float s = pos_feat(0, c);
         for (int d = 1; d < g.np; ++d) s = __fadd_rn(s, pos_feat(d, c));
@@ -302,52 +367,58 @@ __global__ void generic_inputs_backward_kernel(SceneDevN sc, GenGeom g, long P, 
     const float* q = x + p * 6;
     float n0, n1, n2;
     gen_position(sc, q, noise, p, n0, n1, n2);
-    auto pos_taps = [&](int d) {
+    auto pos_grid = [&](int d, float& gx, float& gy) GEN_INL {
         const float* M = sc.proj + 6 * d;
-        return gen_taps(sc.ph[d], sc.pw[d], g.C, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5], sc.align);
+        gx = n0 * M[0] + n1 * M[2] + n2 * M[4]; gy = n0 * M[1] + n1 * M[3] + n2 * M[5];
     };
-    auto view_taps = [&]() {
+    auto view_grid = [&](float& gx, float& gy) GEN_INL {
         const float az = atan2f(q[4], q[3]);
         const float el = atan2f(q[5], sqrtf(__fadd_rn(__fmul_rn(q[3], q[3]), __fmul_rn(q[4], q[4]))));
-        return gen_taps(sc.ph[g.np], sc.pw[g.np], g.Cv, norm_coord(az, sc.lo[3], sc.range[3]), norm_coord(el, sc.lo[4], sc.range[4]), sc.align);
+        gx = norm_coord(az, sc.lo[3], sc.range[3]); gy = norm_coord(el, sc.lo[4], sc.range[4]);
     };
-    auto scatter = [&](int d, const GenTaps& t, int c, float v) {
-        if (!gp.g[d] || v == 0.0f) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (t.w[i] != 0.0f) unsafeAtomicAdd(gp.g[d] + t.o[i] + c, v * t.w[i]);
+    auto scatter_plane = [&](int d, int c, float v) GEN_INL {         // position plane d, channel c
+        float gx, gy;
+        pos_grid(d, gx, gy);
+        gen_scatter(sc, d, g.C, gx, gy, c, v, gp.g[d]);
     };
-    auto scatter_pos = [&](int c, float v) {                 // combine_pos_planes transposed, column c of its result
-        if (g.proj == 2) { scatter(c / g.C, pos_taps(c / g.C), c % g.C, v); return; }
+    auto scatter_view = [&](int c, float v) GEN_INL {
+        float gx, gy;
+        view_grid(gx, gy);
+        gen_scatter(sc, g.np, g.Cv, gx, gy, c, v, gp.g[g.np]);
+    };
+    auto pos_value = [&](int d, int c) GEN_INL { float gx, gy; pos_grid(d, gx, gy); return gen_sample(sc, d, g.C, gx, gy, c); };
+    auto scatter_pos = [&](int c, float v) GEN_INL {                 // combine_pos_planes transposed, column c of its result
+        if (g.proj == 2) { scatter_plane(c / g.C, c % g.C, v); return; }
         const float f = g.proj == 1 ? v / (float)g.np : v;
-        for (int d = 0; d < g.np; ++d) scatter(d, pos_taps(d), c, f);
+        for (int d = 0; d < g.np; ++d) scatter_plane(d, c, f);
     };
-    auto combined_pos = [&](int c) {
-        if (g.proj == 2) return gen_blend(sc.plane[c / g.C], pos_taps(c / g.C), c % g.C);
-        float s = gen_blend(sc.plane[0], pos_taps(0), c);
-        for (int d = 1; d < g.np; ++d) s = __fadd_rn(s, gen_blend(sc.plane[d], pos_taps(d), c));
+    auto combined_pos = [&](int c) GEN_INL {
+        if (g.proj == 2) return pos_value(c / g.C, c % g.C);
+        float s = pos_value(0, c);
+        for (int d = 1; d < g.np; ++d) s = __fadd_rn(s, pos_value(d, c));
         return g.proj == 1 ? __fdiv_rn(s, (float)g.np) : s;
     };
     if (j < g.Kd) { scatter_pos(j, dXd[p * g.Kd + j]); return; }
     const int c = j - g.Kd;
     const float v = dXr[p * g.Kr + c];
     if (g.view == 4) {
-        if (c < g.np * g.C) scatter(c / g.C, pos_taps(c / g.C), c % g.C, v);
-        else scatter(g.np, view_taps(), c - g.np * g.C, v);
+        if (c < g.np * g.C) scatter_plane(c / g.C, c % g.C, v);
+        else scatter_view(c - g.np * g.C, v);
     } else if (g.view == 3) {
         if (c < g.Kd) scatter_pos(c, v);
-        else scatter(g.np, view_taps(), c - g.Kd, v);
+        else scatter_view(c - g.Kd, v);
     } else if (g.view == 0) {
         scatter_pos(c, v);
-        scatter(g.np, view_taps(), c, v);
+        scatter_view(c, v);
     } else if (g.view == 1) {
         scatter_pos(c, v * 0.5f);
-        scatter(g.np, view_taps(), c, v * 0.5f);
+        scatter_view(c, v * 0.5f);
     } else {                                                 // mult: pp * (1 + vv)
-        const GenTaps tv = view_taps();
-        const float pp = combined_pos(c), vv = gen_blend(sc.plane[g.np], tv, c);
+        float gx, gy;
+        view_grid(gx, gy);
+        const float pp = combined_pos(c), vv = gen_sample(sc, g.np, g.Cv, gx, gy, c);
         scatter_pos(c, v * __fadd_rn(1.0f, vv));
-        scatter(g.np, tv, c, v * pp);
+        scatter_view(c, v * pp);
     }
 }
 

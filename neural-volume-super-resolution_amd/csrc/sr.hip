@@ -793,20 +793,33 @@ __global__ void sr_prepare_kernel(const float* __restrict__ lr, int Cc, int R0, 
 }
 
 // PlanesSR output (models.py:915-923): canvas = NaN; canvas[roi] = difference[over:-over] + bilinear_x{sf}(LR)[roi]
-// (F.interpolate(mode='bilinear', align_corners=PlanesSR.align_corners), :858-859)
+// (F.interpolate(mode=PlanesSR.plane_interp, align_corners=PlanesSR.align_corners), :858-859)
 __global__ void sr_finish_kernel(const float* __restrict__ diff, int Ho, int Wo, int over, const float* __restrict__ lr, int Cc, int R0,
-                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out, unsigned* __restrict__ flag, int align) {
+                                 int R1, int sf, int lo0, int lo1, int hi0, int hi1, float* __restrict__ out, unsigned* __restrict__ flag, int align,
+                                 int bicubic) {
     const int HR0 = R0 * sf, HR1 = R1 * sf;
     const long n = (long)Cc * HR0 * HR1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int ox = (int)(i % HR1), oy = (int)((i / HR1) % HR0), c = (int)(i / ((long)HR1 * HR0));
     if (oy < lo0 * sf || oy >= hi0 * sf || ox < lo1 * sf || ox >= hi1 * sf) { out[i] = __builtin_nanf(""); return; }
-    const BilinearTap ty = bilinear_tap(oy, R0, HR0, sf, align), tx = bilinear_tap(ox, R1, HR1, sf, align);
-    const int y0 = ty.i0, x0 = tx.i0, yp = ty.step, xp = tx.step;
-    const float ly1 = ty.w1, ly0 = 1.0f - ly1, lx1 = tx.w1, lx0 = 1.0f - lx1;
-    const float* q = lr + ((long)c * R0 + y0) * R1 + x0;
-    const float res = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * R1] + lx1 * q[(long)yp * R1 + xp]);
+    float res;
+    if (bicubic) {
+        const CubicTap ty = cubic_tap(oy, R0, HR0, sf, align), tx = cubic_tap(ox, R1, HR1, sf, align);
+        const float* pc = lr + (long)c * R0 * R1;
+        res = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* row = pc + (long)ty.i[i] * R1;
+            res += (row[tx.i[0]] * tx.w[0] + row[tx.i[1]] * tx.w[1] + row[tx.i[2]] * tx.w[2] + row[tx.i[3]] * tx.w[3]) * ty.w[i];
+        }
+    } else {
+        const BilinearTap ty = bilinear_tap(oy, R0, HR0, sf, align), tx = bilinear_tap(ox, R1, HR1, sf, align);
+        const int y0 = ty.i0, x0 = tx.i0, yp = ty.step, xp = tx.step;
+        const float ly1 = ty.w1, ly0 = 1.0f - ly1, lx1 = tx.w1, lx0 = 1.0f - lx1;
+        const float* q = lr + ((long)c * R0 + y0) * R1 + x0;
+        res = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * R1] + lx1 * q[(long)yp * R1 + xp]);
+    }
     const int dy = oy - lo0 * sf + over, dx = ox - lo1 * sf + over;
     const float v = diff[((long)c * Ho + dy) * Wo + dx] + res;
     out[i] = v;
@@ -820,6 +833,14 @@ static int g_sr_align_corners = 1;
 int sr_align_corners() { return g_sr_align_corners; }
 extern "C" int nvsr_set_sr_align_corners(int align_corners) { g_sr_align_corners = align_corners ? 1 : 0; return NVSR_OK; }
 extern "C" int nvsr_get_sr_align_corners(void) { return g_sr_align_corners; }
+static int g_sr_bicubic = 0;
+int sr_bicubic() { return g_sr_bicubic; }
+extern "C" int nvsr_set_sr_plane_interp(int plane_interp) {
+    if (plane_interp != NVSR_PLANE_INTERP_BILINEAR && plane_interp != NVSR_PLANE_INTERP_BICUBIC) return NVSR_ERR_SHAPE;
+    g_sr_bicubic = plane_interp == NVSR_PLANE_INTERP_BICUBIC;
+    return NVSR_OK;
+}
+extern "C" int nvsr_get_sr_plane_interp(void) { return g_sr_bicubic ? NVSR_PLANE_INTERP_BICUBIC : NVSR_PLANE_INTERP_BILINEAR; }
 
 // arithmetic of the eligible conv layers (process-wide): -1 = not yet read from the environment
 static int g_conv_arithmetic = -1;
@@ -1268,7 +1289,7 @@ int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, in
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
                            Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b], conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr,
-                           sr_align_corners());
+                           sr_align_corners(), sr_bicubic());
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
     return NVSR_OK;
@@ -1339,7 +1360,7 @@ static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* 
     } else if (int e = nvsr_edsr_forward_batch_arith(xin, 1, Cc, Hp, Wp, packed, Cc, hid, nblocks, n_up, diff, ews, arithmetic, stream_)) return e;
     const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
-                       lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr, sr_align_corners());
+                       lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr, sr_align_corners(), sr_bicubic());
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -516,7 +516,7 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ g, int Cc, int 
 // PlanesSR backward, output side (models.py:915-923): d_out [C][sf R0][sf R1] -> d_diff [C][Ho][Wo] (zero in the over-padding
 // ring) and, when d_lr != NULL, the bilinear residual's share of d_lr (4 float atomics per HR pixel of the ROI)
 __global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int Cc, int R0, int R1, int sf, int lo0, int lo1, int hi0, int hi1,
-                                          int Ho, int Wo, int over, float* __restrict__ d_diff, float* __restrict__ d_lr, int align) {
+                                          int Ho, int Wo, int over, float* __restrict__ d_diff, float* __restrict__ d_lr, int align, int bicubic) {
     const long n = (long)Cc * Ho * Wo;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -529,6 +529,15 @@ __global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int C
     const float g = d_out[((long)c * HR0 + oy) * HR1 + ox];
     d_diff[i] = g;
     if (!d_lr) return;
+    if (bicubic) {
+        const CubicTap ty = cubic_tap(oy, R0, HR0, sf, align), tx = cubic_tap(ox, R1, HR1, sf, align);
+        float* pc = d_lr + (long)c * R0 * R1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unsafeAtomicAdd(pc + (long)ty.i[i] * R1 + tx.i[k], g * (tx.w[k] * ty.w[i]));
+        return;
+    }
     const BilinearTap ty = bilinear_tap(oy, R0, HR0, sf, align), tx = bilinear_tap(ox, R1, HR1, sf, align);
     const int y0 = ty.i0, x0 = tx.i0, yp = ty.step, xp = tx.step;
     const float ly1 = ty.w1, ly0 = 1.0f - ly1, lx1 = tx.w1, lx0 = 1.0f - lx1;
@@ -790,7 +799,7 @@ int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, con
     float* dxin = d_diff + (n_diff + 3) / 4 * 4;
     float* ews = dxin + (n_in + 3) / 4 * 4;
     hipLaunchKernelGGL(sr_finish_backward_kernel, dim3((unsigned)((n_diff + 255) / 256)), dim3(256), 0, stream, d_out, Cc, R0, R1, sf, lo[0],
-                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr, sr_align_corners());
+                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr, sr_align_corners(), sr_bicubic());
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     const float* xin = keep;
     const float* acts = keep + (n_in + 3) / 4 * 4;

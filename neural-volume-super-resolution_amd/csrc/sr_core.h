@@ -24,8 +24,30 @@ __device__ __forceinline__ BilinearTap bilinear_tap(int o, int in, int out, int 
     t.w1 = fminf(fmaxf(src - (float)t.i0, 0.0f), 1.0f);
     return t;
 }
-// process-wide: align_corners of PlanesSR's bilinear residual (sr.hip: nvsr_set_sr_align_corners)
+// The same for mode='bicubic' (UpSample.h: area_pixel_compute_source_index with cubic = true -- no clamp at 0 --, the four taps floor - 1 ..
+// floor + 2 clamped to the axis, cubic convolution weights with A = -0.75)
+struct CubicTap { int i[4]; float w[4]; };
+__device__ __forceinline__ CubicTap cubic_tap(int o, int in, int out, int sf, int align) {
+    float src;
+    if (align) src = (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f) * (float)o;
+    else src = __fsub_rn(__fmul_rn((float)(1.0 / (double)sf), (float)o + 0.5f), 0.5f);
+    const float fl = floorf(src);
+    const float t = fminf(fmaxf(src - fl, 0.0f), 1.0f);
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = x2 + 1.0f;
+    CubicTap c;
+    c.w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c.w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    c.w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c.w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+    const int i0 = (int)fl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.i[k] = min(max(i0 - 1 + k, 0), in - 1);
+    return c;
+}
+// process-wide: align_corners and mode of PlanesSR's residual up-sampling (sr.hip: nvsr_set_sr_align_corners, nvsr_set_sr_plane_interp)
 int sr_align_corners();
+int sr_bicubic();
 
 
 // f16-limb data / weight gradients of the SR network: the power of two that puts the largest |dy| of a gradient tensor (its bits in

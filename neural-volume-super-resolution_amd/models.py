@@ -316,9 +316,9 @@ class TwoDimPlanesModel(nn.Module):
         """[plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every, proj, view] for
         torch.ops.nvsr.triplane_decode_generic (struct nvsr_decoder_geometry)"""
         if not (self.use_viewdirs and 1 <= self.num_density_planes <= capi.MAX_POSITION_PLANES and self.ensemble_size == 1
-                and self.rgb_dec_input == "projections" and self.plane_interp == "bilinear"):
+                and self.rgb_dec_input == "projections" and self.plane_interp in ("bilinear", "bicubic")):
             raise NotImplementedError("the generic decoder kernels cover use_viewdirs=True, 1 .. %d position planes, ensemble_size 1, "
-                                      "rgb_dec_input='projections' and bilinear planes" % capi.MAX_POSITION_PLANES)
+                                      "rgb_dec_input='projections' and bilinear / bicubic planes" % capi.MAX_POSITION_PLANES)
         return [self.num_plane_channels, self.num_viewdir_plane_channels, self.dec_channels, self.dec_density_layers, self.dec_rgb_layers,
                 int(self.skip_connect_every or 0), {"sum": 0, "avg": 1, "concat": 2}[self.proj_combination],
                 {"sum": 0, "avg": 1, "mult": 2, "concat": 3, "concat_pos": 4}[self.viewdir_proj_combination]]
@@ -450,7 +450,8 @@ class TwoDimPlanesModel(nn.Module):
         planes, consts = self.scene_args(planes=planes, check_native=False)
         nat = self.natural_blob()
         capi.require_cuda(nat)
-        return torch.ops.nvsr.triplane_decode_generic(planes, consts, nat, self.generic_geometry(), x, bool(self.align_corners), coord_noise)
+        return torch.ops.nvsr.triplane_decode_generic(planes, consts, nat, self.generic_geometry(), x, bool(self.align_corners), coord_noise,
+                                                      self.plane_interp == "bicubic")
 
     def scene_args(self, planes=None, check_native=True):
         """(planes, consts) of the current scene id as the torch.ops.nvsr operators take them: the channel-last planes (position planes, then
@@ -609,18 +610,19 @@ class _GenericDecodeFn(torch.autograd.Function):
         capi.require_cuda(natural)
         geometry = model.generic_geometry()
         ctx.plane_srcs = plane_srcs
-        ctx.state = (planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise)
-        return torch.ops.nvsr.triplane_decode_generic(planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise)
+        bicubic = model.plane_interp == "bicubic"
+        ctx.state = (planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise, bicubic)
+        return torch.ops.nvsr.triplane_decode_generic(planes_cl, consts, natural, geometry, x, bool(model.align_corners), coord_noise, bicubic)
 
     @staticmethod
     def backward(ctx, g_out):
-        planes_cl, consts, natural, geometry, x, align, coord_noise = ctx.state
+        planes_cl, consts, natural, geometry, x, align, coord_noise, bicubic = ctx.state
         need = ctx.needs_input_grad
         need_planes = [bool(n) for n in need[4:]]
         if not any(need_planes) and not need[2]:
             return (None,) * len(need)
         g = torch.ops.nvsr.triplane_decode_generic_backward(planes_cl, consts, natural, geometry, x, capi.f32c(g_out), bool(need[2]), need_planes,
-                                                            align, coord_noise)
+                                                            align, coord_noise, bicubic)
         return (None, None, g[0] if need[2] else None, None) + \
                tuple(from_channel_last(gp, like=p_) if n else None for gp, p_, n in zip(g[1:], ctx.plane_srcs, need_planes))
 
@@ -776,8 +778,8 @@ class PlanesSR(nn.Module):
         self.plane_interp = plane_interp
         self.input_noise = _cfg_get(sr_config, "sr_input_noise", 0)
         self.output_noise = _cfg_get(sr_config, "sr_output_noise", 0)
-        if plane_interp != "bilinear":
-            raise NotImplementedError("PlanesSR kernels implement the bilinear residual up-sampling of the shipped configs")
+        if plane_interp not in ("bilinear", "bicubic"):
+            raise NotImplementedError("PlanesSR kernels implement the bilinear and bicubic residual up-sampling (config/TrainModels.yml:72,172)")
         self.inner_model = model_arch(in_channels=in_channels, out_channels=out_channels, hidden_size=hidden_size, n_blocks=n_blocks,
                                       scale_factor=scale_factor, padding=0,
                                       receptive_field_bound=_cfg_get(model_cfg, "receptive_field_bound", np.iinfo(np.int32).max))
@@ -846,7 +848,8 @@ class PlanesSR(nn.Module):
         if capi.lib().nvsr_planes_sr_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, None) < 0:
             return
         outs = torch.ops.nvsr.planes_sr([t.reshape(Cc, R0, R1) for t in lrs], self.inner_model.packed_weights(), list(self.inner_model.geometry),
-                                        pad, over, None, mean, std, self.inner_model.arith(), bool(self.align_corners))
+                                        pad, over, None, mean, std, self.inner_model.arith(), bool(self.align_corners),
+                                        self.plane_interp == "bicubic")
         for n, o in zip(todo, outs):
             self.SR_planes[n] = o
 
@@ -908,10 +911,10 @@ class PlanesSR(nn.Module):
             net = self.inner_model
             out, _ = torch.ops.nvsr.planes_sr_train(lr_src if lr_src.dtype == torch.float32 else lr_src.float(), net.natural_blob(differentiable=True),
                                                     net.packed_weights(), net.packed_dgrad_weights(), geometry, pad, over, roi, mean, std,
-                                                    capi.resolve_conv_arithmetic(net.arithmetic), bool(self.align_corners))
+                                                    capi.resolve_conv_arithmetic(net.arithmetic), bool(self.align_corners), self.plane_interp == "bicubic")
             return self._apply_training_noise(out, noise_in, lr_clean) if noisy else out
         out = torch.ops.nvsr.planes_sr([lr.reshape(Cc, R0, R1)], self.inner_model.packed_weights(), geometry, pad, over, roi, mean, std,
-                                       self.inner_model.arith(), bool(self.align_corners))[0]
+                                       self.inner_model.arith(), bool(self.align_corners), self.plane_interp == "bicubic")[0]
         if noisy:
             return self._apply_training_noise(out, noise_in, lr_clean)          # (like the reference, a noisy plane is never cached: training only)
         if full_plane:

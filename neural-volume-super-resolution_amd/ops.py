@@ -193,14 +193,14 @@ def _(planes, consts, packed, x, arith=-1):
     return x.new_empty((x.shape[0], 4))
 
 
-def _scene_ext(planes, consts, channels, align_corners):
+def _scene_ext(planes, consts, channels, align_corners, bicubic=False):
     """struct nvsr_scene_ext from N + 1 channel-last planes (N position planes, then the view-direction plane) + 10 + 6 N host constants
     (lo, range, the N 3x2 projections)"""
     n_pos = len(planes) - 1
     assert 1 <= n_pos <= capi.MAX_POSITION_PLANES, "1 .. %d position planes" % capi.MAX_POSITION_PLANES
     assert len(consts) == 10 + 6 * n_pos, "scene constants: lo[5], range[5] and a 3x2 projection per position plane"
     sc = capi.SceneExt()
-    sc.num_position_planes, sc.align_corners = n_pos, int(bool(align_corners))
+    sc.num_position_planes, sc.align_corners, sc.plane_interp = n_pos, int(bool(align_corners)), int(bool(bicubic))
     for d, p in enumerate(planes):
         capi.require_cuda(p)
         cc = channels[0 if d < n_pos else 1]
@@ -216,7 +216,7 @@ def _scene_ext(planes, consts, channels, align_corners):
     return sc
 
 
-def _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P):
+def _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P, bicubic=False):
     geo = capi.DecoderGeometry(*[int(v) for v in geometry])
     n_pos = len(planes) - 1
     n = capi.lib().nvsr_generic_decoder_natural_floats_ext(C.byref(geo), n_pos)
@@ -226,22 +226,22 @@ def _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise
     if coord_noise is not None:
         assert tuple(coord_noise.shape) == (P, 3) and coord_noise.dtype == torch.float32, "coord_noise: [P,3] f32"
         capi.require_cuda(coord_noise)
-    return geo, n_pos, n, _scene_ext(planes, consts, (geo.plane_channels, geo.viewdir_channels), align_corners)
+    return geo, n_pos, n, _scene_ext(planes, consts, (geo.plane_channels, geo.viewdir_channels), align_corners, bicubic)
 
 
 @custom_op("nvsr::triplane_decode_generic", mutates_args=(), device_types="cuda")
 def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor,
-                            align_corners: bool = True, coord_noise: Optional[Tensor] = None) -> Tensor:
+                            align_corners: bool = True, coord_noise: Optional[Tensor] = None, bicubic: bool = False) -> Tensor:
     """TwoDimPlanesModel.forward for ANY decoder geometry the reference's layer sizes admit (csrc/generic.hip).
     geometry = [plane_channels, viewdir_channels, hidden, density_layers, rgb_layers, skip_connect_every (0 = None), proj_combination
     (0 sum, 1 avg, 2 concat), viewdir_combination (0 sum, 1 avg, 2 mult, 3 concat, 4 concat_pos)]; natural = the parameters in
     state-dict order; planes channel-last: N position planes [H,W,plane_channels], then [H,W,viewdir_channels]; consts = lo[5], range[5],
-    N 3x2 projections; align_corners: grid_sample's; coord_noise [P,3]: added to the normalised positions (point_coords_noise,
-    models.py:291-293)."""
+    N 3x2 projections; align_corners / bicubic: grid_sample's align_corners and mode; coord_noise [P,3]: added to the normalised positions
+    (point_coords_noise, models.py:291-293)."""
     x, natural = _c(x), _c(natural)
     P = x.shape[0]
     coord_noise = None if coord_noise is None else _c(coord_noise)
-    geo, n_pos, _, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P)
+    geo, n_pos, _, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P, bicubic)
     out = _f(P, 4, like=x)
     if P:
         ws = _f(capi.lib().nvsr_generic_decode_workspace_floats_ext(C.byref(geo), n_pos, P), like=x)
@@ -251,20 +251,20 @@ def triplane_decode_generic(planes: Sequence[Tensor], consts: Sequence[float], n
 
 
 @triplane_decode_generic.register_fake
-def _(planes, consts, natural, geometry, x, align_corners=True, coord_noise=None):
+def _(planes, consts, natural, geometry, x, align_corners=True, coord_noise=None, bicubic=False):
     return x.new_empty((x.shape[0], 4))
 
 
 @custom_op("nvsr::triplane_decode_generic_backward", mutates_args=(), device_types="cuda")
 def triplane_decode_generic_backward(planes: Sequence[Tensor], consts: Sequence[float], natural: Tensor, geometry: Sequence[int], x: Tensor,
                                      g_out: Tensor, want_natural: bool, want_planes: Sequence[bool], align_corners: bool = True,
-                                     coord_noise: Optional[Tensor] = None) -> List[Tensor]:
+                                     coord_noise: Optional[Tensor] = None, bicubic: bool = False) -> List[Tensor]:
     """Backward of triplane_decode_generic (csrc/generic.hip; the reference: torch.autograd through models.py:381-421): g_out [P,4] ->
     [d_natural, d_plane0 .. d_planeN] (channel-last like the planes; a gradient that is not wanted comes back as an empty tensor)."""
     x, natural, g_out = _c(x), _c(natural), _c(g_out)
     P = x.shape[0]
     coord_noise = None if coord_noise is None else _c(coord_noise)
-    geo, n_pos, n, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P)
+    geo, n_pos, n, sc = _generic_setup(planes, consts, natural, geometry, align_corners, coord_noise, P, bicubic)
     assert tuple(g_out.shape) == (P, 4)
     want_planes = [bool(w) for w in want_planes]
     assert len(want_planes) == n_pos + 1
@@ -280,7 +280,7 @@ def triplane_decode_generic_backward(planes: Sequence[Tensor], consts: Sequence[
 
 
 @triplane_decode_generic_backward.register_fake
-def _(planes, consts, natural, geometry, x, g_out, want_natural, want_planes, align_corners=True, coord_noise=None):
+def _(planes, consts, natural, geometry, x, g_out, want_natural, want_planes, align_corners=True, coord_noise=None, bicubic=False):
     return [natural.new_empty(natural.numel() if want_natural else 0)] + [pl.new_empty(pl.shape if w else (0,)) for pl, w in zip(planes, want_planes)]
 
 
@@ -715,13 +715,19 @@ def _edsr_train_bwd(ctx, d_out, d_acts):
 edsr_train.register_autograd(_edsr_train_bwd, setup_context=_edsr_train_setup)
 
 
+def _sr_residual(align_corners, bicubic):
+    """PlanesSR's residual up-sampling for the nvsr_planes_sr* call that follows (library state, like the conv arithmetic)"""
+    capi.lib().nvsr_set_sr_align_corners(int(bool(align_corners)))
+    capi.lib().nvsr_set_sr_plane_interp(int(bool(bicubic)))
+
+
 def _roi_c(roi):
     return None if roi is None else (C.c_float * 4)(*[float(v) for v in roi])
 
 
 @custom_op("nvsr::planes_sr", mutates_args=(), device_types="cuda")
 def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad: int, over: int, roi: Optional[Sequence[float]],
-              mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int, align_corners: bool = True) -> List[Tensor]:
+              mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int, align_corners: bool = True, bicubic: bool = False) -> List[Tensor]:
     """PlanesSR.forward for B equally sized LR planes [C,R0,R1] in ONE batched pass: crop + replicate pad -> EDSR -> crop over-padding
     -> + bilinear x sf of the LR plane (F.interpolate's align_corners as given), NaN outside the ROI.  roi: None (full plane) or
     [ymin, xmin, ymax, xmax] in [-1, 1].  -> B tensors [1,C,sf R0,sf R1]"""
@@ -737,7 +743,7 @@ def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad
     sf = 1 << n_up
     outs = [_f(1, Cc, R0 * sf, R1 * sf, like=lr[0]) for _ in lr]
     ws = _f(B * nws, like=lr[0])
-    capi.lib().nvsr_set_sr_align_corners(int(bool(align_corners)))       # (library state, like the conv arithmetic: set for the call that follows)
+    _sr_residual(align_corners, bicubic)
     if B == 1:
         capi.call("nvsr_planes_sr_arith", capi.ptr(lr[0]), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
                   capi.ptr(std), capi.ptr(outs[0]), capi.ptr(ws), arithmetic, capi.stream())
@@ -750,7 +756,7 @@ def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad
 
 
 @planes_sr.register_fake
-def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True):
+def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True, bicubic=False):
     sf = 1 << geometry[4]
     Cc, R0, R1 = lr[0].shape[-3:]
     return [t.new_empty((1, Cc, R0 * sf, R1 * sf)) for t in lr]
@@ -759,7 +765,7 @@ def _(lr, packed, geometry, pad, over, roi, mean, std, arithmetic, align_corners
 @custom_op("nvsr::planes_sr_train", mutates_args=(), device_types="cuda")
 def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: Tensor, geometry: Sequence[int], pad: int, over: int,
                     roi: Optional[Sequence[float]], mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int,
-                    align_corners: bool = True) -> Tuple[Tensor, Tensor]:
+                    align_corners: bool = True, bicubic: bool = False) -> Tuple[Tensor, Tensor]:
     """planes_sr of one plane that keeps the prepared input + activation record (`keep`); differentiable in `lr` and `natural`"""
     lr = _c(lr)
     cin, cout, hid, nb, n_up = geometry
@@ -772,14 +778,14 @@ def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: T
         raise capi.NvsrError("PlanesSR: region of interest too small for the network")
     sf = 1 << n_up
     out, ws, keep = _f(1, Cc, R0 * sf, R1 * sf, like=lr), _f(nws, like=lr), _f(nkeep, like=lr)
-    lib.nvsr_set_sr_align_corners(int(bool(align_corners)))
+    _sr_residual(align_corners, bicubic)
     capi.call("nvsr_planes_sr_train_arith", capi.ptr(lr), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
               capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), arithmetic, capi.stream())
     return out, keep
 
 
 @planes_sr_train.register_fake
-def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True):
+def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners=True, bicubic=False):
     cin, cout, hid, nb, n_up = geometry
     sf = 1 << n_up
     Cc, R0, R1 = lr.shape[-3:]
@@ -790,7 +796,7 @@ def _(lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, ar
 @custom_op("nvsr::planes_sr_backward", mutates_args=(), device_types="cuda")
 def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence[int], geometry: Sequence[int], pad: int, over: int,
                        roi: Optional[Sequence[float]], std: Optional[Tensor], d_out: Tensor, need_lr: bool, arithmetic: int,
-                       align_corners: bool = True) -> Tuple[Tensor, Tensor]:
+                       align_corners: bool = True, bicubic: bool = False) -> Tuple[Tensor, Tensor]:
     """-> (EDSR weight gradients in state-dict order, d_lr [1,C,R0,R1] (empty unless need_lr))"""
     d_out = _c(d_out)
     cin, cout, hid, nb, n_up = geometry
@@ -800,14 +806,14 @@ def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence
     gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
     d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if need_lr else _f(0, like=keep)
     ws = _f(lib.nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c), like=keep)
-    lib.nvsr_set_sr_align_corners(int(bool(align_corners)))
+    _sr_residual(align_corners, bicubic)
     capi.call("nvsr_planes_sr_backward_arith", Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, roi_c, capi.ptr(std),
               capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr) if need_lr else None, capi.ptr(ws), arithmetic, capi.stream())
     return gnat, d_lr
 
 
 @planes_sr_backward.register_fake
-def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, need_lr, arithmetic, align_corners=True):
+def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, need_lr, arithmetic, align_corners=True, bicubic=False):
     cin, cout, hid, nb, n_up = geometry
     n = 9 * (hid * cin + (2 * nb + 1) * hid * hid + n_up * 4 * hid * hid + cout * hid)
     Cc, R0, R1 = plane_shape
@@ -815,18 +821,18 @@ def _(keep, packed_dgrad, plane_shape, geometry, pad, over, roi, std, d_out, nee
 
 
 def _planes_sr_train_setup(ctx, inputs, output):
-    lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners = inputs
+    lr, natural, packed, packed_dgrad, geometry, pad, over, roi, mean, std, arithmetic, align_corners, bicubic = inputs
     ctx.save_for_backward(output[1], packed_dgrad, std)
     ctx.mark_non_differentiable(output[1])
-    ctx.args = (list(lr.shape[-3:]), list(geometry), pad, over, None if roi is None else list(roi), arithmetic, lr.shape, bool(align_corners))
+    ctx.args = (list(lr.shape[-3:]), list(geometry), pad, over, None if roi is None else list(roi), arithmetic, lr.shape, bool(align_corners), bool(bicubic))
 
 
 def _planes_sr_train_bwd(ctx, d_out, d_keep):
     keep, packed_dgrad, std = ctx.saved_tensors
-    shape, geometry, pad, over, roi, arithmetic, lr_shape, align_corners = ctx.args
+    shape, geometry, pad, over, roi, arithmetic, lr_shape, align_corners, bicubic = ctx.args
     gnat, d_lr = torch.ops.nvsr.planes_sr_backward(keep, packed_dgrad, shape, geometry, pad, over, roi, std, capi.f32c(d_out),
-                                                   ctx.needs_input_grad[0], arithmetic, align_corners)
-    return ((d_lr.reshape(lr_shape) if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None)) + (None,) * 10
+                                                   ctx.needs_input_grad[0], arithmetic, align_corners, bicubic)
+    return ((d_lr.reshape(lr_shape) if ctx.needs_input_grad[0] else None), (gnat if ctx.needs_input_grad[1] else None)) + (None,) * 11
 
 
 planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr_train_setup)

@@ -34,8 +34,38 @@ def _bilinear(plane, gx, gy, align_corners=True):
     return out.T                                                   # [P,C]
 
 
+def _cubic_coefficients(t):
+    """UpSample.h get_cubic_upsample_coefficients, A = -0.75"""
+    A = -0.75
+    x0, x1, x2, x3 = t + 1.0, t, 1.0 - t, 2.0 - t
+    return [((A * x0 - 5 * A) * x0 + 8 * A) * x0 - 4 * A, ((A + 2) * x1 - (A + 3)) * x1 * x1 + 1, ((A + 2) * x2 - (A + 3)) * x2 * x2 + 1,
+            ((A * x3 - 5 * A) * x3 + 8 * A) * x3 - 4 * A]
+
+
+def _bicubic(plane, gx, gy, align_corners=True):
+    """F.grid_sample(mode='bicubic', padding_mode='border'): the coordinate is unnormalised and NOT clipped, the 4 x 4 taps start at floor - 1
+    and each tap's index is clipped to the plane (ATen GridSampler.h get_value_bounded)"""
+    C, H, W = plane.shape[-3:]
+    p = plane.reshape(C, H, W).astype(np.float64)
+    if align_corners:
+        x, y = (gx + 1.0) * 0.5 * (W - 1), (gy + 1.0) * 0.5 * (H - 1)
+    else:
+        x, y = ((gx + 1.0) * W - 1.0) * 0.5, ((gy + 1.0) * H - 1.0) * 0.5
+    fx, fy = np.floor(x), np.floor(y)
+    cx, cy = _cubic_coefficients(x - fx), _cubic_coefficients(y - fy)
+    out = 0.0
+    for i in range(4):
+        yi = np.clip(fy - 1 + i, 0, H - 1).astype(np.int64)
+        row = 0.0
+        for j in range(4):
+            xi = np.clip(fx - 1 + j, 0, W - 1).astype(np.int64)
+            row = row + p[:, yi, xi] * cx[j]
+        out = out + row * cy[i]
+    return out.T
+
+
 def decode(sd, planes, box, x, use_viewdirs=True, dec_density_layers=4, dec_rgb_layers=4, skip_connect_every=None, proj_combination="sum",
-           viewdir_proj_combination=None, prefix="", align_corners=True, coord_noise=None, **_ignored):
+           viewdir_proj_combination=None, prefix="", align_corners=True, coord_noise=None, plane_interp="bilinear", **_ignored):
     """sd: state dict (numpy arrays, reference key names); planes: the position planes then the view-direction plane, [1,C,R,R] each;
     box [2,5]; x [P,6] = [xyz, viewdir] -> [P,4].  coord_noise [P,3]: the jitter a training-mode call adds to the normalised positions."""
     assert use_viewdirs
@@ -52,12 +82,13 @@ def decode(sd, planes, box, x, use_viewdirs=True, dec_density_layers=4, dec_rgb_
     if coord_noise is not None:
         n5[:, :3] = n5[:, :3] + np.asarray(coord_noise, np.float32)
     n5 = n5.astype(np.float64)
+    sample = _bicubic if plane_interp == "bicubic" else _bilinear
     pos, n_pos = [], len(planes) - 1
     for dnum in range(n_pos):
         rot = np.asarray(sd[prefix + "coord_projector.rot_mats_NON_LEARNED.%d" % dnum]).astype(np.float32).astype(np.float64)   # (.type(float32) in forward)
         g = n5[:, :3] @ rot[:, 1:]
-        pos.append(_bilinear(np.asarray(planes[dnum]), g[:, 0], g[:, 1], align_corners))
-    view = _bilinear(np.asarray(planes[n_pos]), n5[:, 3], n5[:, 4], align_corners)
+        pos.append(sample(np.asarray(planes[dnum]), g[:, 0], g[:, 1], align_corners))
+    view = sample(np.asarray(planes[n_pos]), n5[:, 3], n5[:, 4], align_corners)
 
     def combine_pos(ts):
         if proj_combination == "sum":

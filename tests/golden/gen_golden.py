@@ -1171,6 +1171,8 @@ def g22_model_options():
                    gradients; and run_one_iter_of_nerf(mode='train') with perturb + density noise over several ray chunks and network
                    batches -- every random tensor in the order the reference draws it
       sr_align_false  PlanesSR(align_corners=False): the bilinear residual F.interpolate(..., align_corners=False) (models.py:858-859)
+      bicubic[_noalign], sr_bicubic[_noalign]  plane_interp='bicubic': grid_sample(mode='bicubic') in the planes model, F.interpolate(mode='bicubic')
+                   as PlanesSR's residual
       rf_bound     EDSR(receptive_field_bound=8): a mix of 3 x 3 and 1 x 1 convolutions (models.py:793-798), alone and inside PlanesSR"""
     arrs = {}
     P = 157
@@ -1204,6 +1206,12 @@ def g22_model_options():
     sid, mc, mf, planes, box = _g22_models(9, 5, 221, align_corners=False, dec_channels=64)
     mc.eval()
     fwd_and_grads("align_false.", mc, planes, sid, points(2210), 3)
+
+    # ---- plane_interp='bicubic' (config/TrainModels.yml:72 lists it beside 'bilinear'), with and without align_corners ---------------------
+    for tag, align in (("bicubic", True), ("bicubic_noalign", False)):
+        sid, mc, mf, planes, box = _g22_models(9, 5, 224 + int(align), plane_interp="bicubic", align_corners=align, dec_channels=64)
+        mc.eval()
+        fwd_and_grads(tag + ".", mc, planes, sid, points(2240 + int(align)), 3)
 
     # ---- five position planes ------------------------------------------------------------------------------------------------
     sid, mc, mf, planes, box = _g22_models(9, 5, 222, n_planes=5, dec_channels=64)
@@ -1299,6 +1307,35 @@ def g22_model_options():
         arrs.update({"sr_align_false.%s_out" % tag: npy(out).copy(), "sr_align_false.%s_gout" % tag: npy(Gp), "sr_align_false.%s_gw" % tag: gw,
                      "sr_align_false.%s_glr" % tag: npy(lrp.grad).copy()})
         sr.clear_SR_planes(all_planes=True)
+    # ---- PlanesSR with plane_interp='bicubic' (the residual is F.interpolate(mode='bicubic'), models.py:858-859), both align_corners ---------
+    for tag, align in (("sr_bicubic", True), ("sr_bicubic_noalign", False)):
+        torch.manual_seed(9)
+        C, hidden, nblocks, sf, R = 6, 16, 2, 4, 20
+        sr = models.PlanesSR(models.EDSR, sf, C, C, CfgNode({"model": {"hidden_size": hidden, "n_blocks": nblocks}}), "bicubic")
+        sr.align_corners = align
+        with torch.no_grad():
+            for p in sr.parameters():
+                p.mul_(10.0)
+        lr = torch.randn(1, C, R, R) * 0.5
+        assert np.array_equal(np.load(os.path.join(HERE, "g09_edsr.npz"))["lr"], npy(lr)), "the bicubic cases must rebuild the g09 network"
+        sr.eval()
+        sr.set_LR_plane(lr, id="p", save_interpolated=False)
+        with torch.no_grad():
+            arrs[tag + ".full"] = npy(sr("p")).copy()
+        sr.train()
+        roi = torch.tensor([[-0.35, -0.6], [0.2, 0.15]])
+        arrs[tag + ".roi"] = npy(roi)
+        lrp = nn.Parameter(lr.clone())
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lrp, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(("p", roi))
+        Gp = torch.randn(out.shape, generator=torch.Generator().manual_seed(2293))
+        valid = ~torch.isnan(out)
+        (torch.where(valid, out, torch.zeros_like(out)) * Gp).sum().backward()
+        arrs.update({tag + ".roi_out": npy(out).copy(), tag + ".roi_gout": npy(Gp), tag + ".roi_glr": npy(lrp.grad).copy(),
+                     tag + ".roi_gw": np.concatenate([npy(p.grad).reshape(-1) for _, p in sr.inner_model.named_parameters()]).astype(np.float32)})
+
     # ---- EDSR with receptive_field_bound (models.py:789-822: layers beyond the bound fall back to 1 x 1 convolutions) --------------------
     # bound 8 with 2 blocks and x4: conv_input 3x3, block 0 3x3, block 1 1x1, conv_mid 1x1, first up-scaling conv 1x1, second 3x3 (its
     # receptive-field increment is halved), conv_output 1x1

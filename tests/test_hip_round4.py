@@ -774,3 +774,49 @@ def test_one_decoder_for_both_passes_reuses_the_coarse_outputs(hip, oracle, monk
     monkeypatch.setenv("NVSR_NO_SHARED_DECODER", "1")
     b = tu.run_one_iter_of_nerf(H, W, focal, mc, mc, batch, opts, sid, mode="validation", scene_config=scfg, randoms=rnd)
     assert torch.equal(a[0], b[0]) and float((a[3] - b[3]).abs().max()) <= 2e-5
+
+
+def test_bicubic_planes_vs_reference(hip):
+    """plane_interp='bicubic' (config/TrainModels.yml:72 lists it beside 'bilinear'): grid_sample(mode='bicubic', padding_mode='border') -- the
+    coordinate is not clipped, each of the 4 x 4 taps is --, with and without align_corners: forward and the gradients of planes and decoder
+    against the reference's (g22), through the generic kernels"""
+    from conftest import load_golden
+    from test_hip_parity import N_, T
+    g = load_golden("g22_model_options.npz")
+    for name, align in (("bicubic", True), ("bicubic_noalign", False)):
+        m = _g22_model(hip, g, name, plane_interp="bicubic", align_corners=align, dec_channels=64)
+        assert not m.is_native_geometry()
+        _g22_check_forward_and_gradients(hip, g, name, m, 3)
+    m2 = _g22_model(hip, g, "bicubic", plane_interp="bilinear", dec_channels=64)
+    with torch.no_grad():
+        assert np.abs(N_(m2(T(g["bicubic.x"]))) - g["bicubic.out"]).max() > 1e-3
+
+
+def test_planes_sr_with_a_bicubic_residual_vs_reference(hip):
+    """PlanesSR(plane_interp='bicubic') (models.py:858-859: the residual is F.interpolate(mode='bicubic')), with and without align_corners: the
+    full plane in evaluation mode, a region in training mode with the gradients of the EDSR weights and of the LR plane (16 taps per HR texel),
+    against the reference (g22, the network of g09)"""
+    from conftest import load_golden
+    from test_hip_parity import N_, T, _rel, _sr_grad_blob, _sr_model
+    g9, g = load_golden("g09_edsr.npz"), load_golden("g22_model_options.npz")
+    for tag, align in (("sr_bicubic", True), ("sr_bicubic_noalign", False)):
+        sr, _ = _sr_model(hip, g9)
+        sr.plane_interp, sr.align_corners = "bicubic", align
+        sr.eval()
+        sr.set_LR_plane(T(g9["lr"]), id="p", save_interpolated=False)
+        with torch.no_grad():
+            full = N_(sr("p"))
+        np.testing.assert_allclose(full, g[tag + ".full"], rtol=0, atol=1e-5)
+        assert np.abs(full - g9["sr_full"]).max() > 1e-2
+        sr.train()
+        lr = torch.nn.Parameter(T(g9["lr"]))
+        sr.clear_SR_planes(all_planes=True)
+        sr.set_LR_plane(lr, id="p", save_interpolated=False)
+        sr.zero_grad(set_to_none=True)
+        out = sr(("p", T(g[tag + ".roi"])))
+        ref = g[tag + ".roi_out"]
+        valid = ~torch.isnan(out)
+        assert np.array_equal(N_(valid), ~np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(N_(out)), np.nan_to_num(ref), rtol=0, atol=1e-5)
+        (torch.where(valid, out, torch.zeros_like(out)) * T(g[tag + ".roi_gout"])).sum().backward()
+        assert _rel(_sr_grad_blob(sr), g[tag + ".roi_gw"]) < 2e-5 and _rel(N_(lr.grad), g[tag + ".roi_glr"]) < 2e-5, tag

@@ -385,11 +385,12 @@ def g22_variant(g, name, n_planes=3):
 
 def test_generic_decoder_restatement_of_the_unshipped_options():
     """oracle/generic_decoder.py against the reference's outputs (g22) for the TwoDimPlanesModel options no shipped YAML sets:
-    grid_sample(align_corners=False), five position planes with CoordProjector's random frames, and the training-mode jitter of the
-    sample positions (point_coords_noise; the fixture holds the jitter the seeded reference call drew)"""
+    grid_sample(align_corners=False), five position planes with CoordProjector's random frames, the training-mode jitter of the sample
+    positions (point_coords_noise; the fixture holds the jitter the seeded reference call drew), and plane_interp='bicubic'"""
     from oracle.generic_decoder import decode
     g = load_golden("g22_model_options.npz")
-    for name, n_planes, extra in (("align_false", 3, dict(align_corners=False)), ("planes5", 5, {}), ("noise", 3, dict(coord_noise=g["noise.jitter"]))):
+    for name, n_planes, extra in (("align_false", 3, dict(align_corners=False)), ("planes5", 5, {}), ("noise", 3, dict(coord_noise=g["noise.jitter"])),
+                                  ("bicubic", 3, dict(plane_interp="bicubic")), ("bicubic_noalign", 3, dict(plane_interp="bicubic", align_corners=False))):
         sd, planes = g22_variant(g, name, n_planes)
         out = decode(sd, planes, G22_BOX, g[name + ".x"], **G22_KW, **extra)
         ref = g[name + ".out"]
@@ -399,6 +400,8 @@ def test_generic_decoder_restatement_of_the_unshipped_options():
     assert np.abs(decode(sd, planes, G22_BOX, g["align_false.x"], **G22_KW) - g["align_false.out"]).max() > 1e-3
     sd, planes = g22_variant(g, "noise")
     assert np.abs(decode(sd, planes, G22_BOX, g["noise.x"], **G22_KW) - g["noise.out"]).max() > 1e-3
+    sd, planes = g22_variant(g, "bicubic")
+    assert np.abs(decode(sd, planes, G22_BOX, g["bicubic.x"], **G22_KW) - g["bicubic.out"]).max() > 1e-3
     assert abs(float(g["noise.jitter"].std()) / float(g["noise.std"]) - 1) < 0.15
     # the frames CoordProjector drew are orthonormal, and no two planes share a normal
     rots = [g["planes5.rot%d" % d] for d in range(5)]
