@@ -91,7 +91,9 @@ class _RenderRaysFn(torch.autograd.Function):
     The arithmetic the forward ran in is stored with the context and handed to every backward operator."""
 
     @staticmethod
-    def forward(ctx, cfg, p0, p1, p2, pv, nat_c, nat_f):
+    def forward(ctx, cfg, p0, p1, p2, pv, nat_c, nat_f, *coarse_leaves):
+        # coarse_leaves: the four planes the COARSE pass samples when they are other tensors than the fine pass's p0..pv -- the reference's default
+        # SR training (train_nerf.py:554-561, apply_2_coarse False): only the fine model super-resolves, the coarse model samples the LR planes
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
         nv = _NV()
         arith_c, arith_f = cfg["arith_c"], cfg["arith_f"]
@@ -136,6 +138,8 @@ class _RenderRaysFn(torch.autograd.Function):
         guarded = [t for t in list(saved.values()) + list(cfg["planes_c"]) + list(cfg["planes_f"]) + [rays, cfg["packed_c"], cfg["packed_f"]]
                    if isinstance(t, torch.Tensor)]
         ctx.save_for_backward(*guarded)
+        if not cfg["coarse_grad"] and Nf > 0:
+            ctx.mark_non_differentiable(rgb_c, disp_c, acc_c)     # the coarse pass ran under the model's optional_no_grad (train_nerf.py:560)
         return tuple(outs)
 
     @staticmethod
@@ -147,16 +151,19 @@ class _RenderRaysFn(torch.autograd.Function):
         dev = rays.device
         rd = rays[:, 3:6].contiguous()
         need = ctx.needs_input_grad
-        need_planes = [bool(n) for n in need[1:5]]
-        gplanes = [None, None, None, None]
+        sep = bool(cfg.get("separate_coarse"))                 # the coarse pass has plane leaves of its own (inputs 7..10)
+        need_planes_f = [bool(n) for n in need[1:5]]
+        need_planes_c = [bool(n) for n in need[7:11]] if sep else need_planes_f
+        gplanes_f = [None, None, None, None]
+        gplanes_c = [None, None, None, None] if sep else gplanes_f
 
-        def add_planes(gs):
-            for d, g in enumerate(gs):
-                if need_planes[d]:
-                    gplanes[d] = g if gplanes[d] is None else gplanes[d].add_(g)
+        def one_pass(S, z, raw, noise, planes, packed, packed_bwd, g_rgb, g_disp, g_acc, disp, acc, want_dec, gates, fwd_rec, arith, need_planes, gplanes):
+            """-> decoder gradient of this pass (state-dict order) or None; plane gradients are added into `gplanes`"""
+            def add_planes(gs):
+                for d, g in enumerate(gs):
+                    if need_planes[d]:
+                        gplanes[d] = g if gplanes[d] is None else gplanes[d].add_(g)
 
-        def one_pass(S, z, raw, noise, planes, packed, packed_bwd, g_rgb, g_disp, g_acc, disp, acc, want_dec, gates, fwd_rec, arith):
-            """-> decoder gradient of this pass (state-dict order) or None"""
             if (g_rgb is None and g_acc is None and g_disp is None) or (not any(need_planes) and not want_dec):
                 return None
             g_rgb = torch.zeros((N, 3), dtype=torch.float32, device=dev) if g_rgb is None else capi.f32c(g_rgb)
@@ -192,14 +199,15 @@ class _RenderRaysFn(torch.autograd.Function):
 
         gdec_c = gdec_f = None
         coarse = lambda: one_pass(Nc, sv["z_c"], sv["raw_c"], cfg["noise_c"], cfg["planes_c"], cfg["packed_c"], cfg["packed_bwd_c"], grads[0], grads[1],
-                                  grads[2], sv["disp_c"], sv["acc_c"], bool(need[5]), sv["gates_c"], sv["rec_c"], cfg["arith_c"])
+                                  grads[2], sv["disp_c"], sv["acc_c"], bool(need[5]), sv["gates_c"], sv["rec_c"], cfg["arith_c"], need_planes_c, gplanes_c)
         fine = lambda: one_pass(Nc + Nf, sv["z_f"], sv["raw_f"], cfg["noise_f"], cfg["planes_f"], cfg["packed_f"], cfg["packed_bwd_f"], grads[3], grads[4],
-                                grads[5], sv["disp_f"], sv["acc_f"], bool(need[6]), sv["gates_f"], sv["rec_f"], cfg["arith_f"])
+                                grads[5], sv["disp_f"], sv["acc_f"], bool(need[6]), sv["gates_f"], sv["rec_f"], cfg["arith_f"], need_planes_f, gplanes_f)
         # The two passes' backward kernels are independent (both ADD into the gradient planes with float atomics): the coarse pass runs on a
         # second stream, so that its workgroups fill the fine pass's partly empty rounds (same-box A/B of the planes-only iteration: eager
         # 1.683 -> 1.631 ms, replayed from a graph 1.728 -> 1.709 ms; NVSR_BWD_STREAMS=0 keeps one stream).  Planes-only passes: nothing
         # allocated on the second stream outlives the join.
-        two = (os.environ.get("NVSR_BWD_STREAMS", "1") == "1" and cfg["coarse_grad"] and Nf > 0 and dev.type == "cuda" and any(need_planes)
+        need_planes, gplanes = need_planes_f, gplanes_f
+        two = (os.environ.get("NVSR_BWD_STREAMS", "1") == "1" and not sep and cfg["coarse_grad"] and Nf > 0 and dev.type == "cuda" and any(need_planes)
                and not need[5] and not need[6] and sv["gates_c"] is not None and sv["gates_f"] is not None
                and all(a.shape == b.shape and a.stride() == b.stride() for a, b in zip(cfg["planes_c"], cfg["planes_f"])))
         if two:
@@ -227,7 +235,14 @@ class _RenderRaysFn(torch.autograd.Function):
             gdec_c = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
         if need[6] and gdec_f is None and Nf > 0:
             gdec_f = torch.zeros(capi.DECODER_NATURAL_FLOATS, dtype=torch.float32, device=dev)
-        return tuple(out) + (gdec_c, gdec_f)
+        out_c = []
+        if sep:
+            for d, src in enumerate(cfg["plane_leaves_c"]):
+                g = gplanes_c[d]
+                if need_planes_c[d] and g is None:
+                    g = torch.zeros(cfg["plane_shapes_c"][d], dtype=torch.float32, device=dev)
+                out_c.append(None if g is None else models.from_channel_last(g, like=src))
+        return tuple(out) + (gdec_c, gdec_f) + tuple(out_c)
 
 
 _SIDE_STREAMS = {}
@@ -316,17 +331,22 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         # training path (mode == "train" only; evaluation never builds a graph): gradients flow to whatever requires grad among the
         # planes of the current scene, the decoder parameters of the two models and -- through the super-resolved planes -- the SR
         # network and its LR planes
+        leaves_c = []
         if sr_on:
-            if Nf > 0 and not (hasattr(model_coarse, "SR_model") and not model_coarse.skip_SR_):
-                raise NotImplementedError("training with only one of the two models super-resolving")
             leaves = top.training_planes(rays)
             planes_f, consts = top.scene_args(planes=[models.to_channel_last(p.detach()) for p in leaves])
             planes_c = planes_f
+            if Nf > 0 and not (hasattr(model_coarse, "SR_model") and not model_coarse.skip_SR_):
+                # the reference's default (train_nerf.py:554-561, super_resolution.apply_2_coarse False): only the fine model super-resolves; the
+                # coarse pass samples the LR planes -- plane leaves of its own
+                leaves_c = model_coarse.training_planes(rays)
+                planes_c, _ = model_coarse.scene_args(planes=[models.to_channel_last(p.detach()) for p in leaves_c])
         else:
             names = [models.get_plane_name(scene_id, d) for d in range(4)]
             leaves = [top.planes_[n] for n in names]
         leaves += [model_coarse.natural_blob(differentiable=True) if dec_c_grad else None,
                    model_fine.natural_blob(differentiable=True) if dec_f_grad else None]
+        leaves += leaves_c
         coarse_grad = not isinstance(model_coarse.optional_no_grad(), torch.no_grad) if hasattr(model_coarse, "optional_no_grad") else True
         # 'f16x2': the library runs the forward of a pass whose decoder is not trained (no weight-gradient record) and every gate-driven
         # backward on 2 f16 limbs, the recording forward and the weight-gradient contraction on 3 bf16 limbs (include/nvsr.h); the gates a
@@ -334,7 +354,8 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, sc
         cfg = dict(N=N, Nc=Nc, Nf=Nf, rays=rays, lindisp=lindisp, white=white, t_rand=t_rand, u=u, noise_c=n_c, noise_f=n_f,
                    planes_c=planes_c, planes_f=planes_f, consts=consts, packed_c=packed_c, packed_f=packed_f,
                    packed_bwd_c=model_coarse.packed_decoder_bwd(), packed_bwd_f=model_fine.packed_decoder_bwd() if Nf > 0 else None,
-                   plane_shapes=[tuple(k.shape) for k in planes_f], plane_leaves=leaves[:4], coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
+                   plane_shapes=[tuple(k.shape) for k in planes_f], plane_leaves=leaves[:4], separate_coarse=bool(leaves_c),
+                   plane_shapes_c=[tuple(k.shape) for k in planes_c], plane_leaves_c=leaves_c, coarse_grad=coarse_grad, dec_c_grad=dec_c_grad,
                    dec_f_grad=dec_f_grad, arith_c=arith_c, arith_f=arith_f)
         outs = _RenderRaysFn.apply(cfg, *leaves)
         if Nf > 0:

@@ -820,3 +820,82 @@ def test_planes_sr_with_a_bicubic_residual_vs_reference(hip):
         np.testing.assert_allclose(np.nan_to_num(N_(out)), np.nan_to_num(ref), rtol=0, atol=1e-5)
         (torch.where(valid, out, torch.zeros_like(out)) * T(g[tag + ".roi_gout"])).sum().backward()
         assert _rel(_sr_grad_blob(sr), g[tag + ".roi_gw"]) < 2e-5 and _rel(N_(lr.grad), g[tag + ".roi_glr"]) < 2e-5, tag
+
+
+def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
+    """The reference's default SR training (train_nerf.py:554-561, super_resolution.apply_2_coarse False): only model_fine gets the SR model, the
+    coarse model samples the LR planes.  (a) what: ['SR'] -- the coarse pass runs under torch.no_grad (optional_no_grad) and picks the importance
+    samples, the fine loss reaches the EDSR weights through the super-resolved region; (b) the coarse model with gradients (decoder / LR planes
+    trained along): the coarse loss reaches the LR planes, the fine loss the SR network -- two sets of plane leaves in one iteration.
+    Oracle = its own SR forward, render backward on the HR planes (fine) / the LR planes (coarse) at the same importance depths, SR backward."""
+    from conftest import load_golden
+    from oracle.oracle import decoder_blob
+    from test_hip_parity import N_, T, _grad_models, _rel, _sr_grad_blob, make_options, sd
+    g = load_golden("g08_render.npz")
+    rng = np.random.default_rng(62)
+    R, Rv, hid, nb = 24, 8, 16, 2
+    planes = [rng.standard_normal((1, 48, R, R), dtype=np.float32) * 0.5 for _ in range(3)] + \
+             [rng.standard_normal((1, 48, Rv, Rv), dtype=np.float32) * 0.5]
+    sid = "lego_DS8_PlRes24_8"
+    H = W = 12
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    N, nc, nf = 60, 24, 24
+    opts, scfg = make_options(nc, nf)
+    for coarse_trains in (False, True):
+        mc, mf = _grad_models(hip, g, planes, sid, what=("planes",) if coarse_trains else ())
+        torch.manual_seed(6)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.mul_(10.0)
+        sr.train()
+        mf.detach_LR_planes = True                                  # (the SR network sees detached LR planes: their gradient below is the coarse pass's alone)
+        mf.assign_SR_model(sr, SR_viewdir=False)
+        mf.assign_LR_planes()
+        assert not hasattr(mc, "SR_model")
+        if not coarse_trains:
+            mc.optional_no_grad = torch.no_grad                     # train_nerf.py:560
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
+        sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
+        batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, sid, mode="train", scene_config=scfg, randoms={})
+        z_fine = N_(out[3].grad_fn.saved["z_f"])
+        gc = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+        gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
+        ((out[0] * gc).sum() * (1.0 if coarse_trains else 0.0) + (out[3] * gf).sum()).backward()
+        got = _sr_grad_blob(sr)
+        # --- oracle
+        blob = np.concatenate([N_(w).reshape(-1) for w in sr.inner_model.conv_weights()])
+        pad, over = int(sr.inner_model.required_padding), int(sr.HR_overpadding)
+        rays_np = oracle.pack_rays(N_(batch[0]), N_(batch[1]), 2.0, 6.0)
+        box = np.asarray(g["box"], np.float64)
+        ends = np.concatenate([rays_np[:, 0:3] + rays_np[:, 3:6] * rays_np[:, 6:7], rays_np[:, 0:3] + rays_np[:, 3:6] * rays_np[:, 7:8]], 0)
+        n_ends = (2 * (ends - box[0, :3].astype(np.float32)) / (box[1, :3] - box[0, :3]).astype(np.float32) - 1).astype(np.float32)
+        hr, rois = [], []
+        for d in range(3):
+            m_ = N_(mf.coord_projector.rot_mats_NON_LEARNED[d])[:, 1:]
+            grid = n_ends @ m_
+            roi = np.array([[grid[:, 1].min(), grid[:, 0].min()], [grid[:, 1].max(), grid[:, 0].max()]], np.float32)
+            rois.append(roi)
+            hr.append(oracle.planes_sr(planes[d][0], blob, hid, nb, 2, pad, over, roi=roi))
+        hr_zero = [np.nan_to_num(h)[None] for h in hr] + [planes[3]]
+        sc_hr, sc_lr = oracle.scene(hr_zero, g["box"]), oracle.scene(planes, g["box"])
+        dec_c, dec_f = oracle.decoder(decoder_blob(sd(g, "coarse."))), oracle.decoder(decoder_blob(sd(g, "fine.")))
+        o = oracle.render_rays(sc_lr, dec_c, dec_f, rays_np, nc, nf)
+        np.testing.assert_allclose(N_(out[0]), o["rgb_coarse"], rtol=0, atol=3e-5)          # the coarse pass sampled the LR planes
+        zero = np.zeros((N, 3), np.float32)
+        gplanes = oracle.render_backward(sc_hr, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)
+        ref = np.zeros_like(blob, dtype=np.float64)
+        for d in range(3):
+            gw, _ = oracle.planes_sr_backward(planes[d][0], blob, hid, nb, 2, pad, over, gplanes[d], roi=rois[d], want_dlr=False)
+            ref += gw
+        assert _rel(got, ref) < 5e-3, "SR weight gradient (coarse model trains: %s): relative L2 error %.2e" % (coarse_trains, _rel(got, ref))
+        lr_params = [mc.planes_[hip.models.get_plane_name(sid, d)] for d in range(4)]
+        if not coarse_trains:
+            assert all(p_.grad is None for p_ in lr_params) and not out[0].requires_grad
+        else:
+            glr = oracle.render_backward(sc_lr, [p.shape for p in planes], dec_c, dec_f, rays_np, nc, nf, N_(gc), zero, z_fine=z_fine)
+            for d in range(3):                                       # (the view plane also collects the fine pass's share: checked on the position planes)
+                assert _rel(N_(lr_params[d].grad)[0], glr[d]) < 5e-3, d
+            gview = oracle.render_backward(sc_hr, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)[3] + glr[3]
+            assert _rel(N_(lr_params[3].grad)[0], gview) < 5e-3
