@@ -899,3 +899,42 @@ def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
                 assert _rel(N_(lr_params[d].grad)[0], glr[d]) < 5e-3, d
             gview = oracle.render_backward(sc_hr, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)[3] + glr[3]
             assert _rel(N_(lr_params[3].grad)[0], gview) < 5e-3
+
+
+def test_default_sr_refinement_steps(hip):
+    """training.TrainStep on the reference's default SR refinement (what: ['SR'], loss: 'fine', apply_2_coarse False: the SR model on the fine
+    model only, the coarse pass under torch.no_grad -- train_nerf.py:554-561,883-889): the steps run, only the SR network moves, the fine
+    loss falls, evaluate_view renders the scene with and without the SR model"""
+    from conftest import load_golden
+    from test_hip_parity import T, _grad_models, _gt_and_student, make_options
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    gt_planes, noisy = _gt_and_student(hip, g, sid, seed=82)
+    H = W = 20
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24)
+    mc, mf = _grad_models(hip, g, noisy, sid, what=())
+    torch.manual_seed(8)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    mc.optional_no_grad = torch.no_grad
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    mf.skip_SR(True)
+    with torch.no_grad():
+        img = hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)[3]   # target = the LR render
+    mf.skip_SR(False)
+    ev = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
+    sr_opt = torch.optim.Adam(sr.parameters(), lr=2e-3)
+    step = hip.training.TrainStep(mc, mf, opts, {"SR"}, SR_optimizer=sr_opt, SR_model=sr, sr_loss="fine")
+    np.random.seed(4)
+    before = [p_.detach().clone() for p_ in sr.parameters()]
+    for it in range(12):
+        r = step(it, img, pose, H, W, focal, 1, sid, scfg, 200, sr_iter=True)
+        assert r["coarse_loss"] is None and r["fine_loss"] is not None and np.isfinite(r["loss"])
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, sr.parameters()))
+    assert all(p_.grad is None for m in (mc, mf) for p_ in list(m.decoder_parameters()) + list(m.planes_.values()))
+    sr.clear_SR_planes()
+    ev2 = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
+    assert ev2["loss"] < ev["loss"], (ev["loss"], ev2["loss"])
