@@ -823,14 +823,18 @@ def test_planes_sr_with_a_bicubic_residual_vs_reference(hip):
 
 
 def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
-    """The reference's default SR training (train_nerf.py:554-561, super_resolution.apply_2_coarse False): only model_fine gets the SR model, the
-    coarse model samples the LR planes.  (a) what: ['SR'] -- the coarse pass runs under torch.no_grad (optional_no_grad) and picks the importance
-    samples, the fine loss reaches the EDSR weights through the super-resolved region; (b) the coarse model with gradients (decoder / LR planes
-    trained along): the coarse loss reaches the LR planes, the fine loss the SR network -- two sets of plane leaves in one iteration.
+    """The reference's default SR training (train_nerf.py:554-561, super_resolution.apply_2_coarse False -- the value of both shipped YAMLs): only
+    model_fine gets the SR model, the coarse model samples the LR planes.
+      sr_only  what: ['SR'] -- the coarse pass runs under torch.no_grad (optional_no_grad) and picks the importance samples, the fine loss reaches
+               the EDSR weights through the super-resolved region;
+      planes   the LR planes train along (SR network fed detached planes): the coarse loss reaches the LR planes, the fine loss the SR network --
+               two sets of plane leaves in one iteration;
+      joint    config/TrainModels.yml's what: ['LR_planes', 'decoder', 'SR'] -- both decoders, the SR network and the LR planes, which collect the
+               coarse pass's gradient AND the fine pass's through the SR network.
     Oracle = its own SR forward, render backward on the HR planes (fine) / the LR planes (coarse) at the same importance depths, SR backward."""
     from conftest import load_golden
     from oracle.oracle import decoder_blob
-    from test_hip_parity import N_, T, _grad_models, _rel, _sr_grad_blob, make_options, sd
+    from test_hip_parity import N_, T, _decoder_grad_blob, _grad_models, _rel, _sr_grad_blob, make_options, sd
     g = load_golden("g08_render.npz")
     rng = np.random.default_rng(62)
     R, Rv, hid, nb = 24, 8, 16, 2
@@ -841,19 +845,19 @@ def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
     focal = 0.5 * W / np.tan(0.5 * 0.6911112)
     N, nc, nf = 60, 24, 24
     opts, scfg = make_options(nc, nf)
-    for coarse_trains in (False, True):
-        mc, mf = _grad_models(hip, g, planes, sid, what=("planes",) if coarse_trains else ())
+    for mode in ("sr_only", "planes", "joint"):
+        mc, mf = _grad_models(hip, g, planes, sid, what={"sr_only": (), "planes": ("planes",), "joint": ("planes", "decoder")}[mode])
         torch.manual_seed(6)
         sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
         with torch.no_grad():
             for p_ in sr.parameters():
                 p_.mul_(10.0)
         sr.train()
-        mf.detach_LR_planes = True                                  # (the SR network sees detached LR planes: their gradient below is the coarse pass's alone)
+        mf.detach_LR_planes = mode != "joint"                       # (detached: the LR planes' gradient is the coarse pass's alone)
         mf.assign_SR_model(sr, SR_viewdir=False)
         mf.assign_LR_planes()
         assert not hasattr(mc, "SR_model")
-        if not coarse_trains:
+        if mode == "sr_only":
             mc.optional_no_grad = torch.no_grad                     # train_nerf.py:560
         ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, T(g["pose"]))
         sel = torch.from_numpy(rng.permutation(H * W)[:N]).to(DEV)
@@ -862,7 +866,7 @@ def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
         z_fine = N_(out[3].grad_fn.saved["z_f"])
         gc = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
         gf = T(rng.standard_normal((N, 3)).astype(np.float32) / N)
-        ((out[0] * gc).sum() * (1.0 if coarse_trains else 0.0) + (out[3] * gf).sum()).backward()
+        ((out[0] * gc).sum() * (0.0 if mode == "sr_only" else 1.0) + (out[3] * gf).sum()).backward()
         got = _sr_grad_blob(sr)
         # --- oracle
         blob = np.concatenate([N_(w).reshape(-1) for w in sr.inner_model.conv_weights()])
@@ -886,19 +890,26 @@ def test_sr_training_with_only_the_fine_model_super_resolving(hip, oracle):
         zero = np.zeros((N, 3), np.float32)
         gplanes = oracle.render_backward(sc_hr, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)
         ref = np.zeros_like(blob, dtype=np.float64)
+        dlr = []
         for d in range(3):
-            gw, _ = oracle.planes_sr_backward(planes[d][0], blob, hid, nb, 2, pad, over, gplanes[d], roi=rois[d], want_dlr=False)
+            gw, dl = oracle.planes_sr_backward(planes[d][0], blob, hid, nb, 2, pad, over, gplanes[d], roi=rois[d], want_dlr=mode == "joint")
             ref += gw
-        assert _rel(got, ref) < 5e-3, "SR weight gradient (coarse model trains: %s): relative L2 error %.2e" % (coarse_trains, _rel(got, ref))
+            dlr.append(dl)
+        assert _rel(got, ref) < 5e-3, "SR weight gradient (%s): relative L2 error %.2e" % (mode, _rel(got, ref))
         lr_params = [mc.planes_[hip.models.get_plane_name(sid, d)] for d in range(4)]
-        if not coarse_trains:
+        if mode == "sr_only":
             assert all(p_.grad is None for p_ in lr_params) and not out[0].requires_grad
-        else:
-            glr = oracle.render_backward(sc_lr, [p.shape for p in planes], dec_c, dec_f, rays_np, nc, nf, N_(gc), zero, z_fine=z_fine)
-            for d in range(3):                                       # (the view plane also collects the fine pass's share: checked on the position planes)
-                assert _rel(N_(lr_params[d].grad)[0], glr[d]) < 5e-3, d
-            gview = oracle.render_backward(sc_hr, [p.shape for p in hr_zero], dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)[3] + glr[3]
-            assert _rel(N_(lr_params[3].grad)[0], gview) < 5e-3
+            continue
+        glr = oracle.render_backward(sc_lr, [p.shape for p in planes], dec_c, dec_f, rays_np, nc, nf, N_(gc), zero, z_fine=z_fine)
+        for d in range(3):
+            want = glr[d] + (dlr[d].reshape(glr[d].shape) if mode == "joint" else 0.0)    # + the fine pass's share through the SR network
+            assert _rel(N_(lr_params[d].grad)[0], want) < 5e-3, (mode, d, _rel(N_(lr_params[d].grad)[0], want))
+        assert _rel(N_(lr_params[3].grad)[0], gplanes[3] + glr[3]) < 5e-3                    # the view plane: both passes
+        if mode == "joint":
+            gdc = oracle.render_backward_decoder(sc_lr, dec_c, dec_f, rays_np, nc, nf, N_(gc), zero, z_fine=z_fine)[0]
+            gdf = oracle.render_backward_decoder(sc_hr, dec_c, dec_f, rays_np, nc, nf, zero, N_(gf), z_fine=z_fine)[1]
+            assert _rel(_decoder_grad_blob(mc), gdc) < 1e-2 and _rel(_decoder_grad_blob(mf), gdf) < 1e-2, (
+                _rel(_decoder_grad_blob(mc), gdc), _rel(_decoder_grad_blob(mf), gdf))
 
 
 def test_default_sr_refinement_steps(hip):
