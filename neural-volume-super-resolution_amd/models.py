@@ -280,6 +280,8 @@ class TwoDimPlanesModel(nn.Module):
         for k in self.planes_:
             if scene is not None and self.scene_coupler is not None and self.scene_coupler.scene2saved[scene] not in k:
                 continue
+            if self.scene_coupler is not None:
+                self._refuse_plane_downsampling(k, for_LR_loading=True)
             if not self.SR_model.SR_viewdir and get_plane_name(None, self.num_density_planes) in k:
                 continue
             plane = self.planes_[k]
@@ -367,11 +369,20 @@ class TwoDimPlanesModel(nn.Module):
             return True
         return self.scene_coupler.should_SR(plane_name, plane_not_scene=True)
 
+    def _refuse_plane_downsampling(self, plane_name, **kw):
+        """models.py:231-238,273: with 'HR_planes' in nerf.train.what (SceneCoupler(planes_res='HR')) an LR scene samples its HR couple's planes
+        DOWN-sampled.  Not mirrored (no shipped config trains HR planes): loud instead of sampling the HR plane as it is."""
+        sd = getattr(self.scene_coupler, "should_downsample", None)
+        if sd is not None and sd(plane_name, **kw):
+            raise NotImplementedError("plane down-sampling ('HR_planes' in nerf.train.what: models.py:231-238) is not implemented; "
+                                      "the shipped configs store LR planes (what: ['LR_planes', ...])")
+
     def _plane_source(self, dim_num):
         """models.py:270-284 `planes()`: the NCHW tensor a projection samples from (raw or super-resolved)."""
         plane_name = get_plane_name(self.cur_id, dim_num)
         super_resolve = dim_num < self.num_density_planes and self._should_SR(plane_name)
         if self.scene_coupler is not None:
+            self._refuse_plane_downsampling(plane_name)
             plane_name = self.scene_coupler.scene_with_saved_plane(plane_name, plane_not_scene=True)
         if super_resolve:
             return plane_name + "/SR", self.SR_model(plane_name)

@@ -491,3 +491,27 @@ def test_random_plane_frames_are_the_references(pkg):
     three = pkg.models.CoordProjector(3)
     assert (np.random.get_state()[1] == state).all()
     assert torch.equal(three.rot_mats_NON_LEARNED[1].detach(), torch.eye(3)[:, [1, 0, 2]])
+
+
+def test_plane_downsampling_is_refused_loudly(pkg):
+    """'HR_planes' training (SceneCoupler(planes_res='HR'): an LR scene samples its HR couple's planes down-sampled, models.py:231-238,273) is
+    not mirrored: as soon as a coupler asks for a down-sampled plane the model raises instead of sampling the HR plane as it is"""
+    class Coupler:
+        def __init__(self, ds):
+            self.ds = ds
+        def should_downsample(self, plane_name, for_LR_loading=False):
+            return self.ds
+        def should_SR(self, plane_name, plane_not_scene=False):
+            return False
+        def scene_with_saved_plane(self, name, plane_not_scene=False):
+            return name
+    sid = "lego_DS8_PlRes4_4"
+    for ds in (False, True):
+        m = pkg.models.TwoDimPlanesModel(use_viewdirs=True, proj_combination="avg", viewdir_proj_combination="concat_pos", scene_coupler=Coupler(ds))
+        m.planes_ = torch.nn.ParameterDict({pkg.models.get_plane_name(sid, d): torch.nn.Parameter(torch.zeros(1, 48, 4, 4)) for d in range(4)})
+        m.cur_id = sid
+        if ds:
+            with pytest.raises(NotImplementedError, match="HR_planes"):
+                m._plane_source(0)
+        else:
+            assert m._plane_source(0)[1] is m.planes_[pkg.models.get_plane_name(sid, 0)]
