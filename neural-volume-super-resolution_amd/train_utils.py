@@ -48,7 +48,7 @@ def _draw_point_jitter(model, n_rays, S, chunksize):
     if not std:
         return None
     n = n_rays * S
-    step = n if chunksize is None else int(chunksize)
+    step = max(1, n if chunksize is None else int(chunksize))
     parts = [torch.normal(mean=0, std=std, size=[min(step, n - i), 3]) for i in range(0, n, step)]
     return torch.cat(parts, 0).reshape(n_rays, S, 3) if parts else torch.empty(0, S, 3)
 
