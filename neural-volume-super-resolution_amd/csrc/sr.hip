@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
 // conv3x3_limb_kernel's, results agree to rounding (both are held to the CPU checker of the test suite at 3e-5).
 // F16 (the 2-f16-limb arithmetic): the accumulators carry 2^(F16_SW + F16_SX) and the ReLU lets a NaN through (an operand beyond the f16
 // range turns the accumulators into NaNs; fmaxf would return 0)
-template <int PB, bool F16 = false>
-__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[2][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo,
+template <int PB, bool F16 = false, int NCB = 2>
+__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[NCB][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo,
                                                  float unscale = 1.0f) {
     float* __restrict__ const out = p.out;
     const float* __restrict__ const skip = p.skip;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
     auto write_out = [&](auto kind) {
         constexpr int EPI = decltype(kind)::value;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -556,8 +556,13 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // workgroup per CU -- the patch is staged once for all 256 channels
 // LIMBS = 3: bf16 limbs (6 products); LIMBS = 2: f16 limbs rounded to nearest with the static scales of limb_core.h (3 products; forward
 // convolutions only -- gradients span too many decades for 5 exponent bits)
-template <int PB, int WAVES = 4, int LIMBS = 3>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p) {
+// NCB = 16-channel output blocks per wave: 2 (a workgroup of 4 waves = 128 channels).  4 (256 channels: one workgroup per pixel tile reads the
+// patch once, every B fragment read from LDS feeds 12 MFMAs instead of 6, half the LDS and L2 streams per MFMA) was measured in round 4 and is
+// not instantiated: with 6 rows it needs 512 registers = one workgroup per CU and the EDSR(256 x 32) plane takes 20.4 instead of 17.0 ms; with
+// 3 rows at two workgroups per CU (256 registers, 20 spilled) 18.4-18.8 against 17.3 ms (same box).  The second wave per SIMD is worth more
+// than the halved streams: the kernel is bound by latency the other workgroup covers, not by LDS or L2 bandwidth.
+template <int PB, int WAVES = 4, int LIMBS = 3, int NCB = 2>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p) {
     constexpr int TPB = 64 * WAVES;
     constexpr int PR = PB + 2, PC = 34;
     constexpr int ITEMS = 4 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int cb0 = (cg * WAVES + wave_u) * 2;                      // first of this wave's two 16-channel output blocks
+    const int cb0 = (cg * WAVES + wave_u) * NCB;                    // first of this wave's NCB 16-channel output blocks
     const int ncb16 = p.Cout / 16;
 
     int voff[IT], sl[IT];
@@ -639,9 +644,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         }
     };
 
-    f32x4 acc[2][PB][2];
+    f32x4 acc[NCB][PB][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NCB; ++a)
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
@@ -657,9 +662,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         if (chunk + 1 < nchunks) gload(chunk + 1);          // in flight during this chunk's MFMAs
         const u32x4* wa = wbase + chunk * wchunk;
         const unsigned* pl = lds + buf * BUF + CV16_ITEM(0, g, i16) * 4;
-        u32x4 A[2][LIMBS], An[2][LIMBS];
+        u32x4 A[NCB][LIMBS], An[NCB][LIMBS];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int t = 0; t < LIMBS; ++t) A[cb][t] = wa[((cb * 9 + 0) * LIMBS + t) * 64 + lane];
 #pragma unroll
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9) {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int t = 0; t < LIMBS; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * LIMBS + t) * 64 + lane];
             }
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
 #pragma unroll
                     for (int t = 0; t < LIMBS; ++t) B[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV16_ITEM(pb + ky, 0, 16 * hx + kx) * 4);
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
+                    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                         for (int qq = 0; qq < limb_products(LIMBS); ++qq)
                             acc[cb][pb][hx] = mfma16_limb<LIMBS>(A[cb][limb_w(LIMBS, qq)], B[limb_x(LIMBS, qq)], acc[cb][pb][hx]);
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9) {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int t = 0; t < LIMBS; ++t) A[cb][t] = An[cb][t];
             }
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv3x3_limb16
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out16<PB, LIMBS == 2>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo, 1.0f / (F16_W_SCALE * xscale));
+    conv_write_out16<PB, LIMBS == 2, NCB>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo, 1.0f / (F16_W_SCALE * xscale));
 #undef CV16_ITEM
 }
 
