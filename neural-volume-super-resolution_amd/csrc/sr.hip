@@ -543,6 +543,11 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
     }
 }
 
+#ifndef CV16_BPF
+#define CV16_BPF 2      // 16x16x32 kernel: B fragments read this many pixel blocks ahead of their MFMAs (0 = where the compiler puts them: a read 2-4
+                        // MFMAs ahead of its use).  Same-box A/B on the EDSR trunk layer (256 -> 256, 270^2 x 3): 0.702 / 0.690 / 0.685 ms for 0 / 1 / 2;
+                        // same bits (the order of the MFMAs of an accumulator does not change)
+#endif
 template <int LIMBS>
 __device__ __forceinline__ f32x4 mfma16_limb(u32x4 a, u32x4 b, f32x4 c) {
     if constexpr (LIMBS == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -628,9 +633,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
             for (int k = 0; k < IT; ++k) st[k][c8] = cbase[voff[k]];
         }
     };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
+    auto sstore_item = [&](int buf, int k) NVSR_INL {
+        {
             Limbs<LIMBS> L;
             float e[8];
 #pragma unroll
@@ -642,6 +646,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
                 for (int t = 0; t < LIMBS; ++t) *reinterpret_cast<u32x4*>(lds + buf * BUF + t * LIMB_WORDS + sl[k]) = L.v[t];
             }
         }
+    };
+    auto sstore = [&](int buf) NVSR_INL {
+#pragma unroll
+        for (int k = 0; k < IT; ++k) sstore_item(buf, k);
     };
 
     f32x4 acc[NCB][PB][2];
@@ -663,6 +671,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
         const u32x4* wa = wbase + chunk * wchunk;
         const unsigned* pl = lds + buf * BUF + CV16_ITEM(0, g, i16) * 4;
         u32x4 A[NCB][LIMBS], An[NCB][LIMBS];
+#if CV16_BPF
+        u32x4 Bq[CV16_BPF + 1][LIMBS];
+#endif
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -678,6 +689,33 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
                     for (int t = 0; t < LIMBS; ++t) An[cb][t] = wa[((cb * 9 + tap + 1) * LIMBS + t) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
+#if CV16_BPF
+            // B fragments CV16_BPF pixel blocks ahead of their MFMAs, through a ring of CV16_BPF + 1 register sets that runs across the taps of
+            // the chunk (the compiler's own schedule issues a read 2-4 MFMAs ahead of its first use: less than the LDS latency)
+            constexpr int NI = PB * 2, NJ = 9 * NI, RING = CV16_BPF + 1;
+            auto loadB = [&](int j, u32x4 (&dst)[LIMBS]) NVSR_INL {
+                const int tp = j / NI, it = j % NI, pb_ = it / 2, hx_ = it % 2;
+#pragma unroll
+                for (int t = 0; t < LIMBS; ++t)
+                    dst[t] = *reinterpret_cast<const u32x4*>(pl + t * LIMB_WORDS + CV16_ITEM(pb_ + tp / 3, 0, 16 * hx_ + tp % 3) * 4);
+            };
+            if (tap == 0) {
+#pragma unroll
+                for (int j = 0; j < CV16_BPF; ++j) loadB(j, Bq[j % RING]);
+            }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int j = tap * NI + it, pb = it / 2, hx = it % 2;
+                if (j + CV16_BPF < NJ) loadB(j + CV16_BPF, Bq[(j + CV16_BPF) % RING]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int qq = 0; qq < limb_products(LIMBS); ++qq)
+                        acc[cb][pb][hx] = mfma16_limb<LIMBS>(A[cb][limb_w(LIMBS, qq)], Bq[j % RING][limb_x(LIMBS, qq)], acc[cb][pb][hx]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -691,6 +729,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
                         for (int qq = 0; qq < limb_products(LIMBS); ++qq)
                             acc[cb][pb][hx] = mfma16_limb<LIMBS>(A[cb][limb_w(LIMBS, qq)], B[limb_x(LIMBS, qq)], acc[cb][pb][hx]);
                 }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < 9) {
 #pragma unroll
@@ -699,6 +738,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
                     for (int t = 0; t < LIMBS; ++t) A[cb][t] = An[cb][t];
             }
         }
+        // (spreading this store over the last taps, one patch item behind a queued group of MFMAs each, was measured: the live staging registers
+        //  beside the fragment ring spill 22-26 VGPRs in the 6-row kernel, 0.662 -> 0.68 ms on the trunk layer)
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
