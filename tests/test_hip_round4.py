@@ -949,3 +949,51 @@ def test_default_sr_refinement_steps(hip):
     sr.clear_SR_planes()
     ev2 = hip.training.evaluate_view(mc, mf, opts, sid, scfg, img, pose, H, W, focal, SR_model=sr, sr_scene=True)
     assert ev2["loss"] < ev["loss"], (ev["loss"], ev2["loss"])
+
+
+def test_image_consistency_iteration(hip):
+    """An image-consistency iteration of config/RefineOnTestScene.yml (im_inconsistency_loss_w: 1; train_nerf.py:806-811,829-835,878-879): an LR
+    target image, num_random_rays // ds^2 LR pixels drawn, each rendered as its ds x ds patch of HR rays through the super-resolved planes (SR
+    model on the fine model only), the patches averaged back to LR pixels before the loss.  TrainStep's reported fine loss is the loss of that
+    computation done by hand on the same draw; only the SR network receives a gradient and moves."""
+    from conftest import load_golden
+    from test_hip_parity import T, _grad_models, _gt_and_student, make_options
+    tr = hip.training
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    _, noisy = _gt_and_student(hip, g, sid, seed=83)
+    H = W = 10                                                      # the LR view; the iteration renders 40 x 40
+    ds = 4
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(16, 16)
+    mc, mf = _grad_models(hip, g, noisy, sid, what=())
+    torch.manual_seed(9)
+    sr = hip.models.PlanesSR(hip.models.EDSR, ds, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    mc.optional_no_grad = torch.no_grad
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+    n_rays = 320                                                    # -> 20 LR pixels x 16 HR rays
+    sr.train()
+    # by hand, on the draw the step will make
+    np.random.seed(11)
+    sel, target = tr.select_training_pixels(img, n_rays, ds)
+    assert sel.shape == (320, 2) and target.shape == (20, 3) and int(sel.max()) < H * ds
+    ro, rd = tr.get_ray_bundle_at(H * ds, W * ds, focal * ds, pose, sel, downsampling_offset=tr.downsampling_offset(ds // ds))
+    with torch.no_grad():
+        out = hip.train_utils.run_one_iter_of_nerf(H * ds, W * ds, focal * ds, mc, mf, (ro, rd), opts, sid, mode="train", scene_config=scfg)
+    by_hand = float(torch.nn.functional.mse_loss(tr.avg_downsampling(out[3], ds), target))
+    sr.clear_SR_planes()
+    opt = torch.optim.SGD(sr.parameters(), lr=1e-3)
+    step = tr.TrainStep(mc, mf, opts, {"SR"}, SR_optimizer=opt, SR_model=sr, sr_loss="fine", im_inconsistency_loss_w=1.0, ds_factor=ds)
+    before = [p_.detach().clone() for p_ in sr.parameters()]
+    np.random.seed(11)
+    r = step(0, img, pose, H, W, focal, ds, sid, scfg, n_rays, sr_iter=True, im_consistency_iter=True)
+    assert r["coarse_loss"] is None and abs(r["fine_loss"] - by_hand) <= 1e-5 * max(1.0, by_hand), (r["fine_loss"], by_hand)
+    assert r["psnr"] is None                                        # (an image-consistency iteration logs no PSNR, train_nerf.py:893-899)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, sr.parameters()))
+    assert all(p_.grad is None for m in (mc, mf) for p_ in list(m.decoder_parameters()) + list(m.planes_.values()))
