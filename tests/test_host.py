@@ -515,3 +515,17 @@ def test_plane_downsampling_is_refused_loudly(pkg):
                 m._plane_source(0)
         else:
             assert m._plane_source(0)[1] is m.planes_[pkg.models.get_plane_name(sid, 0)]
+
+
+def test_image_inconsistency_loss_helper(pkg):
+    """nerf_helpers.py:498-505: L1 between the anti-aliased down-sampling of a super-resolved image and the LR image (or the down-sampled HR one)"""
+    tr = pkg.training
+    g = torch.Generator().manual_seed(2)
+    sr, lr = torch.rand(1, 3, 16, 16, generator=g), torch.rand(1, 3, 4, 4, generator=g)
+    want = torch.nn.functional.l1_loss(lr, torch.nn.functional.interpolate(sr, scale_factor=0.25, mode="bilinear", align_corners=False, antialias=True))
+    assert torch.equal(tr.calc_im_inconsistency_loss(sr, 4, "bilinear", align_corners=False, gt_lr=lr), want)
+    hr = torch.rand(1, 3, 16, 16, generator=g)
+    got = tr.calc_im_inconsistency_loss(sr, 4, "bicubic", align_corners=False, gt_hr=hr)
+    assert torch.equal(got, torch.nn.functional.l1_loss(tr.downsample_plane(hr, 4, "bicubic", False, antialias=True), tr.downsample_plane(sr, 4, "bicubic", False, antialias=True)))
+    with pytest.raises(AssertionError):
+        tr.calc_im_inconsistency_loss(sr, 4, "bilinear", gt_lr=lr, gt_hr=hr)
