@@ -372,6 +372,10 @@ class TwoDimPlanesModel(nn.Module):
     def _refuse_plane_downsampling(self, plane_name, **kw):
         """models.py:231-238,273: with 'HR_planes' in nerf.train.what (SceneCoupler(planes_res='HR')) an LR scene samples its HR couple's planes
         DOWN-sampled.  Not mirrored (no shipped config trains HR planes): loud instead of sampling the HR plane as it is."""
+        rank = getattr(self, "plane_rank", None)
+        if rank:
+            # models.py:223-230 (PlanesOptimizer(planes_rank_ratio=...), which train_nerf.py never passes): planes stored as two low-rank factors
+            raise NotImplementedError("low-rank planes (plane_rank / planes_rank_ratio, models.py:223-230) are not implemented")
         sd = getattr(self.scene_coupler, "should_downsample", None)
         if sd is not None and sd(plane_name, **kw):
             raise NotImplementedError("plane down-sampling ('HR_planes' in nerf.train.what: models.py:231-238) is not implemented; "
@@ -381,8 +385,8 @@ class TwoDimPlanesModel(nn.Module):
         """models.py:270-284 `planes()`: the NCHW tensor a projection samples from (raw or super-resolved)."""
         plane_name = get_plane_name(self.cur_id, dim_num)
         super_resolve = dim_num < self.num_density_planes and self._should_SR(plane_name)
+        self._refuse_plane_downsampling(plane_name)
         if self.scene_coupler is not None:
-            self._refuse_plane_downsampling(plane_name)
             plane_name = self.scene_coupler.scene_with_saved_plane(plane_name, plane_not_scene=True)
         if super_resolve:
             return plane_name + "/SR", self.SR_model(plane_name)
