@@ -973,6 +973,32 @@ def main():
                              "fine_pass_kernel_ms": 1e3 * time_fine_pass_kernel(nvsr_amd, mf, rays, z_fine, reps=2)}
             nvsr_amd.capi.set_decoder_arithmetic(mode)
             result["arithmetic_modes"] = modes
+            # models.fine.type: use_same (train_nerf.py:353-355: ONE model for both passes; NOT the configuration of this line's `value`): the
+            # fine pass evaluates the 128 importance samples only and reuses the coarse pass's outputs for the 64 coarse depths
+            # (nvsr_render_rays_shared_arith) against recomputing them like the reference does
+            def one_model_frame():
+                r, d = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+                return nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mc, r, d, opts, scene_id=sid, scene_config=scfg)
+            one = {}
+            for tag, env in (("shared", None), ("recomputed", "1")):
+                if env is None:
+                    os.environ.pop("NVSR_NO_SHARED_DECODER", None)
+                else:
+                    os.environ["NVSR_NO_SHARED_DECODER"] = env
+                img = one_model_frame()[3]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    one_model_frame()
+                torch.cuda.synchronize()
+                one[tag] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / 2, "frame": img}
+            os.environ.pop("NVSR_NO_SHARED_DECODER", None)
+            result["one_decoder_for_both_passes"] = {
+                "config": "models.fine.type: use_same -- not the headline configuration (two models)",
+                "shared_ms_per_step": one["shared"]["ms_per_step"], "recomputed_ms_per_step": one["recomputed"]["ms_per_step"],
+                "rays_per_s_shared": rays_per_step / one["shared"]["ms_per_step"] * 1e3,
+                "max_abs_rgb_difference": float((one["shared"]["frame"] - one["recomputed"]["frame"]).abs().max())}
+            del one
         if world == 1 and not args.no_cpu_baseline:
             cb, psnr = cpu_baseline(nvsr_amd, mc, mf, sid, rays_row, bufs[3] if inv is None else bufs[3].index_select(0, inv))
             result["cpu_baseline"] = cb
