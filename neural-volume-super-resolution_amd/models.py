@@ -410,10 +410,11 @@ class TwoDimPlanesModel(nn.Module):
         names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
         out, n_ends = [], normalized_points
         for d, name in enumerate(names):
-            if not (d < self.num_density_planes and self._should_SR(name)):
-                out.append(self.planes_[name])
-                continue
+            # models.py:273: every plane name goes through the coupler -- an HR scene coupled to an LR scene samples the LR scene's saved planes
             saved = self.scene_coupler.scene_with_saved_plane(name, plane_not_scene=True) if self.scene_coupler is not None else name
+            if not (d < self.num_density_planes and self._should_SR(name)):
+                out.append(self.planes_[saved])
+                continue
             if not self.SR_model.training:
                 out.append(self.SR_model(saved))                      # full plane, cached (models.py:277: ROI only in training)
                 continue

@@ -447,14 +447,24 @@ def _range_key(*ms):
 
 
 def _sr_fallback(*ms, redo=False):
-    """the SR networks of these models super-resolve in 'bf16x3'; redo: planes cached from an F16X2 pass (NaN inside) are dropped"""
+    """the SR networks of these models super-resolve in 'bf16x3' for the evaluation frame being rendered; redo: planes cached from an F16X2 pass
+    (NaN inside) are dropped.  -> [(network, its arithmetic before)]: the caller puts it back after the frame (_sr_restore), so that a later
+    training iteration of the same SR model runs in the arithmetic it was configured with"""
+    changed = []
     for m in ms:
         sr = _sr_of(m)
         if sr is not None and capi.resolve_conv_arithmetic(sr.inner_model.arithmetic) == capi.ARITHMETIC["f16x2"]:
+            changed.append((sr.inner_model, sr.inner_model.arithmetic))
             sr.inner_model.arithmetic = "bf16x3"
             redo = True
         if sr is not None and redo:
             sr.clear_SR_planes()
+    return changed
+
+
+def _sr_restore(changed):
+    for net, before in changed:
+        net.arithmetic = before
 
 
 def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None, no_ndc=True):
@@ -574,12 +584,12 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
     # kernels at 800 x 800): raised -> the frame is rendered again in the 3-bf16-limb arithmetic (warned once), and later frames of the same
     # parameters go there directly.  Covers hidden activations, which no check of the operands could see beforehand.
     range_checked = mode != "train" and native and N > 0 and _f16_in_play(model_coarse, model_fine)
-    force = None
+    force, sr_changed = None, []
     if range_checked:
         key = _range_key(model_coarse, model_fine)
         if model_fine.__dict__.get("_f16_unfit") == key:
             force = "bf16x3"
-            _sr_fallback(model_coarse, model_fine)
+            sr_changed = _sr_fallback(model_coarse, model_fine)
         else:
             flag = capi.range_flag(rays.device)
             flag.reset()
@@ -595,9 +605,10 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
                 model_fine.__dict__["_f16_unfit_warned"] = True
             model_fine.__dict__["_f16_unfit"] = key
             if bits & 2:
-                _sr_fallback(model_coarse, model_fine, redo=True)
+                sr_changed = _sr_fallback(model_coarse, model_fine, redo=True)
             out = launch_all("bf16x3")
             flag.reset()
+    _sr_restore(sr_changed)
     if inv is not None:
         out = tuple(None if t is None else t.index_select(0, inv) for t in out)
     return out

@@ -258,7 +258,7 @@ class TrainStep:
         self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
         self.pixel_sampler = pixel_sampler or select_training_pixels   # (img_target, num_random_rays, consistency_ds) -> (rows_cols, target_s)
         import collections
-        self._pending, self._range_reset = collections.deque(), False
+        self._pending = collections.deque()
 
     def __call__(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
                  im_consistency_iter=False, confinements=(), randoms=None):
@@ -280,9 +280,10 @@ class TrainStep:
         if device.type != "cuda":
             return None
         flag = capi.range_flag(device)
-        if not self._range_reset:
-            flag.reset()          # (whatever raised the flag before this step object's first iteration is not its business)
-            self._range_reset = True
+        # zeroed on the stream at the start of EVERY iteration: the word an iteration's metrics carry is what its own launches raised -- not an
+        # evaluation frame, a direct model call or a stand-alone planes_sr in F16X2 that ran in between (those read and heal the flag themselves,
+        # or do not look at it at all)
+        flag.reset()
         return flag.word
 
     def run(self, it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter=False,
@@ -331,6 +332,13 @@ class TrainStep:
         rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
         loss_w = self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w
         loss = rendering_loss if loss_w == 1.0 else loss_w * rendering_loss        # (x * 1.0 is x: one kernel and its backward less)
+        self.apply_gradients(loss, last_v, sr_iter, confinements)
+        return loss, rendering_loss, coarse_loss, fine_loss, not im_consistency_iter
+
+    def apply_gradients(self, loss, last_v=True, sr_iter=False, confinements=()):
+        """the tail of an iteration (train_nerf.py:903-914): backward, [data-parallel: grad_sync() averages the gradients over the ranks],
+        then the optimizer steps the iteration is entitled to -- every rank steps from the same averaged gradients, so the ranks' parameters
+        stay identical (tests/test_distributed.py runs this tail on two gloo ranks)"""
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
@@ -345,7 +353,6 @@ class TrainStep:
                     self.optimizer.step()
             if self.SR_optimizer is not None and sr_iter and "SR" not in confinements:
                 self.SR_optimizer.step()
-        return loss, rendering_loss, coarse_loss, fine_loss, not im_consistency_iter
 
 
 class GraphedTrainStep:
@@ -362,6 +369,9 @@ class GraphedTrainStep:
 
     def __init__(self, step, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, randoms_fn=None,
                  generators=(), warmup=3, **step_kwargs):
+        if step.grad_sync is not None:
+            raise ValueError("GraphedTrainStep: a data-parallel step (grad_sync) would capture its all-reduces -- RCCL collectives, or the host-staged "
+                             "gloo path, inside a HIP graph have never been run on this pool; launch the multi-rank iteration with TrainStep")
         if step.vbs != 1:
             raise ValueError("GraphedTrainStep: virtual_batch_size > 1 alternates between two different iterations; capture needs one")
         for o in (step.optimizer, step.SR_optimizer, step.planes_optimizer):
@@ -385,6 +395,7 @@ class GraphedTrainStep:
         flag = capi.range_flag(dev)
 
         def iteration():
+            flag.reset()          # (a memset node at the head of the graph: every replay reports the flag of its own launches, like TrainStep)
             out = step.run(0, *args, randoms=draw(), **step_kwargs)
             vals = [(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
                      else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in out[:4]]
@@ -423,12 +434,25 @@ class GraphedTrainStep:
         self._present = dict(loss=True, psnr=bool(out[4]) and isinstance(out[1], torch.Tensor), coarse_loss=out[2] is not None,
                              fine_loss=out[3] is not None)
         self.replays = 0
+        # what the captured optimizers update in place.  A replay runs no Python: the tensors' version counters -- the key of every derived copy
+        # (packed decoder blobs, channel-last copies of NCHW planes, EDSR fragment blobs, the f16 range cache) -- would stand still and an eager
+        # render / TrainStep between replays would be served the copies of the parameters as they were after the capture
+        self._updated = [p for o in (step.optimizer, step.SR_optimizer, step.planes_optimizer) if isinstance(o, torch.optim.Optimizer)
+                         for grp in o.param_groups for p in grp["params"]]
+        self._opaque_optimizer = any(o is not None and not isinstance(o, torch.optim.Optimizer)
+                                     for o in (step.optimizer, step.SR_optimizer, step.planes_optimizer))
 
     def __call__(self):
         """replay the iteration once (asynchronous, on the current stream)"""
         self.graph.replay()
         self.sampler.calls += 1          # host mirror of the device counter
         self.replays += 1
+        if self._updated:
+            torch._C._increment_version(self._updated)     # the replay wrote them in place
+        if self._opaque_optimizer:                         # (an optimizer object whose parameters cannot be listed: drop the derived copies)
+            for m in (self.step.mc, self.step.mf, self.step.SR_model):
+                if m is not None and hasattr(m, "invalidate"):
+                    m.invalidate()
 
     def metrics(self):
         """loss / psnr / coarse_loss / fine_loss of the last replay, python floats (waits for the device)"""

@@ -94,6 +94,42 @@ def _worker(rank, world, port, tmp):
     roi = D.band_roi(lo, hi, R0)
     import math
     assert math.floor(R0 * (1 + float(roi[0, 0])) / 2) == lo and math.ceil(R0 * (1 + float(roi[1, 0])) / 2) == hi
+    # the tail of a data-parallel training iteration (training.TrainStep.apply_gradients: backward -> grad_sync -> optimizer steps) with the
+    # three optimizers of a joint SR-refinement step: every rank has its OWN rays (here: its own loss), the gradients are averaged by
+    # distributed.allreduce_gradients, and both ranks must end every iteration with bit-identical parameters that equal the one-process step on
+    # the mean of the two losses
+    def make_params():
+        gen = torch.Generator().manual_seed(7)
+        return [torch.nn.Parameter(torch.randn(sh, generator=gen)) for sh in ((1, 4, 6, 6), (16, 8), (8, 4, 3, 3))]
+
+    def loss_of(params, r, it):
+        gen = torch.Generator().manual_seed(100 * it + r)
+        return sum(((p * torch.randn(p.shape, generator=gen)).sum() ** 2 + (p ** 2).sum() * 0.1) for p in params)
+
+    def make_step(params, sync):
+        planes, decp, srp = params
+        return nvsr_amd.training.TrainStep(None, None, None, {"LR_planes", "decoder", "SR"}, optimizer=torch.optim.Adam([decp], lr=1e-2),
+                                           SR_optimizer=torch.optim.Adam([srp], lr=1e-2), planes_optimizer=torch.optim.Adam([planes], lr=1e-2),
+                                           grad_sync=sync)
+    mine = make_params()
+    step = make_step(mine, lambda: D.allreduce_gradients([p.grad for p in mine]))
+    alone = make_params()
+    ref_step = make_step(alone, None)
+    for it in range(3):
+        for p in mine + alone:
+            p.grad = None
+        step.apply_gradients(loss_of(mine, rank, it), sr_iter=True)
+        ref_step.apply_gradients(sum(loss_of(alone, r, it) for r in range(world)) / world, sr_iter=True)
+        for p, q in zip(mine, alone):
+            both = [torch.empty_like(p.data) for _ in range(world)]
+            dist.all_gather(both, p.data.contiguous())
+            assert torch.equal(both[0], both[1]), "the ranks' parameters drifted apart in iteration %d" % it
+            assert torch.allclose(p.data, q.data, rtol=1e-5, atol=1e-6), float((p.data - q.data).abs().max())
+    try:
+        nvsr_amd.training.GraphedTrainStep(step, torch.zeros(4, 4, 3), torch.eye(4), 4, 4, 1.0, 1, "s", None, 8)
+        raise AssertionError("a data-parallel step was accepted for graph capture")
+    except ValueError as e:
+        assert "grad_sync" in str(e)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")

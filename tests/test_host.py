@@ -529,3 +529,21 @@ def test_image_inconsistency_loss_helper(pkg):
     assert torch.equal(got, torch.nn.functional.l1_loss(tr.downsample_plane(hr, 4, "bicubic", False, antialias=True), tr.downsample_plane(sr, 4, "bicubic", False, antialias=True)))
     with pytest.raises(AssertionError):
         tr.calc_im_inconsistency_loss(sr, 4, "bilinear", gt_lr=lr, gt_hr=hr)
+
+
+def test_graphed_step_refuses_a_data_parallel_step(pkg):
+    """training.GraphedTrainStep: a TrainStep with a grad_sync (the data-parallel all-reduce of SURVEY 8e) is refused before anything else is
+    looked at -- a collective inside a HIP-graph capture has never run on this pool"""
+    T = pkg.training
+    step = T.TrainStep(None, None, None, {"LR_planes"}, planes_optimizer=None, grad_sync=lambda: None, pixel_sampler=T.DevicePixelSampler(seed=1))
+    with pytest.raises(ValueError, match="grad_sync"):
+        T.GraphedTrainStep(step, torch.zeros(4, 4, 3), torch.eye(4), 4, 4, 1.0, 1, "s", None, 8)
+
+
+def test_bench_edsr_flop_count_matches_the_survey():
+    """bench.edsr_flops (the roofline numerator of --workload refine) on the full padded plane = SURVEY 8a's 6.74 TFLOP per plane; the ROI
+    bounds restate csrc/sr_core.h sr_roi"""
+    import bench
+    assert abs(bench.edsr_flops(336, 336) / 1e12 - 6.74) < 0.01
+    assert bench.sr_roi_pixels(200, [-1.0, -1.0, 1.0, 1.0]) == [(0, 200), (0, 200)]
+    assert bench.sr_roi_pixels(200, [-0.5, 0.0, 0.25, 0.991]) == [(49, 126), (99, 200)]
