@@ -544,6 +544,30 @@ int nvsr_planes_sr_backward_arith(int C, int R0, int R1, const float* keep, cons
                                   int pad, int over, const float* roi, const float* stdv, const float* d_out, float* grad_natural,
                                   float* d_lr, float* workspace, int arithmetic, nvsr_stream_t stream);
 
+/* ---- SR training on the regions of interest of B planes at once (round 5) -------------------------------------------------------------------
+ * Replaces: the B calls `self.SR_model((plane_name, roi))` a training iteration makes from `TwoDimPlanesModel.planes()` (models.py:270-284 ->
+ * PlanesSR.forward :884-926), one per position plane of the scene, and their autograd backward (train_nerf.py:903 `loss.backward()`).  Every
+ * plane has its own region of interest, i.e. its own crop size; the network is the same.  One launch per layer convolves all B crops (a
+ * ragged batch: one crop of a 200^2 plane leaves the last of its 2-3 workgroup rounds a fifth full), one weight-gradient pass and one reduction
+ * per layer accumulates all planes' contributions, one magnitude reduction per gradient tensor serves all planes (f16 limbs).
+ *   lr / out / d_out / d_lr   HOST arrays of B device pointers (B <= 4); planes [C][R0][R1], outputs / output gradients [C][sf R0][sf R1]
+ *   rois                      B x 4 HOST floats, [[ymin,xmin],[ymax,xmax]] in [-1,1] per plane, or NULL (full planes)
+ *   keep                      one device buffer of nvsr_planes_sr_batch_keep_floats floats: forward -> backward
+ *   align_corners, plane_interp   of the residual up-sampling (PlanesSR.align_corners / .plane_interp), ARGUMENTS of the call (the
+ *                             one-plane entry points read the process-wide nvsr_set_sr_* setting)
+ *   d_lr                      NULL, or per plane NULL (LR plane detached: models.py:272) or [C][R0][R1], += the plane's gradient
+ * Values: those of B one-plane calls up to the order of the weight-gradient sums and (f16 limbs) the shared power-of-two gradient scale. */
+int64_t nvsr_planes_sr_batch_keep_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);
+int64_t nvsr_planes_sr_batch_workspace_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);
+int64_t nvsr_planes_sr_batch_backward_workspace_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);
+int nvsr_planes_sr_train_batch_arith(const float* const* lr, int B, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up,
+                                     int pad, int over, const float* rois, const float* mean, const float* stdv, float* const* out,
+                                     float* workspace, float* keep, int arithmetic, int align_corners, int plane_interp, nvsr_stream_t stream);
+int nvsr_planes_sr_backward_batch_arith(int B, int C, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks,
+                                        int n_up, int pad, int over, const float* rois, const float* stdv, const float* const* d_out,
+                                        float* grad_natural, float* const* d_lr, float* workspace, int arithmetic, int align_corners,
+                                        int plane_interp, nvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

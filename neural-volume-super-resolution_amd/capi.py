@@ -172,6 +172,14 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_planes_sr_batch_arith": ([C.POINTER(C.c_void_p), _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _i, _vp], _i),
     "nvsr_planes_sr_train_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "nvsr_planes_sr_backward_arith": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    # SR training on B regions of interest at once (csrc/sr.hip, csrc/sr_bwd.hip)
+    "nvsr_planes_sr_batch_keep_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr_batch_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr_batch_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),
+    "nvsr_planes_sr_train_batch_arith": ([C.POINTER(C.c_void_p), _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp,
+                                          _i, _i, _i, _vp], _i),
+    "nvsr_planes_sr_backward_batch_arith": ([_i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), _vp,
+                                             _i, _i, _i, _vp], _i),
     # positional-encoding baseline (csrc/posenc.hip)
     "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
@@ -181,6 +189,7 @@ _lib = None
 
 
 ARITHMETIC = {"f32": 0, "f16x2": 2, "bf16x3": 3}
+SR_BATCH_MAX = 4          # planes per nvsr_planes_sr_*_batch_arith call (csrc/sr_core.h CONV_RAGGED_MAX)
 ARITH_INHERIT = -1
 
 

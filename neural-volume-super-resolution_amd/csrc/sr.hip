@@ -169,6 +169,26 @@ __device__ __forceinline__ void conv_tile_of_block(unsigned& bx, unsigned& by, u
 #endif
 }
 
+// The tensors and the logical size of plane `bi` of the launch -> p; false: this workgroup's tile (x0, y0) lies outside the plane (ragged batch:
+// the grid covers the largest plane) and the workgroup has nothing to do.  bi, x0, y0 are workgroup-uniform.
+__device__ __forceinline__ bool conv_select_plane(ConvParams& p, const ConvRagged& rag, unsigned bi, int x0, int y0) {
+    if (rag.n) {
+        // (constant indices + selects: a dynamic index into the by-value parameter struct would put the whole struct into scratch)
+#define CONV_RAG_PICK(A) (bi == 3u ? rag.A[3] : bi == 2u ? rag.A[2] : bi == 1u ? rag.A[1] : rag.A[0])
+        const float* in = CONV_RAG_PICK(in);
+        float* out = CONV_RAG_PICK(out);
+        const float* skip = CONV_RAG_PICK(skip);
+        const int H = CONV_RAG_PICK(H), W = CONV_RAG_PICK(W);
+#undef CONV_RAG_PICK
+        p.in = in; p.out = out; p.skip = skip; p.H = H; p.W = W;
+        return y0 < H - 2 && x0 < W - 2;
+    }
+    p.in += bi * p.in_bs;
+    p.out += bi * p.out_bs;
+    if (p.skip) p.skip += bi * p.skip_bs;
+    return true;
+}
+
 // PB = output rows (32-pixel blocks) per wave: 4 by default; the launcher picks 3 or 2 for a layer whose tile count would otherwise leave most
 // of the last workgroup round empty (a ~270^2 plane is 1.2 rounds of 4-row tiles on 512 workgroup slots, but 1.0 rounds of 3-row tiles... )
 template <int CO_WAVES, int PX_WAVES, int PB = 4>
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
 // cycles and the chip clocks it at 1.76-1.78 GHz (power; profiles/r03_conv_issue_counters.txt): 0.82 x 1.77 / 2.4 = 0.60 is the fraction of the
 // 2.4 GHz roof a launch without tile rounding reaches.
 template <int PB, int CO_WAVES = 4, int CBW = 2>
-__global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p, ConvRagged rag) {
     constexpr int PX_WAVES = 4 / CO_WAVES, ROWS = PX_WAVES * PB;
     constexpr int PR = ROWS + 2, PC = 34;
     constexpr int ITEMS = 2 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
@@ -332,7 +352,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int Ho = p.H - 2, Wo = p.W - 2;
     // tile of this workgroup from the XCD-contiguous linear tile index (conv_tile_index): column chunk, row tile, then (plane, co-group) --
     // co-group SLOWEST for the 2-block wave tile: the workgroups that run together on an XCD then stream ONE co-group's 3.5 MB of weight
     // fragments through its 4 MB L2 (with the co-group fastest the four co-groups of a 256 -> 1024 layer keep 14 MB live and FETCH_SIZE of
@@ -346,9 +365,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p) {
     else { pt = blk % npt; const unsigned q = blk / npt; cg = (int)(q % ncg); bi = q / ncg; }
     const unsigned bx = pt % gridDim.x, by = pt / gridDim.x;
     const int x0 = bx * 32, y0 = by * ROWS;
-    p.in += bi * p.in_bs;
-    p.out += bi * p.out_bs;
-    if (p.skip) p.skip += bi * p.skip_bs;
+    if (!conv_select_plane(p, rag, bi, x0, y0)) return;
+    const int Ho = p.H - 2, Wo = p.W - 2;
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -567,7 +585,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // 3 rows at two workgroups per CU (256 registers, 20 spilled) 18.4-18.8 against 17.3 ms (same box).  The second wave per SIMD is worth more
 // than the halved streams: the kernel is bound by latency the other workgroup covers, not by LDS or L2 bandwidth.
 template <int PB, int WAVES = 4, int LIMBS = 3, int NCB = 2>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void conv3x3_limb16_kernel(ConvParams p, ConvRagged rag) {
     constexpr int TPB = 64 * WAVES;
     constexpr int PR = PB + 2, PC = 34;
     constexpr int ITEMS = 4 * PR * PC;                    // (octet, row, col): 8 channels of one patch pixel
@@ -583,7 +601,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
 #define CV16_ITEM(R, O, COL) ((O) * OSTR + (R) * PC + (COL))
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
-    const int Ho = p.H - 2, Wo = p.W - 2;
     const unsigned blk = conv_tile_index();
     // tile order: the two 128-channel co-groups of a 256-channel set FASTEST (they read the same patch: the second one's loads hit the XCD's L2;
     // their weights together are the 3.5 MB per layer that the 2-block kernel streamed), then the pixel tile, then the 256-channel set and the
@@ -595,9 +612,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
     const int cg = (int)((q % nset) * G + cg_lo);
     const unsigned bi = q / nset;
     const int x0 = bx * 32, y0 = by * PB;
-    p.in += bi * p.in_bs;
-    p.out += bi * p.out_bs;
-    if (p.skip) p.skip += bi * p.skip_bs;
+    if (!conv_select_plane(p, rag, bi, x0, y0)) return;
+    const int Ho = p.H - 2, Wo = p.W - 2;
     const int Hr = p.H - 2 * p.pad, Wr = p.W - 2 * p.pad;   // the tensor in memory
     const long HW = (long)Hr * Wr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -945,10 +961,55 @@ const unsigned* launch_absmax(const float* x, long n, hipStream_t stream, unsign
     return slot;
 }
 
+struct AbsmaxRagged { const float* x[CONV_RAGGED_MAX]; long n[CONV_RAGGED_MAX]; };
+__global__ __launch_bounds__(256) void absmax_ragged_kernel(AbsmaxRagged a, unsigned* __restrict__ out) {
+    // blockIdx.y = tensor; scalar loads with a grid stride (the tensors start anywhere): gradient tensors of a few MB each
+    const float* __restrict__ x = a.x[blockIdx.y];
+    const long n = a.n[blockIdx.y];
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+const unsigned* launch_absmax_ragged(int n, const float* const* x, const long* count, hipStream_t stream, unsigned* owned) {
+    if (n < 1 || n > CONV_RAGGED_MAX || !owned) return nullptr;
+    AbsmaxRagged a{};
+    long mx = 0;
+    for (int b = 0; b < n; ++b) { a.x[b] = x[b]; a.n[b] = count[b]; mx = count[b] > mx ? count[b] : mx; }
+    if (hipMemsetAsync(owned, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
+    const long blocks = (mx + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(absmax_ragged_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 512 ? 512 : blocks), n), dim3(256), 0, stream, a, owned);
+    return owned;
+}
+
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad, int batch, ConvExec cx) {
+                hipStream_t stream, int pad, int batch, ConvExec cx, const ConvRagged* rag) {
     const int arith = conv_resolve_arith(cx.arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
+    if (rag) {
+        // ragged batch: the grid is laid out for the largest plane (H, W = the maxima), the row count per tile is chosen for the tiles that exist
+        if (rag->n < 1 || rag->n > CONV_RAGGED_MAX || arith == NVSR_ARITH_F32) return NVSR_ERR_SHAPE;
+        batch = rag->n;
+        H = W = 0;
+        for (int b = 0; b < rag->n; ++b) {
+            if (!rag->in[b] || !rag->out[b] || rag->H[b] + 2 * pad < 3 || rag->W[b] + 2 * pad < 3) return NVSR_ERR_SHAPE;
+            if ((epilogue == EPI_RESIDUAL || epilogue == EPI_MASK_SCALE || epilogue == EPI_ADD_CENTER) && !rag->skip[b]) return NVSR_ERR_NULL;
+            H = rag->H[b] > H ? rag->H[b] : H;
+            W = rag->W[b] > W ? rag->W[b] : W;
+        }
+        in = rag->in[0]; out = rag->out[0]; skip = rag->skip[0];
+    }
+    // tiles of a launch with `rows` output rows per tile and gx-pixel column chunks: all planes of a ragged batch, or batch x the one size
+    auto count_tiles = [&](int rows, long per_tile_z) -> long {
+        if (!rag) return (long)((W - 2 + 31) / 32) * ((H - 2 + rows - 1) / rows) * per_tile_z * batch;      // (called below: H, W include the border by then)
+        long t = 0;
+        for (int b = 0; b < rag->n; ++b) t += (long)((rag->W[b] + 2 * pad - 2 + 31) / 32) * ((rag->H[b] + 2 * pad - 2 + rows - 1) / rows) * per_tile_z;
+        return t;
+    };
     // NVSR_ARITH_F16X2: the forward convolutions of the wide layers (16x16x32 kernel) on 2 f16 limbs; everything else that runs limbs -- the
     // narrow input / output layers, every data gradient (pad = 2, backward epilogues) -- stays on 3 bf16 limbs
     // (round 3, end: the data gradients of those layers too -- pad = 2, backward epilogues -- with the scale of the whole dy tensor, absmax_kernel)
@@ -967,11 +1028,17 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                                   ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) + conv_packed_limb_words(Cin, Cout) : nullptr;
     const unsigned* wf16 = wlimb16 ? wlimb16 + conv_packed_limb16_words(Cin, Cout) : nullptr;
     ConvParams p{in, wpk, wlimb, wlimb16, wf16, nullptr, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    ConvRagged rg;          // (a second by-value kernel argument, read with constant indices: inside ConvParams -- which the kernels modify -- the
+                            //  whole parameter struct went to scratch)
+    if (rag) {
+        rg = *rag;
+        for (int b = 0; b < rag->n; ++b) { rg.H[b] += 2 * pad; rg.W[b] += 2 * pad; }
+    }
     if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
-        hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
     }
     // rows 16 = the 16x16x32 kernel with its own choice of rows per tile, 18 / 19 / 20 = that kernel with 2 / 3 / 4 rows forced
@@ -987,7 +1054,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             if (pb == 5) continue;
             // rounds of the 512 workgroup slots x rows x the measured cost of a row in a pb-row tile relative to a 4-row tile (tools/conv_time.py
             // rows 18 / 19 / 20 on a layer of full rounds); a last round of at most 256 tiles has every CU to itself (~0.62 of a round's time)
-            const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+            const long tiles = count_tiles(pb, p.ncg);
             constexpr long SLOTS = CV16_WAVES == 4 ? 512 : 256;
             const long full = tiles / SLOTS, rest = tiles % SLOTS;
             const double rounds = (double)full + (rest == 0 ? 0.0 : (CV16_WAVES == 4 && rest <= 256) ? 0.62 : 1.0);
@@ -1004,18 +1071,19 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         grid.y = (Ho + best_pb - 1) / best_pb;
         if (f16) {
             if (f16_dgrad) {
+                if (rag && !cx.in_absmax) return NVSR_ERR_NULL;
                 p.absmax = cx.in_absmax ? cx.in_absmax : launch_absmax(in, in_bs * batch, stream);
                 if (!p.absmax) return NVSR_ERR_LAUNCH;
             }
-            if (best_pb == 6) hipLaunchKernelGGL((conv3x3_limb16_kernel<6, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
-            else if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
-            else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
-            else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+            if (best_pb == 6) hipLaunchKernelGGL((conv3x3_limb16_kernel<6, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
+            else if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
+            else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
+            else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES, 2>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
             return NVSR_CHECK_LAUNCH();
         }
-        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
-        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
-        else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p);
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb16_kernel<4, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb16_kernel<3, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
+        else hipLaunchKernelGGL((conv3x3_limb16_kernel<2, CV16_WAVES>), grid, dim3(64 * CV16_WAVES), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
     }
     if (cx.rows == 8 && !(wlimb && arith != NVSR_ARITH_F32 && p.ncb_total % 4 == 0 && p.ncb_total > 2)) return NVSR_ERR_SHAPE;   // (only the wide limb kernel has it)
@@ -1023,7 +1091,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         // bf16-limb kernel, 1 output block x 8 rows per wave: 4-wave workgroups of 128 output channels x 8 rows x 32 pixels
         p.ncg = p.ncb_total / 4;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
-        hipLaunchKernelGGL((conv3x3_limb_kernel<8, 4, 1>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_limb_kernel<8, 4, 1>), grid, dim3(256), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
     }
     if (wlimb && arith != NVSR_ARITH_F32) {
@@ -1033,7 +1101,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         int best_pb = 4;
         double best_cost = 1e300;
         for (int pb = 4; pb >= 2; --pb) {
-            const long tiles = (long)grid.x * ((Ho + pb - 1) / pb) * grid.z;
+            const long tiles = count_tiles(pb, p.ncg);
 #if CV_COST_MODEL == 0
             const double cost = (double)((tiles + 511) / 512) * pb * (1.0 + 0.03 * (4 - pb));
 #elif CV_COST_MODEL == 1
@@ -1049,10 +1117,17 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         }
         if (cx.rows) best_pb = cx.rows;
         grid.y = (Ho + best_pb - 1) / best_pb;
-        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb_kernel<4>), grid, dim3(256), 0, stream, p);
-        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb_kernel<3>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv3x3_limb_kernel<2>), grid, dim3(256), 0, stream, p);
+        if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb_kernel<4>), grid, dim3(256), 0, stream, p, rg);
+        else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb_kernel<3>), grid, dim3(256), 0, stream, p, rg);
+        else hipLaunchKernelGGL((conv3x3_limb_kernel<2>), grid, dim3(256), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
+    }
+    if (rag) {
+        // a layer no limb kernel is eligible for (e.g. 48 -> 128 channels) runs on the exact-f32 kernels below, which take no ragged batch:
+        // plane after plane
+        for (int b = 0; b < rag->n; ++b)
+            if (int e = launch_conv(rag->in[b], Cin, rag->H[b], rag->W[b], wpk, Cout, epilogue, rag->skip[b], rag->out[b], stream, pad, 1, cx, nullptr)) return e;
+        return NVSR_OK;
     }
     if (p.ncb_total >= 8 && p.ncb_total % 8 == 0) {
         p.ncg = p.ncb_total / 8;
@@ -1408,6 +1483,101 @@ static int planes_sr_impl(const float* lr, int Cc, int R0, int R1, const float* 
     hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff, Ho, Wo, over, lr, Cc, R0, R1, sf,
                        lo[0], lo[1], hi[0], hi[1], out, conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr, sr_align_corners(), sr_bicubic());
     return NVSR_CHECK_LAUNCH();
+}
+
+
+/* ---- SR training on B regions of interest at once (the position planes of a scene, one crop each: models.py:270-284) ------------------------
+ * One launch per layer for all planes (ragged batch, sr_core.h ConvRagged).  rois: B x 4 HOST floats ([[ymin,xmin],[ymax,xmax]] per plane) or
+ * NULL (full planes).  keep: ONE buffer of nvsr_planes_sr_batch_keep_floats floats (plane after plane: prepared input + activation record);
+ * workspace: nvsr_planes_sr_batch_workspace_floats floats.  align_corners / plane_interp of the residual up-sampling are ARGUMENTS here
+ * (the one-plane entry points read the process-wide setting).  B <= 4. */
+static int batch_geometry(int B, int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois, int (*lo)[2], int (*hi)[2],
+                          int* Hp, int* Wp, EdsrPlan* P) {
+    if (B < 1 || B > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
+    for (int b = 0; b < B; ++b) {
+        sr_roi(R0, R1, rois ? rois + 4 * b : nullptr, lo[b], hi[b]);
+        Hp[b] = hi[b][0] - lo[b][0] + 2 * pad; Wp[b] = hi[b][1] - lo[b][1] + 2 * pad;
+        if (P) { if (int e = edsr_plan(Cc, Cc, hid, nblocks, n_up, Hp[b], Wp[b], &P[b])) return e; }
+    }
+    return NVSR_OK;
+}
+int64_t nvsr_planes_sr_batch_keep_floats(int B, int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois) {
+    if (B < 1 || B > CONV_RAGGED_MAX) return -1;
+    int64_t s = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t k = nvsr_planes_sr_keep_floats(Cc, R0, R1, hid, nblocks, n_up, pad, rois ? rois + 4 * b : nullptr);
+        if (k < 0) return -1;
+        s += k;
+    }
+    return s;
+}
+int64_t nvsr_planes_sr_batch_workspace_floats(int B, int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois) {
+    if (B < 1 || B > CONV_RAGGED_MAX) return -1;
+    int64_t s = 0;
+    for (int b = 0; b < B; ++b) {       // the network's output of every plane (the one-plane workspace also holds its input and ping-pong buffers)
+        int lo[2], hi[2], Ho, Wo;
+        sr_roi(R0, R1, rois ? rois + 4 * b : nullptr, lo, hi);
+        if (nvsr_edsr_out_size(hi[0] - lo[0] + 2 * pad, hi[1] - lo[1] + 2 * pad, nblocks, n_up, &Ho, &Wo)) return -1;
+        s += ((int64_t)Cc * Ho * Wo + 3) / 4 * 4;
+    }
+    return s;
+}
+int nvsr_planes_sr_train_batch_arith(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up,
+                                     int pad, int over, const float* rois, const float* mean, const float* stdv, float* const* out, float* workspace,
+                                     float* keep, int arithmetic, int align_corners, int plane_interp, nvsr_stream_t stream_) {
+    if (!lr || !packed || !out || !workspace || !keep) return NVSR_ERR_NULL;
+    if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
+    if (plane_interp != NVSR_PLANE_INTERP_BILINEAR && plane_interp != NVSR_PLANE_INTERP_BICUBIC) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed) || !aligned16(keep) || !aligned16(workspace)) return NVSR_ERR_ALIGN;
+    if (B < 1 || B > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
+    for (int b = 0; b < B; ++b)
+        if (!lr[b] || !out[b]) return NVSR_ERR_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int sf = 1 << n_up;
+    const int arith = conv_resolve_arith(arithmetic);
+    int lo[CONV_RAGGED_MAX][2], hi[CONV_RAGGED_MAX][2], Hp[CONV_RAGGED_MAX], Wp[CONV_RAGGED_MAX];
+    static thread_local EdsrPlan P[CONV_RAGGED_MAX];
+    if (int e = batch_geometry(B, Cc, R0, R1, hid, nblocks, n_up, pad, rois, lo, hi, Hp, Wp, P)) return e;
+    float* xin[CONV_RAGGED_MAX]; float* acts[CONV_RAGGED_MAX]; float* diff[CONV_RAGGED_MAX];
+    float* k = keep; float* w = workspace;
+    for (int b = 0; b < B; ++b) {
+        if (P[b].Ho != (hi[b][0] - lo[b][0]) * sf + 2 * over || P[b].Wo != (hi[b][1] - lo[b][1]) * sf + 2 * over) return NVSR_ERR_SHAPE;
+        const int64_t n_in = (int64_t)Cc * Hp[b] * Wp[b];
+        xin[b] = k; acts[b] = k + (n_in + 3) / 4 * 4;
+        k = acts[b] + P[b].acts_floats;
+        diff[b] = w; w += ((int64_t)Cc * P[b].Ho * P[b].Wo + 3) / 4 * 4;
+        hipLaunchKernelGGL(sr_prepare_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, lr[b], Cc, R0, R1, lo[b][0], lo[b][1], Hp[b],
+                           Wp[b], pad, mean, stdv, xin[b]);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    if (arith == NVSR_ARITH_F32 || B == 1) {
+        // the exact-f32 kernels take no ragged batch (and one plane needs none): plane after plane
+        for (int b = 0; b < B; ++b)
+            if (int e = nvsr_edsr_forward_train_arith(xin[b], Cc, Hp[b], Wp[b], packed, Cc, hid, nblocks, n_up, diff[b], acts[b], arith, stream_)) return e;
+    } else {
+        const ConvExec cx{arith, 0};
+        const float* wp = packed;
+        for (int l = 0; l < P[0].n; ++l) {
+            ConvRagged r;
+            r.n = B;
+            for (int b = 0; b < B; ++b) {
+                r.H[b] = P[b].ih[l]; r.W[b] = P[b].iw[l];
+                r.in[b] = l ? acts[b] + P[b].act_off[l] : xin[b];
+                r.out[b] = (l + 1 < P[b].n) ? acts[b] + P[b].act_off[l + 1] : diff[b];
+                r.skip[b] = (P[b].epi[l] == EPI_RESIDUAL) ? (l >= 2 ? acts[b] + P[b].act_off[l - 1] : xin[b]) : nullptr;      // the block's input
+            }
+            if (int e = launch_conv(nullptr, P[0].L[l].Cin, 0, 0, wp, P[0].L[l].Cout, P[0].epi[l], nullptr, nullptr, stream, 0, B, cx, &r)) return e;
+            wp += conv_packed_floats(P[0].L[l].Cin, P[0].L[l].Cout);
+        }
+    }
+    const int64_t n_out = (int64_t)Cc * R0 * sf * R1 * sf;
+    for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff[b], P[b].Ho, P[b].Wo, over, lr[b], Cc, R0, R1,
+                           sf, lo[b][0], lo[b][1], hi[b][0], hi[b][1], out[b], arith == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr,
+                           align_corners ? 1 : 0, plane_interp == NVSR_PLANE_INTERP_BICUBIC ? 1 : 0);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    return NVSR_OK;
 }
 
 }  // extern "C"

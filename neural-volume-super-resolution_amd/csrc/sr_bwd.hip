@@ -34,7 +34,15 @@ struct WgradParams {
     const unsigned* dy_absmax;   // f16 limbs: bits of max |dy| over the whole tensor (sr.hip absmax_kernel) -> dy's power-of-two scale; else NULL
     int n_wg;            // conv3x3_wgrad_limb_kernel: workgroups = pieces of the linear range of `total` row steps
     long total;
+    // conv3x3_wgrad_limb_kernel: the planes whose contributions ONE pass accumulates (1 = dy / x / Ho / Wo above; up to CONV_RAGGED_MAX planes of
+    // different sizes = the regions of interest of an SR training iteration: one weight gradient, one set of partial sums, one reduction).  A
+    // tile's steps are its planes' (column chunk, row) steps one plane after the other: plane b owns steps [start[b], start[b + 1]) of TS.
+    int nplanes, TS;
+    int pHo[CONV_RAGGED_MAX], pWo[CONV_RAGGED_MAX], start[CONV_RAGGED_MAX + 1];
+    const float* pdy[CONV_RAGGED_MAX];
+    const float* px[CONV_RAGGED_MAX];
 };
+struct WgradPlane { const float* dy; const float* x; int Ho, Wo; };
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
     __shared__ float lds[DY_FLOATS + X_FLOATS];
@@ -180,7 +188,7 @@ __device__ __forceinline__ long wgrad_piece_start(long w, long total, int n_wg) 
 
 // rows [ya, yb) of column chunk x0 of tile (co0, ci0), accumulated into acc.
 template <int LF>
-__device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* lds, f32x16 (&acc)[9], int co0, int ci0, int x0, int ya, int yb, float dscale
+__device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, const WgradPlane& pl, unsigned* lds, f32x16 (&acc)[9], int co0, int ci0, int x0, int ya, int yb, float dscale
 #if WG_STAMP
                                                 , float (&stamp)[8]
 #endif
@@ -189,8 +197,8 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
     unsigned* xl = lds + LF * WL_DY_WORDS;                // [limb][ci][row][WL_ROW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
-    const int W = p.Wo + 2;
-    const long HoWo = (long)p.Ho * p.Wo, HW = (long)(p.Ho + 2) * W;
+    const int W = pl.Wo + 2;
+    const long HoWo = (long)pl.Ho * pl.Wo, HW = (long)(pl.Ho + 2) * W;
 
     // A workgroup walks DOWN a 32-pixel column chunk: consecutive steps share two of their three X rows, which stay in LDS (ring of 3 row
     // slots, row ya + k in slot k % 3) -- a step stages dy and ONE new X row.
@@ -207,14 +215,14 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
     const int dco = tid >> 3, xr = 7 * wave + lane / 9, xq = lane % 9;
     const unsigned dy_voff = ((unsigned)dco * (unsigned)HoWo + 4 * (tid & 7)) * 4u;      // (the launcher checks that 64 channels fit 2^31 bytes)
     const unsigned x_voff = ((unsigned)xr * (unsigned)HW + 4 * xq) * 4u;
-    const int dy_valid = min(max(p.Wo - (x0 + 4 * (tid & 7)), 0), 4);   // pixels past the row's end contribute nothing: they are zeroed
+    const int dy_valid = min(max(pl.Wo - (x0 + 4 * (tid & 7)), 0), 4);   // pixels past the row's end contribute nothing: they are zeroed
     unsigned* const dy_st = dyl + dco * WL_ROW + 2 * (tid & 7);
     unsigned* const x_st = xl + xr * 3 * WL_ROW + 2 * xq;
     const int n_co = min(WG_CO, p.Cout - co0), n_ci = min(WG_CI, p.Cin - ci0);
     const bool x_lane = lane < 63;
     const long dy_rest = (long)(p.Cout - co0) * HoWo - x0, x_rest = (long)(p.Cin - ci0) * HW - x0;   // elements from the bases below to the end
-    const float* const dy_base = p.dy + (long)co0 * HoWo + x0;
-    const float* const x_base = p.x + (long)ci0 * HW + x0;
+    const float* const dy_base = pl.dy + (long)co0 * HoWo + x0;
+    const float* const x_base = pl.x + (long)ci0 * HW + x0;
     // 4 consecutive floats; what lies past a row's end is the next row (finite; it only ever meets dy == 0), what would lie past the
     // tensor's end is not touched: a quad of the LAST row of the LAST channel may reach there, and rows that can (a scalar test per row)
     // take the guarded loads -- a guard is a divergent branch, and hipcc answers each with s_waitcnt vmcnt(0), which serialises the row's
@@ -253,8 +261,8 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, unsigned* 
         }
     };
     auto fetch = [&](int yr) {                                // what step yr adds: dy row ya + yr, X row ya + yr + 2
-        const float* b = dy_base + (long)(ya + yr) * p.Wo;
-        const long rest = dy_rest - (long)(ya + yr) * p.Wo;
+        const float* b = dy_base + (long)(ya + yr) * pl.Wo;
+        const long rest = dy_rest - (long)(ya + yr) * pl.Wo;
         const bool guard = dy_last > rest;                     // (uniform)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -419,8 +427,8 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
     const int cw = wave & 1, iw = wave >> 1;
-    const int nxc = (p.Wo + WG_PX - 1) / WG_PX, n_ci = (p.Cin + WG_CI - 1) / WG_CI;
-    const int TS = nxc * p.Ho;                             // steps of a tile (the launcher checks that `total` fits an int)
+    const int n_ci = (p.Cin + WG_CI - 1) / WG_CI;
+    const int TS = p.TS;                                   // steps of a tile, all planes (the launcher checks that `total` fits an int)
     const int wg = blockIdx.x;
     // (integer division runs on the vector ALU: without readfirstlane everything derived from the quotients counts as divergent, the
     //  TAIL branch below becomes a divergent one and the accumulators are spilled around it)
@@ -439,15 +447,26 @@ __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradPara
 #endif
     while (s < s1) {
         const int tile = __builtin_amdgcn_readfirstlane(s / TS), rem = s - tile * TS;
-        const int chunk = __builtin_amdgcn_readfirstlane(rem / p.Ho), ya = rem - chunk * p.Ho;
-        const int seg_end = min(s1, tile * TS + (chunk + 1) * p.Ho);
+        int b = 0;                                         // the plane this step belongs to (workgroup-uniform)
+#pragma unroll
+        for (int k = 1; k < CONV_RAGGED_MAX; ++k) b = (k < p.nplanes && rem >= p.start[k]) ? k : b;
+        b = __builtin_amdgcn_readfirstlane(b);
+        // (constant indices + selects: a dynamic index into the by-value parameter struct would put the whole struct into scratch)
+        WgradPlane pl{p.pdy[0], p.px[0], p.pHo[0], p.pWo[0]};
+        int start_b = 0;
+#pragma unroll
+        for (int k = 1; k < CONV_RAGGED_MAX; ++k)
+            if (b == k) { pl = WgradPlane{p.pdy[k], p.px[k], p.pHo[k], p.pWo[k]}; start_b = p.start[k]; }
+        const int r2 = rem - start_b;
+        const int chunk = __builtin_amdgcn_readfirstlane(r2 / pl.Ho), ya = r2 - chunk * pl.Ho;
+        const int seg_end = min(s1, tile * TS + start_b + (chunk + 1) * pl.Ho);
         const int yb = ya + (seg_end - s);
         const int cob = __builtin_amdgcn_readfirstlane(tile / n_ci);
         const int co0 = cob * WG_CO, ci0 = (tile - cob * n_ci) * WG_CI, x0 = chunk * WG_PX;
 #if WG_STAMP
-        wgrad_limb_rows<LF>(p, lds, acc, co0, ci0, x0, ya, yb, dscale, stamp);
+        wgrad_limb_rows<LF>(p, pl, lds, acc, co0, ci0, x0, ya, yb, dscale, stamp);
 #else
-        wgrad_limb_rows<LF>(p, lds, acc, co0, ci0, x0, ya, yb, dscale);
+        wgrad_limb_rows<LF>(p, pl, lds, acc, co0, ci0, x0, ya, yb, dscale);
 #endif
         s = seg_end;
         if (s == s1 || s == (tile + 1) * TS) {
@@ -548,6 +567,49 @@ __global__ void sr_finish_backward_kernel(const float* __restrict__ d_out, int C
     unsafeAtomicAdd(q + (long)yp * R1 + xp, g * ly1 * lx1);
 }
 
+// The bilinear residual's share of d_lr (models.py:858-868 transposed) as a GATHER: one thread per LR texel sums the HR pixels of the region
+// of interest whose two taps per axis include it -- candidates oy in [(y - 1) sf, (y + 2) sf] (both align_corners conventions: src(o) lies in
+// (o / sf - 1, o / sf + 1)), each tested with bilinear_tap itself, so the weights are the forward's bit for bit.  The scatter this replaces
+// (4 float atomics per HR pixel of the region, 16 sf^2 colliding on every texel) took 2.1 ms per plane at sf = 4; this takes ~0.2 ms.
+template <int SF>
+__global__ __launch_bounds__(256) void sr_residual_backward_gather_kernel(const float* __restrict__ d_out, int Cc, int R0, int R1, int lo0, int lo1,
+                                                                          int hi0, int hi1, int ty0, int tx0, int th, int tw,
+                                                                          float* __restrict__ d_lr, int align) {
+    constexpr int NC = 3 * SF + 1;
+    const long n = (long)Cc * th * tw;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = tx0 + (int)(i % tw), y = ty0 + (int)((i / tw) % th), c = (int)(i / ((long)tw * th));
+    const int HR0 = R0 * SF, HR1 = R1 * SF;
+    float wy[NC], wx[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int oy = (y - 1) * SF + k, ox = (x - 1) * SF + k;
+        wy[k] = wx[k] = 0.0f;
+        if (oy >= lo0 * SF && oy < hi0 * SF) {
+            const BilinearTap t = bilinear_tap(oy, R0, HR0, SF, align);
+            wy[k] = (t.i0 == y ? 1.0f - t.w1 : 0.0f) + (t.i0 + t.step == y ? t.w1 : 0.0f);
+        }
+        if (ox >= lo1 * SF && ox < hi1 * SF) {
+            const BilinearTap t = bilinear_tap(ox, R1, HR1, SF, align);
+            wx[k] = (t.i0 == x ? 1.0f - t.w1 : 0.0f) + (t.i0 + t.step == x ? t.w1 : 0.0f);
+        }
+    }
+    const float* __restrict__ src = d_out + (long)c * HR0 * HR1;
+    float sum = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < NC; ++ky) {
+        if (wy[ky] == 0.0f) continue;
+        const float* row = src + (long)((y - 1) * SF + ky) * HR1 + (x - 1) * SF;
+        float rs = 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < NC; ++kx)
+            if (wx[kx] != 0.0f) rs += row[kx] * wx[kx];
+        sum += rs * wy[ky];
+    }
+    d_lr[((long)c * R0 + y) * R1 + x] += sum;
+}
+
 // PlanesSR backward, input side: the clamped gather of sr_prepare_kernel transposed (replicate padding sums into the border texels)
 __global__ void sr_prepare_backward_kernel(const float* __restrict__ dxin, int Cc, int R0, int R1, int lo0, int lo1, int Hp, int Wp, int pad,
                                            const float* __restrict__ stdv, float* __restrict__ d_lr) {
@@ -571,16 +633,61 @@ static int wgrad_slabs(int Cin, int Cout, int Ho) {
 static long wgrad_total_steps(int Cin, int Cout, int Ho, int Wo) {
     return (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI) * ((Wo + WG_PX - 1) / WG_PX) * Ho;
 }
-static int wgrad_pieces(int Cin, int Cout, int Ho, int Wo) {
-    const long tiles = (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI), total = wgrad_total_steps(Cin, Cout, Ho, Wo);
+static int wgrad_pieces_of(long tiles, long total) {
     long n = total / 8;                      // at least ~8 steps per piece (prologue: 2 rows), ...
     if (n > 512) n = 512;                    // ... the chip's 512 workgroup slots (2 per CU) when the layer is large enough, ...
     if (n < tiles) n = tiles;                // ... and never longer than a tile: a piece crosses at most one tile boundary
     return (int)n;
 }
+static int wgrad_pieces(int Cin, int Cout, int Ho, int Wo) {
+    return wgrad_pieces_of((long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI), wgrad_total_steps(Cin, Cout, Ho, Wo));
+}
 static int64_t wgrad_partial_floats(int Cin, int Cout, int Ho, int Wo) {
     const int64_t a = (int64_t)wgrad_slabs(Cin, Cout, Ho) * 9 * Cout * Cin, b = (int64_t)wgrad_pieces(Cin, Cout, Ho, Wo) * 2 * 9 * WG_CO * WG_CI;
     return a > b ? a : b;                                  // either kernel may run (nvsr_set_conv_arithmetic)
+}
+// partial sums of a pass over several planes (limb kernel): as many pieces as the pass can have
+static int64_t wgrad_partial_floats_ragged(int Cin, int Cout) {
+    const int64_t tiles = (int64_t)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI);
+    return (tiles > 512 ? tiles : 512) * 2 * 9 * WG_CO * WG_CI;
+}
+
+// dw += scale * sum over the planes of dW(dy[b], x[b]) -- ONE pass of the limb kernel and one reduction for all planes (limb arithmetics only).
+// H[b], W[b] = size of x[b]; dy_absmax (f16 limbs): the word of launch_absmax[_ragged] over ALL planes' dy, or NULL with one plane
+static int launch_wgrad_planes(int nplanes, const float* const* dy, const float* const* x, int Cin, const int* H, const int* W, int Cout, float scale,
+                               float* dw, float* partial, hipStream_t stream, int arith, const unsigned* dy_absmax) {
+    if (nplanes < 1 || nplanes > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
+    const long tiles = (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI);
+    WgradParams p{dy[0], x[0], partial, Cin, Cout, H[0] - 2, W[0] - 2, 0, nullptr, 0, 0};
+    p.nplanes = nplanes;
+    long TS = 0;
+    for (int b = 0; b < CONV_RAGGED_MAX; ++b) {
+        const int k = b < nplanes ? b : 0;
+        const int Ho = H[k] - 2, Wo = W[k] - 2;
+        if (Ho < 1 || Wo < 1 || 64L * H[k] * W[k] >= (1L << 29)) return NVSR_ERR_SHAPE;     // (the kernel's int offset arithmetic)
+        p.pHo[b] = Ho; p.pWo[b] = Wo; p.pdy[b] = dy[k]; p.px[b] = x[k];
+        p.start[b] = (int)TS;
+        if (b < nplanes) TS += (long)((Wo + WG_PX - 1) / WG_PX) * Ho;
+    }
+    p.start[CONV_RAGGED_MAX] = (int)TS;
+    const long total = tiles * TS;
+    if (TS >= (1L << 30) || total >= (1L << 31) - TS) return NVSR_ERR_SHAPE;                   // (the kernel's int step arithmetic)
+    int n_wg = wgrad_pieces_of(tiles, total);
+#ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py; the tool sizes the workspace itself)
+    if (getenv("NVSR_WGRAD_PIECES")) n_wg = atoi(getenv("NVSR_WGRAD_PIECES"));
+#endif
+    const unsigned* am = nullptr;
+    if (arith == NVSR_ARITH_F16X2) {       // 2 f16 limbs: X with the static activation scale, dy with its tensor's own (one reduction)
+        am = dy_absmax;
+        if (!am && nplanes == 1) am = launch_absmax(dy[0], (long)Cout * (H[0] - 2) * (W[0] - 2), stream);
+        if (!am) return nplanes == 1 ? NVSR_ERR_LAUNCH : NVSR_ERR_NULL;
+    }
+    p.TS = (int)TS; p.n_wg = n_wg; p.total = total; p.dy_absmax = am;
+    if (am) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<2>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<3>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
+    hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, stream, partial, n_wg, total, TS, Cout, Cin,
+                       scale, dw, am);
+    return NVSR_CHECK_LAUNCH();
 }
 
 // dw += scale * dW(dy, x);  H, W = size of x
@@ -590,31 +697,36 @@ static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, 
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
     arith = conv_resolve_arith(arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
-    const bool limb = arith != NVSR_ARITH_F32;
+    if (arith != NVSR_ARITH_F32) return launch_wgrad_planes(1, &dy, &x, Cin, &H, &W, Cout, scale, dw, partial, stream, arith, dy_absmax);
     const long n = 9L * Cout * Cin;
-    if (limb) {
-        int n_wg = wgrad_pieces(Cin, Cout, Ho, Wo);
-        const long total = wgrad_total_steps(Cin, Cout, Ho, Wo), TS = (long)((Wo + WG_PX - 1) / WG_PX) * Ho;
-        if (total >= (1L << 31) - TS || 64L * H * W >= (1L << 29)) return NVSR_ERR_SHAPE;   // (the kernel's int step and offset arithmetic)
-#ifdef WG_TUNE     // variant builds only (tools/conv_wgrad_time.py; the tool sizes the workspace itself)
-        if (getenv("NVSR_WGRAD_PIECES")) n_wg = atoi(getenv("NVSR_WGRAD_PIECES"));
-#endif
-        const unsigned* am = nullptr;
-        if (arith == NVSR_ARITH_F16X2) {       // 2 f16 limbs: X with the static activation scale, dy with its tensor's own (one reduction)
-            am = dy_absmax ? dy_absmax : launch_absmax(dy, (long)Cout * Ho * Wo, stream);
-            if (!am) return NVSR_ERR_LAUNCH;
-        }
-        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, 0, am, n_wg, total};
-        if (am) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<2>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
-        else hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<3>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
-        hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, stream, partial, n_wg, total, TS, Cout,
-                           Cin, scale, dw, am);
-    } else {
-        const int ns = wgrad_slabs(Cin, Cout, Ho);
-        WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, nullptr, 0, 0};
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns), dim3(WG_TPB), 0, stream, p);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
-    }
+    const int ns = wgrad_slabs(Cin, Cout, Ho);
+    WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, nullptr, 0, 0};
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((Cout + WG_CO - 1) / WG_CO, (Cin + WG_CI - 1) / WG_CI, ns), dim3(WG_TPB), 0, stream, p);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, ns, Cout, Cin, scale, dw);
+    return NVSR_CHECK_LAUNCH();
+}
+
+static bool launch_residual_gather(const float* d_out, int Cc, int R0, int R1, int sf, const int* lo, const int* hi, float* d_lr, int align,
+                                   hipStream_t stream) {
+    const int ty0 = lo[0] > 0 ? lo[0] - 1 : 0, ty1 = hi[0] + 1 < R0 ? hi[0] + 1 : R0, tx0 = lo[1] > 0 ? lo[1] - 1 : 0, tx1 = hi[1] + 1 < R1 ? hi[1] + 1 : R1;
+    const int th = ty1 - ty0, tw = tx1 - tx0;
+    const long n = (long)Cc * th * tw;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (sf == 4) hipLaunchKernelGGL(sr_residual_backward_gather_kernel<4>, grid, block, 0, stream, d_out, Cc, R0, R1, lo[0], lo[1], hi[0], hi[1], ty0, tx0, th, tw, d_lr, align);
+    else if (sf == 2) hipLaunchKernelGGL(sr_residual_backward_gather_kernel<2>, grid, block, 0, stream, d_out, Cc, R0, R1, lo[0], lo[1], hi[0], hi[1], ty0, tx0, th, tw, d_lr, align);
+    else if (sf == 8) hipLaunchKernelGGL(sr_residual_backward_gather_kernel<8>, grid, block, 0, stream, d_out, Cc, R0, R1, lo[0], lo[1], hi[0], hi[1], ty0, tx0, th, tw, d_lr, align);
+    else return false;                           // (other scale factors keep the scatter of sr_finish_backward_kernel)
+    return true;
+}
+
+// sr_finish_backward for one plane: d_diff, and the residual's share of d_lr (gather for the bilinear residual, scatter for the bicubic one)
+static int finish_backward(const float* d_out, int Cc, int R0, int R1, int sf, const int* lo, const int* hi, int Ho, int Wo, int over, float* d_diff,
+                           float* d_lr, int align, int bicubic, hipStream_t stream) {
+    const int64_t n_diff = (int64_t)Cc * Ho * Wo;
+    bool gathered = false;
+    if (d_lr && !bicubic) gathered = launch_residual_gather(d_out, Cc, R0, R1, sf, lo, hi, d_lr, align, stream);
+    hipLaunchKernelGGL(sr_finish_backward_kernel, dim3((unsigned)((n_diff + 255) / 256)), dim3(256), 0, stream, d_out, Cc, R0, R1, sf, lo[0], lo[1], hi[0],
+                       hi[1], Ho, Wo, over, d_diff, gathered ? nullptr : d_lr, align, bicubic);
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -798,9 +910,7 @@ int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, con
     float* d_diff = workspace;
     float* dxin = d_diff + (n_diff + 3) / 4 * 4;
     float* ews = dxin + (n_in + 3) / 4 * 4;
-    hipLaunchKernelGGL(sr_finish_backward_kernel, dim3((unsigned)((n_diff + 255) / 256)), dim3(256), 0, stream, d_out, Cc, R0, R1, sf, lo[0],
-                       lo[1], hi[0], hi[1], P.Ho, P.Wo, over, d_diff, d_lr, sr_align_corners(), sr_bicubic());
-    if (int e = NVSR_CHECK_LAUNCH()) return e;
+    if (int e = finish_backward(d_out, Cc, R0, R1, sf, lo, hi, P.Ho, P.Wo, over, d_diff, d_lr, sr_align_corners(), sr_bicubic(), stream)) return e;
     const float* xin = keep;
     const float* acts = keep + (n_in + 3) / 4 * 4;
     if (int e = nvsr_edsr_backward_arith(xin, Cc, Hp, Wp, acts, packed_dgrad, Cc, hid, nblocks, n_up, d_diff, grad_natural, d_lr ? dxin : nullptr, ews,
@@ -809,6 +919,208 @@ int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, con
     if (d_lr) {
         hipLaunchKernelGGL(sr_prepare_backward_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, dxin, Cc, R0, R1, lo[0], lo[1],
                            Hp, Wp, pad, stdv, d_lr);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    return NVSR_OK;
+}
+
+
+/* ---- backward of nvsr_planes_sr_train_batch_arith: B regions of interest at once ------------------------------------------------------------
+ * Per layer ONE weight-gradient pass over all planes (one set of partial sums, one reduction: launch_wgrad_planes), ONE data-gradient launch
+ * (ragged batch) and -- f16 limbs -- ONE magnitude reduction per gradient tensor across the planes.  keep: the forward's buffer;
+ * d_out: B HOST pointers to [C][sf R0][sf R1] gradients (entries outside a plane's ROI are ignored); grad_natural += the EDSR weight gradients
+ * of all planes; d_lr: NULL or B HOST pointers, each NULL (plane detached, models.py:272) or [C][R0][R1] += that LR plane's gradient. */
+}  // extern "C"   (helpers below are C++)
+
+namespace nvsr {
+
+// backward of the EDSR forward on B inputs of different sizes (nvsr_edsr_backward_arith with one launch per layer and operation for all planes)
+static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x, const float* const* acts, const float* packed_dgrad,
+                                const float* const* d_out, float* grad_natural, float* const* dx, float* workspace, int arith, hipStream_t stream) {
+    const int n = P[0].n;
+    // workspace: 3 gradient buffers + 1 un-shuffled gradient, each holding one tensor per plane, + the partial sums + one word per gradient tensor
+    int64_t toff[CONV_RAGGED_MAX + 1] = {0};
+    for (int b = 0; b < B; ++b) toff[b + 1] = toff[b] + (P[b].max_tensor + 3) / 4 * 4;
+    const int64_t T = toff[B];
+    auto buf = [&](int k, int b) { return workspace + k * T + toff[b]; };
+    float* partial = workspace + 4 * T;
+    int64_t part_floats = 0;
+    for (int l = 0; l < n; ++l) {
+        const int64_t f = wgrad_partial_floats_ragged(P[0].L[l].Cin, P[0].L[l].Cout);
+        if (f > part_floats) part_floats = f;
+    }
+    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + (part_floats + 3) / 4 * 4);
+    int amax_next = 0;
+    int64_t goff[EDSR_MAX_LAYERS], poff[EDSR_MAX_LAYERS], go = 0, po = 0;
+    for (int l = 0; l < n; ++l) {
+        goff[l] = go; poff[l] = po;
+        go += 9LL * P[0].L[l].Cin * P[0].L[l].Cout;
+        po += conv_packed_floats(P[0].L[l].Cout, P[0].L[l].Cin);
+    }
+    const bool f16 = arith == NVSR_ARITH_F16X2;
+    const float* g[CONV_RAGGED_MAX];       // gradient with respect to the output of layer l (after its epilogue), per plane
+    int gi = -1;                           // index of g in the buffers (-1: the caller's d_out)
+    for (int b = 0; b < B; ++b) g[b] = d_out[b];
+    auto next_buf = [&](int a, int c) { for (int k = 0; k < 3; ++k) if (k != a && k != c) return k; return 0; };
+    auto input_of = [&](int l, int b) { return l ? acts[b] + P[b].act_off[l] : x[b]; };
+    // one magnitude word per gradient tensor, over all planes
+    auto amax = [&](const float* const* t, int co, int l_out, bool unshuffled) -> const unsigned* {
+        if (!f16) return nullptr;
+        long cnt[CONV_RAGGED_MAX];
+        for (int b = 0; b < B; ++b) cnt[b] = (long)co * (P[b].ih[l_out] - 2) * (P[b].iw[l_out] - 2);
+        (void)unshuffled;
+        return launch_absmax_ragged(B, t, cnt, stream, amax_words + amax_next++);
+    };
+    auto wgrad = [&](const float* const* dy, int l, float scale, const unsigned* am) {
+        const float* xs[CONV_RAGGED_MAX]; int H[CONV_RAGGED_MAX], W[CONV_RAGGED_MAX];
+        for (int b = 0; b < B; ++b) { xs[b] = input_of(l, b); H[b] = P[b].ih[l]; W[b] = P[b].iw[l]; }
+        return launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am);
+    };
+    // data gradient of layer l: dy [Cout][ih-2][iw-2] -> [Cin][ih][iw] with the given backward epilogue
+    auto dgrad = [&](const float* const* dy, int l, int epi, const float* const* skip, float* const* out, const unsigned* am) {
+        ConvRagged r;
+        r.n = B;
+        for (int b = 0; b < B; ++b) {
+            r.H[b] = P[b].ih[l] - 2; r.W[b] = P[b].iw[l] - 2;
+            r.in[b] = dy[b]; r.out[b] = out[b]; r.skip[b] = skip ? skip[b] : nullptr;
+        }
+        ConvExec cx{arith, 0};
+        cx.in_absmax = am;
+        return launch_conv(nullptr, P[0].L[l].Cout, 0, 0, packed_dgrad + poff[l], P[0].L[l].Cin, epi, nullptr, nullptr, stream, 2, B, cx, &r);
+    };
+    int e;
+    for (int l = n - 1; l >= 0; --l) {
+        const int co = P[0].L[l].Cout;
+        const bool need_dx = l > 0 || dx;
+        if (P[0].epi[l] == EPI_PIXEL_SHUFFLE) {           // g is [co/4][2(ih-2)][2(iw-2)]: undo the shuffle first
+            const float* un[CONV_RAGGED_MAX];
+            for (int b = 0; b < B; ++b) {
+                const long cnt = (long)co * (P[b].ih[l] - 2) * (P[b].iw[l] - 2);
+                hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, g[b], co / 4, P[b].ih[l] - 2,
+                                   P[b].iw[l] - 2, buf(3, b));
+                un[b] = buf(3, b);
+            }
+            if ((e = NVSR_CHECK_LAUNCH())) return e;
+            const unsigned* am = amax(un, co, l, true);
+            if (f16 && !am) return NVSR_ERR_LAUNCH;
+            if ((e = wgrad(un, l, 1.0f, am))) return e;
+            const int o = next_buf(gi, -1);
+            float* outs[CONV_RAGGED_MAX];
+            for (int b = 0; b < B; ++b) outs[b] = buf(o, b);
+            if ((e = dgrad(un, l, EPI_NONE, nullptr, outs, am))) return e;
+            for (int b = 0; b < B; ++b) g[b] = outs[b];
+            gi = o;
+        } else if (P[0].epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
+            const int l1 = l - 1;
+            const float* t1[CONV_RAGGED_MAX];              // relu(conv1(xb))
+            for (int b = 0; b < B; ++b) t1[b] = input_of(l, b);
+            const unsigned* am = amax(g, co, l, false);
+            if (f16 && !am) return NVSR_ERR_LAUNCH;
+            if ((e = wgrad(g, l, 0.1f, am))) return e;
+            const int o1 = next_buf(gi, -1);
+            float* d1[CONV_RAGGED_MAX]; const float* d1c[CONV_RAGGED_MAX];
+            for (int b = 0; b < B; ++b) d1c[b] = d1[b] = buf(o1, b);
+            if ((e = dgrad(g, l, EPI_MASK_SCALE, t1, d1, am))) return e;
+            const unsigned* am1 = amax(d1c, P[0].L[l1].Cout, l1, false);
+            if (f16 && !am1) return NVSR_ERR_LAUNCH;
+            if ((e = wgrad(d1c, l1, 1.0f, am1))) return e;
+            const int o2 = next_buf(gi, o1);
+            float* d2[CONV_RAGGED_MAX];
+            for (int b = 0; b < B; ++b) d2[b] = buf(o2, b);
+            if ((e = dgrad(d1c, l1, EPI_ADD_CENTER, g, d2, am1))) return e;
+            for (int b = 0; b < B; ++b) g[b] = d2[b];
+            gi = o2;
+            --l;                                           // conv1 is done too
+        } else {                                           // plain conv (conv_input, conv_mid, conv_output)
+            const unsigned* am = amax(g, co, l, false);
+            if (f16 && !am) return NVSR_ERR_LAUNCH;
+            if ((e = wgrad(g, l, 1.0f, am))) return e;
+            if (need_dx) {
+                const int o = next_buf(gi, -1);
+                float* outs[CONV_RAGGED_MAX];
+                for (int b = 0; b < B; ++b) outs[b] = (l == 0) ? dx[b] : buf(o, b);
+                if ((e = dgrad(g, l, EPI_NONE, nullptr, outs, am))) return e;
+                if (l) { for (int b = 0; b < B; ++b) g[b] = outs[b]; gi = o; }
+            }
+        }
+    }
+    return NVSR_OK;
+}
+
+}  // namespace nvsr
+
+extern "C" {
+
+int64_t nvsr_planes_sr_batch_backward_workspace_floats(int B, int Cc, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois) {
+    if (B < 1 || B > CONV_RAGGED_MAX) return -1;
+    static thread_local EdsrPlan P;
+    int64_t s = 0, T = 0, one = 0;
+    for (int b = 0; b < B; ++b) {
+        int lo[2], hi[2];
+        sr_roi(R0, R1, rois ? rois + 4 * b : nullptr, lo, hi);
+        const int Hp = hi[0] - lo[0] + 2 * pad, Wp = hi[1] - lo[1] + 2 * pad;
+        if (edsr_plan(Cc, Cc, hid, nblocks, n_up, Hp, Wp, &P)) return -1;
+        s += ((int64_t)Cc * P.Ho * P.Wo + 3) / 4 * 4 + ((int64_t)Cc * Hp * Wp + 3) / 4 * 4;      // d_diff + the prepared input's gradient
+        T += (P.max_tensor + 3) / 4 * 4;
+        const int64_t w1 = nvsr_edsr_backward_workspace_floats(Cc, Cc, hid, nblocks, n_up, Hp, Wp);   // (the plane-by-plane path of exact f32)
+        if (w1 > one) one = w1;
+    }
+    int64_t part = 0;
+    for (int l = 0; l < P.n; ++l) {
+        const int64_t f = wgrad_partial_floats_ragged(P.L[l].Cin, P.L[l].Cout);
+        if (f > part) part = f;
+    }
+    const int64_t ragged = 4 * T + (part + 3) / 4 * 4 + (P.n + 7) / 4 * 4;
+    return s + (ragged > one ? ragged : one);
+}
+
+int nvsr_planes_sr_backward_batch_arith(int B, int Cc, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up,
+                                        int pad, int over, const float* rois, const float* stdv, const float* const* d_out, float* grad_natural,
+                                        float* const* d_lr, float* workspace, int arithmetic, int align_corners, int plane_interp,
+                                        nvsr_stream_t stream_) {
+    if (!keep || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
+    if (B < 1 || B > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
+    if (plane_interp != NVSR_PLANE_INTERP_BILINEAR && plane_interp != NVSR_PLANE_INTERP_BICUBIC) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed_dgrad) || !aligned16(workspace) || !aligned16(keep)) return NVSR_ERR_ALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int sf = 1 << n_up, arith = conv_resolve_arith(arithmetic);
+    static thread_local EdsrPlan P[CONV_RAGGED_MAX];
+    int lo[CONV_RAGGED_MAX][2], hi[CONV_RAGGED_MAX][2], Hp[CONV_RAGGED_MAX], Wp[CONV_RAGGED_MAX];
+    const float* xin[CONV_RAGGED_MAX]; const float* acts[CONV_RAGGED_MAX];
+    float* d_diff[CONV_RAGGED_MAX]; float* dxin[CONV_RAGGED_MAX];
+    const float* k = keep; float* w = workspace;
+    bool any_lr = false;
+    for (int b = 0; b < B; ++b) {
+        if (!d_out[b]) return NVSR_ERR_NULL;
+        sr_roi(R0, R1, rois ? rois + 4 * b : nullptr, lo[b], hi[b]);
+        Hp[b] = hi[b][0] - lo[b][0] + 2 * pad; Wp[b] = hi[b][1] - lo[b][1] + 2 * pad;
+        if (int e = edsr_plan(Cc, Cc, hid, nblocks, n_up, Hp[b], Wp[b], &P[b])) return e;
+        if (P[b].Ho != (hi[b][0] - lo[b][0]) * sf + 2 * over || P[b].Wo != (hi[b][1] - lo[b][1]) * sf + 2 * over) return NVSR_ERR_SHAPE;
+        const int64_t n_in = (int64_t)Cc * Hp[b] * Wp[b];
+        xin[b] = k; acts[b] = k + (n_in + 3) / 4 * 4;
+        k = acts[b] + P[b].acts_floats;
+        d_diff[b] = w; w += ((int64_t)Cc * P[b].Ho * P[b].Wo + 3) / 4 * 4;
+        dxin[b] = w; w += (n_in + 3) / 4 * 4;
+        any_lr = any_lr || (d_lr && d_lr[b]);
+    }
+    for (int b = 0; b < B; ++b)
+        if (int e = finish_backward(d_out[b], Cc, R0, R1, sf, lo[b], hi[b], P[b].Ho, P[b].Wo, over, d_diff[b], d_lr ? d_lr[b] : nullptr, align_corners ? 1 : 0,
+                                    plane_interp == NVSR_PLANE_INTERP_BICUBIC ? 1 : 0, stream))
+            return e;
+    if (arith == NVSR_ARITH_F32 || B == 1) {
+        for (int b = 0; b < B; ++b)
+            if (int e = nvsr_edsr_backward_arith(xin[b], Cc, Hp[b], Wp[b], acts[b], packed_dgrad, Cc, hid, nblocks, n_up, d_diff[b], grad_natural,
+                                                 (d_lr && d_lr[b]) ? dxin[b] : nullptr, w, arith, stream_))
+                return e;
+    } else {
+        // (a plane whose LR gradient nobody wants still gets its first layer's data gradient when another plane needs it: 0.3 % of the pass)
+        if (int e = edsr_backward_planes(B, P, xin, acts, packed_dgrad, d_diff, grad_natural, any_lr ? dxin : nullptr, w, arith, stream)) return e;
+    }
+    for (int b = 0; b < B; ++b) {
+        if (!(d_lr && d_lr[b])) continue;
+        const int64_t n_in = (int64_t)Cc * Hp[b] * Wp[b];
+        hipLaunchKernelGGL(sr_prepare_backward_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, dxin[b], Cc, R0, R1, lo[b][0], lo[b][1],
+                           Hp[b], Wp[b], pad, stdv, d_lr[b]);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
     return NVSR_OK;

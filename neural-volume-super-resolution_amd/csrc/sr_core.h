@@ -173,7 +173,23 @@ int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
 // bits of max |x| over a tensor, in a device word that stays valid for the launches queued behind it (sr.hip): the power-of-two scale of an
 // f16-limb gradient operand; NULL on a launch error
 const unsigned* launch_absmax(const float* x, long n, hipStream_t stream, unsigned* owned = nullptr);
+// A RAGGED batch: up to CONV_RAGGED_MAX planes of DIFFERENT sizes through one launch with the same weights -- the regions of interest of a
+// scene's position planes in an SR training iteration (models.py:270-284: every plane has its own crop).  One 256-channel layer of one crop is
+// 2-3 workgroup rounds with a last round a fifth full; the three crops together are 6-7 rounds.  The grid is sized for the largest plane;
+// workgroups whose tile lies outside their (smaller) plane leave at once.  H, W: logical input size per plane INCLUDING the virtual border.
+constexpr int CONV_RAGGED_MAX = 4;
+struct ConvRagged {
+    int n = 0;                                   // 0: not ragged (ConvParams' own tensors and batch strides apply)
+    int H[CONV_RAGGED_MAX] = {0, 0, 0, 0}, W[CONV_RAGGED_MAX] = {0, 0, 0, 0};
+    const float* in[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    float* out[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    const float* skip[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
+};
+// rag != NULL: in / skip / out / H / W / batch are ignored (rag->H, rag->W = sizes of the tensors in memory, the virtual border is added here);
+// limb arithmetics only, and an f16 data gradient needs cx.in_absmax (one word for all planes: launch_absmax_ragged)
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
-                hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{});
+                hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{}, const ConvRagged* rag = nullptr);
+// max |x| over up to CONV_RAGGED_MAX tensors in one launch, into the caller's word
+const unsigned* launch_absmax_ragged(int n, const float* const* x, const long* count, hipStream_t stream, unsigned* owned);
 
 }  // namespace nvsr

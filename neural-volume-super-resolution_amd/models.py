@@ -401,33 +401,65 @@ class TwoDimPlanesModel(nn.Module):
             hit = _cache_plane(name, src)
         return hit[2]
 
-    def training_planes(self, rays, normalized_points=None):
-        """The NCHW tensors a training step samples, as autograd sees them: the raw plane parameters, or -- where a plane is
-        super-resolved -- the output of PlanesSR on the region of interest the batch covers (models.py:270-284: the reference takes
-        the ROI of every point chunk; the bounding box of the ray segments [near, far] contains all of them, and the super-resolved
-        values do not depend on the ROI).  rays: packed [N,11]; or normalized_points [P,3]: the normalised (and jittered) positions of a
-        model call, whose own bounding box is the ROI like in the reference."""
-        names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
-        out, n_ends = [], normalized_points
-        for d, name in enumerate(names):
-            # models.py:273: every plane name goes through the coupler -- an HR scene coupled to an LR scene samples the LR scene's saved planes
-            saved = self.scene_coupler.scene_with_saved_plane(name, plane_not_scene=True) if self.scene_coupler is not None else name
-            if not (d < self.num_density_planes and self._should_SR(name)):
-                out.append(self.planes_[saved])
-                continue
-            if not self.SR_model.training:
-                out.append(self.SR_model(saved))                      # full plane, cached (models.py:277: ROI only in training)
-                continue
-            if n_ends is None:
-                box = self.box_coords[self.cur_id + ""].to(rays.device)
-                lo, rng = box[0, :3].float(), (box[1, :3] - box[0, :3]).float()
-                ends = torch.cat([rays[:, 0:3] + rays[:, 3:6] * rays[:, 6:7], rays[:, 0:3] + rays[:, 3:6] * rays[:, 7:8]], 0)
-                n_ends = 2 * (ends - lo) / rng - 1
+    def training_rois(self, rays=None, normalized_points=None):
+        """The regions of interest of a training batch (models.py:270-284: the ROI of every point chunk; the bounding box of the ray segments
+        [near, far] contains all of them, and the super-resolved values do not depend on the ROI): for every position plane that is
+        super-resolved in training mode, [[ymin, xmin], [ymax, xmax]] in normalised plane coordinates.  -> (plane indices, device tensor
+        [n, 2, 2]) -- the arithmetic stays on the device; the caller decides when the host reads it (one copy for all planes).
+        rays: packed [N,11]; or normalized_points [P,3]: the normalised (and jittered) positions of a model call."""
+        names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes)]
+        dims = [d for d, name in enumerate(names) if self._should_SR(name)] if (hasattr(self, "SR_model") and self.SR_model.training) else []
+        if not dims:
+            return [], None
+        n_ends = normalized_points
+        if n_ends is None:
+            # (the box and the projection matrices on the device, cached per version: a host tensor's .to(device) is a blocking copy per call)
+            box_t = self.box_coords[self.cur_id + ""]
+            key = (self.cur_id, str(rays.device), box_t.data_ptr(), box_t._version)
+            cache = self.__dict__.get("_roi_consts")
+            if cache is None or cache[0] != key:
+                box = box_t.to(rays.device)
+                cache = (key, box[0, :3].float(), (box[1, :3] - box[0, :3]).float())
+                self.__dict__["_roi_consts"] = cache
+            lo, rng = cache[1], cache[2]
+            ends = torch.cat([rays[:, 0:3] + rays[:, 3:6] * rays[:, 6:7], rays[:, 0:3] + rays[:, 3:6] * rays[:, 7:8]], 0)
+            n_ends = 2 * (ends - lo) / rng - 1
+        rois = []
+        for d in dims:
             m = self.coord_projector.rot_mats_NON_LEARNED[d].detach().float().to(n_ends.device)[:, 1:]
             grid = n_ends @ m                                         # [2N, (x, y)]
             gmin, gmax = grid.min(0)[0], grid.max(0)[0]
-            roi = torch.stack([torch.stack([gmin[1], gmin[0]]), torch.stack([gmax[1], gmax[0]])], 0)   # rows (min, max), cols (y, x)
-            out.append(self.SR_model((saved, roi)))
+            rois.append(torch.stack([torch.stack([gmin[1], gmin[0]]), torch.stack([gmax[1], gmax[0]])], 0))   # rows (min, max), cols (y, x)
+        return dims, torch.stack(rois, 0)
+
+    def training_planes(self, rays, normalized_points=None):
+        """The NCHW tensors a training step samples, as autograd sees them: the raw plane parameters, or -- where a plane is
+        super-resolved -- the output of PlanesSR on the region of interest the batch covers (training_rois).  All super-resolved planes of the
+        scene go through the SR network together (PlanesSR.forward_many: one launch per layer for all regions of interest).
+        A caller that has the regions on the host already (training.TrainStep computes them ahead of the iteration on a side stream, so that
+        the host never waits for the queue to drain) leaves them in `self._roi_hint = (number of rays, [[4 floats] per plane])`."""
+        names = [get_plane_name(self.cur_id, d) for d in range(self.num_density_planes + 1)]
+        saved = [self.scene_coupler.scene_with_saved_plane(n, plane_not_scene=True) if self.scene_coupler is not None else n for n in names]
+        # models.py:273: every plane name goes through the coupler -- an HR scene coupled to an LR scene samples the LR scene's saved planes
+        out = [None] * len(names)
+        sr_dims = []
+        for d, name in enumerate(names):
+            if not (d < self.num_density_planes and self._should_SR(name)):
+                out[d] = self.planes_[saved[d]]
+            elif not self.SR_model.training:
+                out[d] = self.SR_model(saved[d])                       # full plane, cached (models.py:277: ROI only in training)
+            else:
+                sr_dims.append(d)
+        if sr_dims:
+            hint = self.__dict__.pop("_roi_hint", None)
+            if hint is not None and normalized_points is None and rays is not None and hint[0] == rays.shape[0] and len(hint[1]) == len(sr_dims):
+                rois = hint[1]
+            else:
+                dims, dev_rois = self.training_rois(rays, normalized_points)
+                assert dims == sr_dims
+                rois = dev_rois.detach().reshape(len(dims), 4).cpu().tolist()          # ONE host read for all planes
+            for d, plane in zip(sr_dims, self.SR_model.forward_many([(saved[d], rois[k]) for k, d in enumerate(sr_dims)])):
+                out[d] = plane
         return out
 
     def _generic_forward(self, x, coord_noise=None):
@@ -890,6 +922,31 @@ class PlanesSR(nn.Module):
             pad_n[..., r0:r1, c0:c1] = n_out
             out = out + pad_n
         return out
+
+    def forward_many(self, requests):
+        """[(plane_name, roi | None), ...] -> the super-resolved planes, like one forward() call per request (models.py:884-926).  In training,
+        when gradients are wanted and the planes are equally sized, all requests go through the network TOGETHER (ops.PlanesSRBatchFn: one
+        launch per layer convolves every plane's region of interest, one weight-gradient pass per layer in the backward); anything else --
+        evaluation, the training noises of models.py:896-897,920-921, more than four planes -- is one forward() per request."""
+        reqs = [(r, None) if isinstance(r, str) else (r[0], r[1]) for r in requests]
+        lrs = [self.LR_planes[n] for n, _ in reqs]
+        net = self.inner_model
+        noisy = self.training and (self.input_noise > 0 or self.output_noise > 0)
+        batched = (len(reqs) >= 2 and len(reqs) <= capi.SR_BATCH_MAX and self.training and net.wants_grad(*lrs) and not noisy
+                   and len({tuple(t.shape[-3:]) for t in lrs}) == 1 and all(t.dtype == torch.float32 for t in lrs)
+                   and all((roi is None) == (reqs[0][1] is None) for _, roi in reqs))
+        if not batched:
+            return [self.forward(n if roi is None else (n, roi)) for n, roi in reqs]
+        rois = None
+        if reqs[0][1] is not None:
+            rois = [float(v) for _, roi in reqs for v in (roi if isinstance(roi, (list, tuple)) else torch.as_tensor(roi).detach().cpu().reshape(-1).tolist())]
+        mean = std = None
+        if hasattr(self, "planes_mean_NON_LEARNED"):
+            mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
+        cfg = dict(packed=net.packed_weights(), packed_dgrad=net.packed_dgrad_weights(), geometry=list(net.geometry), pad=self._kernel_pad,
+                   over=self._kernel_over, rois=rois, mean=mean, std=std, arithmetic=capi.resolve_conv_arithmetic(net.arithmetic),
+                   align_corners=bool(self.align_corners), bicubic=self.plane_interp == "bicubic")
+        return list(ops.PlanesSRBatchFn.apply(cfg, net.natural_blob(differentiable=True), *lrs))
 
     def forward(self, plane_name):
         if isinstance(plane_name, tuple):

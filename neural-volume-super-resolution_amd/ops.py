@@ -837,6 +837,110 @@ def _planes_sr_train_bwd(ctx, d_out, d_keep):
 
 planes_sr_train.register_autograd(_planes_sr_train_bwd, setup_context=_planes_sr_train_setup)
 
+
+
+# ---- the regions of interest of B planes through the SR network at once (training; include/nvsr.h "SR training on the regions of interest of B
+# planes at once").  Buffers are allocated at the capacity of FULL planes whatever the regions are: a training iteration's regions change with
+# every batch of rays, and exact sizes would hand the caching allocator a new set of multi-GB block sizes per iteration (measured on the refine
+# workload: the iteration waited ~40 ms for the allocator); with one size per buffer the blocks of the previous iteration are reused as they are.
+def _rois_c(rois, B):
+    if rois is None:
+        return None
+    assert len(rois) == 4 * B
+    return (C.c_float * (4 * B))(*[float(v) for v in rois])
+
+
+@custom_op("nvsr::planes_sr_train_batch", mutates_args=(), device_types="cuda")
+def planes_sr_train_batch(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad: int, over: int, rois: Optional[Sequence[float]],
+                          mean: Optional[Tensor], std: Optional[Tensor], arithmetic: int, align_corners: bool, bicubic: bool) -> List[Tensor]:
+    """planes_sr_train of B equally sized planes [C,R0,R1], every one on its own region of interest (rois: 4 floats per plane, or None), one
+    launch per layer for all of them.  -> [out_0 .. out_{B-1} ([1,C,sf R0,sf R1] each, NaN outside the region), keep]"""
+    lr = [_c(t) for t in lr]
+    cin, cout, hid, nb, n_up = geometry
+    B = len(lr)
+    Cc, R0, R1 = lr[0].shape[-3:]
+    assert Cc == cin == cout and all(tuple(t.shape[-3:]) == (Cc, R0, R1) for t in lr)
+    lib = capi.lib()
+    rois_c = _rois_c(rois, B)
+    if lib.nvsr_planes_sr_batch_keep_floats(B, Cc, R0, R1, hid, nb, n_up, pad, rois_c) < 0:
+        raise capi.NvsrError("PlanesSR: region of interest too small for the network")
+    nkeep = lib.nvsr_planes_sr_batch_keep_floats(B, Cc, R0, R1, hid, nb, n_up, pad, None)
+    nws = lib.nvsr_planes_sr_batch_workspace_floats(B, Cc, R0, R1, hid, nb, n_up, pad, None)
+    sf = 1 << n_up
+    outs = [_f(1, Cc, R0 * sf, R1 * sf, like=lr[0]) for _ in lr]
+    ws, keep = _f(nws, like=lr[0]), _f(nkeep, like=lr[0])
+    lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lr])
+    out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
+    capi.call("nvsr_planes_sr_train_batch_arith", lr_ptrs, B, Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, rois_c, capi.ptr(mean), capi.ptr(std),
+              out_ptrs, capi.ptr(ws), capi.ptr(keep), arithmetic, int(bool(align_corners)), int(bool(bicubic)), capi.stream())
+    return outs + [keep]
+
+
+@planes_sr_train_batch.register_fake
+def _(lr, packed, geometry, pad, over, rois, mean, std, arithmetic, align_corners, bicubic):
+    cin, cout, hid, nb, n_up = geometry
+    sf = 1 << n_up
+    Cc, R0, R1 = lr[0].shape[-3:]
+    nkeep = capi.lib().nvsr_planes_sr_batch_keep_floats(len(lr), int(Cc), int(R0), int(R1), hid, nb, n_up, pad, None)
+    return [t.new_empty((1, Cc, R0 * sf, R1 * sf)) for t in lr] + [lr[0].new_empty((nkeep,))]
+
+
+@custom_op("nvsr::planes_sr_backward_batch", mutates_args=(), device_types="cuda")
+def planes_sr_backward_batch(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence[int], geometry: Sequence[int], pad: int, over: int,
+                             rois: Optional[Sequence[float]], std: Optional[Tensor], d_out: Sequence[Tensor], need_lr: Sequence[bool], arithmetic: int,
+                             align_corners: bool, bicubic: bool) -> List[Tensor]:
+    """-> [EDSR weight gradients in state-dict order (summed over the planes), d_lr_0 .. d_lr_{B-1} ([1,C,R0,R1]; empty where not needed)]"""
+    d_out = [_c(t) for t in d_out]
+    cin, cout, hid, nb, n_up = geometry
+    Cc, R0, R1 = plane_shape
+    B = len(d_out)
+    lib = capi.lib()
+    rois_c = _rois_c(rois, B)
+    gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
+    d_lr = [torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if n else _f(0, like=keep) for n in need_lr]
+    ws = _f(lib.nvsr_planes_sr_batch_backward_workspace_floats(B, Cc, R0, R1, hid, nb, n_up, pad, None), like=keep)
+    d_out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in d_out])
+    d_lr_ptrs = (C.c_void_p * B)(*[(t.data_ptr() if n else None) for t, n in zip(d_lr, need_lr)])
+    capi.call("nvsr_planes_sr_backward_batch_arith", B, Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, rois_c, capi.ptr(std),
+              d_out_ptrs, capi.ptr(gnat), d_lr_ptrs if any(need_lr) else None, capi.ptr(ws), arithmetic, int(bool(align_corners)), int(bool(bicubic)),
+              capi.stream())
+    return [gnat] + d_lr
+
+
+@planes_sr_backward_batch.register_fake
+def _(keep, packed_dgrad, plane_shape, geometry, pad, over, rois, std, d_out, need_lr, arithmetic, align_corners, bicubic):
+    cin, cout, hid, nb, n_up = geometry
+    n = 9 * (hid * cin + (2 * nb + 1) * hid * hid + n_up * 4 * hid * hid + cout * hid)
+    Cc, R0, R1 = plane_shape
+    return [keep.new_empty((n,))] + [keep.new_empty((1, Cc, R0, R1) if k else (0,)) for k in need_lr]
+
+
+class PlanesSRBatchFn(torch.autograd.Function):
+    """PlanesSR on the regions of interest of B planes as ONE autograd node: inputs (cfg, natural weights blob, lr_0 .. lr_{B-1}) -> B
+    super-resolved planes; the backward returns ONE weight-gradient blob (torch's cat / reshape backward hands the slices to the
+    convolutions' parameters once per iteration instead of once per plane) and the LR planes' gradients."""
+
+    @staticmethod
+    def forward(ctx, cfg, natural, *lrs):
+        res = direct.planes_sr_train_batch(list(lrs), cfg["packed"], cfg["geometry"], cfg["pad"], cfg["over"], cfg["rois"], cfg["mean"], cfg["std"],
+                                           cfg["arithmetic"], cfg["align_corners"], cfg["bicubic"])
+        outs, keep = res[:-1], res[-1]
+        ctx.cfg = cfg
+        ctx.shapes = [t.shape for t in lrs]
+        ctx.save_for_backward(keep, cfg["packed_dgrad"])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        keep, packed_dgrad = ctx.saved_tensors
+        cfg = ctx.cfg
+        need = ctx.needs_input_grad
+        need_lr = [bool(n) for n in need[2:]]
+        res = direct.planes_sr_backward_batch(keep, packed_dgrad, list(ctx.shapes[0][-3:]), cfg["geometry"], cfg["pad"], cfg["over"], cfg["rois"], cfg["std"],
+                                              [capi.f32c(g) for g in d_outs], need_lr, cfg["arithmetic"], cfg["align_corners"], cfg["bicubic"])
+        return (None, res[0] if need[1] else None) + tuple(g.reshape(sh) if n else None for g, sh, n in zip(res[1:], ctx.shapes, need_lr))
+
+
 # operators whose forward is checked with torch.library.opcheck in the GPU tests
 # =====================================================================================================================================
 # cumprod_exclusive (nerf_helpers.py:409-430) -- differentiable like the reference's torch helper

@@ -16,7 +16,7 @@ import torch
 
 from . import capi
 from .nerf_helpers import get_focal, img2mse, mse2psnr
-from .train_utils import eval_nerf, run_one_iter_of_nerf
+from .train_utils import _cfg, eval_nerf, pack_rays, run_one_iter_of_nerf
 
 
 def downsampling_offset(ds_factor):
@@ -257,6 +257,7 @@ class TrainStep:
         self.sr_loss, self.ds_factor, self.separate_decoder_sr = sr_loss, int(ds_factor), separate_decoder_sr
         self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
         self.pixel_sampler = pixel_sampler or select_training_pixels   # (img_target, num_random_rays, consistency_ds) -> (rows_cols, target_s)
+        self.prologue_ahead = True          # SR training: pixels, rays and regions of interest on a side stream ahead of the iteration (_draw_rays)
         import collections
         self._pending = collections.deque()
 
@@ -299,8 +300,8 @@ class TrainStep:
                 self.mf.train()
         if im_consistency_iter:      # render in HR although the target image is LR (:806-811)
             H, W, focal, cur_ds_factor = H * self.ds_factor, W * self.ds_factor, focal * self.ds_factor, cur_ds_factor // self.ds_factor
-        sel, target_s = self.pixel_sampler(img_target, num_random_rays, self.ds_factor if im_consistency_iter else None)
-        ro, rd = get_ray_bundle_at(H, W, focal, pose_target, sel, downsampling_offset=downsampling_offset(cur_ds_factor))
+        ro, rd, target_s = self._draw_rays(img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays,
+                                           self.ds_factor if im_consistency_iter else None)
         batch_rays = (ro, rd)               # (run_one_iter_of_nerf indexes [0] / [1]: the reference's stacked tensor costs a copy kernel)
         if first_v:
             for o in (self.optimizer, self.SR_optimizer):
@@ -334,6 +335,51 @@ class TrainStep:
         loss = rendering_loss if loss_w == 1.0 else loss_w * rendering_loss        # (x * 1.0 is x: one kernel and its backward less)
         self.apply_gradients(loss, last_v, sr_iter, confinements)
         return loss, rendering_loss, coarse_loss, fine_loss, not im_consistency_iter
+
+    def _draw_rays(self, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, consistency_ds):
+        """-> (ray origins, ray directions, target pixels) of this iteration's batch (train_nerf.py:814-846).
+        An iteration that trains THROUGH the SR network needs the regions of interest of the batch on the HOST before it can size a single launch
+        (models.py:270-284; the reference reads them back too).  Read on the iteration's own stream, that copy waits for everything queued before
+        it -- the whole previous iteration: the queue drains, and the GPU then idles while the host prepares the SR forward (measured on the refine
+        workload: 20 ms of a 110 ms iteration).  Pixels, rays and regions depend on nothing the previous iteration computes, so with a device-side
+        sampler they are produced on a SIDE stream and only that stream is waited for: the host has the regions ~0.2 ms after it asks, while the
+        GPU is still busy with the previous iteration's backward, and runs ahead of the queue from there.  The regions are left with the fine
+        model (`_roi_hint`, TwoDimPlanesModel.training_planes)."""
+        def draw():
+            sel, target_s = self.pixel_sampler(img_target, num_random_rays, consistency_ds)
+            ro, rd = get_ray_bundle_at(H, W, focal, pose_target, sel, downsampling_offset=downsampling_offset(cur_ds_factor))
+            return ro, rd, target_s
+
+        mf = self.mf
+        sr = getattr(mf, "SR_model", None) if mf is not None else None
+        ahead = (self.prologue_ahead and sr is not None and not getattr(mf, "skip_SR_", False) and sr.training and isinstance(self.pixel_sampler, DevicePixelSampler)
+                 and self.pixel_sampler.state is None and img_target.is_cuda and torch.is_tensor(pose_target) and pose_target.is_cuda
+                 and bool(_cfg(scene_config, "no_ndc", True)) and mf.is_native_geometry() and not getattr(mf, "point_coords_noise", 0))
+        if not ahead:
+            return draw()
+        dev = img_target.device
+        cur = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_prologue_stream")
+        if side is None:
+            side = self.__dict__["_prologue_stream"] = torch.cuda.Stream(device=dev, priority=-1)
+            side.wait_stream(cur)           # (once: the target image and the pose have been written by now)
+        with torch.cuda.stream(side):
+            ro, rd, target_s = draw()
+            mf.set_cur_scene_id(scene_id)
+            dims, rois = mf.training_rois(pack_rays(ro, rd, _cfg(scene_config, "near"), _cfg(scene_config, "far")))
+            host = None
+            if dims:
+                host = torch.empty((len(dims), 4), dtype=torch.float32, pin_memory=True)
+                host.copy_(rois.reshape(len(dims), 4), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        done.synchronize()                  # the side stream only
+        cur.wait_stream(side)
+        for x in (ro, rd, target_s):
+            x.record_stream(cur)            # (allocated on the side stream, read by the iteration's stream)
+        if host is not None:
+            mf._roi_hint = (ro.shape[0], host.tolist())
+        return ro, rd, target_s
 
     def apply_gradients(self, loss, last_v=True, sr_iter=False, confinements=()):
         """the tail of an iteration (train_nerf.py:903-914): backward, [data-parallel: grad_sync() averages the gradients over the ranks],

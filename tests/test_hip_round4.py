@@ -274,8 +274,13 @@ def test_evaluation_heals_an_sr_network_beyond_the_f16_range(hip):
         warnings.simplefilter("always")
         out = ev()
     assert any("bf16x3" in str(w.message) for w in wl)
-    assert torch.isfinite(out[3]).all() and sr.inner_model.arithmetic == "bf16x3" and int(hip.capi.range_flag().word) == 0
+    # (round 5, ADVICE r4: the fallback is scoped to the evaluation frame -- the network keeps the arithmetic it was configured with, so that a
+    #  later training iteration of the same SR model is not silently moved to another arithmetic)
+    assert torch.isfinite(out[3]).all() and sr.inner_model.arithmetic is None and int(hip.capi.range_flag().word) == 0
     assert not torch.equal(out[3], base[3])                     # (the changed weight changes the planes)
+    sr.clear_SR_planes()
+    again = ev()                                                # same parameters: straight to 'bf16x3' (no second F16X2 attempt), same pixels
+    assert torch.equal(again[3], out[3]) and sr.inner_model.arithmetic is None
 
 
 @pytest.mark.parametrize("plane_res,res,n_rays", [(200, 200, 8192), (800, 800, 8192)])

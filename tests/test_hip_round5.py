@@ -113,3 +113,148 @@ def test_eager_renders_between_graph_replays_see_the_updated_parameters(hip, wha
         loss_e = m_e["loss"]
         graphed()
         assert abs(graphed.metrics()["loss"] - loss_e) <= 1e-5 * max(1.0, abs(loss_e)), (graphed.metrics()["loss"], loss_e)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the regions of interest of a scene's planes through the SR network in ONE launch sequence
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _sr_setup(hip, hid, nb, R, seed, scale=10.0):
+    torch.manual_seed(seed)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(scale)
+    sr.train()
+    g = torch.Generator(device=DEV).manual_seed(seed + 1)
+    lrs = [torch.nn.Parameter(torch.randn(1, 48, R, R, device=DEV, generator=g) * 0.5) for _ in range(3)]
+    for k, t in enumerate(lrs):
+        sr.set_LR_plane(t, id="p%d" % k, save_interpolated=False)
+    return sr, lrs
+
+
+def _blob(sr):
+    return torch.cat([(w.grad if w.grad is not None else torch.zeros_like(w)).reshape(-1) for w in sr.inner_model.conv_parameters()])
+
+
+@pytest.mark.parametrize("hid,nb", [(16, 2), (128, 1)])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
+def test_batched_sr_training_equals_the_plane_by_plane_path(hip, hid, nb, mode):
+    """PlanesSR.forward_many (ops.PlanesSRBatchFn -> nvsr_planes_sr_train_batch_arith / _backward_batch_arith: ragged launches, one
+    weight-gradient pass per layer over all planes) against three PlanesSR.forward calls (models.py:884-926 per plane) on three DIFFERENT
+    regions of interest (one of them touching the plane's border: replicate padding), hidden 16 (the narrow limb kernels) and 128 (the
+    16x16x32 kernels): the planes are bit-identical (an output element's accumulation order does not depend on the tile it sits in; exact f32
+    runs plane by plane inside the batch call); gradients: relative L2 <= 1e-5 (the order of the weight-gradient sums; f16 limbs: one
+    power-of-two gradient scale for all planes instead of one per plane)."""
+    R = 24
+    rois = [[-0.9, -0.35, 0.1, 0.8], [-1.0, -1.0, 0.2, 0.3], [-0.2, -0.6, 0.95, 0.4]]
+    res = {}
+    for path in ("batched", "single"):
+        sr, lrs = _sr_setup(hip, hid, nb, R, seed=31)
+        sr.inner_model.arithmetic = mode
+        if path == "batched":
+            outs = sr.forward_many([("p%d" % k, rois[k]) for k in range(3)])
+            assert outs[0].grad_fn is outs[1].grad_fn or type(outs[0].grad_fn).__name__ == type(outs[1].grad_fn).__name__
+        else:
+            outs = [sr(("p%d" % k, torch.tensor(rois[k]).reshape(2, 2))) for k in range(3)]
+        gen = torch.Generator(device=DEV).manual_seed(77)
+        loss = 0.0
+        for o in outs:
+            w = torch.randn(o.shape, device=DEV, generator=gen)
+            loss = loss + (torch.nan_to_num(o) * w).sum()
+        loss.backward()
+        res[path] = ([o.detach().clone() for o in outs], _blob(sr).clone(), [t.grad.clone() for t in lrs])
+    for a, b in zip(res["batched"][0], res["single"][0]):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert float(res["single"][1].norm()) > 0
+    assert rel(res["batched"][1], res["single"][1]) <= 1e-5, rel(res["batched"][1], res["single"][1])
+    for a, b in zip(res["batched"][2], res["single"][2]):
+        assert float(b.norm()) > 0 and rel(a, b) <= 1e-5, rel(a, b)
+
+
+def test_batched_sr_training_with_detached_and_full_planes(hip):
+    """the batch call with full planes (rois None) and with LR planes that want no gradient (detach_LR_planes, models.py:272): only the planes
+    that require it receive one, the weight gradient is the sum over all planes"""
+    R = 20
+    sr, lrs = _sr_setup(hip, 16, 2, R, seed=5)
+    lrs[1].requires_grad_(False)
+    outs = sr.forward_many(["p0", "p1", "p2"])
+    assert all(o.shape == (1, 48, 4 * R, 4 * R) and bool(torch.isfinite(o).all()) for o in outs)
+    sum((o * o).sum() for o in outs).backward()
+    gw = _blob(sr).clone()
+    g0, g2 = lrs[0].grad.clone(), lrs[2].grad.clone()
+    assert lrs[1].grad is None
+    sr2, lrs2 = _sr_setup(hip, 16, 2, R, seed=5)
+    outs2 = [sr2("p%d" % k) for k in range(3)]
+    sum((o * o).sum() for o in outs2).backward()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+    assert rel(gw, _blob(sr2)) <= 1e-5 and rel(g0, lrs2[0].grad) <= 1e-5 and rel(g2, lrs2[2].grad) <= 1e-5
+
+
+def test_residual_gradient_gather_equals_the_scatter(hip, oracle):
+    """the bilinear residual's share of the LR plane's gradient (models.py:858-868 transposed), now a gather per LR texel
+    (sr_residual_backward_gather_kernel), against the oracle's planes_sr_backward on a network with ZERO weights (the residual is then the
+    whole function), ROI touching two borders, align_corners True and False"""
+    R = 18
+    for align in (True, False):
+        torch.manual_seed(3)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 1}}, "bilinear").to(DEV)
+        sr.align_corners = align
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.zero_()
+        sr.train()
+        lr = torch.nn.Parameter(torch.randn(1, 48, R, R, device=DEV))
+        sr.set_LR_plane(lr, id="p", save_interpolated=False)
+        roi = [-1.0, -0.3, 0.4, 1.0]
+        out = sr(("p", torch.tensor(roi).reshape(2, 2)))
+        w = torch.randn(out.shape, device=DEV)
+        (torch.nan_to_num(out) * w).sum().backward()
+        # reference: autograd through F.interpolate on the region's pixels
+        lr2 = lr.detach().clone().requires_grad_(True)
+        up = torch.nn.functional.interpolate(lr2, scale_factor=4, mode="bilinear", align_corners=align)
+        inside = ~torch.isnan(out.detach())
+        (torch.where(inside, up, torch.zeros_like(up)) * w).sum().backward()
+        err = float((lr.grad - lr2.grad).abs().max()) / float(lr2.grad.abs().max())
+        assert err <= 2e-6, (align, err)
+
+
+def test_refine_iteration_with_regions_drawn_ahead_equals_the_in_stream_iteration(hip):
+    """training.TrainStep._draw_rays: pixels, rays and regions of interest produced on a side stream ahead of the iteration (`_roi_hint`) against
+    the same iteration with everything on the iteration's stream -- same pixels (device sampler, same key), same regions, same loss and
+    gradients (to the ordering noise of float atomics)."""
+    from conftest import load_golden
+    from test_hip_parity import T, _grad_models, _gt_and_student, make_options
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    H = W = 20
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24)
+    res = {}
+    for ahead in (True, False):
+        _, noisy = _gt_and_student(hip, g, sid, seed=84)
+        mc, mf = _grad_models(hip, g, noisy, sid, what=("planes",))
+        torch.manual_seed(8)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.mul_(10.0)
+        mf.assign_SR_model(sr, SR_viewdir=False)
+        mf.assign_LR_planes()
+        img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+        step = hip.training.TrainStep(mc, mf, opts, {"SR", "LR_planes"}, SR_optimizer=torch.optim.SGD(sr.parameters(), lr=0.0), SR_model=sr, sr_loss="fine",
+                                      planes_optimizer=torch.optim.SGD(list(mc.planes_.values()), lr=0.0),
+                                      pixel_sampler=hip.training.DevicePixelSampler(seed=9))
+        step.prologue_ahead = ahead
+        torch.manual_seed(12)                        # (the iteration's random inputs come from the CPU generator)
+        m = step(0, img, pose, H, W, focal, 1, sid, scfg, 150, sr_iter=True)
+        assert ("_prologue_stream" in step.__dict__) == ahead and "_roi_hint" not in mf.__dict__        # (the hint was consumed)
+        res[ahead] = (m["loss"], _blob(sr).clone(), [p_.grad.clone() for p_ in mc.planes_.values()])
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * max(1.0, abs(res[False][0]))
+    assert float(res[False][1].norm()) > 0 and rel(res[True][1], res[False][1]) <= 1e-5
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel(a, b) <= 1e-5
