@@ -829,44 +829,40 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
         e.record()
         marks.setdefault(name, []).append(e)
 
-    class _MarkingSampler:
-        def __call__(self, *a, **k):
-            mark("start")
-            return sampler(*a, **k)
-
     rois = {}
-    real_forward = sr.forward
+    real_many = sr.forward_many
 
-    def timed_forward(arg):
+    def timed_many(requests):
         mark("sr_fwd_begin")
-        out = real_forward(arg)
+        outs = real_many(requests)
         mark("sr_fwd_end")
-        if isinstance(arg, tuple):
-            rois[arg[0]] = [float(v) for v in torch.as_tensor(arg[1]).reshape(-1).cpu()]
+        for (name, roi), out in zip(requests, outs):
+            rois[name] = [float(v) for v in roi]
             if out.requires_grad:
                 out.register_hook(lambda g_: (mark("sr_bwd_begin"), g_)[1])
-        return out
+        return outs
 
     split = None
-    probe = mk(lambda: mark("bwd_end"), _MarkingSampler())
-    sr.forward = timed_forward
+    probe = mk(lambda: mark("bwd_end"), sampler)
+    sr.forward_many = timed_many
     try:
         reps = []
         for _ in range(3):
             marks.clear()
+            mark("start")
             one(probe)
             mark("end")
             torch.cuda.synchronize()
             ms = lambda a, b: marks[a][0].elapsed_time(marks[b][-1])
-            reps.append({"sampler + ray generation + ROI bounds": ms("start", "sr_fwd_begin"),
-                         "PlanesSR forward (3 ROI crops, keeps activations)": sum(a.elapsed_time(b) for a, b in zip(marks["sr_fwd_begin"], marks["sr_fwd_end"])),
+            reps.append({"random inputs + pixels + rays + regions of interest (side stream) + weight packing": ms("start", "sr_fwd_begin"),
+                         "PlanesSR forward (3 ROI crops, keeps activations)": ms("sr_fwd_begin", "sr_fwd_end"),
                          "render forward + loss + render backward (coarse on LR planes, fine on the SR planes)": marks["sr_fwd_end"][-1].elapsed_time(marks["sr_bwd_begin"][0]),
                          "PlanesSR backward (3 ROI crops: data + weight gradients)": marks["sr_bwd_begin"][0].elapsed_time(marks["bwd_end"][0]),
                          "optimizers (Adam: EDSR 43.3 M parameters%s)" % (" + planes + decoders" if joint else ""): ms("bwd_end", "end"),
                          "whole iteration": ms("start", "end")})
         split = {k: float(np.median([r[k] for r in reps])) for k in reps[0]}
     finally:
-        sr.forward = real_forward
+        sr.forward_many = real_many
     pad = int(sr.inner_model.required_padding)
     crops, fwd_flop = {}, 0.0
     for name, roi in rois.items():

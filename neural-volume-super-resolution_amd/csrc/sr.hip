@@ -44,6 +44,8 @@ struct ConvParams {
     int pad;              // 0, or 2 for the data gradient of a valid conv ("full" correlation with the flipped kernel)
     int ncg;              // co-groups of the grid; blockIdx.z = batch * ncg + co-group
     long in_bs, out_bs, skip_bs;   // floats between consecutive planes of a batch (the 3 planes of a scene share the weights)
+    unsigned* out_absmax;          // NULL, or a word that receives (atomicMax) the bits of max |out| over everything this launch writes: the
+                                   // power-of-two scale of the NEXT f16-limb gradient launches that read `out` (no separate reduction pass)
 };
 
 __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the virtual border
@@ -52,7 +54,8 @@ __device__ float g_zero_word[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // source of the v
 // (one fully unrolled copy per epilogue kind: with the kind tested inside, the unroller gives up and the accumulators are
 //  indexed dynamically, i.e. go through scratch)
 template <int PB, int NCB = 2>
-__device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16 (&acc)[NCB][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
+__device__ __forceinline__ float conv_write_out(const ConvParams& p, const f32x16 (&acc)[NCB][PB], int x, int y0, int co0, int h, int Ho, int Wo) {
+    float amax = 0.0f;          // largest magnitude this lane writes (-> p.out_absmax, conv_publish_absmax)
     // Round 3: per (co-block, row) the 16 channel rows of a lane are handled as a GROUP -- all 16 skip values are loaded first (independent
     // loads, one wait), then 16 stores -- through restrict-qualified local pointers with 32-bit element offsets (a plane is < 2^31 floats;
     // the batch offset is already in the pointers).  Before, every element was its own load -> s_waitcnt vmcnt(0) -> store behind 64-bit
@@ -106,6 +109,7 @@ __device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16
                     if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;   // backward of (x0.1) o conv2 o ReLU: gate by the forward activation
                     if (EPI == EPI_ADD_CENTER) t += sk[r];             // backward of the cropped identity: the block's output gradient lands in the centre
                     v[r] = t;
+                    if (chan_ok(r)) amax = fmaxf(amax, fabsf(t));
                 }
                 if (EPI == EPI_PIXEL_SHUFFLE) {
                     // co -> (co >> 2, 2y + ((co >> 1) & 1), 2x + (co & 1)); cbase is a multiple of 4: r & 3 = co & 3
@@ -138,6 +142,14 @@ __device__ __forceinline__ void conv_write_out(const ConvParams& p, const f32x16
         case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
         default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
     }
+    return amax;
+}
+// p.out_absmax <- max over the wave of the lanes' largest written magnitude (one atomic per wave; fmaxf drops a NaN like absmax_kernel does)
+__device__ __forceinline__ void conv_publish_absmax(const ConvParams& p, float m) {
+    if (!p.out_absmax) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(p.out_absmax, __float_as_uint(m));
 }
 
 // Which tile a workgroup takes.  Workgroup b (linear over the grid) runs on XCD b % 8 (round-robin dispatch) and each XCD has its own
@@ -171,6 +183,17 @@ __device__ __forceinline__ void conv_tile_of_block(unsigned& bx, unsigned& by, u
 
 // The tensors and the logical size of plane `bi` of the launch -> p; false: this workgroup's tile (x0, y0) lies outside the plane (ragged batch:
 // the grid covers the largest plane) and the workgroup has nothing to do.  bi, x0, y0 are workgroup-uniform.
+// ragged launch: plane of linear tile `blk`, the tile's index inside the plane's share of the list (-> local), the plane's pixel-tile grid
+__device__ __forceinline__ unsigned conv_ragged_locate(const ConvRagged& rag, unsigned blk, int rows, unsigned& local, unsigned& gx, unsigned& npt) {
+    const unsigned bi = (blk >= rag.tile0[1] ? 1u : 0u) + (blk >= rag.tile0[2] ? 1u : 0u) + (blk >= rag.tile0[3] ? 1u : 0u);   // (tile0[k >= n] = ~0)
+#define CONV_RAG_PICK(A) (bi == 3u ? rag.A[3] : bi == 2u ? rag.A[2] : bi == 1u ? rag.A[1] : rag.A[0])
+    local = blk - CONV_RAG_PICK(tile0);
+    const int H = CONV_RAG_PICK(H), W = CONV_RAG_PICK(W);
+#undef CONV_RAG_PICK
+    gx = (unsigned)(W - 2 + 31) / 32u;
+    npt = gx * ((unsigned)(H - 2 + rows - 1) / (unsigned)rows);
+    return bi;
+}
 __device__ __forceinline__ bool conv_select_plane(ConvParams& p, const ConvRagged& rag, unsigned bi, int x0, int y0) {
     if (rag.n) {
         // (constant indices + selects: a dynamic index into the by-value parameter struct would put the whole struct into scratch)
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
         }
     }
 
-    conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, (cg * NCB + cw * 2) * 32, h, Ho, Wo);
+    conv_publish_absmax(p, conv_write_out<PB>(p, acc, x0 + j, y0 + rg * PB, (cg * NCB + cw * 2) * 32, h, Ho, Wo));
 }
 
 // ---- the same conv on the bf16 matrix pipe: f32 operands as 3 exact bf16 limbs (limb_core.h), 6 MFMAs per product block -------------
@@ -357,13 +380,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p, Conv
     // fragments through its 4 MB L2 (with the co-group fastest the four co-groups of a 256 -> 1024 layer keep 14 MB live and FETCH_SIZE of
     // those layers doubles: measured, 2.1 -> 4.1 GB); co-group FASTEST for the 1-block x 8-row wave tile, whose two co-groups share a patch and
     // together stream the same 3.5 MB
-    const unsigned blk = conv_tile_index();
-    const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
-    unsigned pt, bi;
+    unsigned blk = conv_tile_index();
+    const unsigned ncg = (unsigned)p.ncg;
+    unsigned npt = gridDim.x * gridDim.y, gx = gridDim.x, pt, bi, bi_r = 0;
+    if (rag.n) bi_r = conv_ragged_locate(rag, blk, ROWS, blk, gx, npt);      // (blk becomes the index inside the plane's tiles)
     int cg;
     if (CBW == 1) { cg = (int)(blk % ncg); const unsigned q = blk / ncg; pt = q % npt; bi = q / npt; }
     else { pt = blk % npt; const unsigned q = blk / npt; cg = (int)(q % ncg); bi = q / ncg; }
-    const unsigned bx = pt % gridDim.x, by = pt / gridDim.x;
+    if (rag.n) bi = bi_r;
+    const unsigned bx = pt % gx, by = pt / gx;
     const int x0 = bx * 32, y0 = by * ROWS;
     if (!conv_select_plane(p, rag, bi, x0, y0)) return;
     const int Ho = p.H - 2, Wo = p.W - 2;
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p, Conv
         if (chunk + 1 < nchunks && !(CV_ABLATE & 4)) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out<PB, CBW>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo);
+    conv_publish_absmax(p, conv_write_out<PB, CBW>(p, acc, x0 + j, y0 + rg * PB, cb0 * 32, h, Ho, Wo));
 }
 
 // ---- the same conv on v_mfma_f32_16x16x32_bf16 (round 3) -------------------------------------------------------------------------------------
@@ -499,8 +524,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p, Conv
 // F16 (the 2-f16-limb arithmetic): the accumulators carry 2^(F16_SW + F16_SX) and the ReLU lets a NaN through (an operand beyond the f16
 // range turns the accumulators into NaNs; fmaxf would return 0)
 template <int PB, bool F16 = false, int NCB = 2>
-__device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x4 (&acc)[NCB][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo,
-                                                 float unscale = 1.0f) {
+__device__ __forceinline__ float conv_write_out16(const ConvParams& p, const f32x4 (&acc)[NCB][PB][2], int x0, int y0, int co0, int lane, int Ho, int Wo,
+                                                  float unscale = 1.0f) {
+    float amax = 0.0f;
     float* __restrict__ const out = p.out;
     const float* __restrict__ const skip = p.skip;
     const int i = lane & 15, g = lane >> 4;
@@ -539,6 +565,7 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
                         if (EPI == EPI_MASK_SCALE) t = (sk[r] > 0.0f) ? t * 0.1f : 0.0f;
                         if (EPI == EPI_ADD_CENTER) t += sk[r];
                         v[r] = t;
+                        amax = fmaxf(amax, fabsf(t));
                     }
                     if (EPI == EPI_PIXEL_SHUFFLE) {        // co -> (co >> 2, 2y + ((co >> 1) & 1), 2x + (co & 1)); cbase is a multiple of 4
                         const int oplane = 4 * Ho * Wo, o0 = (cbase >> 2) * oplane + (2 * y) * (2 * Wo) + 2 * x;
@@ -559,6 +586,7 @@ __device__ __forceinline__ void conv_write_out16(const ConvParams& p, const f32x
         case EPI_ADD_CENTER: write_out(std::integral_constant<int, EPI_ADD_CENTER>{}); break;
         default: write_out(std::integral_constant<int, EPI_NONE>{}); break;
     }
+    return amax;
 }
 
 #ifndef CV16_BPF
@@ -601,16 +629,18 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
 #define CV16_ITEM(R, O, COL) ((O) * OSTR + (R) * PC + (COL))
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
-    const unsigned blk = conv_tile_index();
+    unsigned blk = conv_tile_index();
     // tile order: the two 128-channel co-groups of a 256-channel set FASTEST (they read the same patch: the second one's loads hit the XCD's L2;
     // their weights together are the 3.5 MB per layer that the 2-block kernel streamed), then the pixel tile, then the 256-channel set and the
     // plane slowest (the sets of a 256 -> 1024 layer would otherwise keep 14 MB of weights live per XCD).  Measured FETCH_SIZE of the SR stage:
     // 34.0 GB with all co-groups slowest
-    const unsigned ncg = (unsigned)p.ncg, npt = gridDim.x * gridDim.y;
+    const unsigned ncg = (unsigned)p.ncg;
+    unsigned npt = gridDim.x * gridDim.y, gx = gridDim.x, bi_r = 0;
+    if (rag.n) bi_r = conv_ragged_locate(rag, blk, PB, blk, gx, npt);        // (blk becomes the index inside the plane's tiles)
     const unsigned G = (WAVES == 8 || (ncg & 1u)) ? 1u : 2u, nset = ncg / G;
-    const unsigned cg_lo = blk % G, r1 = blk / G, pt = r1 % npt, q = r1 / npt, bx = pt % gridDim.x, by = pt / gridDim.x;
+    const unsigned cg_lo = blk % G, r1 = blk / G, pt = r1 % npt, q = r1 / npt, bx = pt % gx, by = pt / gx;
     const int cg = (int)((q % nset) * G + cg_lo);
-    const unsigned bi = q / nset;
+    const unsigned bi = rag.n ? bi_r : q / nset;
     const int x0 = bx * 32, y0 = by * PB;
     if (!conv_select_plane(p, rag, bi, x0, y0)) return;
     const int Ho = p.H - 2, Wo = p.W - 2;
@@ -759,7 +789,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
         if (chunk + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
     }
-    conv_write_out16<PB, LIMBS == 2, NCB>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo, 1.0f / (F16_W_SCALE * xscale));
+    conv_publish_absmax(p, conv_write_out16<PB, LIMBS == 2, NCB>(p, acc, x0, y0, cb0 * 16, lane, Ho, Wo, 1.0f / (F16_W_SCALE * xscale)));
 #undef CV16_ITEM
 }
 
@@ -1028,16 +1058,28 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                                   ? reinterpret_cast<const unsigned*>(wpk + conv_packed_f32_floats(Cin, Cout)) + conv_packed_limb_words(Cin, Cout) : nullptr;
     const unsigned* wf16 = wlimb16 ? wlimb16 + conv_packed_limb16_words(Cin, Cout) : nullptr;
     ConvParams p{in, wpk, wlimb, wlimb16, wf16, nullptr, out, skip, Cin, Cout, H, W, conv_ncb(Cout), conv_nchunks(Cin), epilogue, pad, 1, in_bs, out_bs, skip_bs};
+    p.out_absmax = cx.out_absmax;
     ConvRagged rg;          // (a second by-value kernel argument, read with constant indices: inside ConvParams -- which the kernels modify -- the
                             //  whole parameter struct went to scratch)
     if (rag) {
         rg = *rag;
         for (int b = 0; b < rag->n; ++b) { rg.H[b] += 2 * pad; rg.W[b] += 2 * pad; }
     }
+    // ragged launch: a one-dimensional grid over the planes' tiles, plane after plane (ConvRagged::tile0; no empty tiles)
+    auto ragged_grid = [&](int rows, int ncg) {
+        unsigned t = 0;
+        for (int b = 0; b <= CONV_RAGGED_MAX; ++b) {
+            rg.tile0[b] = b <= rg.n ? t : 0xffffffffu;
+            if (b < rg.n) t += (unsigned)((rg.W[b] - 2 + 31) / 32) * (unsigned)((rg.H[b] - 2 + rows - 1) / rows) * (unsigned)ncg;
+        }
+        for (int b = rg.n; b < CONV_RAGGED_MAX; ++b) rg.tile0[b] = 0xffffffffu;
+        return dim3(t, 1, 1);
+    };
     if (wlimb && arith != NVSR_ARITH_F32 && p.ncb_total == 2) {
         // narrow layer: 4 waves x 2 rows each of the same 64 output channels
         p.ncg = 1;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, batch);
+        if (rag) grid = ragged_grid(8, 1);
         hipLaunchKernelGGL((conv3x3_limb_kernel<2, 1>), grid, dim3(256), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
     }
@@ -1069,6 +1111,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
             if (((forced >= 2 && forced <= 4) || (forced == 6 && f16)) && cx.rows < 18) best_pb = forced;
         }
         grid.y = (Ho + best_pb - 1) / best_pb;
+        if (rag) grid = ragged_grid(best_pb, p.ncg);
         if (f16) {
             if (f16_dgrad) {
                 if (rag && !cx.in_absmax) return NVSR_ERR_NULL;
@@ -1091,6 +1134,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         // bf16-limb kernel, 1 output block x 8 rows per wave: 4-wave workgroups of 128 output channels x 8 rows x 32 pixels
         p.ncg = p.ncb_total / 4;
         dim3 grid((Wo + 31) / 32, (Ho + 7) / 8, p.ncg * batch);
+        if (rag) grid = ragged_grid(8, p.ncg);
         hipLaunchKernelGGL((conv3x3_limb_kernel<8, 4, 1>), grid, dim3(256), 0, stream, p, rg);
         return NVSR_CHECK_LAUNCH();
     }
@@ -1117,6 +1161,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
         }
         if (cx.rows) best_pb = cx.rows;
         grid.y = (Ho + best_pb - 1) / best_pb;
+        if (rag) grid = ragged_grid(best_pb, p.ncg);
         if (best_pb == 4) hipLaunchKernelGGL((conv3x3_limb_kernel<4>), grid, dim3(256), 0, stream, p, rg);
         else if (best_pb == 3) hipLaunchKernelGGL((conv3x3_limb_kernel<3>), grid, dim3(256), 0, stream, p, rg);
         else hipLaunchKernelGGL((conv3x3_limb_kernel<2>), grid, dim3(256), 0, stream, p, rg);

@@ -830,10 +830,19 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
     int gi = -1;                   // index of g in buf (-1: the caller's d_out)
     auto next_buf = [&](int a, int b) { for (int k = 0; k < 3; ++k) if (k != a && k != b) return k; return 0; };
     int e;
-    // f16 limbs: ONE reduction per gradient tensor serves its weight-gradient and its data-gradient launch
+    // f16 limbs: the power-of-two scale of a gradient tensor comes from the bits of its largest magnitude, one word per tensor.  The word of the
+    // caller's d_out is a reduction pass; every other gradient tensor is the output of a data-gradient launch, whose epilogue leaves the word
+    // behind (ConvExec::out_absmax: an atomicMax per wave) -- no pass over the tensor; the un-shuffled gradient is a permutation of one that has it
     const bool f16 = conv_resolve_arith(arith) == NVSR_ARITH_F16X2;
-    auto amax = [&](const float* gt, long n) -> const unsigned* { return f16 ? launch_absmax(gt, n, stream, amax_words + amax_next++) : nullptr; };
-    auto with = [&](const unsigned* am) { ConvExec c = cx; c.in_absmax = am; return c; };
+    if (f16 && hipMemsetAsync(amax_words, 0, sizeof(unsigned) * (P.n + 4), stream) != hipSuccess) return NVSR_ERR_LAUNCH;
+    auto new_word = [&]() -> unsigned* { return f16 ? amax_words + amax_next++ : nullptr; };
+    auto exec = [&](const unsigned* in_am, unsigned* out_am) { ConvExec c = cx; c.in_absmax = in_am; c.out_absmax = out_am; return c; };
+    const unsigned* g_am = nullptr;
+    if (f16) {
+        const int lz = P.n - 1;
+        g_am = launch_absmax(d_out, (long)P.L[lz].Cout * (P.ih[lz] - 2) * (P.iw[lz] - 2), stream, new_word());
+        if (!g_am) return NVSR_ERR_LAUNCH;
+    }
     for (int l = P.n - 1; l >= 0; --l) {
         const int ci = P.L[l].Cin, co = P.L[l].Cout, ih = P.ih[l], iw = P.iw[l];
         const bool need_dx = l > 0 || dx;
@@ -841,32 +850,32 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
             const long n = (long)co * (ih - 2) * (iw - 2);
             hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, co / 4, ih - 2, iw - 2, unsh);
             if ((e = NVSR_CHECK_LAUNCH())) return e;
-            const unsigned* am = amax(unsh, n);
-            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, am))) return e;
+            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
             const int o = next_buf(gi, -1);
-            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, with(am)))) return e;
-            g = buf[o]; gi = o;
+            unsigned* w = new_word();
+            if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, exec(g_am, w)))) return e;
+            g = buf[o]; gi = o; g_am = w;
         } else if (P.epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
             const float* t1 = input_of(l);             // relu(conv1(xb)), [hid][ih][iw]
             const float* xb = input_of(l - 1);         // [hid][ih+2][iw+2]
-            const unsigned* am = amax(g, (long)co * (ih - 2) * (iw - 2));
-            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith, am))) return e;
+            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
             const int o1 = next_buf(gi, -1);
-            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, with(am)))) return e;
+            unsigned* w1 = new_word();
+            if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, exec(g_am, w1)))) return e;
             const int l1 = l - 1;
-            const unsigned* am1 = amax(buf[o1], (long)P.L[l1].Cout * ih * iw);
-            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith, am1))) return e;
+            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith, w1))) return e;
             const int o2 = next_buf(gi, o1);
-            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, with(am1)))) return e;
-            g = buf[o2]; gi = o2;
+            unsigned* w2 = new_word();
+            if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, exec(w1, w2)))) return e;
+            g = buf[o2]; gi = o2; g_am = w2;
             --l;                                        // conv1 is done too
         } else {                                        // plain conv (conv_input, conv_mid, conv_output)
-            const unsigned* am = amax(g, (long)co * (ih - 2) * (iw - 2));
-            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, am))) return e;
+            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
             if (need_dx) {
                 float* o = (l == 0) ? dx : buf[next_buf(gi, -1)];
-                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2, 1, with(am)))) return e;
-                if (l) { gi = next_buf(gi, -1); g = buf[gi]; }
+                unsigned* w = l ? new_word() : nullptr;
+                if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, o, stream, 2, 1, exec(g_am, w)))) return e;
+                if (l) { gi = next_buf(gi, -1); g = buf[gi]; g_am = w; }
             }
         }
     }
@@ -963,21 +972,24 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
     for (int b = 0; b < B; ++b) g[b] = d_out[b];
     auto next_buf = [&](int a, int c) { for (int k = 0; k < 3; ++k) if (k != a && k != c) return k; return 0; };
     auto input_of = [&](int l, int b) { return l ? acts[b] + P[b].act_off[l] : x[b]; };
-    // one magnitude word per gradient tensor, over all planes
-    auto amax = [&](const float* const* t, int co, int l_out, bool unshuffled) -> const unsigned* {
-        if (!f16) return nullptr;
+    // one magnitude word per gradient tensor, over all planes: a reduction pass for the caller's d_out, the data-gradient launches' epilogues for
+    // every other tensor (see nvsr_edsr_backward_arith)
+    if (f16 && hipMemsetAsync(amax_words, 0, sizeof(unsigned) * (n + 4), stream) != hipSuccess) return NVSR_ERR_LAUNCH;
+    auto new_word = [&]() -> unsigned* { return f16 ? amax_words + amax_next++ : nullptr; };
+    const unsigned* g_am = nullptr;
+    if (f16) {
         long cnt[CONV_RAGGED_MAX];
-        for (int b = 0; b < B; ++b) cnt[b] = (long)co * (P[b].ih[l_out] - 2) * (P[b].iw[l_out] - 2);
-        (void)unshuffled;
-        return launch_absmax_ragged(B, t, cnt, stream, amax_words + amax_next++);
-    };
+        for (int b = 0; b < B; ++b) cnt[b] = (long)P[0].L[n - 1].Cout * (P[b].ih[n - 1] - 2) * (P[b].iw[n - 1] - 2);
+        g_am = launch_absmax_ragged(B, d_out, cnt, stream, new_word());
+        if (!g_am) return NVSR_ERR_LAUNCH;
+    }
     auto wgrad = [&](const float* const* dy, int l, float scale, const unsigned* am) {
         const float* xs[CONV_RAGGED_MAX]; int H[CONV_RAGGED_MAX], W[CONV_RAGGED_MAX];
         for (int b = 0; b < B; ++b) { xs[b] = input_of(l, b); H[b] = P[b].ih[l]; W[b] = P[b].iw[l]; }
         return launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am);
     };
     // data gradient of layer l: dy [Cout][ih-2][iw-2] -> [Cin][ih][iw] with the given backward epilogue
-    auto dgrad = [&](const float* const* dy, int l, int epi, const float* const* skip, float* const* out, const unsigned* am) {
+    auto dgrad = [&](const float* const* dy, int l, int epi, const float* const* skip, float* const* out, const unsigned* am, unsigned* out_am) {
         ConvRagged r;
         r.n = B;
         for (int b = 0; b < B; ++b) {
@@ -986,6 +998,7 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
         }
         ConvExec cx{arith, 0};
         cx.in_absmax = am;
+        cx.out_absmax = out_am;
         return launch_conv(nullptr, P[0].L[l].Cout, 0, 0, packed_dgrad + poff[l], P[0].L[l].Cin, epi, nullptr, nullptr, stream, 2, B, cx, &r);
     };
     int e;
@@ -1001,46 +1014,42 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
                 un[b] = buf(3, b);
             }
             if ((e = NVSR_CHECK_LAUNCH())) return e;
-            const unsigned* am = amax(un, co, l, true);
-            if (f16 && !am) return NVSR_ERR_LAUNCH;
-            if ((e = wgrad(un, l, 1.0f, am))) return e;
+            if ((e = wgrad(un, l, 1.0f, g_am))) return e;
             const int o = next_buf(gi, -1);
             float* outs[CONV_RAGGED_MAX];
             for (int b = 0; b < B; ++b) outs[b] = buf(o, b);
-            if ((e = dgrad(un, l, EPI_NONE, nullptr, outs, am))) return e;
+            unsigned* w = new_word();
+            if ((e = dgrad(un, l, EPI_NONE, nullptr, outs, g_am, w))) return e;
             for (int b = 0; b < B; ++b) g[b] = outs[b];
-            gi = o;
+            gi = o; g_am = w;
         } else if (P[0].epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
             const int l1 = l - 1;
             const float* t1[CONV_RAGGED_MAX];              // relu(conv1(xb))
             for (int b = 0; b < B; ++b) t1[b] = input_of(l, b);
-            const unsigned* am = amax(g, co, l, false);
-            if (f16 && !am) return NVSR_ERR_LAUNCH;
-            if ((e = wgrad(g, l, 0.1f, am))) return e;
+            if ((e = wgrad(g, l, 0.1f, g_am))) return e;
             const int o1 = next_buf(gi, -1);
             float* d1[CONV_RAGGED_MAX]; const float* d1c[CONV_RAGGED_MAX];
             for (int b = 0; b < B; ++b) d1c[b] = d1[b] = buf(o1, b);
-            if ((e = dgrad(g, l, EPI_MASK_SCALE, t1, d1, am))) return e;
-            const unsigned* am1 = amax(d1c, P[0].L[l1].Cout, l1, false);
-            if (f16 && !am1) return NVSR_ERR_LAUNCH;
-            if ((e = wgrad(d1c, l1, 1.0f, am1))) return e;
+            unsigned* w1 = new_word();
+            if ((e = dgrad(g, l, EPI_MASK_SCALE, t1, d1, g_am, w1))) return e;
+            if ((e = wgrad(d1c, l1, 1.0f, w1))) return e;
             const int o2 = next_buf(gi, o1);
             float* d2[CONV_RAGGED_MAX];
             for (int b = 0; b < B; ++b) d2[b] = buf(o2, b);
-            if ((e = dgrad(d1c, l1, EPI_ADD_CENTER, g, d2, am1))) return e;
+            unsigned* w2 = new_word();
+            if ((e = dgrad(d1c, l1, EPI_ADD_CENTER, g, d2, w1, w2))) return e;
             for (int b = 0; b < B; ++b) g[b] = d2[b];
-            gi = o2;
+            gi = o2; g_am = w2;
             --l;                                           // conv1 is done too
         } else {                                           // plain conv (conv_input, conv_mid, conv_output)
-            const unsigned* am = amax(g, co, l, false);
-            if (f16 && !am) return NVSR_ERR_LAUNCH;
-            if ((e = wgrad(g, l, 1.0f, am))) return e;
+            if ((e = wgrad(g, l, 1.0f, g_am))) return e;
             if (need_dx) {
                 const int o = next_buf(gi, -1);
                 float* outs[CONV_RAGGED_MAX];
                 for (int b = 0; b < B; ++b) outs[b] = (l == 0) ? dx[b] : buf(o, b);
-                if ((e = dgrad(g, l, EPI_NONE, nullptr, outs, am))) return e;
-                if (l) { for (int b = 0; b < B; ++b) g[b] = outs[b]; gi = o; }
+                unsigned* w = l ? new_word() : nullptr;
+                if ((e = dgrad(g, l, EPI_NONE, nullptr, outs, g_am, w))) return e;
+                if (l) { for (int b = 0; b < B; ++b) g[b] = outs[b]; gi = o; g_am = w; }
             }
         }
     }

@@ -168,15 +168,16 @@ inline void sr_roi(int R0, int R1, const float* roi, int* lo, int* hi) {
 // ConvExec: per-call execution options of the convolutions (include/nvsr.h, the *_arith entry points).  arith = NVSR_ARITH_* or
 // NVSR_ARITH_INHERIT (the process default of nvsr_set_conv_arithmetic); rows = 0 (cost model) or 2 / 3 / 4 rows per workgroup tile of the wide
 // kernels (the parity tests force every instantiation).
-struct ConvExec { int arith = -1; int rows = 0; const unsigned* in_absmax = nullptr; };      // in_absmax: launch_absmax of the input, if the caller has it already (f16 data gradients)
+struct ConvExec { int arith = -1; int rows = 0; const unsigned* in_absmax = nullptr; unsigned* out_absmax = nullptr; };      // out_absmax: ZEROED word that receives the bits of max |out| (the epilogues' atomicMax)
+//      // in_absmax: launch_absmax of the input, if the caller has it already (f16 data gradients)
 int conv_resolve_arith(int arith);      // INHERIT -> process default; sr.hip
 // bits of max |x| over a tensor, in a device word that stays valid for the launches queued behind it (sr.hip): the power-of-two scale of an
 // f16-limb gradient operand; NULL on a launch error
 const unsigned* launch_absmax(const float* x, long n, hipStream_t stream, unsigned* owned = nullptr);
 // A RAGGED batch: up to CONV_RAGGED_MAX planes of DIFFERENT sizes through one launch with the same weights -- the regions of interest of a
 // scene's position planes in an SR training iteration (models.py:270-284: every plane has its own crop).  One 256-channel layer of one crop is
-// 2-3 workgroup rounds with a last round a fifth full; the three crops together are 6-7 rounds.  The grid is sized for the largest plane;
-// workgroups whose tile lies outside their (smaller) plane leave at once.  H, W: logical input size per plane INCLUDING the virtual border.
+// 2-3 workgroup rounds with a last round a fifth full; the three crops together are 6-7 rounds.  The launch is a linear list of the planes'
+// tiles, plane after plane (ConvRagged::tile0).  H, W: logical input size per plane INCLUDING the virtual border.
 constexpr int CONV_RAGGED_MAX = 4;
 struct ConvRagged {
     int n = 0;                                   // 0: not ragged (ConvParams' own tensors and batch strides apply)
@@ -184,6 +185,9 @@ struct ConvRagged {
     const float* in[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
     float* out[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
     const float* skip[CONV_RAGGED_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    // (filled by launch_conv) first workgroup of every plane in the launch's linear tile list -- the list has no empty tiles: a grid sized for the
+    // largest plane would leave the smaller planes' unused tiles in a few XCDs' contiguous shares of the list (measured: two XCDs 28 % idle)
+    unsigned tile0[CONV_RAGGED_MAX + 1] = {0, 0, 0, 0, 0};
 };
 // rag != NULL: in / skip / out / H / W / batch are ignored (rag->H, rag->W = sizes of the tensors in memory, the virtual border is added here);
 // limb arithmetics only, and an f16 data gradient needs cx.in_absmax (one word for all planes: launch_absmax_ragged)
