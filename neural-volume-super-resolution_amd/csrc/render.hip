@@ -32,7 +32,7 @@ constexpr int PTS_PER_WG = NWAVES * 32;
 // =====================================================================================================================
 // TwoDimPlanesModel.forward on an explicit point list x[P,6] -> out[P,4]
 // =====================================================================================================================
-__global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, const float* __restrict__ packed, long P,
+__global__ __launch_bounds__(TPB, 1) void triplane_decode_kernel(SceneDev sc, const float* __restrict__ packed, long P,
                                                                  const float* __restrict__ x, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TPB, 2) void triplane_decode_kernel(SceneDev sc, co
 // pairs, so N*S/128 workgroup-steps are spread over the whole grid; nvsr_composite then consumes raw.
 // =====================================================================================================================
 template <bool MASKS, bool RECORD>
-__global__ __launch_bounds__(TPB, 2) void decode_rays_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+__global__ __launch_bounds__(TPB, 1) void decode_rays_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                              const float* __restrict__ rays, const float* __restrict__ z,
                                                              float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -93,7 +93,7 @@ constexpr int RAY_FLOATS = 16;
 constexpr int RENDER_LDS_FLOATS = LDS_FLOATS + PTS_PER_WG * RAY_FLOATS;
 static_assert(RENDER_LDS_FLOATS * 4 <= 80 * 1024, "two workgroups must fit one CU's 160 KB of LDS");
 
-__global__ __launch_bounds__(TPB, 2) void render_pass_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
+__global__ __launch_bounds__(TPB, 1) void render_pass_kernel(SceneDev sc, const float* __restrict__ packed, long N, int S,
                                                              const float* __restrict__ rays, const float* __restrict__ z,
                                                              const float* __restrict__ noise, int white,
                                                              float* __restrict__ rgb, float* __restrict__ disp,

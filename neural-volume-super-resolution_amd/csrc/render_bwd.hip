@@ -316,18 +316,23 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
 // gate words, the density branch's input gradient -- fits 256 registers: 8-wave workgroups, two waves per SIMD.
 // Used when the decoder is frozen (what: ['LR_planes'], Feature_Planes_Only.yml); decoder gradients need the record above.
 // =====================================================================================================================
-constexpr int MTPB = 512, MNW = MTPB / 64, MPTS = MNW * 32;
-constexpr int MBWD_LDS_FLOATS = LDS_FLOATS + MNW * TILE_FLOATS;
-static_assert(MBWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+// Waves per workgroup: 8 without the record (two waves per SIMD, 256 registers each); with the record the kernel also carries the record's row
+// addresses and spilled 23 registers at 256 (rounds 1-4) -- that instantiation runs 4 waves (one per SIMD, up to 512 registers, no scratch).
+template <bool RECORD> struct MBwd {
+    static constexpr int NW = RECORD ? 4 : 8, TPB = NW * 64, PTS = NW * 32;
+    static constexpr int LDS = LDS_FLOATS + NW * TILE_FLOATS;
+};
+static_assert(MBwd<false>::LDS * 4 <= 160 * 1024, "LDS budget");
 
 template <bool RECORD>
-__global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(SceneDev sc, const float* __restrict__ packed,
+__global__ __launch_bounds__(MBwd<RECORD>::TPB, 1) void render_pass_backward_gates_kernel(SceneDev sc, const float* __restrict__ packed,
                                                                             const float* __restrict__ packed_bwd, long N, int S,
                                                                             const float* __restrict__ rays, const float* __restrict__ z,
                                                                             const float* __restrict__ g_raw,
                                                                             const unsigned* __restrict__ gates, GradPlanes gp,
                                                                             float* __restrict__ gview, DecRecord rec) {
-    __shared__ __attribute__((aligned(16))) float lds[MBWD_LDS_FLOATS];
+    constexpr int MNW = MBwd<RECORD>::NW, MPTS = MBwd<RECORD>::PTS;
+    __shared__ __attribute__((aligned(16))) float lds[MBwd<RECORD>::LDS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<MNW>(rs);                    // head weights / biases of the FORWARD blob -> LDS
     rs.packed = packed_bwd;
@@ -353,15 +358,34 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
         const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw;
-        const u32x4* gk = reinterpret_cast<const u32x4*>(gates + ((ray * S + s) * 2 + h) * 16);
-        const u32x4 k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3];
-        const Masks md[4] = {{{k0[0], k0[1]}}, {{k0[2], k0[3]}}, {{k1[0], k1[1]}}, {{k1[2], k1[3]}}};
-        const Masks mr[4] = {{{k2[0], k2[1]}}, {{k2[2], k2[3]}}, {{k3[0], k3[1]}}, {{k3[2], k3[3]}}};
-        const Taps vt = view_taps(sc, r[8], r[9], r[10]);
-        const float n0 = norm_coord(__fadd_rn(r[0], __fmul_rn(r[3], zc)), sc.lo[0], sc.range[0]);
-        const float n1 = norm_coord(__fadd_rn(r[1], __fmul_rn(r[4], zc)), sc.lo[1], sc.range[1]);
-        const float n2 = norm_coord(__fadd_rn(r[2], __fmul_rn(r[5], zc)), sc.lo[2], sc.range[2]);
+        // (the row index goes through an opaque asm at every use: computed once, hipcc keeps the eight 64-bit row addresses of the record live
+        //  across all transposed layers -- 16 registers this kernel does not have)
+        auto rec_row = [&](float* base, const f32x16 (&a)[4]) {
+            int ql = (int)q;
+            asm volatile("" : "+v"(ql));
+            record128(base, (long)ql, h, a);
+        };
+        // the eight gate word pairs of the point (slot 0..3 density layers, 4..7 rgb layers).  Without the record they are loaded up front (16
+        // registers); WITH it the kernel also holds the record's row pointers and those 16 registers were what spilled (23 VGPRs, 96 B of
+        // scratch in rounds 1-4): a layer's pair is then re-read where the layer uses it (an L1 / L2 hit)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2* gk2 = reinterpret_cast<const u32x2*>(gates + ((ray * S + s) * 2 + h) * 16);
+        u32x2 gw[RECORD ? 1 : 8];
+        if constexpr (!RECORD) {
+            const u32x4* gk = reinterpret_cast<const u32x4*>(gk2);
+            const u32x4 k0 = gk[0], k1 = gk[1], k2 = gk[2], k3 = gk[3];
+            gw[0] = u32x2{k0[0], k0[1]}; gw[1] = u32x2{k0[2], k0[3]}; gw[2] = u32x2{k1[0], k1[1]}; gw[3] = u32x2{k1[2], k1[3]};
+            gw[4] = u32x2{k2[0], k2[1]}; gw[5] = u32x2{k2[2], k2[3]}; gw[6] = u32x2{k3[0], k3[1]}; gw[7] = u32x2{k3[2], k3[3]};
+        }
+        auto gate = [&](int slot) {
+            if constexpr (RECORD) { const u32x2 v = gk2[slot]; return Masks{{v[0], v[1]}}; }
+            else return Masks{{gw[slot][0], gw[slot][1]}};
+        };
+        // (taps are computed where a plane is scattered, from the ray re-read there: nothing of them stays live across the transposed layers)
         auto pos_taps = [&](int d) {
+            const float n0 = norm_coord(__fadd_rn(r[0], __fmul_rn(r[3], zc)), sc.lo[0], sc.range[0]);
+            const float n1 = norm_coord(__fadd_rn(r[1], __fmul_rn(r[4], zc)), sc.lo[1], sc.range[1]);
+            const float n2 = norm_coord(__fadd_rn(r[2], __fmul_rn(r[5], zc)), sc.lo[2], sc.range[2]);
             const float* M = sc.proj + 6 * d;
             return make_taps(sc, d, n0 * M[0] + n1 * M[2] + n2 * M[4], n0 * M[1] + n1 * M[3] + n2 * M[5]);
         };
@@ -376,14 +400,14 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = wv[j] * graw[3];
             }
-        apply_mask(md[3], accA);
-        if (rok) record128(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
-        hidden_T<MNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, md[2], accB, B_DEN_H);
-        if (rok) record128(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
-        hidden_T<MNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, md[1], accA, B_DEN_H + P_HID_FLOATS);
-        if (rok) record128(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
-        hidden_T<MNW>(rs, cur, B_DEN0, 0, accA, md[0], accB, B_DEN_H + 2 * P_HID_FLOATS);
-        if (rok) record128(rec.Gd, q, h, accB);
+        apply_mask(gate(3), accA);
+        if (rok) rec_row(rec.Gd + 3L * HID * rec.Pp, accA);
+        hidden_T<MNW>(rs, cur, B_DEN_H + P_HID_FLOATS, 0, accA, gate(2), accB, B_DEN_H);
+        if (rok) rec_row(rec.Gd + 2L * HID * rec.Pp, accB);
+        hidden_T<MNW>(rs, cur, B_DEN_H + 2 * P_HID_FLOATS, 0, accB, gate(1), accA, B_DEN_H + P_HID_FLOATS);
+        if (rok) rec_row(rec.Gd + 1L * HID * rec.Pp, accA);
+        hidden_T<MNW>(rs, cur, B_DEN0, 0, accA, gate(0), accB, B_DEN_H + 2 * P_HID_FLOATS);
+        if (rok) rec_row(rec.Gd, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -398,6 +422,11 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) gD[b][rr] = div3(gD[b][rr]);
         // ---- rgb branch
+        if constexpr (RECORD) {       // (dL/draw re-read instead of kept live across the density branch: see the gate words above)
+            asm volatile("" ::: "memory");
+            graw = *reinterpret_cast<const f32x4*>(g_raw + (ray * S + s) * 4);
+            if (!valid) graw = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
@@ -409,14 +438,14 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accA[ib][4 * q + j] = fmaf(w2[j], graw[2], fmaf(w1[j], graw[1], w0[j] * graw[0]));
             }
-        apply_mask(mr[3], accA);
-        if (rok) record128(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
-        hidden_T<MNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, mr[2], accB, B_RGB_H);
-        if (rok) record128(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
-        hidden_T<MNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, mr[1], accA, B_RGB_H + P_HID_FLOATS);
-        if (rok) record128(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
-        hidden_T<MNW>(rs, cur, B_RGB0, 0, accA, mr[0], accB, B_RGB_H + 2 * P_HID_FLOATS);
-        if (rok) record128(rec.Gr, q, h, accB);
+        apply_mask(gate(7), accA);
+        if (rok) rec_row(rec.Gr + 3L * HID * rec.Pp, accA);
+        hidden_T<MNW>(rs, cur, B_RGB_H + P_HID_FLOATS, 0, accA, gate(6), accB, B_RGB_H);
+        if (rok) rec_row(rec.Gr + 2L * HID * rec.Pp, accB);
+        hidden_T<MNW>(rs, cur, B_RGB_H + 2 * P_HID_FLOATS, 0, accB, gate(5), accA, B_RGB_H + P_HID_FLOATS);
+        if (rok) rec_row(rec.Gr + 1L * HID * rec.Pp, accA);
+        hidden_T<MNW>(rs, cur, B_RGB0, 0, accA, gate(4), accB, B_RGB_H + 2 * P_HID_FLOATS);
+        if (rok) rec_row(rec.Gr, accB);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             f32x16 gF[2];
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(MTPB, 2) void render_pass_backward_gates_kernel(Sce
                 if (d == 3 && gview) {
                     store_view_rows(gF, tile, gview, rb * MPTS + rs.wave * 32, N, S, s, lane);
                 } else {
-                    const Taps t = (d < 3) ? pos_taps(d) : vt;
+                    const Taps t = (d < 3) ? pos_taps(d) : view_taps(sc, r[8], r[9], r[10]);
                     scatter_plane(gF, tile, t, gp.p[d], lane, valid);
                 }
             }
@@ -658,13 +687,14 @@ int nvsr_render_pass_backward_gates_arith(const nvsr_scene* scene, const float* 
         if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, (S + 31) / 32, rays, view_ws, gp.p[3], (hipStream_t)stream);
         return NVSR_OK;
     }
-    const int64_t ntiles = ((N + MPTS - 1) / MPTS) * S;
+    const int pts = record ? MBwd<true>::PTS : MBwd<false>::PTS;
+    const int64_t ntiles = ((N + pts - 1) / pts) * S;
     const int64_t grid = ntiles < 1024 ? ntiles : 1024;
     if (record)
-        hipLaunchKernelGGL(render_pass_backward_gates_kernel<true>, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
+        hipLaunchKernelGGL(render_pass_backward_gates_kernel<true>, dim3((unsigned)grid), dim3(MBwd<true>::TPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, make_record(record, (long)N, S));
     else
-        hipLaunchKernelGGL(render_pass_backward_gates_kernel<false>, dim3((unsigned)grid), dim3(MTPB), 0, (hipStream_t)stream, to_dev(scene),
+        hipLaunchKernelGGL(render_pass_backward_gates_kernel<false>, dim3((unsigned)grid), dim3(MBwd<false>::TPB), 0, (hipStream_t)stream, to_dev(scene),
                            packed_decoder, packed_bwd, (long)N, S, rays, z, g_raw, gates, gp, view_ws, DecRecord{});
     if (int e = NVSR_CHECK_LAUNCH()) return e;
     if (view_ws && gp.p[3]) return launch_view_reduce(scene, N, S, rays, view_ws, gp.p[3], (hipStream_t)stream);

@@ -418,8 +418,9 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
 def test_no_spills_on_benchmarked_kernels(pkg):
     """The spill gate (VERDICT r2 #1a, widened in round 4 to EVERY kernel of the library): a kernel must fit its register budget -- a spilled
     accumulator turns into scratch traffic inside the MFMA stream (round 2 shipped render_pass_backward_gates_limb_kernel<false> with 165
-    spilled VGPRs).  Exempt by name: the exact-f32 kernels that only an explicit NVSR_ARITH_F32 reaches, and the recorded debt of
-    decoder_wgrad_limb_kernel<4> (tools/kernel_resources.py).  Reads the metadata of the gfx950 code objects in the in-tree library
+    spilled VGPRs).  Round 5: the exact-f32 kernels of render.hip / render_bwd.hip -- exempt by name in rounds 1-4 with 23 to 88 spilled VGPRs
+    -- spill nothing any more and the exemption list is gone; what is left is the recorded debt of decoder_wgrad_limb_kernel<4> (1 VGPR,
+    tools/kernel_resources.py).  Reads the metadata of the gfx950 code objects in the in-tree library
     (temp dir, nothing is executed)."""
     import importlib.util
     import shutil
@@ -434,7 +435,10 @@ def test_no_spills_on_benchmarked_kernels(pkg):
     for must in ("render_pass3_kernel", "render_pass_backward_gates_limb_kernel", "decode_rays_limb_kernel", "conv3x3_limb_kernel", "conv3x3_limb16_kernel"):
         assert must in names, "kernel table is missing %s" % must
     bad = kr.violations(table)
-    assert len(table) >= 60 and sum(any(s_ in k["mangled"] for s_ in kr.F32_OPT_IN) for k in table) <= 10       # the exemption list stays a list of names
+    assert len(table) >= 60 and not hasattr(kr, "F32_OPT_IN") and list(kr.ALLOW) == ["decoder_wgrad_limb_kernelILi4"]
+    for k in table:          # the exact-f32 generations in particular
+        if any(s_ in k["mangled"] for s_ in ("render_pass_kernel", "decode_rays_kernelILb", "triplane_decode_kernel", "render_pass_backward_gates_kernelILb")):
+            assert k["scratch"] == 0, (k["name"][:80], k["scratch"])
     assert not bad, "spilling kernels: " + "; ".join(
         "%s: %d VGPRs, %d B scratch" % (k["name"][:90], k["vgpr_spill"], k["scratch"]) for k in bad)
 
