@@ -25,6 +25,11 @@ Other workloads of the same path (--workload; same JSON contract, their own metr
           --partition bands the stated SR partition of SURVEY 8e: every plane cut into N horizontal bands (68-pixel LR halo), one
           all_gather per plane ("scaling": "strong").
   train --rays-global 4096: the stated training partition of SURVEY 8e (4096 rays -> 4096 / N per GPU, same pixels on all ranks), "strong".
+  refine  BASELINE configs[4]'s iteration (config/RefineOnTestScene.yml, TrainModels.yml): 4096 random rays of an 800x800 view, 64+64 samples, LR
+          planes 200^2, the fine model samples the three position planes super-resolved by PlanesSR(EDSR 256 x 32) in TRAINING mode on the regions
+          of interest of the batch (forward that keeps its activations, data + weight gradients, Adam), the coarse model samples the LR planes;
+          --refine-what joint (what = ['LR_planes', 'decoder', 'SR'], the YAMLs' value; default) | sr (what = ['SR']).  The line carries the
+          split of an iteration (regions of interest / SR forward / render / SR backward / optimizers) and the crops' algorithmic FLOP.
 """
 import argparse
 import json
@@ -821,6 +826,8 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
                                         % (N, " + planes 23 MB + decoders 1 MB" if joint else "")}}
     if rank != 0:
         return None
+    if getattr(args, "no_split", False):          # counter passes: the timed iteration only
+        return result
     # ---- the split of one iteration: events on the launch stream at the phase boundaries of one more (eager) iteration
     marks = {}
 
@@ -956,6 +963,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="train workload: launch the iteration kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
+    ap.add_argument("--no-split", action="store_true", help="--workload refine: skip the three probe iterations of the phase split (counter passes)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="--workload render, N = 1: do not append the short train / sr runs (`other_workloads` of the line)")
     args = ap.parse_args()

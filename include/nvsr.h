@@ -557,6 +557,10 @@ int nvsr_planes_sr_backward_arith(int C, int R0, int R1, const float* keep, cons
  *                             one-plane entry points read the process-wide nvsr_set_sr_* setting)
  *   d_lr                      NULL, or per plane NULL (LR plane detached: models.py:272) or [C][R0][R1], += the plane's gradient
  * Values: those of B one-plane calls up to the order of the weight-gradient sums and (f16 limbs) the shared power-of-two gradient scale. */
+/* nvsr_planes_sr_batch_arith (evaluation: B equally sized planes, ONE region of interest or none) with the residual's settings as arguments */
+int nvsr_planes_sr_batch_ex(const float* const* lr, int B, int C, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
+                            int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
+                            int arithmetic, int align_corners, int plane_interp, nvsr_stream_t stream);
 int64_t nvsr_planes_sr_batch_keep_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);
 int64_t nvsr_planes_sr_batch_workspace_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);
 int64_t nvsr_planes_sr_batch_backward_workspace_floats(int B, int C, int R0, int R1, int hid, int nblocks, int n_up, int pad, const float* rois);

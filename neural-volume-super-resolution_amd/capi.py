@@ -173,6 +173,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_planes_sr_train_arith": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "nvsr_planes_sr_backward_arith": ([_i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     # SR training on B regions of interest at once (csrc/sr.hip, csrc/sr_bwd.hip)
+    "nvsr_planes_sr_batch_ex": ([C.POINTER(C.c_void_p), _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _fp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _i, _i, _i, _vp], _i),
     "nvsr_planes_sr_batch_keep_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr_batch_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),
     "nvsr_planes_sr_batch_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i, _i, _fp], _i64),

@@ -87,6 +87,22 @@ __device__ __forceinline__ float f16_rest(float x, unsigned pair) {
     else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
     return r;
 }
+// EXPERIMENT (round 5, -DF16_MIX_SPLIT=1; not the product): the LOW limb of a pair written straight into its half of the packed word --
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 compute fma(f16 half of `pair`, -1.0, x) = x - hi in f32 (exact, see above) and round it to f16 into the
+// low / high half of the destination: 1 + 1 instructions per pair where f16_rest + f16_pair take 1 + 1 + 1, i.e. 1.5 instead of 2 split
+// instructions per element (of ~5 element instructions per layer), same bits.  Measured same-box, three alternations each
+// (profiles/r05_f16_mix_split_ab.txt): fine render pass 77.56-77.71 ms with it, 77.29-77.50 ms without; planes-only training step 1.80 / 1.80-1.83 ms;
+// SR stage 48.90-49.13 / 48.78-48.93 ms -- a tenth fewer element instructions move nothing: these kernels are not bound by vector issue
+// (the matrix pipe runs at 2.0 GHz of 2.4 under load: a power-managed clock).  Left off.
+#ifndef F16_MIX_SPLIT
+#define F16_MIX_SPLIT 0
+#endif
+__device__ __forceinline__ void f16_low_limb_lo(unsigned& lo, float x0, unsigned pair) {
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(pair), "v"(x0));
+}
+__device__ __forceinline__ void f16_low_limb_hi(unsigned& lo, float x1, unsigned pair) {
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(pair), "v"(x1));
+}
 template <int LIMBS>
 __device__ __forceinline__ f32x16 mfma_limb(u32x4 a, u32x4 b, f32x16 c) {
     if constexpr (LIMBS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -114,9 +130,14 @@ __device__ __forceinline__ void split_slice(int slice, Get get, Limbs<LIMBS>& ou
         if (st == 4) { p.r1 = limb_rest(p.r1); }
         if (st == 5) { out.v[2][j] = trunc_pair(p.r1, p.r0); }
     } else {
+#if F16_MIX_SPLIT
+        if (st == 0) { out.v[0][j] = f16_pair(get(2 * j + 1), get(2 * j)); unsigned w; f16_low_limb_lo(w, get(2 * j), out.v[0][j]); out.v[1][j] = w; }
+        if (st == 1) { unsigned w = out.v[1][j]; f16_low_limb_hi(w, get(2 * j + 1), out.v[0][j]); out.v[1][j] = w; }
+#else
         if (st == 0) { out.v[0][j] = f16_pair(get(2 * j + 1), get(2 * j)); p.r0 = f16_rest<0>(get(2 * j), out.v[0][j]); }
         if (st == 1) { p.r1 = f16_rest<1>(get(2 * j + 1), out.v[0][j]); }
         if (st == 2) { out.v[1][j] = f16_pair(p.r1, p.r0); }
+#endif
     }
 }
 template <int LIMBS, class Get>

@@ -1427,7 +1427,16 @@ int nvsr_planes_sr_batch(const float* const* lr, int B, int Cc, int R0, int R1, 
 int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
                                int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
                                int arithmetic, nvsr_stream_t stream_) {
+    return nvsr_planes_sr_batch_ex(lr, B, Cc, R0, R1, packed, hid, nblocks, n_up, pad, over, roi, mean, stdv, out, workspace, arithmetic,
+                                   sr_align_corners(), sr_bicubic() ? NVSR_PLANE_INTERP_BICUBIC : NVSR_PLANE_INTERP_BILINEAR, stream_);
+}
+/* the same with align_corners / plane_interp of the residual up-sampling as ARGUMENTS (re-entrant: two PlanesSR models with different settings
+ * in one process, backward passes on other threads and streams -- ADVICE r4) */
+int nvsr_planes_sr_batch_ex(const float* const* lr, int B, int Cc, int R0, int R1, const float* packed, int hid, int nblocks, int n_up, int pad,
+                            int over, const float* roi, const float* mean, const float* stdv, float* const* out, float* workspace,
+                            int arithmetic, int align_corners, int plane_interp, nvsr_stream_t stream_) {
     if (!lr || !packed || !out || !workspace) return NVSR_ERR_NULL;
+    if (plane_interp != NVSR_PLANE_INTERP_BILINEAR && plane_interp != NVSR_PLANE_INTERP_BICUBIC) return NVSR_ERR_SHAPE;
     if ((mean == nullptr) != (stdv == nullptr)) return NVSR_ERR_NULL;
     if (B < 1 || B > 64) return NVSR_ERR_SHAPE;
     for (int b = 0; b < B; ++b)
@@ -1455,7 +1464,7 @@ int nvsr_planes_sr_batch_arith(const float* const* lr, int B, int Cc, int R0, in
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(sr_finish_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, diff + b * n_diff, Ho, Wo, over, lr[b],
                            Cc, R0, R1, sf, lo[0], lo[1], hi[0], hi[1], out[b], conv_resolve_arith(arithmetic) == NVSR_ARITH_F16X2 ? nvsr_get_range_flag() : nullptr,
-                           sr_align_corners(), sr_bicubic());
+                           align_corners ? 1 : 0, plane_interp == NVSR_PLANE_INTERP_BICUBIC ? 1 : 0);
         if (int e = NVSR_CHECK_LAUNCH()) return e;
     }
     return NVSR_OK;

@@ -159,7 +159,14 @@ __device__ __forceinline__ void split4_f16(const float (&e)[4], float scale, u32
         const float v0 = e[2 * j] * scale, v1 = e[2 * j + 1] * scale;
         const unsigned hi = f16_pair(v1, v0);
         out[0][j] = hi;
+#if F16_MIX_SPLIT
+        unsigned lo;
+        f16_low_limb_lo(lo, v0, hi);
+        f16_low_limb_hi(lo, v1, hi);
+        out[1][j] = lo;
+#else
         out[1][j] = f16_pair(f16_rest<1>(v1, hi), f16_rest<0>(v0, hi));
+#endif
     }
 }
 constexpr int WL_ROW = 20;                                // words per row of 40 bf16 pixels

@@ -715,12 +715,6 @@ def _edsr_train_bwd(ctx, d_out, d_acts):
 edsr_train.register_autograd(_edsr_train_bwd, setup_context=_edsr_train_setup)
 
 
-def _sr_residual(align_corners, bicubic):
-    """PlanesSR's residual up-sampling for the nvsr_planes_sr* call that follows (library state, like the conv arithmetic)"""
-    capi.lib().nvsr_set_sr_align_corners(int(bool(align_corners)))
-    capi.lib().nvsr_set_sr_plane_interp(int(bool(bicubic)))
-
-
 def _roi_c(roi):
     return None if roi is None else (C.c_float * 4)(*[float(v) for v in roi])
 
@@ -743,15 +737,11 @@ def planes_sr(lr: Sequence[Tensor], packed: Tensor, geometry: Sequence[int], pad
     sf = 1 << n_up
     outs = [_f(1, Cc, R0 * sf, R1 * sf, like=lr[0]) for _ in lr]
     ws = _f(B * nws, like=lr[0])
-    _sr_residual(align_corners, bicubic)
-    if B == 1:
-        capi.call("nvsr_planes_sr_arith", capi.ptr(lr[0]), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
-                  capi.ptr(std), capi.ptr(outs[0]), capi.ptr(ws), arithmetic, capi.stream())
-    else:
-        lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lr])
-        out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
-        capi.call("nvsr_planes_sr_batch_arith", lr_ptrs, B, Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
-                  capi.ptr(std), out_ptrs, capi.ptr(ws), arithmetic, capi.stream())
+    # (align_corners / interpolation of the residual are arguments of the call: no process-wide state between this thread and a backward thread)
+    lr_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in lr])
+    out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in outs])
+    capi.call("nvsr_planes_sr_batch_ex", lr_ptrs, B, Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
+              capi.ptr(std), out_ptrs, capi.ptr(ws), arithmetic, int(bool(align_corners)), int(bool(bicubic)), capi.stream())
     return outs
 
 
@@ -778,9 +768,10 @@ def planes_sr_train(lr: Tensor, natural: Tensor, packed: Tensor, packed_dgrad: T
         raise capi.NvsrError("PlanesSR: region of interest too small for the network")
     sf = 1 << n_up
     out, ws, keep = _f(1, Cc, R0 * sf, R1 * sf, like=lr), _f(nws, like=lr), _f(nkeep, like=lr)
-    _sr_residual(align_corners, bicubic)
-    capi.call("nvsr_planes_sr_train_arith", capi.ptr(lr), Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
-              capi.ptr(std), capi.ptr(out), capi.ptr(ws), capi.ptr(keep), arithmetic, capi.stream())
+    # (the B = 1 case of the batch entry point: same kernels plane by plane, the residual's settings are arguments of the call)
+    lr_ptrs, out_ptrs = (C.c_void_p * 1)(lr.data_ptr()), (C.c_void_p * 1)(out.data_ptr())
+    capi.call("nvsr_planes_sr_train_batch_arith", lr_ptrs, 1, Cc, R0, R1, capi.ptr(packed), hid, nb, n_up, pad, over, roi_c, capi.ptr(mean),
+              capi.ptr(std), out_ptrs, capi.ptr(ws), capi.ptr(keep), arithmetic, int(bool(align_corners)), int(bool(bicubic)), capi.stream())
     return out, keep
 
 
@@ -805,10 +796,12 @@ def planes_sr_backward(keep: Tensor, packed_dgrad: Tensor, plane_shape: Sequence
     lib = capi.lib()
     gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
     d_lr = torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if need_lr else _f(0, like=keep)
-    ws = _f(lib.nvsr_planes_sr_backward_workspace_floats(Cc, R0, R1, hid, nb, n_up, pad, roi_c), like=keep)
-    _sr_residual(align_corners, bicubic)
-    capi.call("nvsr_planes_sr_backward_arith", Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, roi_c, capi.ptr(std),
-              capi.ptr(d_out), capi.ptr(gnat), capi.ptr(d_lr) if need_lr else None, capi.ptr(ws), arithmetic, capi.stream())
+    ws = _f(lib.nvsr_planes_sr_batch_backward_workspace_floats(1, Cc, R0, R1, hid, nb, n_up, pad, roi_c), like=keep)
+    d_out_ptrs = (C.c_void_p * 1)(d_out.data_ptr())
+    d_lr_ptrs = (C.c_void_p * 1)(d_lr.data_ptr() if need_lr else None)
+    capi.call("nvsr_planes_sr_backward_batch_arith", 1, Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, roi_c, capi.ptr(std),
+              d_out_ptrs, capi.ptr(gnat), d_lr_ptrs if need_lr else None, capi.ptr(ws), arithmetic, int(bool(align_corners)), int(bool(bicubic)),
+              capi.stream())
     return gnat, d_lr
 
 

@@ -258,3 +258,60 @@ def test_refine_iteration_with_regions_drawn_ahead_equals_the_in_stream_iteratio
     assert float(res[False][1].norm()) > 0 and rel(res[True][1], res[False][1]) <= 1e-5
     for a, b in zip(res[True][2], res[False][2]):
         assert rel(a, b) <= 1e-5
+
+
+def test_default_sr_training_on_a_coupled_scene(hip):
+    """the reference's real SR setup couples an HR scene to the LR scene whose planes it samples (SceneCoupler, models.py:936-1011:
+    every plane name goes through scene_with_saved_plane, :273).  With only the fine model super-resolving (apply_2_coarse False) the COARSE
+    model samples the saved LR planes raw -- training_planes must map its plane names through the coupler too (it raised KeyError).  The
+    coupled iteration equals the iteration of an un-coupled twin that holds the same planes under the HR scene's own names."""
+    from conftest import load_golden
+    from test_hip_parity import T, _grad_models, _gt_and_student, make_options
+
+    class Coupler:                       # what models.SceneCoupler answers for one HR scene coupled to one LR scene
+        def __init__(self, hr, lr):
+            self.scene2saved, self.hr = {hr: lr, lr: lr}, hr
+        def scene_with_saved_plane(self, name, plane_not_scene=False):
+            return name.replace(self.hr, self.scene2saved[self.hr]) if plane_not_scene else self.scene2saved[name]
+        def should_SR(self, name, plane_not_scene=False):
+            return self.hr in name
+        def should_downsample(self, plane_name, for_LR_loading=False):
+            return False
+
+    g = load_golden("g11_grads.npz")
+    lr_id, hr_id = "lego_DS8_PlRes20_8", "lego_DS2_PlRes80_8"
+    H = W = 20
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24)
+    res = {}
+    for coupled in (True, False):
+        _, noisy = _gt_and_student(hip, g, lr_id, seed=85)
+        saved_id = lr_id if coupled else hr_id
+        mc, mf = _grad_models(hip, g, noisy, saved_id, what=("planes",))
+        if coupled:
+            for m in (mc, mf):
+                m.scene_coupler = Coupler(hr_id, lr_id)
+                m.box_coords = {hr_id: m.box_coords[lr_id]}
+                m.__dict__.pop("_scene_consts", None)
+        torch.manual_seed(8)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.mul_(10.0)
+        sr.train()
+        mf.assign_SR_model(sr, SR_viewdir=False)
+        mf.assign_LR_planes()
+        ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+        sel = torch.arange(0, H * W, 3, device=DEV)
+        batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        out = hip.train_utils.run_one_iter_of_nerf(H, W, focal, mc, mf, batch, opts, hr_id, mode="train", scene_config=scfg, randoms={})
+        (out[0].sum() + out[3].sum()).backward()
+        planes = [mc.planes_[hip.models.get_plane_name(saved_id, d)] for d in range(4)]
+        assert all(p_.grad is not None and float(p_.grad.abs().sum()) > 0 for p_ in planes)
+        res[coupled] = (out[0].detach().clone(), out[3].detach().clone(), _blob(sr).clone(), [p_.grad.clone() for p_ in planes])
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert rel(res[True][2], res[False][2]) <= 1e-5
+    for a, b in zip(res[True][3], res[False][3]):
+        assert rel(a, b) <= 1e-5

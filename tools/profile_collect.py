@@ -5,7 +5,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 out = {}
-for w in ("render", "train", "train_dec", "sr"):
+for w in ("render", "train", "train_dec", "sr", "refine_joint", "refine_sr"):
     f = os.path.join(src, "bench_%s.json" % w)
     if os.path.exists(f):
         line = [l for l in open(f).read().splitlines() if l.startswith("{")]
@@ -99,6 +99,45 @@ for w, prefix, pick, what in (("train", "pmc_train_", longest(lambda k: "backwar
                      "kernel_ms_under_pmc": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]], "traffic_bytes": traffic,
                      "arithmetic": out.get(w, {}).get("dtype", "")}
         print("%s: traffic %.2f GB (%s)" % (w, traffic / 1e9, what))
+# refine: every convolution launch (forward, data gradient, weight gradient + its reduction) of the ONE timed iteration of the counter pass (the
+# warm-up iteration's launches come first in the trace: the second half of the matching dispatches), and the split of the SR backward from the
+# kernel-stat run: weight-gradient kernels by name; the data gradients share their kernels with the forward, so they are the backward's rest
+def second_half(match):
+    def pick(rows):
+        rows = sorted([r for r in rows if match(r["Kernel_Name"])], key=lambda r: int(r["Start_Timestamp"]))
+        rows = rows[len(rows) // 2:]
+        return (sum(float(r["Counter_Value"]) for r in rows), sum(dur_ms(r) for r in rows)) if rows else None
+    return pick
+
+
+is_sr_conv = lambda k: "conv3x3" in k or "wgrad_reduce" in k
+for w in ("refine_joint", "refine_sr"):
+    pm = counters("pmc_%s_" % w, second_half(is_sr_conv))
+    if pm:
+        traffic = (2.0 * pm["FETCH_SIZE"][0] + pm["WRITE_SIZE"][0]) * 1024.0
+        latest[w] = {"what": "all conv3x3 / weight-gradient launches of one iteration (3 ROI crops: forward + data gradients + weight gradients)",
+                     "fetch_size_kb": pm["FETCH_SIZE"][0], "write_size_kb": pm["WRITE_SIZE"][0],
+                     "kernel_ms_under_pmc": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]], "traffic_bytes": traffic,
+                     "arithmetic": out.get(w, {}).get("dtype", "")}
+        print("%s: traffic %.2f GB" % (w, traffic / 1e9))
+    st = glob.glob(os.path.join(src, "stats_%s" % w, "*", "*kernel_stats.csv"))
+    line = os.path.join(src, "stats_%s.json" % w)
+    if st and os.path.exists(line) and w in latest:
+        try:
+            b = json.loads([l for l in open(line).read().splitlines() if l.startswith("{")][-1])
+            iters = b["steps"] + b["warmup"] + 3                       # timed + warm-up + the three probe iterations of the split
+            rows = list(csv.DictReader(open(st[0])))
+            tot = lambda pred: sum(int(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / 1e6 / iters
+            wg = tot(lambda k: "wgrad" in k)
+            conv = tot(lambda k: "conv3x3" in k and "wgrad" not in k)
+            bw = b["split_ms"]["PlanesSR backward (3 ROI crops: data + weight gradients)"]
+            fw = b["split_ms"]["PlanesSR forward (3 ROI crops, keeps activations)"]
+            latest[w]["sr_backward_split_ms"] = {"weight gradients (conv3x3_wgrad_limb_kernel + wgrad_reduce_pieces_kernel)": wg,
+                                                 "data gradients + the rest of the backward (same kernels as the forward: the backward's time minus the weight gradients)": bw - wg,
+                                                 "all conv3x3 forward + data-gradient launches": conv, "forward (events)": fw, "backward (events)": bw,
+                                                 "source": "rocprofv3 --kernel-trace --stats of bench.py --workload refine (per-iteration means over %d iterations)" % iters}
+        except Exception as e:      # a condensed profile must not fail on a missing field
+            print("refine split:", e)
 if "traffic_bytes" in latest:
     json.dump(latest, open(os.path.join(dst, "%s_pmc.json" % tag), "w"), indent=1)
     json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
