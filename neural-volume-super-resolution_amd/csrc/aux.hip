@@ -695,7 +695,8 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 
 extern "C" {
 
-int nvsr_version(void) { return 410; }   // 4xx: round 4 (range flag, device-keyed pixel sampler, tile-pair training forward, gate bit layout, per-point backward scales;
+int nvsr_version(void) { return 500; }   // 5xx: round 5 (nvsr_planes_sr_*_batch_arith / nvsr_planes_sr_batch_ex: SR training on the regions of interest of B planes at once);
+                                         // 4xx: round 4 (range flag, device-keyed pixel sampler, tile-pair training forward, gate bit layout, per-point backward scales;
                                          // 410: nvsr_scene_ext / *_ext generic entry points, nvsr_set_sr_align_corners, nvsr_render_rays_shared_arith)
 int64_t nvsr_fused_min_rays(void) { return NVSR_FUSED_MIN_RAYS; }
 

@@ -315,3 +315,57 @@ def test_default_sr_training_on_a_coupled_scene(hip):
     assert rel(res[True][2], res[False][2]) <= 1e-5
     for a, b in zip(res[True][3], res[False][3]):
         assert rel(a, b) <= 1e-5
+
+
+@pytest.mark.parametrize("variant", ["align_corners_false", "bicubic", "normalized", "rf_bound"])
+def test_batched_sr_training_with_the_options_of_planes_sr(hip, variant):
+    """the batched path under the options PlanesSR.forward is pinned for by g20 / g22 (models.py:858-859 align_corners / plane_interp of the
+    residual, :899-901 input normalisation, :793-798 receptive_field_bound): forward_many on three regions equals three forward calls"""
+    R, hid, nb = 22, 16, 2
+    rois = [[-0.8, -0.5, 0.3, 0.9], [-1.0, -0.2, 0.1, 1.0], [-0.3, -1.0, 1.0, 0.2]]
+    res = {}
+    for path in ("batched", "single"):
+        torch.manual_seed(41)
+        model_cfg = {"hidden_size": hid, "n_blocks": nb}
+        if variant == "rf_bound":
+            model_cfg["receptive_field_bound"] = 7
+        cfg = {"model": model_cfg, "input_normalization": variant == "normalized"}
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, cfg, "bicubic" if variant == "bicubic" else "bilinear").to(DEV)
+        with torch.no_grad():
+            for n_, p_ in sr.named_parameters():
+                if "NON_LEARNED" not in n_:
+                    p_.mul_(10.0)
+        if variant == "normalized":
+            g_ = torch.Generator().manual_seed(3)
+            sr.normalization_params({"mean": torch.randn(48, generator=g_) * 0.1, "std": 0.5 + torch.rand(48, generator=g_)})
+            sr = sr.to(DEV)
+        sr.align_corners = variant != "align_corners_false"
+        sr.train()
+        g = torch.Generator(device=DEV).manual_seed(42)
+        lrs = [torch.nn.Parameter(torch.randn(1, 48, R, R, device=DEV, generator=g) * 0.5) for _ in range(3)]
+        for k, t in enumerate(lrs):
+            sr.set_LR_plane(t, id="p%d" % k, save_interpolated=False)
+        if path == "batched":
+            outs = sr.forward_many([("p%d" % k, rois[k]) for k in range(3)])
+        else:
+            outs = [sr(("p%d" % k, torch.tensor(rois[k]).reshape(2, 2))) for k in range(3)]
+        gen = torch.Generator(device=DEV).manual_seed(7)
+        sum((torch.nan_to_num(o) * torch.randn(o.shape, device=DEV, generator=gen)).sum() for o in outs).backward()
+        res[path] = ([o.detach().clone() for o in outs], _blob(sr).clone(), [t.grad.clone() for t in lrs])
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for a, b in zip(res["batched"][0], res["single"][0]):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    assert float(res["single"][1].norm()) > 0 and rel(res["batched"][1], res["single"][1]) <= 1e-5
+    for a, b in zip(res["batched"][2], res["single"][2]):
+        assert float(b.norm()) > 0 and rel(a, b) <= 1e-5
+
+
+def test_refine_iteration_on_two_ranks():
+    """SURVEY 8e training partition for BASELINE configs[4]: `bench.py --workload refine --gpus 2` (two ranks on cuda:0 over gloo, rehearsal): every
+    rank draws its own rays and regions of interest, the gradients of the SR network (173 MB), the planes and both decoders go through
+    distributed.allreduce_gradients before the three optimizers step; the run finishes with one line, finite, weak scaling."""
+    from test_hip_round3 import _bench_rehearsal
+    r, err = _bench_rehearsal(["--workload", "refine", "--refine-what", "joint", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["rays_per_step_per_gpu"] == 4096
+    assert np.isfinite(r["value"]) and r["value"] > 0 and r["roofline"]["frac"] > 0
+    assert r["collectives"]["backend"] == "gloo" and r["collectives"]["world_size"] == 2
