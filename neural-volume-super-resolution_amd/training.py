@@ -362,7 +362,16 @@ class TrainStep:
         side = self.__dict__.get("_prologue_stream")
         if side is None:
             side = self.__dict__["_prologue_stream"] = torch.cuda.Stream(device=dev, priority=-1)
-            side.wait_stream(cur)           # (once: the target image and the pose have been written by now)
+            self.__dict__["_prologue_inputs"] = set()
+        # The side stream reads the target image and the pose without waiting for the iteration's stream.  A tensor (storage, version) it has
+        # not met before may still be being written there (a view just uploaded, a pose just computed): the first time it meets one it waits for
+        # that stream once -- one drained queue per NEW input, none for the views of a resident dataset from their second use on
+        key = (img_target.data_ptr(), img_target._version, pose_target.data_ptr(), pose_target._version)
+        if key not in self.__dict__["_prologue_inputs"]:
+            if len(self.__dict__["_prologue_inputs"]) > 4096:
+                self.__dict__["_prologue_inputs"].clear()
+            self.__dict__["_prologue_inputs"].add(key)
+            side.wait_stream(cur)
         with torch.cuda.stream(side):
             ro, rd, target_s = draw()
             mf.set_cur_scene_id(scene_id)
@@ -429,6 +438,12 @@ class GraphedTrainStep:
             if m is not None and getattr(m, "point_coords_noise", 0):
                 raise ValueError("GraphedTrainStep: point_coords_noise is drawn by torch.normal on the CPU generator for every model call "
                                  "(models.py:291-293): a host draw cannot be replayed; use TrainStep")
+        for m in (step.mc, step.mf):
+            sr = getattr(m, "SR_model", None) if m is not None else None
+            if sr is not None and not getattr(m, "skip_SR_", False) and "SR" in step.what:
+                raise ValueError("GraphedTrainStep: an iteration that trains through the SR network sizes every launch from the regions of interest of "
+                                 "its batch (models.py:270-284: read on the host per iteration) -- its launch sequence changes with every batch and "
+                                 "cannot be replayed; use TrainStep (its regions are drawn ahead on a side stream)")
         if not (img_target.is_cuda and torch.as_tensor(pose_target).is_cuda):
             raise ValueError("GraphedTrainStep: img_target and pose_target must be CUDA tensors (the graph reads them at every replay)")
         self.step, self.sampler = step, step.pixel_sampler

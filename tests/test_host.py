@@ -544,6 +544,19 @@ def test_graphed_step_refuses_a_data_parallel_step(pkg):
         T.GraphedTrainStep(step, torch.zeros(4, 4, 3), torch.eye(4), 4, 4, 1.0, 1, "s", None, 8)
 
 
+def test_graphed_step_refuses_an_sr_training_iteration(pkg):
+    """an iteration that trains through PlanesSR reads its regions of interest on the host (models.py:270-284): no fixed launch sequence to replay"""
+    T = pkg.training
+
+    class _M:
+        skip_SR_ = False
+        point_coords_noise = 0
+        SR_model = object()
+    step = T.TrainStep(None, _M(), None, {"SR"}, SR_optimizer=None, pixel_sampler=T.DevicePixelSampler(seed=1))
+    with pytest.raises(ValueError, match="regions of interest"):
+        T.GraphedTrainStep(step, torch.zeros(4, 4, 3), torch.eye(4), 4, 4, 1.0, 1, "s", None, 8)
+
+
 def test_bench_edsr_flop_count_matches_the_survey():
     """bench.edsr_flops (the roofline numerator of --workload refine) on the full padded plane = SURVEY 8a's 6.74 TFLOP per plane; the ROI
     bounds restate csrc/sr_core.h sr_roi"""
