@@ -250,12 +250,26 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
                                   ((o3 != __shfl(o3, prev)) ? 8 : 0);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;              // this lane's channel of slot j
     float* const gl = gplane + lane;
+#if defined(BL_SCATTER_FALLTHROUGH) && BL_SCATTER_FALLTHROUGH
+    // experiment (round 5, -DBL_SCATTER_FALLTHROUGH=1; off): the flush of a slot is the UNCOMMON case (the fine pass flushes 1.4 of 4 slots per
+    // point) -- marked unlikely, so that the common path falls through instead of taking a branch around every flush block, and all four tests
+    // sit behind one test of the point's whole flag word.  Same box, three alternations (tools/bwd_time_one.py): S = 64 0.391-0.398 ms product /
+    // 0.397-0.407 with it, S = 128 0.593-0.605 / 0.600-0.604: branches are not what the loop waits for
+#define NVSR_FLUSH_V(BIT, S, O)                                                                          \
+        if (f & BIT) {                                                                                   \
+            if (p > 0) NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(O, p - 1), S);                     \
+            S = 0.0f;                                                                                    \
+        }
+#define NVSR_SLOT_V(BIT, S, O, A)                                                                        \
+        S = fmaf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
+#else
 #define NVSR_SLOT_V(BIT, S, O, A)                                                                        \
         if (f & BIT) {                                             /* (wave-uniform) */                  \
             if (p > 0) NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(O, p - 1), S);                     \
             S = 0.0f;                                                                                    \
         }                                                                                                \
         S = fmaf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
+#endif
     // lanes 48..63 sit the whole loop out (one exec mask around it instead of one around every atomic; v_readlane ignores exec)
     if (lane < C) {
 #pragma unroll 2
@@ -268,6 +282,14 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
             const int p = p0 + j;
             const int f = __builtin_amdgcn_readlane(fl, p);
             const float v = vv[j];
+#if defined(BL_SCATTER_FALLTHROUGH) && BL_SCATTER_FALLTHROUGH
+            if (__builtin_expect(f != 0, 0)) {
+                NVSR_FLUSH_V(1, s0, o0)
+                NVSR_FLUSH_V(2, s1, o1)
+                NVSR_FLUSH_V(4, s2, o2)
+                NVSR_FLUSH_V(8, s3, o3)
+            }
+#endif
             NVSR_SLOT_V(1, s0, o0, a0)
             NVSR_SLOT_V(2, s1, o1, a1)
             NVSR_SLOT_V(4, s2, o2, a2)
@@ -275,6 +297,9 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
         }
     }
 #undef NVSR_SLOT_V
+#ifdef NVSR_FLUSH_V
+#undef NVSR_FLUSH_V
+#endif
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o0, 31), s0);
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o1, 31), s1);
         NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(o2, 31), s2);
