@@ -1,5 +1,6 @@
 """gate-driven backward kernel alone (f16x2, planes only, all four planes + view rows), 4096 rays x {64, 128} sorted random depths, planes 200^2.
-   NVSR_HIP_LIB selects a variant.  Prints min ms of 8 launches."""
+   NVSR_HIP_LIB selects a variant.  Prints min ms of 8 launches.  BWD_ZERO_WEIGHTS=1: the decoder matrices are zeroed after the gates were made (same
+   instruction stream and traffic, operands that toggle fewer bits: does the kernel run on a power-managed clock?)."""
 import sys, os, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import nvsr_amd
@@ -19,6 +20,11 @@ for S in (64, 128):
     raw = torch.empty(N, S, 4, device=dev); gates = torch.empty(N, S, 32, dtype=torch.int32, device=dev)
     capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(mf.packed_decoder()), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), None, capi.stream())
     g_raw = torch.randn(N, S, 4, device=dev, generator=g) * 1e-3
+    if os.environ.get("BWD_ZERO_WEIGHTS") == "1":
+        with torch.no_grad():
+            for n_, p_ in mf.named_parameters():
+                if n_.endswith(".weight") and (n_.startswith("density_dec.") or n_.startswith("rgb_dec.")):
+                    p_.zero_()
     gpl = [torch.zeros_like(k) for k in keep]
     gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
     vws = torch.empty(lib.nvsr_view_grad_workspace_floats(N, S), device=dev)
