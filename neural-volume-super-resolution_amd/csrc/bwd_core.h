@@ -268,19 +268,22 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
             if (p > 0) NVSR_BWD_ATOMIC(gl + __builtin_amdgcn_readlane(O, p - 1), S);                     \
             S = 0.0f;                                                                                    \
         }                                                                                                \
-        S = fmaf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
+        S = fmaf(v, (SCV_ABLATE & 2) ? A : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), p)), S);
 #endif
     // lanes 48..63 sit the whole loop out (one exec mask around it instead of one around every atomic; v_readlane ignores exec)
+#ifndef SCV_ABLATE
+#define SCV_ABLATE 0      // timing experiments only (wrong results): 1 no per-point loop, 2 weights without v_readlane, 4 no flag tests / flushes, 8 no LDS reads
+#endif
     if (lane < C) {
 #pragma unroll 2
-    for (int p0 = 0; p0 < 32; p0 += 4) {
+    for (int p0 = 0; p0 < ((SCV_ABLATE & 1) ? 0 : 32); p0 += 4) {
         float vv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + lane];                // 4 points' rows in flight
+        for (int j = 0; j < 4; ++j) vv[j] = (SCV_ABLATE & 8) ? (float)(p0 + j) : tile[(p0 + j) * C + lane];                // 4 points' rows in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p0 + j;
-            const int f = __builtin_amdgcn_readlane(fl, p);
+            const int f = (SCV_ABLATE & 4) ? 0 : __builtin_amdgcn_readlane(fl, p);
             const float v = vv[j];
 #if defined(BL_SCATTER_FALLTHROUGH) && BL_SCATTER_FALLTHROUGH
             if (__builtin_expect(f != 0, 0)) {
