@@ -354,7 +354,7 @@ class TrainStep:
         sr = getattr(mf, "SR_model", None) if mf is not None else None
         ahead = (self.prologue_ahead and sr is not None and not getattr(mf, "skip_SR_", False) and sr.training and isinstance(self.pixel_sampler, DevicePixelSampler)
                  and self.pixel_sampler.state is None and img_target.is_cuda and torch.is_tensor(pose_target) and pose_target.is_cuda
-                 and bool(_cfg(scene_config, "no_ndc", True)) and mf.is_native_geometry() and not getattr(mf, "point_coords_noise", 0))
+                 and mf.is_native_geometry() and not getattr(mf, "point_coords_noise", 0))
         if not ahead:
             return draw()
         dev = img_target.device
@@ -375,7 +375,9 @@ class TrainStep:
         with torch.cuda.stream(side):
             ro, rd, target_s = draw()
             mf.set_cur_scene_id(scene_id)
-            dims, rois = mf.training_rois(pack_rays(ro, rd, _cfg(scene_config, "near"), _cfg(scene_config, "far")))
+            # (the rays as run_one_iter_of_nerf will pack them: NDC scenes -- LLFF, `no_ndc: False` -- project them first, train_utils.py:215-218)
+            dims, rois = mf.training_rois(pack_rays(ro, rd, _cfg(scene_config, "near"), _cfg(scene_config, "far"), H, W, focal,
+                                                    no_ndc=_cfg(scene_config, "no_ndc")))
             host = None
             if dims:
                 host = torch.empty((len(dims), 4), dtype=torch.float32, pin_memory=True)

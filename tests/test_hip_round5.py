@@ -221,7 +221,8 @@ def test_residual_gradient_gather_equals_the_scatter(hip, oracle):
         assert err <= 2e-6, (align, err)
 
 
-def test_refine_iteration_with_regions_drawn_ahead_equals_the_in_stream_iteration(hip):
+@pytest.mark.parametrize("ndc", [False, True])
+def test_refine_iteration_with_regions_drawn_ahead_equals_the_in_stream_iteration(hip, ndc):
     """training.TrainStep._draw_rays: pixels, rays and regions of interest produced on a side stream ahead of the iteration (`_roi_hint`) against
     the same iteration with everything on the iteration's stream -- same pixels (device sampler, same key), same regions, same loss and
     gradients (to the ordering noise of float atomics)."""
@@ -233,6 +234,9 @@ def test_refine_iteration_with_regions_drawn_ahead_equals_the_in_stream_iteratio
     focal = 0.5 * W / np.tan(0.5 * 0.6911112)
     pose = T(load_golden("g08_render.npz")["pose"])
     opts, scfg = make_options(24, 24)
+    if ndc:                                          # an LLFF-style scene (BASELINE configs[4]): NDC rays, near 0, far 1 (train_utils.py:215-218)
+        from test_hip_parity import Opt
+        scfg = Opt(near=0.0, far=1.0, no_ndc=False)
     res = {}
     for ahead in (True, False):
         _, noisy = _gt_and_student(hip, g, sid, seed=84)
