@@ -28,7 +28,8 @@ Other workloads of the same path (--workload; same JSON contract, their own metr
   refine  BASELINE configs[4]'s iteration (config/RefineOnTestScene.yml, TrainModels.yml): 4096 random rays of an 800x800 view, 64+64 samples, LR
           planes 200^2, the fine model samples the three position planes super-resolved by PlanesSR(EDSR 256 x 32) in TRAINING mode on the regions
           of interest of the batch (forward that keeps its activations, data + weight gradients, Adam), the coarse model samples the LR planes;
-          --refine-what joint (what = ['LR_planes', 'decoder', 'SR'], the YAMLs' value; default) | sr (what = ['SR']).  The line carries the
+          --refine-what joint (what = ['LR_planes', 'decoder', 'SR'], the YAMLs' value; default) | sr (what = ['SR']); --refine-scene llff: configs[4] as
+          written (LLFF-'fern'-like forward-facing 378x504 view, NDC rays, 64+128 samples; `other_workloads.refine_llff_ndc`).  The line carries the
           split of an iteration (regions of interest / SR forward / render / SR backward / optimizers) and the crops' algorithmic FLOP.
 """
 import argparse
@@ -764,6 +765,9 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
                             decoders and the SR network train."""
     capi, M, T = nvsr_amd.capi, nvsr_amd.models, nvsr_amd.training
     R, N, Nc, Nf = 200, 4096, 64, 64
+    llff = getattr(args, "refine_scene", "blender") == "llff"
+    if llff:
+        Nf = 128                                            # BASELINE configs[4] as written: LLFF 'fern', NDC rays, 64 + 128 samples
     joint = args.refine_what == "joint"
     what = {"LR_planes", "decoder", "SR"} if joint else {"SR"}
     mc, mf, sid, pose = make_synthetic_scene(dev, R, 32, seed=0, theta=30.0, channels_last=True)
@@ -782,6 +786,15 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
     opts, scfg = render_options(Nc, Nf, perturb=True, noise=0.2)
+    if llff:
+        # a forward-facing view at 1/8 of the LLFF resolution (tests/test_hip_round2.py: the same scene against the oracle): NDC rays
+        # (scene_config.no_ndc False, train_utils.py:215-218), near 0, far 1, the box spans the NDC cube
+        H, W, focal = 378, 504, 407.6
+        pose = torch.tensor([[1.0, 0.0, 0.0, 0.03], [0.0, 1.0, 0.0, -0.02], [0.0, 0.0, 1.0, 0.1], [0.0, 0.0, 0.0, 1.0]], device=dev)
+        scfg = Opt(near=0.0, far=1.0, no_ndc=False)
+        for m in (mc, mf):
+            m.box_coords = {sid: torch.tensor([[-1.5, -1.5, -1.5, -np.pi, -np.pi / 2], [1.5, 1.5, 1.5, np.pi, np.pi / 2]], dtype=torch.float64)}
+            m.invalidate()
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     target = torch.rand(H, W, 3, device=dev, generator=g)
     dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
@@ -813,15 +826,17 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     mode = capi.get_conv_arithmetic()
     arith = ARITHMETIC[mode]
     label = "what = ['LR_planes', 'decoder', 'SR']" if joint else "what = ['SR']"
-    result = {"metric": "SR-refinement training rays/sec (4096 rays/iter, 64+64 samples, LR planes 200^2 -> ROI x4 by PlanesSR(EDSR 256x32) in training "
-                        "mode on the fine model, %s, Adam)" % label,
+    view = "LLFF-'fern'-like forward-facing %dx%d view, NDC rays" % (H, W) if llff else "800x800 view"
+    result = {"metric": "SR-refinement training rays/sec (4096 rays/iter of %s, %d+%d samples, LR planes 200^2 -> ROI x4 by PlanesSR(EDSR 256x32) in training "
+                        "mode on the fine model, %s, Adam)" % (view if llff else "an 800x800 view", Nc, Nf, label),
               "value": world * N * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "host_issue_ms_per_step": host_issue_ms, "dtype": arith["dtype"], "conv_arithmetic": mode, "data": "synthetic",
-              "config": {"workload": "SR refinement iteration (BASELINE configs[4]; config/RefineOnTestScene.yml / TrainModels.yml): 4096 random rays of an "
-                                     "800x800 view, 64 coarse + 64 fine samples, 3x200^2x48 + 32^2x48 LR planes, EDSR(hidden 256, 32 blocks, x4) on the "
+              "config": {"workload": "SR refinement iteration (BASELINE configs[4]; config/RefineOnTestScene.yml / TrainModels.yml): 4096 random rays of %s, "
+                                     "%d coarse + %d fine samples, 3x200^2x48 + 32^2x48 LR planes, EDSR(hidden 256, 32 blocks, x4) on the "
                                      "regions of interest of the three position planes, SR model on the fine model only, loss on the fine output, %s, Adam"
-                                     % label, "rays_per_step_per_gpu": N, "refine_what": args.refine_what,
+                                     % ("a " + view if llff else "an 800x800 view", Nc, Nf, label), "rays_per_step_per_gpu": N, "refine_what": args.refine_what,
+                         "refine_scene": "llff" if llff else "blender",
                          "parallelism": "every rank draws its own %d rays; one in-place all-reduce per gradient tensor (EDSR 173 MB%s) per step"
                                         % (N, " + planes 23 MB + decoders 1 MB" if joint else "")}}
     if rank != 0:
@@ -888,7 +903,7 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     result["roofline"] = {"kernel": "conv3x3_limb16_kernel (forward + data gradients) + conv3x3_wgrad_limb_kernel: every convolution launch of the three "
                                     "PlanesSR forward + backward passes of one iteration",
                           "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                          "traffic": pmc_traffic("refine_" + args.refine_what, arith["dtype"]),
+                          "traffic": None if llff else pmc_traffic("refine_" + args.refine_what, arith["dtype"]),      # (the counter passes ran the blender scene)
                           "kernel_ms": 1e3 * (t_fwd + t_bwd), "kernel_ms_source": "HIP events on the launch stream around the PlanesSR phases of an iteration, this process",
                           "algorithmic_flop_per_step": sr_flop, "algorithmic_flop_forward": fwd_flop,
                           "forward": {"ms": 1e3 * t_fwd, "achieved": fwd_flop / t_fwd / 1e12, "frac": fwd_flop / t_fwd / 1e12 / peak},
@@ -900,9 +915,9 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
                                        "peak = %.1f TFLOP/s dense on the pipe used / %d MFMA products per f32 product" % (arith["pipe_peak"], arith["products"])}
     result["roofline"]["traffic_source"] = None if result["roofline"]["traffic"] is None else pmc_source()
     rec = pmc_record()
-    if rec is not None and rec.get("refine_" + args.refine_what, {}).get("sr_backward_split_ms"):
+    if rec is not None and not llff and rec.get("refine_" + args.refine_what, {}).get("sr_backward_split_ms"):
         result["sr_backward_split_ms"] = dict(rec["refine_" + args.refine_what]["sr_backward_split_ms"], source=pmc_source())
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not llff:        # (the CPU leg times the blender scene's rays; `--refine-scene blender` carries it)
         from oracle.oracle import Oracle, decoder_blob
         o = Oracle(f32=True)
         x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
@@ -963,6 +978,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="train workload: launch the iteration kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-arithmetic-mode frames (profiling passes)")
+    ap.add_argument("--refine-scene", choices=["blender", "llff"], default="blender",
+                    help="--workload refine: blender = 4096 rays of an 800x800 Lego-like view, 64+64 samples (the YAMLs' values); llff = BASELINE configs[4] as "
+                         "written: an LLFF-'fern'-like forward-facing 378x504 view, NDC rays, 64+128 samples")
     ap.add_argument("--no-split", action="store_true", help="--workload refine: skip the three probe iterations of the phase split (counter passes)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="--workload render, N = 1: do not append the short train / sr runs (`other_workloads` of the line)")
@@ -1234,7 +1252,8 @@ def main():
                                                ("train_decoder", bench_train, 20, 3, {"train_what": "planes+decoder"}),
                                                ("sr", bench_sr, 3, 1, {}),
                                                ("refine", bench_refine, 5, 2, {"refine_what": "joint"}),
-                                               ("refine_sr_only", bench_refine, 5, 2, {"refine_what": "sr"})):
+                                               ("refine_sr_only", bench_refine, 5, 2, {"refine_what": "sr"}),
+                                               ("refine_llff_ndc", bench_refine, 5, 2, {"refine_what": "joint", "refine_scene": "llff"})):
                 sub.steps, sub.warmup = steps, warm
                 for k, v in extra.items():
                     setattr(sub, k, v)
