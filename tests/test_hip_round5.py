@@ -373,3 +373,58 @@ def test_refine_iteration_on_two_ranks():
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["rays_per_step_per_gpu"] == 4096
     assert np.isfinite(r["value"]) and r["value"] > 0 and r["roofline"]["frac"] > 0
     assert r["collectives"]["backend"] == "gloo" and r["collectives"]["world_size"] == 2
+
+
+def test_rccl_backend_executes_the_collective_branch_on_one_rank():
+    """"the RCCL branch has still never executed against RCCL".  No second GPU is reachable from a test box, but RCCL itself is: a
+    process group of ONE rank on backend "nccl" (= RCCL on ROCm) runs the collectives of distributed.py on device buffers through the library
+    -- initialisation, `all_reduce(async_op=True)` on a row-major tensor and on the row-major [N,H,W,C] view of a channels_last plane gradient
+    (RCCL refuses non-contiguous tensors: the gloo rehearsals could not tell), `all_gather_into_tensor` into a caller's buffer, the averaging of
+    allreduce_gradients' RCCL path (forced: world 1 short-circuits it) and a row-sharded frame through the real renderer.  Sums over one rank
+    are the inputs: values are checked, not only that nothing raises."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, socket
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl"
+        import nvsr_amd
+        D = nvsr_amd.distributed
+        base = torch.arange(2 * 48 * 5 * 7, dtype=torch.float32, device=dev).reshape(2, 48, 5, 7)
+        cl = base.clone().contiguous(memory_format=torch.channels_last)
+        rm = torch.arange(1000, dtype=torch.float32, device=dev)
+        ptrs = (cl.data_ptr(), rm.data_ptr())
+        D.allreduce_in_place([cl, rm], scale=0.5)                      # the RCCL branch of allreduce_gradients: async all-reduces, one wait, one fused scale
+        torch.cuda.synchronize()
+        assert torch.equal(cl, base * 0.5) and torch.equal(rm, torch.arange(1000, dtype=torch.float32, device=dev) * 0.5)
+        assert (cl.data_ptr(), rm.data_ptr()) == ptrs and cl.is_contiguous(memory_format=torch.channels_last)
+        out = torch.empty(6, 3, device=dev)
+        t = torch.rand(6, 3, device=dev)
+        dist.all_gather_into_tensor(out, t)                            # what gather_row_blocks issues on an even split
+        assert torch.equal(out, t)
+        w = torch.ones(3, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX); dist.barrier()
+        # the row-sharded frame of the bench's N > 1 default partition, through the fused passes
+        from bench import make_synthetic_scene, render_options
+        mc, mf, sid, pose = make_synthetic_scene(dev, plane_res=48, view_res=16, seed=2)
+        H = W = 32; focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+        opts, scfg = render_options(16, 16)
+        c, f = D.render_views_sharded(H, W, focal, mc, mf, [pose], opts, sid, scfg)
+        ro, rd = nvsr_amd.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+        alone = nvsr_amd.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+        assert torch.equal(c[0], alone[0]) and torch.equal(f[0], alone[3])
+        dist.barrier(); dist.destroy_process_group()
+        print("RCCL_ONE_RANK_OK")
+    """ % root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
