@@ -312,8 +312,12 @@ class TrainStep:
         if hasattr(self.mf, "SR_model") and sr_iter and "LR_planes" in self.what:
             self.mf.SR_model.clear_SR_planes(all_planes=True)
             self.mf.assign_LR_planes(scene=scene_id)
-        out = run_one_iter_of_nerf(H, W, focal, self.mc, self.mf, batch_rays, self.options, scene_id, mode="train", scene_config=scene_config,
-                                   randoms=randoms)
+        try:
+            out = run_one_iter_of_nerf(H, W, focal, self.mc, self.mf, batch_rays, self.options, scene_id, mode="train", scene_config=scene_config,
+                                       randoms=randoms)
+        finally:
+            if self.mf is not None:          # (the regions of interest drawn ahead for THIS batch never outlive it, consumed or not)
+                self.mf.__dict__.pop("_roi_hint", None)
         rgb_coarse, rgb_fine = out[0], out[3]
         target = target_s[..., :3]
         if im_consistency_iter:
