@@ -514,9 +514,14 @@ class GraphedTrainStep:
         self.graph.replay()
         self.sampler.calls += 1          # host mirror of the device counter
         self.replays += 1
+        bumped = False
         if self._updated:
-            torch._C._increment_version(self._updated)     # the replay wrote them in place
-        if self._opaque_optimizer:                         # (an optimizer object whose parameters cannot be listed: drop the derived copies)
+            try:
+                torch._C._increment_version(self._updated)     # the replay wrote them in place
+                bumped = True
+            except (AttributeError, TypeError):                # (a torch without this hook / without its list form: drop the derived copies instead)
+                pass
+        if self._opaque_optimizer or not bumped:           # (an optimizer object whose parameters cannot be listed: drop the derived copies)
             for m in (self.step.mc, self.step.mf, self.step.SR_model):
                 if m is not None and hasattr(m, "invalidate"):
                     m.invalidate()
