@@ -428,3 +428,40 @@ def test_rccl_backend_executes_the_collective_branch_on_one_rank():
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_batched_sr_training_at_the_benchmark_size(hip):
+    """BASELINE configs[4] at its real size: PlanesSR(EDSR hidden 256, 32 blocks, x4) on the regions of interest of three 48 x 200^2 planes (the crops of
+    the refine bench: 115 x 143, 115 x 125, 143 x 125 LR texels + 68 of context per side) -- the batched path (69 ragged launches per pass, one
+    weight-gradient pass per layer over the three crops, gradient magnitudes from the epilogues) against three PlanesSR.forward calls: planes bit
+    for bit, the 43.3 M weight gradients and the LR gradients within 1e-5 relative L2."""
+    R = 200
+    rois = [[-0.73, -0.88, 0.42, 0.55], [-0.73, -0.82, 0.42, 0.43], [-0.88, -0.82, 0.55, 0.43]]
+    res = {}
+    for path in ("batched", "single"):
+        torch.manual_seed(51)
+        sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 256, "n_blocks": 32}}, "bilinear").to(DEV)
+        with torch.no_grad():
+            for p_ in sr.parameters():
+                p_.mul_(3.0)
+        sr.train()
+        g = torch.Generator(device=DEV).manual_seed(52)
+        lrs = [torch.nn.Parameter(torch.randn(1, 48, R, R, device=DEV, generator=g) * 0.5) for _ in range(3)]
+        for k, t in enumerate(lrs):
+            sr.set_LR_plane(t, id="p%d" % k, save_interpolated=False)
+        if path == "batched":
+            outs = sr.forward_many([("p%d" % k, rois[k]) for k in range(3)])
+        else:
+            outs = [sr(("p%d" % k, torch.tensor(rois[k]).reshape(2, 2))) for k in range(3)]
+        gen = torch.Generator(device=DEV).manual_seed(53)
+        sum((torch.nan_to_num(o) * torch.randn(o.shape, device=DEV, generator=gen) * 1e-3).sum() for o in outs).backward()
+        res[path] = ([o.detach().clone() for o in outs], _blob(sr).clone(), [t.grad.clone() for t in lrs])
+        del sr, lrs, outs
+        torch.cuda.empty_cache()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for a, b in zip(res["batched"][0], res["single"][0]):
+        assert bool(torch.isnan(a).any()) and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        assert bool(torch.isfinite(torch.nan_to_num(a)).all())
+    assert float(res["single"][1].norm()) > 0 and rel(res["batched"][1], res["single"][1]) <= 1e-5, rel(res["batched"][1], res["single"][1])
+    for a, b in zip(res["batched"][2], res["single"][2]):
+        assert float(b.norm()) > 0 and rel(a, b) <= 1e-5, rel(a, b)
