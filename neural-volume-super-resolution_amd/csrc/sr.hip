@@ -795,13 +795,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
 
 // limb fragments for conv3x3_limb16_kernel: [chunk of 32 ci][cb16][tap][limb][lane][4 words]; lane (co = 16 cb + (l & 15), g = l >> 4) holds the
 // 8 input channels 32 chunk + 8 g + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
-template <int LIMBS = 3>
-__global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int transposed) {
+template <int LIMBS>
+__device__ __forceinline__ void pack_conv_limbs16_word(long idx, const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int transposed) {
     constexpr int FRAG = 9 * LIMBS * 256;
     const int ncb = Cout / 16;
-    const long n = (long)(Cin / 32) * ncb * FRAG;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
     const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % LIMBS), tap = (int)((idx / (256 * LIMBS)) % 9);
     const long rest = idx / FRAG;
     const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
@@ -827,13 +824,16 @@ __global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* 
     }
     out[idx] = word;
 }
+template <int LIMBS = 3>
+__global__ void pack_conv_limbs16_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int transposed) {
+    const long n = (long)(Cin / 32) * (Cout / 16) * (9 * LIMBS * 256);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) pack_conv_limbs16_word<LIMBS>(idx, w, out, Cin, Cout, transposed);
+}
 
 // limb fragments of a conv's weights: [chunk of 16 ci][cb][tap][limb][lane][4 words]; lane (co = 32 cb + (l & 31), h = l >> 5) holds
 // the 8 input channels 16 chunk + 8 h + 0..7 of tap `tap` as bf16 pairs (even channel in the low half)
-__global__ void pack_conv_limbs_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int ncb, int transposed) {
-    const long n = (long)(Cin / 16) * ncb * CL_FRAG_WORDS;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+__device__ __forceinline__ void pack_conv_limbs_word(long idx, const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int ncb, int transposed) {
     const int wd = idx & 3, lane = (idx >> 2) & 63, t = (int)((idx >> 8) % 3), tap = (int)((idx / 768) % 9);
     const long rest = idx / CL_FRAG_WORDS;
     const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
@@ -854,13 +854,15 @@ __global__ void pack_conv_limbs_kernel(const float* __restrict__ w, unsigned* __
     }
     out[idx] = word;
 }
+__global__ void pack_conv_limbs_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int Cin, int Cout, int ncb, int transposed) {
+    const long n = (long)(Cin / 16) * ncb * CL_FRAG_WORDS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) pack_conv_limbs_word(idx, w, out, Cin, Cout, ncb, transposed);
+}
 
 // [Cout][Cin][3][3] -> [chunk][cb][t][lane].  transposed: the packed conv is the DATA GRADIENT of w's conv, i.e. it maps Cout
 // channels to Cin channels with w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]; (Cin, Cout) are then those of the packed conv.
-__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int nchunks, int transposed) {
-    const long n = (long)nchunks * ncb * FRAG_FLOATS;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+__device__ __forceinline__ void pack_conv_word(long idx, const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int transposed) {
     const int lane = idx & 63, t = (int)((idx >> 6) % K_PER_CHUNK);
     const long rest = idx / FRAG_FLOATS;
     const int cb = (int)(rest % ncb), chunk = (int)(rest / ncb);
@@ -868,6 +870,60 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
     float v = 0.0f;
     if (co < Cout && ci < Cin) v = transposed ? w[((long)ci * Cout + co) * 9 + (8 - tap)] : w[((long)co * Cin + ci) * 9 + tap];
     wpk[idx] = v;
+}
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int ncb, int nchunks, int transposed) {
+    const long n = (long)nchunks * ncb * FRAG_FLOATS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) pack_conv_word(idx, w, wpk, Cin, Cout, ncb, transposed);
+}
+
+// All layers of a network in ONE launch per fragment kind (round 5): packing EDSR(256 x 32) for the forward and for the data gradient was 4 launches per
+// layer = 552 launches of a few microseconds each per training iteration (the weights change every iteration); a table of up to PACK_TABLE_LAYERS
+// layers rides in the kernel arguments, blockIdx.y is the layer, a grid-stride loop covers the layer's words.
+// KIND: 0 f32 fragments, 1 bf16-limb fragments (32x32x16), 2 bf16-limb fragments (16x16x32), 3 f16-limb fragments (16x16x32)
+constexpr int PACK_TABLE_LAYERS = 36;
+struct PackLayer { const float* w; float* packed; int Cin, Cout, ncb, pad_; long n[4], off[4]; };     // (Cin, Cout) as the packing kernels see them
+struct PackTable { int transposed, nlayers; PackLayer layer[PACK_TABLE_LAYERS]; };
+template <int KIND>
+__global__ __launch_bounds__(256) void pack_table_kernel(PackTable t) {
+    const PackLayer& L = t.layer[blockIdx.y];
+    const long n = L.n[KIND];
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        if (KIND == 0) pack_conv_word(idx, L.w, L.packed + L.off[0], L.Cin, L.Cout, L.ncb, t.transposed);
+        else if (KIND == 1) pack_conv_limbs_word(idx, L.w, reinterpret_cast<unsigned*>(L.packed + L.off[1]), L.Cin, L.Cout, L.ncb, t.transposed);
+        else if (KIND == 2) pack_conv_limbs16_word<3>(idx, L.w, reinterpret_cast<unsigned*>(L.packed + L.off[2]), L.Cin, L.Cout, t.transposed);
+        else pack_conv_limbs16_word<2>(idx, L.w, reinterpret_cast<unsigned*>(L.packed + L.off[3]), L.Cin, L.Cout, t.transposed);
+    }
+}
+// natural: the layers' [Cout][Cin][3][3] weights one after the other; packed: their fragment blobs one after the other (conv_packed_floats each)
+int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream) {
+    for (int l0 = 0; l0 < nl; l0 += PACK_TABLE_LAYERS) {
+        PackTable t{};
+        t.transposed = transposed;
+        t.nlayers = nl - l0 < PACK_TABLE_LAYERS ? nl - l0 : PACK_TABLE_LAYERS;
+        long mx[4] = {0, 0, 0, 0};
+        for (int k = 0; k < t.nlayers; ++k) {
+            const ConvLayer& c = layers[l0 + k];
+            const int ci = transposed ? c.Cout : c.Cin, co = transposed ? c.Cin : c.Cout;          // the packed conv's own (Cin, Cout)
+            PackLayer& L = t.layer[k];
+            L.w = natural; L.packed = packed; L.Cin = ci; L.Cout = co; L.ncb = conv_ncb(co);
+            L.n[0] = conv_packed_f32_floats(ci, co);
+            L.n[1] = conv_packed_limb_words(ci, co);
+            L.n[2] = conv_packed_limb16_words(ci, co);
+            L.n[3] = conv_packed_f16_words(ci, co);
+            L.off[0] = 0; L.off[1] = L.n[0]; L.off[2] = L.n[0] + L.n[1]; L.off[3] = L.n[0] + L.n[1] + L.n[2];
+            for (int q = 0; q < 4; ++q) mx[q] = L.n[q] > mx[q] ? L.n[q] : mx[q];
+            natural += 9LL * c.Cin * c.Cout;
+            packed += conv_packed_floats(ci, co);
+        }
+        auto grid = [&](long n) { long b = (n + 255) / 256; return dim3((unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b), t.nlayers); };
+        if (mx[0]) hipLaunchKernelGGL(pack_table_kernel<0>, grid(mx[0]), dim3(256), 0, stream, t);
+        if (mx[1]) hipLaunchKernelGGL(pack_table_kernel<1>, grid(mx[1]), dim3(256), 0, stream, t);
+        if (mx[2]) hipLaunchKernelGGL(pack_table_kernel<2>, grid(mx[2]), dim3(256), 0, stream, t);
+        if (mx[3]) hipLaunchKernelGGL(pack_table_kernel<3>, grid(mx[3]), dim3(256), 0, stream, t);
+        if (int e = NVSR_CHECK_LAUNCH()) return e;
+    }
+    return NVSR_OK;
 }
 
 // PlanesSR input: crop with as much real context as available + replicate padding == clamped gather (models.py:906-914),
@@ -1294,14 +1350,10 @@ int64_t nvsr_edsr_packed_floats(int Cin, int Cout, int hid, int nblocks, int n_u
 int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream) {
     if (!natural || !packed) return NVSR_ERR_NULL;
     if (nvsr_edsr_packed_floats(Cin, Cout, hid, nblocks, n_up) < 0) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed)) return NVSR_ERR_ALIGN;
     ConvLayer L[600]; int n;
     edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
-    for (int i = 0; i < n; ++i) {
-        if (int e = nvsr_pack_conv3x3(natural, L[i].Cin, L[i].Cout, packed, stream)) return e;
-        natural += 9LL * L[i].Cin * L[i].Cout;
-        packed += conv_packed_floats(L[i].Cin, L[i].Cout);
-    }
-    return NVSR_OK;
+    return pack_layers(natural, L, n, packed, 0, (hipStream_t)stream);       // (4 launches per 36 layers instead of 4 per layer)
 }
 
 /* spatial size of the EDSR output for an [*, H, W] input */

@@ -772,14 +772,10 @@ int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, i
 int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream) {
     if (!natural || !packed_dgrad) return NVSR_ERR_NULL;
     if (!edsr_geometry_ok(nblocks, n_up)) return NVSR_ERR_SHAPE;
+    if (!aligned16(packed_dgrad)) return NVSR_ERR_ALIGN;
     ConvLayer L[EDSR_MAX_LAYERS]; int n;
     edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
-    for (int i = 0; i < n; ++i) {
-        if (int e = nvsr_pack_conv3x3_dgrad(natural, L[i].Cin, L[i].Cout, packed_dgrad, stream)) return e;
-        natural += 9LL * L[i].Cin * L[i].Cout;
-        packed_dgrad += conv_packed_floats(L[i].Cout, L[i].Cin);
-    }
-    return NVSR_OK;
+    return pack_layers(natural, L, n, packed_dgrad, 1, (hipStream_t)stream);
 }
 
 /* 3 gradient tensors + 1 un-shuffled gradient + the weight-gradient partial sums */

@@ -193,6 +193,9 @@ struct ConvRagged {
 // limb arithmetics only, and an f16 data gradient needs cx.in_absmax (one word for all planes: launch_absmax_ragged)
 int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Cout, int epilogue, const float* skip, float* out,
                 hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{}, const ConvRagged* rag = nullptr);
+// fragment blobs of nl consecutive layers (natural: their [Cout][Cin][3][3] weights one after the other) in 4 launches per 36 layers; transposed: the
+// data gradients' fragments (nvsr_pack_conv3x3_dgrad per layer).  sr.hip
+int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream);
 // max |x| over up to CONV_RAGGED_MAX tensors in one launch, into the caller's word
 const unsigned* launch_absmax_ragged(int n, const float* const* x, const long* count, hipStream_t stream, unsigned* owned);
 

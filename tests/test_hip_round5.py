@@ -465,3 +465,30 @@ def test_batched_sr_training_at_the_benchmark_size(hip):
     assert float(res["single"][1].norm()) > 0 and rel(res["batched"][1], res["single"][1]) <= 1e-5, rel(res["batched"][1], res["single"][1])
     for a, b in zip(res["batched"][2], res["single"][2]):
         assert float(b.norm()) > 0 and rel(a, b) <= 1e-5, rel(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# one launch per fragment kind for a whole network's weights (pack_layers) against the layer-by-layer packing it replaced
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("geometry", [(48, 48, 256, 32, 2), (48, 48, 64, 3, 2), (48, 48, 128, 40, 1), (16, 16, 32, 1, 0)])
+@pytest.mark.parametrize("dgrad", [False, True])
+def test_network_pack_is_the_layer_by_layer_pack(hip, geometry, dgrad):
+    """nvsr_pack_edsr / nvsr_pack_edsr_dgrad (a table of up to 36 layers per launch; 82 layers for the 40-block case = three tables) give bit for
+    bit the blobs nvsr_pack_conv3x3 / nvsr_pack_conv3x3_dgrad write layer by layer (models.py:803-872 EDSR: head, 2 convs per block, body tail,
+    upsampler convs, tail)."""
+    capi = hip.capi
+    lib = capi.lib()
+    Cin, Cout, hid, nb, n_up = geometry
+    shapes = [(Cin, hid)] + [(hid, hid)] * (2 * nb + 1) + [(hid, 4 * hid)] * n_up + [(hid, Cout)]
+    g = torch.Generator(device=DEV).manual_seed(sum(geometry))
+    nat = torch.randn(sum(9 * a * b for a, b in shapes), device=DEV, generator=g)
+    got = torch.ops.nvsr.pack_edsr(nat, list(geometry), dgrad)
+    want = torch.full_like(got, float("nan"))
+    o_nat = o_pk = 0
+    for ci, co in shapes:
+        n_pk = lib.nvsr_conv3x3_packed_floats(co, ci) if dgrad else lib.nvsr_conv3x3_packed_floats(ci, co)
+        capi.call("nvsr_pack_conv3x3_dgrad" if dgrad else "nvsr_pack_conv3x3", capi.ptr(nat[o_nat:]), ci, co, capi.ptr(want[o_pk:]), capi.stream())
+        o_nat += 9 * ci * co
+        o_pk += n_pk
+    assert o_nat == nat.numel() and o_pk == got.numel()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
