@@ -659,10 +659,80 @@ static int64_t wgrad_partial_floats_ragged(int Cin, int Cout) {
     return (tiles > 512 ? tiles : 512) * 2 * 9 * WG_CO * WG_CI;
 }
 
+// The reductions of a backward pass on a stream of their own (round 5).  wgrad_reduce_pieces_kernel is the one memory-bound kernel of the layer loop
+// (it reads the ~75 MB of partial sums a trunk layer's 512 pieces wrote: ~30 us at HBM rate, 2.5 ms of the 54 ms of a refine iteration's SR backward)
+// between matrix-bound ones: on the caller's stream it holds the next data-gradient launch back; on a side stream it runs under that launch.  The
+// partial sums alternate between two buffers: the reduction of layer l reads buffer l & 1 while layer l - 1's pieces fill the other one; the pieces of
+// layer l - 2 wait for the reduction of layer l (an event that has long fired).  join() -- on every exit of the pass, errors included -- makes the
+// caller's stream wait for the last reductions: the caller sees ordinary stream semantics.  Inside a stream capture the lane stays closed (everything on
+// the caller's stream).
+struct ReduceLane {
+    hipStream_t side = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    int device = -1;
+    bool ok = false;
+    bool open_on(int dev) {
+        if (ok && dev == device) return true;
+        if (ok) close();
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;      // (hi = the numerically lowest = greatest priority)
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess) { side = nullptr; return false; }
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&ready[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) {
+                close();
+                return false;
+            }
+        device = dev; ok = true;
+        return true;
+    }
+    void close() {
+        for (int k = 0; k < 2; ++k) {
+            if (ready[k]) (void)hipEventDestroy(ready[k]);
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            ready[k] = done[k] = nullptr;
+        }
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr; ok = false; device = -1;
+    }
+};
+// one pass's use of the lane: which buffer is next, which reductions are in flight
+struct ReducePass {
+    ReduceLane* lane = nullptr;            // NULL: reductions on the caller's stream, one buffer
+    hipStream_t stream = nullptr;
+    float* partial[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0;
+    bool failed = false;
+    void join() {
+        if (!lane) return;
+        for (int k = 0; k < 2; ++k)
+            if (busy[k]) { if (hipStreamWaitEvent(stream, lane->done[k], 0) != hipSuccess) failed = true; busy[k] = false; }
+    }
+    ~ReducePass() { join(); }
+};
+#ifndef WG_REDUCE_LANE
+#define WG_REDUCE_LANE 1     // 0: the reductions on the caller's stream (A/B builds)
+#endif
+// opens the lane for a pass on `stream` with two buffers of `stride` floats at `partial`; leaves it closed (in-stream reductions) inside a capture
+static void reduce_pass_begin(ReducePass& rp, float* partial, int64_t stride, hipStream_t stream) {
+    static thread_local ReduceLane lane;
+    rp.stream = stream;
+    rp.partial[0] = partial; rp.partial[1] = partial + stride;
+    rp.lane = nullptr;
+#if WG_REDUCE_LANE
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    int dev = 0;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (lane.open_on(dev)) rp.lane = &lane;
+#endif
+}
+
 // dw += scale * sum over the planes of dW(dy[b], x[b]) -- ONE pass of the limb kernel and one reduction for all planes (limb arithmetics only).
 // H[b], W[b] = size of x[b]; dy_absmax (f16 limbs): the word of launch_absmax[_ragged] over ALL planes' dy, or NULL with one plane
+// rp: the pass's reduce lane (its buffers replace `partial`), or NULL
 static int launch_wgrad_planes(int nplanes, const float* const* dy, const float* const* x, int Cin, const int* H, const int* W, int Cout, float scale,
-                               float* dw, float* partial, hipStream_t stream, int arith, const unsigned* dy_absmax) {
+                               float* dw, float* partial, hipStream_t stream, int arith, const unsigned* dy_absmax, ReducePass* rp = nullptr) {
     if (nplanes < 1 || nplanes > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
     const long tiles = (long)((Cout + WG_CO - 1) / WG_CO) * ((Cin + WG_CI - 1) / WG_CI);
     WgradParams p{dy[0], x[0], partial, Cin, Cout, H[0] - 2, W[0] - 2, 0, nullptr, 0, 0};
@@ -690,10 +760,27 @@ static int launch_wgrad_planes(int nplanes, const float* const* dy, const float*
         if (!am) return nplanes == 1 ? NVSR_ERR_LAUNCH : NVSR_ERR_NULL;
     }
     p.TS = (int)TS; p.n_wg = n_wg; p.total = total; p.dy_absmax = am;
+    hipStream_t rstream = stream;
+    int k = 0;
+    if (rp && rp->lane) {
+        k = rp->next & 1;
+        rp->next++;
+        partial = p.partial = rp->partial[k];
+        rstream = rp->lane->side;
+        if (rp->busy[k] && hipStreamWaitEvent(stream, rp->lane->done[k], 0) != hipSuccess) return NVSR_ERR_LAUNCH;   // the reduction that last read this buffer
+        rp->busy[k] = false;
+    }
     if (am) hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<2>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
     else hipLaunchKernelGGL(conv3x3_wgrad_limb_kernel<3>, dim3(n_wg), dim3(WG_TPB), 0, stream, p);
-    hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, stream, partial, n_wg, total, TS, Cout, Cin,
+    if (rstream != stream) {
+        if (hipEventRecord(rp->lane->ready[k], stream) != hipSuccess || hipStreamWaitEvent(rstream, rp->lane->ready[k], 0) != hipSuccess) return NVSR_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_pieces_kernel, dim3((Cin + 63) / 64, (Cout + 3) / 4, 9), dim3(256), 0, rstream, partial, n_wg, total, TS, Cout, Cin,
                        scale, dw, am);
+    if (rstream != stream) {
+        if (hipEventRecord(rp->lane->done[k], rstream) != hipSuccess) return NVSR_ERR_LAUNCH;
+        rp->busy[k] = true;
+    }
     return NVSR_CHECK_LAUNCH();
 }
 
@@ -961,7 +1048,10 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
         const int64_t f = wgrad_partial_floats_ragged(P[0].L[l].Cin, P[0].L[l].Cout);
         if (f > part_floats) part_floats = f;
     }
-    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + (part_floats + 3) / 4 * 4);
+    part_floats = (part_floats + 3) / 4 * 4;
+    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + 2 * part_floats);      // (two buffers of partial sums: ReduceLane)
+    ReducePass rp;                                                                       // (its destructor joins the lane on every exit)
+    reduce_pass_begin(rp, partial, part_floats, stream);
     int amax_next = 0;
     int64_t goff[EDSR_MAX_LAYERS], poff[EDSR_MAX_LAYERS], go = 0, po = 0;
     for (int l = 0; l < n; ++l) {
@@ -989,7 +1079,7 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
     auto wgrad = [&](const float* const* dy, int l, float scale, const unsigned* am) {
         const float* xs[CONV_RAGGED_MAX]; int H[CONV_RAGGED_MAX], W[CONV_RAGGED_MAX];
         for (int b = 0; b < B; ++b) { xs[b] = input_of(l, b); H[b] = P[b].ih[l]; W[b] = P[b].iw[l]; }
-        return launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am);
+        return launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am, &rp);
     };
     // data gradient of layer l: dy [Cout][ih-2][iw-2] -> [Cin][ih][iw] with the given backward epilogue
     auto dgrad = [&](const float* const* dy, int l, int epi, const float* const* skip, float* const* out, const unsigned* am, unsigned* out_am) {
@@ -1056,7 +1146,8 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
             }
         }
     }
-    return NVSR_OK;
+    rp.join();
+    return rp.failed ? NVSR_ERR_LAUNCH : NVSR_OK;
 }
 
 }  // namespace nvsr
@@ -1082,7 +1173,7 @@ int64_t nvsr_planes_sr_batch_backward_workspace_floats(int B, int Cc, int R0, in
         const int64_t f = wgrad_partial_floats_ragged(P.L[l].Cin, P.L[l].Cout);
         if (f > part) part = f;
     }
-    const int64_t ragged = 4 * T + (part + 3) / 4 * 4 + (P.n + 7) / 4 * 4;
+    const int64_t ragged = 4 * T + 2 * ((part + 3) / 4 * 4) + (P.n + 7) / 4 * 4;       // (edsr_backward_planes: 4 tensors, 2 x partial sums, the words)
     return s + (ragged > one ? ragged : one);
 }
 
