@@ -786,12 +786,12 @@ static int launch_wgrad_planes(int nplanes, const float* const* dy, const float*
 
 // dw += scale * dW(dy, x);  H, W = size of x
 static int launch_wgrad(const float* dy, const float* x, int Cin, int H, int W, int Cout, float scale, float* dw, float* partial,
-                        hipStream_t stream, int arith, const unsigned* dy_absmax = nullptr) {
+                        hipStream_t stream, int arith, const unsigned* dy_absmax = nullptr, ReducePass* rp = nullptr) {
     const int Ho = H - 2, Wo = W - 2;
     if (Ho < 1 || Wo < 1) return NVSR_ERR_SHAPE;
     arith = conv_resolve_arith(arith);
     if (arith != NVSR_ARITH_F32 && arith != NVSR_ARITH_BF16X3 && arith != NVSR_ARITH_F16X2) return NVSR_ERR_SHAPE;
-    if (arith != NVSR_ARITH_F32) return launch_wgrad_planes(1, &dy, &x, Cin, &H, &W, Cout, scale, dw, partial, stream, arith, dy_absmax);
+    if (arith != NVSR_ARITH_F32) return launch_wgrad_planes(1, &dy, &x, Cin, &H, &W, Cout, scale, dw, partial, stream, arith, dy_absmax, rp);
     const long n = 9L * Cout * Cin;
     const int ns = wgrad_slabs(Cin, Cout, Ho);
     WgradParams p{dy, x, partial, Cin, Cout, Ho, Wo, (Ho + ns - 1) / ns, nullptr, 0, 0};
@@ -877,7 +877,7 @@ int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblo
     const int64_t t = (P.max_tensor + 3) / 4 * 4;
     // + one word per gradient tensor for its largest magnitude (f16 limbs: absmax_kernel) -- caller-owned, so that backward passes queued on
     // different streams never share a result word
-    return 4 * t + (part + 3) / 4 * 4 + (P.n + 7) / 4 * 4;
+    return 4 * t + 2 * ((part + 3) / 4 * 4) + (P.n + 7) / 4 * 4;       // (two buffers of partial sums: ReduceLane)
 }
 
 /* Backward of nvsr_edsr_forward_train.  x, acts: the forward's input and activation record; d_out [Cout][Ho][Wo];
@@ -906,8 +906,11 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
         const int64_t f = wgrad_partial_floats(P.L[l].Cin, P.L[l].Cout, P.ih[l] - 2, P.iw[l] - 2);
         if (f > part_floats) part_floats = f;
     }
-    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + (part_floats + 3) / 4 * 4);     // P.n + 4 words, one per gradient tensor
+    part_floats = (part_floats + 3) / 4 * 4;
+    unsigned* amax_words = reinterpret_cast<unsigned*>(partial + 2 * part_floats);     // P.n + 4 words, one per gradient tensor
     int amax_next = 0;
+    ReducePass rp;                                                                      // (joins the lane on every exit)
+    if (arith != NVSR_ARITH_F32) reduce_pass_begin(rp, partial, part_floats, stream);
     // per-layer offsets into the natural gradient blob and the packed data-gradient blob
     int64_t goff[EDSR_MAX_LAYERS], poff[EDSR_MAX_LAYERS], go = 0, po = 0;
     for (int l = 0; l < P.n; ++l) {
@@ -940,7 +943,7 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
             const long n = (long)co * (ih - 2) * (iw - 2);
             hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, co / 4, ih - 2, iw - 2, unsh);
             if ((e = NVSR_CHECK_LAUNCH())) return e;
-            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
+            if ((e = launch_wgrad(unsh, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am, &rp))) return e;
             const int o = next_buf(gi, -1);
             unsigned* w = new_word();
             if ((e = launch_conv(unsh, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_NONE, nullptr, buf[o], stream, 2, 1, exec(g_am, w)))) return e;
@@ -948,19 +951,19 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
         } else if (P.epi[l] == EPI_RESIDUAL) {         // block: y = 0.1 conv2(relu(conv1(xb))) + crop(xb); layers l-1 (conv1), l (conv2)
             const float* t1 = input_of(l);             // relu(conv1(xb)), [hid][ih][iw]
             const float* xb = input_of(l - 1);         // [hid][ih+2][iw+2]
-            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
+            if ((e = launch_wgrad(g, t1, ci, ih, iw, co, 0.1f, grad_natural + goff[l], partial, stream, arith, g_am, &rp))) return e;
             const int o1 = next_buf(gi, -1);
             unsigned* w1 = new_word();
             if ((e = launch_conv(g, co, ih - 2, iw - 2, packed_dgrad + poff[l], ci, EPI_MASK_SCALE, t1, buf[o1], stream, 2, 1, exec(g_am, w1)))) return e;
             const int l1 = l - 1;
-            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith, w1))) return e;
+            if ((e = launch_wgrad(buf[o1], xb, P.L[l1].Cin, P.ih[l1], P.iw[l1], P.L[l1].Cout, 1.0f, grad_natural + goff[l1], partial, stream, arith, w1, &rp))) return e;
             const int o2 = next_buf(gi, o1);
             unsigned* w2 = new_word();
             if ((e = launch_conv(buf[o1], P.L[l1].Cout, ih, iw, packed_dgrad + poff[l1], P.L[l1].Cin, EPI_ADD_CENTER, g, buf[o2], stream, 2, 1, exec(w1, w2)))) return e;
             g = buf[o2]; gi = o2; g_am = w2;
             --l;                                        // conv1 is done too
         } else {                                        // plain conv (conv_input, conv_mid, conv_output)
-            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am))) return e;
+            if ((e = launch_wgrad(g, input_of(l), ci, ih, iw, co, 1.0f, grad_natural + goff[l], partial, stream, arith, g_am, &rp))) return e;
             if (need_dx) {
                 float* o = (l == 0) ? dx : buf[next_buf(gi, -1)];
                 unsigned* w = l ? new_word() : nullptr;
@@ -969,7 +972,8 @@ int nvsr_edsr_backward_arith(const float* x, int Cin, int H, int W, const float*
             }
         }
     }
-    return NVSR_OK;
+    rp.join();
+    return rp.failed ? NVSR_ERR_LAUNCH : NVSR_OK;
 }
 
 /* 1 d_diff + the prepared-input gradient + the EDSR backward workspace */
