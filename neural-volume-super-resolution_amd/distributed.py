@@ -186,12 +186,51 @@ def allreduce_in_place(tensors, group=None, scale=None):
         torch._foreach_mul_(list(tensors), scale)
 
 
+def allreduce_coalesced(tensors, group=None, scale=None, bucket_bytes=64 << 20):
+    """Sum MANY SMALL dense tensors over the ranks: flat buckets of ~bucket_bytes (one concatenation in, one all-reduce per bucket, all queued
+    before the first wait, one multiply by `scale`, one fused copy back).  The EDSR gradient of a refine iteration is 69 tensors of 2.4-9.4 MB
+    (173 MB): one collective each would pay RCCL's per-call latency 69 times for messages far below the size at which the xGMI
+    links run at their rate; three buckets do not, and the two copies move 2 x 173 MB through HBM (~0.1 ms of an ~88 ms iteration)."""
+    tensors = list(tensors)
+    if not tensors:
+        return
+    buckets, cur, size = [], [], 0
+    for t in tensors:
+        cur.append(t)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    flats = [torch.cat([t.reshape(-1) for t in b]) for b in buckets]                  # (logical order: any dense layout)
+    works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group, async_op=True) for f in flats]
+    for wk in works:
+        wk.wait()
+    if scale is not None:
+        torch._foreach_mul_(flats, scale)
+    dst, src = [], []
+    for b, f in zip(buckets, flats):
+        off = 0
+        for t in b:
+            dst.append(t)
+            src.append(f[off: off + t.numel()].view(t.shape))
+            off += t.numel()
+    torch._foreach_copy_(dst, src)
+
+
+# RCCL path of allreduce_gradients: with more than DIRECT_MAX_TENSORS dense tensors, those below COALESCE_BELOW bytes share buckets
+DIRECT_MAX_TENSORS = 8
+COALESCE_BELOW = 16 << 20
+
+
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):
     """Sum (or average) a list of gradient tensors over the ranks.  The loss is a mean over rays (train_nerf.py:884-891), so with rays
     sharded evenly the data-parallel gradient is the average of the per-rank gradients.
     RCCL: every dense tensor (row-major or channels_last -- the plane gradients are channels_last views) is reduced IN PLACE by its own
     asynchronous all-reduce, all queued before the first wait: no flattening copy in, none out (round 2 concatenated the 23 MB of plane
-    gradients into a bucket and copied them back every step).  Other backends (gloo rehearsals) and non-dense tensors go through flat buckets of
+    gradients into a bucket and copied them back every step) -- up to DIRECT_MAX_TENSORS tensors; beyond that (an SR network in `what`) the
+    tensors below COALESCE_BELOW bytes go through allreduce_coalesced's buckets.  Other backends (gloo rehearsals) and non-dense tensors go through flat buckets of
     ~bucket_bytes, staged through the host when the backend needs it."""
     rank, world = world_info(group)
     if world == 1:
@@ -201,8 +240,13 @@ def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True
 
     # RCCL: one asynchronous collective per tensor, queued back to back on its stream (4 planes + 2 decoder blobs per step), then one wait
     direct = [t for t in tensors if t.is_cuda and _dense(t)] if dist.get_backend(group) == "nccl" else []
-    allreduce_in_place(direct, group, scale)
     ids = {id(t) for t in direct}
+    if len(direct) > DIRECT_MAX_TENSORS:       # many tensors (an SR network's 69 weight gradients): the small ones in buckets, the large ones in place
+        small = [t for t in direct if t.numel() * t.element_size() < COALESCE_BELOW]
+        small_ids = {id(t) for t in small}
+        direct = [t for t in direct if id(t) not in small_ids]
+        allreduce_coalesced(small, group, scale)
+    allreduce_in_place(direct, group, scale)
     bucket, size = [], 0
 
     def flush():

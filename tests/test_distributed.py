@@ -65,6 +65,17 @@ def _worker(rank, world, port, tmp):
         raise AssertionError("a strided tensor was accepted")
     except ValueError:
         pass
+    # the bucketed RCCL branch (allreduce_coalesced: an SR network's 69 small weight gradients share flat buckets) on this backend: several
+    # buckets, a channels_last member, values that tell a mis-sliced bucket from a correct one; layouts and storage kept
+    many = [torch.arange(n, dtype=torch.float32) * (rank + 1) + k for k, n in enumerate([300, 7, 1024, 513, 2, 4096, 33])]
+    many.insert(3, (base * (rank + 1)).contiguous(memory_format=torch.channels_last))
+    ptrs = [t.data_ptr() for t in many]
+    D.allreduce_coalesced(many, scale=0.5, bucket_bytes=4096)
+    for k, n in enumerate([300, 7, 1024, 513, 2, 4096, 33]):
+        assert torch.equal(many[k if k < 3 else k + 1], torch.arange(n, dtype=torch.float32) * 1.5 + k)
+    assert torch.equal(many[3], base * 1.5) and many[3].is_contiguous(memory_format=torch.channels_last)
+    assert [t.data_ptr() for t in many] == ptrs
+    D.allreduce_coalesced([])
     # gather_row_blocks into a caller's buffer: ragged split (3 + 4 rows) and the one-rank case
     mine = torch.full((3 + rank, 2), float(rank + 1))
     out = torch.empty(7, 2)

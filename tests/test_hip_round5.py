@@ -405,6 +405,14 @@ def test_rccl_backend_executes_the_collective_branch_on_one_rank():
         torch.cuda.synchronize()
         assert torch.equal(cl, base * 0.5) and torch.equal(rm, torch.arange(1000, dtype=torch.float32, device=dev) * 0.5)
         assert (cl.data_ptr(), rm.data_ptr()) == ptrs and cl.is_contiguous(memory_format=torch.channels_last)
+        # an SR network's many small weight gradients: flat buckets through RCCL (allreduce_coalesced), layouts and storage kept
+        many = [torch.arange(n, dtype=torch.float32, device=dev) + k for k, n in enumerate([300, 7, 1024, 513, 2, 4096, 33])] + [cl]
+        mptrs = [t.data_ptr() for t in many]
+        D.allreduce_coalesced(many, scale=2.0, bucket_bytes=4096)
+        torch.cuda.synchronize()
+        for k, n in enumerate([300, 7, 1024, 513, 2, 4096, 33]):
+            assert torch.equal(many[k], (torch.arange(n, dtype=torch.float32, device=dev) + k) * 2.0)
+        assert torch.equal(cl, base) and [t.data_ptr() for t in many] == mptrs and cl.is_contiguous(memory_format=torch.channels_last)
         out = torch.empty(6, 3, device=dev)
         t = torch.rand(6, 3, device=dev)
         dist.all_gather_into_tensor(out, t)                            # what gather_row_blocks issues on an even split
