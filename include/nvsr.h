@@ -402,7 +402,11 @@ int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* 
 int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
 int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream);
 int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W);
-/* d_out [Cout][Ho][Wo] -> grad_natural (state-dict order) += weight gradients, dx [Cin][H][W] (or NULL) = input gradient */
+/* d_out [Cout][Ho][Wo] -> grad_natural (state-dict order) += weight gradients, dx [Cin][H][W] (or NULL) = input gradient.
+ * Streams: the limb arithmetics run the per-layer reductions of the weight gradients' partial sums on a library-owned side stream (one per host
+ * thread and device) under the next layer's data-gradient launch; `stream` waits for that lane before the call returns (also on an error), so for
+ * the caller everything the call enqueued is ordered on `stream` as usual.  Inside a stream capture all work stays on `stream`.  The same holds
+ * for nvsr_planes_sr_backward and nvsr_planes_sr_backward_batch_arith. */
 int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
                        int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, nvsr_stream_t stream);
 /* PlanesSR: forward that keeps the prepared input + activation record, and its backward.  d_lr (or NULL: LR plane detached,

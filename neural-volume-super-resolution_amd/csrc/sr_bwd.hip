@@ -506,15 +506,35 @@ __global__ void wgrad_reduce_pieces_kernel(const float* __restrict__ partial, in
     const int ci = blockIdx.x * 64 + (threadIdx.x & 63), co = blockIdx.y * 4 + (threadIdx.x >> 6), t = blockIdx.z;
     if (ci >= Cin || co >= Cout) return;
     const long tile = (long)(co / WG_CO) * n_ci + ci / WG_CI, lo = tile * TS, hi = lo + TS;
-    long w = lo * n_wg / total;
-    while (w + 1 < n_wg && wgrad_piece_start(w + 1, total, n_wg) <= lo) ++w;
-    while (w > 0 && wgrad_piece_start(w, total, n_wg) > lo) --w;
+    // pieces [w0, w1) overlap the tile (uniform over the workgroup: 64 ci and 4 co of ONE tile).  w0 = the last piece that starts at or before
+    // lo: it alone may have started in the previous tile (its slot 1 belongs to this one); every later piece starts inside the tile (slot 0)
+    long w0 = lo * n_wg / total;
+    while (w0 + 1 < n_wg && wgrad_piece_start(w0 + 1, total, n_wg) <= lo) ++w0;
+    while (w0 > 0 && wgrad_piece_start(w0, total, n_wg) > lo) --w0;
+    long w1 = hi * n_wg / total;
+    if (w1 > n_wg) w1 = n_wg;
+    while (w1 < n_wg && wgrad_piece_start(w1, total, n_wg) < hi) ++w1;
+    while (w1 > w0 + 1 && wgrad_piece_start(w1 - 1, total, n_wg) >= hi) --w1;
+    constexpr long S = 9L * WG_CO * WG_CI;
     const long e = ((long)t * WG_CO + (co % WG_CO)) * WG_CI + (ci % WG_CI);
+    const float* __restrict__ src = partial + e;
     float sum = 0.0f;
-    for (; w < n_wg && wgrad_piece_start(w, total, n_wg) < hi; ++w) {
-        const int slot = wgrad_piece_start(w, total, n_wg) >= lo ? 0 : 1;       // the piece's first tile, or the one it crossed into
-        sum += partial[(w * 2 + slot) * (9L * WG_CO * WG_CI) + e];
+    if (wgrad_piece_start(w0, total, n_wg) < hi) sum = src[(w0 * 2 + (wgrad_piece_start(w0, total, n_wg) >= lo ? 0 : 1)) * S];
+    // the same fixed order as ever (piece after piece), eight loads in flight: a trunk layer's element is the sum of ~32 slots 147 KB apart, and
+    // one load per round trip (the loop used to recompute the piece boundaries -- two 64-bit divisions -- before every load) made the kernel a
+    // chain of memory latencies: 36 us for 75 MB
+    long w = w0 + 1;
+#ifndef WG_REDUCE_UNROLL
+#define WG_REDUCE_UNROLL 1     // 0: one load per round trip (A/B builds)
+#endif
+    for (; WG_REDUCE_UNROLL && w + 8 <= w1; w += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(w + k) * 2 * S];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
     }
+    for (; w < w1; ++w) sum += src[w * 2 * S];
     dw[((long)co * Cin + ci) * 9 + t] += scale * sum;
 }
 
