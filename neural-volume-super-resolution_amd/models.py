@@ -267,6 +267,13 @@ class TwoDimPlanesModel(nn.Module):
                 _PLANE_CACHE.pop(k, None)
                 _PLANE_CACHE.pop(k + "/SR", None)
 
+    def train(self, mode=True):
+        """nn.Module.train, and on a CHANGE of mode the derived copies are dropped: a training loop may have updated the parameters through
+        something that does not bump version counters (a fused optimizer outside TrainStep); the first forward of the other mode re-derives"""
+        if bool(mode) != self.training:
+            self.invalidate()
+        return super().train(mode)
+
     def skip_SR(self, skip):
         self.skip_SR_ = skip
 
@@ -748,6 +755,12 @@ class EDSR(nn.Module):
         """forget the packed weight blobs (needed after writes through `.data`, which do not bump a tensor's version counter)"""
         self._packed_cache = None
         self._packed_dgrad_cache = None
+
+    def train(self, mode=True):
+        """nn.Module.train; a CHANGE of mode drops the packed blobs (see TwoDimPlanesModel.train)"""
+        if bool(mode) != self.training:
+            self.invalidate()
+        return super().train(mode)
 
     def arith(self):
         return capi.arith_code(self.arithmetic)

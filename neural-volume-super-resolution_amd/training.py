@@ -404,16 +404,51 @@ class TrainStep:
         if self.grad_sync is not None:
             self.grad_sync()
         if self.planes_optimizer is not None:
-            self.planes_optimizer.step()
+            self._step(self.planes_optimizer)
         if last_v:
             if self.optimizer is not None:
                 decoder_step = "decoder" not in confinements
                 if "SR" in self.what and self.separate_decoder_sr:
                     decoder_step &= not sr_iter
                 if decoder_step:
-                    self.optimizer.step()
+                    self._step(self.optimizer)
             if self.SR_optimizer is not None and sr_iter and "SR" not in confinements:
-                self.SR_optimizer.step()
+                self._step(self.SR_optimizer)
+
+    def _step(self, opt):
+        """opt.step(), and the version counters of what it updated.  Every derived copy of the parameters -- packed decoder blobs, EDSR fragment
+        blobs, channel-last copies of NCHW planes, the f16 range cache -- is keyed on (data_ptr, tensor._version).  torch's FUSED optimizers
+        (`Adam(fused=True)`: one multi-tensor kernel writing the parameters) do not bump the counters: the next forward would be served the blobs
+        packed from the parameters as they were before the step, and training would run on frozen weights (found in round 5: the refine bench packed
+        its EDSR weights once per process).  Parameters whose counter stood still across the step are bumped here; an optimizer object that cannot
+        list its parameters (PlanesOptimizer wrappers) makes the models forget their copies instead."""
+        if not isinstance(opt, torch.optim.Optimizer):
+            opt.step()
+            for m in (self.mc, self.mf, self.SR_model):
+                if m is not None and hasattr(m, "invalidate"):
+                    m.invalidate()
+            return
+        params = [p for grp in opt.param_groups for p in grp["params"] if p.grad is not None]
+        before = [p._version for p in params]
+        opt.step()
+        stale = [p for p, v in zip(params, before) if p._version == v]
+        if stale:
+            mark_updated(stale)
+
+
+def mark_updated(params):
+    """Tell the models that `params` were written in place by something that does not bump tensor version counters (a fused optimizer stepped
+    outside TrainStep, a custom kernel): bumps the counters, so every derived copy keyed on them is rebuilt at its next use.  (Writes through
+    `.data` replace storage or bypass autograd altogether: call the models' invalidate() for those.)"""
+    params = [p for p in params if p is not None]
+    if not params:
+        return
+    try:
+        torch._C._increment_version(params)
+    except (AttributeError, TypeError):          # (a torch without the list form)
+        with torch.no_grad():
+            for p in params:
+                p.add_(0)
 
 
 class GraphedTrainStep:

@@ -500,3 +500,53 @@ def test_network_pack_is_the_layer_by_layer_pack(hip, geometry, dgrad):
         o_pk += n_pk
     assert o_nat == nat.numel() and o_pk == got.numel()
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fused optimizers do not bump tensor version counters: the derived copies of the parameters must follow the step all the same
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False])
+def test_derived_copies_follow_a_fused_optimizer_step(hip, fused):
+    """A joint SR-refinement iteration (what = LR_planes + decoder + SR) stepped by Adam(fused=True) -- the optimizers of bench.py -- and by plain
+    Adam: after the iteration every derived copy the NEXT forward would use is the copy of the CURRENT parameters: the EDSR fragment blobs
+    (forward and data gradient), the packed decoder blobs of both models.  (torch's fused Adam leaves `_version` alone: before round 5's
+    TrainStep._step the blobs of the next iteration were the ones packed before the step.)"""
+    from conftest import load_golden
+    from test_hip_parity import T, _grad_models, _gt_and_student, make_options
+    g = load_golden("g11_grads.npz")
+    sid = "lego_DS8_PlRes20_8"
+    H = W = 20
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    pose = T(load_golden("g08_render.npz")["pose"])
+    opts, scfg = make_options(24, 24)
+    _, noisy = _gt_and_student(hip, g, sid, seed=84)
+    mc, mf = _grad_models(hip, g, noisy, sid, what=("planes", "decoder"))
+    torch.manual_seed(8)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 16, "n_blocks": 2}}, "bilinear").to(DEV)
+    with torch.no_grad():
+        for p_ in sr.parameters():
+            p_.mul_(10.0)
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+    dec = [p_ for m in (mc, mf) for p_ in m.decoder_parameters()]
+    kw = {"fused": True} if fused else {}
+    step = hip.training.TrainStep(mc, mf, opts, {"SR", "LR_planes", "decoder"}, optimizer=torch.optim.Adam(dec, lr=1e-3, **kw),
+                                  SR_optimizer=torch.optim.Adam(sr.parameters(), lr=1e-3, **kw), SR_model=sr, sr_loss="fine",
+                                  planes_optimizer=torch.optim.Adam(list(mc.planes_.values()), lr=1e-3, **kw),
+                                  pixel_sampler=hip.training.DevicePixelSampler(seed=9))
+    net = sr.inner_model
+    torch.manual_seed(12)
+    step(0, img, pose, H, W, focal, 1, sid, scfg, 150, sr_iter=True)
+    used = (net.packed_weights().clone(), net.packed_dgrad_weights().clone(), mc.packed_decoder().clone(), mf.packed_decoder().clone())
+    torch.manual_seed(13)
+    step(1, img, pose, H, W, focal, 1, sid, scfg, 150, sr_iter=True)
+    torch.cuda.synchronize()
+    fresh = lambda dgrad: torch.ops.nvsr.pack_edsr(net.natural_blob(), list(net.geometry), dgrad)
+    now = (net.packed_weights(), net.packed_dgrad_weights(), mc.packed_decoder(), mf.packed_decoder())
+    assert torch.equal(now[0].view(torch.int32), fresh(False).view(torch.int32)) and torch.equal(now[1].view(torch.int32), fresh(True).view(torch.int32))
+    for m, blob in ((mc, now[2]), (mf, now[3])):
+        m._packed_cache = None
+        assert torch.equal(blob.view(torch.int32), m.packed_decoder().view(torch.int32))
+    for a, b in zip(used, now):                      # ... and the step did move every one of them
+        assert not torch.equal(a.view(torch.int32), b.view(torch.int32))

@@ -564,3 +564,51 @@ def test_bench_edsr_flop_count_matches_the_survey():
     assert abs(bench.edsr_flops(336, 336) / 1e12 - 6.74) < 0.01
     assert bench.sr_roi_pixels(200, [-1.0, -1.0, 1.0, 1.0]) == [(0, 200), (0, 200)]
     assert bench.sr_roi_pixels(200, [-0.5, 0.0, 0.25, 0.991]) == [(49, 126), (99, 200)]
+
+
+def test_fused_optimizer_steps_bump_the_version_counters():
+    """Every derived copy of the parameters (packed decoder / EDSR blobs, channel-last plane copies, the f16 range cache) is keyed on
+    (data_ptr, tensor._version); torch's fused optimizers write the parameters WITHOUT bumping the counters (checked here: if torch ever changes
+    that, the first assertion says so), so TrainStep.apply_gradients bumps what stood still -- exactly once per step, and the ordinary optimizers'
+    own bump is left alone."""
+    import nvsr_amd
+    T = nvsr_amd.training
+    for kw, bumps_itself in (({"fused": True}, False), ({}, True), ({"foreach": True}, True)):
+        p = torch.nn.Parameter(torch.randn(5, 3))
+        try:
+            opt = torch.optim.Adam([p], lr=1e-2, **kw)
+        except (RuntimeError, TypeError):
+            continue                                   # (a torch whose CPU build has no fused Adam)
+        v0 = p._version
+        p.grad = torch.ones_like(p)
+        opt.step()
+        assert (p._version > v0) == bumps_itself, (kw, "torch's own behaviour changed")
+        q = torch.nn.Parameter(torch.randn(5, 3))
+        frozen = torch.nn.Parameter(torch.randn(2))   # (in the optimizer, no gradient this iteration: not updated, not bumped)
+        step = T.TrainStep(None, None, None, {"LR_planes"}, planes_optimizer=torch.optim.Adam([q, frozen], lr=1e-2, **kw))
+        before, v, vf = q.detach().clone(), q._version, frozen._version
+        step.apply_gradients((q ** 2).sum())
+        assert not torch.equal(q.detach(), before) and q._version == v + 1 and frozen._version == vf
+    # the helper for loops that step a fused optimizer themselves
+    r = torch.nn.Parameter(torch.zeros(3))
+    v = r._version
+    T.mark_updated([r, None])
+    assert r._version == v + 1
+
+
+def test_a_change_of_mode_drops_the_derived_copies():
+    """train() <-> eval() on the plane model and on EDSR forgets the packed blobs (a loop with a fused optimizer outside TrainStep leaves them
+    stale; the first forward of the other mode re-derives); the same mode again keeps them"""
+    import nvsr_amd
+    M = nvsr_amd.models
+    net = M.EDSR(4, 4, 8, 1, 2, padding=0)
+    net._packed_cache = net._packed_dgrad_cache = ("key", "blob")
+    net.train(True)
+    assert net._packed_cache == ("key", "blob")
+    net.eval()
+    assert net._packed_cache is None and net._packed_dgrad_cache is None
+    net._packed_cache = ("key", "blob")
+    net.eval()
+    assert net._packed_cache == ("key", "blob")
+    net.train()
+    assert net._packed_cache is None
