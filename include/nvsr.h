@@ -289,6 +289,13 @@ int nvsr_conv3x3(const float* in, int Cin, int H, int W, const float* packed, in
 int64_t nvsr_edsr_natural_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
 int64_t nvsr_edsr_packed_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
 int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream);
+/* The same blob with only the fragment regions that a launch in `arithmetic` reads (NVSR_ARITH_INHERIT = the process default) -- for callers whose
+ * weights change between launches: a training iteration (train_nerf.py:903-914: optimizer steps between forwards) re-packs both blobs of the network
+ * every iteration, and of the four regions of a layer (f32 fragments, bf16 limbs for two MFMA shapes, f16 limbs) an arithmetic reads one.  The other
+ * regions keep whatever `packed` held: such a blob serves launches in THAT arithmetic only (the *_arith entry points with the same value).
+ * NVSR_PACK_ALL_ARITHMETICS = every region (what nvsr_pack_edsr does). */
+#define NVSR_PACK_ALL_ARITHMETICS (-3)
+int nvsr_pack_edsr_arith(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, int arithmetic, nvsr_stream_t stream);
 int nvsr_edsr_out_size(int H, int W, int nblocks, int n_up, int* Ho, int* Wo);
 int64_t nvsr_edsr_workspace_floats(int hid, int nblocks, int n_up, int H, int W);
 int nvsr_edsr_forward(const float* x, int Cin, int H, int W, const float* packed, int Cout, int hid, int nblocks, int n_up, float* out,
@@ -401,12 +408,14 @@ int nvsr_edsr_forward_train(const float* x, int Cin, int H, int W, const float* 
                             float* acts, nvsr_stream_t stream);
 int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, int n_up);
 int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream);
+int nvsr_pack_edsr_dgrad_arith(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, int arithmetic,
+                               nvsr_stream_t stream);      /* (see nvsr_pack_edsr_arith) */
 int64_t nvsr_edsr_backward_workspace_floats(int Cin, int Cout, int hid, int nblocks, int n_up, int H, int W);
 /* d_out [Cout][Ho][Wo] -> grad_natural (state-dict order) += weight gradients, dx [Cin][H][W] (or NULL) = input gradient.
- * Streams: the limb arithmetics run the per-layer reductions of the weight gradients' partial sums on a library-owned side stream (one per host
- * thread and device) under the next layer's data-gradient launch; `stream` waits for that lane before the call returns (also on an error), so for
- * the caller everything the call enqueued is ordered on `stream` as usual.  Inside a stream capture all work stays on `stream`.  The same holds
- * for nvsr_planes_sr_backward and nvsr_planes_sr_backward_batch_arith. */
+ * Streams: everything the call enqueues is ordered on `stream`, and the library creates no stream of its own.  (A build with -DWG_REDUCE_LANE=1
+ * runs the per-layer reductions of the weight gradients' partial sums on a library-owned side stream that `stream` waits for before the call
+ * returns; measured and switched off: one more hardware queue in a process that already uses four costs more than the overlap gains, sr_bwd.hip.)
+ * The same holds for nvsr_planes_sr_backward and nvsr_planes_sr_backward_batch_arith. */
 int nvsr_edsr_backward(const float* x, int Cin, int H, int W, const float* acts, const float* packed_dgrad, int Cout, int hid, int nblocks,
                        int n_up, const float* d_out, float* grad_natural, float* dx, float* workspace, nvsr_stream_t stream);
 /* PlanesSR: forward that keeps the prepared input + activation record, and its backward.  d_lr (or NULL: LR plane detached,

@@ -92,6 +92,7 @@ _PROTOS = {
     "nvsr_render_rays": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp], _i),
 }
+PACK_ALL_ARITHMETICS = -3      # include/nvsr.h NVSR_PACK_ALL_ARITHMETICS
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
@@ -101,6 +102,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_edsr_natural_floats": ([_i, _i, _i, _i, _i], _i64),
     "nvsr_edsr_packed_floats": ([_i, _i, _i, _i, _i], _i64),
     "nvsr_pack_edsr": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "nvsr_pack_edsr_arith": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "nvsr_edsr_out_size": ([_i, _i, _i, _i, _ip, _ip], _i),
     "nvsr_edsr_workspace_floats": ([_i, _i, _i, _i, _i], _i64),
     "nvsr_edsr_forward": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
@@ -130,6 +132,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_edsr_forward_train": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "nvsr_edsr_packed_dgrad_floats": ([_i, _i, _i, _i, _i], _i64),
     "nvsr_pack_edsr_dgrad": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "nvsr_pack_edsr_dgrad_arith": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "nvsr_edsr_backward_workspace_floats": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "nvsr_edsr_backward": ([_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_planes_sr_keep_floats": ([_i, _i, _i, _i, _i, _i, _i, _fp], _i64),

@@ -896,7 +896,9 @@ __global__ __launch_bounds__(256) void pack_table_kernel(PackTable t) {
     }
 }
 // natural: the layers' [Cout][Cin][3][3] weights one after the other; packed: their fragment blobs one after the other (conv_packed_floats each)
-int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream) {
+int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream, int arith) {
+    // arith: NVSR_PACK_ALL_ARITHMETICS = every fragment region of every layer; an arithmetic = only the region launch_conv reads for it
+    // (conv_kinds_for, sr_core.h): the others keep whatever the blob held
     for (int l0 = 0; l0 < nl; l0 += PACK_TABLE_LAYERS) {
         PackTable t{};
         t.transposed = transposed;
@@ -912,7 +914,11 @@ int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* pa
             L.n[2] = conv_packed_limb16_words(ci, co);
             L.n[3] = conv_packed_f16_words(ci, co);
             L.off[0] = 0; L.off[1] = L.n[0]; L.off[2] = L.n[0] + L.n[1]; L.off[3] = L.n[0] + L.n[1] + L.n[2];
-            for (int q = 0; q < 4; ++q) mx[q] = L.n[q] > mx[q] ? L.n[q] : mx[q];
+            const unsigned kinds = conv_kinds_for(ci, co, arith, CV_USE_16X16X32 != 0, CV_WIDE_ROWS8 != 0);
+            for (int q = 0; q < 4; ++q) {
+                if (!(kinds >> q & 1u)) L.n[q] = 0;          // (a region this arithmetic never reads)
+                mx[q] = L.n[q] > mx[q] ? L.n[q] : mx[q];
+            }
             natural += 9LL * c.Cin * c.Cout;
             packed += conv_packed_floats(ci, co);
         }
@@ -1347,13 +1353,20 @@ int64_t nvsr_edsr_packed_floats(int Cin, int Cout, int hid, int nblocks, int n_u
     for (int i = 0; i < n; ++i) s += conv_packed_floats(L[i].Cin, L[i].Cout);
     return s;
 }
-int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream) {
+int nvsr_pack_edsr_arith(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, int arithmetic, nvsr_stream_t stream) {
     if (!natural || !packed) return NVSR_ERR_NULL;
     if (nvsr_edsr_packed_floats(Cin, Cout, hid, nblocks, n_up) < 0) return NVSR_ERR_SHAPE;
     if (!aligned16(packed)) return NVSR_ERR_ALIGN;
+    if (arithmetic != NVSR_PACK_ALL_ARITHMETICS) {
+        arithmetic = conv_resolve_arith(arithmetic);
+        if (arithmetic != NVSR_ARITH_F32 && arithmetic != NVSR_ARITH_F16X2 && arithmetic != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    }
     ConvLayer L[600]; int n;
     edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
-    return pack_layers(natural, L, n, packed, 0, (hipStream_t)stream);       // (4 launches per 36 layers instead of 4 per layer)
+    return pack_layers(natural, L, n, packed, 0, (hipStream_t)stream, arithmetic);       // (4 launches per 36 layers instead of 4 per layer)
+}
+int nvsr_pack_edsr(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed, nvsr_stream_t stream) {
+    return nvsr_pack_edsr_arith(natural, Cin, Cout, hid, nblocks, n_up, packed, NVSR_PACK_ALL_ARITHMETICS, stream);
 }
 
 /* spatial size of the EDSR output for an [*, H, W] input */

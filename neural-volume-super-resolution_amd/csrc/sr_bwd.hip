@@ -730,8 +730,15 @@ struct ReducePass {
     }
     ~ReducePass() { join(); }
 };
+// OFF in the product (round 5, second measurement): alone in a process the lane buys 0.3 ms of an 87 ms refine iteration -- but it is one more
+// hardware queue.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues; a training process already holds the
+// default stream, the backward's side stream, the high-priority prologue stream and whatever captured a graph, and with the lane as the fifth two
+// streams share a queue: their event waits become full barriers of that queue, and EVERY phase of the iteration slows down (same box, the refine
+// workload after the other workloads of bench.py's default line: 100.8 ms with the lane, 87.8 ms without, 87.6 ms with the lane and
+// GPU_MAX_HW_QUEUES=8; stand-alone process: 87.1 ms with it; profiles/r05_hw_queue_oversubscription.txt).  A library must not spend a hardware queue
+// for 0.4 %: -DWG_REDUCE_LANE=1 builds the lane for experiments.
 #ifndef WG_REDUCE_LANE
-#define WG_REDUCE_LANE 1     // 0: the reductions on the caller's stream (A/B builds)
+#define WG_REDUCE_LANE 0     // 0: the reductions on the caller's stream; 1: on the lane (A/B builds)
 #endif
 // opens the lane for a pass on `stream` with two buffers of `stride` floats at `partial`; leaves it closed (in-stream reductions) inside a capture
 static void reduce_pass_begin(ReducePass& rp, float* partial, int64_t stride, hipStream_t stream) {
@@ -876,13 +883,21 @@ int64_t nvsr_edsr_packed_dgrad_floats(int Cin, int Cout, int hid, int nblocks, i
     for (int i = 0; i < n; ++i) s += conv_packed_floats(L[i].Cout, L[i].Cin);
     return s;
 }
-int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream) {
+int nvsr_pack_edsr_dgrad_arith(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, int arithmetic,
+                               nvsr_stream_t stream) {
     if (!natural || !packed_dgrad) return NVSR_ERR_NULL;
     if (!edsr_geometry_ok(nblocks, n_up)) return NVSR_ERR_SHAPE;
     if (!aligned16(packed_dgrad)) return NVSR_ERR_ALIGN;
+    if (arithmetic != NVSR_PACK_ALL_ARITHMETICS) {
+        arithmetic = conv_resolve_arith(arithmetic);
+        if (arithmetic != NVSR_ARITH_F32 && arithmetic != NVSR_ARITH_F16X2 && arithmetic != NVSR_ARITH_BF16X3) return NVSR_ERR_SHAPE;
+    }
     ConvLayer L[EDSR_MAX_LAYERS]; int n;
     edsr_layers(Cin, Cout, hid, nblocks, n_up, L, &n);
-    return pack_layers(natural, L, n, packed_dgrad, 1, (hipStream_t)stream);
+    return pack_layers(natural, L, n, packed_dgrad, 1, (hipStream_t)stream, arithmetic);
+}
+int nvsr_pack_edsr_dgrad(const float* natural, int Cin, int Cout, int hid, int nblocks, int n_up, float* packed_dgrad, nvsr_stream_t stream) {
+    return nvsr_pack_edsr_dgrad_arith(natural, Cin, Cout, hid, nblocks, n_up, packed_dgrad, NVSR_PACK_ALL_ARITHMETICS, stream);
 }
 
 /* 3 gradient tensors + 1 un-shuffled gradient + the weight-gradient partial sums */

@@ -98,6 +98,22 @@ inline int64_t conv_packed_f16_words(int Cin, int Cout) {
 inline int64_t conv_packed_floats(int Cin, int Cout) {
     return conv_packed_f32_floats(Cin, Cout) + conv_packed_limb_words(Cin, Cout) + conv_packed_limb16_words(Cin, Cout) + conv_packed_f16_words(Cin, Cout);
 }
+// Fragment kinds of a packed layer (bit k = region k of the blob: 0 f32, 1 bf16 limbs 32x32x16, 2 bf16 limbs 16x16x32, 3 f16 limbs 16x16x32) that
+// launch_conv (sr.hip) READS for a launch in `arith` with the library's own choice of rows per tile (rows_per_tile 0: what every EDSR / PlanesSR entry
+// point passes) -- the same predicates in the same order as the launcher's branches.  A training iteration re-packs both blobs of the network (the
+// weights change every iteration): packing only these regions writes a fifth of the bytes (nvsr_pack_edsr_arith).  arith == NVSR_PACK_ALL_ARITHMETICS: every region.
+constexpr unsigned CONV_KINDS_ALL = 15u;
+inline unsigned conv_kinds_for(int Cin, int Cout, int arith, bool use_16x16x32, bool wide_rows8) {
+    if (arith == NVSR_PACK_ALL_ARITHMETICS) return CONV_KINDS_ALL;
+    if (arith == NVSR_ARITH_F32) return 1u;
+    const bool wl = conv_limb_eligible(Cin, Cout), w16 = conv_limb16_eligible(Cin, Cout);
+    const int ncb = conv_ncb(Cout);
+    if (wl && ncb == 2) return 2u;                                              // narrow layer: conv3x3_limb_kernel<2, 1>
+    if (w16 && use_16x16x32) return arith == NVSR_ARITH_F16X2 ? 8u : 4u;        // conv3x3_limb16_kernel
+    (void)wide_rows8;                                                           // (the 8-row wide kernel reads region 1 like the 2..4-row one)
+    if (wl) return 2u;                                                          // conv3x3_limb_kernel
+    return 1u;                                                                  // no limb kernel eligible: exact-f32 kernels
+}
 
 // conv_input, (conv1, conv2) x nblocks, conv_mid, n_up x up-conv, conv_output  (state-dict order, models.py:802-816)
 inline void edsr_layers(int Cin, int Cout, int hid, int nblocks, int n_up, ConvLayer* L, int* n) {
@@ -195,7 +211,7 @@ int launch_conv(const float* in, int Cin, int H, int W, const float* wpk, int Co
                 hipStream_t stream, int pad = 0, int batch = 1, ConvExec cx = ConvExec{}, const ConvRagged* rag = nullptr);
 // fragment blobs of nl consecutive layers (natural: their [Cout][Cin][3][3] weights one after the other) in 4 launches per 36 layers; transposed: the
 // data gradients' fragments (nvsr_pack_conv3x3_dgrad per layer).  sr.hip
-int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream);
+int pack_layers(const float* natural, const ConvLayer* layers, int nl, float* packed, int transposed, hipStream_t stream, int arith = NVSR_PACK_ALL_ARITHMETICS);
 // max |x| over up to CONV_RAGGED_MAX tensors in one launch, into the caller's word
 const unsigned* launch_absmax_ragged(int n, const float* const* x, const long* count, hipStream_t stream, unsigned* owned);
 

@@ -780,27 +780,34 @@ class EDSR(nn.Module):
         gradient of the 3 x 3 blob reaches the 1 x 1 parameter through its centre tap"""
         return [w if w.shape[-1] == 3 else torch.nn.functional.pad(w, (1, 1, 1, 1)) for w in self.conv_parameters()]
 
-    def packed_weights(self):
+    def packed_weights(self, arithmetic=None):
+        """the fragment blob of the forward convolutions, cached on the parameters' (data_ptr, version).  arithmetic: None = every fragment region
+        (a blob any arithmetic can run: evaluation, whose range fallback re-renders in bf16x3); an NVSR_ARITH_* code = only the regions that
+        arithmetic reads (training: the weights change every iteration and both blobs are re-packed -- a fifth of the bytes); a cached blob with
+        every region serves any request"""
         key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
-        if self._packed_cache is None or self._packed_cache[0] != key:
+        kinds = capi.PACK_ALL_ARITHMETICS if arithmetic is None else int(arithmetic)
+        c = self._packed_cache
+        if c is None or c[0] != key or c[2] not in (kinds, capi.PACK_ALL_ARITHMETICS):
             ws = self.conv_weights()
             nat = torch.cat([w.detach().reshape(-1).float() for w in ws])
             capi.require_cuda(nat)
-            self._packed_cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), False))
-        return self._packed_cache[1]
+            c = self._packed_cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), False, kinds), kinds)
+        return c[1]
 
     def natural_blob(self, differentiable=False):
         """conv weights flattened in state-dict order (the layout nvsr_pack_edsr consumes and nvsr_edsr_backward fills)"""
         return torch.cat([(w if differentiable else w.detach()).reshape(-1).float() for w in self.conv_weights()])
 
-    def packed_dgrad_weights(self):
+    def packed_dgrad_weights(self, arithmetic=None):
         """fragments of every layer's data gradient (flipped, transposed kernels), cached like packed_weights()"""
         key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
+        kinds = capi.PACK_ALL_ARITHMETICS if arithmetic is None else int(arithmetic)
         cache = getattr(self, "_packed_dgrad_cache", None)
-        if cache is None or cache[0] != key:
+        if cache is None or cache[0] != key or cache[2] not in (kinds, capi.PACK_ALL_ARITHMETICS):
             nat = self.natural_blob()
             capi.require_cuda(nat)
-            cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), True))
+            cache = (key, torch.ops.nvsr.pack_edsr(nat, list(self.geometry), True, kinds), kinds)
             self._packed_dgrad_cache = cache
         return cache[1]
 
@@ -817,8 +824,9 @@ class EDSR(nn.Module):
             x4 = torch.nn.functional.pad(x4, (self._extra_pad,) * 4)
         if self.wants_grad(x):
             # gradients for the conv weights (through the flat state-dict-order blob) and the input: torch.ops.nvsr.edsr_train
-            out, _ = torch.ops.nvsr.edsr_train(x4, self.natural_blob(differentiable=True), self.packed_weights(), self.packed_dgrad_weights(),
-                                               list(self.geometry), capi.resolve_conv_arithmetic(self.arithmetic))
+            arith = capi.resolve_conv_arithmetic(self.arithmetic)
+            out, _ = torch.ops.nvsr.edsr_train(x4, self.natural_blob(differentiable=True), self.packed_weights(arith), self.packed_dgrad_weights(arith),
+                                               list(self.geometry), arith)
         else:
             out = torch.ops.nvsr.edsr(x4, self.packed_weights(), list(self.geometry), self.arith())
         if self._extra_crop:
@@ -956,8 +964,9 @@ class PlanesSR(nn.Module):
         mean = std = None
         if hasattr(self, "planes_mean_NON_LEARNED"):
             mean, std = capi.f32c(self.planes_mean_NON_LEARNED.detach().reshape(-1)), capi.f32c(self.planes_std_NON_LEARNED.detach().reshape(-1))
-        cfg = dict(packed=net.packed_weights(), packed_dgrad=net.packed_dgrad_weights(), geometry=list(net.geometry), pad=self._kernel_pad,
-                   over=self._kernel_over, rois=rois, mean=mean, std=std, arithmetic=capi.resolve_conv_arithmetic(net.arithmetic),
+        arith = capi.resolve_conv_arithmetic(net.arithmetic)
+        cfg = dict(packed=net.packed_weights(arith), packed_dgrad=net.packed_dgrad_weights(arith), geometry=list(net.geometry), pad=self._kernel_pad,
+                   over=self._kernel_over, rois=rois, mean=mean, std=std, arithmetic=arith,
                    align_corners=bool(self.align_corners), bicubic=self.plane_interp == "bicubic")
         return list(ops.PlanesSRBatchFn.apply(cfg, net.natural_blob(differentiable=True), *lrs))
 
@@ -995,9 +1004,10 @@ class PlanesSR(nn.Module):
         if differentiable:
             # training: gradients for the EDSR weights and the (non-detached) LR plane; the result is never cached
             net = self.inner_model
+            arith = capi.resolve_conv_arithmetic(net.arithmetic)
             out, _ = torch.ops.nvsr.planes_sr_train(lr_src if lr_src.dtype == torch.float32 else lr_src.float(), net.natural_blob(differentiable=True),
-                                                    net.packed_weights(), net.packed_dgrad_weights(), geometry, pad, over, roi, mean, std,
-                                                    capi.resolve_conv_arithmetic(net.arithmetic), bool(self.align_corners), self.plane_interp == "bicubic")
+                                                    net.packed_weights(arith), net.packed_dgrad_weights(arith), geometry, pad, over, roi, mean, std,
+                                                    arith, bool(self.align_corners), self.plane_interp == "bicubic")
             return self._apply_training_noise(out, noise_in, lr_clean) if noisy else out
         out = torch.ops.nvsr.planes_sr([lr.reshape(Cc, R0, R1)], self.inner_model.packed_weights(), geometry, pad, over, roi, mean, std,
                                        self.inner_model.arith(), bool(self.align_corners), self.plane_interp == "bicubic")[0]

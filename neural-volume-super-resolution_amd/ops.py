@@ -24,6 +24,8 @@ from torch.library import custom_op
 
 from . import capi
 
+PACK_ALL_ARITHMETICS = capi.PACK_ALL_ARITHMETICS
+
 PC = capi.PLANE_CHANNELS
 # decoder-gradient record: up to this many points of a pass (19 GB of record) the forward itself records the layer inputs and the backward
 # never recomputes; beyond, the chunked recomputing path runs RECORD_RAYS rays at a time (train_utils re-exports both)
@@ -612,20 +614,23 @@ def _edsr_out_size(H, W, nb, n_up):
 
 
 @custom_op("nvsr::pack_edsr", mutates_args=(), device_types="cuda")
-def pack_edsr(natural: Tensor, geometry: Sequence[int], dgrad: bool) -> Tensor:
-    """conv weights in state-dict order -> MFMA-fragment blob (dgrad: of the flipped, transposed kernels of the data gradient)"""
+def pack_edsr(natural: Tensor, geometry: Sequence[int], dgrad: bool, arithmetic: int = PACK_ALL_ARITHMETICS) -> Tensor:
+    """conv weights in state-dict order -> MFMA-fragment blob (dgrad: of the flipped, transposed kernels of the data gradient).
+    arithmetic: PACK_ALL_ARITHMETICS = every fragment region; an NVSR_ARITH_* code = only the regions a launch in that arithmetic reads
+    (nvsr_pack_edsr_arith: a fifth of the bytes, for weights that change every iteration); the other regions are uninitialised memory, so the
+    blob serves launches in THAT arithmetic only (EDSR.packed_weights keys its cache on it)"""
     nat = capi.f32c(natural)
     lib = capi.lib()
     assert nat.numel() == lib.nvsr_edsr_natural_floats(*geometry)
     n = (lib.nvsr_edsr_packed_dgrad_floats if dgrad else lib.nvsr_edsr_packed_floats)(*geometry)
     assert n > 0
     packed = _f(n, like=nat)
-    capi.call("nvsr_pack_edsr_dgrad" if dgrad else "nvsr_pack_edsr", capi.ptr(nat), *geometry, capi.ptr(packed), capi.stream())
+    capi.call("nvsr_pack_edsr_dgrad_arith" if dgrad else "nvsr_pack_edsr_arith", capi.ptr(nat), *geometry, capi.ptr(packed), int(arithmetic), capi.stream())
     return packed
 
 
 @pack_edsr.register_fake
-def _(natural, geometry, dgrad):
+def _(natural, geometry, dgrad, arithmetic=PACK_ALL_ARITHMETICS):
     lib = capi.lib()
     return natural.new_empty(((lib.nvsr_edsr_packed_dgrad_floats if dgrad else lib.nvsr_edsr_packed_floats)(*[int(g) for g in geometry]),))
 

@@ -503,6 +503,58 @@ def test_network_pack_is_the_layer_by_layer_pack(hip, geometry, dgrad):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+# nvsr_pack_edsr_arith: a blob with only the fragment regions ONE arithmetic reads (what a training iteration re-packs)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hid,nb", [(16, 2), (64, 1), (128, 1), (256, 1)])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f32"])
+def test_arithmetic_packed_blob_runs_its_arithmetic(hip, hid, nb, mode):
+    """nvsr_pack_edsr_arith / nvsr_pack_edsr_dgrad_arith into NaN-filled buffers: every word they write is the word nvsr_pack_edsr writes, they
+    write fewer words than it, and the EDSR training forward + backward (models.py:769-822 under autograd; edsr_train / edsr_backward) in THAT
+    arithmetic give bit for bit the outputs, input gradient and weight gradients of the full blobs without a single NaN -- i.e. launch_conv reads
+    no region that conv_kinds_for (sr_core.h) left out, for the narrow (16, 64), the 128- and the 256-channel layer families."""
+    capi, nv = hip.capi, torch.ops.nvsr
+    lib = capi.lib()
+    torch.manual_seed(hid + nb)
+    net = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": hid, "n_blocks": nb}}, "bilinear").to(DEV).inner_model
+    geom = list(net.geometry)
+    code = capi.ARITHMETIC[mode]
+    nat = net.natural_blob()
+    blobs = {}
+    for dgrad in (False, True):
+        full = nv.pack_edsr(nat, geom, dgrad)
+        part = torch.full_like(full, float("nan"))
+        fill = part.view(torch.int32)[0].item()
+        capi.call("nvsr_pack_edsr_dgrad_arith" if dgrad else "nvsr_pack_edsr_arith", capi.ptr(nat), *geom, capi.ptr(part), code, capi.stream())
+        pi, fi = part.view(torch.int32), full.view(torch.int32)
+        written = pi != fill
+        assert torch.equal(pi[written], fi[written])
+        n_written = int(written.sum())
+        assert 0 < n_written < 0.75 * full.numel(), (n_written, full.numel())
+        blobs[dgrad] = (full, part)
+        # the operator's own path (uninitialised remainder) writes the same words
+        op = nv.pack_edsr(nat, geom, dgrad, code).view(torch.int32)
+        assert torch.equal(op[written], fi[written])
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((1, 48, 4 * nb + 14, 4 * nb + 17), device=DEV, generator=g)
+    res = []
+    for which in (0, 1):
+        out, acts = nv.edsr_train(x, nat, blobs[False][which], blobs[True][which], geom, code)
+        gy = torch.randn(out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+        gnat, dx = nv.edsr_backward(x, acts, blobs[True][which], geom, gy, True, code)
+        res.append((out, gnat, dx))
+    for a, b in zip(res[0], res[1]):
+        assert bool(torch.isfinite(b).all())
+        assert torch.equal(a, b)
+    # the model's cache: a blob of one arithmetic is not served to another arithmetic or to a caller that asks for every region
+    net.invalidate()
+    p_a = net.packed_weights(code)
+    assert net.packed_weights(code) is p_a
+    p_all = net.packed_weights()
+    assert p_all is not p_a and torch.equal(p_all.view(torch.int32), blobs[False][0].view(torch.int32))
+    assert net.packed_weights(code) is p_all                  # (a blob with every region serves any arithmetic)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
 # fused optimizers do not bump tensor version counters: the derived copies of the parameters must follow the step all the same
 # ---------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fused", [True, False])
