@@ -195,6 +195,13 @@ int nvsr_sample_pixels_seq(int64_t total, int H, int W, uint64_t* state, int64_t
  * (one workgroup sums them; a training batch is 3 x 4096). */
 #define NVSR_MSE_PAIR_MAX_ELEMS (1 << 22)
 int nvsr_mse_pair(int64_t n, const float* a, const float* b, const float* target, float* losses, float* g_a, float* g_b, nvsr_stream_t stream);
+/* the same two losses and their sum, losses3 = {mean((a - t)^2), mean((b - t)^2), their f32 sum} (train_nerf.py:905: loss = coarse_loss +
+ * fine_loss) -- the three scalars an iteration reports, contiguous for one copy to the host; no gradients (nvsr_mse_pair_backward) */
+int nvsr_mse_pair_sum(int64_t n, const float* a, const float* b, const float* target, float* losses3, nvsr_stream_t stream);
+/* gradients of the two losses with the incoming gradients folded in: g_a = (2 (a - t) / n) * *scale_a, g_b = (2 (b - t) / n) * *scale_b
+ * (device scalars; NULL = 1; g_a / g_b may be NULL) -- one launch where autograd would run two multiplies behind nvsr_mse_pair's gradients */
+int nvsr_mse_pair_backward(int64_t n, const float* a, const float* b, const float* target, const float* scale_a, const float* scale_b, float* g_a,
+                           float* g_b, nvsr_stream_t stream);
 /* ndc_rays (nerf_helpers.py:578-605) */
 int nvsr_ndc_rays(int H, int W, double focal, double near_, int64_t N, const float* ro, const float* rd, float* ro_out,
                   float* rd_out, nvsr_stream_t stream);
@@ -354,6 +361,10 @@ int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, 
  * depth_map and acc_map: its gradient is folded into g_depth / g_acc by the caller (ops.py `composite` does). */
 int nvsr_composite_backward_depth(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                                   const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream);
+/* nvsr_composite_backward_depth with the ray directions read out of packed rays [N,11] (columns 3..5 of nvsr_pack_rays' rows, what
+ * nvsr_composite_rays reads in the forward): a training step's backward needs no [N,3] copy of them */
+int nvsr_composite_backward_rays(int64_t N, int S, const float* raw, const float* z, const float* rays, const float* noise, int white_bkgd,
+                                 const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream);
 /* the same for nvsr_composite_mip (z [N,S+1]) */
 int nvsr_composite_backward_mip(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
                                 const float* g_rgb, const float* g_acc, float* g_raw, nvsr_stream_t stream);

@@ -72,6 +72,8 @@ _PROTOS = {
     "nvsr_sample_key": ([C.c_uint64, C.c_uint64], C.c_uint64),
     "nvsr_sample_pixels_seq": ([_i64, _i, _i, _vp, _i64, _i64, _vp, _i, _vp, _vp, _vp], _i),
     "nvsr_mse_pair": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_mse_pair_sum": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "nvsr_mse_pair_backward": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_ndc_rays": ([_i, _i, _d, _d, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_pack_rays": ([_i64, _vp, _vp, _vp, _d, _d, _vp, _vp], _i),
     "nvsr_coarse_z": ([_i64, _i, _vp, _i, _vp, _vp, _vp], _i),
@@ -114,6 +116,7 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
     "nvsr_composite_backward": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_backward_mip": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "nvsr_composite_backward_depth": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp], _i),
+    "nvsr_composite_backward_rays": ([_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "nvsr_render_pass_backward": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp], _i),
     "nvsr_decode_rays_ex": ([C.POINTER(Scene), _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "nvsr_render_pass_backward_gates": ([C.POINTER(Scene), _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp], _i),

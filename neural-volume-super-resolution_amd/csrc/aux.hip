@@ -208,8 +208,9 @@ __global__ void sample_pixels_seq_kernel(long total, int hb, int H, int Wd, unsi
 
 // img2mse of the coarse and the fine image against one target in ONE launch, with the gradients the backward will want
 // (train_nerf.py:893-905: two F.mse_loss calls; here 2 (x - t) / n is written beside the forward sums): one 1024-thread workgroup.
+// with_sum: losses[2] = losses[0] + losses[1] (the iteration's loss, train_nerf.py:905: coarse_loss + fine_loss -- one f32 addition, like torch's)
 __global__ void __launch_bounds__(1024) mse_pair_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ t,
-                                                        float* __restrict__ losses, float* __restrict__ ga, float* __restrict__ gb) {
+                                                        float* __restrict__ losses, float* __restrict__ ga, float* __restrict__ gb, int with_sum) {
     __shared__ float red[2][16];
     const float inv = 1.0f / (float)n, two_inv = 2.0f / (float)n;
     float sa = 0.0f, sb = 0.0f;
@@ -233,7 +234,24 @@ __global__ void __launch_bounds__(1024) mse_pair_kernel(long n, const float* __r
         float s = 0.0f;
         for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
         if (threadIdx.x == 0 || b) losses[threadIdx.x] = s * inv;
+        if (with_sum && b) {          // (threads 0 and 1 are lanes of one wave)
+            const float other = __shfl_xor(s * inv, 1);
+            if (threadIdx.x == 0) losses[2] = __fadd_rn(s * inv, other);
+        }
     }
+}
+
+// gradients of the two losses of mse_pair_kernel with the incoming gradients folded in: ga = (2 (a - t) / n) * *scale_a, gb likewise (a NULL scale
+// is 1; the product is rounded after the gradient, like the two torch multiplies this launch replaces)
+__global__ void __launch_bounds__(256) mse_pair_backward_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ t,
+                                                                const float* __restrict__ scale_a, const float* __restrict__ scale_b,
+                                                                float* __restrict__ ga, float* __restrict__ gb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float two_inv = 2.0f / (float)n;
+    const float tv = t[i];
+    if (ga) { const float g = __fmul_rn(two_inv, a[i] - tv); ga[i] = scale_a ? __fmul_rn(g, *scale_a) : g; }
+    if (gb) { const float g = __fmul_rn(two_inv, b[i] - tv); gb[i] = scale_b ? __fmul_rn(g, *scale_b) : g; }
 }
 
 __global__ void ndc_rays_kernel(float sx, float sy, float nr, float two_near, float m_two_near, long N, const float* __restrict__ ro,
@@ -766,7 +784,24 @@ int nvsr_sample_pixels_seq(int64_t total, int H, int W, uint64_t* state, int64_t
 int nvsr_mse_pair(int64_t n, const float* a, const float* b, const float* target, float* losses, float* g_a, float* g_b, nvsr_stream_t stream) {
     if (!a || !target || !losses || (g_b && !b)) return NVSR_ERR_NULL;
     if (n < 1 || n > NVSR_MSE_PAIR_MAX_ELEMS) return NVSR_ERR_SHAPE;
-    hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)n, a, b, target, losses, g_a, g_b);
+    hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)n, a, b, target, losses, g_a, g_b, 0);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_mse_pair_sum(int64_t n, const float* a, const float* b, const float* target, float* losses3, nvsr_stream_t stream) {
+    if (!a || !b || !target || !losses3) return NVSR_ERR_NULL;
+    if (n < 1 || n > NVSR_MSE_PAIR_MAX_ELEMS) return NVSR_ERR_SHAPE;
+    hipLaunchKernelGGL(mse_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)n, a, b, target, losses3, (float*)nullptr, (float*)nullptr, 1);
+    return NVSR_CHECK_LAUNCH();
+}
+
+int nvsr_mse_pair_backward(int64_t n, const float* a, const float* b, const float* target, const float* scale_a, const float* scale_b, float* g_a,
+                           float* g_b, nvsr_stream_t stream) {
+    if (!target || (g_a && !a) || (g_b && !b)) return NVSR_ERR_NULL;
+    if (n < 1 || n > NVSR_MSE_PAIR_MAX_ELEMS) return NVSR_ERR_SHAPE;
+    if (!g_a && !g_b) return NVSR_OK;
+    hipLaunchKernelGGL(mse_pair_backward_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (long)n, a, b, target, scale_a, scale_b,
+                       g_a, g_b);
     return NVSR_CHECK_LAUNCH();
 }
 

@@ -499,13 +499,16 @@ constexpr int CB_WPB = 4;
 __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N, int S, const float* __restrict__ raw, const float* __restrict__ z,
                                                                         const float* __restrict__ rd, const float* __restrict__ noise, int white,
                                                                         const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
-                                                                        const float* __restrict__ g_dep, float* __restrict__ g_raw, int mip) {
+                                                                        const float* __restrict__ g_dep, float* __restrict__ g_raw, int mip,
+                                                                        int rd_stride, int rd_off) {
+    // (rd_stride, rd_off): 3, 0 = ray directions [N,3]; 11, 3 = the directions inside packed rays [N,11] (nvsr_composite_backward_rays)
     __shared__ float sT[CB_WPB][512], sA[CB_WPB][512], sG[CB_WPB][512];   // T_s, alpha_s, dL/dw_s
     const int zp = S + (mip ? 1 : 0);                                      // mip: z holds S + 1 interval edges, no 1e10 tail
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * CB_WPB + wave;
     if (ray >= N) return;
-    const float d0 = rd[ray * 3], d1 = rd[ray * 3 + 1], d2 = rd[ray * 3 + 2];
+    const float* rdr = rd + ray * rd_stride + rd_off;
+    const float d0 = rdr[0], d1 = rdr[1], d2 = rdr[2];
     const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     const float g0 = g_rgb[ray * 3], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
     const float ga = (g_acc ? g_acc[ray] : 0.0f) - (white ? (g0 + g1 + g2) : 0.0f);
@@ -591,15 +594,25 @@ int nvsr_pack_decoder_bwd(const float* natural, float* packed_bwd, nvsr_stream_t
     return nvsr_pack_decoder_bwd_limbs_launch(natural, packed_bwd, stream);      // the bf16-limb fragments behind the f32 ones
 }
 
-int nvsr_composite_backward_depth(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
-                                  const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream) {
+static int composite_backward_launch(int64_t N, int S, const float* raw, const float* z, const float* rd, int rd_stride, int rd_off, const float* noise,
+                                     int white_bkgd, const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw,
+                                     nvsr_stream_t stream) {
     if (!raw || !z || !rd || !g_rgb || !g_raw) return NVSR_ERR_NULL;
     if (!aligned16(raw) || !aligned16(g_raw)) return NVSR_ERR_ALIGN;
     if (N < 0 || S < 1 || S > 512) return NVSR_ERR_SHAPE;
     if (N == 0) return NVSR_OK;
     hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((N + CB_WPB - 1) / CB_WPB)), dim3(CB_WPB * 64), 0, (hipStream_t)stream, (long)N, S,
-                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_depth, g_raw, mip_nerf ? 1 : 0);
+                       raw, z, rd, noise, white_bkgd, g_rgb, g_acc, g_depth, g_raw, mip_nerf ? 1 : 0, rd_stride, rd_off);
     return NVSR_CHECK_LAUNCH();
+}
+int nvsr_composite_backward_depth(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,
+                                  const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream) {
+    return composite_backward_launch(N, S, raw, z, rd, 3, 0, noise, white_bkgd, g_rgb, g_acc, g_depth, mip_nerf, g_raw, stream);
+}
+/* the same with the ray directions read out of packed rays [N,11] (columns 3..5, nvsr_pack_rays): no [N,3] copy per backward pass */
+int nvsr_composite_backward_rays(int64_t N, int S, const float* raw, const float* z, const float* rays, const float* noise, int white_bkgd,
+                                 const float* g_rgb, const float* g_acc, const float* g_depth, int mip_nerf, float* g_raw, nvsr_stream_t stream) {
+    return composite_backward_launch(N, S, raw, z, rays, 11, 3, noise, white_bkgd, g_rgb, g_acc, g_depth, mip_nerf, g_raw, stream);
 }
 
 int nvsr_composite_backward(int64_t N, int S, const float* raw, const float* z, const float* rd, const float* noise, int white_bkgd,

@@ -569,6 +569,28 @@ def _(raw, z, rd, noise, white, mip, g_rgb, g_acc, g_depth=None):
     return torch.empty_like(raw)
 
 
+@custom_op("nvsr::composite_backward_rays", mutates_args=(), device_types="cuda")
+def composite_backward_rays(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white: bool, mip: bool, g_rgb: Tensor,
+                            g_acc: Optional[Tensor], g_depth: Optional[Tensor] = None) -> Tensor:
+    """composite_backward with the ray directions taken from packed rays [N,11] (the backward of composite_rays; no [N,3] copy)"""
+    raw, z, rays, noise, g_rgb, g_acc, g_depth = _c(raw), _c(z), _c(rays), _c(noise), _c(g_rgb), _c(g_acc), _c(g_depth)
+    N = z.shape[0]
+    S = z.shape[1] - (1 if mip else 0)
+    assert rays.shape == (N, 11)
+    g_raw = torch.empty_like(raw)
+    if N:
+        if S > 512:
+            raise NotImplementedError("nvsr_composite_backward handles up to 512 samples per ray")
+        capi.call("nvsr_composite_backward_rays", N, S, capi.ptr(raw), capi.ptr(z), capi.ptr(rays), capi.ptr(noise), int(white), capi.ptr(g_rgb),
+                  capi.ptr(g_acc), capi.ptr(g_depth), int(mip), capi.ptr(g_raw), capi.stream())
+    return g_raw
+
+
+@composite_backward_rays.register_fake
+def _(raw, z, rays, noise, white, mip, g_rgb, g_acc, g_depth=None):
+    return torch.empty_like(raw)
+
+
 def fold_disp_grad(g_disp, q, acc, depth, g_acc, g_depth):
     """disp_map = 1 / max(1e-10, q), q = depth_map / acc_map (volume_rendering_utils.py:46): the incoming gradient of disp_map as additions to
     those of depth_map and acc_map (per-ray scalars; torch.max passes the gradient to the larger operand, q = NaN (acc = 0) passes none)

@@ -149,7 +149,6 @@ class _RenderRaysFn(torch.autograd.Function):
         N, Nc, Nf, rays = cfg["N"], cfg["Nc"], cfg["Nf"], cfg["rays"]
         nv = _NV()
         dev = rays.device
-        rd = rays[:, 3:6].contiguous()
         need = ctx.needs_input_grad
         sep = bool(cfg.get("separate_coarse"))                 # the coarse pass has plane leaves of its own (inputs 7..10)
         need_planes_f = [bool(n) for n in need[1:5]]
@@ -172,7 +171,7 @@ class _RenderRaysFn(torch.autograd.Function):
             if g_disp is not None:
                 q = 1.0 / disp                      # disp = 1 / max(1e-10, q): q itself wherever the gradient is not zero (NaN stays NaN)
                 g_acc, g_depth = ops.fold_disp_grad(g_disp, q, acc, q * acc, g_acc, None)
-            g_raw = nv.composite_backward(raw, z, rd, noise, bool(cfg["white"]), False, g_rgb, g_acc, g_depth)
+            g_raw = nv.composite_backward_rays(raw, z, rays, noise, bool(cfg["white"]), False, g_rgb, g_acc, g_depth)     # (directions read from the packed rays)
             if gates is not None and (not want_dec or fwd_rec is not None):
                 # gate-driven backward (no recomputation); with the forward's record it adds the gradient half, then ONE contraction
                 rec = fwd_rec if want_dec else None

@@ -167,6 +167,54 @@ class _MsePair(torch.autograd.Function):
         return (None if ga is None or g0 is None else ga * g0), (None if gb is None or g1 is None else gb * g1), None
 
 
+class _MsePairSum(torch.autograd.Function):
+    """(F.mse_loss(a, t), F.mse_loss(b, t), their sum) from one launch (nvsr_mse_pair_sum); the backward is ONE launch that writes both gradients
+    with the incoming gradients folded in (nvsr_mse_pair_backward) -- autograd's own chain for `coarse_loss + fine_loss` is an addition in the
+    forward and two multiplies behind the stored gradients in the backward: three few-microsecond kernels of a 1.6 ms iteration.  The three
+    scalars are views of one [3] tensor (`packed`), which the iteration's metrics copy to the host as they are."""
+
+    @staticmethod
+    def forward(ctx, a, b, t):
+        a, b, t = capi.f32c(a), capi.f32c(b), capi.f32c(t)
+        losses = torch.empty(3, dtype=torch.float32, device=a.device)
+        capi.call("nvsr_mse_pair_sum", a.numel(), capi.ptr(a), capi.ptr(b), capi.ptr(t), capi.ptr(losses), capi.stream())
+        ctx.save_for_backward(a, b, t)
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2], losses
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, _gp):
+        a, b, t = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        def scale(g, gs):          # the incoming gradient of one loss: its own + the sum's (either may be absent)
+            if g is None:
+                return gs
+            return g if gs is None else g + gs
+        sa, sb = scale(g0, g2), scale(g1, g2)
+        ga = torch.empty_like(a) if need_a and sa is not None else None
+        gb = torch.empty_like(b) if need_b and sb is not None else None
+        if ga is not None or gb is not None:
+            sa_, sb_ = (None if sa is None else capi.f32c(sa)), (None if sb is None else capi.f32c(sb))
+            capi.call("nvsr_mse_pair_backward", a.numel(), capi.ptr(a), capi.ptr(b), capi.ptr(t), capi.ptr(sa_), capi.ptr(sb_), capi.ptr(ga), capi.ptr(gb),
+                      capi.stream())
+        return ga, gb, None
+
+
+def _pair_on_device(a, b, target):
+    return (a.is_cuda and a.shape == b.shape == target.shape and a.dtype == b.dtype == target.dtype == torch.float32
+            and 0 < a.numel() <= capi.MSE_PAIR_MAX_ELEMS and not target.requires_grad)
+
+
+def mse_loss_pair_sum(a, b, target):
+    """(mse_loss(a, target), mse_loss(b, target), their sum, packed) -- train_nerf.py:893-905's coarse loss, fine loss and `coarse_loss +
+    fine_loss`; `packed` = the [3] device tensor holding the three (None off the device path: torch's own operators)."""
+    if _pair_on_device(a, b, target):
+        lc, lf, both, packed = _MsePairSum.apply(a, b, target)
+        return lc, lf, both, packed.detach()
+    lc, lf = mse_loss(a, target), mse_loss(b, target)
+    return lc, lf, lc + lf, None
+
+
 def mse_loss_pair(a, b, target):
     """(mse_loss(a, target), mse_loss(b, target)) -- train_nerf.py:893-905's coarse and fine losses.  One `nvsr_mse_pair` launch for float32
     CUDA images of one shape (a training batch); anything else goes through torch like mse_loss()."""
@@ -189,14 +237,29 @@ class StepMetrics(Mapping):
     RANGE_ERROR = ("NVSR_ARITH_F16X2 range exceeded in training iteration %s (a weight >= 255, a feature or activation >= 4094, or a non-finite "
                    "parameter): the kernels wrote NaN; set model.arithmetic = 'bf16x3' (capi.set_decoder_arithmetic('bf16x3')) for this model")
 
-    def __init__(self, loss, rendering_loss, coarse_loss, fine_loss, with_psnr, range_word=None, it=None):
+    def __init__(self, loss, rendering_loss, coarse_loss, fine_loss, with_psnr, range_word=None, it=None, packed=None):
         self._present = dict(loss=True, psnr=with_psnr and isinstance(rendering_loss, torch.Tensor), coarse_loss=coarse_loss is not None,
                              fine_loss=fine_loss is not None)
-        src = [loss, rendering_loss, coarse_loss, fine_loss]
+        self._it = it
+        self._vals = None
+        self._packed_host = None
         dev = loss.device
+        if packed is not None and dev.type == "cuda":
+            # packed = [coarse_loss, fine_loss, loss = rendering_loss] as the loss kernel wrote them (mse_loss_pair_sum): two asynchronous copies
+            # (the three scalars; the range flag word) and no launch, where gathering five scalars is a conversion, a stack and a copy
+            self._packed_host = torch.empty(3, dtype=torch.float32, pin_memory=True)
+            self._packed_host.copy_(packed, non_blocking=True)
+            self._flag_host = None
+            if range_word is not None:
+                self._flag_host = torch.empty(range_word.shape, dtype=range_word.dtype, pin_memory=True)
+                self._flag_host.copy_(range_word, non_blocking=True)
+            self._host = None
+            self._event = torch.cuda.Event()
+            self._event.record()
+            return
+        src = [loss, rendering_loss, coarse_loss, fine_loss]
         # (5th value: the library's range flag as it stands at the end of this iteration -- capi.RangeFlag; read with the others)
         src.append(range_word.reshape(()) if range_word is not None else 0.0)
-        self._it = it
         vals = torch.stack([(v.detach().to(torch.float32).reshape(()) if isinstance(v, torch.Tensor)
                              else torch.full((), float("nan") if v is None else float(v), device=dev)) for v in src])
         if dev.type == "cuda":
@@ -206,13 +269,17 @@ class StepMetrics(Mapping):
             self._event.record()
         else:
             self._host, self._event = vals, None
-        self._vals = None
 
     def _read(self):
         if self._vals is None:
             if self._event is not None:
                 self._event.synchronize()
-            self._vals = self._host.tolist()
+            if self._packed_host is not None:
+                c, f, s = self._packed_host.tolist()
+                flag = 0.0 if self._flag_host is None else float(self._flag_host.reshape(-1)[0].item())
+                self._vals = [s, s, c, f, flag]
+            else:
+                self._vals = self._host.tolist()
         if self._vals[4] != 0.0:
             raise capi.NvsrError(self.RANGE_ERROR % ("?" if self._it is None else self._it))
         return self._vals
@@ -270,7 +337,7 @@ class TrainStep:
         word = self._range_word(img_target.device)
         out = self.run(it, img_target, pose_target, H, W, focal, cur_ds_factor, scene_id, scene_config, num_random_rays, sr_iter,
                        im_consistency_iter, confinements, randoms)
-        m = StepMetrics(*out, range_word=word, it=it)
+        m = StepMetrics(*out, range_word=word, it=it, packed=self.__dict__.pop("_packed_metrics", None))
         if m._event is not None:
             self._pending.append(m)
             if len(self._pending) > 64:          # (a consumer that never lets the queue drain: wait for the oldest)
@@ -323,20 +390,25 @@ class TrainStep:
         if im_consistency_iter:
             rgb_coarse = avg_downsampling(rgb_coarse, self.ds_factor)
             rgb_fine = None if rgb_fine is None else avg_downsampling(rgb_fine, self.ds_factor)
-        coarse_loss = fine_loss = None
+        coarse_loss = fine_loss = both = packed = None
         trains_scene = bool(self.what & {"decoder", "LR_planes"})
         if self.rendering_loss_w is not None:
             want_c = trains_scene or self.sr_loss != "fine"
             want_f = rgb_fine is not None and (trains_scene or self.sr_loss != "coarse")
             if want_c and want_f:
-                coarse_loss, fine_loss = mse_loss_pair(rgb_coarse, rgb_fine, target)
+                coarse_loss, fine_loss, both, packed = mse_loss_pair_sum(rgb_coarse, rgb_fine, target)
             elif want_c:
                 coarse_loss = mse_loss(rgb_coarse, target)
             elif want_f:
                 fine_loss = mse_loss(rgb_fine, target)
-        rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
+        if both is not None:
+            rendering_loss = both           # (coarse_loss + fine_loss, added by the loss kernel)
+        else:
+            rendering_loss = (coarse_loss if coarse_loss is not None else 0.0) + (fine_loss if fine_loss is not None else 0.0)
         loss_w = self.im_inconsistency_loss_w if im_consistency_iter else self.rendering_loss_w
         loss = rendering_loss if loss_w == 1.0 else loss_w * rendering_loss        # (x * 1.0 is x: one kernel and its backward less)
+        # the iteration's scalars as ONE device tensor where they are one (coarse, fine, sum = rendering loss = loss): StepMetrics copies it as it is
+        self._packed_metrics = packed if (packed is not None and loss is both) else None
         self.apply_gradients(loss, last_v, sr_iter, confinements)
         return loss, rendering_loss, coarse_loss, fine_loss, not im_consistency_iter
 
@@ -400,7 +472,11 @@ class TrainStep:
         """the tail of an iteration (train_nerf.py:903-914): backward, [data-parallel: grad_sync() averages the gradients over the ranks],
         then the optimizer steps the iteration is entitled to -- every rank steps from the same averaged gradients, so the ranks' parameters
         stay identical (tests/test_distributed.py runs this tail on two gloo ranks)"""
-        loss.backward()
+        # (the seed of the backward pass from a cached scalar: `loss.backward()` fills a new ones_like(loss) -- one more launch -- every iteration)
+        seed = self.__dict__.get("_seed")
+        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype:
+            seed = self.__dict__["_seed"] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(seed if loss.dim() == 0 else None)
         if self.grad_sync is not None:
             self.grad_sync()
         if self.planes_optimizer is not None:

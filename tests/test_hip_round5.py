@@ -602,3 +602,88 @@ def test_derived_copies_follow_a_fused_optimizer_step(hip, fused):
         assert torch.equal(blob.view(torch.int32), m.packed_decoder().view(torch.int32))
     for a, b in zip(used, now):                      # ... and the step did move every one of them
         assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the launches between the render passes of a training iteration (round 5, second half): loss sum + one-launch loss backward, the
+# compositor's backward on packed rays, the iteration's scalars as one device tensor
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_loss_pair_sum_and_its_backward_equal_torch(hip):
+    """training.mse_loss_pair_sum (nvsr_mse_pair_sum / nvsr_mse_pair_backward) against F.mse_loss + torch's addition and autograd
+    (train_nerf.py:893-905): the three losses within 1e-6 relative, the gradients of every way the losses can be used -- the sum alone (the
+    iteration), a weighted sum, one loss alone, the sum plus one loss -- within 1e-6 of torch's, and bit-identical to the launch they replace
+    (nvsr_mse_pair's gradients times the incoming scalar)."""
+    T = hip.training
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for n in (1, 7, 4096, 5000):
+        a0, b0, t = (torch.rand(n, 3, device=DEV, generator=g) for _ in range(3))
+        for use in ("sum", "weighted", "coarse", "sum+fine"):
+            a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            ar, br = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            lc, lf, both, packed = T.mse_loss_pair_sum(a, b, t)
+            rc, rf = torch.nn.functional.mse_loss(ar, t), torch.nn.functional.mse_loss(br, t)
+            assert packed.shape == (3,) and torch.equal(packed, torch.stack([lc, lf, both]).detach())
+            torch.testing.assert_close(torch.stack([lc, lf, both]), torch.stack([rc, rf, rc + rf]), rtol=1e-6, atol=0)
+            assert torch.equal(both.detach(), (lc + lf).detach())
+            if use == "sum":
+                both.backward(); (rc + rf).backward()
+            elif use == "weighted":
+                (both * 0.37).backward(); ((rc + rf) * 0.37).backward()
+            elif use == "coarse":
+                lc.backward(); rc.backward()
+            else:
+                (both + 2.0 * lf).backward(); (rc + 3.0 * rf).backward()
+            for x, r in ((a, ar), (b, br)):
+                if r.grad is None:
+                    assert x.grad is None
+                else:
+                    torch.testing.assert_close(x.grad, r.grad, rtol=2e-6, atol=1e-12)
+        # bit for bit what the pair operator's stored gradients times the seed give
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        T.mse_loss_pair_sum(a, b, t)[2].backward()
+        l0, l1 = T.mse_loss_pair(a2, b2, t)
+        (l0 + l1).backward()
+        assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+
+
+def test_composite_backward_reads_the_directions_from_packed_rays(hip):
+    """nvsr_composite_backward_rays (directions = columns 3..5 of the packed rays) is nvsr_composite_backward_depth on their contiguous copy, bit
+    for bit, with and without noise / opacity / depth gradients (volume_rendering_utils.py:18-49 under autograd)."""
+    nv = torch.ops.nvsr
+    g = torch.Generator(device=DEV).manual_seed(11)
+    N, S = 37, 65
+    rays = torch.randn(N, 11, device=DEV, generator=g)
+    raw = torch.randn(N, S, 4, device=DEV, generator=g)
+    z = torch.sort(torch.rand(N, S, device=DEV, generator=g) * 4 + 2, -1)[0].contiguous()
+    noise = torch.randn(N, S, device=DEV, generator=g) * 0.2
+    g_rgb, g_acc, g_dep = torch.randn(N, 3, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    rd = rays[:, 3:6].contiguous()
+    for nz, ga, gd, white in ((None, None, None, False), (noise, g_acc, None, True), (noise, g_acc, g_dep, False)):
+        want = nv.composite_backward(raw, z, rd, nz, white, False, g_rgb, ga, gd)
+        got = nv.composite_backward_rays(raw, z, rays, nz, white, False, g_rgb, ga, gd)
+        assert torch.equal(got, want) and bool(torch.isfinite(got).all())
+
+
+def test_step_metrics_from_the_packed_scalars(hip):
+    """StepMetrics of a planes-only iteration (the loss kernel's [coarse, fine, sum] tensor + the range flag word, two asynchronous copies) reports
+    what the five-scalar gather reports: loss = rendering loss = coarse + fine, psnr = mse2psnr(loss) (train_nerf.py:893-921)."""
+    from bench import make_synthetic_scene, render_options
+    T = hip.training
+    mc, mf, sid, pose = make_synthetic_scene(DEV, 48, 16, seed=2, channels_last=True)
+    opts, scfg = render_options(16, 16, perturb=True, noise=0.2)
+    for m_ in (mc, mf):
+        for n_, p_ in m_.named_parameters():
+            p_.requires_grad_("rot_mats" not in n_ and "planes_" in n_)
+        m_.train()
+    popt = torch.optim.Adam(list(mc.planes_.values()), lr=1e-3)
+    step = T.TrainStep(mc, mf, opts, ["LR_planes"], planes_optimizer=popt, pixel_sampler=T.DevicePixelSampler(seed=5))
+    H = W = 64
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    target = torch.rand(H, W, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    m = step(0, target, pose, H, W, focal, 1, sid, scfg, 256)
+    assert m._packed_host is not None                      # (the device path was taken)
+    vals = dict(m)
+    assert abs(vals["loss"] - (vals["coarse_loss"] + vals["fine_loss"])) <= 1e-6 * vals["loss"]
+    assert abs(vals["psnr"] - hip.nerf_helpers.mse2psnr(vals["loss"])) < 1e-9
+    assert all(np.isfinite(v) for v in vals.values())
