@@ -872,7 +872,16 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
         for _ in range(3):
             marks.clear()
             mark("start")
-            one(probe)
+            try:
+                one(probe)
+            except capi.NvsrError:
+                # which operands are non-finite when the range flag comes up (a two-process rehearsal on ONE GPU has raised it in ~1 % of its
+                # runs on some pool boxes -- never a one-process run): parameters = the previous iteration's update wrote
+                # them, none = this iteration's forward met something else
+                bad = [n_ for n_, p_ in list(mc.named_parameters()) + list(mf.named_parameters()) + list(sr.named_parameters())
+                       if not bool(torch.isfinite(p_.detach()).all())]
+                print("RANGE_FLAG_DIAGNOSTICS iteration %d: non-finite parameters: %s" % (it[0], bad[:8] if bad else "none"), file=sys.stderr, flush=True)
+                raise
             mark("end")
             torch.cuda.synchronize()
             ms = lambda a, b: marks[a][0].elapsed_time(marks[b][-1])

@@ -50,7 +50,14 @@ def _stale():
 # index; before the selection folds away the body counts every alternative, and beyond 16 k instructions LLVM ignores the pragma -- the slot
 # index then reaches an asm immediate ("constraint 'n' expects an integer constant expression") or a register index as a run-time value.
 _PAIR_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]
-PER_FILE_FLAGS = {"render3.hip": _PAIR_FLAGS, "decode_pair.hip": _PAIR_FLAGS, "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"]}
+# sr.hip / sr_bwd.hip: without the post-RA machine scheduler (round 5).  The convolution kernels place their fragment loads, LDS reads and MFMA groups
+# by hand between sched_barriers; the pre-RA scheduler respects those, the post-RA pass still reorders inside the regions.  Same box, alternating
+# (bench.py --workload sr / refine): SR stage 49.2 -> 48.0 ms, refine iteration 86.4 -> 84.9 ms, same bits (the SR tests).  The render / training
+# kernels do not gain (fine pass 77.1 -> 77.5 ms, planes-only backward 0.58 -> 0.595 ms with the flag): they keep the default.  Other strategies
+# tried on these two files (max-ilp, max-memory-clause, no pre-RA scheduler): none better (scratch timings of the session, profiles/r05_README.md).
+_SR_FLAGS = ["-mllvm", "-enable-post-misched=0"]
+PER_FILE_FLAGS = {"render3.hip": _PAIR_FLAGS, "decode_pair.hip": _PAIR_FLAGS, "decode_limb.hip": ["-fno-slp-vectorize"], "render_bwd_limb.hip": ["-fno-slp-vectorize"],
+                  "sr.hip": _SR_FLAGS, "sr_bwd.hip": _SR_FLAGS}
 OBJ_DIR = os.path.join(CSRC, "_obj")      # (of the product build; experiment variants use <out_path>.obj)
 
 

@@ -5,6 +5,7 @@ and state-dict keys, so checkpoints and the `PlanesOptimizer`-style wiring of th
 fused gather + MFMA decoder kernel (csrc/render.hip) on channel-last copies of the planes and a fragment-packed copy of the
 weights, both cached and refreshed when the source tensors change."""
 import ctypes as C
+import os
 import weakref
 from re import search
 
@@ -786,7 +787,7 @@ class EDSR(nn.Module):
         arithmetic reads (training: the weights change every iteration and both blobs are re-packed -- a fifth of the bytes); a cached blob with
         every region serves any request"""
         key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
-        kinds = capi.PACK_ALL_ARITHMETICS if arithmetic is None else int(arithmetic)
+        kinds = capi.PACK_ALL_ARITHMETICS if (arithmetic is None or os.environ.get("NVSR_PACK_ALL") == "1") else int(arithmetic)
         c = self._packed_cache
         if c is None or c[0] != key or c[2] not in (kinds, capi.PACK_ALL_ARITHMETICS):
             ws = self.conv_weights()
@@ -802,7 +803,7 @@ class EDSR(nn.Module):
     def packed_dgrad_weights(self, arithmetic=None):
         """fragments of every layer's data gradient (flipped, transposed kernels), cached like packed_weights()"""
         key = tuple((w.data_ptr(), w._version) for w in self.conv_parameters())
-        kinds = capi.PACK_ALL_ARITHMETICS if arithmetic is None else int(arithmetic)
+        kinds = capi.PACK_ALL_ARITHMETICS if (arithmetic is None or os.environ.get("NVSR_PACK_ALL") == "1") else int(arithmetic)
         cache = getattr(self, "_packed_dgrad_cache", None)
         if cache is None or cache[0] != key or cache[2] not in (kinds, capi.PACK_ALL_ARITHMETICS):
             nat = self.natural_blob()

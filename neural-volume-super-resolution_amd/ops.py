@@ -16,6 +16,7 @@ Conventions
 Reference functions behind the operators: models.py:381-421 (decoder), train_utils.py:71-182 (render passes), volume_rendering_utils.py:6-51
 (compositing), nerf_helpers.py:668-702 (importance sampling), models.py:769-822,884-926 (EDSR / PlanesSR)."""
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -647,6 +648,8 @@ def pack_edsr(natural: Tensor, geometry: Sequence[int], dgrad: bool, arithmetic:
     n = (lib.nvsr_edsr_packed_dgrad_floats if dgrad else lib.nvsr_edsr_packed_floats)(*geometry)
     assert n > 0
     packed = _f(n, like=nat)
+    if os.environ.get("NVSR_PACK_POISON") == "1":          # (tests / tools: NaN words wherever the packer does not write)
+        packed.fill_(float("nan"))
     capi.call("nvsr_pack_edsr_dgrad_arith" if dgrad else "nvsr_pack_edsr_arith", capi.ptr(nat), *geometry, capi.ptr(packed), int(arithmetic), capi.stream())
     return packed
 

@@ -9,6 +9,7 @@ What changes against the reference:
     optimizer gating (:848-853, :905-914), the SR-vs-no-SR double render and PSNR bookkeeping of `evaluate()` (:655-713);
   * optional: `DevicePixelSampler` draws the pixels on the device (`nvsr_sample_pixels`: one kernel instead of a host permutation of H*W
     indices), and the coarse + fine MSE of one step come from one launch (`mse_loss_pair`)."""
+import os
 from collections.abc import Mapping
 
 import numpy as np
@@ -281,7 +282,7 @@ class StepMetrics(Mapping):
             else:
                 self._vals = self._host.tolist()
         if self._vals[4] != 0.0:
-            raise capi.NvsrError(self.RANGE_ERROR % ("?" if self._it is None else self._it))
+            raise capi.NvsrError((self.RANGE_ERROR % ("?" if self._it is None else self._it)) + " [range flag bits %d: 1 = decoder kernels, 2 = SR network]" % int(self._vals[4]))
         return self._vals
 
     def poll(self):
@@ -324,7 +325,8 @@ class TrainStep:
         self.sr_loss, self.ds_factor, self.separate_decoder_sr = sr_loss, int(ds_factor), separate_decoder_sr
         self.grad_sync = grad_sync          # callable() run between backward and the optimizer steps (data-parallel all-reduce)
         self.pixel_sampler = pixel_sampler or select_training_pixels   # (img_target, num_random_rays, consistency_ds) -> (rows_cols, target_s)
-        self.prologue_ahead = True          # SR training: pixels, rays and regions of interest on a side stream ahead of the iteration (_draw_rays)
+        # SR training: pixels, rays and regions of interest on a side stream ahead of the iteration (_draw_rays); NVSR_PROLOGUE_AHEAD=0: in-stream
+        self.prologue_ahead = os.environ.get("NVSR_PROLOGUE_AHEAD", "1") != "0"
         import collections
         self._pending = collections.deque()
 
