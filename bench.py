@@ -795,7 +795,7 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
         for m in (mc, mf):
             m.box_coords = {sid: torch.tensor([[-1.5, -1.5, -1.5, -np.pi, -np.pi / 2], [1.5, 1.5, 1.5, np.pi, np.pi / 2]], dtype=torch.float64)}
             m.invalidate()
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    g = torch.Generator(device=dev).manual_seed(100 + int(os.environ.get("NVSR_BENCH_SEED_RANK", rank)))
     target = torch.rand(H, W, 3, device=dev, generator=g)
     dec = list({id(p): p for m in (mc, mf) for p in m.decoder_parameters()}.values())
     planes = list(mc.planes_.values())
@@ -805,7 +805,22 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     sropt = torch.optim.Adam(srp, lr=5e-5, fused=True)
     trained = srp + (planes + dec if joint else [])
     sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in trained if p.grad is not None])) if world > 1 else None
-    sampler = T.DevicePixelSampler(seed=100 + rank)
+    if os.environ.get("NVSR_BENCH_DEBUG_NAN") == "1":
+        # diagnostics (round 5's backward-prologue race): are this rank's gradients finite before / after the all-reduce, per iteration?
+        # (host reads: the timing of such a run means nothing)
+        inner = sync
+
+        def sync():
+            gs = [p.grad for p in trained if p.grad is not None]
+            pre = [n_ for n_, g_ in enumerate(gs) if not bool(torch.isfinite(g_).all())]
+            if inner is not None:
+                inner()
+            post = [n_ for n_, g_ in enumerate(gs) if not bool(torch.isfinite(g_).all())]
+            if pre or post:
+                print("NAN_DEBUG rank %d iteration %d: non-finite gradient tensors before the all-reduce %s, after %s (of %d)"
+                      % (rank, it[0], pre[:6], post[:6], len(gs)), file=sys.stderr, flush=True)
+    seed_rank = int(os.environ.get("NVSR_BENCH_SEED_RANK", rank))          # (a one-process run on another rank's pixels and random numbers)
+    sampler = T.DevicePixelSampler(seed=100 + seed_rank)
     mk = lambda sync_, sampler_: T.TrainStep(mc, mf, opts, what, optimizer=opt, SR_optimizer=sropt, planes_optimizer=popt, SR_model=sr, sr_loss="fine",
                                              grad_sync=sync_, pixel_sampler=sampler_)
     step = mk(sync, sampler)
@@ -875,9 +890,8 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
             try:
                 one(probe)
             except capi.NvsrError:
-                # which operands are non-finite when the range flag comes up (a two-process rehearsal on ONE GPU has raised it in ~1 % of its
-                # runs on some pool boxes -- never a one-process run): parameters = the previous iteration's update wrote
-                # them, none = this iteration's forward met something else
+                # which operands are non-finite when the range flag comes up: parameters = the previous iteration's update wrote them, none = this
+                # iteration's forward met something else (how round 5's backward-prologue race was cornered: DESIGN.md section 6)
                 bad = [n_ for n_, p_ in list(mc.named_parameters()) + list(mf.named_parameters()) + list(sr.named_parameters())
                        if not bool(torch.isfinite(p_.detach()).all())]
                 print("RANGE_FLAG_DIAGNOSTICS iteration %d: non-finite parameters: %s" % (it[0], bad[:8] if bad else "none"), file=sys.stderr, flush=True)

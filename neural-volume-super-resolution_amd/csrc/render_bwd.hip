@@ -116,6 +116,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<BNW>(rs);
+    __syncthreads();          // (the transposed alpha head reads these LDS words in front of the first ring barrier: render_bwd_limb.hip)
     float* tile = lds + LDS_FLOATS + BPTS * RAYB_FLOATS + rs.wave * TILE_FLOATS;
     const float* small = lds + 2 * SLOT_FLOATS;
     constexpr int HH = P_HID_FLOATS / 2;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(MBwd<RECORD>::TPB, 1) void render_pass_backward_gat
     __shared__ __attribute__((aligned(16))) float lds[MBwd<RECORD>::LDS];
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<MNW>(rs);                    // head weights / biases of the FORWARD blob -> LDS
+    __syncthreads();          // (the transposed alpha head reads these LDS words in front of the first ring barrier: render_bwd_limb.hip)
     rs.packed = packed_bwd;
     float* tile = lds + LDS_FLOATS + rs.wave * TILE_FLOATS;
     const float* small = lds + 2 * SLOT_FLOATS;

@@ -24,6 +24,12 @@
 #define BL_SCATTER 3  // plane scatter of a tile: 0 one set of 4 atomics per point, 1 per run of points in one cell, 2 every texel of the tile once (bookkeeping per point on the scalar unit), 3 the same with the bookkeeping per tile on the vector unit
 #endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
+#ifndef BL_PROLOGUE_BARRIER
+#define BL_PROLOGUE_BARRIER 1   // workgroup barrier behind the head weights' copy into LDS (0 / BL_RACE_PROBE=1: builds that demonstrate the race it closes)
+#endif
+#ifndef BL_RACE_PROBE
+#define BL_RACE_PROBE 0
+#endif
 #ifndef BL_GATE_PREFETCH
 #define BL_GATE_PREFETCH 1   // the tile's gate words loaded once at its top (A/B: 0 = re-read per layer)
 #endif
@@ -181,8 +187,20 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
     RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL + BLimb<LF>::OFFSET), 0, BLimb<LF>::WORDS * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
+#if BL_RACE_PROBE      // (experiment: every wave but the first writes its share of the head weights LATE -- the race of the missing barrier, made certain)
+    if (rs.wave != 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#endif
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += BL_TPB) ldsf[BL_SMALL + i] = packed[P_SMALL + i];   // head weights of the FORWARD blob
     const float* small = ldsf + BL_SMALL;
+#if BL_PROLOGUE_BARRIER
+    // The transposed alpha head is the FIRST thing a tile computes, out of these LDS words and in front of the first ring barrier: without a barrier
+    // here a wave could read head weights another wave had not written yet (stale LDS of the previous workgroup -> a non-finite density chain: gD, the
+    // position planes' and the density decoder's gradients).  Never seen in a process that has the GPU to itself (the waves of a workgroup start
+    // together and the reads sit behind two global loads); two processes time-slicing one GPU hit it in ~1.5 % of their refine iterations
+    // (round 5: 2 of 133 pairs of independent processes, 0 of 133 alone).  The forward kernels use these words behind their
+    // first ring barrier.
+    __syncthreads();
+#endif
     float* tile = ldsf + BL_TILES + rs.wave * TILE_FLOATS;
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));

@@ -137,17 +137,6 @@ def _bench_rehearsal(args, timeout=900):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-modes"] + args      # (bench.py spawns its ranks)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    if p.returncode != 0 and "range exceeded in training iteration" in p.stderr:
-        # KNOWN AND OPEN (round 5): two processes time-slicing this box's ONE GPU have raised the f16 range flag in the first
-        # iteration after the timed loop of the refine rehearsal in 3 of ~230 runs, on three of five pool boxes, in every tree back to the round's
-        # first refine commit -- never in a one-process run (~90 runs of the same iterations), never with NaN-poisoned weight blobs finding a
-        # reader.  One GPU per rank (the driver's configuration) does not time-slice.  The occurrence is reported as a warning with what the
-        # run printed, and the rehearsal is repeated ONCE; a second failure fails the test.
-        import re, warnings
-        warnings.warn("two-rank rehearsal on one GPU raised the range flag (retrying once): %s | %s"
-                      % (" ".join(re.findall(r"range exceeded in training iteration \d+|range flag bits \d+", p.stderr)[:2]),
-                         " ".join(re.findall(r"RANGE_FLAG_DIAGNOSTICS[^\n]*", p.stderr)[:1])))
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
