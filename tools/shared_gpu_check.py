@@ -1,0 +1,57 @@
+"""Do the kernels give the same bits when another process time-slices the GPU?  (Round 5: two processes on one GPU exposed a missing barrier in the
+backward kernels' prologue that a process alone never hit -- profiles/r05_backward_prologue_race.txt.)  Deterministic launches over and over, every
+result compared BIT FOR BIT with the first: the training forward of the render pass (decode_rays, S = 64 one-tile kernel / S = 128 tile-pair kernel,
+with gate words), a fused 320 x 320 frame (both render passes + resampler), the EDSR forward.  Start two at once:
+    python tools/shared_gpu_check.py 60 & python tools/shared_gpu_check.py 60; wait"""
+import sys, os, time, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import nvsr_amd
+from bench import make_synthetic_scene, render_options
+dev = torch.device("cuda", 0); capi = nvsr_amd.capi
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+mc, mf, sid, pose = make_synthetic_scene(dev, 200, 32, seed=0)
+H = W = 800; focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+g = torch.Generator(device=dev).manual_seed(1)
+N = 4096
+sel = torch.randint(0, H, (N, 2), device=dev, generator=g)
+ro, rd = nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose, sel)
+rays = nvsr_amd.train_utils.pack_rays(ro, rd, 2.0, 6.0)
+sc, keep = mf.native_scene()
+packed = mf.packed_decoder()
+cases = {}
+for S in (64, 128):
+    z = torch.sort(torch.rand(N, S, device=dev, generator=g) * 4 + 2, -1)[0].contiguous()
+    raw = torch.empty(N, S, 4, device=dev); gates = torch.empty(N, S, 32, dtype=torch.int32, device=dev)
+    def run(S=S, z=z, raw=raw, gates=gates):
+        capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(packed), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), None, capi.stream())
+        return [raw, gates]
+    cases["decode_rays S=%d" % S] = run
+opts, scfg = render_options(64, 128)
+Hs = Ws = 320; fs = 0.5 * Ws / np.tan(0.5 * 0.6911112)
+ro2, rd2 = nvsr_amd.nerf_helpers.get_ray_bundle(Hs, Ws, fs, pose)
+def frame():
+    out = nvsr_amd.train_utils.eval_nerf(Hs, Ws, fs, mc, mf, ro2, rd2, opts, scene_id=sid, scene_config=scfg)
+    return [out[0], out[3]]
+cases["fused frame 320x320"] = frame
+torch.manual_seed(0)
+net = nvsr_amd.models.PlanesSR(nvsr_amd.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 256, "n_blocks": 4}}, "bilinear").to(dev).inner_model.eval()
+x = torch.randn(1, 48, 120, 120, device=dev, generator=g)
+def edsr():
+    with torch.no_grad():
+        return [net(x)]
+cases["EDSR 256x4 forward"] = edsr
+bits = lambda t: t.view(torch.int32) if t.dtype == torch.float32 else t
+ref = {k: [t.clone() for t in f()] for k, f in cases.items()}
+torch.cuda.synchronize()
+bad = {k: 0 for k in cases}; runs = {k: 0 for k in cases}
+t0 = time.time()
+while time.time() - t0 < secs:
+    for k, f in cases.items():
+        outs = f()
+        same = all(torch.equal(bits(a), bits(b)) for a, b in zip(outs, ref[k]))
+        runs[k] += 1
+        if not same:
+            bad[k] += 1
+            if bad[k] <= 2:
+                print("MISMATCH %s run %d: differing elements %s" % (k, runs[k], [int((bits(a) != bits(b)).sum()) for a, b in zip(outs, ref[k])]), flush=True)
+print("pid %d: " % os.getpid() + "; ".join("%s: %d mismatches of %d" % (k, bad[k], runs[k]) for k in cases), flush=True)
