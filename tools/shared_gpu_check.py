@@ -40,6 +40,25 @@ def edsr():
     with torch.no_grad():
         return [net(x)]
 cases["EDSR 256x4 forward"] = edsr
+# the gate-driven backward (float atomics: the order of the sums varies from launch to launch, so this case is held to a relative L2 of 1e-4
+# against the first result instead of to its bits -- the prologue race of round 5 gave non-finite or grossly wrong gradients)
+lib = capi.lib()
+TOL = {}
+for S in (64, 128):
+    z = torch.sort(torch.rand(N, S, device=dev, generator=g) * 4 + 2, -1)[0].contiguous()
+    raw = torch.empty(N, S, 4, device=dev); gates = torch.empty(N, S, 32, dtype=torch.int32, device=dev)
+    capi.call("nvsr_decode_rays_ex", C.byref(sc), capi.ptr(packed), N, S, capi.ptr(rays), capi.ptr(z), capi.ptr(raw), capi.ptr(gates), None, capi.stream())
+    g_raw = torch.randn(N, S, 4, device=dev, generator=g) * 1e-3
+    vws = torch.empty(lib.nvsr_view_grad_workspace_floats(N, S), device=dev)
+    packed_bwd = mf.packed_decoder_bwd()
+    def runb(S=S, z=z, gates=gates, g_raw=g_raw, vws=vws):
+        gpl = [torch.zeros_like(k) for k in keep]
+        gptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in gpl])
+        capi.call("nvsr_render_pass_backward_gates", C.byref(sc), capi.ptr(packed), capi.ptr(packed_bwd), N, S, capi.ptr(rays), capi.ptr(z),
+                  capi.ptr(g_raw), capi.ptr(gates), gptrs, capi.ptr(vws), None, capi.stream())
+        return gpl
+    cases["backward S=%d" % S] = runb
+    TOL["backward S=%d" % S] = 1e-4
 bits = lambda t: t.view(torch.int32) if t.dtype == torch.float32 else t
 ref = {k: [t.clone() for t in f()] for k, f in cases.items()}
 torch.cuda.synchronize()
@@ -48,7 +67,10 @@ t0 = time.time()
 while time.time() - t0 < secs:
     for k, f in cases.items():
         outs = f()
-        same = all(torch.equal(bits(a), bits(b)) for a, b in zip(outs, ref[k]))
+        if k in TOL:
+            same = all(bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm().clamp_min(1e-30)) <= TOL[k] for a, b in zip(outs[:3], ref[k][:3]))
+        else:
+            same = all(torch.equal(bits(a), bits(b)) for a, b in zip(outs, ref[k]))
         runs[k] += 1
         if not same:
             bad[k] += 1
