@@ -691,8 +691,8 @@ def test_step_metrics_from_the_packed_scalars(hip):
 
 def test_kernels_give_the_same_results_while_another_process_shares_the_gpu():
     """Two processes time-slicing the GPU (tools/shared_gpu_check.py, 25 s each, started together): the training forward (S = 64 / 128), a fused
-    320 x 320 frame and the EDSR forward repeat their first result BIT FOR BIT, the gate-driven backward (float atomics) within a relative L2 of
-    1e-4, launch after launch.  Round 5: a workgroup barrier was missing in front of the backward kernels' transposed alpha head (train_nerf.py:860-906
+    320 x 320 frame, the EDSR forward and the EDSR training forward + backward repeat their first result BIT FOR BIT, the gate-driven backward and a
+    whole training iteration's plane + decoder gradients (float atomics) within a relative L2 of 1e-4, launch after launch.  Round 5: a workgroup barrier was missing in front of the backward kernels' transposed alpha head (train_nerf.py:860-906
     through models.py:381-421's autograd); a process that had the GPU to itself never hit the race, two sharing it did in ~0.1 % of the launches
     (profiles/r05_backward_prologue_race.txt) -- which is what this test would see again."""
     import os, re, subprocess, sys
@@ -703,5 +703,5 @@ def test_kernels_give_the_same_results_while_another_process_shares_the_gpu():
     for p, out in zip(procs, outs):
         assert p.returncode == 0, out[-3000:]
         counts = re.findall(r"(\d+) mismatches of (\d+)", out)
-        assert len(counts) == 6, out[-3000:]
-        assert all(int(bad) == 0 and int(n) >= 20 for bad, n in counts), out[-3000:]
+        assert len(counts) == 8, out[-3000:]
+        assert all(int(bad) == 0 and int(n) >= 10 for bad, n in counts), out[-3000:]

@@ -59,6 +59,43 @@ for S in (64, 128):
         return gpl
     cases["backward S=%d" % S] = runb
     TOL["backward S=%d" % S] = 1e-4
+# a whole training iteration's gradients, planes + both decoders (forward with the weight-gradient record, compositor and its backward, resampler,
+# gate-driven backward with the record, the weight-gradient contractions) on fixed pixels and random numbers -- within 1e-4 of the first result
+mc2, mf2, sid2, pose2 = make_synthetic_scene(dev, 200, 32, seed=1, channels_last=True)
+for m_ in (mc2, mf2):
+    for n_, p_ in m_.named_parameters():
+        p_.requires_grad_("rot_mats" not in n_)
+    m_.train()
+params2 = list({id(p_): p_ for m_ in (mc2, mf2) for p_ in m_.parameters() if p_.requires_grad}.values())
+topts, tscfg = render_options(64, 64, perturb=True, noise=0.2)
+Nt = 2048
+selt = torch.randint(0, H, (Nt, 2), device=dev, generator=g)
+rot, rdt = nvsr_amd.training.get_ray_bundle_at(H, W, focal, pose2, selt)
+rnd = dict(t_rand=torch.rand(Nt, 64, device=dev, generator=g), u=torch.rand(Nt, 64, device=dev, generator=g),
+           noise_coarse=torch.randn(Nt, 64, device=dev, generator=g) * 0.2, noise_fine=torch.randn(Nt, 128, device=dev, generator=g) * 0.2)
+w_c, w_f = torch.randn(Nt, 3, device=dev, generator=g), torch.randn(Nt, 3, device=dev, generator=g)
+def train_grads():
+    out = nvsr_amd.train_utils.run_one_iter_of_nerf(H, W, focal, mc2, mf2, (rot, rdt), topts, sid2, mode="train", scene_config=tscfg, randoms=rnd)
+    loss = (out[0] * w_c).sum() + (out[3] * w_f).sum()
+    return [g_.contiguous() for g_ in torch.autograd.grad(loss, params2, allow_unused=False)]
+cases["training iteration gradients"] = train_grads
+TOL["training iteration gradients"] = 1e-4
+# the SR network's training forward + backward (data gradients, weight gradients with their fixed-order reduction): deterministic, bit for bit
+net_t = nvsr_amd.models.PlanesSR(nvsr_amd.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 256, "n_blocks": 3}}, "bilinear").to(dev).inner_model
+geom = list(net_t.geometry)
+arith = capi.resolve_conv_arithmetic(None)
+nat = net_t.natural_blob()
+pk, pkd = torch.ops.nvsr.pack_edsr(nat, geom, False), torch.ops.nvsr.pack_edsr(nat, geom, True)
+xt = torch.randn(1, 48, 70, 90, device=dev, generator=g)
+gy_t = None
+def sr_train():
+    global gy_t
+    out, acts = torch.ops.nvsr.edsr_train(xt, nat, pk, pkd, geom, arith)
+    if gy_t is None:
+        gy_t = torch.randn(out.shape, device=dev, generator=g)
+    gnat, dx = torch.ops.nvsr.edsr_backward(xt, acts, pkd, geom, gy_t, True, arith)
+    return [out, gnat, dx]
+cases["EDSR 256x3 training forward + backward"] = sr_train
 bits = lambda t: t.view(torch.int32) if t.dtype == torch.float32 else t
 ref = {k: [t.clone() for t in f()] for k, f in cases.items()}
 torch.cuda.synchronize()
@@ -68,7 +105,8 @@ while time.time() - t0 < secs:
     for k, f in cases.items():
         outs = f()
         if k in TOL:
-            same = all(bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm().clamp_min(1e-30)) <= TOL[k] for a, b in zip(outs[:3], ref[k][:3]))
+            cmp_ = list(zip(outs, ref[k]))[:3] if k.startswith("backward") else list(zip(outs, ref[k]))      # (the backward alone: its view plane goes through a second kernel)
+            same = all(bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm().clamp_min(1e-30)) <= TOL[k] for a, b in cmp_)
         else:
             same = all(torch.equal(bits(a), bits(b)) for a, b in zip(outs, ref[k]))
         runs[k] += 1
