@@ -30,14 +30,22 @@ constexpr int BL_WORDS = BL_FRAGS * 256;                 // 208896
 // ---- and, behind those, the same fragments as 2 f16 limbs (round 3; limb_core.h: round to nearest, UNSCALED -- a transposed weight's low
 // limb is a subnormal below |w| = 0.125, absolute error <= 2^-25: about 1e-6 of a typical weight, three orders inside the tolerance of a
 // gradient, and the accumulator of one layer is the operand of the next without a rescaling multiply): the same 34 chunks, 16 fragments each
+// Round 5: the rgb layer-0^T is ONE [192 x 128] product, not four [48 (padded to 64) x 128] ones -- the four planes' shares of W0 are contiguous rows
+// and all multiply the same gradient, so the 192 rows are cut into THREE pairs of 32-row blocks (rows 64 q .. 64 q + 63 = plane boundaries at 48, 96,
+// 144) instead of four padded pairs: 144 instead of 192 MFMAs (f16 limbs), 6 instead of 8 chunks; the kernel re-assembles a plane's 48 rows from
+// the pair(s) that hold them (static register renames).  The density layer-0^T keeps its padded pair.  RGB0_PAIRS = 4 restores the old layout.
+#ifndef BL_RGB0_PAIRS
+#define BL_RGB0_PAIRS 3
+#endif
 template <int LF>
 struct BLimb {
     static constexpr int HID_FRAGS = 32 * LF, L0_FRAGS = 16 * LF, CHUNK_FRAGS = 8 * LF;
-    static constexpr int FRAGS = 6 * HID_FRAGS + 5 * L0_FRAGS, CHUNK_WORDS = CHUNK_FRAGS * 256, WORDS = FRAGS * 256;
-    static constexpr int OFFSET = LF == 3 ? 0 : 6 * 96 * 256 + 5 * 48 * 256;      // words behind B_TOTAL
+    static constexpr int FRAGS = 6 * HID_FRAGS + (1 + BL_RGB0_PAIRS) * L0_FRAGS, CHUNK_WORDS = CHUNK_FRAGS * 256, WORDS = FRAGS * 256;
+    static constexpr int CHUNKS = FRAGS / CHUNK_FRAGS;                             // 32 (34 with four padded pairs)
+    static constexpr int OFFSET = LF == 3 ? 0 : 6 * 96 * 256 + 5 * 48 * 256;      // words behind B_TOTAL (the regions keep the places of the four-pair layout)
 };
-static_assert(BLimb<3>::WORDS == BL_WORDS && BLimb<3>::CHUNK_WORDS == BL_CHUNK_WORDS, "3-limb region");
-static_assert(B_TOTAL + BL_WORDS + BLimb<2>::WORDS == NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
+static_assert(BLimb<3>::WORDS <= BL_WORDS && BLimb<3>::CHUNK_WORDS == BL_CHUNK_WORDS, "3-limb region");
+static_assert(B_TOTAL + BL_WORDS + BLimb<2>::WORDS <= NVSR_DECODER_PACKED_BWD_FLOATS, "backward blob size");
 
 __device__ __forceinline__ void apply_mask(const Masks& k, f32x16 (&g)[4]) {
 #pragma unroll

@@ -11,7 +11,7 @@
 // the length.  Skeleton as in decode_limb.hip, except that a wave's 32-point tile is 32 CONSECUTIVE SAMPLES OF ONE RAY (their texel cells
 // repeat, so the scatter merges runs of samples into one set of atomics); two independent 4-wave workgroups per CU cover each other's
 // splits, masks, transposes and atomics; the weights stream through a ring of two 24-KB slots
-// (2 K-blocks of a hidden layer / 4 of a plane's layer 0), 34 chunks per step.  Scatter into the planes, view-plane rows and the record of
+// (2 K-blocks of a hidden layer / 4 of a layer-0 block pair), 32 chunks per step (round 5: the rgb layer-0^T as three 64-row pairs, bwd_core.h).  Scatter into the planes, view-plane rows and the record of
 // the pre-activation gradients are those of the f32 kernel (bwd_core.h).
 #include <type_traits>
 
@@ -85,7 +85,13 @@ __global__ void pack_decoder_bwd_limbs_kernel(const float* __restrict__ nat, uns
             const int kb = r / (2 * LF), ob = (r % (2 * LF)) / LF;
             const int k = 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
             const int c = 32 * ob + (lane & 31);
+#if BL_RGB0_PAIRS == 3
+            // rgb: pair p holds rows 64 p + c of the [192 x 128] layer-0^T (the four planes' 48 rows each, contiguous in W0's input index)
+            if (rgb) v = nat[N_RGB_W0 + k * (4 * C) + 64 * p + c];
+            else if (c < C) v = nat[N_DEN_W0 + k * C + c];
+#else
             if (c < C) v = rgb ? nat[N_RGB_W0 + k * (4 * C) + C * p + c] : nat[N_DEN_W0 + k * C + c];
+#endif
         }
         const int t = hidden ? (f % FH) % LF : ((f - 3 * FH) % F0) % LF;
         unsigned bits = 0;
@@ -397,20 +403,8 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         if (rok) record_grad(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 4, accB, 22)
         if (rok) record_grad(rec.Gr, q, h, accB);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            f32x16 gF[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3 && LF != 2) ? gD[b][rr] : 0.0f;
-            BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
-            if constexpr (LF == 2) {        // the rgb part back to its true magnitude, plus the density part (position planes)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? fmaf(gF[b][rr], gu_r, gD[b][rr]) : gF[b][rr] * gu_r;
-            }
+        // what happens to a plane's finished feature gradient gF (rows c = 32 b + (r & 3) + 8 (r >> 2) + 4 h, TRUE magnitudes): view rows or scatter
+        auto emit_plane = [&](int d, f32x16 (&gF)[2]) {
             if (gp.p[d] && !(BL_ABLATE & 4)) {
                 if (d == 3 && gview) {
                     // every sample of the ray taps the same four view-plane texels: the tile's 32 gradient rows are summed here, ONE row
@@ -450,7 +444,80 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #endif
                 }
             }
+        };
+#if BL_RGB0_PAIRS == 3
+        // Three pairs of 32-row blocks cover the 192 rows of the rgb layer-0^T; pair q holds rows 64 q .. 64 q + 63:
+        //   P0 = plane 0 (rows 0..47) + plane 1's channels 0..15;  P1 = plane 1's channels 16..47 + plane 2's channels 0..31;
+        //   P2 = plane 2's channels 32..47 + plane 3 (the view plane).
+        // Register r of block b is row 32 b + (r & 3) + 8 (r >> 2) + 4 h: registers 0..7 are rows 0..15 of the block, 8..15 rows 16..31, for either
+        // lane half -- so a 16-row shift is a shift by 8 registers and the planes' rows are re-assembled by renaming registers.
+        const float ur = LF == 2 ? gu_r : 1.0f;                    // (f16 limbs: the rgb chain back to its true magnitude)
+        auto val = [&](float a) { return LF == 2 ? a * ur : a; };
+        auto vald = [&](float a, float d_) { return LF == 2 ? fmaf(a, ur, d_) : a + d_; };        // + the density part (position planes)
+        f32x16 P[2], gF[2];
+        float carry[16];
+        auto zeroP = [&]() {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) P[b][rr] = 0.0f;
+        };
+        zeroP();
+        BL_LAYER0_T(accB, P, 26, false)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {                          // plane 0 = P0 rows 0..47
+            gF[0][rr] = vald(P[0][rr], gD[0][rr]);
+            gF[1][rr] = rr < 8 ? vald(P[1][rr], gD[1][rr]) : 0.0f;
         }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) carry[rr] = vald(P[1][rr + 8], gD[0][rr]);             // plane 1's channels 0..15 (P0 rows 48..63)
+        emit_plane(0, gF);
+        zeroP();
+        BL_LAYER0_T(accB, P, 28, false)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                           // plane 1 = [carry | P1 rows 0..31]
+            gF[0][rr] = carry[rr];
+            gF[0][rr + 8] = vald(P[0][rr], gD[0][rr + 8]);         // channels 16..31
+            gF[1][rr] = vald(P[0][rr + 8], gD[1][rr]);             // channels 32..47
+            gF[1][rr + 8] = 0.0f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) carry[rr] = vald(P[1][rr], gD[0][rr]);                // plane 2's channels 0..31 (P1 rows 32..63)
+        emit_plane(1, gF);
+        zeroP();
+        BL_LAYER0_T(accB, P, 30, true)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {                          // plane 2 = [carry | P2 rows 0..15]
+            gF[0][rr] = carry[rr];
+            gF[1][rr] = rr < 8 ? vald(P[0][rr], gD[1][rr]) : 0.0f;
+        }
+        emit_plane(2, gF);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                           // plane 3 (view) = P2 rows 16..63: no density part
+            gF[0][rr] = val(P[0][rr + 8]);
+            gF[0][rr + 8] = val(P[1][rr]);
+            gF[1][rr] = val(P[1][rr + 8]);
+            gF[1][rr + 8] = 0.0f;
+        }
+        emit_plane(3, gF);
+#else
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f32x16 gF[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3 && LF != 2) ? gD[b][rr] : 0.0f;
+            BL_LAYER0_T(accB, gF, 26 + 2 * d, d == 3)
+            if constexpr (LF == 2) {        // the rgb part back to its true magnitude, plus the density part (position planes)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) gF[b][rr] = (d < 3) ? fmaf(gF[b][rr], gu_r, gD[b][rr]) : gF[b][rr] * gu_r;
+            }
+            emit_plane(d, gF);
+        }
+#endif
 #undef BL_LAYER0_T
 #undef BL_HIDDEN_T
 #undef BL_HBLOCK
