@@ -14,6 +14,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _poison_uninitialised_tensors():
+    """NVSR_POISON_EMPTY=1 (a diagnostic run of the suite, round 5): every floating-point tensor that torch.empty / empty_like / new_empty hands out
+    is filled with NaN, so a kernel that reads memory nobody wrote -- or leaves part of an output it promises unwritten -- is loud.  In an ordinary
+    run the caching allocator hands such a kernel the previous iteration's block: stale values of the right shape and magnitude, which is how the
+    refine workload's once-per-process weight packing stayed invisible for most of a round."""
+    import torch
+
+    def wrap(fn):
+        def poisoned(*a, **k):
+            t = fn(*a, **k)
+            if t.is_floating_point() and t.numel():
+                t.fill_(float("nan"))
+            return t
+        return poisoned
+
+    torch.empty = wrap(torch.empty)
+    torch.empty_like = wrap(torch.empty_like)
+    torch.Tensor.new_empty = wrap(torch.Tensor.new_empty)
+
+
+if os.environ.get("NVSR_POISON_EMPTY") == "1":
+    _poison_uninitialised_tensors()
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
