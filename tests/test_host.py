@@ -612,3 +612,31 @@ def test_a_change_of_mode_drops_the_derived_copies():
     assert net._packed_cache == ("key", "blob")
     net.train()
     assert net._packed_cache is None
+
+
+def test_loss_pair_sum_off_the_device_is_torchs():
+    """training.mse_loss_pair_sum on CPU tensors (no HIP launch: torch's own mse_loss and addition, train_nerf.py:893-905) -> (coarse, fine, their sum,
+    no packed tensor), differentiable like the two losses; TrainStep.apply_gradients seeds a scalar loss's backward from its cached one (the same
+    gradients as loss.backward()); the blob cache of EDSR.packed_weights keys on the arithmetic it was packed for (logic only: no GPU here)."""
+    import nvsr_amd
+    T = nvsr_amd.training
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(7, 3, generator=g, requires_grad=True)
+    b = torch.rand(7, 3, generator=g, requires_grad=True)
+    t = torch.rand(7, 3, generator=g)
+    lc, lf, both, packed = T.mse_loss_pair_sum(a, b, t)
+    assert packed is None
+    assert torch.equal(lc, torch.nn.functional.mse_loss(a, t)) and torch.equal(lf, torch.nn.functional.mse_loss(b, t)) and torch.equal(both, lc + lf)
+    both.backward()
+    assert torch.allclose(a.grad, 2 * (a.detach() - t) / a.numel()) and torch.allclose(b.grad, 2 * (b.detach() - t) / b.numel())
+    # the cached seed: two steps in a row, the gradients of plain backward()
+    q = torch.nn.Parameter(torch.randn(4))
+    step = T.TrainStep(None, None, None, {"LR_planes"}, planes_optimizer=torch.optim.SGD([q], lr=0.0))
+    for _ in range(2):
+        q.grad = None
+        step.apply_gradients((q ** 3).sum())
+        assert torch.allclose(q.grad, 3 * q.detach() ** 2)
+    assert step.__dict__["_seed"].shape == () and float(step.__dict__["_seed"]) == 1.0
+    # PACK_ALL_ARITHMETICS is the header's value
+    hdr = open(os.path.join(ROOT, "include", "nvsr.h")).read()
+    assert "#define NVSR_PACK_ALL_ARITHMETICS (%d)" % nvsr_amd.capi.PACK_ALL_ARITHMETICS in hdr
