@@ -71,6 +71,98 @@ ARITHMETIC = {
 }
 CAMERA_ANGLE_X = 0.6911112
 
+# ---- the line the driver parses -------------------------------------------------------------------------------------------------------
+# Round 5's line had grown to 28 KB and the driver could not parse it (BENCH_r05.json: parsed null).  The LAST stdout line is now a compact
+# record of at most COMPACT_LIMIT characters; the full record goes to bench_full.json next to this script (and to gpurun_out/ when that
+# directory exists) and to stderr -- never after the compact line.  tests/test_host.py holds the size and the keys on a maximal record.
+COMPACT_LIMIT = 4096
+SHORT_DTYPE = {"f32": "f32", "bf16x3": "f32 as 3 bf16 limbs (6 MFMA products, f32 acc)", "f16x2": "f32 as 2 f16 limbs (3 MFMA products, f32 acc)"}
+
+
+def _short(v, sig=6):
+    """floats to `sig` significant digits (integers and everything else untouched; `value` / `ms_per_step` keep every digit: the driver and
+    the rehearsal tests re-derive one from the other)"""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if np.isfinite(v) else None
+    if isinstance(v, dict):
+        return {k: (x if k in ("value", "ms_per_step") and isinstance(x, float) and np.isfinite(x) else _short(x, sig)) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x, sig) for x in v]
+    return v
+
+
+def _compact_roofline(r):
+    if not r:
+        return None
+    out = {"kernel": str(r.get("kernel_short") or r.get("kernel", ""))[:72]}
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_flop_per_launch", "algorithmic_flop_per_step",
+              "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step"):
+        if k in r:
+            out[k] = r[k]
+    return out
+
+
+def compact_record(full):
+    """The driver's line: the contract's keys + roofline + cpu_baseline + one row per other workload, short strings only."""
+    arith = full.get("arithmetic") or full.get("decoder_arithmetic") or full.get("conv_arithmetic")
+    cfg = full.get("config", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    out["metric"] = str(out["metric"])[:120]
+    out["dtype"] = SHORT_DTYPE.get(arith, str(full.get("dtype", ""))[:48])
+    out["data"] = full.get("data", "synthetic")
+    out["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:160]}
+    for k in ("rays_per_step_per_gpu", "planes_per_step_per_gpu", "partition_short", "partition"):
+        if k in cfg and not (k == "partition" and "partition" in out["config"]):
+            out["config"]["partition" if k == "partition_short" else k] = cfg[k] if not isinstance(cfg[k], str) else cfg[k][:48]
+    out["roofline"] = _compact_roofline(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: (cb[k] if k != "sample" else str(cb.get("sample_short") or cb[k])[:100])
+                               for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+    for k in ("psnr_vs_oracle_db", "decoder_evals_per_s_per_gpu", "host_issue_ms_per_step"):
+        if k in full:
+            out[k] = full[k]
+    c = full.get("collectives")
+    if c:
+        out["collectives"] = {"backend": c.get("backend"), "rccl_ranks": c.get("rccl_ranks"), "world_size": c.get("world_size")}
+    ow = full.get("other_workloads")
+    if ow:
+        rows = {}
+        for name, r in ow.items():
+            if "error" in r:
+                rows[name] = {"error": str(r["error"])[:80]}
+                continue
+            rf = r.get("roofline") or {}
+            rows[name] = {"value": r.get("value"), "unit": r.get("unit"), "ms_per_step": r.get("ms_per_step"), "roofline_bound": rf.get("bound"),
+                          "roofline_frac": rf.get("frac"), "traffic": rf.get("traffic"),
+                          "algorithmic_bytes": rf.get("algorithmic_bytes_per_step", rf.get("algorithmic_bytes_per_launch")),
+                          "cpu_baseline_value": (r.get("cpu_baseline") or {}).get("value")}
+        out["other_workloads"] = rows
+    out["full_record"] = "bench_full.json"
+    out = _short(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:            # never the reason a line cannot be parsed: drop the optional parts, widest first
+        for k in ("other_workloads", "collectives", "host_issue_ms_per_step"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    assert len(line) <= COMPACT_LIMIT and "\n" not in line, len(line)
+    return line
+
+
+def emit(full, path=None):
+    """full record -> bench_full.json (+ gpurun_out/bench_full.json; + `path` = --full-record) and stderr; compact record -> the last stdout line"""
+    text = json.dumps(full)
+    for f in [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)] + ([path] if path else []):
+        try:
+            with open(f, "w") as fh:
+                fh.write(text + "\n")
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (f, e), file=sys.stderr)
+    print("BENCH_FULL_RECORD " + text, file=sys.stderr, flush=True)
+    print(compact_record(full), flush=True)
+
 
 class Opt:
     def __init__(self, **kw):
@@ -533,7 +625,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
               # time the host needed to ENQUEUE a step (python + launches; the GPU runs behind): a value near ms_per_step = the step waits for the host
-              "host_issue_ms_per_step": host_issue_ms,
+              "host_issue_ms_per_step": host_issue_ms, "arithmetic": capi.get_decoder_arithmetic(),
               "launch": launch,
               "dtype": {"f32": ARITHMETIC["f32"]["dtype"], "bf16x3": ARITHMETIC["bf16x3"]["dtype"],
                         "f16x2": "f32 (forward -- with or without the weight-gradient record -- and gate-driven backward of every pass: GEMM operands split "
@@ -604,7 +696,7 @@ def bench_train(args, nvsr_amd, dist, dev, rank, world):
             osc = o.scene(pl, mc.box_coords[sid].numpy())
             dc = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
             df = o.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
-            n = 256                                  # ~10 s of single-threaded CPU work
+            n = 96 if getattr(args, "cpu_cache", None) is not None else 256      # ~10 s of single-threaded CPU work (~4 s as a side workload)
             rn = rays[:n].cpu().numpy()
             gg = np.full((n, 3), 1e-3, np.float32)
             t0 = time.perf_counter()
@@ -712,23 +804,35 @@ def bench_sr(args, nvsr_amd, dist, dev, rank, world):
                                                "algorithmic_tflop": {"forward": 6.74, "backward": 13.48},
                                                "achieved_tflops": {"forward": 6.74 / tf if tf else None, "backward": 13.48 / tb if tb else None}}
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.oracle import Oracle
-            o = Oracle(f32=True)
-            x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
-            w = np.random.default_rng(1).standard_normal((256, 256, 3, 3), dtype=np.float32) * 0.01
-            o.conv3x3(x[:, :10, :10], w)
-            o.conv3x3(x, w)
-            fl = 2 * 256 * 256 * 9 * 64 * 64
-            reps, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 10.0 and reps < 20000:        # ~10 s of CPU work
-                o.conv3x3(x, w)
-                reps += 1
-            t = time.perf_counter() - t0
-            cores = os.cpu_count() or 1
-            result["cpu_baseline"] = {"value": (reps * fl / t) / (flop_scene / 3), "unit": "planes/s", "cores": cores, "kind": "port",
+            cv = cpu_conv_rate(args, 10.0)
+            result["cpu_baseline"] = {"value": cv["flops"] / (flop_scene / 3), "unit": "planes/s", "cores": cv["cores"], "kind": "port",
                                       "sample": "%d x one 256->256 3x3 conv on a 66x66 tile (%.2f GFLOP each, %.1f s in total, C oracle fp32 OpenMP "
-                                                "%d threads), scaled by FLOPs to a whole plane" % (reps, fl / 1e9, t, cores)}
+                                                "%d threads), scaled by FLOPs to a whole plane" % (cv["reps"], cv["gflop_each"], cv["seconds"], cv["cores"])}
         return result
+
+
+def cpu_conv_rate(args, budget_s):
+    """FLOP/s of the C oracle's 256 -> 256 3 x 3 convolution on a 66 x 66 tile (fp32, OpenMP over all host cores), timed for ~budget_s; measured once
+    per process when the side workloads of the default line share it (args.cpu_cache)."""
+    cache = getattr(args, "cpu_cache", None)
+    if cache is not None and "conv" in cache:
+        return cache["conv"]
+    from oracle.oracle import Oracle
+    o = Oracle(f32=True)
+    x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
+    w = np.random.default_rng(1).standard_normal((256, 256, 3, 3), dtype=np.float32) * 0.01
+    o.conv3x3(x[:, :10, :10], w)
+    o.conv3x3(x, w)
+    fl = 2 * 256 * 256 * 9 * 64 * 64
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and reps < 20000:
+        o.conv3x3(x, w)
+        reps += 1
+    t = time.perf_counter() - t0
+    out = {"flops": reps * fl / t, "reps": reps, "seconds": t, "gflop_each": fl / 1e9, "cores": os.cpu_count() or 1}
+    if cache is not None:
+        cache["conv"] = out
+    return out
 
 
 def edsr_flops(Hp, Wp, cin=48, cout=48, hid=256, nb=32, n_up=2):
@@ -909,11 +1013,14 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     finally:
         sr.forward_many = real_many
     pad = int(sr.inner_model.required_padding)
-    crops, fwd_flop = {}, 0.0
+    crops, fwd_flop, pass_bytes = {}, 0.0, 0.0
     for name, roi in rois.items():
         (l0, h0), (l1, h1) = sr_roi_pixels(R, roi)
         crops[name] = {"lr_rows": [l0, h0], "lr_cols": [l1, h1], "network_input": [h0 - l0 + 2 * pad, h1 - l1 + 2 * pad]}
         fwd_flop += edsr_flops(h0 - l0 + 2 * pad, h1 - l1 + 2 * pad)
+        # one pass over a crop, counted like the sr workload counts a plane: the weights once + the activations in / out of the 66 wide layers at the
+        # crop's mid-network size (network input - 66)
+        pass_bytes += 173e6 + 2 * 4 * 256 * (h0 - l0 + 2 * pad - 66) * (h1 - l1 + 2 * pad - 66) * 66
     t_fwd = split["PlanesSR forward (3 ROI crops, keeps activations)"] * 1e-3
     t_bwd = split["PlanesSR backward (3 ROI crops: data + weight gradients)"] * 1e-3
     sr_flop = 3.0 * fwd_flop                                  # forward + data gradient + weight gradient (dx of conv_input is 0.3 % and counted)
@@ -929,6 +1036,7 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
                           "traffic": None if llff else pmc_traffic("refine_" + args.refine_what, arith["dtype"]),      # (the counter passes ran the blender scene)
                           "kernel_ms": 1e3 * (t_fwd + t_bwd), "kernel_ms_source": "HIP events on the launch stream around the PlanesSR phases of an iteration, this process",
                           "algorithmic_flop_per_step": sr_flop, "algorithmic_flop_forward": fwd_flop,
+                          "algorithmic_bytes_per_step": 3.0 * pass_bytes,                 # forward, data-gradient and weight-gradient pass over every crop
                           "forward": {"ms": 1e3 * t_fwd, "achieved": fwd_flop / t_fwd / 1e12, "frac": fwd_flop / t_fwd / 1e12 / peak},
                           "backward": {"ms": 1e3 * t_bwd, "achieved": 2 * fwd_flop / t_bwd / 1e12, "frac": 2 * fwd_flop / t_bwd / 1e12 / peak},
                           "render_algorithmic_flop_per_step": render_flop,
@@ -940,39 +1048,38 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     rec = pmc_record()
     if rec is not None and not llff and rec.get("refine_" + args.refine_what, {}).get("sr_backward_split_ms"):
         result["sr_backward_split_ms"] = dict(rec["refine_" + args.refine_what]["sr_backward_split_ms"], source=pmc_source())
-    if world == 1 and not args.no_cpu_baseline and not llff:        # (the CPU leg times the blender scene's rays; `--refine-scene blender` carries it)
+    if world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle, decoder_blob
-        o = Oracle(f32=True)
-        x = np.random.default_rng(0).standard_normal((256, 66, 66), dtype=np.float32)
-        w = np.random.default_rng(1).standard_normal((256, 256, 3, 3), dtype=np.float32) * 0.01
-        o.conv3x3(x[:, :10, :10], w)
-        fl = 2 * 256 * 256 * 9 * 64 * 64
-        reps_c, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 8.0 and reps_c < 20000:
-            o.conv3x3(x, w)
-            reps_c += 1
-        t_conv = time.perf_counter() - t0
-        cores = os.cpu_count() or 1
-        o64 = Oracle(f32=False)
-        pl = [mc.planes_[M.get_plane_name(sid, d)].detach().cpu().numpy() for d in range(4)]
-        osc = o64.scene(pl, mc.box_coords[sid].numpy())
-        dc = o64.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
-        df = o64.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
-        n = 192
-        batch = torch.stack(T.get_ray_bundle_at(H, W, focal, pose, torch.randint(0, H, (n, 2), device=dev)), 0)
-        rn = nvsr_amd.train_utils.pack_rays(batch[0], batch[1], 2.0, 6.0).cpu().numpy()
-        gg = np.full((n, 3), 1e-3, np.float32)
-        t0 = time.perf_counter()
-        o64.render_rays(osc, dc, df, rn, Nc, Nf)
-        o64.render_backward(osc, [p_.shape for p_ in pl], dc, df, rn, Nc, Nf, gg, gg)
-        t_rays = time.perf_counter() - t0
+        cv = cpu_conv_rate(args, 8.0)
+        cache = getattr(args, "cpu_cache", None)
+        key = ("rays", Nc, Nf)
+        if cache is not None and key in cache:
+            n, t_rays = cache[key]
+        else:
+            # (Blender-style rays of the same sample counts also for the LLFF scene: the oracle's cost per ray depends on the sample counts only)
+            o64 = Oracle(f32=False)
+            pl = [mc.planes_[M.get_plane_name(sid, d)].detach().cpu().numpy() for d in range(4)]
+            osc = o64.scene(pl, mc.box_coords[sid].numpy())
+            dc = o64.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mc.state_dict().items()}))
+            df = o64.decoder(decoder_blob({k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}))
+            n = 96 if cache is not None else 192
+            batch = torch.stack(T.get_ray_bundle_at(800, 800, 0.5 * 800 / np.tan(0.5 * CAMERA_ANGLE_X), torch.from_numpy(pose_spherical(30.0, -30.0, 4.0)).to(dev),
+                                                    torch.randint(0, 800, (n, 2), device=dev)), 0)
+            rn = nvsr_amd.train_utils.pack_rays(batch[0], batch[1], 2.0, 6.0).cpu().numpy()
+            gg = np.full((n, 3), 1e-3, np.float32)
+            t0 = time.perf_counter()
+            o64.render_rays(osc, dc, df, rn, Nc, Nf)
+            o64.render_backward(osc, [p_.shape for p_ in pl], dc, df, rn, Nc, Nf, gg, gg)
+            t_rays = time.perf_counter() - t0
+            if cache is not None:
+                cache[key] = (n, t_rays)
         # one iteration on the host = the convolutions' FLOP at the measured conv rate + 4096 rays at the measured render rate
-        t_iter = sr_flop / (reps_c * fl / t_conv) + N * t_rays / n
-        result["cpu_baseline"] = {"value": N / t_iter, "unit": "rays/s", "cores": cores, "kind": "port",
+        t_iter = sr_flop / cv["flops"] + N * t_rays / n
+        result["cpu_baseline"] = {"value": N / t_iter, "unit": "rays/s", "cores": cv["cores"], "kind": "port",
                                   "sample": "C oracle: %d x one 256->256 3x3 convolution on a 66x66 tile (fp32, OpenMP %d threads, %.1f s) scaled by FLOP to the "
                                             "%.1f TFLOP of the iteration's three PlanesSR forward + backward passes, + %d rays of the render step (forward + "
                                             "analytic plane backward, double accumulation, single thread, %.1f s) scaled to 4096 rays"
-                                            % (reps_c, cores, t_conv, sr_flop / 1e12, n, t_rays)}
+                                            % (cv["reps"], cv["cores"], cv["seconds"], sr_flop / 1e12, n, t_rays)}
     return result
 
 
@@ -1005,6 +1112,8 @@ def main():
                     help="--workload refine: blender = 4096 rays of an 800x800 Lego-like view, 64+64 samples (the YAMLs' values); llff = BASELINE configs[4] as "
                          "written: an LLFF-'fern'-like forward-facing 378x504 view, NDC rays, 64+128 samples")
     ap.add_argument("--no-split", action="store_true", help="--workload refine: skip the three probe iterations of the phase split (counter passes)")
+    ap.add_argument("--full-record", default=None, metavar="PATH",
+                    help="also write the full record (every key; the stdout line is its compact form, <= 4 KB) to PATH")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="--workload render, N = 1: do not append the short train / sr runs (`other_workloads` of the line)")
     args = ap.parse_args()
@@ -1061,7 +1170,7 @@ def main():
         res = {"train": bench_train, "sr": bench_sr, "refine": bench_refine}[args.workload](args, nvsr_amd, dist, dev, rank, world)
         if res is not None:          # rank 0
             res["collectives"] = comm
-            print(json.dumps(res), flush=True)
+            emit(res, args.full_record)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -1269,7 +1378,8 @@ def main():
             # the three 200^2 planes of a scene (+ its training forward / backward per plane).  Same JSON contract per entry.
             del out
             sub = argparse.Namespace(**vars(args))
-            sub.no_cpu_baseline, sub.no_modes = True, False
+            # their CPU legs share one convolution probe and one render probe per sample count (sub.cpu_cache), ~25 s of host time in all
+            sub.no_cpu_baseline, sub.no_modes, sub.cpu_cache = args.no_cpu_baseline, False, {}
             other = {}
             for wl, fn, steps, warm, extra in (("train", bench_train, 30, 5, {"train_what": "planes"}),
                                                ("train_decoder", bench_train, 20, 3, {"train_what": "planes+decoder"}),
@@ -1287,7 +1397,7 @@ def main():
                 torch.cuda.empty_cache()
             result["other_workloads"] = other
         result["collectives"] = comm
-        print(json.dumps(result), flush=True)
+        emit(result, args.full_record)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

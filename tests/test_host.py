@@ -566,6 +566,86 @@ def test_bench_edsr_flop_count_matches_the_survey():
     assert bench.sr_roi_pixels(200, [-0.5, 0.0, 0.25, 0.991]) == [(49, 126), (99, 200)]
 
 
+def _maximal_bench_record():
+    """a record at least as wide as the widest bench.py has ever produced (round 5: 28 KB): long prose in every string, every optional block,
+    seven side workloads each with its own prose"""
+    prose = "x" * 400
+    roof = {"kernel": "render_pass3_kernel<2> (fine pass, S=192) " + prose, "bound": "mfma", "achieved": 405.492643607369, "peak": 838.8666666666667,
+            "unit": "TFLOP/s", "frac": 0.4833815190424013, "traffic": 10882250496.0, "traffic_source": prose, "kernel_ms": 78.50886535644531,
+            "kernel_ms_source": prose, "algorithmic_flop_per_launch": 31834767360000, "algorithmic_gather_bytes_per_launch": 377487360000,
+            "algorithmic_bytes_per_step": 56.1e9, "peak_note": prose, "executed_mfma_tflops": 1216.477930822107,
+            "sustained_pipe_rate": {k: 1234.5678901 for k in "abcdefgh"}, "forward": {"ms": 1.0, "achieved": 2.0, "frac": 0.5}}
+    cpu = {"value": 8213.730830436181, "unit": "rays/s", "cores": 256, "kind": "port", "sample": prose, "evals_per_s": 2102715.09,
+           "reference_on_cpu": {"value": 1021.45, "unit": "rays/s", "cores": 8, "kind": "reference", "sample": prose}}
+    side = {"metric": prose, "value": 47853.85127473234, "unit": "rays/s", "n_gpus": 1, "steps": 5, "warmup": 2, "ms_per_step": 85.59394679614343,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "host_issue_ms_per_step": 18.767876201309264, "dtype": prose,
+            "conv_arithmetic": "f16x2", "data": "synthetic", "config": {"workload": prose, "rays_per_step_per_gpu": 4096, "parallelism": prose},
+            "split_ms": {prose[:90] + str(i): 1.2345678 for i in range(6)}, "roi_crops": {"p%d" % i: {"lr_rows": [27, 142], "lr_cols": [12, 156]} for i in range(3)},
+            "roofline": dict(roof), "cpu_baseline": dict(cpu), "sr_backward_split_ms": {prose[:80]: 27.9}}
+    full = {"metric": "rendered rays/sec (64+128 samples) at 800x800 Lego-like view", "value": 6038413.3705886705, "unit": "rays/s", "n_gpus": 8, "steps": 20,
+            "warmup": 5, "ms_per_step": 105.98810659721494, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prose, "data": "synthetic",
+            "decoder_arithmetic": "f16x2", "config": {"workload": prose, "rays_per_step_per_gpu": 640000, "decoder_evals_per_ray": 256, "partition": "rows",
+                                                      "ray_order": prose, "parallelism": prose},
+            "decoder_evals_per_s_per_gpu": 1545833822.8706996, "roofline_counters": {"note": prose, "source": prose, "mfma_busy_frac": 0.5766},
+            "roofline": roof, "hbm_stages": {prose[:60] + str(i): {"ms": 0.0235, "GB/s": 651.9, "frac_of_hbm_peak": 0.08} for i in range(5)},
+            "arithmetic_modes": {m: {"rays_per_s": 1.9e6, "ms_per_step": 333.06, "psnr_vs_oracle_db": 86.9} for m in ("f32", "bf16x3", "f16x2")},
+            "cpu_baseline": cpu, "frame_error_evidence": {m: {prose[:50] + str(i): 0.123456789 for i in range(10)} for m in ("f32", "bf16x3", "f16x2")},
+            "psnr_vs_oracle_db": 86.46044072986612, "psnr_vs_oracle": {"checker": prose},
+            "other_workloads": {n: dict(side) for n in ("train", "train_decoder", "sr", "refine", "refine_sr_only", "refine_llff_ndc", "one_more_for_margin")},
+            "collectives": {"backend": "nccl", "rccl_ranks": 8, "world_size": 8, "rank_devices": ["cuda:%d (AMD Instinct MI355X)" % i for i in range(8)]}}
+    full["other_workloads"]["sr"]["unit"] = "planes/s"
+    full["other_workloads"]["failed"] = {"error": "NvsrError: " + prose}
+    return full
+
+
+def test_bench_line_is_compact_and_complete():
+    """BENCH_r05.json.parsed was null because the line had grown to 28 KB.  The LAST stdout line of bench.py is
+    bench.compact_record(full): valid JSON, one line, <= 4096 characters whatever the full record holds, and it carries the contract's keys,
+    `roofline` (with frac / traffic / kernel_ms) and `cpu_baseline`, plus one short row per side workload (with its CPU baseline and traffic)."""
+    import json
+    import bench
+    full = _maximal_bench_record()
+    assert len(json.dumps(full)) > 28000                       # wider than round 5's line
+    line = bench.compact_record(full)
+    assert "\n" not in line and len(line) <= bench.COMPACT_LIMIT == 4096, len(line)
+    r = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["value"] == full["value"] and r["ms_per_step"] == full["ms_per_step"]              # not rounded: the driver re-derives one from the other
+    assert r["config"]["workload"] and r["config"]["rays_per_step_per_gpu"] == 640000 and r["config"]["partition"] == "rows"
+    assert "model" not in r["config"] and len(r["dtype"]) <= 48 and r["dtype"].startswith("f32")
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_flop_per_launch"):
+        assert k in r["roofline"], k
+    assert abs(r["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 and r["roofline"]["bound"] in ("mfma", "hbm")
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 256 and abs(r["cpu_baseline"]["value"] - 8213.73) < 0.01
+    assert len(r["cpu_baseline"]["sample"]) <= 100
+    assert r["collectives"] == {"backend": "nccl", "rccl_ranks": 8, "world_size": 8}
+    assert set(r["other_workloads"]) == set(full["other_workloads"])
+    row = r["other_workloads"]["refine"]
+    assert set(row) == {"value", "unit", "ms_per_step", "roofline_bound", "roofline_frac", "traffic", "algorithmic_bytes", "cpu_baseline_value"}
+    assert row["cpu_baseline_value"] is not None and row["algorithmic_bytes"] == 56.1e9 and row["traffic"] is not None
+    assert "error" in r["other_workloads"]["failed"]
+    # a record without the optional blocks (a multi-rank line, --no-cpu-baseline) stays valid and says nothing it does not know
+    lean = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                                  "data", "config", "roofline")}
+    r2 = json.loads(bench.compact_record(lean))
+    assert "cpu_baseline" not in r2 and "other_workloads" not in r2 and r2["roofline"]["frac"] > 0
+
+
+def test_bench_emit_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
+    """bench.emit: the full record to --full-record PATH (and stderr), the compact line as the last line of stdout"""
+    import json
+    import bench
+    full = _maximal_bench_record()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full, str(tmp_path / "full.json"))
+    cap = capsys.readouterr()
+    out_lines = cap.out.strip().splitlines()
+    assert len(out_lines) == 1 and len(out_lines[0]) <= 4096 and json.loads(out_lines[0])["roofline"]["frac"] > 0
+    assert json.load(open(tmp_path / "full.json")) == full
+    assert cap.err.startswith("BENCH_FULL_RECORD {") and json.load(open(tmp_path / "bench_full.json")) == full
+
+
 def test_fused_optimizer_steps_bump_the_version_counters():
     """Every derived copy of the parameters (packed decoder / EDSR blobs, channel-last plane copies, the f16 range cache) is keyed on
     (data_ptr, tensor._version); torch's fused optimizers write the parameters WITHOUT bumping the counters (checked here: if torch ever changes

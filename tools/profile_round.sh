@@ -6,18 +6,18 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; T=${1:-r01}; PART=${2:-
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if [ "$PART" != pmc ]; then
-python3 $R/bench.py > $O/bench_render.json 2> $O/bench_render.err
-python3 $R/bench.py --workload train --steps 30 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
-python3 $R/bench.py --workload train --train-what planes+decoder --steps 30 --warmup 5 > $O/bench_train_dec.json 2> $O/bench_train_dec.err
-python3 $R/bench.py --workload sr --steps 3 --warmup 1 > $O/bench_sr.json 2> $O/bench_sr.err
-python3 $R/bench.py --workload refine --refine-what joint --steps 8 --warmup 2 > $O/bench_refine_joint.json 2> $O/bench_refine_joint.err
-python3 $R/bench.py --workload refine --refine-what sr --steps 8 --warmup 2 > $O/bench_refine_sr.json 2> $O/bench_refine_sr.err
+python3 $R/bench.py --full-record $O/bench_render.json > $O/bench_render.line 2> $O/bench_render.err
+python3 $R/bench.py --workload train --steps 30 --warmup 5 --full-record $O/bench_train.json > $O/bench_train.line 2> $O/bench_train.err
+python3 $R/bench.py --workload train --train-what planes+decoder --steps 30 --warmup 5 --full-record $O/bench_train_dec.json > $O/bench_train_dec.line 2> $O/bench_train_dec.err
+python3 $R/bench.py --workload sr --steps 3 --warmup 1 --full-record $O/bench_sr.json > $O/bench_sr.line 2> $O/bench_sr.err
+python3 $R/bench.py --workload refine --refine-what joint --steps 8 --warmup 2 --full-record $O/bench_refine_joint.json > $O/bench_refine_joint.line 2> $O/bench_refine_joint.err
+python3 $R/bench.py --workload refine --refine-what sr --steps 8 --warmup 2 --full-record $O/bench_refine_sr.json > $O/bench_refine_sr.line 2> $O/bench_refine_sr.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_render -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 $R/bench.py --workload train --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_dec -- python3 $R/bench.py --workload train --train-what planes+decoder --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sr -- python3 $R/bench.py --workload sr --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_refine_joint -- python3 $R/bench.py --workload refine --refine-what joint --steps 5 --warmup 1 --no-cpu-baseline > $O/stats_refine_joint.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_refine_sr -- python3 $R/bench.py --workload refine --refine-what sr --steps 5 --warmup 1 --no-cpu-baseline > $O/stats_refine_sr.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_refine_joint -- python3 $R/bench.py --workload refine --refine-what joint --steps 5 --warmup 1 --no-cpu-baseline --full-record $O/stats_refine_joint.json > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_refine_sr -- python3 $R/bench.py --workload refine --refine-what sr --steps 5 --warmup 1 --no-cpu-baseline --full-record $O/stats_refine_sr.json > /dev/null 2>&1
 find $O/stats_* -name "*kernel_trace.csv" -delete
 fi
 if [ "$PART" != lines ]; then
@@ -37,4 +37,4 @@ bash $R/tools/train_pmc.sh > $O/train_issue_counters.txt 2>&1
 find $O/pmc_* $R/gpurun_out/pmc_t* -name "*kernel_trace.csv" -delete 2>/dev/null
 du -sh $O/* $R/gpurun_out/pmc_t* 2>/dev/null | sort -h | tail -8
 fi
-[ -f $O/bench_render.json ] && tail -c 400 $O/bench_render.json
+[ -f $O/bench_render.line ] && tail -c 600 $O/bench_render.line
