@@ -460,6 +460,7 @@ def cpu_baseline(nvsr_amd, mc, mf, sid, rays, rgb_fine_gpu, budget_s=15.0):
     cores = os.cpu_count() or 1
     return {"value": n / t, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d rays of the same 800x800 / 64+128 / planes 800^2 frame, %.1f s, C oracle fp32 -Ofast OpenMP (%d threads)" % (n, t, cores),
+            "sample_short": "%d rays of the same frame, %.1f s, C oracle fp32 OpenMP %d threads" % (n, t, cores),
             "evals_per_s": n * 256 / t,
             # the reference ITSELF never travels to the GPU box; its only CPU figure is the survey's
             "reference_on_cpu": {"value": 10000 / 9.79, "unit": "rays/s", "cores": 8, "kind": "reference",

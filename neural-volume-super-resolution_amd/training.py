@@ -440,15 +440,7 @@ class TrainStep:
         side = self.__dict__.get("_prologue_stream")
         if side is None:
             side = self.__dict__["_prologue_stream"] = torch.cuda.Stream(device=dev, priority=-1)
-            self.__dict__["_prologue_inputs"] = set()
-        # The side stream reads the target image and the pose without waiting for the iteration's stream.  A tensor (storage, version) it has
-        # not met before may still be being written there (a view just uploaded, a pose just computed): the first time it meets one it waits for
-        # that stream once -- one drained queue per NEW input, none for the views of a resident dataset from their second use on
-        key = (img_target.data_ptr(), img_target._version, pose_target.data_ptr(), pose_target._version)
-        if key not in self.__dict__["_prologue_inputs"]:
-            if len(self.__dict__["_prologue_inputs"]) > 4096:
-                self.__dict__["_prologue_inputs"].clear()
-            self.__dict__["_prologue_inputs"].add(key)
+        if not self._prologue_known(img_target, pose_target):
             side.wait_stream(cur)
         with torch.cuda.stream(side):
             ro, rd, target_s = draw()
@@ -469,6 +461,36 @@ class TrainStep:
         if host is not None:
             mf._roi_hint = (ro.shape[0], host.tolist())
         return ro, rd, target_s
+
+    # bound of the side stream's input cache: entries, and bytes of device memory its retained storages may keep alive (resident datasets are alive
+    # anyway; a caller that produces a new target every iteration has at most this much kept behind it)
+    PROLOGUE_CACHE_ENTRIES, PROLOGUE_CACHE_BYTES = 1024, 4 << 30
+
+    def _prologue_known(self, img_target, pose_target):
+        """May the side stream read these two tensors WITHOUT waiting for the iteration's stream?  Only if it has met this very (storage, version)
+        pair before -- whatever wrote them was waited for then.  The cache entry RETAINS both storages: a key on (data_ptr, _version)
+        alone is met again by a freshly produced tensor -- version 0, on the block the allocator just recycled -- while its producer is still queued
+        behind the previous iteration; with the storage kept alive the allocator cannot hand that address to anything else, so an equal key IS the
+        same memory in the same state.  Least-recently-used entries are dropped beyond PROLOGUE_CACHE_ENTRIES / PROLOGUE_CACHE_BYTES (a dropped
+        input costs one drained queue at its next use, never a stale read).  False -> the caller makes the side stream wait, and the pair is known
+        from now on."""
+        import collections
+        cache = self.__dict__.get("_prologue_inputs")
+        if cache is None:
+            cache = self.__dict__["_prologue_inputs"] = collections.OrderedDict()
+            self.__dict__["_prologue_bytes"] = 0
+        key = (img_target.data_ptr(), img_target._version, pose_target.data_ptr(), pose_target._version)
+        if key in cache:
+            cache.move_to_end(key)
+            return True
+        keep = (img_target.untyped_storage(), pose_target.untyped_storage())
+        nbytes = sum(int(st.nbytes()) for st in keep)
+        cache[key] = (keep, nbytes)
+        self.__dict__["_prologue_bytes"] += nbytes
+        while len(cache) > 1 and (len(cache) > self.PROLOGUE_CACHE_ENTRIES or self.__dict__["_prologue_bytes"] > self.PROLOGUE_CACHE_BYTES):
+            _, (_, nb) = cache.popitem(last=False)
+            self.__dict__["_prologue_bytes"] -= nb
+        return False
 
     def apply_gradients(self, loss, last_v=True, sr_iter=False, confinements=()):
         """the tail of an iteration (train_nerf.py:903-914): backward, [data-parallel: grad_sync() averages the gradients over the ranks],

@@ -720,3 +720,33 @@ def test_loss_pair_sum_off_the_device_is_torchs():
     # PACK_ALL_ARITHMETICS is the header's value
     hdr = open(os.path.join(ROOT, "include", "nvsr.h")).read()
     assert "#define NVSR_PACK_ALL_ARITHMETICS (%d)" % nvsr_amd.capi.PACK_ALL_ARITHMETICS in hdr
+
+
+def test_prologue_input_cache_retains_storages_and_is_bounded(pkg):
+    """TrainStep._draw_rays lets its side stream read the target image / pose without waiting for the iteration's stream once it
+    has met the (address, version) pair.  A freshly produced tensor has version 0 and lands on the block the allocator just recycled: the key
+    alone would match.  The cache entry now keeps both storages alive, so a recycled address cannot be met again; and the cache is a bounded LRU."""
+    T = pkg.training
+    step = T.TrainStep(None, None, None, {"SR"})
+    img, pose = torch.rand(64, 64, 3), torch.eye(4)
+    assert not step._prologue_known(img, pose) and step._prologue_known(img, pose)          # second use: known
+    img.mul_(0.5)                                                                            # written in place: a new version is a new input
+    assert not step._prologue_known(img, pose) and step._prologue_known(img, pose)
+    # a target produced anew every iteration: with the storage retained its memory is never recycled into an equal key
+    seen = set()
+    for _ in range(50):
+        fresh = torch.rand(64, 64, 3)
+        assert fresh._version == 0 and not step._prologue_known(fresh, pose)
+        assert fresh.data_ptr() not in seen
+        seen.add(fresh.data_ptr())
+        del fresh
+    # bounded: entries and bytes
+    step.PROLOGUE_CACHE_ENTRIES = 8
+    for _ in range(20):
+        step._prologue_known(torch.rand(8, 8, 3), pose)
+    assert len(step._prologue_inputs) <= 8
+    step.PROLOGUE_CACHE_BYTES = 3 * 64 * 64 * 3 * 4
+    for _ in range(10):
+        step._prologue_known(torch.rand(64, 64, 3), pose)
+    assert step._prologue_bytes <= step.PROLOGUE_CACHE_BYTES + 64 and len(step._prologue_inputs) <= 3
+    assert step._prologue_bytes == sum(nb for _, nb in step._prologue_inputs.values())
