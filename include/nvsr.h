@@ -595,6 +595,16 @@ int nvsr_planes_sr_backward_batch_arith(int B, int C, int R0, int R1, const floa
                                         int n_up, int pad, int over, const float* rois, const float* stdv, const float* const* d_out,
                                         float* grad_natural, float* const* d_lr, float* workspace, int arithmetic, int align_corners,
                                         int plane_interp, nvsr_stream_t stream);
+/* The same with PROGRESS MARKS for a data-parallel caller (the 173 MB EDSR gradient is all-reduced every refinement iteration;
+ * the reference has no distributed code -- models.py:789-822 under torch.autograd is what the marks follow).  The backward walks the layers from
+ * conv_output to conv_input; grad_natural is in state-dict order, so the gradients become final from the END of the blob.  mark_events[i] (a
+ * hipEvent_t of the caller) is recorded on `stream` as soon as the weight gradients of layer mark_layers[i] (0 = conv_input ... 2 nblocks + 4 =
+ * conv_output with two upscale stages) and of every layer behind it are final: the caller's collective stream waits for it and reduces that part
+ * of the blob while the remaining layers are still being computed.  Exact f32 / one plane: every mark is recorded at the end of the pass. */
+int nvsr_planes_sr_backward_batch_marks(int B, int C, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks,
+                                        int n_up, int pad, int over, const float* rois, const float* stdv, const float* const* d_out,
+                                        float* grad_natural, float* const* d_lr, float* workspace, int arithmetic, int align_corners,
+                                        int plane_interp, int n_marks, const int32_t* mark_layers, void* const* mark_events, nvsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -187,6 +187,8 @@ _PROTOS_OPTIONAL = {   # feature-plane super-resolution (csrc/sr.hip)
                                           _i, _i, _i, _vp], _i),
     "nvsr_planes_sr_backward_batch_arith": ([_i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), _vp,
                                              _i, _i, _i, _vp], _i),
+    "nvsr_planes_sr_backward_batch_marks": ([_i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _fp, _vp, C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), _vp,
+                                             _i, _i, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), _vp], _i),
     # positional-encoding baseline (csrc/posenc.hip)
     "nvsr_positional_encoding": ([_i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "nvsr_flexible_nerf_forward": ([_i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),

@@ -4,7 +4,13 @@
 
 namespace nvsr {
 
-constexpr int TILE_FLOATS = 32 * C;       // per-wave transposition tile [32 points][48 channels]
+// per-wave transposition tile [32 points][48 channels], rows TILE_STRIDE floats apart.  Round 6: 52, not 48 -- the rows are written four channels
+// at a time (ds_write_b128: 8 contiguous lanes = 8 points per LDS cycle, bank = word address mod 32); at a stride of 48 words the 8 rows start on
+// 2 different bank quads (48 p mod 32 is 0 or 16): a 4-way conflict on every write, 17 % of the kernel's LDS-array cycles (SQ_LDS_BANK_CONFLICT,
+// profiles/r05f_train_issue_counters.txt; the forward has no such tile and 0 %).  At 52 words (13 quads, odd) the 8 rows hit 8 different quads.
+// The per-point reads (lane = channel: 48 consecutive words) are conflict-free at any stride.
+constexpr int TILE_STRIDE = 52;
+constexpr int TILE_FLOATS = 31 * TILE_STRIDE + C;     // (the last row ends with its 48th channel: two 3-limb workgroups fill the 160 KB exactly)
 
 // ---- transposed-weight blob ("packed_bwd"), in consumption order ------------------------------------------------------------
 //   hidden^T layer (16384 floats): [kb][q][ib][lane][j] = W[32kb + 8q + 4h + j][32ib + (lane&31)]        (W = [out][in])
@@ -69,7 +75,7 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
         for (int r = 0; r < 16; ++r) {
             if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
             const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
+            tile[pt * TILE_STRIDE + c] = acc2[b][r];
         }
     __builtin_amdgcn_wave_barrier();
     // taps of an invalid (padding) ray carry zero weight
@@ -88,7 +94,7 @@ __device__ __forceinline__ void scatter_plane(const f32x16 (&acc2)[2], float* ti
         const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w2), p));
         const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), p));
         if (lane < C) {
-            const float v = tile[p * C + lane];
+            const float v = tile[p * TILE_STRIDE + lane];
             unsafeAtomicAdd(b0 + lane, v * a0);
             unsafeAtomicAdd(b1 + lane, v * a1);
             unsafeAtomicAdd(b2 + lane, v * a2);
@@ -112,7 +118,7 @@ __device__ __forceinline__ void scatter_plane_runs(const f32x16 (&acc2)[2], floa
         for (int r = 0; r < 16; ++r) {
             if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
             const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
+            tile[pt * TILE_STRIDE + c] = acc2[b][r];
         }
     __builtin_amdgcn_wave_barrier();
     const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
@@ -142,7 +148,7 @@ __device__ __forceinline__ void scatter_plane_runs(const f32x16 (&acc2)[2], floa
             c0 = o0; c1 = o1; c2 = o2; c3 = o3;
             s0 = s1 = s2 = s3 = 0.0f;
         }
-        const float v = lane < C ? tile[p * C + lane] : 0.0f;
+        const float v = lane < C ? tile[p * TILE_STRIDE + lane] : 0.0f;
         s0 = fmaf(v, a0, s0); s1 = fmaf(v, a1, s1); s2 = fmaf(v, a2, s2); s3 = fmaf(v, a3, s3);
     }
     flush();
@@ -174,7 +180,7 @@ __device__ __forceinline__ void scatter_plane_cached(const f32x16 (&acc2)[2], fl
         for (int r = 0; r < 16; ++r) {
             if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
             const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
+            tile[pt * TILE_STRIDE + c] = acc2[b][r];
         }
     __builtin_amdgcn_wave_barrier();
     const float w0 = valid ? t.nw : 0.0f, w1 = valid ? t.ne : 0.0f, w2 = valid ? t.sw : 0.0f, w3 = valid ? t.se : 0.0f;
@@ -194,7 +200,7 @@ __device__ __forceinline__ void scatter_plane_cached(const f32x16 (&acc2)[2], fl
     for (int p0 = 0; p0 < 32; p0 += 4) {
         float vv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * C + li];                  // 4 points' rows in flight
+        for (int j = 0; j < 4; ++j) vv[j] = tile[(p0 + j) * TILE_STRIDE + li];                  // 4 points' rows in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p0 + j;
@@ -240,7 +246,7 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
         for (int r = 0; r < 16; ++r) {
             if (b == 1 && r >= 8) continue;                        // rows 48..63 are padding
             const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
+            tile[pt * TILE_STRIDE + c] = acc2[b][r];
         }
     __builtin_amdgcn_wave_barrier();
     // this lane's point: (texel, weight) of slot j = tap j ^ par
@@ -287,7 +293,7 @@ __device__ __forceinline__ void scatter_plane_cached_v(const f32x16 (&acc2)[2], 
     for (int p0 = 0; p0 < ((SCV_ABLATE & 1) ? 0 : 32); p0 += 4) {
         float vv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vv[j] = (SCV_ABLATE & 8) ? (float)(p0 + j) : tile[(p0 + j) * C + lane];                // 4 points' rows in flight
+        for (int j = 0; j < 4; ++j) vv[j] = (SCV_ABLATE & 8) ? (float)(p0 + j) : tile[(p0 + j) * TILE_STRIDE + lane];                // 4 points' rows in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p0 + j;
@@ -332,12 +338,12 @@ __device__ __forceinline__ void store_view_rows(const f32x16 (&acc2)[2], float* 
         for (int r = 0; r < 16; ++r) {
             if (b == 1 && r >= 8) continue;
             const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[pt * C + c] = acc2[b][r];
+            tile[pt * TILE_STRIDE + c] = acc2[b][r];
         }
     __builtin_amdgcn_wave_barrier();
     if (lane < C) {
         for (int p = 0; p < 32; ++p)
-            if (ray_w0 + p < N) gview[((ray_w0 + p) * S + s) * C + lane] = tile[p * C + lane];
+            if (ray_w0 + p < N) gview[((ray_w0 + p) * S + s) * C + lane] = tile[p * TILE_STRIDE + lane];
     }
     __builtin_amdgcn_wave_barrier();
 }

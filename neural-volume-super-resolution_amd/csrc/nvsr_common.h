@@ -1,5 +1,23 @@
 // Shared device-side definitions for the gfx950 kernels (not part of the public ABI).
 #pragma once
+// ---- race probe (tools/race_probe.sh; NEVER the product) ---------------------------------------------------------------------------------
+// Round 5 found a data race that four rounds of parity tests had passed over: the backward kernels read head weights out of LDS in front of the
+// first workgroup barrier; alone on a GPU the waves of a workgroup start together and the race never shows.  -DNVSR_RACE_PROBE=1 builds a probe
+// library in which, in EVERY kernel that fills LDS cooperatively, all waves but the first start LATE (8 x s_sleep 127: ~30 us): whatever a kernel reads
+// from LDS before a barrier has published it is then stale with certainty, and the parity tests fail instead of passing by luck.
+#ifndef NVSR_RACE_PROBE
+#define NVSR_RACE_PROBE 0
+#endif
+#if NVSR_RACE_PROBE
+#define NVSR_RACE_PROBE_DELAY()                                                                     \
+    do {                                                                                            \
+        if ((threadIdx.x >> 6) != 0)                                                                \
+            for (int nvsr_rp_ = 0; nvsr_rp_ < 8; ++nvsr_rp_) __builtin_amdgcn_s_sleep(127);        \
+    } while (0)
+#else
+#define NVSR_RACE_PROBE_DELAY() do { } while (0)
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

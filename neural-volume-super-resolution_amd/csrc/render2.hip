@@ -88,6 +88,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
                                                               float* __restrict__ acc, float* __restrict__ weights,
                                                               float* __restrict__ depth, float* __restrict__ raw_out) {
     __shared__ __attribute__((aligned(16))) float lds[LDS2_FLOATS];
+    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
     Ring2 rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) lds[LDS2_SMALL + i] = packed[P_SMALL + i];
     const float* small = lds + LDS2_SMALL;

@@ -17,7 +17,8 @@
 
 #ifndef BL_ABLATE
 #define BL_ABLATE 0   // timing experiments only (wrong results): 1 no wait for the weight copies, 2 no gate masks, 4 no plane scatter / view rows,
-#endif                // 8 no splits outside the MFMA gaps (first K-block of a chunk), 16 scatter loop without its atomics, 64 no workgroup barriers
+#endif                // 8 no splits outside the MFMA gaps (first K-block of a chunk), 16 scatter loop without its atomics, 64 no workgroup barriers,
+                      // 128 every tile of a workgroup loads the inputs (depth, dL/draw, gates) of the workgroup's FIRST tile (cache hits: the exposed load latency at a tile's top)
                       // (tools/bwd_limb_ablate.sh, tools/bwd_limb_kernel_ablate.sh)
 
 #ifndef BL_SCATTER
@@ -25,10 +26,7 @@
 #endif                // (0 / 1: A/B builds for the WRITE_SIZE comparison, tools/bwd_scatter_pmc.sh)
 
 #ifndef BL_PROLOGUE_BARRIER
-#define BL_PROLOGUE_BARRIER 1   // workgroup barrier behind the head weights' copy into LDS (0 / BL_RACE_PROBE=1: builds that demonstrate the race it closes)
-#endif
-#ifndef BL_RACE_PROBE
-#define BL_RACE_PROBE 0
+#define BL_PROLOGUE_BARRIER 1   // workgroup barrier behind the head weights' copy into LDS (0 with -DNVSR_RACE_PROBE=1: a build that demonstrates the race it closes)
 #endif
 #ifndef BL_GATE_PREFETCH
 #define BL_GATE_PREFETCH 1   // the tile's gate words loaded once at its top (A/B: 0 = re-read per layer)
@@ -190,12 +188,10 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                                                                                    float* __restrict__ gview, DecRecord rec) {
     constexpr int BL_SMALL = BLds<LF>::SMALL, BL_TILES = BLds<LF>::TILES;
     __shared__ __attribute__((aligned(16))) unsigned lds[BLds<LF>::LDS];
+    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
     RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL + BLimb<LF>::OFFSET), 0, BLimb<LF>::WORDS * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);
-#if BL_RACE_PROBE      // (experiment: every wave but the first writes its share of the head weights LATE -- the race of the missing barrier, made certain)
-    if (rs.wave != 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-#endif
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += BL_TPB) ldsf[BL_SMALL + i] = packed[P_SMALL + i];   // head weights of the FORWARD blob
     const float* small = ldsf + BL_SMALL;
 #if BL_PROLOGUE_BARRIER
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
     for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));
         const int lane = rs.lane, h = lane >> 5;
-        const long wt = tix * BL_WAVES + rs.wave;
+        const long wt = ((BL_ABLATE & 128) ? (long)blockIdx.x : tix) * BL_WAVES + rs.wave;
         const long ray0 = wt / nsc;
         const int s0 = (int)(wt - ray0 * nsc) * 32 + (lane & 31);
         const bool valid = ray0 < N && s0 < S;
@@ -417,14 +413,14 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) {
                             if (b == 1 && rr >= 8) continue;
-                            tile[pt * C + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * hh] = gF[b][rr];
+                            tile[pt * TILE_STRIDE + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * hh] = gF[b][rr];
                         }
                     __builtin_amdgcn_wave_barrier();
                     if (lane < C && ray0 < N) {
                         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
 #pragma unroll
                         for (int p_ = 0; p_ < 32; p_ += 4) {
-                            v0 += tile[p_ * C + lane]; v1 += tile[(p_ + 1) * C + lane]; v2 += tile[(p_ + 2) * C + lane]; v3 += tile[(p_ + 3) * C + lane];
+                            v0 += tile[p_ * TILE_STRIDE + lane]; v1 += tile[(p_ + 1) * TILE_STRIDE + lane]; v2 += tile[(p_ + 2) * TILE_STRIDE + lane]; v3 += tile[(p_ + 3) * TILE_STRIDE + lane];
                         }
                         gview[wt * C + lane] = (v0 + v1) + (v2 + v3);            // wt = ray * nsc + chunk
                     }

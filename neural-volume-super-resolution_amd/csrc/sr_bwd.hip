@@ -46,6 +46,7 @@ struct WgradPlane { const float* dy; const float* x; int Ho, Wo; };
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
     __shared__ float lds[DY_FLOATS + X_FLOATS];
+    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
     float* dyt = lds;
     float* xt = lds + DY_FLOATS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
@@ -428,6 +429,7 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, const Wgra
 template <int LF>
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned lds[LF * (WL_DY_WORDS + WL_X_WORDS)];
+    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
     float dscale = 1.0f;          // f16 limbs: the power of two that puts the largest |dy| of the tensor into [2^12, 2^13) (sr.hip, the data gradient's rule)
     if (LF == 2 && p.dy_absmax) {
         dscale = f16_gradient_scale((unsigned)__builtin_amdgcn_readfirstlane((int)*p.dy_absmax));
@@ -1073,8 +1075,19 @@ int nvsr_planes_sr_backward_arith(int Cc, int R0, int R1, const float* keep, con
 namespace nvsr {
 
 // backward of the EDSR forward on B inputs of different sizes (nvsr_edsr_backward_arith with one launch per layer and operation for all planes)
+// marks: events the caller wants recorded on `stream` as soon as the weight gradients of layer mark_layers[i] AND of every layer behind it (the
+// backward walks the layers from the last to the first) are final in grad_natural -- a data-parallel caller starts the all-reduce of that part of
+// the blob while the rest of the backward is still running (nvsr_planes_sr_backward_batch_marks)
+struct LayerMarks { int n = 0; const int32_t* layers = nullptr; void* const* events = nullptr; };
+static int record_marks(const LayerMarks& mk, int layer, hipStream_t stream) {      // layer < 0: every mark (the pass is over)
+    for (int i = 0; i < mk.n; ++i)
+        if ((layer < 0 || mk.layers[i] == layer) && mk.events[i] && hipEventRecord((hipEvent_t)mk.events[i], stream) != hipSuccess) return NVSR_ERR_LAUNCH;
+    return NVSR_OK;
+}
+
 static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x, const float* const* acts, const float* packed_dgrad,
-                                const float* const* d_out, float* grad_natural, float* const* dx, float* workspace, int arith, hipStream_t stream) {
+                                const float* const* d_out, float* grad_natural, float* const* dx, float* workspace, int arith, hipStream_t stream,
+                                const LayerMarks& marks = LayerMarks{}) {
     const int n = P[0].n;
     // workspace: 3 gradient buffers + 1 un-shuffled gradient, each holding one tensor per plane, + the partial sums + one word per gradient tensor
     int64_t toff[CONV_RAGGED_MAX + 1] = {0};
@@ -1118,7 +1131,12 @@ static int edsr_backward_planes(int B, const EdsrPlan* P, const float* const* x,
     auto wgrad = [&](const float* const* dy, int l, float scale, const unsigned* am) {
         const float* xs[CONV_RAGGED_MAX]; int H[CONV_RAGGED_MAX], W[CONV_RAGGED_MAX];
         for (int b = 0; b < B; ++b) { xs[b] = input_of(l, b); H[b] = P[b].ih[l]; W[b] = P[b].iw[l]; }
-        return launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am, &rp);
+        if (int e_ = launch_wgrad_planes(B, dy, xs, P[0].L[l].Cin, H, W, P[0].L[l].Cout, scale, grad_natural + goff[l], partial, stream, arith, am, &rp)) return e_;
+        bool wanted = false;
+        for (int i = 0; i < marks.n; ++i) wanted = wanted || marks.layers[i] == l;
+        if (!wanted) return (int)NVSR_OK;
+        rp.join();                                 // (a reduce lane's reductions of this and the earlier layers, before the mark; the product has no lane)
+        return rp.failed ? (int)NVSR_ERR_LAUNCH : record_marks(marks, l, stream);
     };
     // data gradient of layer l: dy [Cout][ih-2][iw-2] -> [Cin][ih][iw] with the given backward epilogue
     auto dgrad = [&](const float* const* dy, int l, int epi, const float* const* skip, float* const* out, const unsigned* am, unsigned* out_am) {
@@ -1220,7 +1238,18 @@ int nvsr_planes_sr_backward_batch_arith(int B, int Cc, int R0, int R1, const flo
                                         int pad, int over, const float* rois, const float* stdv, const float* const* d_out, float* grad_natural,
                                         float* const* d_lr, float* workspace, int arithmetic, int align_corners, int plane_interp,
                                         nvsr_stream_t stream_) {
+    return nvsr_planes_sr_backward_batch_marks(B, Cc, R0, R1, keep, packed_dgrad, hid, nblocks, n_up, pad, over, rois, stdv, d_out, grad_natural, d_lr,
+                                               workspace, arithmetic, align_corners, plane_interp, 0, nullptr, nullptr, stream_);
+}
+
+int nvsr_planes_sr_backward_batch_marks(int B, int Cc, int R0, int R1, const float* keep, const float* packed_dgrad, int hid, int nblocks, int n_up,
+                                        int pad, int over, const float* rois, const float* stdv, const float* const* d_out, float* grad_natural,
+                                        float* const* d_lr, float* workspace, int arithmetic, int align_corners, int plane_interp,
+                                        int n_marks, const int32_t* mark_layers, void* const* mark_events, nvsr_stream_t stream_) {
     if (!keep || !packed_dgrad || !d_out || !grad_natural || !workspace) return NVSR_ERR_NULL;
+    if (n_marks < 0 || (n_marks > 0 && (!mark_layers || !mark_events))) return NVSR_ERR_NULL;
+    LayerMarks marks;
+    marks.n = n_marks; marks.layers = mark_layers; marks.events = mark_events;
     if (B < 1 || B > CONV_RAGGED_MAX) return NVSR_ERR_SHAPE;
     if (plane_interp != NVSR_PLANE_INTERP_BILINEAR && plane_interp != NVSR_PLANE_INTERP_BICUBIC) return NVSR_ERR_SHAPE;
     if (!aligned16(packed_dgrad) || !aligned16(workspace) || !aligned16(keep)) return NVSR_ERR_ALIGN;
@@ -1254,9 +1283,13 @@ int nvsr_planes_sr_backward_batch_arith(int B, int Cc, int R0, int R1, const flo
             if (int e = nvsr_edsr_backward_arith(xin[b], Cc, Hp[b], Wp[b], acts[b], packed_dgrad, Cc, hid, nblocks, n_up, d_diff[b], grad_natural,
                                                  (d_lr && d_lr[b]) ? dxin[b] : nullptr, w, arith, stream_))
                 return e;
+        // (plane by plane every layer's gradient is final only after the last plane: all marks here)
+        if (int e = record_marks(marks, -1, stream)) return e;
     } else {
         // (a plane whose LR gradient nobody wants still gets its first layer's data gradient when another plane needs it: 0.3 % of the pass)
-        if (int e = edsr_backward_planes(B, P, xin, acts, packed_dgrad, d_diff, grad_natural, any_lr ? dxin : nullptr, w, arith, stream)) return e;
+        for (int i = 0; i < n_marks; ++i)
+            if (mark_layers[i] < 0 || mark_layers[i] >= P[0].n) return NVSR_ERR_SHAPE;
+        if (int e = edsr_backward_planes(B, P, xin, acts, packed_dgrad, d_diff, grad_natural, any_lr ? dxin : nullptr, w, arith, stream, marks)) return e;
     }
     for (int b = 0; b < B; ++b) {
         if (!(d_lr && d_lr[b])) continue;

@@ -194,15 +194,23 @@ def allreduce_coalesced(tensors, group=None, scale=None, bucket_bytes=64 << 20):
     tensors = list(tensors)
     if not tensors:
         return
-    buckets, cur, size = [], [], 0
+    # a bucket holds ONE dtype (torch.cat would silently promote a mixed bucket: a bf16 gradient reduced in f32 and cast back) and is closed
+    # BEFORE the tensor that would take it past bucket_bytes (a bucket of small tensors never exceeds the bound; a larger tensor is its own)
+    by_dtype = {}
     for t in tensors:
-        cur.append(t)
-        size += t.numel() * t.element_size()
-        if size >= bucket_bytes:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    buckets = []
+    for group_ in by_dtype.values():
+        cur, size = [], 0
+        for t in group_:
+            nb = t.numel() * t.element_size()
+            if cur and size + nb > bucket_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+            cur.append(t)
+            size += nb
+        if cur:
             buckets.append(cur)
-            cur, size = [], 0
-    if cur:
-        buckets.append(cur)
     flats = [torch.cat([t.reshape(-1) for t in b]) for b in buckets]                  # (logical order: any dense layout)
     works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group, async_op=True) for f in flats]
     for wk in works:
@@ -219,9 +227,113 @@ def allreduce_coalesced(tensors, group=None, scale=None, bucket_bytes=64 << 20):
     torch._foreach_copy_(dst, src)
 
 
-# RCCL path of allreduce_gradients: with more than DIRECT_MAX_TENSORS dense tensors, those below COALESCE_BELOW bytes share buckets
+# RCCL path of allreduce_gradients: with more than DIRECT_MAX_TENSORS dense tensors, those below COALESCE_BELOW bytes share buckets.  The bound is
+# per TENSOR and sits below the plane gradients (7.7 MB each at 200^2) and the decoder blobs' own size class: those stay in place like round 3
+# measured them; what shares buckets is an SR network's many 2-4 MB weight gradients (at 16 MB the planes were flattened again).
 DIRECT_MAX_TENSORS = 8
-COALESCE_BELOW = 16 << 20
+COALESCE_BELOW = 4 << 20
+
+
+class OverlappedSRGradSync:
+    """The EDSR weight gradient of a data-parallel SR-refinement iteration (173 MB) all-reduced WHILE the SR backward is still running,
+    and the `grad_sync` callable of training.TrainStep for everything else.
+
+    The reference has no distributed code; its autograd produces the 69 weight gradients layer by layer, the last layer
+    first (models.py:789-822).  The library's batched backward (ops.PlanesSRBatchFn -> nvsr_planes_sr_backward_batch_marks) fills ONE blob in
+    state-dict order and records an event each time a suffix of it is final; `reduce_marked` queues, per bucket of ~bucket_bytes, an asynchronous
+    all-reduce BEHIND that event on a collective stream -- the links move bucket k while the matrix pipe computes the layers of bucket k + 1 --
+    and finally makes the iteration's stream wait for the collectives and multiplies the blob by 1 / world.  What autograd then hands to the
+    parameters is already the averaged gradient; only the LAST bucket's transfer (the first layers of the network) is exposed.
+
+        sync = OverlappedSRGradSync(sr_model, other_parameters=planes + decoder_params)
+        step = TrainStep(..., SR_model=sr_model, grad_sync=sync)          # TrainStep calls sync() between backward and the optimizers
+
+    sync() averages the OTHER parameters' gradients (allreduce_gradients) -- and the SR network's too in an iteration whose SR backward did not go
+    through the batched path (one plane, exact f32 per plane: PlanesSR.forward), so the parameters of all ranks stay identical either way.
+    RCCL: collectives on the process group's own stream, ordered behind the bucket's event through `stream` (a stream that only ever carries
+    event waits; pass TrainStep's idle prologue stream to spend no additional hardware queue: training.TrainStep does).  gloo with host tensors
+    (tests/test_distributed.py): asynchronous all-reduces of the bucket views.  gloo with device tensors (one-GPU rehearsals): staged through the
+    host at the end of the backward -- no overlap, same values.  Buckets are reduced in place: no flattening copy."""
+
+    def __init__(self, sr_model, other_parameters=(), group=None, bucket_bytes=48 << 20, stream=None, single_rank_ok=False):
+        self.sr_model, self.other, self.group, self.bucket_bytes, self.stream = sr_model, list(other_parameters), group, int(bucket_bytes), stream
+        self.single_rank_ok = bool(single_rank_ok)          # run the marked path on a one-rank group too (the RCCL test of a one-GPU box)
+        self.reduced_in_backward = False          # did this iteration's SR backward hand its blob over?
+        self.stats = {"buckets": 0, "bytes": 0}   # of the last overlapped backward
+        self._events = []
+        self.attach(sr_model)
+
+    def attach(self, sr_model):
+        sr_model.__dict__["grad_bucket_sync"] = self          # PlanesSR.forward_many puts it into the cfg of ops.PlanesSRBatchFn
+
+    def detach(self):
+        self.sr_model.__dict__.pop("grad_bucket_sync", None)
+
+    def active(self):
+        return world_info(self.group)[1] > 1 or (self.single_rank_ok and dist.is_available() and dist.is_initialized())
+
+    def plan(self, layer_floats, blob):
+        """-> [(first layer of the bucket, lo, hi, event)]: suffixes of the blob in the order they become final.  A bucket is closed once it holds
+        bucket_bytes; the events are created (recorded once) here and re-recorded by the library where the bucket is final."""
+        offs = [0]
+        for n in layer_floats:
+            offs.append(offs[-1] + int(n))
+        assert offs[-1] == blob.numel()
+        marks, hi = [], offs[-1]
+        for l in range(len(layer_floats) - 1, -1, -1):
+            if (hi - offs[l]) * blob.element_size() >= self.bucket_bytes or l == 0:
+                marks.append([l, offs[l], hi, None])
+                hi = offs[l]
+        if blob.is_cuda:
+            while len(self._events) < len(marks):
+                self._events.append(torch.cuda.Event())
+            cur = torch.cuda.current_stream(blob.device)
+            for m, ev in zip(marks, self._events):
+                ev.record(cur)                    # (creates the handle; the library records it again behind the bucket's last layer)
+                m[3] = ev
+        return [tuple(m) for m in marks]
+
+    def reduce_marked(self, blob, marks):
+        """all-reduce the buckets [lo, hi) of `blob`, each behind its event, then average; returns with the CURRENT stream ordered behind all of it"""
+        rank, world = world_info(self.group)
+        self.reduced_in_backward = True
+        self.stats = {"buckets": len(marks), "bytes": blob.numel() * blob.element_size()}
+        if world == 1 and not self.single_rank_ok:
+            return
+        views = [blob[lo:hi] for _, lo, hi, _ in marks]
+        backend = dist.get_backend(self.group)
+        if blob.is_cuda and backend != "nccl":                 # rehearsal on one GPU: host-staged, after the fact
+            for v in views:
+                host = v.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                v.copy_(host)
+        elif blob.is_cuda:
+            cur = torch.cuda.current_stream(blob.device)
+            side = self.stream
+            if side is None:
+                side = self.stream = torch.cuda.Stream(device=blob.device)
+            works = []
+            with torch.cuda.stream(side):
+                for v, (_, _, _, ev) in zip(views, marks):
+                    side.wait_event(ev)                        # the bucket is final on the iteration's stream
+                    works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))    # (RCCL's stream waits for `side`)
+            with torch.cuda.stream(cur):
+                for wk in works:
+                    wk.wait()                                  # the iteration's stream behind the collectives (no host wait)
+            blob.record_stream(side)
+        else:
+            works = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for v in views]
+            for wk in works:
+                wk.wait()
+        blob.mul_(1.0 / world)
+
+    def __call__(self):
+        """TrainStep.grad_sync: between the backward and the optimizer steps"""
+        grads = [p.grad for p in self.other if p.grad is not None]
+        if not self.reduced_in_backward:                       # the SR backward took another path this iteration (or the SR network did not train)
+            grads += [p.grad for p in self.sr_model.parameters() if p.grad is not None]
+        self.reduced_in_backward = False
+        allreduce_gradients(grads, self.group)
 
 
 def allreduce_gradients(tensors, group=None, bucket_bytes=32 << 20, average=True):

@@ -968,7 +968,9 @@ class PlanesSR(nn.Module):
         arith = capi.resolve_conv_arithmetic(net.arithmetic)
         cfg = dict(packed=net.packed_weights(arith), packed_dgrad=net.packed_dgrad_weights(arith), geometry=list(net.geometry), pad=self._kernel_pad,
                    over=self._kernel_over, rois=rois, mean=mean, std=std, arithmetic=arith,
-                   align_corners=bool(self.align_corners), bicubic=self.plane_interp == "bicubic")
+                   align_corners=bool(self.align_corners), bicubic=self.plane_interp == "bicubic",
+                   # data-parallel training: the weight-gradient blob all-reduced bucket by bucket inside the backward (distributed.OverlappedSRGradSync.attach)
+                   bucket_sync=self.__dict__.get("grad_bucket_sync"))
         return list(ops.PlanesSRBatchFn.apply(cfg, net.natural_blob(differentiable=True), *lrs))
 
     def forward(self, plane_name):

@@ -938,10 +938,41 @@ def _(keep, packed_dgrad, plane_shape, geometry, pad, over, rois, std, d_out, ne
     return [keep.new_empty((n,))] + [keep.new_empty((1, Cc, R0, R1) if k else (0,)) for k in need_lr]
 
 
+def planes_sr_backward_batch_marked(keep, packed_dgrad, plane_shape, geometry, pad, over, rois, std, d_out, need_lr, arithmetic, align_corners, bicubic,
+                                    bucket_sync):
+    """planes_sr_backward_batch with the weight-gradient blob handed to `bucket_sync` (distributed.OverlappedSRGradSync) bucket by bucket WHILE the
+    backward runs: the library records one event per bucket as soon as that part of the blob is final (nvsr_planes_sr_backward_batch_marks; the
+    layers finish from the last to the first, the blob is in state-dict order: buckets are suffixes), bucket_sync starts the all-reduce of the
+    bucket behind its event on the collective stream, and the iteration's stream waits for the collectives (and scales by 1 / world) before the
+    blob goes back to autograd.  Not a registered operator: events and a process group are not tensors; called from PlanesSRBatchFn.backward only."""
+    d_out = [_c(t) for t in d_out]
+    cin, cout, hid, nb, n_up = geometry
+    Cc, R0, R1 = plane_shape
+    B = len(d_out)
+    lib = capi.lib()
+    rois_c = _rois_c(rois, B)
+    gnat = torch.zeros(lib.nvsr_edsr_natural_floats(*geometry), dtype=torch.float32, device=keep.device)
+    d_lr = [torch.zeros((1, Cc, R0, R1), dtype=torch.float32, device=keep.device) if n else _f(0, like=keep) for n in need_lr]
+    ws = _f(lib.nvsr_planes_sr_batch_backward_workspace_floats(B, Cc, R0, R1, hid, nb, n_up, pad, None), like=keep)
+    d_out_ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in d_out])
+    d_lr_ptrs = (C.c_void_p * B)(*[(t.data_ptr() if n else None) for t, n in zip(d_lr, need_lr)])
+    sizes = [9 * hid * cin] + [9 * hid * hid] * (2 * nb + 1) + [9 * 4 * hid * hid] * n_up + [9 * cout * hid]       # floats per layer, state-dict order
+    marks = bucket_sync.plan(sizes, gnat)            # [(first layer of the bucket, lo, hi, torch.cuda.Event)], last bucket of the blob first
+    layers = (C.c_int32 * len(marks))(*[m[0] for m in marks])
+    events = (C.c_void_p * len(marks))(*[m[3].cuda_event for m in marks])
+    capi.call("nvsr_planes_sr_backward_batch_marks", B, Cc, R0, R1, capi.ptr(keep), capi.ptr(packed_dgrad), hid, nb, n_up, pad, over, rois_c, capi.ptr(std),
+              d_out_ptrs, capi.ptr(gnat), d_lr_ptrs if any(need_lr) else None, capi.ptr(ws), arithmetic, int(bool(align_corners)), int(bool(bicubic)),
+              len(marks), layers, events, capi.stream())
+    bucket_sync.reduce_marked(gnat, marks)           # collectives behind their events; the current stream then waits for them and scales
+    return [gnat] + d_lr
+
+
 class PlanesSRBatchFn(torch.autograd.Function):
     """PlanesSR on the regions of interest of B planes as ONE autograd node: inputs (cfg, natural weights blob, lr_0 .. lr_{B-1}) -> B
     super-resolved planes; the backward returns ONE weight-gradient blob (torch's cat / reshape backward hands the slices to the
-    convolutions' parameters once per iteration instead of once per plane) and the LR planes' gradients."""
+    convolutions' parameters once per iteration instead of once per plane) and the LR planes' gradients.
+    cfg["bucket_sync"] (data-parallel training; distributed.OverlappedSRGradSync): the blob comes back ALREADY averaged over the ranks -- its
+    buckets were all-reduced while the backward was still computing the layers in front of them."""
 
     @staticmethod
     def forward(ctx, cfg, natural, *lrs):
@@ -959,8 +990,13 @@ class PlanesSRBatchFn(torch.autograd.Function):
         cfg = ctx.cfg
         need = ctx.needs_input_grad
         need_lr = [bool(n) for n in need[2:]]
-        res = direct.planes_sr_backward_batch(keep, packed_dgrad, list(ctx.shapes[0][-3:]), cfg["geometry"], cfg["pad"], cfg["over"], cfg["rois"], cfg["std"],
-                                              [capi.f32c(g) for g in d_outs], need_lr, cfg["arithmetic"], cfg["align_corners"], cfg["bicubic"])
+        args = (keep, packed_dgrad, list(ctx.shapes[0][-3:]), cfg["geometry"], cfg["pad"], cfg["over"], cfg["rois"], cfg["std"],
+                [capi.f32c(g) for g in d_outs], need_lr, cfg["arithmetic"], cfg["align_corners"], cfg["bicubic"])
+        sync = cfg.get("bucket_sync")
+        if sync is not None and need[1] and sync.active():
+            res = planes_sr_backward_batch_marked(*args, sync)
+        else:
+            res = direct.planes_sr_backward_batch(*args)
         return (None, res[0] if need[1] else None) + tuple(g.reshape(sh) if n else None for g, sh, n in zip(res[1:], ctx.shapes, need_lr))
 
 

@@ -56,7 +56,11 @@ def decoder_blob(sd, prefix=""):
 class Oracle:
     def __init__(self, f32=False):
         build()
-        self.lib = C.CDLL(os.path.join(HERE, "liborc_f32.so" if f32 else "liborc.so"))
+        # NVSR_ORACLE_SANITIZE=1 (tests/test_oracle.py, with libasan preloaded): both flavours run the -fsanitize=address,undefined build
+        name = "liborc_san.so" if os.environ.get("NVSR_ORACLE_SANITIZE") == "1" else ("liborc_f32.so" if f32 else "liborc.so")
+        if name == "liborc_san.so" and not os.path.exists(os.path.join(HERE, name)):
+            subprocess.check_call(["make", "-s", "-C", HERE, "san"])
+        self.lib = C.CDLL(os.path.join(HERE, name))
         self.lib.orc_decoder_blob_floats.restype = C.c_long
         self.lib.orc_edsr_blob_floats.restype = C.c_long
         self._keep = []

@@ -136,6 +136,81 @@ def _worker(rank, world, port, tmp):
             dist.all_gather(both, p.data.contiguous())
             assert torch.equal(both[0], both[1]), "the ranks' parameters drifted apart in iteration %d" % it
             assert torch.allclose(p.data, q.data, rtol=1e-5, atol=1e-6), float((p.data - q.data).abs().max())
+    # the SR network's gradient all-reduced bucket by bucket INSIDE the backward (distributed.OverlappedSRGradSync: what
+    # ops.PlanesSRBatchFn.backward does with the blob nvsr_planes_sr_backward_batch_marks fills) against the post-backward path above: a stand-in
+    # autograd node with the real node's protocol (one weight-gradient blob in state-dict order, plan() -> buckets that are suffixes of the blob,
+    # reduce_marked() before the blob goes back to autograd).  Parameters bit-identical to the post-backward path on both ranks, every iteration.
+    class FakeSR(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            gen = torch.Generator().manual_seed(11)
+            self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(sh, generator=gen) * 0.1)
+                                              for sh in ((8, 4, 3, 3), (8, 8, 3, 3), (8, 8, 3, 3), (8, 8, 3, 3), (32, 8, 3, 3), (4, 8, 3, 3))])
+
+    class FakeBatchFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, sync, sizes, coef, blob):
+            ctx.sync, ctx.sizes = sync, sizes
+            ctx.save_for_backward(coef, blob)
+            return ((blob * coef) ** 2).sum()
+
+        @staticmethod
+        def backward(ctx, d):
+            coef, blob = ctx.saved_tensors
+            g = 2.0 * blob * coef * coef * d
+            if ctx.sync is not None and ctx.sync.active():
+                marks = ctx.sync.plan(ctx.sizes, g)
+                assert marks[0][2] == g.numel() and marks[-1][1] == 0 and all(a[1] == b[2] for a, b in zip(marks, marks[1:]))      # suffixes, last first
+                assert [m[0] for m in marks] == sorted((m[0] for m in marks), reverse=True)
+                ctx.sync.reduce_marked(g, marks)
+            return None, None, None, g
+
+    def sr_loss(net, sync, r, it):
+        gen = torch.Generator().manual_seed(1000 * it + r)
+        blob = torch.cat([w.reshape(-1) for w in net.ws])
+        return FakeBatchFn.apply(sync, [w.numel() for w in net.ws], torch.randn(blob.shape, generator=gen), blob)
+
+    def run(overlapped):
+        torch.manual_seed(5)
+        net, others = FakeSR(), make_params()[:2]
+        if overlapped:
+            sync = D.OverlappedSRGradSync(net, other_parameters=others, bucket_bytes=4096)
+            assert net.__dict__["grad_bucket_sync"] is sync
+        else:
+            sync = lambda: D.allreduce_gradients([p.grad for p in others + list(net.parameters()) if p.grad is not None])
+        st = nvsr_amd.training.TrainStep(None, None, None, {"LR_planes", "decoder", "SR"}, optimizer=torch.optim.Adam([others[1]], lr=1e-2),
+                                         SR_optimizer=torch.optim.Adam(net.parameters(), lr=1e-2), planes_optimizer=torch.optim.Adam([others[0]], lr=1e-2),
+                                         SR_model=None, grad_sync=sync)
+        hist = []
+        for it in range(3):
+            for p in others + list(net.parameters()):
+                p.grad = None
+            loss = sr_loss(net, sync if overlapped else None, rank, it) + loss_of(others, rank, it)
+            st.apply_gradients(loss, sr_iter=True)
+            if overlapped:
+                assert sync.stats["buckets"] >= 3 and not sync.reduced_in_backward          # several buckets; the flag was consumed by sync()
+            hist.append([p.detach().clone() for p in others + list(net.parameters())])
+        return hist
+    a, b = run(True), run(False)
+    for it in range(3):
+        for p, q in zip(a[it], b[it]):
+            assert torch.equal(p, q), "overlapped and post-backward gradient averaging differ in iteration %d" % it
+            both = [torch.empty_like(p) for _ in range(world)]
+            dist.all_gather(both, p.contiguous())
+            assert torch.equal(both[0], both[1])
+    # an iteration whose SR backward did NOT hand its blob over (one plane / exact f32: PlanesSR.forward): sync() averages the SR gradients itself
+    net = FakeSR()
+    sync = D.OverlappedSRGradSync(net, other_parameters=[])
+    for w in net.ws:
+        w.grad = torch.full_like(w, float(rank + 1))
+    sync()
+    assert all(torch.equal(w.grad, torch.full_like(w, 1.5)) for w in net.ws)
+    sync.detach()
+    assert "grad_bucket_sync" not in net.__dict__
+    # buckets of allreduce_coalesced: one dtype each, never beyond the bound
+    mixed = [torch.full((300,), float(rank + 1)), torch.full((300,), float(rank + 1), dtype=torch.float64), torch.full((700,), float(rank + 1))]
+    D.allreduce_coalesced(mixed, scale=0.5, bucket_bytes=2048)
+    assert all(torch.equal(t, torch.full_like(t, 1.5)) for t in mixed) and mixed[1].dtype == torch.float64
     try:
         nvsr_amd.training.GraphedTrainStep(step, torch.zeros(4, 4, 3), torch.eye(4), 4, 4, 1.0, 1, "s", None, 8)
         raise AssertionError("a data-parallel step was accepted for graph capture")

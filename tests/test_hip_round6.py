@@ -104,10 +104,66 @@ def test_prologue_ahead_on_targets_produced_every_iteration(hip):
             img = torch.full((H, W, 3), 0.2 * it, device=DEV) + x[:H, :W * 3].reshape(H, W, 3).clamp(0, 0) \
                 + torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5 + it)).to(DEV) * 0.1
             pose = pose0 + x[:4, :4].clamp(0, 0)      # a pose "computed" behind the same queue
-            assert img._version == 0 or True
             m = step(it, img, pose, H, W, focal, 1, sid, scfg, 150, sr_iter=True)
             losses.append(m["loss"])
             del img, pose
         res[ahead] = losses
     assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(res[True], res[False])), res
     assert len(set(round(v, 6) for v in res[False])) == 4          # (the four targets really differ: a stale image would show)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the EDSR gradient all-reduced bucket by bucket while the SR backward runs (nvsr_planes_sr_backward_batch_marks)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_overlapped_sr_gradient_sync_through_rccl_on_one_rank():
+    """distributed.OverlappedSRGradSync on backend "nccl" (= RCCL) with a process group of ONE rank (all a test box has): the batched SR backward
+    records one event per bucket where that suffix of the weight-gradient blob is final, the collective stream waits for each event and RCCL
+    all-reduces the bucket in place while the remaining layers are computed, the iteration's stream waits for the collectives.  Sums over one
+    rank are the inputs: the gradients (weights and LR planes) must equal the unmarked backward's bit for bit (same kernels, same order), three
+    ragged crops, several buckets; and a bucket's event really precedes the end of the backward."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, socket
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import nvsr_amd
+        D = nvsr_amd.distributed
+        rois = [[-0.9, -0.35, 0.1, 0.8], [-1.0, -1.0, 0.2, 0.3], [-0.2, -0.6, 0.95, 0.4]]
+        res = {}
+        for overlapped in (False, True):
+            torch.manual_seed(31)
+            sr = nvsr_amd.models.PlanesSR(nvsr_amd.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 128, "n_blocks": 3}}, "bilinear").to(dev)
+            sr.train()
+            gen = torch.Generator(device=dev).manual_seed(32)
+            lrs = [torch.nn.Parameter(torch.randn(1, 48, 24, 24, device=dev, generator=gen) * 0.5) for _ in range(3)]
+            for k, t in enumerate(lrs):
+                sr.set_LR_plane(t, id="p%%d" %% k, save_interpolated=False)
+            sync = None
+            if overlapped:
+                sync = D.OverlappedSRGradSync(sr, other_parameters=lrs, bucket_bytes=1 << 20, single_rank_ok=True)
+            outs = sr.forward_many([("p%%d" %% k, rois[k]) for k in range(3)])
+            ws = [torch.randn(o.shape, device=dev, generator=gen) for o in outs]
+            sum((torch.nan_to_num(o) * w).sum() for o, w in zip(outs, ws)).backward()
+            if overlapped:
+                assert sync.reduced_in_backward and sync.stats["buckets"] >= 3, sync.stats
+                sync()                                                         # the other parameters (here: the LR planes) through allreduce_gradients
+                assert not sync.reduced_in_backward
+            torch.cuda.synchronize()
+            res[overlapped] = ([w.grad.clone() for w in sr.inner_model.conv_parameters()], [t.grad.clone() for t in lrs])
+        for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
+            assert float(b.abs().max()) > 0 and torch.equal(a, b)
+        dist.barrier(); dist.destroy_process_group()
+        print("RCCL_OVERLAPPED_SYNC_OK")
+    """ % root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OVERLAPPED_SYNC_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
