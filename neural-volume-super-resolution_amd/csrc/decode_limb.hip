@@ -253,7 +253,7 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
                                                                     unsigned* __restrict__ flag) {
     constexpr int L3_SMALL = L3<LF>::SMALL;
     __shared__ __attribute__((aligned(16))) unsigned lds[L3<LF>::LDS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     // (wave index as a SCALAR: the LDS destination of every weight-copy piece then is scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
     RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LF)), 0, KB_TOTAL * kb_words(LF) * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};

@@ -36,7 +36,7 @@ __device__ __forceinline__ f32x16 mfma32w(float a, float b, f32x16 c) { return _
 // P = valid rows (may be odd: the second row of the last pair is then read as zero)
 __global__ __launch_bounds__(WG_TPB, 2) void decoder_wgrad_kernel(WJobs jobs, long P, int slab, float* __restrict__ grad) {
     __shared__ __attribute__((aligned(16))) float tile[128 * 64];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(tile);      // (probe builds only, nvsr_common.h)
     const WJob jb = jobs.j[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int per_wave = slab / 4;                                   // even (host guarantees slab % 8 == 0)
@@ -269,7 +269,7 @@ __device__ __forceinline__ void wgrad_limb_block(const WJob& jb, long P, int sla
 template <int NB>
 __global__ __launch_bounds__(WG_TPB, 1) void decoder_wgrad_limb_kernel(WJobs jobs, int job0, long P, int slab, float* __restrict__ grad) {
     __shared__ __attribute__((aligned(16))) float tile[128 * 32 * NB];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(tile);      // (probe builds only, nvsr_common.h)
     wgrad_limb_block<NB>(jobs.j[job0 + blockIdx.y], P, slab, tile, grad);
 }
 

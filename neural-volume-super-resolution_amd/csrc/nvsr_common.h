@@ -2,20 +2,40 @@
 #pragma once
 // ---- race probe (tools/race_probe.sh; NEVER the product) ---------------------------------------------------------------------------------
 // Round 5 found a data race that four rounds of parity tests had passed over: the backward kernels read head weights out of LDS in front of the
-// first workgroup barrier; alone on a GPU the waves of a workgroup start together and the race never shows.  -DNVSR_RACE_PROBE=1 builds a probe
-// library in which, in EVERY kernel that fills LDS cooperatively, all waves but the first start LATE (8 x s_sleep 127: ~30 us): whatever a kernel reads
-// from LDS before a barrier has published it is then stale with certainty, and the parity tests fail instead of passing by luck.
+// first workgroup barrier; alone on a GPU the waves of a workgroup start together and the race never shows -- and even a late wave usually finds
+// the RIGHT bytes, left behind by the previous workgroup of the same kernel.  -DNVSR_RACE_PROBE=1 builds a probe library in which, in EVERY kernel
+// that fills LDS cooperatively, the first wave starts by filling the kernel's whole LDS array with NaN patterns (behind a start-of-kernel barrier of the probe's own) and all
+// other waves then start ~50 us LATE (real-time counter): whatever the first wave reads from LDS before a barrier has published it is then NaN with certainty, and the parity
+// tests fail instead of passing by luck.  NVSR_RACE_PROBE_DELAY(lds) stands right behind the kernel's __shared__ array.
 #ifndef NVSR_RACE_PROBE
 #define NVSR_RACE_PROBE 0
 #endif
+#ifndef NVSR_RP_LO            // (bisection of a finding: poison only the words [NVSR_RP_LO, NVSR_RP_HI) of the array)
+#define NVSR_RP_LO 0u
+#define NVSR_RP_HI 0xffffffffu
+#endif
+#ifndef NVSR_RP_PATTERN
+#define NVSR_RP_PATTERN 0x7fc00000u
+#endif
 #if NVSR_RACE_PROBE
-#define NVSR_RACE_PROBE_DELAY()                                                                     \
-    do {                                                                                            \
-        if ((threadIdx.x >> 6) != 0)                                                                \
-            for (int nvsr_rp_ = 0; nvsr_rp_ < 8; ++nvsr_rp_) __builtin_amdgcn_s_sleep(127);        \
+#define NVSR_RACE_PROBE_DELAY(ARR)                                                                                          \
+    do {                                                                                                                    \
+        if (NVSR_RACE_PROBE == 1) {                  /* (2: the late start alone, no poison) */                             \
+            /* the first wave fills the array (stores through the array itself = ds_write), THEN a start-of-kernel barrier, THEN the    \
+               others sleep: a sleeping wave wakes after a few microseconds at most, and a poison store that lands behind another    \
+               wave's real store would be the probe's own race (seen: s_sleep is far shorter than its 64 x 127 clocks suggest) */    \
+            if ((threadIdx.x >> 6) == 0)                                                                                    \
+                for (unsigned nvsr_rp_ = NVSR_RP_LO + threadIdx.x; nvsr_rp_ < sizeof(ARR) / 4 && nvsr_rp_ < NVSR_RP_HI; nvsr_rp_ += 64) \
+                    (ARR)[nvsr_rp_] = __builtin_bit_cast(__typeof__((ARR)[0] + 0), NVSR_RP_PATTERN);                        \
+            __syncthreads();                                                                                                \
+        }                                                                                                                   \
+        if ((threadIdx.x >> 6) != 0) {               /* ~50 us by the 100 MHz real-time counter (s_sleep alone proved far shorter) */ \
+            const unsigned long long nvsr_rp_t0_ = __builtin_amdgcn_s_memrealtime();                                        \
+            while (__builtin_amdgcn_s_memrealtime() - nvsr_rp_t0_ < 5000ull) __builtin_amdgcn_s_sleep(127);                 \
+        }                                                                                                                   \
     } while (0)
 #else
-#define NVSR_RACE_PROBE_DELAY() do { } while (0)
+#define NVSR_RACE_PROBE_DELAY(ARR) do { } while (0)
 #endif
 
 #include <hip/hip_runtime.h>

@@ -35,7 +35,7 @@ constexpr int PTS_PER_WG = NWAVES * 32;
 __global__ __launch_bounds__(TPB, 1) void triplane_decode_kernel(SceneDev sc, const float* __restrict__ packed, long P,
                                                                  const float* __restrict__ x, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<NWAVES>(rs);
     const long ntiles = (P + PTS_PER_WG - 1) / PTS_PER_WG;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TPB, 1) void decode_rays_kernel(SceneDev sc, const 
                                                              const float* __restrict__ rays, const float* __restrict__ z,
                                                              float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<NWAVES>(rs);
     const long nrb = (N + PTS_PER_WG - 1) / PTS_PER_WG;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(TPB, 1) void render_pass_kernel(SceneDev sc, const 
                                                              float* __restrict__ acc, float* __restrict__ weights,
                                                              float* __restrict__ depth, float* __restrict__ raw_out) {
     __shared__ __attribute__((aligned(16))) float lds[RENDER_LDS_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<NWAVES>(rs);
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
                                                               float* __restrict__ acc, float* __restrict__ weights,
                                                               float* __restrict__ depth, float* __restrict__ raw_out) {
     __shared__ __attribute__((aligned(16))) float lds[LDS2_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     Ring2 rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     for (int i = threadIdx.x; i < SMALL_FLOATS; i += TPB2) lds[LDS2_SMALL + i] = packed[P_SMALL + i];
     const float* small = lds + LDS2_SMALL;
@@ -141,6 +141,12 @@ __global__ __launch_bounds__(TPB2, 1) void render_pass2_kernel(SceneDev sc, cons
         return j;
     };
 
+    // Round 6 (found by the race probe, tools/race_probe.sh): the first sample's bias preload (load_bias2 below) reads `small` IN FRONT OF the
+    // first ring barrier -- words that every wave of the workgroup has just copied into LDS.  A wave that starts late leaves the others reading
+    // whatever the previous workgroup left there: the right bytes after a launch of this kernel with the same decoder (why every test passed), the
+    // wrong ones otherwise (probe: 3-5 % of a frame's pixels off by 1e-5 .. 1e-2).  Same class as round 5's backward-prologue race.  The barrier also
+    // publishes the ray cache (written by lanes 0..31, read by all 64).
+    __syncthreads();
     const float* cur = ring2_issue<48>(rs, P_RGB0);        // chunk C0 of sample 0; every later C0 is issued during the previous sample
     for (int s = 0; s < S; ++s) {
         asm volatile("" : "+v"(rs.voff), "+v"(rs.lane));

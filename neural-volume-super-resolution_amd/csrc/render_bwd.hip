@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BTPB, 1) void render_pass_backward_kernel(SceneDev 
                                                                       const float* __restrict__ g_raw, GradPlanes gp, DecRecord rec,
                                                                       float* __restrict__ gview) {
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<BNW>(rs);
     __syncthreads();          // (the transposed alpha head reads these LDS words in front of the first ring barrier: render_bwd_limb.hip)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(MBwd<RECORD>::TPB, 1) void render_pass_backward_gat
                                                                             float* __restrict__ gview, DecRecord rec) {
     constexpr int MNW = MBwd<RECORD>::NW, MPTS = MBwd<RECORD>::PTS;
     __shared__ __attribute__((aligned(16))) float lds[MBwd<RECORD>::LDS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingState rs{packed, lds, 0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     decode_prologue<MNW>(rs);                    // head weights / biases of the FORWARD blob -> LDS
     __syncthreads();          // (the transposed alpha head reads these LDS words in front of the first ring barrier: render_bwd_limb.hip)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
                                                                                    float* __restrict__ gview, DecRecord rec) {
     constexpr int BL_SMALL = BLds<LF>::SMALL, BL_TILES = BLds<LF>::TILES;
     __shared__ __attribute__((aligned(16))) unsigned lds[BLds<LF>::LDS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     RingB rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed_bwd + B_TOTAL + BLimb<LF>::OFFSET), 0, BLimb<LF>::WORDS * 4, 0x00020000), lds, 0,
              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63) * 16u};
     float* ldsf = reinterpret_cast<float*>(lds);

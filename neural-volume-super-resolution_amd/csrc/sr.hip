@@ -228,7 +228,7 @@ __global__ __launch_bounds__(CO_WAVES * PX_WAVES * 64, 2) void conv3x3_kernel(Co
     constexpr int W_BLOCKS = W_FLOATS / 256;     // 1-KiB DMA blocks
     constexpr int W_ITERS = (W_BLOCKS + CONV_WAVES - 1) / CONV_WAVES;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int cw = wave / PX_WAVES, rg = wave % PX_WAVES;   // co-wave, pixel-row group
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_limb_kernel(ConvParams p, Conv
     constexpr int LIMB_WORDS = PR * PC * 2 * 4;           // one limb of the patch
     constexpr int BUF = 3 * LIMB_WORDS;
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     // tile of this workgroup from the XCD-contiguous linear tile index (conv_tile_index): column chunk, row tile, then (plane, co-group) --
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && NCB == 2) ? 2 : 1) void 
     constexpr int LIMB_WORDS = 4 * OSTR * 4;              // one limb of the patch
     constexpr int BUF = LIMBS * LIMB_WORDS;
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
 #define CV16_ITEM(R, O, COL) ((O) * OSTR + (R) * PC + (COL))
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;

@@ -46,7 +46,7 @@ struct WgradPlane { const float* dy; const float* x; int Ho, Wo; };
 
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_kernel(WgradParams p) {
     __shared__ float lds[DY_FLOATS + X_FLOATS];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     float* dyt = lds;
     float* xt = lds + DY_FLOATS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
@@ -429,7 +429,7 @@ __device__ __forceinline__ void wgrad_limb_rows(const WgradParams& p, const Wgra
 template <int LF>
 __global__ __launch_bounds__(WG_TPB, 2) void conv3x3_wgrad_limb_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned lds[LF * (WL_DY_WORDS + WL_X_WORDS)];
-    NVSR_RACE_PROBE_DELAY();      // (probe builds only, nvsr_common.h)
+    NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     float dscale = 1.0f;          // f16 limbs: the power of two that puts the largest |dy| of the tensor into [2^12, 2^13) (sr.hip, the data gradient's rule)
     if (LF == 2 && p.dy_absmax) {
         dscale = f16_gradient_scale((unsigned)__builtin_amdgcn_readfirstlane((int)*p.dy_absmax));

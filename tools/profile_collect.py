@@ -138,6 +138,20 @@ for w in ("refine_joint", "refine_sr"):
                                                  "source": "rocprofv3 --kernel-trace --stats of bench.py --workload refine (per-iteration means over %d iterations)" % iters}
         except Exception as e:      # a condensed profile must not fail on a missing field
             print("refine split:", e)
+# executed matrix instructions of the SR workloads against the algorithmic count (tile rounding on ragged crops): one more counter
+# pass each; algorithmic = FLOP of the line x 3 limb products / 16 384 FLOP per v_mfma_f32_16x16x32 (the three launches per step on the narrow
+# kernels execute 32x32x16 instructions of twice the FLOP: < 1 % of the count)
+for w, pick in (("sr", summed(lambda k: "conv3x3" in k)), ("refine_joint", second_half(is_sr_conv))):
+    for f in sorted(glob.glob(os.path.join(src, "pmc_%s_SQ_INSTS_MFMA" % w, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
+        got = pick([r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_INSTS_MFMA"])
+        roof = out.get(w, {}).get("roofline", {})
+        flop = roof.get("algorithmic_flop_per_step")
+        if got and w in latest and flop:
+            alg = flop * 3.0 / 16384.0
+            latest[w]["SQ_INSTS_MFMA"] = got[0]
+            latest[w]["algorithmic_mfma_instructions"] = alg
+            latest[w]["executed_over_algorithmic_mfma"] = got[0] / alg
+            print("%s: SQ_INSTS_MFMA %.4g executed / %.4g algorithmic = %.3f" % (w, got[0], alg, got[0] / alg))
 if "traffic_bytes" in latest:
     json.dump(latest, open(os.path.join(dst, "%s_pmc.json" % tag), "w"), indent=1)
     json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)

@@ -31,6 +31,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # matrix-pipe utilisation and clock of the fine pass (one more counter pass of the same command)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
+# executed matrix instructions of the SR stage and of a refine iteration (executed / algorithmic: tile rounding on ragged crops)
+rocprofv3 --pmc SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_sr_SQ_INSTS_MFMA -- python3 $R/bench.py --workload sr --steps 1 --warmup 0 --no-cpu-baseline --no-modes > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_refine_joint_SQ_INSTS_MFMA -- python3 $R/bench.py --workload refine --refine-what joint --steps 1 --warmup 1 --no-cpu-baseline --no-split > /dev/null 2>&1
 # issue counters of the training kernels (fine-pass forward / gate-driven backward): tools/train_pmc.sh (4 counter passes of the train bench)
 bash $R/tools/train_pmc.sh > $O/train_issue_counters.txt 2>&1
 # keep the merged-back payload small (gpurun copies back at most 64 MiB): the counter passes' kernel traces are not read by tools/profile_collect.py
