@@ -16,7 +16,7 @@
 
 #ifndef L3_ABLATE
 #define L3_ABLATE 0   // timing experiments only (wrong results): 1 no plane gathers, 2 no gate words, 4 no wait for the weight copies,
-#endif                // 8 no bias + ReLU                                                        (tools/ab_flags.sh)
+#endif                // 8 no bias + ReLU; 16 (correct results) the old vmcnt(0) behind a layer's record stores          (tools/ab_flags.sh)
 
 namespace nvsr {
 
@@ -52,9 +52,13 @@ __device__ __forceinline__ const unsigned* ringl_issue(RingL& rs, int kb0) {
     rs.slot ^= 1;
     return dst;
 }
+// YOUNGER: vector-memory operations this wave has issued AFTER the copy it waits for and that may stay in flight (vmcnt counts loads, stores and
+// LDS-DMA together, in issue order: MI355X_MICROARCH.md) -- the record / gate stores of a finished layer, which come behind the next chunk's copy
+template <int YOUNGER = 0>
 __device__ __forceinline__ void ringl_sync() {
 #if !(L3_ABLATE & 4)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (YOUNGER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(YOUNGER) : "memory");
 #endif
     __syncthreads();
 }
@@ -149,9 +153,10 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
 #endif
     // one chunk: wait for it, start the copy of the next one, split the block's first K-block, multiply
     // (FIRST: the block's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
-#define L3_BLOCK_(NKB, ZERO, FIRST, SRC, NEXT, TAIL)                                           \
+#define L3_BLOCK_(NKB, ZERO, FIRST, SRC, NEXT, TAIL) L3_BLOCK_Y(0, NKB, ZERO, FIRST, SRC, NEXT, TAIL)
+#define L3_BLOCK_Y(YOUNGER, NKB, ZERO, FIRST, SRC, NEXT, TAIL)                                 \
     {                                                                                          \
-        ringl_sync();                                                                          \
+        ringl_sync<YOUNGER>();                                                                 \
         const unsigned* nw = NEXT;                                                             \
         if (FIRST) { auto s_ = SRC; split_all<LF>([&](int i) { return s_(0, i); }, cur); }      \
         limb_block<LF, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, TAIL);               \
@@ -168,10 +173,17 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     L3_BLOCK(2, false, hid(act, 6), NEXT)
 #else
 #define L3_HIDDEN(KB0, NEXT)                                                                   \
-    L3_BLOCK_(3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), tail_of(act, 3))      \
+    L3_BLOCK_Y(FIN_YOUNG, 3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), tail_of(act, 3))      \
     L3_BLOCK_(3, false, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6), tail_of(act, 6))    \
     L3_BLOCK_(2, false, false, hid(act, 6), NEXT, NoTail{})
 #endif
+    // Round 6: the 16 record stores of a finished layer (512 B per point) are the YOUNGEST vector-memory operations when the next layer's first
+    // block waits for its weight chunk -- the chunk's copy was issued a block earlier.  That wait used to be vmcnt(0): every layer's record went
+    // out to HBM with the wave standing still behind it (the recording forward took compute + stores, 0.41 + 0.57 ms at S = 128).  It now leaves
+    // those 16 in flight (ringl_sync<16>); they have the whole first block to land before the second block's vmcnt(0).  For the count to hold on
+    // every wave the record stores are issued unconditionally: padding lanes rewrite the record row of the valid point they mirror with the same
+    // values (rec_ok is true for every lane of a recording launch, see the kernel).
+    constexpr int FIN_YOUNG = (RECORD && !(L3_ABLATE & 16)) ? 16 : 0;
     auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
         if (L3_ABLATE & 8) {
 #pragma unroll
@@ -225,7 +237,7 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         for (int c = 0; c < 3; ++c) raw[c] = hd[c] + small[S_HEAD_B + 1 + c];
     }
     // ---- density decoder: 48 -> 128 x 4 -> 1 -----------------------------------------------------------------------------------------
-    L3_BLOCK(3, true, feat(D), L3_ISSUE(3, KB_DEN1))
+    L3_BLOCK_Y(FIN_YOUNG, 3, true, true, feat(D), L3_ISSUE(3, KB_DEN1), NoTail{})        // (behind finish(7)'s record stores)
     finish(0, rec.Hd);
     L3_HIDDEN(KB_DEN1, L3_ISSUE(3, KB_DEN1 + 8))
     finish(1, rec.Hd + LP);
@@ -295,7 +307,8 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
         float raw[4];
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
-        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, ppx, ppy, ppz, vt, raw, gl, rec, record_row(ray, s, N, S), valid, nscale);
+        // (rec_ok = true on every lane of a recording launch: padding lanes hold the clamped point's values and rewrite its row -- FIN_YOUNG)
+        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, ppx, ppy, ppz, vt, raw, gl, rec, record_row(ray, s, N, S), RECORD ? true : valid, nscale);
         if (valid && rs.lane < 32) {
             *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
             // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag)

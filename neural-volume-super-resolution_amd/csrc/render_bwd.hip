@@ -13,6 +13,7 @@
 //      them into the channel-last gradient plane with one global_atomic_add_f32 wave-instruction per (point, tap): 48 lanes =
 //      192 contiguous bytes, the fast shape of float atomics (one-lane-per-row scatter is ~17x slower, MI355X_MICROARCH.md).
 #include "bwd_core.h"
+#include "wave_scan.h"
 
 namespace nvsr {
 
@@ -533,13 +534,13 @@ __global__ __launch_bounds__(CB_WPB * 64) void composite_backward_kernel(long N,
             gw = g0 / (1.0f + expf(-rv[0])) + g1 / (1.0f + expf(-rv[1])) + g2 / (1.0f + expf(-rv[2])) + ga;
             if (g_dep) gw += gd * (mip ? 0.5f * (z[ray * zp + s] + z[ray * zp + s + 1]) : z[ray * zp + s]);      // d depth_map / d w_s = the sample's depth
         }
-        float incl = fac;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if (lane >= o) incl *= t; }
+        // (the forward compositor's own scan and carry, aux.hip composite_kernel: the transmittances recomputed here are the forward's bit for bit
+        //  -- rounds 1-5 ran a Hillis-Steele order over __shfl_up here, which since round 5's DPP scans differed from the forward's in the last ulp)
+        const float incl = wave_scan_mul(fac, lane);
         float excl = __shfl_up(incl, 1);
         if (lane == 0) excl = 1.0f;
-        const float T = excl * Tcarry;
-        Tcarry *= __shfl(incl, 63);
+        const float T = __fmul_rn(excl, Tcarry);
+        Tcarry = __fmul_rn(__shfl(incl, 63), Tcarry);
         if (s < S) { sT[wave][s] = T; sA[wave][s] = alpha; sG[wave][s] = gw; }
     }
     __builtin_amdgcn_wave_barrier();

@@ -132,9 +132,13 @@ __device__ __forceinline__ const unsigned* ringb_issue(RingB& rs, int chunk) {
     rs.slot = slot ^ 1;
     return dst;
 }
-__device__ __forceinline__ void ringb_sync() {
+// YOUNGER: vector-memory operations issued AFTER the copy being waited for that may stay in flight (the 16 record stores of the layer just finished:
+// vmcnt counts loads, stores and LDS-DMA together, in issue order); `counted` (wave-uniform): the wave really issued them
+template <int YOUNGER = 0>
+__device__ __forceinline__ void ringb_sync(bool counted = false) {
 #if !(BL_ABLATE & 1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (YOUNGER > 0 && counted) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(YOUNGER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #if !(BL_ABLATE & 64)
     __syncthreads();
@@ -257,6 +261,11 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         }
         const long q = record_row(ray, s, N, S);                             // record row (the forward wrote X / H of the same row)
         const bool rok = RECORD && valid;
+        // Round 6: a layer's 16 record stores are the youngest vector-memory operations when the next layer's first block waits for its weight chunk
+        // (the chunk's copy was issued a block earlier): that wait leaves them in flight instead of draining them (decode_limb.hip FIN_YOUNG).  The
+        // stores are lane-masked (padding lanes hold zero gradients and must not touch a valid row), so the count holds only on a wave with a valid lane.
+        constexpr int REC_YOUNG = RECORD ? 16 : 0;
+        const bool rec_any = RECORD && __builtin_amdgcn_ballot_w64(valid) != 0ull;
         // (f16 limbs: the accumulators carry the tile's power-of-two scale; the weight-gradient contraction reads unscaled f32 rows)
         float gunscale = gu_d;        // unscale of the chain being walked (record rows)
         auto record_grad = [&](float* base, long q_, int h_, const f32x16 (&a)[4]) {
@@ -303,9 +312,10 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         asm volatile("" : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]) : : "memory");         \
         __builtin_amdgcn_sched_barrier(0);
         // (FIRST: the chunk's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
-#define BL_HBLOCK(ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL)                                            \
+#define BL_HBLOCK(ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL) BL_HBLOCK_Y(0, ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL)
+#define BL_HBLOCK_Y(YOUNGER, ZERO, FIRST, G, KB0, GN, NEXT_CHUNK, TAIL)                                 \
         {                                                                                               \
-            ringb_sync();                                                                               \
+            ringb_sync<YOUNGER>(rec_any);                                                               \
             const unsigned* nw = ringb_issue<LF>(rs, NEXT_CHUNK);                                           \
             if (FIRST && !(BL_ABLATE & 8)) { auto s_ = hid(G, KB0); split_all<LF>([&](int i) { return s_(0, i); }, cur); } \
             limb_block<LF, 2, ZERO, true>(cw, lane, GN, cur, fa, hid(G, KB0), none, TAIL);               \
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         if (!(BL_ABLATE & 2)) { apply_mask(gate(MK), GN); BL_FENCE(GN) }
 #else
 #define BL_HIDDEN_T(G, MK, GN, C0)                                                                      \
-        BL_HBLOCK(true, true, G, 0, GN, (C0) + 1, tail_of(G, 2))                                        \
+        BL_HBLOCK_Y(REC_YOUNG, true, true, G, 0, GN, (C0) + 1, tail_of(G, 2))                           \
         BL_HBLOCK(false, false, G, 2, GN, (C0) + 2, tail_of(G, 4))                                      \
         BL_HBLOCK(false, false, G, 4, GN, (C0) + 3, tail_of(G, 6))                                      \
         BL_HBLOCK(false, false, G, 6, GN, (C0) + 4, NoTail{})                                           \

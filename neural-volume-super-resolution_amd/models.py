@@ -893,6 +893,7 @@ class PlanesSR(nn.Module):
     def clear_SR_planes(self, all_planes=False):
         for name in list(getattr(self, "SR_planes", {})):          # ... and their channel-last copies in the renderer's plane cache
             _PLANE_CACHE.pop(name + "/SR", None)
+        self.__dict__.pop("_planes_arith", None)                     # (train_utils._sr_fallback: the arithmetic the cached planes were made in)
         planes_2_clear = ["SR_planes"]
         if all_planes:
             planes_2_clear += ["LR_planes", "residual_planes"]

@@ -446,24 +446,34 @@ def _range_key(*ms):
 
 
 def _sr_fallback(*ms, redo=False):
-    """the SR networks of these models super-resolve in 'bf16x3' for the evaluation frame being rendered; redo: planes cached from an F16X2 pass
-    (NaN inside) are dropped.  -> [(network, its arithmetic before)]: the caller puts it back after the frame (_sr_restore), so that a later
-    training iteration of the same SR model runs in the arithmetic it was configured with"""
-    changed = []
+    """the SR networks of these models super-resolve in 'bf16x3' for the evaluation frame being rendered.  Cached SR planes are dropped when `redo`
+    says so (they come from an F16X2 pass that raised the range flag: NaN inside) or when they were NOT made in 'bf16x3' (`_planes_arith`, set by
+    _sr_restore behind a fallback frame, forgotten by clear_SR_planes): planes a fallback frame has super-resolved stay cached for the next frames of
+    the same parameters (the arithmetic was put back after every frame, so every later frame found 'f16x2', dropped the planes and ran the
+    SR stage again, ~80 ms per scene and frame).  -> [(PlanesSR, its network's arithmetic before)]: the caller puts it back after the frame
+    (_sr_restore, in a `finally`), so that a later training iteration of the same SR model runs in the arithmetic it was configured with"""
+    changed, seen = [], set()
     for m in ms:
         sr = _sr_of(m)
-        if sr is not None and capi.resolve_conv_arithmetic(sr.inner_model.arithmetic) == capi.ARITHMETIC["f16x2"]:
-            changed.append((sr.inner_model, sr.inner_model.arithmetic))
+        if sr is None or id(sr) in seen:
+            continue
+        seen.add(id(sr))
+        if capi.resolve_conv_arithmetic(sr.inner_model.arithmetic) == capi.ARITHMETIC["f16x2"]:
+            changed.append((sr, sr.inner_model.arithmetic))
             sr.inner_model.arithmetic = "bf16x3"
-            redo = True
-        if sr is not None and redo:
+            if redo or sr.__dict__.get("_planes_arith") != "bf16x3":
+                sr.clear_SR_planes()
+        elif redo:
             sr.clear_SR_planes()
     return changed
 
 
-def _sr_restore(changed):
-    for net, before in changed:
-        net.arithmetic = before
+def _sr_restore(changed, rendered=True):
+    """puts the SR networks' arithmetic back; rendered: the frame completed, the planes now cached were made in 'bf16x3'"""
+    for sr, before in changed:
+        sr.inner_model.arithmetic = before
+        if rendered:
+            sr.__dict__["_planes_arith"] = "bf16x3"
 
 
 def pack_rays(ray_origins, ray_directions, near, far, H=None, W=None, focal=None, no_ndc=True):
@@ -588,26 +598,33 @@ def run_one_iter_of_nerf(H, W, focal, model_coarse, model_fine, batch_rays, opti
         key = _range_key(model_coarse, model_fine)
         if model_fine.__dict__.get("_f16_unfit") == key:
             force = "bf16x3"
-            sr_changed = _sr_fallback(model_coarse, model_fine)
+            # (only when it was the SR stage that left the range -- bit 2: a decoder out of range says nothing about planes super-resolved in f16x2)
+            if model_fine.__dict__.get("_f16_unfit_bits", 3) & 2:
+                sr_changed = _sr_fallback(model_coarse, model_fine)
         else:
             flag = capi.range_flag(rays.device)
             flag.reset()
-    out = launch_all(force)
-    if range_checked and force is None:
-        bits = capi.RangeFlag.raised(flag.read_async())
-        if bits:
-            import warnings
-            if not model_fine.__dict__.get("_f16_unfit_warned"):
-                warnings.warn("weights, plane values or activations beyond NVSR_ARITH_F16X2's range (|W| < 255, |feature / activation| < 4094): this "
-                              "model renders in 'bf16x3' while its parameters stay as they are (set model.arithmetic = 'bf16x3' to render there in "
-                              "the first place)")
-                model_fine.__dict__["_f16_unfit_warned"] = True
-            model_fine.__dict__["_f16_unfit"] = key
-            if bits & 2:
-                sr_changed = _sr_fallback(model_coarse, model_fine, redo=True)
-            out = launch_all("bf16x3")
-            flag.reset()
-    _sr_restore(sr_changed)
+    rendered = False
+    try:
+        out = launch_all(force)
+        if range_checked and force is None:
+            bits = capi.RangeFlag.raised(flag.read_async())
+            if bits:
+                import warnings
+                if not model_fine.__dict__.get("_f16_unfit_warned"):
+                    warnings.warn("weights, plane values or activations beyond NVSR_ARITH_F16X2's range (|W| < 255, |feature / activation| < 4094): this "
+                                  "model renders in 'bf16x3' while its parameters stay as they are (set model.arithmetic = 'bf16x3' to render there in "
+                                  "the first place)")
+                    model_fine.__dict__["_f16_unfit_warned"] = True
+                model_fine.__dict__["_f16_unfit"] = key
+                model_fine.__dict__["_f16_unfit_bits"] = int(bits)
+                if bits & 2:
+                    sr_changed = _sr_fallback(model_coarse, model_fine, redo=True)
+                out = launch_all("bf16x3")
+                flag.reset()
+        rendered = True
+    finally:
+        _sr_restore(sr_changed, rendered)          # (also when a launch raised: the model must not stay in 'bf16x3')
     if inv is not None:
         out = tuple(None if t is None else t.index_select(0, inv) for t in out)
     return out

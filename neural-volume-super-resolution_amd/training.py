@@ -496,10 +496,14 @@ class TrainStep:
         """the tail of an iteration (train_nerf.py:903-914): backward, [data-parallel: grad_sync() averages the gradients over the ranks],
         then the optimizer steps the iteration is entitled to -- every rank steps from the same averaged gradients, so the ranks' parameters
         stay identical (tests/test_distributed.py runs this tail on two gloo ranks)"""
-        # (the seed of the backward pass from a cached scalar: `loss.backward()` fills a new ones_like(loss) -- one more launch -- every iteration)
+        # (the seed of the backward pass from a cached scalar: `loss.backward()` fills a new ones_like(loss) -- one more launch -- every iteration.
+        #  READ-ONLY by contract: _MsePairSum hands it to its backward kernel as an input, nothing in this package writes through it.  A caller who
+        #  registers tensor hooks that modify gradients IN PLACE on the loss itself must set `step.clone_seed = True`: the hook then gets a copy)
         seed = self.__dict__.get("_seed")
         if seed is None or seed.device != loss.device or seed.dtype != loss.dtype:
             seed = self.__dict__["_seed"] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        if getattr(self, "clone_seed", False):
+            seed = seed.clone()
         loss.backward(seed if loss.dim() == 0 else None)
         if self.grad_sync is not None:
             self.grad_sync()

@@ -168,3 +168,51 @@ def test_overlapped_sr_gradient_sync_through_rccl_on_one_rank():
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_OVERLAPPED_SYNC_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# planes super-resolved by a fallback frame stay cached; an exception inside a frame leaves the network's arithmetic alone
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_fallback_frames_keep_their_super_resolved_planes(hip):
+    """An SR network beyond NVSR_ARITH_F16X2's range (a trunk weight of 300): the first frame raises bit 2, super-resolves and renders again in 'bf16x3'.
+    Every LATER frame of the same parameters goes to 'bf16x3' directly and must find the planes that frame cached (round 5 dropped them and ran the SR
+    stage again on every frame).  The network's configured arithmetic is untouched in between, also when a launch inside the frame raises."""
+    import warnings
+    from bench import make_synthetic_scene, render_options
+    mc, mf, sid, pose = make_synthetic_scene(DEV, plane_res=24, view_res=8, seed=9)
+    torch.manual_seed(3)
+    sr = hip.models.PlanesSR(hip.models.EDSR, 4, 48, 48, {"model": {"hidden_size": 128, "n_blocks": 1}}, "bilinear").to(DEV)
+    sr.eval()
+    mf.assign_SR_model(sr, SR_viewdir=False)
+    mf.assign_LR_planes()
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = hip.nerf_helpers.get_ray_bundle(H, W, focal, pose)
+    opts, scfg = render_options(16, 16)
+    ev = lambda: hip.train_utils.eval_nerf(H, W, focal, mc, mf, ro, rd, opts, scene_id=sid, scene_config=scfg)
+    with torch.no_grad():
+        sr.inner_model.residual[0].conv1.weight[17, 3, 1, 1] = 300.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        first = ev()
+    assert torch.isfinite(first[3]).all() and sr.inner_model.arithmetic is None and sr.__dict__.get("_planes_arith") == "bf16x3"
+    cached = {k: v for k, v in sr.SR_planes.items()}
+    assert len(cached) == 3
+    second = ev()
+    assert torch.equal(second[3], first[3]) and sr.inner_model.arithmetic is None
+    assert all(sr.SR_planes[k] is v for k, v in cached.items()), "the fallback frame's planes were super-resolved again"
+    sr.clear_SR_planes()                                        # (the caller changed a plane: the tag goes with the planes)
+    assert "_planes_arith" not in sr.__dict__
+    # a launch that raises inside a fallback frame: the arithmetic is put back, the tag is not set
+    real = hip.train_utils.predict_and_render_radiance
+    def boom(*a, **k):
+        raise RuntimeError("boom")
+    hip.train_utils.predict_and_render_radiance = boom
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            ev()
+    finally:
+        hip.train_utils.predict_and_render_radiance = real
+    assert sr.inner_model.arithmetic is None and "_planes_arith" not in sr.__dict__
+    third = ev()
+    assert torch.equal(third[3], first[3])
