@@ -140,14 +140,15 @@ for w in ("refine_joint", "refine_sr"):
             print("refine split:", e)
 # executed matrix instructions of the SR workloads against the algorithmic count (tile rounding on ragged crops): one more counter
 # pass each; algorithmic = FLOP of the line x 3 limb products / 16 384 FLOP per v_mfma_f32_16x16x32 (the three launches per step on the narrow
-# kernels execute 32x32x16 instructions of twice the FLOP: < 1 % of the count)
+# kernels execute 32x32x16 instructions of twice the FLOP: < 1 % of the count); a refine iteration's weight gradients -- a third of its FLOP --
+# run conv3x3_wgrad_limb_kernel on v_mfma_f32_32x32x16 (32 768 FLOP per instruction): (2/3 + 1/6) of the 16x16x32 count
 for w, pick in (("sr", summed(lambda k: "conv3x3" in k)), ("refine_joint", second_half(is_sr_conv))):
     for f in sorted(glob.glob(os.path.join(src, "pmc_%s_SQ_INSTS_MFMA" % w, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         got = pick([r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_INSTS_MFMA"])
         roof = out.get(w, {}).get("roofline", {})
         flop = roof.get("algorithmic_flop_per_step")
         if got and w in latest and flop:
-            alg = flop * 3.0 / 16384.0
+            alg = flop * 3.0 / 16384.0 * ((2.0 / 3.0 + 1.0 / 6.0) if w == "refine_joint" else 1.0)
             latest[w]["SQ_INSTS_MFMA"] = got[0]
             latest[w]["algorithmic_mfma_instructions"] = alg
             latest[w]["executed_over_algorithmic_mfma"] = got[0] / alg
