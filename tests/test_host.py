@@ -750,3 +750,24 @@ def test_prologue_input_cache_retains_storages_and_is_bounded(pkg):
         step._prologue_known(torch.rand(64, 64, 3), pose)
     assert step._prologue_bytes <= step.PROLOGUE_CACHE_BYTES + 64 and len(step._prologue_inputs) <= 3
     assert step._prologue_bytes == sum(nb for _, nb in step._prologue_inputs.values())
+
+
+def test_every_cooperative_lds_kernel_carries_the_race_probe():
+    """tools/race_probe.sh (round 6: it found a second prologue race, profiles/r06_race_probe.txt) only sees kernels that carry
+    NVSR_RACE_PROBE_DELAY(<array>) right behind their __shared__ array.  Static check: every 16-byte-aligned __shared__ array of the decoder / render /
+    SR kernels (the arrays several waves fill cooperatively) is followed by the macro naming that array; the product build leaves the macro empty."""
+    csrc = os.path.join(ROOT, "neural-volume-super-resolution_amd", "csrc")
+    found = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip") or f in ("aux.hip", "posenc.hip", "generic.hip"):      # (per-wave regions / plain element-wise staging: no cross-wave prologue)
+            continue
+        lines = open(os.path.join(csrc, f)).read().split("\n")
+        for i, line in enumerate(lines):
+            m = re.search(r"__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?(?:float|unsigned)\s+(\w+)\[", line)
+            if not m or m.group(1) in ("part", "bsum", "wm", "sT", "red"):               # (small per-wave reduction scratch)
+                continue
+            found += 1
+            assert "NVSR_RACE_PROBE_DELAY(%s);" % m.group(1) in lines[i + 1], "%s:%d: __shared__ array `%s` without the race probe" % (f, i + 1, m.group(1))
+    assert found >= 17, found
+    common = open(os.path.join(csrc, "nvsr_common.h")).read()
+    assert "#define NVSR_RACE_PROBE 0" in common and "#define NVSR_RACE_PROBE_DELAY(ARR) do { } while (0)" in common
