@@ -174,14 +174,28 @@ __device__ __forceinline__ void relu_publish(f32x16 (&acc)[4], unsigned* __restr
 }
 
 // record helpers: one accumulator set (128 features x 32 points, C/D layout) -> rows [row][128]; 32 B per lane pair and store, the
-// wave's 16 stores fill 32 complete 512-byte rows
+// wave's 16 stores fill 32 complete 512-byte rows.
+// NVSR_RECORD_NT (round 6 experiment, OFF): the record is written once and read once, by another kernel, after 7 GB more of it have gone by, so a
+// non-temporal store hint looked right -- measured it is 3-5 x SLOWER (recording forward 0.82 -> 4.0 ms, recording backward 0.79 -> 2.35 ms, step 4.3
+// -> 10.4-10.9 ms, same box): a record row is 512 B assembled from 32-byte stores of 16 lanes pairs, and `nt` stores leave L2's write combining, so
+// HBM sees partial-line writes
+#ifndef NVSR_RECORD_NT
+#define NVSR_RECORD_NT 0
+#endif
+__device__ __forceinline__ void rec_store(float* p, f32x4 v) {
+#if NVSR_RECORD_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ void record128(float* __restrict__ base, long q, int h, const f32x16 (&a)[4]) {
     float* row = base + q * HID + 4 * h;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
+            rec_store(row + 32 * ib + 8 * qq, f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]});
 }
 // the same with every value multiplied by a (wave-uniform) factor on its way out: accumulators that carry a power-of-two scale
 __device__ __forceinline__ void record128_scaled(float* __restrict__ base, long q, int h, const f32x16 (&a)[4], float f) {
@@ -190,19 +204,19 @@ __device__ __forceinline__ void record128_scaled(float* __restrict__ base, long 
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-            *reinterpret_cast<f32x4*>(row + 32 * ib + 8 * qq) = f32x4{a[ib][4 * qq] * f, a[ib][4 * qq + 1] * f, a[ib][4 * qq + 2] * f, a[ib][4 * qq + 3] * f};
+            rec_store(row + 32 * ib + 8 * qq, f32x4{a[ib][4 * qq] * f, a[ib][4 * qq + 1] * f, a[ib][4 * qq + 2] * f, a[ib][4 * qq + 3] * f});
 }
 // a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[24h ..]
 __device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
 #pragma unroll
     for (int i = 0; i < HALF_C / 4; ++i)
-        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+        rec_store(row + HALF_C * h + 4 * i, f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]});
 }
 
 __device__ __forceinline__ void record24_scaled(float* __restrict__ row, int h, const float (&f)[HALF_C], float k) {
 #pragma unroll
     for (int i = 0; i < HALF_C / 4; ++i)
-        *reinterpret_cast<f32x4*>(row + HALF_C * h + 4 * i) = f32x4{f[4 * i] * k, f[4 * i + 1] * k, f[4 * i + 2] * k, f[4 * i + 3] * k};
+        rec_store(row + HALF_C * h + 4 * i, f32x4{f[4 * i] * k, f[4 * i + 1] * k, f[4 * i + 2] * k, f[4 * i + 3] * k});
 }
 
 // MFMA block shared by the feature and hidden layers: NG groups of 4 MFMAs on one accumulator; group g uses the A fragment
