@@ -189,23 +189,68 @@ __device__ __forceinline__ void rec_store(float* p, f32x4 v) {
     *reinterpret_cast<f32x4*>(p) = v;
 #endif
 }
+// NVSR_RECORD_TIMING_COALESCED (timing experiment, WRONG layout): the same 16 stores with every instruction writing 1 KB of consecutive addresses
+// inside the tile's 16-KB block of rows -- what the record would cost if a store instruction covered whole cache lines instead of 64 pieces of 16 B
+#ifndef NVSR_RECORD_TIMING_COALESCED
+#define NVSR_RECORD_TIMING_COALESCED 0
+#endif
+__device__ __forceinline__ float* rec_piece(float* base, long q, int h, int ib, int qq) {
+#if NVSR_RECORD_TIMING_COALESCED
+    return base + (q - (q & 31)) * HID + ((ib * 4 + qq) * 64 + h * 32 + (int)(q & 31)) * 4;
+#else
+    return base + q * HID + 4 * h + 32 * ib + 8 * qq;
+#endif
+}
 __device__ __forceinline__ void record128(float* __restrict__ base, long q, int h, const f32x16 (&a)[4]) {
-    float* row = base + q * HID + 4 * h;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-            rec_store(row + 32 * ib + 8 * qq, f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]});
+            rec_store(rec_piece(base, q, h, ib, qq), f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]});
 }
 // the same with every value multiplied by a (wave-uniform) factor on its way out: accumulators that carry a power-of-two scale
 __device__ __forceinline__ void record128_scaled(float* __restrict__ base, long q, int h, const f32x16 (&a)[4], float f) {
-    float* row = base + q * HID + 4 * h;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-            rec_store(row + 32 * ib + 8 * qq, f32x4{a[ib][4 * qq] * f, a[ib][4 * qq + 1] * f, a[ib][4 * qq + 2] * f, a[ib][4 * qq + 3] * f});
+            rec_store(rec_piece(base, q, h, ib, qq), f32x4{a[ib][4 * qq] * f, a[ib][4 * qq + 1] * f, a[ib][4 * qq + 2] * f, a[ib][4 * qq + 3] * f});
 }
+// ---- the same rows through a per-wave LDS stage (round 6) ---------------------------------------------------------------------------------
+// record128 hands the memory system 64 pieces of 16 B per store instruction (lane (pt, h) owns features 8 qq + 4 h .. + 3 of its point: the two
+// lanes of a point sit in different quarter-waves, and neighbouring lanes are neighbouring ROWS, 512 B apart).  Timing build with the same bytes in
+// whole lines per instruction: recording forward 0.82 -> 0.74 ms, recording backward 0.80 -> 0.69 ms at S = 128 (NVSR_RECORD_TIMING_COALESCED).
+// Here a 32-feature block of the tile goes through LDS -- [32 points][RSTG_STRIDE floats], 4 ds_write_b128 in, 4 ds_read_b128 out -- so that the 8
+// lanes 8 k' .. 8 k' + 7 hold the 8 consecutive 16-byte pieces of ONE row's 128-byte segment: a store instruction writes 8 whole cache lines.
+// The tile's points must be consecutive record rows q0 .. q0 + 31 (32 consecutive samples of one ray: the limb kernels' tiles); points >= nvalid
+// (a partial chunk, a tile behind the last ray) go to the record's dump rows: all 16 stores are issued by every wave.
+constexpr int RSTG_STRIDE = 36;                    // 32 + 4: the 8 lanes of a ds_write_b128 group land on 8 different bank quads
+constexpr int RSTG_FLOATS = 32 * RSTG_STRIDE;      // per wave
+template <bool SCALED>
+__device__ __forceinline__ void record128_staged(float* stage, float* __restrict__ base, long q0, int nvalid, long dump, int lane, const f32x16 (&a)[4], float f) {
+    const int pt = lane & 31, h = lane >> 5;
+    const int p_ = lane >> 3, c = lane & 7;        // read side: point 8 k + p_, piece c of its 128-byte segment
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            f32x4 v = f32x4{a[ib][4 * qq], a[ib][4 * qq + 1], a[ib][4 * qq + 2], a[ib][4 * qq + 3]};
+            if (SCALED) v = v * f;
+            *reinterpret_cast<f32x4*>(stage + pt * RSTG_STRIDE + 8 * qq + 4 * h) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 8 * k + p_;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + p * RSTG_STRIDE + 4 * c);
+            const long row = p < nvalid ? q0 + p : dump + p;
+            rec_store(base + row * HID + 32 * ib + 4 * c, v);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[24h ..]
 __device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
 #pragma unroll

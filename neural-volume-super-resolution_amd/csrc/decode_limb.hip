@@ -30,6 +30,14 @@ struct L3 {
     static constexpr int LDS = SMALL + SMALL_FLOATS;
 };
 static_assert(2 * L3<3>::LDS * 4 <= 160 * 1024, "two workgroups per CU");
+// the recording forward on f16 limbs stages its record rows through LDS (record128_staged, decode_core.h): 4.5 KB per wave behind the ring; the
+// 3-limb kernel has no room for it (2 x 80 KB) and stores its rows directly.  (Sample-major record rows -- an A/B switch -- are not consecutive.)
+#ifdef NVSR_RECORD_SAMPLE_MAJOR
+template <int LF> constexpr bool L3_STAGED = false;
+#else
+template <int LF> constexpr bool L3_STAGED = (LF == 2);
+#endif
+static_assert(2 * (L3<2>::LDS + L3_WAVES * RSTG_FLOATS) * 4 <= 160 * 1024, "two recording workgroups per CU");
 
 struct RingL {
     __amdgpu_buffer_rsrc_t rsrc;   // 3-limb fragment region of the packed blob
@@ -107,7 +115,8 @@ __device__ __forceinline__ void publish_gates(const f32x16 (&act)[4], unsigned* 
 
 template <bool MASKS, bool RECORD, int LF>
 __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, const float* small, float px, float py, float pz, const Taps& vt_,
-                                                 float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok, float nsc) {
+                                                 float (&raw)[4], unsigned* __restrict__ gates, const DecRecord& rec, long q, bool rec_ok, float nsc,
+                                                 float* stage = nullptr, long q0 = 0, int nvalid = 0) {
     auto scaled = [](Taps t) {          // f16 limbs: features carry 2^F16_SX, put on the four blend weights (exact)
         if constexpr (LF == 2) { t.nw *= F16_X_SCALE; t.ne *= F16_X_SCALE; t.sw *= F16_X_SCALE; t.se *= F16_X_SCALE; }
         return t;
@@ -192,7 +201,8 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
             bias_relu<LF>(acc, small + S_BIAS + vec * HID, h, act, nsc);
         }
         if (MASKS && !(L3_ABLATE & 2)) publish_gates(act, gates, vec);
-        if (RECORD && rec_ok) { if constexpr (LF == 2) record128_scaled(hrow, q, h, act, REC_UNSCALE); else record128(hrow, q, h, act); }
+        if constexpr (RECORD && L3_STAGED<LF>) record128_staged<true>(stage, hrow, q0, nvalid, rec.dump, lane, act, REC_UNSCALE);     // (whole cache lines per store)
+        else if (RECORD && rec_ok) { if constexpr (LF == 2) record128_scaled(hrow, q, h, act, REC_UNSCALE); else record128(hrow, q, h, act); }
     };
     const long LP = (long)HID * rec.Pp;
 
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
                                                                     float* __restrict__ raw_out, unsigned* __restrict__ gates, DecRecord rec,
                                                                     unsigned* __restrict__ flag) {
     constexpr int L3_SMALL = L3<LF>::SMALL;
-    __shared__ __attribute__((aligned(16))) unsigned lds[L3<LF>::LDS];
+    __shared__ __attribute__((aligned(16))) unsigned lds[L3<LF>::LDS + ((RECORD && L3_STAGED<LF>) ? L3_WAVES * RSTG_FLOATS : 0)];
     NVSR_RACE_PROBE_DELAY(lds);      // (probe builds only, nvsr_common.h)
     // (wave index as a SCALAR: the LDS destination of every weight-copy piece then is scalar arithmetic into M0 instead of a vector add + v_readfirstlane per piece)
     RingL rs{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + limb_region(LF)), 0, KB_TOTAL * kb_words(LF) * 4, 0x00020000), lds, 0,
@@ -308,7 +318,13 @@ __global__ __launch_bounds__(L3_TPB, 2) void decode_rays_limb_kernel(SceneDev sc
         // gate record of this lane: [point ray*S+s][lane half][16 words]; padding lanes rewrite a valid point's record with the same values
         unsigned* gl = MASKS ? gates + ((ray * S + s) * 2 + (rs.lane >> 5)) * 16 : nullptr;
         // (rec_ok = true on every lane of a recording launch: padding lanes hold the clamped point's values and rewrite its row -- FIN_YOUNG)
-        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, ppx, ppy, ppz, vt, raw, gl, rec, record_row(ray, s, N, S), RECORD ? true : valid, nscale);
+        // staged record rows: the tile's 32 points are the consecutive rows q0 .. q0 + 31; points behind the ray's last sample / the last ray -> dump rows
+        // (S = 1: a tile is 32 consecutive points = rows 32 wt ..)
+        const int chunk0 = S == 1 ? 0 : (int)(wt - (wt / nsc) * nsc) * 32;
+        const long tq0 = S == 1 ? wt * 32 : (wt / nsc) * S + chunk0;
+        const long tleft = S == 1 ? N - wt * 32 : ((wt / nsc) < N ? (long)(S - chunk0) : 0L);
+        decode_step_limb<MASKS, RECORD, LF>(sc, rs, small, ppx, ppy, ppz, vt, raw, gl, rec, record_row(ray, s, N, S), RECORD ? true : valid, nscale,
+                                            ldsf + L3<LF>::LDS + rs.wave * RSTG_FLOATS, tleft > 0 ? tq0 : 0, (int)(tleft < 0 ? 0 : tleft > 32 ? 32 : tleft));
         if (valid && rs.lane < 32) {
             *reinterpret_cast<f32x4*>(raw_out + (ray * S + s) * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
             // range flag of the f16 limbs (nvsr.h: nvsr_set_range_flag)

@@ -115,23 +115,29 @@ inline SceneDev to_dev(const nvsr_scene* s) {
 
 // ---- activation / delta record of one training pass (decoder-weight gradients) ---------------------------------------------
 // One row per decoded point, row q = s * N + ray (sample-major: the 32 rays of a wave at one sample are 32 consecutive rows, so a
-// half-wave stores whole 512-byte rows).  Arrays are allocated for Pp = N*S rounded up to 8 rows; rows >= N*S are never read.
+// half-wave stores whole 512-byte rows).  Arrays are allocated for Pp = N*S rounded up to 8 rows + RECORD_DUMP_ROWS; rows >= N*S are never read.
+// The last RECORD_DUMP_ROWS rows of every array are a dump (round 6): the limb kernels write a tile's 32 rows through an LDS stage with whole
+// cache lines per store instruction (record128_staged), and the padding points of a partial tile go there instead of being masked off -- every
+// wave issues every store, which is what lets the ring waits count them (decode_limb.hip FIN_YOUNG).
 //   Xd [Pp][64]   density-decoder input (mean of the 3 position features; columns 48..63 zero)     } written by the pass that
 //   Hd [4][Pp][128]  post-ReLU output of density layer l;  Xr [Pp][192], Hr likewise for the rgb decoder } runs the FORWARD layers
 //   Gd / Gr [4][Pp][128]  dL/d(pre-activation of layer l);  g4 [Pp][4]  dL/d raw (rgb, sigma)        } written by the backward
+constexpr int RECORD_DUMP_ROWS = 32;
 struct DecRecord {
     float *Xd, *Hd, *Gd, *Xr, *Hr, *Gr, *g4;
     long Pp;   // allocated rows = stride between the per-layer arrays
     long P;    // valid rows (N * S)
+    long dump; // first of the RECORD_DUMP_ROWS dump rows (= Pp - RECORD_DUMP_ROWS)
 };
 constexpr long DEC_RECORD_FLOATS_PER_SLOT = 64 + 4 * HID + 4 * HID + 4 * C + 4 * HID + 4 * HID + 4;   // 2308
 inline long record_rows(long N, int S) { return N * (long)S; }
-inline long record_alloc_rows(long N, int S) { return (record_rows(N, S) + 7) / 8 * 8; }
+inline long record_alloc_rows(long N, int S) { return (record_rows(N, S) + 7) / 8 * 8 + RECORD_DUMP_ROWS; }
 inline DecRecord make_record(float* base, long N, int S) {
     DecRecord r;
     const long Pp = record_alloc_rows(N, S);
     r.Pp = Pp;
     r.P = record_rows(N, S);
+    r.dump = Pp - RECORD_DUMP_ROWS;
     r.Xd = base;            base += 64 * Pp;
     r.Hd = base;            base += 4L * HID * Pp;
     r.Gd = base;            base += 4L * HID * Pp;

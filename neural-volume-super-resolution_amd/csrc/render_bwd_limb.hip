@@ -265,13 +265,30 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         // (the chunk's copy was issued a block earlier): that wait leaves them in flight instead of draining them (decode_limb.hip FIN_YOUNG).  The
         // stores are lane-masked (padding lanes hold zero gradients and must not touch a valid row), so the count holds only on a wave with a valid lane.
         constexpr int REC_YOUNG = RECORD ? 16 : 0;
+#ifdef NVSR_RECORD_SAMPLE_MAJOR
         const bool rec_any = RECORD && __builtin_amdgcn_ballot_w64(valid) != 0ull;
+#else
+        const bool rec_any = RECORD;              // (staged rows: issued by every wave)
+#endif
         // (f16 limbs: the accumulators carry the tile's power-of-two scale; the weight-gradient contraction reads unscaled f32 rows)
         float gunscale = gu_d;        // unscale of the chain being walked (record rows)
+        // (round 6: whole cache lines per store through the wave's transposition tile, free until the planes are emitted -- record128_staged,
+        //  decode_core.h; the tile's points are the consecutive record rows rq0 .. rq0 + 31, padding points go to the record's dump rows, so every
+        //  wave issues all 16 stores of a layer: REC_YOUNG)
+#ifdef NVSR_RECORD_SAMPLE_MAJOR
         auto record_grad = [&](float* base, long q_, int h_, const f32x16 (&a)[4]) {
+            if (!rok) return;
             if constexpr (LF == 2) record128_scaled(base, q_, h_, a, gunscale);
             else record128(base, q_, h_, a);
         };
+#else
+        const int rchunk0 = (int)(wt - ray0 * nsc) * 32;
+        const long rq0 = ray0 < N ? ray0 * S + rchunk0 : 0;
+        const int rnvalid = ray0 < N ? (S - rchunk0 < 32 ? S - rchunk0 : 32) : 0;
+        auto record_grad = [&](float* base, long, int, const f32x16 (&a)[4]) {
+            record128_staged<LF == 2>(tile, base, rq0, rnvalid, rec.dump, lane, a, gunscale);
+        };
+#endif
         if (rok && h == 0) *reinterpret_cast<f32x4*>(rec.g4 + 4 * q) = graw_true;     // (the record holds UNSCALED gradients)
         // Everything below is re-read where it is used instead of being kept across the step (two accumulator sets, gD and the limbs
         // already fill the 256 registers of a wave at two waves per SIMD): a layer's two gate words (slot 0..3 density, 4..7 rgb) ...
@@ -366,13 +383,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
         apply_mask(gate(3), accA);
         BL_FENCE(accA)      // the masked gradient is a value of its own: without the fence hipcc keeps mask AND unmasked value alive to fold
                             // `(g & keep) & 0xffff0000` of the limb split into one v_bitop3 -- 128 more live registers, 165 spills
-        if (rok) record_grad(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
+        if (RECORD) record_grad(rec.Gd + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 2, accB, 0)
-        if (rok) record_grad(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
+        if (RECORD) record_grad(rec.Gd + 2L * HID * rec.Pp, q, h, accB);
         BL_HIDDEN_T(accB, 1, accA, 4)
-        if (rok) record_grad(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
+        if (RECORD) record_grad(rec.Gd + 1L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 0, accB, 8)
-        if (rok) record_grad(rec.Gd, q, h, accB);
+        if (RECORD) record_grad(rec.Gd, q, h, accB);
         f32x16 gD[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -402,13 +419,13 @@ __global__ __launch_bounds__(BL_TPB, BL_WG_PER_CU) void render_pass_backward_gat
             }
         apply_mask(gate(7), accA);
         BL_FENCE(accA)
-        if (rok) record_grad(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
+        if (RECORD) record_grad(rec.Gr + 3L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 6, accB, 14)
-        if (rok) record_grad(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
+        if (RECORD) record_grad(rec.Gr + 2L * HID * rec.Pp, q, h, accB);
         BL_HIDDEN_T(accB, 5, accA, 18)
-        if (rok) record_grad(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
+        if (RECORD) record_grad(rec.Gr + 1L * HID * rec.Pp, q, h, accA);
         BL_HIDDEN_T(accA, 4, accB, 22)
-        if (rok) record_grad(rec.Gr, q, h, accB);
+        if (RECORD) record_grad(rec.Gr, q, h, accB);
         // what happens to a plane's finished feature gradient gF (rows c = 32 b + (r & 3) + 8 (r >> 2) + 4 h, TRUE magnitudes): view rows or scatter
         auto emit_plane = [&](int d, f32x16 (&gF)[2]) {
             if (gp.p[d] && !(BL_ABLATE & 4)) {
