@@ -251,6 +251,38 @@ __device__ __forceinline__ void record128_staged(float* stage, float* __restrict
     __builtin_amdgcn_wave_barrier();
 }
 
+// A plane's 48 feature columns of the tile's 32 rows the same way (lane (pt, h) holds channels 24 h .. 24 h + 23 of its point): the two lane
+// halves go through the stage one after the other -- [32 points][RSTG24_STRIDE floats], 6 quads in per lane, then 192 pieces of 16 B out over
+// 3 store instructions in which 6 neighbouring lanes cover 96 consecutive bytes of one row.  6 stores per call like record24.
+constexpr int RSTG24_STRIDE = 28;                  // 24 + 4: conflict-free ds_write_b128 (8 lanes on 8 bank quads); 32 x 28 <= RSTG_FLOATS
+static_assert(32 * RSTG24_STRIDE <= RSTG_FLOATS, "feature stage fits the hidden-row stage");
+template <bool SCALED>
+__device__ __forceinline__ void record24_staged(float* stage, float* __restrict__ base /* array + first column */, int rowstride, long q0, int nvalid,
+                                                long dump, int lane, const float (&f)[HALF_C], float k) {
+    const int pt = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        __builtin_amdgcn_wave_barrier();
+        if (h == hh) {
+#pragma unroll
+            for (int i = 0; i < HALF_C / 4; ++i) {
+                f32x4 v = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+                if (SCALED) v = v * k;
+                *reinterpret_cast<f32x4*>(stage + pt * RSTG24_STRIDE + 4 * i) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int g = 64 * j + lane, p = g / 6, c = g - 6 * p;          // point 0..31, piece 0..5 of its 96 bytes
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + p * RSTG24_STRIDE + 4 * c);
+            const long row = p < nvalid ? q0 + p : dump + p;
+            rec_store(base + row * rowstride + HALF_C * hh + 4 * c, v);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // a lane's 24 channels of one plane's feature (channels 24h .. 24h+23) -> row[24h ..]
 __device__ __forceinline__ void record24(float* __restrict__ row, int h, const float (&f)[HALF_C]) {
 #pragma unroll

@@ -129,6 +129,7 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     //  recorded value is multiplied by 2^-F16_SX on its way out -- exact)
     constexpr float REC_UNSCALE = LF == 2 ? 1.0f / F16_X_SCALE : 1.0f;
     auto rec24 = [&](float* row, const float (&f)[HALF_C]) {
+        if (L3_ABLATE & 32) return;                         // (timing experiment: no feature rows in the record)
         if constexpr (LF == 2) record24_scaled(row, lane_h, f, REC_UNSCALE); else record24(row, lane_h, f);
     };
     const float n0 = norm_coord(px, sc.lo[0], sc.range[0]);
@@ -207,31 +208,51 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     const long LP = (long)HID * rec.Pp;
 
     // ---- rgb layer 0: K = 192 in the limb blob's order [f_view | f0 | f1 | f2], one plane = one chunk ---------------------------------
+    // Round 6: a plane's feature rows of the record go out INSIDE the block that multiplies them, behind the next chunk's copy -- F is intact
+    // until the next gather, and the stores then have the block's 72 MFMAs to land (they used to sit between the gather and the block's
+    // vmcnt(0): a timing build without them ran the recording forward 0.74 -> 0.65 ms) -- and, on f16 limbs, as whole segments through the
+    // LDS stage (record24_staged).
+    auto rec24x = [&](float* colbase, int rowstride, const float (&f)[HALF_C]) {
+        if constexpr (!RECORD) return;
+        if (L3_ABLATE & 32) return;                         // (timing experiment: no feature rows in the record)
+        if constexpr (L3_STAGED<LF>) record24_staged<true>(stage, colbase, rowstride, q0, nvalid, rec.dump, lane, f, REC_UNSCALE);
+        else if (rec_ok) rec24(colbase + q * rowstride, f);
+    };
+#define L3_BLOCK_R(STMT, NKB, ZERO, SRC, NEXT)                                                 \
+    {                                                                                          \
+        ringl_sync<0>();                                                                       \
+        const unsigned* nw = NEXT;                                                             \
+        STMT;                                                                                  \
+        { auto s_ = SRC; split_all<LF>([&](int i) { return s_(0, i); }, cur); }                 \
+        limb_block<LF, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, NoTail{});           \
+        cw = nw;                                                                               \
+        L3_FENCE                                                                               \
+    }
     const unsigned* cw = L3_ISSUE(3, KB_RGB0);
     L3_GATHER(sc.plane[3], vt, h, F);
-    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + 3 * C, F);
-    L3_BLOCK(3, true, feat(F), L3_ISSUE(3, KB_RGB0 + 3))
+    L3_BLOCK_R(rec24x(rec.Xr + 3 * C, 4 * C, F), 3, true, feat(F), L3_ISSUE(3, KB_RGB0 + 3))
     L3_GATHER(sc.plane[0], pos_taps(0), h, F);
-    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C), F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = F[c];
-    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 6))
+    L3_BLOCK_R(rec24x(rec.Xr, 4 * C, F), 3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 6))
     L3_GATHER(sc.plane[1], pos_taps(1), h, F);
-    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + C, F);
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = __fadd_rn(D[c], F[c]);
-    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 9))
+    L3_BLOCK_R(rec24x(rec.Xr + C, 4 * C, F), 3, false, feat(F), L3_ISSUE(3, KB_RGB0 + 9))
     L3_GATHER(sc.plane[2], pos_taps(2), h, F);
-    if (RECORD && rec_ok) rec24(rec.Xr + q * (4 * C) + 2 * C, F);
     // combine_pos_planes 'avg' = stack(...).mean(0)  (models.py:358-359)
 #pragma unroll
     for (int c = 0; c < HALF_C; ++c) D[c] = div3(__fadd_rn(D[c], F[c]));
-    if (RECORD && rec_ok) {
-        rec24(rec.Xd + q * 64, D);
-        *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    L3_BLOCK(3, false, feat(F), L3_ISSUE(3, KB_RGB1))
+    auto rec_last = [&]() {
+        rec24x(rec.Xr + 2 * C, 4 * C, F);
+        rec24x(rec.Xd, 64, D);
+        if (RECORD && rec_ok && !(L3_ABLATE & 32)) {          // (columns 48..63 of the density input: the contraction's padded block reads them)
+            *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(rec.Xd + q * 64 + C + 8 * h + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    L3_BLOCK_R(rec_last(), 3, false, feat(F), L3_ISSUE(3, KB_RGB1))
+#undef L3_BLOCK_R
     finish(4, rec.Hr);
     // ---- rgb layers 1..3, rgb head ---------------------------------------------------------------------------------------------------
     L3_HIDDEN(KB_RGB1, L3_ISSUE(3, KB_RGB1 + 8))
