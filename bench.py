@@ -115,6 +115,9 @@ def compact_record(full):
         if k in cfg and not (k == "partition" and "partition" in out["config"]):
             out["config"]["partition" if k == "partition_short" else k] = cfg[k] if not isinstance(cfg[k], str) else cfg[k][:48]
     out["roofline"] = _compact_roofline(full.get("roofline"))
+    rc = full.get("roofline_counters")
+    if out["roofline"] and rc:                  # matrix-pipe busy fraction and clock of the same launch (committed rocprofv3 --pmc pass, hash-tied)
+        out["roofline"]["mfma_busy_frac"], out["roofline"]["clock_ghz"] = rc.get("mfma_busy_frac"), rc.get("clock_ghz")
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: (cb[k] if k != "sample" else str(cb.get("sample_short") or cb[k])[:100])
