@@ -912,7 +912,12 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
     popt = torch.optim.Adam(planes, lr=5e-4, fused=True) if joint else None
     sropt = torch.optim.Adam(srp, lr=5e-5, fused=True)
     trained = srp + (planes + dec if joint else [])
-    sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in trained if p.grad is not None])) if world > 1 else None
+    # N > 1: the EDSR gradient is all-reduced bucket by bucket WHILE the SR backward runs (distributed.OverlappedSRGradSync: the batched backward records an
+    # event per bucket of its gradient blob), the planes' and decoders' gradients behind the backward; NVSR_BENCH_SYNC=after: everything behind the backward
+    if world > 1 and os.environ.get("NVSR_BENCH_SYNC", "overlapped") == "overlapped":
+        sync = nvsr_amd.distributed.OverlappedSRGradSync(sr, other_parameters=(planes + dec if joint else []))
+    else:
+        sync = (lambda: nvsr_amd.distributed.allreduce_gradients([p.grad for p in trained if p.grad is not None])) if world > 1 else None
     if os.environ.get("NVSR_BENCH_DEBUG_NAN") == "1":
         # diagnostics (round 5's backward-prologue race): are this rank's gradients finite before / after the all-reduce, per iteration?
         # (host reads: the timing of such a run means nothing)
@@ -946,6 +951,21 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
 
     elapsed = _sync_time(dist, dev, one, args.warmup, args.steps)
     host_issue_ms = 1e3 * _sync_time.issue_s / args.steps
+    if world > 1 and os.environ.get("NVSR_BENCH_REHEARSAL", "0") == "1":
+        # rehearsal (tests/test_hip_round5.py): every rank started from the same parameters and stepped on the same averaged gradients -- a sample of
+        # every parameter group (the SR network's first and last layers, a plane, a decoder matrix) is bit-identical on all ranks after the timed steps
+        probe_ = [srp[0], srp[-1]] + ([planes[0], dec[0]] if joint else [])
+        mine = torch.cat([p_.detach().reshape(-1)[:4096].float().cpu() for p_ in probe_])
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        same = all(torch.equal(both[0], b_) for b_ in both[1:]) and bool(torch.isfinite(mine).all())
+        overlapped = isinstance(sync, nvsr_amd.distributed.OverlappedSRGradSync)
+        print("REFINE_PARAMS_%s rank %d of %d (%s gradient sync%s)" % ("IDENTICAL" if same else "DIFFER", rank, world, "overlapped" if overlapped else "post-backward",
+              ", %d buckets" % sync.stats["buckets"] if overlapped else ""), file=sys.stderr, flush=True)
+        if not same:
+            sys.exit(3)
+    if world > 1 and isinstance(sync, nvsr_amd.distributed.OverlappedSRGradSync):
+        sync.detach()          # (the probe iterations below run on rank 0 ALONE: the SR backward must not start collectives there)
     mode = capi.get_conv_arithmetic()
     arith = ARITHMETIC[mode]
     label = "what = ['LR_planes', 'decoder', 'SR']" if joint else "what = ['SR']"
@@ -960,8 +980,8 @@ def bench_refine(args, nvsr_amd, dist, dev, rank, world):
                                      "regions of interest of the three position planes, SR model on the fine model only, loss on the fine output, %s, Adam"
                                      % ("a " + view if llff else "an 800x800 view", Nc, Nf, label), "rays_per_step_per_gpu": N, "refine_what": args.refine_what,
                          "refine_scene": "llff" if llff else "blender",
-                         "parallelism": "every rank draws its own %d rays; one in-place all-reduce per gradient tensor (EDSR 173 MB%s) per step"
-                                        % (N, " + planes 23 MB + decoders 1 MB" if joint else "")}}
+                         "parallelism": "every rank draws its own %d rays; EDSR gradient (173 MB) all-reduced in ~48 MB buckets during the SR backward%s"
+                                        % (N, ", planes 23 MB + decoders 1 MB behind it" if joint else "")}}
     if rank != 0:
         return None
     if getattr(args, "no_split", False):          # counter passes: the timed iteration only

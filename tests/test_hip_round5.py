@@ -366,10 +366,14 @@ def test_batched_sr_training_with_the_options_of_planes_sr(hip, variant):
 
 def test_refine_iteration_on_two_ranks():
     """SURVEY 8e training partition for BASELINE configs[4]: `bench.py --workload refine --gpus 2` (two ranks on cuda:0 over gloo, rehearsal): every
-    rank draws its own rays and regions of interest, the gradients of the SR network (173 MB), the planes and both decoders go through
-    distributed.allreduce_gradients before the three optimizers step; the run finishes with one line, finite, weak scaling."""
+    rank draws its own rays and regions of interest; round 6: the SR network's gradient (173 MB) is all-reduced bucket by bucket inside the SR backward
+    (distributed.OverlappedSRGradSync through nvsr_planes_sr_backward_batch_marks; host-staged over gloo here), the planes' and both decoders' gradients go
+    through distributed.allreduce_gradients behind it, then the three optimizers step; the run asserts that a sample of every parameter group is
+    bit-identical on both ranks after its iterations and finishes with one line, finite, weak scaling."""
     from test_hip_round3 import _bench_rehearsal
     r, err = _bench_rehearsal(["--workload", "refine", "--refine-what", "joint", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for rank in (0, 1):
+        assert "REFINE_PARAMS_IDENTICAL rank %d of 2 (overlapped gradient sync, 4 buckets)" % rank in err, err[-3000:]
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["rays_per_step_per_gpu"] == 4096
     assert np.isfinite(r["value"]) and r["value"] > 0 and r["roofline"]["frac"] > 0
     assert r["collectives"]["backend"] == "gloo" and r["collectives"]["world_size"] == 2
