@@ -14,6 +14,12 @@
 
 #include "limb_core.h"
 
+#ifndef L3_REC_LATE
+#define L3_REC_LATE 0   // recording forward on f16 limbs, experiment (round 6): 1 = a layer's record rows are stored inside the NEXT layer's first block, two
+                        // blocks of MFMAs ahead of the wait that needs them done, instead of where the layer ends (one block).  Same box, three
+                        // alternations: 0.731 / 0.698 / 0.722 ms against 0.724 / 0.731 / 0.709 at S = 128, 0.43 against 0.42 at S = 64 -- the stores
+                        // are bound by bytes and requests, not by the latency a later wait sees.  Off.
+#endif
 #ifndef L3_ABLATE
 #define L3_ABLATE 0   // timing experiments only (wrong results): 1 no plane gathers, 2 no gate words, 4 no wait for the weight copies,
 #endif                // 8 no bias + ReLU; 16 (correct results) the old vmcnt(0) behind a layer's record stores          (tools/ab_flags.sh)
@@ -164,10 +170,13 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     // one chunk: wait for it, start the copy of the next one, split the block's first K-block, multiply
     // (FIRST: the block's first K-block is split here, exposed; otherwise the previous block's tail produced it in its MFMA gaps)
 #define L3_BLOCK_(NKB, ZERO, FIRST, SRC, NEXT, TAIL) L3_BLOCK_Y(0, NKB, ZERO, FIRST, SRC, NEXT, TAIL)
-#define L3_BLOCK_Y(YOUNGER, NKB, ZERO, FIRST, SRC, NEXT, TAIL)                                 \
+#define L3_BLOCK_Y(YOUNGER, NKB, ZERO, FIRST, SRC, NEXT, TAIL) L3_BLOCK_YS(YOUNGER, (void)0, NKB, ZERO, FIRST, SRC, NEXT, TAIL)
+    // (STMT: issued behind the next chunk's copy -- the pending record rows of the layer below, L3_REC_LATE)
+#define L3_BLOCK_YS(YOUNGER, STMT, NKB, ZERO, FIRST, SRC, NEXT, TAIL)                          \
     {                                                                                          \
         ringl_sync<YOUNGER>();                                                                 \
         const unsigned* nw = NEXT;                                                             \
+        STMT;                                                                                  \
         if (FIRST) { auto s_ = SRC; split_all<LF>([&](int i) { return s_(0, i); }, cur); }      \
         limb_block<LF, NKB, ZERO, true>(cw, lane, acc, cur, fa, SRC, none, TAIL);               \
         cw = nw;                                                                               \
@@ -177,14 +186,16 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
 #define L3_BLOCK(NKB, ZERO, SRC, NEXT) L3_BLOCK_(NKB, ZERO, true, SRC, NEXT, NoTail{})
     // a hidden layer = 3 + 3 + 2 K-blocks of the previous activation; NEXT = the chunk that follows the layer
 #ifdef NVSR_NO_TAILS      // A/B switch (tools/): every block splits its first K-block itself
-#define L3_HIDDEN(KB0, NEXT)                                                                   \
-    L3_BLOCK(3, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3))                              \
-    L3_BLOCK(3, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6))                             \
+#define L3_HIDDEN(KB0, NEXT) L3_HIDDEN_Y(YA_LAYER, KB0, NEXT)
+#define L3_HIDDEN_Y(YA, KB0, NEXT)                                                             \
+    L3_BLOCK_YS(YA, flush_pending(), 3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), NoTail{})  \
+    L3_BLOCK_YS(YB_LAYER, (void)0, 3, false, true, hid(act, 3), L3_ISSUE(2, (KB0) + 6), NoTail{})   \
     L3_BLOCK(2, false, hid(act, 6), NEXT)
 #else
-#define L3_HIDDEN(KB0, NEXT)                                                                   \
-    L3_BLOCK_Y(FIN_YOUNG, 3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), tail_of(act, 3))      \
-    L3_BLOCK_(3, false, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6), tail_of(act, 6))    \
+#define L3_HIDDEN(KB0, NEXT) L3_HIDDEN_Y(YA_LAYER, KB0, NEXT)
+#define L3_HIDDEN_Y(YA, KB0, NEXT)                                                             \
+    L3_BLOCK_YS(YA, flush_pending(), 3, true, true, hid(act, 0), L3_ISSUE(3, (KB0) + 3), tail_of(act, 3))      \
+    L3_BLOCK_YS(YB_LAYER, (void)0, 3, false, false, hid(act, 3), L3_ISSUE(2, (KB0) + 6), tail_of(act, 6))    \
     L3_BLOCK_(2, false, false, hid(act, 6), NEXT, NoTail{})
 #endif
     // Round 6: the 16 record stores of a finished layer (512 B per point) are the YOUNGEST vector-memory operations when the next layer's first
@@ -194,6 +205,15 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
     // every wave the record stores are issued unconditionally: padding lanes rewrite the record row of the valid point they mirror with the same
     // values (rec_ok is true for every lane of a recording launch, see the kernel).
     constexpr int FIN_YOUNG = (RECORD && !(L3_ABLATE & 16)) ? 16 : 0;
+    // L3_REC_LATE (staged rows only): a finished layer's rows are not stored where the layer ends but INSIDE the next layer's first block, behind the
+    // copy of that layer's second chunk (`act` lives on as the next layer's operand): the second block's wait then leaves them in flight too
+    // (vmcnt(16)) and only the third block's wait needs them done -- two blocks of MFMAs to land in instead of one.
+    constexpr bool LATE = RECORD && L3_STAGED<LF> && (L3_REC_LATE != 0) && !(L3_ABLATE & 16);
+    constexpr int YA_LAYER = LATE ? 0 : FIN_YOUNG, YB_LAYER = LATE ? 16 : 0;
+    float* pend_row = nullptr;
+    auto flush_pending = [&]() {
+        if constexpr (LATE) record128_staged<true>(stage, pend_row, q0, nvalid, rec.dump, lane, act, REC_UNSCALE);
+    };
     auto finish = [&](int vec, float* hrow) {             // bias + ReLU of the finished layer, its gate words, its record row
         if (L3_ABLATE & 8) {
 #pragma unroll
@@ -202,7 +222,8 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
             bias_relu<LF>(acc, small + S_BIAS + vec * HID, h, act, nsc);
         }
         if (MASKS && !(L3_ABLATE & 2)) publish_gates(act, gates, vec);
-        if constexpr (RECORD && L3_STAGED<LF>) record128_staged<true>(stage, hrow, q0, nvalid, rec.dump, lane, act, REC_UNSCALE);     // (whole cache lines per store)
+        if constexpr (LATE) pend_row = hrow;                                                                                             // (stored by the next block)
+        else if constexpr (RECORD && L3_STAGED<LF>) record128_staged<true>(stage, hrow, q0, nvalid, rec.dump, lane, act, REC_UNSCALE);     // (whole cache lines per store)
         else if (RECORD && rec_ok) { if constexpr (LF == 2) record128_scaled(hrow, q, h, act, REC_UNSCALE); else record128(hrow, q, h, act); }
     };
     const long LP = (long)HID * rec.Pp;
@@ -268,14 +289,16 @@ __device__ __forceinline__ void decode_step_limb(const SceneDev& sc, RingL& rs, 
         for (int c = 0; c < 3; ++c) raw[c] = hd[c] + small[S_HEAD_B + 1 + c];
     }
     // ---- density decoder: 48 -> 128 x 4 -> 1 -----------------------------------------------------------------------------------------
-    L3_BLOCK_Y(FIN_YOUNG, 3, true, true, feat(D), L3_ISSUE(3, KB_DEN1), NoTail{})        // (behind finish(7)'s record stores)
+    L3_BLOCK_YS(YA_LAYER, flush_pending(), 3, true, true, feat(D), L3_ISSUE(3, KB_DEN1), NoTail{})        // (behind / carrying finish(7)'s record stores)
     finish(0, rec.Hd);
-    L3_HIDDEN(KB_DEN1, L3_ISSUE(3, KB_DEN1 + 8))
+    // (LATE: rgb layer 3's rows went out inside the density layer-0 block, behind the copy this layer's first block waits for: 16 young stores)
+    L3_HIDDEN_Y(FIN_YOUNG, KB_DEN1, L3_ISSUE(3, KB_DEN1 + 8))
     finish(1, rec.Hd + LP);
     L3_HIDDEN(KB_DEN1 + 8, L3_ISSUE(3, KB_DEN1 + 16))
     finish(2, rec.Hd + 2 * LP);
     L3_HIDDEN(KB_DEN1 + 16, (const unsigned*)nullptr)
     finish(3, rec.Hd + 3 * LP);
+    flush_pending();                                       // (the tile's last layer: nothing follows to carry its rows)
     {
         float hd[1];
         head_dots<1>(small + S_ALPHA_W, h, act, hd);
