@@ -522,6 +522,7 @@ def test_sharded_render_is_bit_identical_to_one_rank(partition, res, self_launch
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["partition"] == partition and r["scaling"] == ("strong" if partition == "frame" else "weak")
+    assert r["sharded_frame_identical_to_one_gpu"] is True          # (round 6: the N > 1 line says that its frames are the one-GPU frames)
     frames = 1 if partition == "frame" else 2
     assert abs(r["value"] - frames * res * res * 2 / (r["ms_per_step"] * 2e-3)) <= 1e-6 * r["value"]
 
