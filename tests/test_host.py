@@ -590,7 +590,7 @@ def _maximal_bench_record():
             "roofline": roof, "hbm_stages": {prose[:60] + str(i): {"ms": 0.0235, "GB/s": 651.9, "frac_of_hbm_peak": 0.08} for i in range(5)},
             "arithmetic_modes": {m: {"rays_per_s": 1.9e6, "ms_per_step": 333.06, "psnr_vs_oracle_db": 86.9} for m in ("f32", "bf16x3", "f16x2")},
             "cpu_baseline": cpu, "frame_error_evidence": {m: {prose[:50] + str(i): 0.123456789 for i in range(10)} for m in ("f32", "bf16x3", "f16x2")},
-            "psnr_vs_oracle_db": 86.46044072986612, "psnr_vs_oracle": {"checker": prose},
+            "psnr_vs_oracle_db": 86.46044072986612, "psnr_vs_oracle": {"checker": prose}, "sharded_frame_identical_to_one_gpu": True,
             "other_workloads": {n: dict(side) for n in ("train", "train_decoder", "sr", "refine", "refine_sr_only", "refine_llff_ndc", "one_more_for_margin")},
             "collectives": {"backend": "nccl", "rccl_ranks": 8, "world_size": 8, "rank_devices": ["cuda:%d (AMD Instinct MI355X)" % i for i in range(8)]}}
     full["other_workloads"]["sr"]["unit"] = "planes/s"
@@ -619,7 +619,7 @@ def test_bench_line_is_compact_and_complete():
     assert abs(r["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 and r["roofline"]["bound"] in ("mfma", "hbm")
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 256 and abs(r["cpu_baseline"]["value"] - 8213.73) < 0.01
     assert len(r["cpu_baseline"]["sample"]) <= 100
-    assert r["collectives"] == {"backend": "nccl", "rccl_ranks": 8, "world_size": 8}
+    assert r["collectives"] == {"backend": "nccl", "rccl_ranks": 8, "world_size": 8} and r["sharded_frame_identical_to_one_gpu"] is True
     assert set(r["other_workloads"]) == set(full["other_workloads"])
     row = r["other_workloads"]["refine"]
     assert set(row) == {"value", "unit", "ms_per_step", "roofline_bound", "roofline_frac", "traffic", "algorithmic_bytes", "cpu_baseline_value"}
