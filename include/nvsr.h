@@ -385,7 +385,9 @@ int nvsr_render_pass_backward_gates(const nvsr_scene* scene, const float* packed
  * torch.autograd's addmm backward (dW = delta^T @ input, db = sum delta) through models.py:169-195,395-421 becomes two calls:
  * the backward pass additionally RECORDS every layer's input and pre-activation gradient, then one contraction over all points
  * adds the weight / bias gradients into a blob in the natural (state-dict) order of nvsr_pack_decoder. */
-/* floats of the record workspace of one pass (9.2 KB per point, one row per point: row = ray * S + s).  The half that the forward
+/* floats of the record workspace of one pass (9.2 KB per point, one row per point: row = ray * S + s; every array of the record is allocated
+ * for N * S rows rounded up to 8 + 32 DUMP rows -- round 6: the limb kernels write a tile's 32 rows as whole cache lines through an LDS stage and
+ * send the padding points of a partial tile there; rows >= N * S are never read).  The half that the forward
  * layers produce (layer inputs) is written either by nvsr_decode_rays_ex(record) at forward time or by the recomputing
  * nvsr_render_pass_backward_ex(record); the gradient half by whichever backward entry receives the record. */
 int64_t nvsr_decoder_record_floats(int64_t N, int S);
